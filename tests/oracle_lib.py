@@ -1,0 +1,168 @@
+"""ctypes access to the CPU checker (oracle/) for tests, smoke() and the
+cpu_baseline leg of bench.py.  Never imported by the product package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libkbest_oracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libref_kbest.so")
+REF_OFAST_SO = os.path.join(ORACLE_DIR, "_ref", "libref_kbest_ofast.so")
+
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+
+
+class OrcStats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in (
+        "children_solved", "children_pushed", "dijkstra_steps", "row_visits", "max_queue", "root_steps")]
+
+
+def build_oracle(force: bool = False) -> None:
+    src = os.path.join(ORACLE_DIR, "kbest_oracle.c")
+    if force or not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "libkbest_oracle.so"], stdout=subprocess.DEVNULL)
+
+
+_oracle = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        build_oracle()
+        lib = C.CDLL(ORACLE_SO)
+        lib.orc_kbest.restype = C.c_int
+        lib.orc_kbest.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_double,
+                                  _i32p, _i32p, _dp, C.POINTER(OrcStats)]
+        lib.orc_kbest_batch.restype = C.c_int64
+        lib.orc_kbest_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_double,
+                                        _i32p, _i32p, _dp, _i32p, C.c_void_p]
+        lib.orc_assign2d.restype = C.c_int
+        lib.orc_assign2d.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _i32p, _i32p, _dp]
+        lib.orc_condition_costs.restype = C.c_int
+        lib.orc_condition_costs.argtypes = [_dp, C.c_int, C.c_int, _dp, _i32p]
+        lib.orc_to_probs.restype = None
+        lib.orc_to_probs.argtypes = [_dp, C.c_int]
+        lib.orc_assignment_prob.restype = C.c_int
+        lib.orc_assignment_prob.argtypes = [_dp, C.c_int, C.c_int, C.c_int, _dp]
+        lib.orc_brute_force_prob.restype = C.c_int
+        lib.orc_brute_force_prob.argtypes = [_dp, C.c_int, C.c_int, _dp, C.POINTER(C.c_int)]
+        lib.orc_permanent.restype = C.c_double
+        lib.orc_permanent.argtypes = [_dp, C.c_int, C.c_int]
+        _oracle = lib
+    return _oracle
+
+
+def have_ref() -> bool:
+    return os.path.exists(REF_SO)
+
+
+_ref = {}
+
+
+def ref(ofast: bool = False):
+    path = REF_OFAST_SO if ofast else REF_SO
+    if path not in _ref:
+        lib = C.CDLL(path)
+        lib.ref_kbest2d.restype = C.c_int64
+        lib.ref_kbest2d.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int, _dp, _i64p, _i64p, _dp]
+        lib.ref_kbest2d_cutoff.restype = C.c_int64
+        lib.ref_kbest2d_cutoff.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int, _dp, _i64p, _i64p, _dp,
+                                           C.c_double]
+        lib.ref_assign2d.restype = C.c_int
+        lib.ref_assign2d.argtypes = [C.c_int64, C.c_int64, C.c_int, _dp, _i64p, _i64p, _dp]
+        lib.ref_kbest2d_batch.restype = C.c_int64
+        lib.ref_kbest2d_batch.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, _dp,
+                                          _i64p, _i64p, _dp, _i64p]
+        _ref[path] = lib
+    return _ref[path]
+
+
+# ---------------------------------------------------------------- wrappers
+
+def orc_kbest(cost, N, M, k, maximize=False, cutoff=None, want_stats=False):
+    """Oracle k-best of one N x M column-major problem.
+    Returns (nf, row4col[k,M], col4row[k,N], gain[k]) (+ stats)."""
+    cost = np.ascontiguousarray(cost, dtype=np.float64).reshape(-1)
+    c4r = np.full((k, N), -7, np.int32)
+    r4c = np.full((k, M), -7, np.int32)
+    g = np.full(k, np.nan)
+    st = OrcStats()
+    nf = oracle().orc_kbest(k, N, M, int(maximize), cost, int(cutoff is not None),
+                            float(cutoff if cutoff is not None else 0.0), c4r, r4c, g, C.byref(st))
+    if want_stats:
+        return nf, r4c, c4r, g, st
+    return nf, r4c, c4r, g
+
+
+def orc_kbest_batch(costs, N, M, k, maximize=False, cutoff=None):
+    costs = np.ascontiguousarray(costs, dtype=np.float64)
+    B = costs.shape[0]
+    c4r = np.full((B, k, N), -7, np.int32)
+    r4c = np.full((B, k, M), -7, np.int32)
+    g = np.full((B, k), np.nan)
+    nf = np.zeros(B, np.int32)
+    pushed = np.zeros(B, np.int64)
+    oracle().orc_kbest_batch(B, k, N, M, int(maximize), costs.reshape(-1), int(cutoff is not None),
+                             float(cutoff if cutoff is not None else 0.0), c4r.reshape(-1), r4c.reshape(-1),
+                             g.reshape(-1), nf, pushed.ctypes.data)
+    return nf, r4c, c4r, g, pushed
+
+
+def ref_kbest(cost, N, M, k, maximize=False, cutoff=None, ofast=False):
+    """The compiled reference itself (only where oracle/_ref exists)."""
+    cost = np.ascontiguousarray(cost, dtype=np.float64).reshape(-1)
+    c4r = np.full((k, N), -7, np.int64)
+    r4c = np.full((k, M), -7, np.int64)
+    g = np.full(k, np.nan)
+    lib = ref(ofast)
+    if cutoff is None:
+        nf = lib.ref_kbest2d(k, N, M, int(maximize), cost, c4r.reshape(-1), r4c.reshape(-1), g)
+    else:
+        nf = lib.ref_kbest2d_cutoff(k, N, M, int(maximize), cost, c4r.reshape(-1), r4c.reshape(-1), g,
+                                    float(cutoff))
+    return int(nf), r4c, c4r, g
+
+
+def canon_col4row(c4r, M):
+    """rows that landed on padded columns (>= M) compare as -1."""
+    c = np.array(c4r, dtype=np.int64, copy=True)
+    c[c >= M] = -1
+    return c
+
+
+def condition_costs(cost, nRows, nCols):
+    cost = np.ascontiguousarray(cost, dtype=np.float64).reshape(-1)
+    out = np.empty(nRows * nCols)
+    idx = np.empty(nRows, np.int32)
+    good = oracle().orc_condition_costs(cost, nRows, nCols, out, idx)
+    return out[: good * nCols].copy(), idx[:good].copy()
+
+
+def assignment_prob(cost, nL, nM, k):
+    cost = np.ascontiguousarray(cost, dtype=np.float64).reshape(-1)
+    probs = np.zeros((nM, nL + 1))
+    nf = oracle().orc_assignment_prob(cost, nL, nM, k, probs.reshape(-1))
+    return probs, nf
+
+
+def brute_force_prob(cost, nL, nM):
+    cost = np.ascontiguousarray(cost, dtype=np.float64).reshape(-1)
+    probs = np.zeros((nM, nL + 1))
+    uk = C.c_int(0)
+    nf = oracle().orc_brute_force_prob(cost, nL, nM, probs.reshape(-1), C.byref(uk))
+    return probs, nf, uk.value
+
+
+def permanent(A):
+    """A: (m, n) array.  Exact permanent (rectangular: nwPerm.cpp:217-231 convention)."""
+    A = np.asarray(A, dtype=np.float64)
+    m, n = A.shape
+    return oracle().orc_permanent(np.ascontiguousarray(A.T).reshape(-1), m, n)
