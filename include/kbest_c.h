@@ -1,0 +1,125 @@
+/*
+ * kbest_c.h -- C ABI of the MI355X-native k-best assignment engine.
+ *
+ * This is the drop-in boundary for the reference's k-best / association-weight
+ * hot path.  Every entry point names the reference interface it replaces
+ * (paths relative to the reference repository root):
+ *
+ *   kbest_batch_f64 / kbest_batch_f64_dev
+ *        batched form of  kBest2D        (shortestPathCPP.hpp:204-212, cpp:571-644)
+ *        and of           kBest2DCutoff  (shortestPathCPP.hpp:256-265, cpp:646-733)
+ *        (opts.use_cutoff selects which); with k == 1 it is also the batched
+ *        form of          assign2D       (shortestPathCPP.hpp:144-149) as used by
+ *        asgnBB (assignment.cpp:750, k=1, maximize).
+ *   kbest_weights_batch_f64
+ *        batched form of  assignmentProb (assignment.h:11, assignment.cpp:547-683)
+ *   kbest_condition_costs_f64
+ *        conditionCosts   (assignment.h:26, assignment.cpp:439-525)
+ *
+ * Conventions kept from the reference: cost matrices are column-major
+ * C[row + col*numRow] with numRow >= numCol (shortestPathCPP.hpp:185-190);
+ * row4col is indexed by column, col4row by row; col4row values >= numCol mean
+ * "row sits on a zero-padded column" (SURVEY 8(a) quirk 6); the number of
+ * solutions found is returned per problem, 0 = infeasible (cpp:588-593).
+ * The solver never throws; negative return values are engine errors.
+ * Index outputs are int32 (the reference ABI uses ptrdiff_t; the C++ shims in
+ * include/kbest_shims.hpp widen on the host).
+ *
+ * All compute runs in hand-written HIP kernels for gfx950
+ * (probabilisticsemslam_amd/csrc/kbest_engine.hip).  There is no CPU fallback:
+ * without a GPU every compute entry point returns KBEST_ERR_NO_DEVICE.
+ */
+#ifndef KBEST_C_H
+#define KBEST_C_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kbest_ctx kbest_ctx; /* opaque: device, stream, workspace pools */
+
+enum {
+    KBEST_OK = 0,
+    KBEST_ERR_NO_DEVICE = -1,   /* no HIP device / HIP runtime error at create    */
+    KBEST_ERR_BAD_ARG = -2,     /* null pointer, k < 1, numRow < numCol, ...      */
+    KBEST_ERR_UNSUPPORTED = -3, /* numRow > KBEST_MAX_DIM or k beyond LDS pool    */
+    KBEST_ERR_HIP = -4,         /* a HIP call failed; see kbest_last_error()      */
+    KBEST_ERR_NOMEM = -5
+};
+
+#define KBEST_MAX_DIM 64 /* rows per problem handled by the wave-per-child kernels */
+
+/* flags */
+#define KBEST_FLAG_NO_PRUNE 1u     /* disable early termination (for counting P)   */
+#define KBEST_FLAG_COUNT_PUSHED 2u /* fill `pushed` with the reference's push count */
+
+typedef struct kbest_opts {
+    int32_t  maximize;     /* reference `maximize` argument                       */
+    int32_t  use_cutoff;   /* 0: kBest2D semantics; 1: kBest2DCutoff semantics    */
+    double   cutoff;       /* reference `cutoff` argument (assignment.cpp:9: 42)  */
+    uint32_t flags;        /* KBEST_FLAG_*                                        */
+    int32_t  root_col_offset; /* subtree sharding (multi-GPU latency mode):       */
+    int32_t  root_col_stride; /* only root children on columns c with             */
+                              /* c % stride == offset are expanded; 0/1 = all     */
+} kbest_opts;
+
+void kbest_default_opts(kbest_opts *o);
+
+int kbest_create(kbest_ctx **ctx, int device);
+int kbest_destroy(kbest_ctx *ctx);
+const char *kbest_strerror(int code);
+const char *kbest_last_error(const kbest_ctx *ctx);
+int kbest_device_count(void);
+
+/*
+ * Batched k-best, buffers already resident in device memory (HBM).
+ *   B         number of problems
+ *   maxRow/maxCol  upper bounds of the shapes in the batch; also the leading
+ *             dimensions of the outputs
+ *   d_nRow/d_nCol  per-problem shapes, or NULL for uniform maxRow x maxCol
+ *   d_cost    packed column-major cost blocks; problem b starts at
+ *             d_costOff[b] doubles (or b*maxRow*maxCol when d_costOff is NULL)
+ *   d_row4col [B][k][maxCol] int32   col -> row   (row4colBest, hpp:228-229)
+ *   d_col4row [B][k][maxRow] int32   row -> col   (col4rowBest, hpp:226-227)
+ *   d_gain    [B][k] double                       (gainBest,    hpp:230-231)
+ *   d_nf      [B] int32   number found, 0 = infeasible (return value of kBest2D)
+ *   d_pushed  [B] int64 or NULL; with KBEST_FLAG_COUNT_PUSHED the number of
+ *             feasible children the reference would push (SURVEY 8(d) "P")
+ *   stream    hipStream_t (NULL = the context's own stream).  Asynchronous:
+ *             returns after enqueueing; no host synchronisation inside.
+ */
+int kbest_batch_f64_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, int maxCol,
+                        const int32_t *d_nRow, const int32_t *d_nCol, const double *d_cost,
+                        const int64_t *d_costOff, int k, int32_t *d_row4col, int32_t *d_col4row,
+                        double *d_gain, int32_t *d_nf, int64_t *d_pushed, void *stream);
+
+/* Same with host buffers (copies in, runs, copies out, synchronises). */
+int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, int maxCol,
+                    const int32_t *nRow, const int32_t *nCol, const double *cost,
+                    const int64_t *costOff, int k, int32_t *row4col, int32_t *col4row, double *gain,
+                    int32_t *nf, int64_t *pushed);
+
+/* Make sure the context's workspace can hold a (B, maxRow, k) launch.  Called
+ * implicitly by the batch functions; call it up front to keep allocation out
+ * of a timed / graph-captured region. */
+int kbest_reserve(kbest_ctx *ctx, int B, int maxRow, int k);
+
+/*
+ * Batched assignmentProb (assignment.cpp:547-683): k-best with cutoff 42, then
+ * sum of exp(best - cost) over the solutions scattered into probs.
+ *   nL[b], nM[b]   landmarks / measurements of problem b; its cost block is
+ *                  (nL+nM) x nM column-major
+ *   probs          packed, problem b at probOff[b] doubles: [nM][nL+1] row-major
+ *                  (the reference's vector<vector<double>>)
+ * Host buffers.
+ */
+int kbest_weights_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM,
+                            const double *cost, const int64_t *costOff, int k, double *probs,
+                            const int64_t *probOff, int32_t *nf);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KBEST_C_H */

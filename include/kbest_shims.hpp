@@ -1,0 +1,86 @@
+// kbest_shims.hpp -- C++ drop-in declarations with the reference's own names
+// and signatures, implemented on the MI355X engine (kbest_c.h) with B = 1.
+//
+// A caller written against the reference's shortestPathCPP.hpp / assignment.h
+// keeps compiling against this header and links libkbest_amd.so instead of
+// shortestPathCPP.o / the solver part of assignment.o:
+//
+//   kBest2D        shortestPathCPP.hpp:204-212   (callers: assignment.cpp:880)
+//   kBest2DCutoff  shortestPathCPP.hpp:256-265   (callers: assignment.cpp:594)
+//   assign2D       shortestPathCPP.hpp:144-149   (no caller in the reference)
+//   assignmentProb assignment.h:11               (callers: assignment.cpp:66, comparison.cpp:194-222)
+//
+// MurtyHyp / ScratchSpace keep the reference's public member names, types and
+// declaration order (shortestPathCPP.hpp:22-65, 73-142) so that objects built
+// by such a caller have the layout these functions expect.  The engine keeps
+// its own device workspace, so ScratchSpace is only honoured as an interface:
+// its flags are set the way kBest2DCutoff sets them (cpp:650-651), its buffers
+// are not used.
+//
+// Error behaviour follows the reference: no exceptions from the solver, the
+// return value is the number of solutions found and 0 means infeasible.  An
+// engine failure (no GPU, unsupported size) cannot be expressed in that
+// convention, so it throws std::runtime_error -- the product never silently
+// falls back to a CPU path.
+#ifndef KBEST_SHIMS_HPP
+#define KBEST_SHIMS_HPP
+
+#include <cstddef>
+#include <vector>
+
+class MurtyHyp {
+private:
+    char *buffer;
+
+public:
+    ptrdiff_t *col4row;
+    ptrdiff_t *row4col;
+    double gain;
+    double *u;
+    double *v;
+    size_t activeCol;
+    bool *forbiddenActiveRows;
+    bool solved;
+
+    MurtyHyp() : buffer(nullptr) {}
+    MurtyHyp(const size_t numRow, const size_t numCol);
+    ~MurtyHyp() { delete[] buffer; }
+    MurtyHyp(const MurtyHyp &) = delete;
+    MurtyHyp &operator=(const MurtyHyp &) = delete;
+};
+
+class ScratchSpace {
+public:
+    char *buffer;
+    double *C;
+    size_t *ScannedColIdx;
+    bool *ScannedRows;
+    size_t *pred;
+    double *shortestPathCost;
+    ptrdiff_t *Row2ScanParent;
+    ptrdiff_t *Row2Scan;
+    bool *forbiddenActiveRows;
+    bool toCut;
+    double cutoffGain;
+    bool maximize;
+
+    ScratchSpace() : buffer(nullptr), toCut(false) {}
+    ScratchSpace(const size_t numRow, const size_t numCol) : buffer(nullptr) { init(numRow, numCol); }
+    void init(const size_t numRow, const size_t numCol);
+    ~ScratchSpace() { delete[] buffer; }
+    inline bool cutHyp(double gain) const { return toCut ? (maximize ? gain < cutoffGain : gain > cutoffGain) : false; }
+};
+
+size_t kBest2D(const size_t k, const size_t numRow, const size_t numCol, const bool maximize, const double *C,
+               ScratchSpace &workMem, ptrdiff_t *col4rowBest, ptrdiff_t *row4colBest, double *gainBest);
+
+size_t kBest2DCutoff(const size_t k, const size_t numRow, const size_t numCol, const bool maximize, const double *C,
+                     ScratchSpace &workMem, ptrdiff_t *col4rowBest, ptrdiff_t *row4colBest, double *gainBest,
+                     double cutoff);
+
+int assign2D(const size_t numRow, const size_t numCol, const bool maximize, const double *C, ScratchSpace &workMem,
+             MurtyHyp *problemSol);
+
+std::vector<std::vector<double>> assignmentProb(const std::vector<double> &costMatrix, size_t nL, size_t nM, size_t k);
+
+#endif

@@ -1,0 +1,318 @@
+// kbest_capi.cpp -- the C ABI of include/kbest_c.h on top of the HIP kernels.
+// Plain pointers and sizes only; no torch types.  There is no CPU fallback:
+// every compute entry point needs a HIP device and fails loudly without one.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "kbest_c.h"
+#include "kbest_engine.h"
+
+struct kbest_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    unsigned char *states = nullptr;  // hypothesis-state workspace
+    size_t statesBytes = 0;
+    int ldsLimit = 65536;
+    int nWaves = 4;
+    std::string err;
+    std::mutex mu;  // shim entry points may be called from several host threads
+};
+
+namespace {
+
+int fail(kbest_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess)
+{
+    if (ctx) {
+        ctx->err = what;
+        if (e != hipSuccess) { ctx->err += ": "; ctx->err += hipGetErrorString(e); }
+    }
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                   \
+    do {                                                                     \
+        hipError_t e_ = (call);                                              \
+        if (e_ != hipSuccess) return fail(ctx, KBEST_ERR_HIP, #call, e_);    \
+    } while (0)
+
+struct DevBuf {  // RAII device buffer for the host-pointer entry points
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+    template <class T> T *as() { return static_cast<T *>(p); }
+};
+
+}  // namespace
+
+extern "C" {
+
+void kbest_default_opts(kbest_opts *o)
+{
+    if (!o) return;
+    o->maximize = 0;
+    o->use_cutoff = 0;
+    o->cutoff = 0.0;
+    o->flags = 0;
+    o->root_col_offset = 0;
+    o->root_col_stride = 0;
+}
+
+const char *kbest_strerror(int code)
+{
+    switch (code) {
+    case KBEST_OK: return "ok";
+    case KBEST_ERR_NO_DEVICE: return "no HIP device available (this engine has no CPU fallback)";
+    case KBEST_ERR_BAD_ARG: return "bad argument";
+    case KBEST_ERR_UNSUPPORTED: return "problem size not supported by the device kernels";
+    case KBEST_ERR_HIP: return "HIP runtime error";
+    case KBEST_ERR_NOMEM: return "out of device memory";
+    default: return "unknown error";
+    }
+}
+
+const char *kbest_last_error(const kbest_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int kbest_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int kbest_create(kbest_ctx **out, int device)
+{
+    if (!out) return KBEST_ERR_BAD_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return KBEST_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return KBEST_ERR_NO_DEVICE;
+    kbest_ctx *ctx = new kbest_ctx;
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return KBEST_ERR_NO_DEVICE;
+    }
+    int lds = 0;
+    if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds > 0)
+        ctx->ldsLimit = lds;
+    if (const char *e = getenv("KBEST_NWAVES")) {
+        int w = atoi(e);
+        if (w == 1 || w == 2 || w == 4 || w == 8) ctx->nWaves = w;
+    }
+    *out = ctx;
+    return KBEST_OK;
+}
+
+int kbest_destroy(kbest_ctx *ctx)
+{
+    if (!ctx) return KBEST_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->states) (void)hipFree(ctx->states);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return KBEST_OK;
+}
+
+int kbest_reserve(kbest_ctx *ctx, int B, int maxRow, int k)
+{
+    if (!ctx || B < 0 || maxRow < 1 || k < 1) return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_reserve: bad argument");
+    const size_t need = (size_t)B * (size_t)k * (size_t)kb::state_stride(maxRow);
+    if (need <= ctx->statesBytes) return KBEST_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->states) { HIP_TRY(ctx, hipDeviceSynchronize()); (void)hipFree(ctx->states); ctx->states = nullptr; ctx->statesBytes = 0; }
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->states), need);
+    if (e != hipSuccess) return fail(ctx, KBEST_ERR_NOMEM, "hipMalloc(state workspace)", e);
+    ctx->statesBytes = need;
+    return KBEST_OK;
+}
+
+int kbest_batch_f64_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, int maxCol,
+                        const int32_t *d_nRow, const int32_t *d_nCol, const double *d_cost,
+                        const int64_t *d_costOff, int k, int32_t *d_row4col, int32_t *d_col4row,
+                        double *d_gain, int32_t *d_nf, int64_t *d_pushed, void *stream)
+{
+    if (!ctx) return KBEST_ERR_BAD_ARG;
+    if (!opts || B < 0 || k < 1 || maxCol < 1 || maxRow < maxCol || !d_cost || !d_row4col || !d_col4row || !d_gain || !d_nf)
+        return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_batch_f64_dev: bad argument");
+    if ((d_nRow == nullptr) != (d_nCol == nullptr))
+        return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_batch_f64_dev: give both nRow and nCol or neither");
+    if (maxRow > KBEST_MAX_DIM) return fail(ctx, KBEST_ERR_UNSUPPORTED, "numRow > KBEST_MAX_DIM");
+    if (k > (1 << 23)) return fail(ctx, KBEST_ERR_UNSUPPORTED, "k too large");
+    const kb::Lds L = kb::lds_layout(maxRow, k);
+    if (L.total > ctx->ldsLimit) return fail(ctx, KBEST_ERR_UNSUPPORTED, "k too large for the LDS candidate pool");
+    if (B == 0) return KBEST_OK;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    int rc = kbest_reserve(ctx, B, maxRow, k);
+    if (rc != KBEST_OK) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    kb::Params p;
+    p.cost = d_cost;
+    p.costOff = reinterpret_cast<const long long *>(d_costOff);
+    p.nRow = d_nRow;
+    p.nCol = d_nCol;
+    p.maxRow = maxRow;
+    p.maxCol = maxCol;
+    p.k = k;
+    p.maximize = opts->maximize;
+    p.useCutoff = opts->use_cutoff;
+    p.flags = opts->flags;
+    p.cutoff = opts->cutoff;
+    p.rootColOffset = opts->root_col_offset;
+    p.rootColStride = opts->root_col_stride;
+    p.row4col = d_row4col;
+    p.col4row = d_col4row;
+    p.gain = d_gain;
+    p.nf = d_nf;
+    p.pushed = reinterpret_cast<long long *>(d_pushed);
+    p.states = ctx->states;
+    p.stateStride = kb::state_stride(maxRow);
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    hipError_t e = kb::launch_kbest(p, B, ctx->nWaves, s);
+    if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "kbest kernel launch", e);
+    return KBEST_OK;
+}
+
+int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, int maxCol,
+                    const int32_t *nRow, const int32_t *nCol, const double *cost,
+                    const int64_t *costOff, int k, int32_t *row4col, int32_t *col4row, double *gain,
+                    int32_t *nf, int64_t *pushed)
+{
+    if (!ctx) return KBEST_ERR_BAD_ARG;
+    if (!opts || B < 0 || k < 1 || !cost || !row4col || !col4row || !gain || !nf)
+        return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_batch_f64: bad argument");
+    if ((nRow == nullptr) != (nCol == nullptr))
+        return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_batch_f64: give both nRow and nCol or neither");
+    if (B == 0) return KBEST_OK;
+    size_t nCost = 0;
+    if (nRow) {
+        for (int b = 0; b < B; b++) {
+            if (nCol[b] < 1 || nRow[b] < nCol[b] || nRow[b] > maxRow || nCol[b] > maxCol)
+                return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_batch_f64: shape out of range (need 1 <= numCol <= numRow <= maxRow)");
+            const size_t end = (costOff ? (size_t)costOff[b] : (size_t)b * maxRow * maxCol) + (size_t)nRow[b] * nCol[b];
+            if (end > nCost) nCost = end;
+        }
+    } else {
+        if (costOff) return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_batch_f64: costOff needs per-problem shapes");
+        nCost = (size_t)B * maxRow * maxCol;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf dCost, dOff, dNR, dNC, dR4C, dC4R, dGain, dNf, dPushed;
+    const size_t nR4C = (size_t)B * k * maxCol, nC4R = (size_t)B * k * maxRow, nG = (size_t)B * k;
+    HIP_TRY(ctx, dCost.alloc(nCost * 8));
+    HIP_TRY(ctx, dR4C.alloc(nR4C * 4));
+    HIP_TRY(ctx, dC4R.alloc(nC4R * 4));
+    HIP_TRY(ctx, dGain.alloc(nG * 8));
+    HIP_TRY(ctx, dNf.alloc((size_t)B * 4));
+    HIP_TRY(ctx, hipMemcpy(dCost.p, cost, nCost * 8, hipMemcpyHostToDevice));
+    if (nRow) {
+        HIP_TRY(ctx, dNR.alloc((size_t)B * 4));
+        HIP_TRY(ctx, dNC.alloc((size_t)B * 4));
+        HIP_TRY(ctx, hipMemcpy(dNR.p, nRow, (size_t)B * 4, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(dNC.p, nCol, (size_t)B * 4, hipMemcpyHostToDevice));
+    }
+    if (costOff) {
+        HIP_TRY(ctx, dOff.alloc((size_t)B * 8));
+        HIP_TRY(ctx, hipMemcpy(dOff.p, costOff, (size_t)B * 8, hipMemcpyHostToDevice));
+    }
+    if (pushed) HIP_TRY(ctx, dPushed.alloc((size_t)B * 8));
+    // slots beyond nf are never written by the kernel: give them a defined value
+    HIP_TRY(ctx, hipMemset(dR4C.p, 0xFF, nR4C * 4));
+    HIP_TRY(ctx, hipMemset(dC4R.p, 0xFF, nC4R * 4));
+    HIP_TRY(ctx, hipMemset(dGain.p, 0, nG * 8));
+    int rc = kbest_batch_f64_dev(ctx, opts, B, maxRow, maxCol, nRow ? dNR.as<int32_t>() : nullptr,
+                                 nRow ? dNC.as<int32_t>() : nullptr, dCost.as<double>(),
+                                 costOff ? dOff.as<int64_t>() : nullptr, k, dR4C.as<int32_t>(), dC4R.as<int32_t>(),
+                                 dGain.as<double>(), dNf.as<int32_t>(), pushed ? dPushed.as<int64_t>() : nullptr,
+                                 ctx->stream);
+    if (rc != KBEST_OK) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(row4col, dR4C.p, nR4C * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(col4row, dC4R.p, nC4R * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(gain, dGain.p, nG * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(nf, dNf.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+    if (pushed) HIP_TRY(ctx, hipMemcpy(pushed, dPushed.p, (size_t)B * 8, hipMemcpyDeviceToHost));
+    return KBEST_OK;
+}
+
+int kbest_weights_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM,
+                            const double *cost, const int64_t *costOff, int k, double *probs,
+                            const int64_t *probOff, int32_t *nf)
+{
+    if (!ctx) return KBEST_ERR_BAD_ARG;
+    if (B < 0 || k < 1 || !nL || !nM || !cost || !costOff || !probs || !probOff)
+        return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_weights_batch_f64: bad argument");
+    if (B == 0) return KBEST_OK;
+    int maxRow = 1, maxCol = 1;
+    size_t nCost = 0, nProb = 0;
+    std::vector<int32_t> nRow(B);
+    for (int b = 0; b < B; b++) {
+        if (nM[b] < 1 || nL[b] < 0) return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_weights_batch_f64: need nM >= 1, nL >= 0");
+        nRow[b] = nL[b] + nM[b];
+        if (nRow[b] > maxRow) maxRow = nRow[b];
+        if (nM[b] > maxCol) maxCol = nM[b];
+        const size_t ce = (size_t)costOff[b] + (size_t)nRow[b] * nM[b];
+        const size_t pe = (size_t)probOff[b] + (size_t)nM[b] * (nL[b] + 1);
+        if (ce > nCost) nCost = ce;
+        if (pe > nProb) nProb = pe;
+    }
+    if (maxRow > KBEST_MAX_DIM) return fail(ctx, KBEST_ERR_UNSUPPORTED, "nL + nM > KBEST_MAX_DIM");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf dCost, dOff, dNR, dNC, dNL, dR4C, dC4R, dGain, dNf, dProbs, dPOff;
+    const size_t nR4C = (size_t)B * k * maxCol, nC4R = (size_t)B * k * maxRow, nG = (size_t)B * k;
+    HIP_TRY(ctx, dCost.alloc(nCost * 8));
+    HIP_TRY(ctx, dOff.alloc((size_t)B * 8));
+    HIP_TRY(ctx, dNR.alloc((size_t)B * 4));
+    HIP_TRY(ctx, dNC.alloc((size_t)B * 4));
+    HIP_TRY(ctx, dNL.alloc((size_t)B * 4));
+    HIP_TRY(ctx, dR4C.alloc(nR4C * 4));
+    HIP_TRY(ctx, dC4R.alloc(nC4R * 4));
+    HIP_TRY(ctx, dGain.alloc(nG * 8));
+    HIP_TRY(ctx, dNf.alloc((size_t)B * 4));
+    HIP_TRY(ctx, dProbs.alloc(nProb * 8));
+    HIP_TRY(ctx, dPOff.alloc((size_t)B * 8));
+    HIP_TRY(ctx, hipMemcpy(dCost.p, cost, nCost * 8, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(dOff.p, costOff, (size_t)B * 8, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(dNR.p, nRow.data(), (size_t)B * 4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(dNC.p, nM, (size_t)B * 4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(dNL.p, nL, (size_t)B * 4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(dPOff.p, probOff, (size_t)B * 8, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemset(dProbs.p, 0, nProb * 8));
+    kbest_opts o;
+    kbest_default_opts(&o);
+    o.use_cutoff = 1;   // assignment.cpp:594: kBest2DCutoff(..., cutoff = 42)
+    o.cutoff = 42.0;
+    int rc = kbest_batch_f64_dev(ctx, &o, B, maxRow, maxCol, dNR.as<int32_t>(), dNC.as<int32_t>(), dCost.as<double>(),
+                                 dOff.as<int64_t>(), k, dR4C.as<int32_t>(), dC4R.as<int32_t>(), dGain.as<double>(),
+                                 dNf.as<int32_t>(), nullptr, ctx->stream);
+    if (rc != KBEST_OK) return rc;
+    kb::WeightParams w;
+    w.nL = dNL.as<int>();
+    w.nM = dNC.as<int>();
+    w.cost = dCost.as<double>();
+    w.costOff = dOff.as<long long>();
+    w.gain = dGain.as<double>();
+    w.row4col = dR4C.as<int>();
+    w.nf = dNf.as<int>();
+    w.probs = dProbs.as<double>();
+    w.probOff = dPOff.as<long long>();
+    w.k = k;
+    w.maxCol = maxCol;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        hipError_t e = kb::launch_weights(w, B, ctx->stream);
+        if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "weights kernel launch", e);
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(probs, dProbs.p, nProb * 8, hipMemcpyDeviceToHost));
+    if (nf) HIP_TRY(ctx, hipMemcpy(nf, dNf.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+    return KBEST_OK;
+}
+
+}  // extern "C"

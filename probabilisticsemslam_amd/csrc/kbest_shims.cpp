@@ -1,0 +1,135 @@
+// kbest_shims.cpp -- reference-named C++ entry points (include/kbest_shims.hpp)
+// forwarding to the C ABI with B = 1 on a lazily created process-global context.
+#include "kbest_shims.hpp"
+
+#include <cstdint>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+
+#include "kbest_c.h"
+
+namespace {
+
+kbest_ctx *global_ctx()
+{
+    static kbest_ctx *ctx = nullptr;
+    static std::once_flag once;
+    static int rc = KBEST_OK;
+    std::call_once(once, [] { rc = kbest_create(&ctx, 0); });
+    if (rc != KBEST_OK || !ctx) throw std::runtime_error(std::string("kbest engine: ") + kbest_strerror(rc));
+    return ctx;
+}
+
+void check(kbest_ctx *ctx, int rc)
+{
+    if (rc != KBEST_OK)
+        throw std::runtime_error(std::string("kbest engine: ") + kbest_strerror(rc) + " (" + kbest_last_error(ctx) + ")");
+}
+
+size_t kbest_one(size_t k, size_t numRow, size_t numCol, bool maximize, const double *C, bool useCut, double cutoff,
+                 ptrdiff_t *col4rowBest, ptrdiff_t *row4colBest, double *gainBest)
+{
+    kbest_ctx *ctx = global_ctx();
+    kbest_opts o;
+    kbest_default_opts(&o);
+    o.maximize = maximize;
+    o.use_cutoff = useCut;
+    o.cutoff = cutoff;
+    std::vector<int32_t> r4c(k * numCol), c4r(k * numRow);
+    int32_t nf = 0;
+    check(ctx, kbest_batch_f64(ctx, &o, 1, (int)numRow, (int)numCol, nullptr, nullptr, C, nullptr, (int)k, r4c.data(),
+                               c4r.data(), gainBest, &nf, nullptr));
+    if (nf < 0) throw std::runtime_error("kbest engine: internal error");
+    // the reference also writes the slot it breaks on under a cutoff (cpp:705-718); callers only read
+    // the first `nf` slots, which is what is widened here
+    const size_t n = (size_t)nf;
+    for (size_t i = 0; i < n * numRow; i++) col4rowBest[i] = c4r[i];
+    for (size_t i = 0; i < n * numCol; i++) row4colBest[i] = r4c[i];
+    return n;
+}
+
+}  // namespace
+
+MurtyHyp::MurtyHyp(const size_t numRow, const size_t numCol)
+{
+    const size_t bytes = numRow * sizeof(ptrdiff_t) + numCol * sizeof(ptrdiff_t) + numCol * sizeof(double) +
+                         numRow * sizeof(double) + numRow * sizeof(bool);
+    buffer = new char[bytes];
+    char *p = buffer;
+    u = reinterpret_cast<double *>(p);            p += numCol * sizeof(double);
+    v = reinterpret_cast<double *>(p);            p += numRow * sizeof(double);
+    col4row = reinterpret_cast<ptrdiff_t *>(p);   p += numRow * sizeof(ptrdiff_t);
+    row4col = reinterpret_cast<ptrdiff_t *>(p);   p += numCol * sizeof(ptrdiff_t);
+    forbiddenActiveRows = reinterpret_cast<bool *>(p);
+    gain = 0.0;
+    activeCol = 0;
+    solved = false;
+}
+
+void ScratchSpace::init(const size_t numRow, const size_t numCol)
+{
+    // Same capacity contract as the reference (C must hold numRow*numCol doubles,
+    // shortestPathCPP.hpp:100-119); the engine itself works in device memory.
+    delete[] buffer;
+    const size_t bytes = numRow * numCol * sizeof(double) + numRow * sizeof(double) + numCol * sizeof(size_t) +
+                         numRow * (sizeof(size_t) + 2 * sizeof(ptrdiff_t) + 2 * sizeof(bool));
+    buffer = new char[bytes];
+    char *p = buffer;
+    C = reinterpret_cast<double *>(p);                 p += numRow * numCol * sizeof(double);
+    shortestPathCost = reinterpret_cast<double *>(p);  p += numRow * sizeof(double);
+    ScannedColIdx = reinterpret_cast<size_t *>(p);     p += numCol * sizeof(size_t);
+    pred = reinterpret_cast<size_t *>(p);              p += numRow * sizeof(size_t);
+    Row2ScanParent = reinterpret_cast<ptrdiff_t *>(p); p += numRow * sizeof(ptrdiff_t);
+    Row2Scan = reinterpret_cast<ptrdiff_t *>(p);       p += numRow * sizeof(ptrdiff_t);
+    ScannedRows = reinterpret_cast<bool *>(p);         p += numRow * sizeof(bool);
+    forbiddenActiveRows = reinterpret_cast<bool *>(p);
+    toCut = false;
+}
+
+size_t kBest2D(const size_t k, const size_t numRow, const size_t numCol, const bool maximize, const double *C,
+               ScratchSpace &, ptrdiff_t *col4rowBest, ptrdiff_t *row4colBest, double *gainBest)
+{
+    return kbest_one(k, numRow, numCol, maximize, C, false, 0.0, col4rowBest, row4colBest, gainBest);
+}
+
+size_t kBest2DCutoff(const size_t k, const size_t numRow, const size_t numCol, const bool maximize, const double *C,
+                     ScratchSpace &workMem, ptrdiff_t *col4rowBest, ptrdiff_t *row4colBest, double *gainBest,
+                     double cutoff)
+{
+    workMem.toCut = true;  // cpp:650-651 (sticky, as in the reference)
+    workMem.maximize = maximize;
+    const size_t n = kbest_one(k, numRow, numCol, maximize, C, true, cutoff, col4rowBest, row4colBest, gainBest);
+    if (n) workMem.cutoffGain = maximize ? gainBest[0] - cutoff : gainBest[0] + cutoff;
+    return n;
+}
+
+int assign2D(const size_t numRow, const size_t numCol, const bool maximize, const double *C, ScratchSpace &,
+             MurtyHyp *problemSol)
+{
+    // Best assignment of the numRow x numCol problem (cpp:735-762).  The engine solves the zero-padded
+    // square problem; rows it parks on padded columns are the reference's unassigned rows (-1).
+    std::vector<ptrdiff_t> c4r(numRow), r4c(numCol);
+    double g = 0.0;
+    if (kbest_one(1, numRow, numCol, maximize, C, false, 0.0, c4r.data(), r4c.data(), &g) == 0) return 0;
+    for (size_t r = 0; r < numRow; r++) problemSol->col4row[r] = c4r[r] >= (ptrdiff_t)numCol ? -1 : c4r[r];
+    for (size_t c = 0; c < numCol; c++) problemSol->row4col[c] = r4c[c];
+    problemSol->gain = g;
+    problemSol->solved = true;
+    return 1;
+}
+
+std::vector<std::vector<double>> assignmentProb(const std::vector<double> &costMatrix, size_t nL, size_t nM, size_t k)
+{
+    kbest_ctx *ctx = global_ctx();
+    const int32_t l = (int32_t)nL, m = (int32_t)nM;
+    const int64_t zero = 0;
+    // the single-column path returns 1 x costMatrix.size() (assignment.cpp:557); otherwise nM x (nL+1)
+    const size_t width = (nM == 1) ? costMatrix.size() : nL + 1;
+    std::vector<double> flat(nM * (nL + 1), 0.0);
+    check(ctx, kbest_weights_batch_f64(ctx, 1, &l, &m, costMatrix.data(), &zero, (int)k, flat.data(), &zero, nullptr));
+    std::vector<std::vector<double>> probs(nM, std::vector<double>(width, 0.0));
+    for (size_t c = 0; c < nM; c++)
+        for (size_t j = 0; j <= nL; j++) probs[c][j] = flat[c * (nL + 1) + j];
+    return probs;
+}

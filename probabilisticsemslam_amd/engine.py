@@ -1,0 +1,204 @@
+"""ctypes binding of include/kbest_c.h.  No compute happens in Python and there
+is no fallback: if the HIP library is missing or no GPU is present, calls fail
+loudly (KBestError)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+KBEST_FLAG_NO_PRUNE = 1
+KBEST_FLAG_COUNT_PUSHED = 2
+KBEST_MAX_DIM = 64
+
+# every symbol include/kbest_c.h declares
+C_ABI_SYMBOLS = (
+    "kbest_default_opts", "kbest_create", "kbest_destroy", "kbest_strerror", "kbest_last_error",
+    "kbest_device_count", "kbest_batch_f64_dev", "kbest_batch_f64", "kbest_reserve", "kbest_weights_batch_f64",
+)
+
+
+class KBestError(RuntimeError):
+    pass
+
+
+class KBestOpts(C.Structure):
+    _fields_ = [("maximize", C.c_int32), ("use_cutoff", C.c_int32), ("cutoff", C.c_double), ("flags", C.c_uint32),
+                ("root_col_offset", C.c_int32), ("root_col_stride", C.c_int32)]
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "libkbest_amd.so")
+
+
+_lib = None
+
+
+def load_library():
+    """Load the in-tree HIP library; raises KBestError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise KBestError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "(there is no CPU fallback)")
+    lib = C.CDLL(path)
+    vp, i32p, i64p, dp = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
+    lib.kbest_default_opts.argtypes = [C.POINTER(KBestOpts)]
+    lib.kbest_default_opts.restype = None
+    lib.kbest_create.argtypes = [C.POINTER(vp), C.c_int]
+    lib.kbest_destroy.argtypes = [vp]
+    lib.kbest_strerror.argtypes = [C.c_int]
+    lib.kbest_strerror.restype = C.c_char_p
+    lib.kbest_last_error.argtypes = [vp]
+    lib.kbest_last_error.restype = C.c_char_p
+    lib.kbest_device_count.restype = C.c_int
+    lib.kbest_reserve.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    lib.kbest_batch_f64_dev.argtypes = [vp, C.POINTER(KBestOpts), C.c_int, C.c_int, C.c_int, i32p, i32p, dp, i64p,
+                                        C.c_int, i32p, i32p, dp, i32p, i64p, vp]
+    lib.kbest_batch_f64.argtypes = [vp, C.POINTER(KBestOpts), C.c_int, C.c_int, C.c_int, i32p, i32p, dp, i64p,
+                                    C.c_int, i32p, i32p, dp, i32p, i64p]
+    lib.kbest_weights_batch_f64.argtypes = [vp, C.c_int, i32p, i32p, dp, i64p, C.c_int, dp, i64p, i32p]
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class KBestEngine:
+    """One engine context = one GPU, one stream, one hypothesis-state workspace."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        self.ctx = C.c_void_p()
+        rc = self.lib.kbest_create(C.byref(self.ctx), device)
+        if rc != 0:
+            raise KBestError(f"kbest_create(device={device}): {self.lib.kbest_strerror(rc).decode()}")
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.kbest_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise KBestError(f"{self.lib.kbest_strerror(rc).decode()}: {self.lib.kbest_last_error(self.ctx).decode()}")
+
+    def _opts(self, maximize, cutoff, flags=0, root_shard=None):
+        o = KBestOpts()
+        self.lib.kbest_default_opts(C.byref(o))
+        o.maximize = int(bool(maximize))
+        o.use_cutoff = int(cutoff is not None)
+        o.cutoff = float(cutoff) if cutoff is not None else 0.0
+        o.flags = flags
+        if root_shard is not None:
+            o.root_col_offset, o.root_col_stride = root_shard
+        return o
+
+    # ---- host buffers -----------------------------------------------------------------
+    def kbest(self, costs, N, M, k, maximize=False, cutoff=None, nRow=None, nCol=None, costOff=None,
+              count_pushed=False, prune=True, root_shard=None):
+        """Batched kBest2D / kBest2DCutoff.  costs: (B, N*M) for uniform shapes, or a flat packed
+        array with per-problem nRow/nCol/costOff (N, M are then the maxima).
+        Returns (nf[B], row4col[B,k,M], col4row[B,k,N], gain[B,k]) (+ pushed[B] if count_pushed)."""
+        costs = np.ascontiguousarray(costs, dtype=np.float64)
+        if nRow is None:
+            costs = costs.reshape(-1, N * M)
+            B = costs.shape[0]
+        else:
+            nRow = np.ascontiguousarray(nRow, dtype=np.int32)
+            nCol = np.ascontiguousarray(nCol, dtype=np.int32)
+            costOff = np.ascontiguousarray(costOff, dtype=np.int64)
+            B = len(nRow)
+        r4c = np.empty((B, k, M), np.int32)
+        c4r = np.empty((B, k, N), np.int32)
+        gain = np.empty((B, k), np.float64)
+        nf = np.empty(B, np.int32)
+        pushed = np.zeros(B, np.int64) if count_pushed else None
+        flags = (KBEST_FLAG_COUNT_PUSHED if count_pushed else 0) | (0 if prune else KBEST_FLAG_NO_PRUNE)
+        o = self._opts(maximize, cutoff, flags, root_shard)
+        self._check(self.lib.kbest_batch_f64(self.ctx, C.byref(o), B, N, M, _ptr(nRow), _ptr(nCol), _ptr(costs),
+                                             _ptr(costOff), k, _ptr(r4c), _ptr(c4r), _ptr(gain), _ptr(nf),
+                                             _ptr(pushed)))
+        if count_pushed:
+            return nf, r4c, c4r, gain, pushed
+        return nf, r4c, c4r, gain
+
+    def weights(self, costs, nL, nM, k):
+        """Batched assignmentProb.  costs: list of 1-D column-major (nL+nM) x nM blocks.
+        Returns (list of [nM, nL+1] arrays, nf[B])."""
+        nL = np.ascontiguousarray(nL, dtype=np.int32)
+        nM = np.ascontiguousarray(nM, dtype=np.int32)
+        B = len(nL)
+        sizes = [(int(nL[b]) + int(nM[b])) * int(nM[b]) for b in range(B)]
+        psizes = [int(nM[b]) * (int(nL[b]) + 1) for b in range(B)]
+        costOff = np.zeros(B, np.int64)
+        probOff = np.zeros(B, np.int64)
+        costOff[1:] = np.cumsum(sizes)[:-1]
+        probOff[1:] = np.cumsum(psizes)[:-1]
+        flat = np.concatenate([np.ascontiguousarray(c, dtype=np.float64).reshape(-1) for c in costs])
+        probs = np.zeros(int(sum(psizes)), np.float64)
+        nf = np.zeros(B, np.int32)
+        self._check(self.lib.kbest_weights_batch_f64(self.ctx, B, _ptr(nL), _ptr(nM), _ptr(flat), _ptr(costOff), k,
+                                                     _ptr(probs), _ptr(probOff), _ptr(nf)))
+        out = [probs[probOff[b]: probOff[b] + psizes[b]].reshape(int(nM[b]), int(nL[b]) + 1) for b in range(B)]
+        return out, nf
+
+    # ---- device buffers (torch tensors already resident in HBM) -------------------------
+    def reserve(self, B, N, k):
+        self._check(self.lib.kbest_reserve(self.ctx, B, N, k))
+
+    def kbest_dev(self, d_cost, B, N, M, k, d_row4col, d_col4row, d_gain, d_nf, maximize=False, cutoff=None,
+                  d_pushed=None, prune=True, stream=None, root_shard=None, d_nRow=None, d_nCol=None, d_costOff=None):
+        """Asynchronous launch on `stream` (a raw hipStream_t integer, e.g.
+        torch.cuda.current_stream().cuda_stream).  All d_* are torch CUDA tensors."""
+        flags = (KBEST_FLAG_COUNT_PUSHED if d_pushed is not None else 0) | (0 if prune else KBEST_FLAG_NO_PRUNE)
+        o = self._opts(maximize, cutoff, flags, root_shard)
+
+        def dp(t):
+            return None if t is None else C.c_void_p(t.data_ptr())
+
+        self._check(self.lib.kbest_batch_f64_dev(self.ctx, C.byref(o), B, N, M, dp(d_nRow), dp(d_nCol), dp(d_cost),
+                                                 dp(d_costOff), k, dp(d_row4col), dp(d_col4row), dp(d_gain), dp(d_nf),
+                                                 dp(d_pushed), C.c_void_p(stream) if stream else None))
+
+
+# ---- reference-named conveniences (B = 1), mirroring shortestPathCPP.hpp / assignment.h -------------
+_default = None
+
+
+def _engine():
+    global _default
+    if _default is None:
+        _default = KBestEngine(0)
+    return _default
+
+
+def kBest2D(k, numRow, numCol, maximize, C_):
+    """shortestPathCPP.hpp:204-212.  Returns (numFound, col4rowBest[k,numRow], row4colBest[k,numCol], gainBest[k])."""
+    nf, r4c, c4r, g = _engine().kbest(np.asarray(C_).reshape(1, -1), numRow, numCol, k, maximize)
+    return int(nf[0]), c4r[0], r4c[0], g[0]
+
+
+def kBest2DCutoff(k, numRow, numCol, maximize, C_, cutoff):
+    """shortestPathCPP.hpp:256-265."""
+    nf, r4c, c4r, g = _engine().kbest(np.asarray(C_).reshape(1, -1), numRow, numCol, k, maximize, cutoff)
+    return int(nf[0]), c4r[0], r4c[0], g[0]
+
+
+def assignmentProb(costMatrix, nL, nM, k):
+    """assignment.h:11.  Returns probs[nM][nL+1]."""
+    out, _ = _engine().weights([costMatrix], [nL], [nM], k)
+    return out[0]

@@ -1,0 +1,224 @@
+"""GPU: the HIP engine, called through the C ABI, against (a) the golden vectors recorded from the
+unmodified reference solver, (b) the CPU oracle on seeded inputs, (c) size-independent properties at
+BASELINE.json's full sizes.  Bit-exact for nf / row4col / col4row / gains; weights within 1e-12
+(north star: 1e-6 relative)."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import probabilisticsemslam_amd as pk
+from probabilisticsemslam_amd import workloads as wl
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.int64)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    return pk.KBestEngine(0)
+
+
+def check_against(eng_out, want_nf, want_r4c, want_c4r, want_g, tag=""):
+    nf, r4c, c4r, g = eng_out
+    assert nf == want_nf, (tag, nf, want_nf)
+    assert (r4c[:nf] == want_r4c[:nf]).all(), tag
+    assert (c4r[:nf] == want_c4r[:nf]).all(), tag
+    assert (bits(g[:nf]) == bits(want_g[:nf])).all(), tag
+
+
+def test_golden_vectors(eng, golden):
+    for name in golden.names:
+        c = golden.case(name)
+        nf, r4c, c4r, g = eng.kbest(c["cost"].reshape(1, -1), c["N"], c["M"], c["k"], c["maximize"], c["cutoff"])
+        check_against((int(nf[0]), r4c[0], c4r[0], g[0]), c["nf"], c["row4col"], c["col4row"], c["gain"], name)
+
+
+def test_golden_vectors_no_prune(eng, golden):
+    # early termination off: same answers, and the push count equals the oracle's (SURVEY 8(d) "P")
+    for name in golden.names:
+        c = golden.case(name)
+        nf, r4c, c4r, g, pushed = eng.kbest(c["cost"].reshape(1, -1), c["N"], c["M"], c["k"], c["maximize"],
+                                            c["cutoff"], count_pushed=True, prune=False)
+        check_against((int(nf[0]), r4c[0], c4r[0], g[0]), c["nf"], c["row4col"], c["col4row"], c["gain"], name)
+        st = ol.orc_kbest(c["cost"], c["N"], c["M"], c["k"], c["maximize"], c["cutoff"], want_stats=True)[4]
+        assert int(pushed[0]) == st.children_pushed, name
+
+
+def test_golden_as_one_ragged_batch(eng, golden):
+    # all golden cases with the same (k, maximize, cutoff) in ONE launch with per-problem shapes
+    groups = {}
+    for name in golden.names:
+        c = golden.case(name)
+        groups.setdefault((c["k"], c["maximize"], c["cutoff"]), []).append(c)
+    for (k, maximize, cutoff), cs in groups.items():
+        nRow = np.array([c["N"] for c in cs], np.int32)
+        nCol = np.array([c["M"] for c in cs], np.int32)
+        sizes = nRow.astype(np.int64) * nCol
+        off = np.zeros(len(cs), np.int64)
+        off[1:] = np.cumsum(sizes)[:-1]
+        flat = np.concatenate([c["cost"] for c in cs])
+        N, M = int(nRow.max()), int(nCol.max())
+        nf, r4c, c4r, g = eng.kbest(flat, N, M, k, maximize, cutoff, nRow=nRow, nCol=nCol, costOff=off)
+        for i, c in enumerate(cs):
+            check_against((int(nf[i]), r4c[i][:, :c["M"]], c4r[i][:, :c["N"]], g[i]), c["nf"], c["row4col"],
+                          c["col4row"], c["gain"], c["name"])
+
+
+@pytest.mark.parametrize("name,nb", [("c1", 1), ("c2", 64), ("c3", 24), ("c4", 8)])
+def test_dense_configs_vs_oracle(eng, name, nb):
+    costs, N, M, k = wl.dense_config(name, B=nb)
+    nf, r4c, c4r, g = eng.kbest(costs, N, M, k)
+    onf, or4c, oc4r, og, _ = ol.orc_kbest_batch(costs, N, M, k)
+    assert (nf == onf).all()
+    assert (r4c == or4c).all() and (c4r == oc4r).all()
+    assert (bits(g) == bits(og)).all()
+
+
+def test_random_shapes_vs_oracle(eng):
+    rng = np.random.default_rng(2024)
+    for trial in range(60):
+        N = int(rng.integers(1, 65))
+        M = int(rng.integers(1, N + 1))
+        k = int(rng.integers(1, 80))
+        B = int(rng.integers(1, 6))
+        costs = rng.random((B, N * M)) * 20 - 5
+        mode = trial % 4
+        if mode == 1:
+            costs[rng.random((B, N * M)) < 0.4] = np.inf
+        maximize = mode == 2
+        cutoff = [None, None, None, 4.0][mode]
+        nf, r4c, c4r, g = eng.kbest(costs, N, M, k, maximize, cutoff)
+        onf, or4c, oc4r, og, _ = ol.orc_kbest_batch(costs, N, M, k, maximize, cutoff)
+        assert (nf == onf).all(), trial
+        for b in range(B):
+            n = nf[b]
+            assert (r4c[b, :n] == or4c[b, :n]).all(), trial
+            assert (c4r[b, :n] == oc4r[b, :n]).all(), trial
+            assert (bits(g[b, :n]) == bits(og[b, :n])).all(), trial
+
+
+def test_ties_multiset(eng):
+    # integer costs: equal-gain hypotheses have unspecified relative order:
+    # the multiset of gains and the validity / distinctness of assignments must still hold
+    rng = np.random.default_rng(5)
+    for trial in range(20):
+        N = int(rng.integers(2, 10)); M = int(rng.integers(1, N + 1)); k = int(rng.integers(1, 50))
+        cost = rng.integers(0, 4, N * M).astype(np.float64)
+        nf, r4c, c4r, g = eng.kbest(cost.reshape(1, -1), N, M, k)
+        onf, or4c, oc4r, og = ol.orc_kbest(cost, N, M, k)
+        n = int(nf[0])
+        assert n == onf
+        assert sorted(g[0, :n].tolist()) == sorted(og[:n].tolist())
+        seen = set()
+        for s in range(n):
+            rows = tuple(r4c[0, s].tolist())
+            assert len(set(rows)) == M and rows not in seen
+            seen.add(rows)
+            assert g[0, s] == sum(cost[c * N + r] for c, r in enumerate(rows))
+
+
+@pytest.mark.parametrize("name", ["c2", "c3", "c4"])
+def test_full_size_properties(eng, name):
+    """BASELINE.json full sizes: gains non-decreasing, assignments are distinct injections, each gain is the
+    serial column-order sum of the chosen entries (bit-exact), nf == k, first/last problems equal the oracle."""
+    costs, N, M, k = wl.dense_config(name)
+    B = costs.shape[0]
+    nf, r4c, c4r, g = eng.kbest(costs, N, M, k)
+    assert (nf == k).all()
+    assert (np.diff(g, axis=1) >= 0).all()
+    # rows distinct per solution
+    srt = np.sort(r4c, axis=2)
+    assert (np.diff(srt, axis=2) > 0).all()
+    # col4row is the inverse of row4col
+    bi, si, ci = np.meshgrid(np.arange(B), np.arange(k), np.arange(M), indexing="ij")
+    assert (c4r[bi, si, r4c] == ci).all()
+    # gain = serial sum in column order of the shifted costs + CDelta*M (kBest2D cpp:583-600)
+    cd = costs.min(axis=1)
+    shifted = costs - cd[:, None]
+    acc = np.zeros((B, k))
+    for c in range(M):
+        acc = acc + shifted[np.arange(B)[:, None], c * N + r4c[:, :, c]]
+    assert (bits(acc + (cd * M)[:, None]) == bits(g)).all()
+    # solutions of one problem are pairwise distinct (hash rows)
+    h = (r4c.astype(np.int64) * (np.arange(M, dtype=np.int64) * 2654435761 % (1 << 31) + 1)).sum(axis=2)
+    assert all(len(set(h[b].tolist())) == k for b in range(0, B, max(1, B // 64)))
+    for b in (0, B - 1):
+        onf, or4c, oc4r, og = ol.orc_kbest(costs[b], N, M, k)
+        assert (r4c[b] == or4c).all() and (bits(g[b]) == bits(og)).all()
+
+
+def test_weights_kitti_like(eng):
+    frames = wl.kitti_like_frames(40)
+    conds, nLs, nMs = [], [], []
+    for f in frames:
+        cond, idx = ol.condition_costs(f, 30, 10)
+        conds.append(cond); nLs.append(len(idx) - 10); nMs.append(10)
+    probs, nf = eng.weights(conds, nLs, nMs, 200)
+    for i, cond in enumerate(conds):
+        po, onf = ol.assignment_prob(cond, nLs[i], 10, 200)
+        assert nf[i] == onf
+        np.testing.assert_allclose(probs[i], po, rtol=1e-12, atol=1e-15)   # north star: 1e-6 relative
+    # SURVEY 8(c) weight KAT
+    assert abs(probs[0][0][9] - 0.61485235124407667) < 1e-14
+
+
+def test_weights_small_vs_permanent(eng):
+    # config 5's check: weights equal the exact permanent ratio on small exhaustive sub-problems
+    frames = wl.kitti_like_frames(12, nL=6, nM=3)
+    conds, nLs = [], []
+    for f in frames:
+        cond, idx = ol.condition_costs(f, 9, 3)
+        conds.append(cond); nLs.append(len(idx) - 3)
+    probs, nf = eng.weights(conds, nLs, [3] * len(conds), 200)
+    for i, cond in enumerate(conds):
+        nR = nLs[i] + 3
+        A = np.exp(-cond.reshape(3, nR).T)
+        Z = ol.permanent(A)
+        want = np.zeros((3, nLs[i] + 1))
+        for c in range(3):
+            for r in range(nR):
+                if A[r, c] > 0:
+                    want[c, min(r, nLs[i])] += A[r, c] * ol.permanent(np.delete(np.delete(A, r, 0), c, 1)) / Z
+        np.testing.assert_allclose(probs[i], want, rtol=0, atol=1e-9)
+
+
+def test_weights_single_column(eng):
+    cost = np.array([0.5, 43.0, 2.0, 10.0])
+    p = pk.assignmentProb(cost, 3, 1, 200)
+    po, _ = ol.assignment_prob(cost, 3, 1, 200)
+    np.testing.assert_allclose(p, po, rtol=1e-14)
+
+
+def test_reference_named_mirrors(eng):
+    cs, N, M, k = wl.dense_config("c1")
+    nf, c4r, r4c, g = pk.kBest2D(k, N, M, False, cs[0])
+    assert nf == 10 and r4c[0].tolist() == [0, 2, 7, 5, 3, 4, 6, 1] and float.hex(g[0]) == "0x1.0bd6f90d82018p+0"
+    nf2, _, r4c2, g2 = pk.kBest2DCutoff(k, N, M, False, cs[0], 0.1)
+    onf, or4c, _, og = ol.orc_kbest(cs[0], N, M, k, cutoff=0.1)
+    assert nf2 == onf and (r4c2[:nf2] == or4c[:nf2]).all()
+
+
+def test_unsupported_and_bad_args(eng):
+    with pytest.raises(pk.KBestError):
+        eng.kbest(np.zeros((1, 65 * 65)), 65, 65, 2)        # beyond KBEST_MAX_DIM: loud, no fallback
+    with pytest.raises(pk.KBestError):
+        eng.kbest(np.zeros((1, 6)), 2, 3, 2)                # numRow < numCol
+
+
+def test_subtree_sharding_merges_to_global_kbest(eng):
+    """Multi-GPU latency mode: rank g expands only root children on columns c % G == g; the k
+    smallest of {root} U per-rank lists equal the single-GPU k-best."""
+    costs, N, M, k = wl.dense_config("c3", B=3)
+    nf, r4c, c4r, g = eng.kbest(costs, N, M, k)
+    for G in (2, 4):
+        parts = [eng.kbest(costs, N, M, k, root_shard=(r, G)) for r in range(G)]
+        for b in range(costs.shape[0]):
+            cand = [(g[b, 0], tuple(r4c[b, 0]))]
+            for pnf, pr4c, pc4r, pg in parts:
+                cand += [(pg[b, s], tuple(pr4c[b, s])) for s in range(1, pnf[b])]
+            cand.sort(key=lambda t: t[0])
+            assert [c[0] for c in cand[:k]] == g[b].tolist()
+            assert [c[1] for c in cand[:k]] == [tuple(x) for x in r4c[b]]
