@@ -112,7 +112,11 @@ def main():
 
     eng = pk.KBestEngine(local)
     eng.reserve(B, N, k)
-    stream = torch.cuda.current_stream().cuda_stream
+    # a dedicated (non-null) HIP stream: the kernel, the timing events and the collective all go through it
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    assert stream != 0
 
     # untimed: the reference's push count P per matrix (no-prune mode), for the algorithmic byte count
     eng.kbest_dev(d_cost, B, N, M, k, d_r4c, d_c4r, d_gain, d_nf, d_pushed=d_pushed, prune=False, stream=stream)

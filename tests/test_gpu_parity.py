@@ -142,9 +142,9 @@ def test_full_size_properties(eng, name):
     for c in range(M):
         acc = acc + shifted[np.arange(B)[:, None], c * N + r4c[:, :, c]]
     assert (bits(acc + (cd * M)[:, None]) == bits(g)).all()
-    # solutions of one problem are pairwise distinct (hash rows)
-    h = (r4c.astype(np.int64) * (np.arange(M, dtype=np.int64) * 2654435761 % (1 << 31) + 1)).sum(axis=2)
-    assert all(len(set(h[b].tolist())) == k for b in range(0, B, max(1, B // 64)))
+    # solutions of one problem are pairwise distinct
+    for b in range(0, B, max(1, B // 64)):
+        assert len({tuple(x) for x in r4c[b].tolist()}) == k
     for b in (0, B - 1):
         onf, or4c, oc4r, og = ol.orc_kbest(costs[b], N, M, k)
         assert (r4c[b] == or4c).all() and (bits(g[b]) == bits(og)).all()
