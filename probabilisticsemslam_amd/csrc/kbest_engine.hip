@@ -62,7 +62,8 @@ __device__ __forceinline__ double readlane_f64(double x, int l)
     return __hiloint2double(hi, lo);
 }
 
-// min over the 64 lanes, returned wave-uniform.  All lanes must be active.
+// fp64 min over the 64 lanes, returned wave-uniform (set-up code only; the hot
+// loop uses the integer-key form below).  All lanes must be active.
 __device__ __forceinline__ double wave_min_f64(double x)
 {
     x = min_keep(x, dpp_f64<0xB1, 0xF>(x));   // quad_perm [1,0,3,2]
@@ -72,6 +73,68 @@ __device__ __forceinline__ double wave_min_f64(double x)
     x = min_keep(x, dpp_f64<0x142, 0xA>(x));  // row_bcast:15 -> rows 1,3
     x = min_keep(x, dpp_f64<0x143, 0xC>(x));  // row_bcast:31 -> rows 2,3
     return readlane_f64(x, 63);
+}
+
+// Order-preserving integer key of a double: (khi as int32, klo as uint32)
+// compared lexicographically == IEEE '<' on the doubles (no NaNs; -0.0 cannot
+// occur in a reduced cost).  Negative values (rounding can make a
+// tight arc's reduced cost -1e-17) have their magnitude bits flipped.
+__device__ __forceinline__ void to_key(double x, int &khi, u32 &klo)
+{
+    const int hi = __double2hiint(x), lo = __double2loint(x);
+    const int s = hi >> 31;
+    khi = hi ^ (int)((u32)s >> 1);
+    klo = (u32)(lo ^ s);
+}
+__device__ __forceinline__ double from_key(int khi, u32 klo)  // same involution
+{
+    const int s = khi >> 31;
+    return __hiloint2double(khi ^ (int)((u32)s >> 1), (int)klo ^ s);
+}
+constexpr int KEY_INF_HI = 0x7ff00000;  // key of +inf is (0x7ff00000, 0)
+
+// One VOP2+DPP instruction per butterfly stage; `s_nop 1` covers the two wait
+// states a DPP read needs after a VALU write of the same VGPR (the assembler
+// does not pad inline asm).  The result lands in lane 63 and is read into an
+// SGPR.  EXEC must be all ones.
+#define KB_DPP_MIN_CHAIN(OP)                                                             \
+    "s_nop 1\n\t" OP " %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"     \
+    "s_nop 1\n\t" OP " %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"     \
+    "s_nop 1\n\t" OP " %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"         \
+    "s_nop 1\n\t" OP " %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"              \
+    "s_nop 1\n\t" OP " %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"            \
+    "s_nop 1\n\t" OP " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"            \
+    "s_nop 1\n\t" "v_readlane_b32 %0, %1, 63\n\t"
+
+__device__ __forceinline__ int wave_min_i32(int x)
+{
+    int r;
+    asm volatile(KB_DPP_MIN_CHAIN("v_min_i32_dpp") : "=s"(r), "+v"(x));
+    return r;
+}
+__device__ __forceinline__ u32 wave_min_u32(u32 x)
+{
+    u32 r;
+    asm volatile(KB_DPP_MIN_CHAIN("v_min_u32_dpp") : "=s"(r), "+v"(x));
+    return r;
+}
+
+// force a wave-uniform 64-bit value into SGPRs (values loaded from LDS live in VGPRs)
+__device__ __forceinline__ u64 uni64(u64 x)
+{
+    const u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)x);
+    const u32 hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(x >> 32));
+    return ((u64)hi << 32) | lo;
+}
+
+__device__ __forceinline__ int uni32(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// per-lane select driven directly by a 64-bit scalar lane mask
+__device__ __forceinline__ int sel32(u64 mask, int ifset, int ifclear)
+{
+    int r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(ifclear), "v"(ifset), "s"(mask));
+    return r;
 }
 
 __device__ __forceinline__ u64 bit64(int i) { return 1ull << (i & 63); }
@@ -84,50 +147,77 @@ __device__ __forceinline__ u64 bit64(int i) { return 1ull << (i & 63); }
 //   forb    rows skipped while the start column itself is scanned (cpp:310)
 //   c4r     this lane's row -> column, -1 = unassigned (a sink)
 //   u       LDS array, duals per column; v this lane's row dual
+// shortestPathCost[row] is held per lane as an order-preserving integer key
+// (to_key): the strict '<' update (cpp:185, 314) is one 64-bit integer compare
+// and the arg-min (cpp:191-194, 320-323: first minimum in ascending row order)
+// is two 6-stage DPP min chains (high word, then low word among the lanes that
+// tie on the high word) + ballot + ff1.  A scanned row's key is overwritten
+// with +inf so it never wins again; when FULL, its distance is kept in dv for
+// the dual update (a scanned row's shortestPathCost never changes afterwards).
 // Returns 0 = path found, 1 = infeasible (cpp:197, 327), 2 = abandoned because
-// base + delta already exceeds bound (only when EARLY).
-template <bool EARLY>
+// delta exceeds the bound key (only when EARLY).
+template <bool EARLY, bool FULL>
 __device__ __forceinline__ int dijkstra(const double *Cs, int LDC, const double *u, int rl, int lane,
-                                        double v, int c4r, u64 cand, u64 forb, int start,
-                                        double base, double bound, double &spc, int &pred,
-                                        u64 &scannedOut, double &deltaOut, int &sinkOut)
+                                        double v, int c4r, u64 cand, u64 forb, int start, int bndHi,
+                                        u32 bndLo, int &pred, double &dv, u64 &scannedOut,
+                                        double &deltaOut, int &sinkOut)
 {
-    const double INF = d_inf();
-    const u64 mybit = 1ull << lane;
-    u64 scanned = 0, act = cand & ~forb;
-    int cur = start;
+    int khi = KEY_INF_HI;
+    u32 klo = 0;
+    int dvlo = 0, dvhi = 0;
+    cand = uni64(cand);
+    u64 scanned = 0, act = cand & ~uni64(forb);
+    int cur = uni32(start);
+    bndHi = uni32(bndHi);
+    bndLo = (u32)uni32((int)bndLo);
     double delta = 0.0;
-    spc = INF;
     pred = 0;
     for (int it = 0;; it++) {
         if (it > 64) return 1;  // cannot happen (one row leaves `cand` per step); keeps a bug from hanging the GPU
         const double cval = Cs[rl + cur * LDC];
         const double ucur = u[cur];
         const double rc = ((delta + cval) - ucur) - v;  // cpp:183 / cpp:313, left to right
-        const bool in = (act & mybit) != 0;
-        if (in && rc < spc) { spc = rc; pred = cur; }   // strict '<': cpp:185, 314
-        const double key = in ? spc : INF;
-        const double m = wave_min_f64(key);
-        if (m == INF) return 1;
-        if (EARLY && (base + m > bound)) return 2;
-        const u64 eq = __ballot(key == m);
+        int nhi;
+        u32 nlo;
+        to_key(rc, nhi, nlo);
+        const long long nk = (long long)(((u64)(u32)nhi << 32) | nlo);
+        const long long ok = (long long)(((u64)(u32)khi << 32) | klo);
+        const u64 upd = __ballot(nk < ok) & act;        // strict '<': cpp:185, 314
+        khi = sel32(upd, nhi, khi);
+        klo = (u32)sel32(upd, (int)nlo, (int)klo);
+        pred = sel32(upd, cur, pred);
+        const int mhi = wave_min_i32(khi);
+        const u64 m1 = __ballot(khi == mhi);
+        const u32 t = (u32)sel32(m1, (int)klo, -1);
+        const u32 mlo = wave_min_u32(t);
+        if (mhi >= KEY_INF_HI) return 1;                 // minimum is +inf: infeasible
+        if (EARLY && (mhi > bndHi || (mhi == bndHi && mlo > bndLo))) return 2;
+        const u64 eq = __ballot(t == mlo) & m1;
         const int closest = __ffsll((long long)eq) - 1;  // lowest row index: cpp:191, 320
         const u64 cbit = 1ull << closest;
         scanned |= cbit;
         cand &= ~cbit;
-        delta = m;
+        delta = from_key(mhi, mlo);
+        khi = sel32(cbit, KEY_INF_HI, khi);   // retire the row (gfx9 v_writelane cannot take two SGPRs)
+        klo = (u32)sel32(cbit, 0, (int)klo);
+        if (FULL) {
+            dvlo = sel32(cbit, __double2loint(delta), dvlo);
+            dvhi = sel32(cbit, __double2hiint(delta), dvhi);
+        }
         const int cc = __builtin_amdgcn_readlane(c4r, closest);
         if (cc < 0) { sinkOut = closest; break; }
         cur = cc;
         act = cand;
     }
+    dv = __hiloint2double(dvhi, dvlo);
     scannedOut = scanned;
     deltaOut = delta;
     return 0;
 }
 
 // updateDualAndAugment (cpp:82-117), lane = row for v / c4r and lane = column
-// for r4c; u lives in LDS.
+// for r4c; u lives in LDS.  spc = this row's shortestPathCost (valid for
+// scanned rows).
 __device__ __forceinline__ void dual_update_flip(double *u, int lane, double &v, int &c4r, int &r4c,
                                                  double spc, int pred, u64 scanned, double delta,
                                                  int sink, int start)
@@ -244,6 +334,10 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
                 if (c < M) {
                     const double x = Cg[r + (long long)c * N];
                     val = maximize ? (-x + cdel) : (x - cdel);  // cpp:558 / cpp:564
+                    // inf - inf (e.g. an all-inf matrix) gives NaN; every comparison the reference makes with
+                    // a NaN reduced cost is false (cpp:185, 314), i.e. the arc behaves exactly like +inf.  The
+                    // integer-key compare below needs that made explicit.
+                    if (val != val) val = INF;
                     if (val < INF && val > cm) cm = val;
                 }
                 Cs[r + c * LDC] = val;
@@ -301,8 +395,8 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
         u64 scanned;
         bool bad = false;
         for (int c = 0; c < D; c++) {
-            if (dijkstra<false>(Cs, LDC, pu, rl, lane, v, c4r, allRows, 0ull, c, 0.0, INF, spc, pred, scanned,
-                                delta, sink)) { bad = true; break; }
+            if (dijkstra<false, true>(Cs, LDC, pu, rl, lane, v, c4r, allRows, 0ull, c, KEY_INF_HI, 0u, pred, spc,
+                                      scanned, delta, sink)) { bad = true; break; }
             dual_update_flip(pu, lane, v, c4r, r4c, spc, pred, scanned, delta, sink, c);
         }
         if (bad) {
@@ -319,7 +413,7 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
         }
     }
     __syncthreads();
-    if (ctrl->stop) {  // infeasible: kBest2D returns 0 (cpp:588-593)
+    if (uni32(ctrl->stop)) {  // infeasible: kBest2D returns 0 (cpp:588-593)
         if (tid == 0) { p.nf[b] = 0; if (p.pushed) p.pushed[b] = 0; }
         return;
     }
@@ -328,19 +422,24 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
     int nf = k;
     for (int s = 0;; s++) {
         if (s + 1 >= k) break;
-        const int a = ctrl->activeCol;
+        // control values come out of LDS in VGPRs: make them provably wave-uniform so that every loop below
+        // is a scalar-controlled loop
+        const int a = uni32(ctrl->activeCol);
         const int nch = M - a;
         const int R = k - (s + 1);  // candidates that can still be output
-        const int src = ctrl->cur, nqOld = ctrl->nq, head = ctrl->head;
+        const int src = uni32(ctrl->cur), nqOld = uni32(ctrl->nq), head = uni32(ctrl->head);
         const int nOld = nqOld - head;
         const double pgain = ctrl->gain;
         const double cutG = ctrl->cutoffGain;
-        const u64 pforb = ctrl->forb;
-        double bound = INF;
+        const u64 pforb = uni64(ctrl->forb);
+        // early-termination bound on a child's Dijkstra distance: child gain = parent gain + delta (up to
+        // rounding), so delta > (T - parent gain) + margin can never enter the k best.  Kept as an integer key.
+        int bndHi = KEY_INF_HI;
+        u32 bndLo = 0;
         if (prune) {
             double T = (nOld >= R) ? PG[src][head + R - 1] : INF;
             if (useCut && !maximize && cutG < T) T = cutG;
-            if (T < INF) bound = T + 1e-9 * (fabs(T) + ctrl->cmax);
+            if (T < INF) to_key((T - pgain) + 1e-9 * (fabs(T) + ctrl->cmax), bndHi, bndLo);
         }
         // -- children of the parent, one wave each (shortestPathUpdateCPP, gain only)
         {
@@ -360,8 +459,8 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
                     double spc, delta;
                     int pred, sink = 0;
                     u64 scanned;
-                    const int st = dijkstra<true>(Cs, LDC, pu, rl, lane, v, c4r, cand, forbm, c, pgain, bound, spc,
-                                                  pred, scanned, delta, sink);
+                    const int st = dijkstra<true, false>(Cs, LDC, pu, rl, lane, v, c4r, cand, forbm, c, bndHi, bndLo,
+                                                         pred, spc, scanned, delta, sink);
                     if (st == 0) {
                         int r4c = (lane == c) ? -1 : r4cP;
                         int r = sink, cc, guard = 0;
@@ -385,6 +484,7 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
         const int dst = src ^ 1;
         int nValid = 0;
         for (int j = 0; j < nch; j++) nValid += (childGain[j] < INF) ? 1 : 0;
+        nValid = uni32(nValid);
         for (int i = tid; i < nOld; i += NT) {
             const double g = PG[src][head + i];
             int pos = i;
@@ -413,7 +513,7 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
         if (nq == 0) { nf = s + 1; break; }  // queue empty: cpp:631-633
         // -- pop the best candidate and re-solve it in full from its parent's state
         if (wave == 0) {
-            const u32 meta = PM[dst][0];
+            const u32 meta = (u32)uni32((int)PM[dst][0]);
             const int par = (int)(meta >> 8), col = (int)(meta & 255u);
             const unsigned char *st = stBase + (long long)par * p.stateStride;
             const double *su = reinterpret_cast<const double *>(st);
@@ -425,8 +525,8 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
                 r4c = st[16 * p.maxRow + lane];
                 c4r = st[17 * p.maxRow + lane];
             }
-            const u64 forbP = *reinterpret_cast<const u64 *>(st + offTail);
-            const int aP = *reinterpret_cast<const int *>(st + offTail + 16);
+            const u64 forbP = uni64(*reinterpret_cast<const u64 *>(st + offTail));
+            const int aP = uni32(*reinterpret_cast<const int *>(st + offTail + 16));
             const int fr = __builtin_amdgcn_readlane(r4c, col);
             const u64 cand = __ballot(lane < D && c4r >= col);
             const u64 forbm = (col == aP) ? forbP : bit64(fr);
@@ -435,8 +535,8 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
             double spc, delta;
             int pred, sink = 0;
             u64 scanned;
-            const int rc = dijkstra<false>(Cs, LDC, pu, rl, lane, v, c4r, cand, forbm, col, 0.0, INF, spc, pred,
-                                           scanned, delta, sink);
+            const int rc = dijkstra<false, true>(Cs, LDC, pu, rl, lane, v, c4r, cand, forbm, col, KEY_INF_HI, 0u, pred,
+                                                 spc, scanned, delta, sink);
             if (rc == 0) dual_update_flip(pu, lane, v, c4r, r4c, spc, pred, scanned, delta, sink, col);
             const double g = serial_gain(Cs, LDC, lane, r4c, 0, M, 0.0, prefix);
             const u64 forbN = forbm | bit64(__builtin_amdgcn_readlane(r4c, col));  // cpp:362
@@ -454,7 +554,8 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
             }
         }
         __syncthreads();
-        if (ctrl->stop) { nf = (ctrl->stop == 2) ? -3 : s + 1; break; }
+        const int stop = uni32(ctrl->stop);
+        if (stop) { nf = (stop == 2) ? -3 : s + 1; break; }
     }
     if (tid == 0) {
         p.nf[b] = nf;
