@@ -19,7 +19,9 @@ struct kbest_ctx {
     unsigned char *states = nullptr;  // hypothesis-state workspace
     size_t statesBytes = 0;
     int ldsLimit = 65536;
-    int nWaves = 4;
+    int nWaves = 8;   // waves per cost matrix (workgroup = nWaves * 64 threads)
+    int spec = 4;     // candidates re-solved / split per round
+    int extraStates = 64;  // state slots beyond k per matrix (room for speculative splits)
     std::string err;
     std::mutex mu;  // shim entry points may be called from several host threads
 };
@@ -101,10 +103,15 @@ int kbest_create(kbest_ctx **out, int device)
     int lds = 0;
     if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds > 0)
         ctx->ldsLimit = lds;
-    if (const char *e = getenv("KBEST_NWAVES")) {
+    if (const char *e = getenv("KBEST_NWAVES")) {  // tuning knobs (defaults are the tuned values)
         int w = atoi(e);
-        if (w == 1 || w == 2 || w == 4 || w == 8) ctx->nWaves = w;
+        if (w == 4 || w == 8 || w == 16) ctx->nWaves = w;
     }
+    if (const char *e = getenv("KBEST_SPEC")) {
+        int w = atoi(e);
+        if (w >= 1 && w <= 16) ctx->spec = w;
+    }
+    if (ctx->spec > ctx->nWaves) ctx->spec = ctx->nWaves;
     *out = ctx;
     return KBEST_OK;
 }
@@ -122,7 +129,7 @@ int kbest_destroy(kbest_ctx *ctx)
 int kbest_reserve(kbest_ctx *ctx, int B, int maxRow, int k)
 {
     if (!ctx || B < 0 || maxRow < 1 || k < 1) return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_reserve: bad argument");
-    const size_t need = (size_t)B * (size_t)k * (size_t)kb::state_stride(maxRow);
+    const size_t need = (size_t)B * (size_t)(k + ctx->extraStates) * (size_t)kb::state_stride(maxRow);
     if (need <= ctx->statesBytes) return KBEST_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->states) { HIP_TRY(ctx, hipDeviceSynchronize()); (void)hipFree(ctx->states); ctx->states = nullptr; ctx->statesBytes = 0; }
@@ -143,8 +150,10 @@ int kbest_batch_f64_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRo
     if ((d_nRow == nullptr) != (d_nCol == nullptr))
         return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_batch_f64_dev: give both nRow and nCol or neither");
     if (maxRow > KBEST_MAX_DIM) return fail(ctx, KBEST_ERR_UNSUPPORTED, "numRow > KBEST_MAX_DIM");
-    if (k > (1 << 23)) return fail(ctx, KBEST_ERR_UNSUPPORTED, "k too large");
-    const kb::Lds L = kb::lds_layout(maxRow, k);
+    if (k + ctx->extraStates > 65535) return fail(ctx, KBEST_ERR_UNSUPPORTED, "k too large");
+    // counting the reference's pushes needs the reference's exact order of splits: no speculation
+    const int spec = (opts->flags & KBEST_FLAG_COUNT_PUSHED) ? 1 : ctx->spec;
+    const kb::Lds L = kb::lds_layout(maxRow, k, spec);
     if (L.total > ctx->ldsLimit) return fail(ctx, KBEST_ERR_UNSUPPORTED, "k too large for the LDS candidate pool");
     if (B == 0) return KBEST_OK;
     std::lock_guard<std::mutex> lock(ctx->mu);
@@ -173,6 +182,8 @@ int kbest_batch_f64_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRo
     p.pushed = reinterpret_cast<long long *>(d_pushed);
     p.states = ctx->states;
     p.stateStride = kb::state_stride(maxRow);
+    p.statesPerProblem = k + ctx->extraStates;
+    p.spec = spec;
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
     hipError_t e = kb::launch_kbest(p, B, ctx->nWaves, s);
     if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "kbest kernel launch", e);

@@ -32,8 +32,10 @@ struct Params {
     double *gain;             // [B][k]
     int *nf;                  // [B]
     long long *pushed;        // [B] or nullptr
-    unsigned char *states;    // workspace: [B][k] saved hypotheses, stateStride bytes each
+    unsigned char *states;    // workspace: [B][statesPerProblem] saved hypotheses, stateStride bytes each
     long long stateStride;
+    int statesPerProblem;     // >= k; the surplus bounds how far candidates are split speculatively
+    int spec;                 // candidates re-solved / split per round (1 = the reference's order exactly)
 };
 
 struct WeightParams {
@@ -52,33 +54,33 @@ struct WeightParams {
 // forbidden-row mask, gain, activeCol.
 __host__ __device__ inline long long state_stride(int maxRow)
 {
-    return (((long long)18 * maxRow + 7) & ~7LL) + 24;
+    // rounded to whole 128-byte lines: neighbouring states never share a cache line
+    return ((((long long)18 * maxRow + 7) & ~7LL) + 24 + 127) & ~127LL;
 }
 
 // LDS carve-up of one workgroup (= one cost matrix).
 struct Lds {
-    int offC, offU, offV, offPrefix, offChildGain, offPoolG[2], offPoolM[2], offR4C, offC4R, offCtrl, total;
+    int offC, offNodes, nodeStride, offFreshG, offFreshM, offPoolG[2], offPoolM[2], offPoolS[2], offSlotSid, offRed,
+        offCtrl, total;
 };
 
-__host__ __device__ inline Lds lds_layout(int maxRow, int k)
+__host__ __device__ inline Lds lds_layout(int maxRow, int k, int spec)
 {
     Lds L;
     const int ldc = maxRow | 1;
     int o = 0;
-    L.offC = o;          o += maxRow * ldc * 8;  // shifted, zero-padded cost tile
-    L.offU = o;          o += maxRow * 8;        // parent duals per column
-    L.offV = o;          o += maxRow * 8;        // parent duals per row
-    L.offPrefix = o;     o += maxRow * 8;        // parent's serial gain prefix sums
-    L.offChildGain = o;  o += 64 * 8;            // gains of this sweep's children
-    L.offPoolG[0] = o;   o += k * 8;             // candidate pool, ping
-    L.offPoolG[1] = o;   o += k * 8;             //                 pong
-    L.offPoolM[0] = o;   o += k * 4;
-    L.offPoolM[1] = o;   o += k * 4;
+    L.offC = o;          o += maxRow * ldc * 8;      // shifted, zero-padded cost tile
+    L.nodeStride = 32 * maxRow + 32;                 // u, v, prefix (fp64), row4col, col4row (int), scalars
+    L.offNodes = o;      o += spec * L.nodeStride;   // solved hypotheses waiting to be split
+    L.offFreshG = o;     o += spec * 64 * 8;         // surviving children of this round: gain
+    for (int i = 0; i < 2; i++) { L.offPoolG[i] = o; o += k * 8; }  // sorted candidate pool (ping-pong): gain
+    L.offRed = o;        o += 16 * 8;                // cross-wave reduction scratch
+    L.offFreshM = o;     o += spec * 64 * 4;         //   (parent state, column)
+    for (int i = 0; i < 2; i++) { L.offPoolM[i] = o; o += k * 4; }  //   (parent state, column)
+    for (int i = 0; i < 2; i++) { L.offPoolS[i] = o; o += k * 4; }  //   own state slot / flags
+    L.offSlotSid = o;    o += k * 2;                 // state slot of each emitted output slot
     o = (o + 7) & ~7;
-    L.offR4C = o;        o += maxRow * 4;
-    L.offC4R = o;        o += maxRow * 4;
-    o = (o + 7) & ~7;
-    L.offCtrl = o;       o += 96;                // struct Ctrl
+    L.offCtrl = o;       o += 96;                    // struct Ctrl
     L.total = (o + 15) & ~15;
     return L;
 }

@@ -258,21 +258,71 @@ __device__ __forceinline__ double serial_gain(const double *Cs, int LDC, int lan
 }
 
 // ------------------------------------------------------------------ the kernel
+//
+// Batched-frontier form of Murty's loop (kBest2D cpp:607-634 + split
+// cpp:455-532).  Per round:
+//   B  all children of all freshly solved nodes are solved for their gain by
+//      all waves (dynamic work queue), with early termination; survivors are
+//      appended to the fresh list;
+//   C  the fresh list is merged by rank into the sorted pool, which is cut to
+//      the (k - emitted) candidates that can still be output;
+//   A  the first `spec` not-yet-solved candidates of the pool are re-solved IN
+//      PARALLEL, one wave each, from their parents' saved states (exactly the
+//      reference's shortestPathUpdateCPP on that (parent, column));
+//   D  the pool head is emitted while it is solved: a solved head is certain
+//      to be the next-best hypothesis once every hypothesis emitted before it
+//      has been split, so a head solved only in this round (not split yet) is
+//      emitted too but ends the run.
+// With spec = 1 this is the reference's order of operations exactly (pop the
+// minimum, split it, emit the new top).  With spec > 1 later candidates are
+// split speculatively; the pool always holds a partition of the not yet
+// emitted assignments, so the emitted sequence -- assignments in increasing
+// gain -- is unchanged (tie-free inputs).
 struct Ctrl {
-    double gain;        // shifted gain of the current parent
     double cdelta;      // CDelta * numCol (cpp:583)
     double cutoffGain;  // workMem.cutoffGain (cpp:681/684)
     double cmax;        // largest finite shifted cost (scale of the safety margin)
     double gain0u;      // gainBest[0]
-    u64 forb;           // parent's accumulated forbidden rows (forbiddenActiveRows)
-    int activeCol;
-    int nq;    // entries in the current pool buffer
-    int cur;   // current pool buffer
-    int head;  // 1 if entry 0 of the current buffer has been popped
-    int stop;
+    int nq;       // end of the valid pool range in the current buffer
+    int head;     // start of it (entries before head were emitted)
+    int cur;      // current pool buffer
+    int emitted;  // output slots filled so far
+    int stop;     // 1: finished   2: internal error   3: infeasible root
     int pushed;
+    int nsel;     // nodes solved this round = nodes to split next
+    int nextItem; // work queue of phase B
+    int nextSid;  // next free hypothesis-state slot
+    int nFresh;   // surviving children appended this round
 };
 static_assert(sizeof(Ctrl) <= 96, "Ctrl must fit the LDS slot reserved by lds_layout");
+
+constexpr u32 SID_NONE = 0xFFFFFFFFu;   // pool entry not solved yet
+constexpr u32 SID_SPLIT = 0x80000000u;  // flag: solved AND children already merged
+constexpr u32 SID_FRESH = 0x40000000u;  // flag: solved in the current round (children not generated yet)
+constexpr u32 SID_MASK = 0x3FFFFFFFu;
+
+// a solved hypothesis waiting to be split, in LDS
+struct NodeRef {
+    double *u, *v, *prefix;
+    int *r4c, *c4r;
+    double *gain;  // [0] shifted gain
+    u64 *forb;
+    int *info;     // [0] activeCol, [1] sid
+};
+
+__device__ __forceinline__ NodeRef node_ref(unsigned char *base, int maxRow)
+{
+    NodeRef n;
+    n.u = reinterpret_cast<double *>(base);
+    n.v = n.u + maxRow;
+    n.prefix = n.v + maxRow;
+    n.r4c = reinterpret_cast<int *>(n.prefix + maxRow);
+    n.c4r = n.r4c + maxRow;
+    n.gain = reinterpret_cast<double *>(n.c4r + maxRow);
+    n.forb = reinterpret_cast<u64 *>(n.gain + 1);
+    n.info = reinterpret_cast<int *>(n.forb + 1);
+    return n;
+}
 
 template <int NW>
 __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
@@ -292,17 +342,17 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
         return;
     }
     const int D = N, LDC = D | 1;
-    const Lds L = lds_layout(p.maxRow, k);
+    const int spec = p.spec < NW ? p.spec : NW;  // nodes solved / split per round
+    const Lds L = lds_layout(p.maxRow, k, p.spec);
     double *Cs = reinterpret_cast<double *>(smem + L.offC);
-    double *pu = reinterpret_cast<double *>(smem + L.offU);
-    double *pv = reinterpret_cast<double *>(smem + L.offV);
-    double *prefix = reinterpret_cast<double *>(smem + L.offPrefix);
-    double *childGain = reinterpret_cast<double *>(smem + L.offChildGain);
+    double *freshG = reinterpret_cast<double *>(smem + L.offFreshG);
+    u32 *freshM = reinterpret_cast<u32 *>(smem + L.offFreshM);
     double *PG[2] = {reinterpret_cast<double *>(smem + L.offPoolG[0]),
                      reinterpret_cast<double *>(smem + L.offPoolG[1])};
     u32 *PM[2] = {reinterpret_cast<u32 *>(smem + L.offPoolM[0]), reinterpret_cast<u32 *>(smem + L.offPoolM[1])};
-    int *pr4c = reinterpret_cast<int *>(smem + L.offR4C);
-    int *pc4r = reinterpret_cast<int *>(smem + L.offC4R);
+    u32 *PS[2] = {reinterpret_cast<u32 *>(smem + L.offPoolS[0]), reinterpret_cast<u32 *>(smem + L.offPoolS[1])};
+    unsigned short *slotSid = reinterpret_cast<unsigned short *>(smem + L.offSlotSid);
+    double *red = reinterpret_cast<double *>(smem + L.offRed);
     Ctrl *ctrl = reinterpret_cast<Ctrl *>(smem + L.offCtrl);
 
     const double *Cg = p.cost + (p.costOff ? p.costOff[b] : (long long)b * p.maxRow * p.maxCol);
@@ -310,6 +360,7 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
     const bool prune = (p.flags & KBEST_FLAG_NO_PRUNE) == 0;
     const int rl = lane < D ? lane : D - 1;
     const u64 allRows = (D >= 64) ? ~0ull : ((1ull << D) - 1ull);
+    const int maxSid = p.statesPerProblem;
 
     // ---- phase 0: makeCostMatrixSafe + zero padding (cpp:534-569, 582-585) --
     {
@@ -321,10 +372,10 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
                 mn = min_keep(mn, x);
             }
         mn = wave_min_f64(mn);
-        if (lane == 0) childGain[wave] = mn;
+        if (lane == 0) red[wave] = mn;
         __syncthreads();
-        mn = childGain[0];
-        for (int w = 1; w < NW; w++) mn = min_keep(mn, childGain[w]);
+        mn = red[0];
+        for (int w = 1; w < NW; w++) mn = min_keep(mn, red[w]);
         const double cdel = maximize ? -mn : mn;
         __syncthreads();
         double cm = 0.0;
@@ -336,191 +387,278 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
                     val = maximize ? (-x + cdel) : (x - cdel);  // cpp:558 / cpp:564
                     // inf - inf (e.g. an all-inf matrix) gives NaN; every comparison the reference makes with
                     // a NaN reduced cost is false (cpp:185, 314), i.e. the arc behaves exactly like +inf.  The
-                    // integer-key compare below needs that made explicit.
+                    // integer-key compare of the Dijkstra step needs that made explicit.
                     if (val != val) val = INF;
                     if (val < INF && val > cm) cm = val;
                 }
                 Cs[r + c * LDC] = val;
             }
         cm = -wave_min_f64(-cm);
-        if (lane == 0) childGain[wave] = cm;
+        if (lane == 0) red[wave] = cm;
         __syncthreads();
         if (tid == 0) {
-            for (int w = 1; w < NW; w++) cm = childGain[w] > cm ? childGain[w] : cm;
+            for (int w = 1; w < NW; w++) cm = red[w] > cm ? red[w] : cm;
             ctrl->cmax = cm;
             ctrl->cdelta = cdel * (double)M;  // cpp:583
             ctrl->stop = 0;
             ctrl->pushed = 0;
             ctrl->nq = 0;
-            ctrl->cur = 0;
             ctrl->head = 0;
+            ctrl->cur = 0;
+            ctrl->emitted = 0;
+            ctrl->nsel = 0;
+            ctrl->nextItem = 0;
+            ctrl->nextSid = 1;
+            ctrl->nFresh = 0;
         }
         __syncthreads();
     }
 
-    unsigned char *stBase = p.states + (long long)b * k * p.stateStride;
+    unsigned char *stBase = p.states + (long long)b * maxSid * p.stateStride;
     const int offTail = (18 * p.maxRow + 7) & ~7;
+    const long long outBase = (long long)b * k;
 
-    // save the hypothesis held by wave 0 (u in LDS) as state `slot`, and emit it
-    auto save_and_emit = [&](int slot, double v, int r4c, int c4r, u64 forb, double gain, int activeCol) {
-        unsigned char *st = stBase + (long long)slot * p.stateStride;
+    // Store the hypothesis this wave holds (u already in nd.u) as state `sid` and publish it as node nd.
+    auto save_node = [&](const NodeRef &nd, int sid, double v, int r4c, int c4r, u64 forb, double gain, int activeCol) {
+        unsigned char *st = stBase + (long long)sid * p.stateStride;
         double *su = reinterpret_cast<double *>(st);
         if (lane < D) {
-            su[lane] = pu[lane];
+            su[lane] = nd.u[lane];
             su[p.maxRow + lane] = v;
             st[16 * p.maxRow + lane] = (unsigned char)r4c;
             st[17 * p.maxRow + lane] = (unsigned char)c4r;
+            nd.v[lane] = v;
+            nd.r4c[lane] = r4c;
+            nd.c4r[lane] = c4r;
         }
         if (lane == 0) {
             *reinterpret_cast<u64 *>(st + offTail) = forb;
             *reinterpret_cast<double *>(st + offTail + 8) = gain;
             *reinterpret_cast<int *>(st + offTail + 16) = activeCol;
+            nd.gain[0] = gain;
+            nd.forb[0] = forb;
+            nd.info[0] = activeCol;
+            nd.info[1] = sid;
         }
-        const long long o = (long long)b * k + slot;
-        if (lane < M) p.row4col[o * p.maxCol + lane] = r4c;
-        if (lane < N) p.col4row[o * p.maxRow + lane] = c4r;
-        if (lane == 0) p.gain[o] = maximize ? (-gain + ctrl->cdelta) : (gain + ctrl->cdelta);  // cpp:599-603
-    };
-    // publish the hypothesis held by wave 0 as the parent of the next split
-    auto publish_parent = [&](double v, int r4c, int c4r, u64 forb, double gain, int activeCol) {
-        if (lane < D) { pv[lane] = v; pr4c[lane] = r4c; pc4r[lane] = c4r; }
-        if (lane == 0) { ctrl->gain = gain; ctrl->forb = forb; ctrl->activeCol = activeCol; }
     };
 
-    // ---- phase 1: root LAP (shortestPathCPP, cpp:119-238) on wave 0 ----------
+    // ---- phase 1: root LAP (shortestPathCPP, cpp:119-238) on wave 0 -> node 0, state 0, slot 0 ----
     if (wave == 0) {
-        if (lane < D) pu[lane] = 0.0;
+        const NodeRef nd = node_ref(smem + L.offNodes, p.maxRow);
+        if (lane < D) nd.u[lane] = 0.0;
         double v = 0.0, spc, delta;
         int c4r = -1, r4c = -1, pred, sink = 0;
         u64 scanned;
         bool bad = false;
         for (int c = 0; c < D; c++) {
-            if (dijkstra<false, true>(Cs, LDC, pu, rl, lane, v, c4r, allRows, 0ull, c, KEY_INF_HI, 0u, pred, spc,
+            if (dijkstra<false, true>(Cs, LDC, nd.u, rl, lane, v, c4r, allRows, 0ull, c, KEY_INF_HI, 0u, pred, spc,
                                       scanned, delta, sink)) { bad = true; break; }
-            dual_update_flip(pu, lane, v, c4r, r4c, spc, pred, scanned, delta, sink, c);
+            dual_update_flip(nd.u, lane, v, c4r, r4c, spc, pred, scanned, delta, sink, c);
         }
         if (bad) {
-            if (lane == 0) ctrl->stop = 1;
+            if (lane == 0) ctrl->stop = 3;
         } else {
-            const double g = serial_gain(Cs, LDC, lane, r4c, 0, M, 0.0, prefix);
+            const double g = serial_gain(Cs, LDC, lane, r4c, 0, M, 0.0, nd.prefix);
             const u64 forb = bit64(__builtin_amdgcn_readlane(r4c, 0));  // cpp:235
-            publish_parent(v, r4c, c4r, forb, g, 0);
+            save_node(nd, 0, v, r4c, c4r, forb, g, 0);
             if (lane == 0) {
                 ctrl->cutoffGain = maximize ? (g - p.cutoff) : (g + p.cutoff);          // cpp:681/684
-                ctrl->gain0u = maximize ? (-g + ctrl->cdelta) : (g + ctrl->cdelta);
+                const double gu = maximize ? (-g + ctrl->cdelta) : (g + ctrl->cdelta);  // cpp:599-603
+                ctrl->gain0u = gu;
+                p.gain[outBase] = gu;
+                slotSid[0] = 0;
+                ctrl->emitted = 1;
+                ctrl->nsel = 1;
+                if (k == 1) ctrl->stop = 1;
             }
-            save_and_emit(0, v, r4c, c4r, forb, g, 0);
         }
     }
     __syncthreads();
-    if (uni32(ctrl->stop)) {  // infeasible: kBest2D returns 0 (cpp:588-593)
+    if (uni32(ctrl->stop) == 3) {  // infeasible: kBest2D returns 0 (cpp:588-593)
         if (tid == 0) { p.nf[b] = 0; if (p.pushed) p.pushed[b] = 0; }
         return;
     }
 
-    // ---- phase 2: Murty sweeps (kBest2D loop cpp:607-634, split cpp:455-532) --
-    int nf = k;
-    for (int s = 0;; s++) {
-        if (s + 1 >= k) break;
-        // control values come out of LDS in VGPRs: make them provably wave-uniform so that every loop below
-        // is a scalar-controlled loop
-        const int a = uni32(ctrl->activeCol);
-        const int nch = M - a;
-        const int R = k - (s + 1);  // candidates that can still be output
-        const int src = uni32(ctrl->cur), nqOld = uni32(ctrl->nq), head = uni32(ctrl->head);
-        const int nOld = nqOld - head;
-        const double pgain = ctrl->gain;
+    // ---- phase 2: rounds ----------------------------------------------------------------------------
+    while (uni32(ctrl->stop) == 0) {
+        // control values come out of LDS in VGPRs: readfirstlane makes them provably wave-uniform, so every
+        // loop below is scalar-controlled.  They are only rewritten in D, behind a barrier.
+        const int nsel = uni32(ctrl->nsel);
+        const int emitted = uni32(ctrl->emitted);
+        const int R = k - emitted;  // candidates that can still be output
+        const int src = uni32(ctrl->cur), nqEnd = uni32(ctrl->nq), head = uni32(ctrl->head);
+        const int nOld = nqEnd - head;
+        const int sidBase = uni32(ctrl->nextSid);
         const double cutG = ctrl->cutoffGain;
-        const u64 pforb = uni64(ctrl->forb);
-        // early-termination bound on a child's Dijkstra distance: child gain = parent gain + delta (up to
-        // rounding), so delta > (T - parent gain) + margin can never enter the k best.  Kept as an integer key.
-        int bndHi = KEY_INF_HI;
-        u32 bndLo = 0;
-        if (prune) {
+        // -- B: children of the nsel solved nodes (shortestPathUpdateCPP, gain only), dynamic queue.
+        //    Work item -> (node, column): node w owns the next (M - activeCol_w) items.
+        int totalItems = 0;
+        for (int w = 0; w < nsel; w++)
+            totalItems += M - uni32(node_ref(smem + L.offNodes + (size_t)w * L.nodeStride, p.maxRow).info[0]);
+        {
+            // threshold of the pool: once it holds R candidates only children below its largest can matter
             double T = (nOld >= R) ? PG[src][head + R - 1] : INF;
             if (useCut && !maximize && cutG < T) T = cutG;
-            if (T < INF) to_key((T - pgain) + 1e-9 * (fabs(T) + ctrl->cmax), bndHi, bndLo);
-        }
-        // -- children of the parent, one wave each (shortestPathUpdateCPP, gain only)
-        {
-            const double v = (lane < D) ? pv[lane] : 0.0;
-            const int c4rP = (lane < D) ? pc4r[lane] : -1;
-            const int r4cP = (lane < D) ? pr4c[lane] : -1;
             int npush = 0;
-            for (int ci = wave; ci < nch; ci += NW) {
-                const int c = a + ci;
-                double g = INF;
-                const bool skip = (s == 0 && p.rootColStride > 1 && (c % p.rootColStride) != p.rootColOffset);
-                if (!skip) {
-                    const int fr = __builtin_amdgcn_readlane(r4cP, c);       // row freed: cpp:277-278
-                    const u64 cand = __ballot(lane < D && c4rP >= c);         // rows of columns >= c: cpp:480-488, 525-527
-                    const u64 forbm = (c == a) ? pforb : bit64(fr);           // cpp:490 / cpp:510-516
-                    const int c4r = (lane == fr) ? -1 : c4rP;
-                    double spc, delta;
-                    int pred, sink = 0;
-                    u64 scanned;
-                    const int st = dijkstra<true, false>(Cs, LDC, pu, rl, lane, v, c4r, cand, forbm, c, bndHi, bndLo,
-                                                         pred, spc, scanned, delta, sink);
-                    if (st == 0) {
-                        int r4c = (lane == c) ? -1 : r4cP;
-                        int r = sink, cc, guard = 0;
-                        do {  // path flip, row4col side only (cpp:108-116)
-                            cc = __builtin_amdgcn_readlane(pred, r);
-                            const int nxt = __builtin_amdgcn_readlane(r4c, cc);
-                            r4c = (lane == cc) ? r : r4c;
-                            r = nxt;
-                        } while (cc != c && ++guard < 64);
-                        g = serial_gain(Cs, LDC, lane, r4c, c, M, prefix[c], nullptr);
-                        if (useCut && (maximize ? (g < cutG) : (g > cutG))) g = INF;  // cutHyp, cpp:496/521
-                        else npush++;
-                    }
+            for (;;) {
+                int item = 0;
+                if (lane == 0) item = atomicAdd(&ctrl->nextItem, 1);
+                item = uni32(item);
+                if (item >= totalItems) break;
+                int w = 0, first = 0;
+                for (;; w++) {  // locate the node of this item (nsel <= spec is small)
+                    const int nchw = M - uni32(node_ref(smem + L.offNodes + (size_t)w * L.nodeStride, p.maxRow).info[0]);
+                    if (item < first + nchw) break;
+                    first += nchw;
                 }
-                if (lane == 0) childGain[ci] = g;
+                const NodeRef nd = node_ref(smem + L.offNodes + (size_t)w * L.nodeStride, p.maxRow);
+                const int a = uni32(nd.info[0]);
+                const int sid = uni32(nd.info[1]);
+                const int c = a + (item - first);
+                if (sid == 0 && p.rootColStride > 1 && (c % p.rootColStride) != p.rootColOffset) continue;
+                const double pgain = nd.gain[0];
+                const double v = (lane < D) ? nd.v[lane] : 0.0;
+                const int c4rP = (lane < D) ? nd.c4r[lane] : -1;
+                const int r4cP = (lane < D) ? nd.r4c[lane] : -1;
+                // early-termination bound on the Dijkstra distance: child gain = parent gain + delta (up to
+                // rounding), so delta > (T - parent gain) + margin can never enter the k best.
+                int bndHi = KEY_INF_HI;
+                u32 bndLo = 0;
+                if (prune && T < INF) to_key((T - pgain) + 1e-9 * (fabs(T) + ctrl->cmax), bndHi, bndLo);
+                const int fr = __builtin_amdgcn_readlane(r4cP, c);           // row freed: cpp:277-278
+                const u64 cand = __ballot(lane < D && c4rP >= c);             // rows of columns >= c: cpp:480-488, 525-527
+                const u64 forbm = (c == a) ? uni64(nd.forb[0]) : bit64(fr);   // cpp:490 / cpp:510-516
+                const int c4r = (lane == fr) ? -1 : c4rP;
+                double spc, delta;
+                int pred, sink = 0;
+                u64 scanned;
+                const int st = dijkstra<true, false>(Cs, LDC, nd.u, rl, lane, v, c4r, cand, forbm, c, bndHi, bndLo,
+                                                     pred, spc, scanned, delta, sink);
+                if (st != 0) continue;
+                int r4c = (lane == c) ? -1 : r4cP;
+                int r = sink, cc, guard = 0;
+                do {  // path flip, row4col side only (cpp:108-116)
+                    cc = __builtin_amdgcn_readlane(pred, r);
+                    const int nxt = __builtin_amdgcn_readlane(r4c, cc);
+                    r4c = (lane == cc) ? r : r4c;
+                    r = nxt;
+                } while (cc != c && ++guard < 64);
+                const double g = serial_gain(Cs, LDC, lane, r4c, c, M, nd.prefix[c], nullptr);
+                if (useCut && (maximize ? (g < cutG) : (g > cutG))) continue;  // cutHyp, cpp:496/521
+                npush++;
+                if (lane == 0) {
+                    const int pos = atomicAdd(&ctrl->nFresh, 1);
+                    freshG[pos] = g;
+                    freshM[pos] = ((u32)sid << 8) | (u32)c;  // (parent state, column) of this candidate
+                }
             }
             if ((p.flags & KBEST_FLAG_COUNT_PUSHED) && lane == 0 && npush) atomicAdd(&ctrl->pushed, npush);
         }
         __syncthreads();
-        // -- merge the fresh candidates into the sorted pool, keep the R smallest
+        // -- C: rank-merge the fresh candidates into the sorted pool, keep the R smallest.  Ties in gain are
+        //    ordered by (parent, column), so the result does not depend on the arrival order of the fresh list.
         const int dst = src ^ 1;
-        int nValid = 0;
-        for (int j = 0; j < nch; j++) nValid += (childGain[j] < INF) ? 1 : 0;
-        nValid = uni32(nValid);
+        const int nFresh = uni32(ctrl->nFresh);
         for (int i = tid; i < nOld; i += NT) {
             const double g = PG[src][head + i];
             int pos = i;
-            for (int j = 0; j < nch; j++) pos += (childGain[j] < g) ? 1 : 0;
-            if (pos < R) { PG[dst][pos] = g; PM[dst][pos] = PM[src][head + i]; }
-        }
-        for (int j = tid; j < nch; j += NT) {
-            const double g = childGain[j];
-            if (g < INF) {
-                int lo = 0, hi = nOld;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (PG[src][head + mid] <= g) lo = mid + 1; else hi = mid;
-                }
-                int pos = lo;
-                for (int j2 = 0; j2 < nch; j2++) {
-                    const double g2 = childGain[j2];
-                    pos += (g2 < g || (g2 == g && j2 < j)) ? 1 : 0;
-                }
-                if (pos < R) { PG[dst][pos] = g; PM[dst][pos] = ((u32)s << 8) | (u32)(a + j); }
+            for (int j = 0; j < nFresh; j++) pos += (freshG[j] < g) ? 1 : 0;
+            if (pos < R) {
+                PG[dst][pos] = g;
+                PM[dst][pos] = PM[src][head + i];
+                const u32 sdv = PS[src][head + i];
+                PS[dst][pos] = (sdv == SID_NONE) ? SID_NONE : ((sdv & SID_MASK) | SID_SPLIT);  // every solved node was split in B
             }
         }
-        int nq = nOld + nValid;
+        for (int j = tid; j < nFresh; j += NT) {
+            const double g = freshG[j];
+            const u32 mj = freshM[j];
+            int lo = 0, hi = nOld;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (PG[src][head + mid] <= g) lo = mid + 1; else hi = mid;
+            }
+            int pos = lo;
+            for (int j2 = 0; j2 < nFresh; j2++) {
+                const double g2 = freshG[j2];
+                pos += (g2 < g || (g2 == g && freshM[j2] < mj)) ? 1 : 0;
+            }
+            if (pos < R) { PG[dst][pos] = g; PM[dst][pos] = mj; PS[dst][pos] = SID_NONE; }
+        }
+        int nq = nOld + nFresh;
         if (nq > R) nq = R;
         __syncthreads();
-        if (nq == 0) { nf = s + 1; break; }  // queue empty: cpp:631-633
-        // -- pop the best candidate and re-solve it in full from its parent's state
-        if (wave == 0) {
-            const u32 meta = (u32)uni32((int)PM[dst][0]);
+        // -- A + D: every wave finds the unsolved candidates itself (the pool is stable now); wave w solves the
+        //    w-th of them; lane 0 of wave 0 also does the emission bookkeeping, which depends only on the pool
+        //    order and flags.  State slots: keep one in hand for every output still to come.
+        int budget = (maxSid - k) + 1 - (sidBase - emitted);
+        if (budget > spec) budget = spec;
+        if (budget < 1) budget = 1;
+        int mySel = -1, nselNew = 0;
+        for (int base = 0; base < nq && nselNew < budget; base += 64) {
+            const int i = base + lane;
+            // (an entry already flagged FRESH belongs to a wave of this round that is ahead of us: same set)
+            const u32 sdv = (i < nq) ? PS[dst][i] : 0u;
+            u64 m = __ballot(i < nq && (sdv == SID_NONE || (sdv & SID_FRESH)));
+            while (m && nselNew < budget) {
+                const int bitpos = __ffsll((long long)m) - 1;
+                if (nselNew == wave) mySel = base + bitpos;
+                nselNew++;
+                m &= m - 1;
+            }
+        }
+        if (wave == 0 && lane == 0) {
+            int e = emitted, h = 0, stop = 0, selSeen = 0;
+            while (h < nq && e < k) {
+                const u32 sdv = PS[dst][h];
+                int sid;
+                bool fresh = false;
+                // a candidate selected in this round reads as SID_NONE or as (sid | SID_FRESH) depending on whether
+                // its wave has finished already: both mean "solved in this round"
+                if (sdv == SID_NONE || (sdv & SID_FRESH)) {
+                    if (selSeen >= nselNew) break;  // unsolved and not selected this round: wait
+                    sid = sidBase + selSeen;          // selection is in pool order
+                    selSeen++;
+                    fresh = true;
+                } else {
+                    sid = (int)(sdv & SID_MASK);
+                }
+                const double g = PG[dst][h];
+                const double gu = maximize ? (-g + ctrl->cdelta) : (g + ctrl->cdelta);  // cpp:626-630
+                p.gain[outBase + e] = gu;
+                slotSid[e] = (unsigned short)sid;
+                if (useCut && (maximize ? (gu < ctrl->gain0u - p.cutoff) : (gu > ctrl->gain0u + p.cutoff))) {
+                    stop = 1;  // cpp:709-719: slot written, not counted
+                    break;
+                }
+                e++;
+                h++;
+                if (fresh) break;  // its children are not in the pool yet
+            }
+            if (e >= k) stop = 1;
+            if (h >= nq && nselNew == 0) stop = 1;  // queue empty, nothing left to split: cpp:631-633
+            ctrl->emitted = e;
+            ctrl->nsel = nselNew;
+            ctrl->nextSid = sidBase + nselNew;
+            ctrl->nextItem = 0;
+            ctrl->nFresh = 0;
+            ctrl->cur = dst;
+            ctrl->nq = nq;
+            ctrl->head = h;
+            if (stop) ctrl->stop = 1;
+        }
+        if (wave < nselNew) {
+            // re-solve candidate mySel in full from its parent's saved state
+            const u32 meta = (u32)uni32((int)PM[dst][mySel]);
             const int par = (int)(meta >> 8), col = (int)(meta & 255u);
+            const int sid = sidBase + wave;
+            const NodeRef nd = node_ref(smem + L.offNodes + (size_t)wave * L.nodeStride, p.maxRow);
             const unsigned char *st = stBase + (long long)par * p.stateStride;
             const double *su = reinterpret_cast<const double *>(st);
             double v = 0.0;
             int r4c = -1, c4r = -1;
             if (lane < D) {
-                pu[lane] = su[lane];
+                nd.u[lane] = su[lane];
                 v = su[p.maxRow + lane];
                 r4c = st[16 * p.maxRow + lane];
                 c4r = st[17 * p.maxRow + lane];
@@ -535,27 +673,27 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
             double spc, delta;
             int pred, sink = 0;
             u64 scanned;
-            const int rc = dijkstra<false, true>(Cs, LDC, pu, rl, lane, v, c4r, cand, forbm, col, KEY_INF_HI, 0u, pred,
+            const int rc = dijkstra<false, true>(Cs, LDC, nd.u, rl, lane, v, c4r, cand, forbm, col, KEY_INF_HI, 0u, pred,
                                                  spc, scanned, delta, sink);
-            if (rc == 0) dual_update_flip(pu, lane, v, c4r, r4c, spc, pred, scanned, delta, sink, col);
-            const double g = serial_gain(Cs, LDC, lane, r4c, 0, M, 0.0, prefix);
+            if (rc == 0) dual_update_flip(nd.u, lane, v, c4r, r4c, spc, pred, scanned, delta, sink, col);
+            const double g = serial_gain(Cs, LDC, lane, r4c, 0, M, 0.0, nd.prefix);
             const u64 forbN = forbm | bit64(__builtin_amdgcn_readlane(r4c, col));  // cpp:362
-            publish_parent(v, r4c, c4r, forbN, g, col);
-            save_and_emit(s + 1, v, r4c, c4r, forbN, g, col);
+            save_node(nd, sid, v, r4c, c4r, forbN, g, col);
             if (lane == 0) {
-                ctrl->cur = dst;
-                ctrl->nq = nq;
-                ctrl->head = 1;
+                PS[dst][mySel] = (u32)sid | SID_FRESH;  // solved; the next merge turns FRESH into SPLIT
                 if (rc != 0) ctrl->stop = 2;  // cannot happen: the candidate was solved before
-                if (useCut) {                 // cpp:709-719
-                    const double gu = maximize ? (-g + ctrl->cdelta) : (g + ctrl->cdelta);
-                    if (maximize ? (gu < ctrl->gain0u - p.cutoff) : (gu > ctrl->gain0u + p.cutoff)) ctrl->stop = 1;
-                }
             }
         }
         __syncthreads();
-        const int stop = uni32(ctrl->stop);
-        if (stop) { nf = (stop == 2) ? -3 : s + 1; break; }
+    }
+    const int stopCode = uni32(ctrl->stop);
+    const int nf = (stopCode == 2) ? -3 : uni32(ctrl->emitted);
+    // ---- phase 3: outputs.  Slot s holds hypothesis slotSid[s]: widen its saved row4col / col4row --------
+    for (int idx = tid; idx < nf * (N + M); idx += NT) {
+        const int s = idx / (N + M), j = idx - s * (N + M);
+        const unsigned char *st = stBase + (long long)slotSid[s] * p.stateStride;
+        if (j < M) p.row4col[(outBase + s) * p.maxCol + j] = st[16 * p.maxRow + j];
+        else p.col4row[(outBase + s) * p.maxRow + (j - M)] = st[17 * p.maxRow + (j - M)];
     }
     if (tid == 0) {
         p.nf[b] = nf;
@@ -614,7 +752,7 @@ __global__ void __launch_bounds__(64) weights_kernel(WeightParams p)
 template <int NW>
 static hipError_t launch_nw(const Params &p, int B, hipStream_t stream)
 {
-    const Lds L = lds_layout(p.maxRow, p.k);
+    const Lds L = lds_layout(p.maxRow, p.k, p.spec);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kbest_kernel<NW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
     if (e != hipSuccess) return e;
@@ -627,8 +765,9 @@ hipError_t launch_kbest(const Params &p, int B, int nWaves, hipStream_t stream)
     switch (nWaves) {
     case 1: return launch_nw<1>(p, B, stream);
     case 2: return launch_nw<2>(p, B, stream);
-    case 8: return launch_nw<8>(p, B, stream);
-    default: return launch_nw<4>(p, B, stream);
+    case 4: return launch_nw<4>(p, B, stream);
+    case 16: return launch_nw<16>(p, B, stream);
+    default: return launch_nw<8>(p, B, stream);
     }
 }
 
