@@ -106,6 +106,10 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
  * of a timed / graph-captured region. */
 int kbest_reserve(kbest_ctx *ctx, int B, int maxRow, int k);
 
+/* Diagnostic builds only (make -C probabilisticsemslam_amd/csrc PROFILE=1): device buffer of B*16 uint64
+ * that receives per-matrix cycle stamps of the kernel phases.  The regular build never touches it. */
+int kbest_set_profile_buffer(kbest_ctx *ctx, void *d_buf);
+
 /*
  * Batched assignmentProb (assignment.cpp:547-683): k-best with cutoff 42, then
  * sum of exp(best - cost) over the solutions scattered into probs.

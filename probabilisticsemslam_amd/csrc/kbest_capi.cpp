@@ -22,6 +22,7 @@ struct kbest_ctx {
     int nWaves = 8;   // waves per cost matrix (workgroup = nWaves * 64 threads)
     int spec = 4;     // candidates re-solved / split per round
     int extraStates = 64;  // state slots beyond k per matrix (room for speculative splits)
+    unsigned long long *prof = nullptr;  // diagnostic builds only (kbest_set_profile_buffer)
     std::string err;
     std::mutex mu;  // shim entry points may be called from several host threads
 };
@@ -126,6 +127,13 @@ int kbest_destroy(kbest_ctx *ctx)
     return KBEST_OK;
 }
 
+int kbest_set_profile_buffer(kbest_ctx *ctx, void *d_buf)
+{
+    if (!ctx) return KBEST_ERR_BAD_ARG;
+    ctx->prof = static_cast<unsigned long long *>(d_buf);
+    return KBEST_OK;
+}
+
 int kbest_reserve(kbest_ctx *ctx, int B, int maxRow, int k)
 {
     if (!ctx || B < 0 || maxRow < 1 || k < 1) return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_reserve: bad argument");
@@ -184,6 +192,7 @@ int kbest_batch_f64_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRo
     p.stateStride = kb::state_stride(maxRow);
     p.statesPerProblem = k + ctx->extraStates;
     p.spec = spec;
+    p.prof = ctx->prof;
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
     hipError_t e = kb::launch_kbest(p, B, ctx->nWaves, s);
     if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "kbest kernel launch", e);

@@ -36,6 +36,7 @@ struct Params {
     long long stateStride;
     int statesPerProblem;     // >= k; the surplus bounds how far candidates are split speculatively
     int spec;                 // candidates re-solved / split per round (1 = the reference's order exactly)
+    unsigned long long *prof; // [B][16] cycle stamps; only read by diagnostic builds (make PROFILE=1)
 };
 
 struct WeightParams {

@@ -98,7 +98,7 @@ constexpr int KEY_INF_HI = 0x7ff00000;  // key of +inf is (0x7ff00000, 0)
 // does not pad inline asm).  The result lands in lane 63 and is read into an
 // SGPR.  EXEC must be all ones.
 #define KB_DPP_MIN_CHAIN(OP)                                                             \
-    "s_nop 1\n\t" OP " %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"     \
+    "s_nop 1\n\t" OP " %1, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"     \
     "s_nop 1\n\t" OP " %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"     \
     "s_nop 1\n\t" OP " %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"         \
     "s_nop 1\n\t" OP " %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"              \
@@ -108,14 +108,14 @@ constexpr int KEY_INF_HI = 0x7ff00000;  // key of +inf is (0x7ff00000, 0)
 
 __device__ __forceinline__ int wave_min_i32(int x)
 {
-    int r;
-    asm volatile(KB_DPP_MIN_CHAIN("v_min_i32_dpp") : "=s"(r), "+v"(x));
+    int r, t;
+    asm volatile(KB_DPP_MIN_CHAIN("v_min_i32_dpp") : "=s"(r), "=&v"(t) : "v"(x));
     return r;
 }
 __device__ __forceinline__ u32 wave_min_u32(u32 x)
 {
-    u32 r;
-    asm volatile(KB_DPP_MIN_CHAIN("v_min_u32_dpp") : "=s"(r), "+v"(x));
+    u32 r, t;
+    asm volatile(KB_DPP_MIN_CHAIN("v_min_u32_dpp") : "=s"(r), "=&v"(t) : "v"(x));
     return r;
 }
 
@@ -147,69 +147,69 @@ __device__ __forceinline__ u64 bit64(int i) { return 1ull << (i & 63); }
 //   forb    rows skipped while the start column itself is scanned (cpp:310)
 //   c4r     this lane's row -> column, -1 = unassigned (a sink)
 //   u       LDS array, duals per column; v this lane's row dual
-// shortestPathCost[row] is held per lane as an order-preserving integer key
-// (to_key): the strict '<' update (cpp:185, 314) is one 64-bit integer compare
-// and the arg-min (cpp:191-194, 320-323: first minimum in ascending row order)
-// is two 6-stage DPP min chains (high word, then low word among the lanes that
-// tie on the high word) + ballot + ff1.  A scanned row's key is overwritten
-// with +inf so it never wins again; when FULL, its distance is kept in dv for
-// the dual update (a scanned row's shortestPathCost never changes afterwards).
+//   spc     shortestPathCost of this lane's row (out: valid for scanned rows)
+// The strict '<' update (cpp:185, 314) is one fp64 compare.  The arg-min
+// (cpp:191-194, 320-323: first minimum in ascending row order) runs on an
+// order-preserving integer key of the candidates' spc: one 6-stage DPP min
+// chain over the high words, ballot of the lanes that hold that minimum, and
+// -- only if more than one lane ties on the high word (values within 2^-20 of
+// each other, or +inf) -- a second chain over the low words; ff1 of the ballot
+// picks the lowest row.  delta is then read back from the winning lane, so it
+// is the exact double.  Early termination compares key high words in SALU and
+// falls back to an fp64 compare only when they are equal.
 // Returns 0 = path found, 1 = infeasible (cpp:197, 327), 2 = abandoned because
-// delta exceeds the bound key (only when EARLY).
-template <bool EARLY, bool FULL>
+// delta exceeds `bound` (only when EARLY).
+template <bool EARLY>
 __device__ __forceinline__ int dijkstra(const double *Cs, int LDC, const double *u, int rl, int lane,
-                                        double v, int c4r, u64 cand, u64 forb, int start, int bndHi,
-                                        u32 bndLo, int &pred, double &dv, u64 &scannedOut,
-                                        double &deltaOut, int &sinkOut)
+                                        double v, int c4r, u64 cand, u64 forb, int start, double bound,
+                                        double &spc, int &pred, u64 &scannedOut, double &deltaOut,
+                                        int &sinkOut)
 {
-    int khi = KEY_INF_HI;
-    u32 klo = 0;
-    int dvlo = 0, dvhi = 0;
+    int slo = 0, shi = KEY_INF_HI;  // spc = +inf
     cand = uni64(cand);
     u64 scanned = 0, act = cand & ~uni64(forb);
     int cur = uni32(start);
-    bndHi = uni32(bndHi);
-    bndLo = (u32)uni32((int)bndLo);
+    // the bound is computed from LDS values (VGPRs): make it provably uniform or the loop turns divergent
+    bound = __hiloint2double(uni32(__double2hiint(bound)), uni32(__double2loint(bound)));
+    int bndHi;
+    u32 bndLo;
+    to_key(bound, bndHi, bndLo);
     double delta = 0.0;
     pred = 0;
+    scannedOut = 0;
     for (int it = 0;; it++) {
         if (it > 64) return 1;  // cannot happen (one row leaves `cand` per step); keeps a bug from hanging the GPU
         const double cval = Cs[rl + cur * LDC];
         const double ucur = u[cur];
         const double rc = ((delta + cval) - ucur) - v;  // cpp:183 / cpp:313, left to right
-        int nhi;
-        u32 nlo;
-        to_key(rc, nhi, nlo);
-        const long long nk = (long long)(((u64)(u32)nhi << 32) | nlo);
-        const long long ok = (long long)(((u64)(u32)khi << 32) | klo);
-        const u64 upd = __ballot(nk < ok) & act;        // strict '<': cpp:185, 314
-        khi = sel32(upd, nhi, khi);
-        klo = (u32)sel32(upd, (int)nlo, (int)klo);
+        const u64 upd = __ballot(rc < __hiloint2double(shi, slo)) & act;  // strict '<': cpp:185, 314
+        slo = sel32(upd, __double2loint(rc), slo);
+        shi = sel32(upd, __double2hiint(rc), shi);
         pred = sel32(upd, cur, pred);
+        const int sg = shi >> 31;
+        const int khi = sel32(act, shi ^ (int)((u32)sg >> 1), KEY_INF_HI);  // candidates only
         const int mhi = wave_min_i32(khi);
-        const u64 m1 = __ballot(khi == mhi);
-        const u32 t = (u32)sel32(m1, (int)klo, -1);
-        const u32 mlo = wave_min_u32(t);
-        if (mhi >= KEY_INF_HI) return 1;                 // minimum is +inf: infeasible
-        if (EARLY && (mhi > bndHi || (mhi == bndHi && mlo > bndLo))) return 2;
-        const u64 eq = __ballot(t == mlo) & m1;
+        if (mhi >= KEY_INF_HI) { scannedOut = scanned; return 1; }  // minimum is +inf: infeasible
+        u64 eq = __ballot(khi == mhi);
+        if (eq & (eq - 1)) {  // several rows share the high word: decide on the low word
+            const u32 t = (u32)sel32(eq, slo ^ sg, -1);
+            const u32 mlo = wave_min_u32(t);
+            eq &= __ballot(t == mlo);
+        }
         const int closest = __ffsll((long long)eq) - 1;  // lowest row index: cpp:191, 320
+        delta = __hiloint2double(__builtin_amdgcn_readlane(shi, closest), __builtin_amdgcn_readlane(slo, closest));
+        if (EARLY && mhi >= bndHi) {
+            if (mhi > bndHi || delta > bound) { scannedOut = scanned; return 2; }
+        }
         const u64 cbit = 1ull << closest;
         scanned |= cbit;
         cand &= ~cbit;
-        delta = from_key(mhi, mlo);
-        khi = sel32(cbit, KEY_INF_HI, khi);   // retire the row (gfx9 v_writelane cannot take two SGPRs)
-        klo = (u32)sel32(cbit, 0, (int)klo);
-        if (FULL) {
-            dvlo = sel32(cbit, __double2loint(delta), dvlo);
-            dvhi = sel32(cbit, __double2hiint(delta), dvhi);
-        }
         const int cc = __builtin_amdgcn_readlane(c4r, closest);
         if (cc < 0) { sinkOut = closest; break; }
         cur = cc;
         act = cand;
     }
-    dv = __hiloint2double(dvhi, dvlo);
+    spc = __hiloint2double(shi, slo);
     scannedOut = scanned;
     deltaOut = delta;
     return 0;
@@ -256,6 +256,16 @@ __device__ __forceinline__ double serial_gain(const double *Cs, int LDC, int lan
     if (prefixOut && lane >= from && lane < M) prefixOut[lane] = mine;
     return acc;
 }
+
+// ---- optional in-kernel cycle stamps (diagnostic builds only: make PROFILE=1).  In the shipped kernel no
+// stamp executes; the stamp values only ever go to the separate `prof` buffer.
+#ifdef KB_PROFILE
+#define KB_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define KB_ACC(slot, expr) do { profAcc[slot] += (unsigned long long)(expr); } while (0)
+#else
+#define KB_T(var) do { } while (0)
+#define KB_ACC(slot, expr) do { } while (0)
+#endif
 
 // ------------------------------------------------------------------ the kernel
 //
@@ -361,6 +371,10 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
     const int rl = lane < D ? lane : D - 1;
     const u64 allRows = (D >= 64) ? ~0ull : ((1ull << D) - 1ull);
     const int maxSid = p.statesPerProblem;
+#ifdef KB_PROFILE
+    unsigned long long profAcc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long profT0 = __builtin_readcyclecounter();
+#endif
 
     // ---- phase 0: makeCostMatrixSafe + zero padding (cpp:534-569, 582-585) --
     {
@@ -451,8 +465,8 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
         u64 scanned;
         bool bad = false;
         for (int c = 0; c < D; c++) {
-            if (dijkstra<false, true>(Cs, LDC, nd.u, rl, lane, v, c4r, allRows, 0ull, c, KEY_INF_HI, 0u, pred, spc,
-                                      scanned, delta, sink)) { bad = true; break; }
+            if (dijkstra<false>(Cs, LDC, nd.u, rl, lane, v, c4r, allRows, 0ull, c, INF, spc, pred, scanned, delta,
+                                sink)) { bad = true; break; }
             dual_update_flip(nd.u, lane, v, c4r, r4c, spc, pred, scanned, delta, sink, c);
         }
         if (bad) {
@@ -479,8 +493,11 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
         return;
     }
 
+    KB_ACC(0, __builtin_readcyclecounter() - profT0);  // [0] set-up + root solve
     // ---- phase 2: rounds ----------------------------------------------------------------------------
     while (uni32(ctrl->stop) == 0) {
+        KB_T(tRound);
+        KB_ACC(7, 1);  // [7] rounds
         // control values come out of LDS in VGPRs: readfirstlane makes them provably wave-uniform, so every
         // loop below is scalar-controlled.  They are only rewritten in D, behind a barrier.
         const int nsel = uni32(ctrl->nsel);
@@ -499,12 +516,15 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
             // threshold of the pool: once it holds R candidates only children below its largest can matter
             double T = (nOld >= R) ? PG[src][head + R - 1] : INF;
             if (useCut && !maximize && cutG < T) T = cutG;
+            const double cmaxv = ctrl->cmax;
             int npush = 0;
             for (;;) {
+                KB_T(tItem);
                 int item = 0;
                 if (lane == 0) item = atomicAdd(&ctrl->nextItem, 1);
                 item = uni32(item);
                 if (item >= totalItems) break;
+                KB_ACC(4, 1);  // [4] children started
                 int w = 0, first = 0;
                 for (;; w++) {  // locate the node of this item (nsel <= spec is small)
                     const int nchw = M - uni32(node_ref(smem + L.offNodes + (size_t)w * L.nodeStride, p.maxRow).info[0]);
@@ -522,9 +542,7 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
                 const int r4cP = (lane < D) ? nd.r4c[lane] : -1;
                 // early-termination bound on the Dijkstra distance: child gain = parent gain + delta (up to
                 // rounding), so delta > (T - parent gain) + margin can never enter the k best.
-                int bndHi = KEY_INF_HI;
-                u32 bndLo = 0;
-                if (prune && T < INF) to_key((T - pgain) + 1e-9 * (fabs(T) + ctrl->cmax), bndHi, bndLo);
+                const double bound = (prune && T < INF) ? (T - pgain) + 1e-9 * (fabs(T) + cmaxv) : INF;
                 const int fr = __builtin_amdgcn_readlane(r4cP, c);           // row freed: cpp:277-278
                 const u64 cand = __ballot(lane < D && c4rP >= c);             // rows of columns >= c: cpp:480-488, 525-527
                 const u64 forbm = (c == a) ? uni64(nd.forb[0]) : bit64(fr);   // cpp:490 / cpp:510-516
@@ -532,9 +550,15 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
                 double spc, delta;
                 int pred, sink = 0;
                 u64 scanned;
-                const int st = dijkstra<true, false>(Cs, LDC, nd.u, rl, lane, v, c4r, cand, forbm, c, bndHi, bndLo,
-                                                     pred, spc, scanned, delta, sink);
+                KB_T(tDij0);
+                KB_ACC(9, tDij0 - tItem);  // [9] per-child set-up cycles
+                const int st = dijkstra<true>(Cs, LDC, nd.u, rl, lane, v, c4r, cand, forbm, c, bound, spc, pred,
+                                              scanned, delta, sink);
+                KB_T(tDij1);
+                KB_ACC(8, tDij1 - tDij0);  // [8] cycles inside child Dijkstra
+                KB_ACC(5, __popcll(scanned) + (st != 0));  // [5] child Dijkstra steps (approx: scanned rows)
                 if (st != 0) continue;
+                KB_ACC(6, 1);  // [6] children completed
                 int r4c = (lane == c) ? -1 : r4cP;
                 int r = sink, cc, guard = 0;
                 do {  // path flip, row4col side only (cpp:108-116)
@@ -546,6 +570,7 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
                 const double g = serial_gain(Cs, LDC, lane, r4c, c, M, nd.prefix[c], nullptr);
                 if (useCut && (maximize ? (g < cutG) : (g > cutG))) continue;  // cutHyp, cpp:496/521
                 npush++;
+                KB_ACC(10, __builtin_readcyclecounter() - tDij1);  // [10] flip + exact gain of completed children
                 if (lane == 0) {
                     const int pos = atomicAdd(&ctrl->nFresh, 1);
                     freshG[pos] = g;
@@ -554,7 +579,11 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
             }
             if ((p.flags & KBEST_FLAG_COUNT_PUSHED) && lane == 0 && npush) atomicAdd(&ctrl->pushed, npush);
         }
+        KB_T(tB1);
+        KB_ACC(1, tB1 - tRound);  // [1] phase B busy (this wave)
         __syncthreads();
+        KB_T(tC0);
+        KB_ACC(11, tC0 - tB1);    // [11] wait at the barrier after B
         // -- C: rank-merge the fresh candidates into the sorted pool, keep the R smallest.  Ties in gain are
         //    ordered by (parent, column), so the result does not depend on the arrival order of the fresh list.
         const int dst = src ^ 1;
@@ -588,6 +617,8 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
         int nq = nOld + nFresh;
         if (nq > R) nq = R;
         __syncthreads();
+        KB_T(tA0);
+        KB_ACC(2, tA0 - tC0);     // [2] merge incl. its barrier
         // -- A + D: every wave finds the unsolved candidates itself (the pool is stable now); wave w solves the
         //    w-th of them; lane 0 of wave 0 also does the emission bookkeeping, which depends only on the pool
         //    order and flags.  State slots: keep one in hand for every output still to come.
@@ -673,8 +704,8 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
             double spc, delta;
             int pred, sink = 0;
             u64 scanned;
-            const int rc = dijkstra<false, true>(Cs, LDC, nd.u, rl, lane, v, c4r, cand, forbm, col, KEY_INF_HI, 0u, pred,
-                                                 spc, scanned, delta, sink);
+            const int rc = dijkstra<false>(Cs, LDC, nd.u, rl, lane, v, c4r, cand, forbm, col, INF, spc, pred, scanned,
+                                           delta, sink);
             if (rc == 0) dual_update_flip(nd.u, lane, v, c4r, r4c, spc, pred, scanned, delta, sink, col);
             const double g = serial_gain(Cs, LDC, lane, r4c, 0, M, 0.0, nd.prefix);
             const u64 forbN = forbm | bit64(__builtin_amdgcn_readlane(r4c, col));  // cpp:362
@@ -684,7 +715,10 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
                 if (rc != 0) ctrl->stop = 2;  // cannot happen: the candidate was solved before
             }
         }
+        KB_T(tA1);
+        KB_ACC(3, tA1 - tA0);     // [3] select / emit / re-solve busy
         __syncthreads();
+        KB_ACC(12, __builtin_readcyclecounter() - tA1);  // [12] wait at the barrier after A
     }
     const int stopCode = uni32(ctrl->stop);
     const int nf = (stopCode == 2) ? -3 : uni32(ctrl->emitted);
@@ -699,6 +733,11 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
         p.nf[b] = nf;
         if (p.pushed) p.pushed[b] = ctrl->pushed;
     }
+#ifdef KB_PROFILE
+    profAcc[13] = __builtin_readcyclecounter() - profT0;  // [13] whole kernel (this wave)
+    if (p.prof && lane == 0)
+        for (int i = 0; i < 16; i++) atomicAdd(p.prof + (long long)b * 16 + i, profAcc[i]);
+#endif
 }
 
 // ------------------------------------------------- association weights epilogue

@@ -18,6 +18,7 @@ KBEST_MAX_DIM = 64
 C_ABI_SYMBOLS = (
     "kbest_default_opts", "kbest_create", "kbest_destroy", "kbest_strerror", "kbest_last_error",
     "kbest_device_count", "kbest_batch_f64_dev", "kbest_batch_f64", "kbest_reserve", "kbest_weights_batch_f64",
+    "kbest_set_profile_buffer",
 )
 
 
@@ -31,7 +32,8 @@ class KBestOpts(C.Structure):
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "libkbest_amd.so")
+    # KBEST_LIB selects another in-tree build of the same library (the diagnostic libkbest_amd_prof.so)
+    return os.path.join(_HERE, os.environ.get("KBEST_LIB", "libkbest_amd.so"))
 
 
 _lib = None
@@ -58,6 +60,7 @@ def load_library():
     lib.kbest_last_error.restype = C.c_char_p
     lib.kbest_device_count.restype = C.c_int
     lib.kbest_reserve.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    lib.kbest_set_profile_buffer.argtypes = [vp, vp]
     lib.kbest_batch_f64_dev.argtypes = [vp, C.POINTER(KBestOpts), C.c_int, C.c_int, C.c_int, i32p, i32p, dp, i64p,
                                         C.c_int, i32p, i32p, dp, i32p, i64p, vp]
     lib.kbest_batch_f64.argtypes = [vp, C.POINTER(KBestOpts), C.c_int, C.c_int, C.c_int, i32p, i32p, dp, i64p,

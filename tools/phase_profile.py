@@ -1,0 +1,52 @@
+"""Diagnostic: per-phase cycle shares of the k-best kernel (needs `make -C probabilisticsemslam_amd/csrc PROFILE=1`).
+Run on the GPU box:  KBEST_LIB=libkbest_amd_prof.so python tools/phase_profile.py [config] [B]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("KBEST_LIB", "libkbest_amd_prof.so")
+import numpy as np
+import torch
+import probabilisticsemslam_amd as pk
+from probabilisticsemslam_amd import workloads as wl
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "c4"
+Bc, N, M, k, seed = wl.DENSE_CONFIGS[cfg]
+B = int(sys.argv[2]) if len(sys.argv) > 2 else Bc
+nw = int(os.environ.get("KBEST_NWAVES", "8"))
+dev = torch.device("cuda", 0)
+costs = wl.dense_batch(B, N, M, seed)
+d_cost = torch.from_numpy(costs).to(dev)
+d_r4c = torch.empty((B, k, M), dtype=torch.int32, device=dev)
+d_c4r = torch.empty((B, k, N), dtype=torch.int32, device=dev)
+d_gain = torch.empty((B, k), dtype=torch.float64, device=dev)
+d_nf = torch.empty(B, dtype=torch.int32, device=dev)
+prof = torch.zeros((B, 16), dtype=torch.int64, device=dev)
+eng = pk.KBestEngine(0)
+eng.lib.kbest_set_profile_buffer(eng.ctx, C.c_void_p(prof.data_ptr()))
+s = torch.cuda.Stream()
+for it in range(2):
+    prof.zero_()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(s):
+        e0.record()
+        eng.kbest_dev(d_cost, B, N, M, k, d_r4c, d_c4r, d_gain, d_nf, stream=s.cuda_stream)
+        e1.record()
+    torch.cuda.synchronize()
+ms = e0.elapsed_time(e1)
+p = prof.cpu().numpy().astype(np.float64)
+m = p.mean(axis=0)
+names = ["setup+root", "B busy", "C merge(+barrier)", "A/D busy", "children started", "child steps", "children completed",
+         "rounds", "cyc in child dijkstra", "cyc child set-up", "cyc flip+gain", "wait after B", "wait after A", "kernel cyc (sum over waves)"]
+print(f"{cfg} B={B} NW={nw} SPEC={os.environ.get('KBEST_SPEC','4')} kernel {ms:.3f} ms (profiled build)")
+tot = m[13]
+for i, n in enumerate(names):
+    extra = ""
+    if i in (0, 1, 2, 3, 8, 9, 10, 11, 12):
+        extra = f"  = {100*m[i]/tot:5.1f}% of wave-cycles"
+    print(f"  [{i:2d}] {n:28s} {m[i]:14.1f}{extra}")
+print(f"  per wave kernel cycles {tot/nw:.0f}; cycles/step in child dijkstra {m[8]/max(m[5],1):.0f}; set-up cycles/child {m[9]/max(m[4],1):.0f}; "
+      f"flip+gain cycles/completed child {m[10]/max(m[6],1):.0f}; steps/child {m[5]/max(m[4],1):.2f}")
