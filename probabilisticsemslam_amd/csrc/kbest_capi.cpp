@@ -16,11 +16,13 @@
 struct kbest_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    unsigned char *states = nullptr;  // hypothesis-state workspace
+    unsigned char *states = nullptr;  // hypothesis-state workspace (+ the slot -> state table behind it)
     size_t statesBytes = 0;
+    size_t slotSidOffset = 0;
     int ldsLimit = 65536;
     int nWaves = 8;   // waves per cost matrix (workgroup = nWaves * 64 threads)
-    int spec = 4;     // candidates re-solved / split per round
+    int spec = 0;     // candidates re-solved / split per round; 0 = choose per launch (choose_spec)
+    int ldsPerCU = 160 * 1024;
     int extraStates = 64;  // state slots beyond k per matrix (room for speculative splits)
     unsigned long long *prof = nullptr;  // diagnostic builds only (kbest_set_profile_buffer)
     std::string err;
@@ -43,6 +45,17 @@ int fail(kbest_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess)
         hipError_t e_ = (call);                                              \
         if (e_ != hipSuccess) return fail(ctx, KBEST_ERR_HIP, #call, e_);    \
     } while (0)
+
+// Speculation width (candidates re-solved / split per round).  Measured on MI355X at 64x64, k=200: 4 with three
+// matrices per CU beats 2 with four per CU (fewer, fuller rounds matter more than the extra resident waves), and
+// 8 loses to 4 (the speculative splits stop paying).  Smaller problems simply have the LDS for 4.
+int choose_spec(const kbest_ctx *ctx, int maxRow, int k)
+{
+    if (ctx->spec > 0) return ctx->spec;
+    int spec = ctx->nWaves < 4 ? ctx->nWaves : 4;
+    while (spec > 1 && kb::lds_layout(maxRow, k, spec).total > ctx->ldsLimit) spec /= 2;
+    return spec;
+}
 
 struct DevBuf {  // RAII device buffer for the host-pointer entry points
     void *p = nullptr;
@@ -113,6 +126,10 @@ int kbest_create(kbest_ctx **out, int device)
         if (w >= 1 && w <= 16) ctx->spec = w;
     }
     if (ctx->spec > ctx->nWaves) ctx->spec = ctx->nWaves;
+    int ldsCU = 0;
+    if (hipDeviceGetAttribute(&ldsCU, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, device) == hipSuccess &&
+        ldsCU > 0)
+        ctx->ldsPerCU = ldsCU;
     *out = ctx;
     return KBEST_OK;
 }
@@ -137,13 +154,15 @@ int kbest_set_profile_buffer(kbest_ctx *ctx, void *d_buf)
 int kbest_reserve(kbest_ctx *ctx, int B, int maxRow, int k)
 {
     if (!ctx || B < 0 || maxRow < 1 || k < 1) return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_reserve: bad argument");
-    const size_t need = (size_t)B * (size_t)(k + ctx->extraStates) * (size_t)kb::state_stride(maxRow);
-    if (need <= ctx->statesBytes) return KBEST_OK;
+    const size_t nStates = (size_t)B * (size_t)(k + ctx->extraStates) * (size_t)kb::state_stride(maxRow);
+    const size_t need = nStates + (size_t)B * (size_t)k * 2 + 256;
+    if (need <= ctx->statesBytes) { ctx->slotSidOffset = (nStates + 127) & ~(size_t)127; return KBEST_OK; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->states) { HIP_TRY(ctx, hipDeviceSynchronize()); (void)hipFree(ctx->states); ctx->states = nullptr; ctx->statesBytes = 0; }
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->states), need);
     if (e != hipSuccess) return fail(ctx, KBEST_ERR_NOMEM, "hipMalloc(state workspace)", e);
     ctx->statesBytes = need;
+    ctx->slotSidOffset = (nStates + 127) & ~(size_t)127;
     return KBEST_OK;
 }
 
@@ -160,7 +179,8 @@ int kbest_batch_f64_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRo
     if (maxRow > KBEST_MAX_DIM) return fail(ctx, KBEST_ERR_UNSUPPORTED, "numRow > KBEST_MAX_DIM");
     if (k + ctx->extraStates > 65535) return fail(ctx, KBEST_ERR_UNSUPPORTED, "k too large");
     // counting the reference's pushes needs the reference's exact order of splits: no speculation
-    const int spec = (opts->flags & KBEST_FLAG_COUNT_PUSHED) ? 1 : ctx->spec;
+    const int spec = (opts->flags & KBEST_FLAG_COUNT_PUSHED) ? 1 : choose_spec(ctx, maxRow, k);
+    if (k > 4 * ctx->nWaves * 64) return fail(ctx, KBEST_ERR_UNSUPPORTED, "k too large for the in-register pool merge");
     const kb::Lds L = kb::lds_layout(maxRow, k, spec);
     if (L.total > ctx->ldsLimit) return fail(ctx, KBEST_ERR_UNSUPPORTED, "k too large for the LDS candidate pool");
     if (B == 0) return KBEST_OK;
@@ -193,6 +213,7 @@ int kbest_batch_f64_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRo
     p.statesPerProblem = k + ctx->extraStates;
     p.spec = spec;
     p.prof = ctx->prof;
+    p.slotSid = reinterpret_cast<unsigned short *>(ctx->states + ctx->slotSidOffset);
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
     hipError_t e = kb::launch_kbest(p, B, ctx->nWaves, s);
     if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "kbest kernel launch", e);

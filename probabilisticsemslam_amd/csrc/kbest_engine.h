@@ -37,6 +37,7 @@ struct Params {
     int statesPerProblem;     // >= k; the surplus bounds how far candidates are split speculatively
     int spec;                 // candidates re-solved / split per round (1 = the reference's order exactly)
     unsigned long long *prof; // [B][16] cycle stamps; only read by diagnostic builds (make PROFILE=1)
+    unsigned short *slotSid;  // workspace: [B][k] state slot of each output slot
 };
 
 struct WeightParams {
@@ -61,8 +62,7 @@ __host__ __device__ inline long long state_stride(int maxRow)
 
 // LDS carve-up of one workgroup (= one cost matrix).
 struct Lds {
-    int offC, offNodes, nodeStride, offFreshG, offFreshM, offPoolG[2], offPoolM[2], offPoolS[2], offSlotSid, offRed,
-        offCtrl, total;
+    int offC, offNodes, nodeStride, offFreshG, offFreshM, offPoolG, offPoolM, offPoolS, offCtrl, total;
 };
 
 __host__ __device__ inline Lds lds_layout(int maxRow, int k, int spec)
@@ -71,17 +71,15 @@ __host__ __device__ inline Lds lds_layout(int maxRow, int k, int spec)
     const int ldc = maxRow | 1;
     int o = 0;
     L.offC = o;          o += maxRow * ldc * 8;      // shifted, zero-padded cost tile
-    L.nodeStride = 32 * maxRow + 32;                 // u, v, prefix (fp64), row4col, col4row (int), scalars
+    L.nodeStride = (26 * maxRow + 32 + 7) & ~7;      // u, v, prefix (fp64), scalars, row4col, col4row (u8)
     L.offNodes = o;      o += spec * L.nodeStride;   // solved hypotheses waiting to be split
-    L.offFreshG = o;     o += spec * 64 * 8;         // surviving children of this round: gain
-    for (int i = 0; i < 2; i++) { L.offPoolG[i] = o; o += k * 8; }  // sorted candidate pool (ping-pong): gain
-    L.offRed = o;        o += 16 * 8;                // cross-wave reduction scratch
+    L.offFreshG = o;     o += (spec * 64 > 16 ? spec * 64 : 16) * 8;  // surviving children of this round: gain
+    L.offPoolG = o;      o += k * 8;                 // sorted candidate pool: gain
     L.offFreshM = o;     o += spec * 64 * 4;         //   (parent state, column)
-    for (int i = 0; i < 2; i++) { L.offPoolM[i] = o; o += k * 4; }  //   (parent state, column)
-    for (int i = 0; i < 2; i++) { L.offPoolS[i] = o; o += k * 4; }  //   own state slot / flags
-    L.offSlotSid = o;    o += k * 2;                 // state slot of each emitted output slot
+    L.offPoolM = o;      o += k * 4;                 //   (parent state, column, flags)
+    L.offPoolS = o;      o += k * 2;                 //   own state slot
     o = (o + 7) & ~7;
-    L.offCtrl = o;       o += 96;                    // struct Ctrl
+    L.offCtrl = o;       o += 80;                    // struct Ctrl
     L.total = (o + 15) & ~15;
     return L;
 }

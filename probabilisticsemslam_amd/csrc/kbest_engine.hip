@@ -295,7 +295,6 @@ struct Ctrl {
     double gain0u;      // gainBest[0]
     int nq;       // end of the valid pool range in the current buffer
     int head;     // start of it (entries before head were emitted)
-    int cur;      // current pool buffer
     int emitted;  // output slots filled so far
     int stop;     // 1: finished   2: internal error   3: infeasible root
     int pushed;
@@ -304,20 +303,21 @@ struct Ctrl {
     int nextSid;  // next free hypothesis-state slot
     int nFresh;   // surviving children appended this round
 };
-static_assert(sizeof(Ctrl) <= 96, "Ctrl must fit the LDS slot reserved by lds_layout");
+static_assert(sizeof(Ctrl) <= 80, "Ctrl must fit the LDS slot reserved by lds_layout");
 
-constexpr u32 SID_NONE = 0xFFFFFFFFu;   // pool entry not solved yet
-constexpr u32 SID_SPLIT = 0x80000000u;  // flag: solved AND children already merged
-constexpr u32 SID_FRESH = 0x40000000u;  // flag: solved in the current round (children not generated yet)
-constexpr u32 SID_MASK = 0x3FFFFFFFu;
+// pool entry: gain (fp64), meta (u32: column | parent state << 8 | flags), own state slot (u16)
+constexpr unsigned short SID_NONE = 0xFFFFu;  // not solved yet
+constexpr u32 META_SPLIT = 0x80000000u;        // solved AND children already merged
+constexpr u32 META_FRESH = 0x40000000u;        // solved in the current round (children not generated yet)
+constexpr u32 META_MASK = 0x00FFFFFFu;
 
 // a solved hypothesis waiting to be split, in LDS
 struct NodeRef {
     double *u, *v, *prefix;
-    int *r4c, *c4r;
     double *gain;  // [0] shifted gain
     u64 *forb;
     int *info;     // [0] activeCol, [1] sid
+    unsigned char *r4c, *c4r;
 };
 
 __device__ __forceinline__ NodeRef node_ref(unsigned char *base, int maxRow)
@@ -326,11 +326,11 @@ __device__ __forceinline__ NodeRef node_ref(unsigned char *base, int maxRow)
     n.u = reinterpret_cast<double *>(base);
     n.v = n.u + maxRow;
     n.prefix = n.v + maxRow;
-    n.r4c = reinterpret_cast<int *>(n.prefix + maxRow);
-    n.c4r = n.r4c + maxRow;
-    n.gain = reinterpret_cast<double *>(n.c4r + maxRow);
+    n.gain = n.prefix + maxRow;
     n.forb = reinterpret_cast<u64 *>(n.gain + 1);
     n.info = reinterpret_cast<int *>(n.forb + 1);
+    n.r4c = reinterpret_cast<unsigned char *>(n.info + 4);
+    n.c4r = n.r4c + maxRow;
     return n;
 }
 
@@ -351,18 +351,19 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
         if (tid == 0) p.nf[b] = -1;
         return;
     }
+    // odd column stride of the LDS cost tile: row-wise (lane = row) and column-wise (lane = column) walks are
+    // both bank-conflict free
     const int D = N, LDC = D | 1;
     const int spec = p.spec < NW ? p.spec : NW;  // nodes solved / split per round
     const Lds L = lds_layout(p.maxRow, k, p.spec);
     double *Cs = reinterpret_cast<double *>(smem + L.offC);
     double *freshG = reinterpret_cast<double *>(smem + L.offFreshG);
     u32 *freshM = reinterpret_cast<u32 *>(smem + L.offFreshM);
-    double *PG[2] = {reinterpret_cast<double *>(smem + L.offPoolG[0]),
-                     reinterpret_cast<double *>(smem + L.offPoolG[1])};
-    u32 *PM[2] = {reinterpret_cast<u32 *>(smem + L.offPoolM[0]), reinterpret_cast<u32 *>(smem + L.offPoolM[1])};
-    u32 *PS[2] = {reinterpret_cast<u32 *>(smem + L.offPoolS[0]), reinterpret_cast<u32 *>(smem + L.offPoolS[1])};
-    unsigned short *slotSid = reinterpret_cast<unsigned short *>(smem + L.offSlotSid);
-    double *red = reinterpret_cast<double *>(smem + L.offRed);
+    double *PG = reinterpret_cast<double *>(smem + L.offPoolG);
+    u32 *PM = reinterpret_cast<u32 *>(smem + L.offPoolM);
+    unsigned short *PS = reinterpret_cast<unsigned short *>(smem + L.offPoolS);
+    unsigned short *slotSid = p.slotSid + (long long)blockIdx.x * k;  // global: state slot of each output slot
+    double *red = freshG;  // cross-wave reduction scratch of phase 0
     Ctrl *ctrl = reinterpret_cast<Ctrl *>(smem + L.offCtrl);
 
     const double *Cg = p.cost + (p.costOff ? p.costOff[b] : (long long)b * p.maxRow * p.maxCol);
@@ -418,7 +419,6 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
             ctrl->pushed = 0;
             ctrl->nq = 0;
             ctrl->head = 0;
-            ctrl->cur = 0;
             ctrl->emitted = 0;
             ctrl->nsel = 0;
             ctrl->nextItem = 0;
@@ -442,8 +442,8 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
             st[16 * p.maxRow + lane] = (unsigned char)r4c;
             st[17 * p.maxRow + lane] = (unsigned char)c4r;
             nd.v[lane] = v;
-            nd.r4c[lane] = r4c;
-            nd.c4r[lane] = c4r;
+            nd.r4c[lane] = (unsigned char)r4c;
+            nd.c4r[lane] = (unsigned char)c4r;
         }
         if (lane == 0) {
             *reinterpret_cast<u64 *>(st + offTail) = forb;
@@ -503,7 +503,7 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
         const int nsel = uni32(ctrl->nsel);
         const int emitted = uni32(ctrl->emitted);
         const int R = k - emitted;  // candidates that can still be output
-        const int src = uni32(ctrl->cur), nqEnd = uni32(ctrl->nq), head = uni32(ctrl->head);
+        const int nqEnd = uni32(ctrl->nq), head = uni32(ctrl->head);
         const int nOld = nqEnd - head;
         const int sidBase = uni32(ctrl->nextSid);
         const double cutG = ctrl->cutoffGain;
@@ -514,7 +514,7 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
             totalItems += M - uni32(node_ref(smem + L.offNodes + (size_t)w * L.nodeStride, p.maxRow).info[0]);
         {
             // threshold of the pool: once it holds R candidates only children below its largest can matter
-            double T = (nOld >= R) ? PG[src][head + R - 1] : INF;
+            double T = (nOld >= R) ? PG[head + R - 1] : INF;
             if (useCut && !maximize && cutG < T) T = cutG;
             const double cmaxv = ctrl->cmax;
             int npush = 0;
@@ -584,36 +584,54 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
         __syncthreads();
         KB_T(tC0);
         KB_ACC(11, tC0 - tB1);    // [11] wait at the barrier after B
-        // -- C: rank-merge the fresh candidates into the sorted pool, keep the R smallest.  Ties in gain are
-        //    ordered by (parent, column), so the result does not depend on the arrival order of the fresh list.
-        const int dst = src ^ 1;
+        // -- C: rank-merge the fresh candidates into the sorted pool IN PLACE (every thread first pulls its
+        //    entries into registers), keep the R smallest.  Ties in gain are ordered by (parent, column), so the
+        //    result does not depend on the arrival order of the fresh list.
         const int nFresh = uni32(ctrl->nFresh);
-        for (int i = tid; i < nOld; i += NT) {
-            const double g = PG[src][head + i];
-            int pos = i;
-            for (int j = 0; j < nFresh; j++) pos += (freshG[j] < g) ? 1 : 0;
-            if (pos < R) {
-                PG[dst][pos] = g;
-                PM[dst][pos] = PM[src][head + i];
-                const u32 sdv = PS[src][head + i];
-                PS[dst][pos] = (sdv == SID_NONE) ? SID_NONE : ((sdv & SID_MASK) | SID_SPLIT);  // every solved node was split in B
+        constexpr int EPT = 4;  // pool entries per thread held across the barrier (k <= EPT * NT)
+        double og[EPT];
+        u32 om[EPT];
+        unsigned short os[EPT];
+        int opos[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            const int i = tid + e * NT;
+            opos[e] = -1;
+            if (i < nOld) {
+                const double g = PG[head + i];
+                int pos = i;
+                for (int j = 0; j < nFresh; j++) pos += (freshG[j] < g) ? 1 : 0;
+                og[e] = g;
+                const u32 mv = PM[head + i];
+                os[e] = PS[head + i];
+                // every solved node was split in B: FRESH -> SPLIT
+                om[e] = (os[e] == SID_NONE) ? mv : ((mv & META_MASK) | META_SPLIT);
+                opos[e] = pos;
             }
         }
-        for (int j = tid; j < nFresh; j += NT) {
-            const double g = freshG[j];
-            const u32 mj = freshM[j];
+        double fg = 0.0;
+        u32 fm = 0;
+        int fpos = -1;
+        if (tid < nFresh) {  // nFresh <= spec * 64 <= NT
+            const double g = freshG[tid];
+            const u32 mj = freshM[tid];
             int lo = 0, hi = nOld;
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
-                if (PG[src][head + mid] <= g) lo = mid + 1; else hi = mid;
+                if (PG[head + mid] <= g) lo = mid + 1; else hi = mid;
             }
             int pos = lo;
             for (int j2 = 0; j2 < nFresh; j2++) {
                 const double g2 = freshG[j2];
                 pos += (g2 < g || (g2 == g && freshM[j2] < mj)) ? 1 : 0;
             }
-            if (pos < R) { PG[dst][pos] = g; PM[dst][pos] = mj; PS[dst][pos] = SID_NONE; }
+            fg = g; fm = mj; fpos = pos;
         }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EPT; e++)
+            if (opos[e] >= 0 && opos[e] < R) { PG[opos[e]] = og[e]; PM[opos[e]] = om[e]; PS[opos[e]] = os[e]; }
+        if (fpos >= 0 && fpos < R) { PG[fpos] = fg; PM[fpos] = fm; PS[fpos] = SID_NONE; }
         int nq = nOld + nFresh;
         if (nq > R) nq = R;
         __syncthreads();
@@ -629,8 +647,8 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
         for (int base = 0; base < nq && nselNew < budget; base += 64) {
             const int i = base + lane;
             // (an entry already flagged FRESH belongs to a wave of this round that is ahead of us: same set)
-            const u32 sdv = (i < nq) ? PS[dst][i] : 0u;
-            u64 m = __ballot(i < nq && (sdv == SID_NONE || (sdv & SID_FRESH)));
+            const bool unsolved = i < nq && (PS[i] == SID_NONE || (PM[i] & META_FRESH));
+            u64 m = __ballot(unsolved);
             while (m && nselNew < budget) {
                 const int bitpos = __ffsll((long long)m) - 1;
                 if (nselNew == wave) mySel = base + bitpos;
@@ -641,20 +659,20 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
         if (wave == 0 && lane == 0) {
             int e = emitted, h = 0, stop = 0, selSeen = 0;
             while (h < nq && e < k) {
-                const u32 sdv = PS[dst][h];
+                const unsigned short sdv = PS[h];
                 int sid;
                 bool fresh = false;
-                // a candidate selected in this round reads as SID_NONE or as (sid | SID_FRESH) depending on whether
-                // its wave has finished already: both mean "solved in this round"
-                if (sdv == SID_NONE || (sdv & SID_FRESH)) {
+                // a candidate selected in this round reads as SID_NONE or as FRESH depending on whether its wave
+                // has finished already: both mean "solved in this round"
+                if (sdv == SID_NONE || (PM[h] & META_FRESH)) {
                     if (selSeen >= nselNew) break;  // unsolved and not selected this round: wait
                     sid = sidBase + selSeen;          // selection is in pool order
                     selSeen++;
                     fresh = true;
                 } else {
-                    sid = (int)(sdv & SID_MASK);
+                    sid = (int)sdv;
                 }
-                const double g = PG[dst][h];
+                const double g = PG[h];
                 const double gu = maximize ? (-g + ctrl->cdelta) : (g + ctrl->cdelta);  // cpp:626-630
                 p.gain[outBase + e] = gu;
                 slotSid[e] = (unsigned short)sid;
@@ -673,14 +691,13 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
             ctrl->nextSid = sidBase + nselNew;
             ctrl->nextItem = 0;
             ctrl->nFresh = 0;
-            ctrl->cur = dst;
             ctrl->nq = nq;
             ctrl->head = h;
             if (stop) ctrl->stop = 1;
         }
         if (wave < nselNew) {
             // re-solve candidate mySel in full from its parent's saved state
-            const u32 meta = (u32)uni32((int)PM[dst][mySel]);
+            const u32 meta = (u32)uni32((int)PM[mySel]) & META_MASK;
             const int par = (int)(meta >> 8), col = (int)(meta & 255u);
             const int sid = sidBase + wave;
             const NodeRef nd = node_ref(smem + L.offNodes + (size_t)wave * L.nodeStride, p.maxRow);
@@ -711,7 +728,8 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
             const u64 forbN = forbm | bit64(__builtin_amdgcn_readlane(r4c, col));  // cpp:362
             save_node(nd, sid, v, r4c, c4r, forbN, g, col);
             if (lane == 0) {
-                PS[dst][mySel] = (u32)sid | SID_FRESH;  // solved; the next merge turns FRESH into SPLIT
+                PS[mySel] = (unsigned short)sid;  // solved; the next merge turns FRESH into SPLIT
+                PM[mySel] = meta | META_FRESH;
                 if (rc != 0) ctrl->stop = 2;  // cannot happen: the candidate was solved before
             }
         }
