@@ -123,7 +123,7 @@ int kbest_create(kbest_ctx **out, int device)
     }
     if (const char *e = getenv("KBEST_SPEC")) {
         int w = atoi(e);
-        if (w >= 1 && w <= 16) ctx->spec = w;
+        if (w >= 1 && w <= 8) ctx->spec = w;
     }
     if (ctx->spec > ctx->nWaves) ctx->spec = ctx->nWaves;
     int ldsCU = 0;

@@ -167,18 +167,19 @@ __device__ __forceinline__ int dijkstra(const double *Cs, int LDC, const double 
 {
     int slo = 0, shi = KEY_INF_HI;  // spc = +inf
     cand = uni64(cand);
-    u64 scanned = 0, act = cand & ~uni64(forb);
+    u64 act = cand & ~uni64(forb);
+    const u64 cand0 = cand;
     int cur = uni32(start);
     // the bound is computed from LDS values (VGPRs): make it provably uniform or the loop turns divergent
     bound = __hiloint2double(uni32(__double2hiint(bound)), uni32(__double2loint(bound)));
     int bndHi;
     u32 bndLo;
-    to_key(bound, bndHi, bndLo);
+    to_key(EARLY ? bound : d_inf(), bndHi, bndLo);  // bndHi <= KEY_INF_HI: one compare catches "+inf" too
     double delta = 0.0;
+    int closest, cc;
     pred = 0;
-    scannedOut = 0;
-    for (int it = 0;; it++) {
-        if (it > 64) return 1;  // cannot happen (one row leaves `cand` per step); keeps a bug from hanging the GPU
+    // One conditional exit in the common path and one back edge; everything rare sits behind the exit test.
+    do {
         const double cval = Cs[rl + cur * LDC];
         const double ucur = u[cur];
         const double rc = ((delta + cval) - ucur) - v;  // cpp:183 / cpp:313, left to right
@@ -189,28 +190,27 @@ __device__ __forceinline__ int dijkstra(const double *Cs, int LDC, const double 
         const int sg = shi >> 31;
         const int khi = sel32(act, shi ^ (int)((u32)sg >> 1), KEY_INF_HI);  // candidates only
         const int mhi = wave_min_i32(khi);
-        if (mhi >= KEY_INF_HI) { scannedOut = scanned; return 1; }  // minimum is +inf: infeasible
         u64 eq = __ballot(khi == mhi);
-        if (eq & (eq - 1)) {  // several rows share the high word: decide on the low word
+        if (__builtin_expect(__popcll(eq) > 1, 0)) {  // several rows share the high word: decide on the low word
             const u32 t = (u32)sel32(eq, slo ^ sg, -1);
             const u32 mlo = wave_min_u32(t);
             eq &= __ballot(t == mlo);
         }
-        const int closest = __ffsll((long long)eq) - 1;  // lowest row index: cpp:191, 320
+        closest = __builtin_ctzll(eq);  // lowest row index: cpp:191, 320 (eq != 0: some lane holds the minimum)
         delta = __hiloint2double(__builtin_amdgcn_readlane(shi, closest), __builtin_amdgcn_readlane(slo, closest));
-        if (EARLY && mhi >= bndHi) {
-            if (mhi > bndHi || delta > bound) { scannedOut = scanned; return 2; }
+        if (__builtin_expect(mhi >= bndHi, 0)) {
+            scannedOut = cand0 & ~cand;
+            if (mhi >= KEY_INF_HI) return 1;                        // minimum is +inf: infeasible (cpp:197, 327)
+            if (EARLY && (mhi > bndHi || delta > bound)) return 2;  // cannot enter the k best any more
         }
-        const u64 cbit = 1ull << closest;
-        scanned |= cbit;
-        cand &= ~cbit;
-        const int cc = __builtin_amdgcn_readlane(c4r, closest);
-        if (cc < 0) { sinkOut = closest; break; }
-        cur = cc;
+        cand &= ~(1ull << closest);
         act = cand;
-    }
+        cc = __builtin_amdgcn_readlane(c4r, closest);
+        cur = cc;
+    } while (cc >= 0);
+    sinkOut = closest;
     spc = __hiloint2double(shi, slo);
-    scannedOut = scanned;
+    scannedOut = cand0 & ~cand;
     deltaOut = delta;
     return 0;
 }
@@ -243,17 +243,29 @@ __device__ __forceinline__ void dual_update_flip(double *u, int lane, double &v,
 // < from are taken from the caller's partial sum acc0 (the parent's prefix:
 // a child on column c only changes columns >= c).  If prefixOut != nullptr the
 // partial sums before each column are written there (lane = column).
+template <bool PREFIX>
 __device__ __forceinline__ double serial_gain(const double *Cs, int LDC, int lane, int r4c, int from,
                                               int M, double acc0, double *prefixOut)
 {
+    // lanes outside [from, M) contribute +0.0, and x + 0.0 == x exactly for the non-negative partial sums
+    // here, so the chain can run in whole blocks of 8 lanes: the 16 lane reads of a block are independent
+    // and issue back to back, only the 8 adds are a dependent chain, in the reference's order.
     double t = 0.0;
     if (lane >= from && lane < M) t = Cs[r4c + lane * LDC];
+    const int tlo = __double2loint(t), thi = __double2hiint(t);
     double acc = acc0, mine = 0.0;
-    for (int j = from; j < M; j++) {
-        if (lane == j) mine = acc;
-        acc = acc + readlane_f64(t, j);
+    for (int j0 = from & ~7; j0 < M; j0 += 8) {
+        double term[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            term[i] = __hiloint2double(__builtin_amdgcn_readlane(thi, j0 + i), __builtin_amdgcn_readlane(tlo, j0 + i));
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (PREFIX && lane == j0 + i) mine = acc;
+            acc = acc + term[i];
+        }
     }
-    if (prefixOut && lane >= from && lane < M) prefixOut[lane] = mine;
+    if (PREFIX && lane >= from && lane < M) prefixOut[lane] = mine;
     return acc;
 }
 
@@ -472,7 +484,7 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
         if (bad) {
             if (lane == 0) ctrl->stop = 3;
         } else {
-            const double g = serial_gain(Cs, LDC, lane, r4c, 0, M, 0.0, nd.prefix);
+            const double g = serial_gain<true>(Cs, LDC, lane, r4c, 0, M, 0.0, nd.prefix);
             const u64 forb = bit64(__builtin_amdgcn_readlane(r4c, 0));  // cpp:235
             save_node(nd, 0, v, r4c, c4r, forb, g, 0);
             if (lane == 0) {
@@ -508,44 +520,62 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
         const int sidBase = uni32(ctrl->nextSid);
         const double cutG = ctrl->cutoffGain;
         // -- B: children of the nsel solved nodes (shortestPathUpdateCPP, gain only), dynamic queue.
-        //    Work item -> (node, column): node w owns the next (M - activeCol_w) items.
+        //    Work item -> (node, column): node w owns the next (M - activeCol_w) items.  The per-node data a
+        //    wave needs is cached in registers across consecutive items of the same node, and the next queue
+        //    ticket is drawn before the current child is solved so that its LDS round trip is hidden.
+        int itemEnd[8];  // spec <= 8: end of node w's item range (scalar registers)
         int totalItems = 0;
-        for (int w = 0; w < nsel; w++)
-            totalItems += M - uni32(node_ref(smem + L.offNodes + (size_t)w * L.nodeStride, p.maxRow).info[0]);
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            if (w < nsel)
+                totalItems += M - uni32(node_ref(smem + L.offNodes + (size_t)w * L.nodeStride, p.maxRow).info[0]);
+            itemEnd[w] = totalItems;
+        }
         {
             // threshold of the pool: once it holds R candidates only children below its largest can matter
             double T = (nOld >= R) ? PG[head + R - 1] : INF;
             if (useCut && !maximize && cutG < T) T = cutG;
             const double cmaxv = ctrl->cmax;
             int npush = 0;
+            int curW = -1, a = 0, sid = 0, first = 0;
+            double v = 0.0, bound = INF;
+            int c4rP = -1, r4cP = -1;
+            u64 nforb = 0;
+            NodeRef nd = node_ref(smem + L.offNodes, p.maxRow);
+            int ticket = 0;
+            if (lane == 0) ticket = atomicAdd(&ctrl->nextItem, 1);
             for (;;) {
                 KB_T(tItem);
-                int item = 0;
-                if (lane == 0) item = atomicAdd(&ctrl->nextItem, 1);
-                item = uni32(item);
+                const int item = uni32(ticket);
                 if (item >= totalItems) break;
+                if (lane == 0) ticket = atomicAdd(&ctrl->nextItem, 1);  // prefetch the next ticket
                 KB_ACC(4, 1);  // [4] children started
-                int w = 0, first = 0;
-                for (;; w++) {  // locate the node of this item (nsel <= spec is small)
-                    const int nchw = M - uni32(node_ref(smem + L.offNodes + (size_t)w * L.nodeStride, p.maxRow).info[0]);
-                    if (item < first + nchw) break;
-                    first += nchw;
+                int w = 0;
+#pragma unroll
+                for (int i = 0; i < 7; i++) w += (item >= itemEnd[i]) ? 1 : 0;
+                if (w != curW) {  // (re)load this node's data
+                    curW = w;
+                    nd = node_ref(smem + L.offNodes + (size_t)w * L.nodeStride, p.maxRow);
+                    a = uni32(nd.info[0]);
+                    sid = uni32(nd.info[1]);
+                    first = w ? itemEnd[0] : 0;
+#pragma unroll
+                    for (int i = 1; i < 7; i++) first = (w > i) ? itemEnd[i] : first;
+                    const double pgain = nd.gain[0];
+                    nforb = uni64(nd.forb[0]);
+                    v = (lane < D) ? nd.v[lane] : 0.0;
+                    c4rP = (lane < D) ? (int)nd.c4r[lane] : -1;
+                    r4cP = (lane < D) ? (int)nd.r4c[lane] : -1;
+                    // early-termination bound on the Dijkstra distance: child gain = parent gain + delta (up to
+                    // rounding), so delta > (T - parent gain) + margin can never enter the k best.
+                    bound = (prune && T < INF) ? (T - pgain) + 1e-9 * (fabs(T) + cmaxv) : INF;
                 }
-                const NodeRef nd = node_ref(smem + L.offNodes + (size_t)w * L.nodeStride, p.maxRow);
-                const int a = uni32(nd.info[0]);
-                const int sid = uni32(nd.info[1]);
                 const int c = a + (item - first);
                 if (sid == 0 && p.rootColStride > 1 && (c % p.rootColStride) != p.rootColOffset) continue;
-                const double pgain = nd.gain[0];
-                const double v = (lane < D) ? nd.v[lane] : 0.0;
-                const int c4rP = (lane < D) ? nd.c4r[lane] : -1;
-                const int r4cP = (lane < D) ? nd.r4c[lane] : -1;
-                // early-termination bound on the Dijkstra distance: child gain = parent gain + delta (up to
-                // rounding), so delta > (T - parent gain) + margin can never enter the k best.
-                const double bound = (prune && T < INF) ? (T - pgain) + 1e-9 * (fabs(T) + cmaxv) : INF;
+                const double pfx = nd.prefix[c];
                 const int fr = __builtin_amdgcn_readlane(r4cP, c);           // row freed: cpp:277-278
                 const u64 cand = __ballot(lane < D && c4rP >= c);             // rows of columns >= c: cpp:480-488, 525-527
-                const u64 forbm = (c == a) ? uni64(nd.forb[0]) : bit64(fr);   // cpp:490 / cpp:510-516
+                const u64 forbm = (c == a) ? nforb : bit64(fr);                // cpp:490 / cpp:510-516
                 const int c4r = (lane == fr) ? -1 : c4rP;
                 double spc, delta;
                 int pred, sink = 0;
@@ -567,7 +597,7 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
                     r4c = (lane == cc) ? r : r4c;
                     r = nxt;
                 } while (cc != c && ++guard < 64);
-                const double g = serial_gain(Cs, LDC, lane, r4c, c, M, nd.prefix[c], nullptr);
+                const double g = serial_gain<false>(Cs, LDC, lane, r4c, c, M, pfx, nullptr);
                 if (useCut && (maximize ? (g < cutG) : (g > cutG))) continue;  // cutHyp, cpp:496/521
                 npush++;
                 KB_ACC(10, __builtin_readcyclecounter() - tDij1);  // [10] flip + exact gain of completed children
@@ -724,7 +754,7 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
             const int rc = dijkstra<false>(Cs, LDC, nd.u, rl, lane, v, c4r, cand, forbm, col, INF, spc, pred, scanned,
                                            delta, sink);
             if (rc == 0) dual_update_flip(nd.u, lane, v, c4r, r4c, spc, pred, scanned, delta, sink, col);
-            const double g = serial_gain(Cs, LDC, lane, r4c, 0, M, 0.0, nd.prefix);
+            const double g = serial_gain<true>(Cs, LDC, lane, r4c, 0, M, 0.0, nd.prefix);
             const u64 forbN = forbm | bit64(__builtin_amdgcn_readlane(r4c, col));  // cpp:362
             save_node(nd, sid, v, r4c, c4r, forbN, g, col);
             if (lane == 0) {
