@@ -108,7 +108,7 @@ def main():
     d_gain = torch.empty((B, k), dtype=torch.float64, device=dev)
     d_nf = torch.empty(B, dtype=torch.int32, device=dev)
     d_pushed = torch.zeros(B, dtype=torch.int64, device=dev)
-    d_allgain = torch.empty((world, B, k), dtype=torch.float64, device=dev) if world > 1 else None
+    d_allgain = torch.empty((world * B, k), dtype=torch.float64, device=dev) if world > 1 else None
 
     eng = pk.KBestEngine(local)
     eng.reserve(B, N, k)

@@ -13,8 +13,6 @@
  *        asgnBB (assignment.cpp:750, k=1, maximize).
  *   kbest_weights_batch_f64
  *        batched form of  assignmentProb (assignment.h:11, assignment.cpp:547-683)
- *   kbest_condition_costs_f64
- *        conditionCosts   (assignment.h:26, assignment.cpp:439-525)
  *
  * Conventions kept from the reference: cost matrices are column-major
  * C[row + col*numRow] with numRow >= numCol (shortestPathCPP.hpp:185-190);

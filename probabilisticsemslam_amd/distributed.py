@@ -1,0 +1,79 @@
+"""Multi-GPU layer of the k-best path: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI
+on the GPU node, "gloo" in the CPU tests).  SURVEY 8(e).
+
+The path shards two ways, both without any collective inside the solve:
+
+* batch mode (default): the B cost matrices are independent, rank g solves the contiguous block
+  ``shard_range(B, g, G)``.  The only exchange is the final all-gather of the per-rank result tables
+  (``gather_batch``) so that every rank holds the global table.
+* subtree mode (few large matrices): Murty's partition of the root is disjoint, so rank g expands only the
+  root children on columns c with c % G == g (``root_shard=(g, G)`` of the engine) and enumerates its own
+  k best; the global k best are the k smallest of {root} U all per-rank lists (``merge_subtree_topk``):
+  one all-gather of (gain[k], row4col[k, M], nf) per matrix, then a k-way merge.
+
+Nothing here computes assignments: tensors come from the engine (GPU) or, in the CPU tests, from the checker.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(B: int, rank: int, world: int):
+    """Contiguous block of problems owned by `rank` (sizes differ by at most one)."""
+    base, rem = divmod(B, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def _all_gather(t: torch.Tensor, world: int) -> torch.Tensor:
+    t = t.contiguous()
+    if t.dim() == 0:
+        t = t.view(1)
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t)  # concatenated along dim 0 (the layout gloo and nccl both accept)
+    return out.view((world,) + tuple(t.shape))
+
+
+def gather_batch(gain: torch.Tensor, row4col: torch.Tensor, nf: torch.Tensor, B: int):
+    """Batch mode: every rank passes its own shard (padded to the largest shard); returns the global
+    (gain[B,k], row4col[B,k,M], nf[B]) on every rank."""
+    world = dist.get_world_size()
+    per = max(shard_range(B, r, world)[1] - shard_range(B, r, world)[0] for r in range(world))
+
+    def pad(t):
+        if t.shape[0] == per:
+            return t
+        z = torch.zeros((per - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        return torch.cat([t, z], 0)
+
+    G, R, N = _all_gather(pad(gain), world), _all_gather(pad(row4col), world), _all_gather(pad(nf), world)
+    parts = [(shard_range(B, r, world)[1] - shard_range(B, r, world)[0]) for r in range(world)]
+    cat = lambda X: torch.cat([X[r, :parts[r]] for r in range(world)], 0)  # noqa: E731
+    return cat(G), cat(R), cat(N)
+
+
+def merge_subtree_topk(gain: torch.Tensor, row4col: torch.Tensor, nf: torch.Tensor, k: int, maximize: bool = False):
+    """Subtree mode.  gain[B,k], row4col[B,k,M], nf[B] are this rank's k best of ITS root subtrees; slot 0 is
+    the root itself on every rank.  Returns the global (gain[B,k], row4col[B,k,M], nf[B]), identical on all
+    ranks: root first, then the k-1 best of the union of the ranks' slots 1.. in increasing cost
+    (decreasing profit when maximize)."""
+    world = dist.get_world_size()
+    G = _all_gather(gain, world)        # [W, B, k]
+    R = _all_gather(row4col, world)     # [W, B, k, M]
+    Nf = _all_gather(nf, world)         # [W, B]
+    W, B, kk = G.shape
+    bad = float("-inf") if maximize else float("inf")
+    slot = torch.arange(kk, device=G.device).view(1, 1, kk)
+    valid = (slot >= 1) & (slot < Nf.unsqueeze(-1))
+    cand = torch.where(valid, G, torch.full_like(G, bad)).permute(1, 0, 2).reshape(B, W * kk)
+    order = torch.argsort(cand, dim=1, descending=maximize, stable=True)[:, : k - 1]
+    cg = torch.gather(cand, 1, order)
+    rows = R.permute(1, 0, 2, 3).reshape(B, W * kk, -1)
+    cr = torch.gather(rows, 1, order.unsqueeze(-1).expand(-1, -1, rows.shape[-1]))
+    out_g = torch.cat([G[0, :, :1], cg], 1)
+    out_r = torch.cat([R[0, :, :1], cr], 1)
+    n_other = valid.sum(dim=(0, 2))
+    feasible = Nf[0] > 0
+    out_nf = torch.where(feasible, torch.clamp(1 + n_other, max=k), torch.zeros_like(n_other)).to(nf.dtype)
+    return out_g, out_r, out_nf

@@ -1,15 +1,19 @@
-"""Summarise the rocprofv3 CSVs written by tools/prof.sh (per-kernel durations and PMC sums)."""
+"""Summarise the rocprofv3 CSVs written by tools/prof.sh: per-kernel durations, PMC means, HBM traffic.
+The bench run under the profiler makes 1 untimed no-prune dispatch (push counting), W warm-up dispatches and K timed
+ones; only the last K dispatches of the k-best kernel are the measured workload, so means are taken over those."""
 import csv
 import glob
+import json
 import os
 import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 
 
 def rows(pattern):
-    for f in glob.glob(os.path.join(out, pattern), recursive=True):
+    for f in sorted(glob.glob(os.path.join(out, pattern), recursive=True)):
         with open(f) as fh:
             for r in csv.DictReader(fh):
                 yield r
@@ -17,18 +21,40 @@ def rows(pattern):
 
 dur = defaultdict(list)
 for r in rows("trace/**/*kernel_trace.csv"):
-    dur[r["Kernel_Name"][:60]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-print("== kernel durations (us) from --kernel-trace")
-for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
-    print(f"{k:60s} n={len(v):4d} avg={sum(v)/len(v):12.1f} min={min(v):12.1f} max={max(v):12.1f} total={sum(v):12.1f}")
+    dur[r["Kernel_Name"][:60]].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+print("== kernel durations (us) from --kernel-trace --stats")
+res = {}
+for k, v in sorted(dur.items(), key=lambda kv: -sum(d for _, d in kv[1])):
+    v.sort()
+    d = [x for _, x in v]
+    line = f"{k:60s} n={len(d):4d} avg={sum(d)/len(d):12.1f} min={min(d):12.1f} max={max(d):12.1f} total={sum(d):12.1f}"
+    if "kbest_kernel" in k:
+        last = d[-K:]
+        line += f"  | last {K} (timed workload): avg={sum(last)/len(last):.1f}"
+        res["kernel_avg_us_timed"] = sum(last) / len(last)
+    print(line)
+pm = {}
 for d in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
     acc = defaultdict(lambda: defaultdict(list))
     for r in rows(f"{d}/**/*counter_collection.csv"):
-        acc[r["Kernel_Name"][:40]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        acc[r["Kernel_Name"][:40]][r["Counter_Name"]].append((int(r.get("Dispatch_Id", 0)), float(r["Counter_Value"])))
     if acc:
-        print(f"== {d}: per-dispatch mean of each counter")
+        print(f"== {d}: mean over the last {K} dispatches of the k-best kernel")
     for k, cs in acc.items():
         if "kbest" not in k:
             continue
         for c, v in sorted(cs.items()):
-            print(f"{k:40s} {c:24s} n={len(v):3d} mean={sum(v)/len(v):.6g}")
+            v.sort()
+            last = [x for _, x in v][-K:]
+            pm[c] = sum(last) / len(last)
+            print(f"{k:40s} {c:24s} n={len(last):3d} mean={pm[c]:.6g}")
+if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
+    # MI355X_MICROARCH.md (HBM): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reads 1/2 of the bytes of a
+    # coalesced stream -> double it; WRITE_SIZE reads exactly.  Separate --pmc passes (TCC slots).
+    traffic = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
+    print(f"== HBM traffic per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024 = {traffic:.4g} bytes "
+          f"(FETCH_SIZE {pm['FETCH_SIZE']:.6g} KiB, WRITE_SIZE {pm['WRITE_SIZE']:.6g} KiB)")
+    res.update({"bytes_per_launch": traffic, "FETCH_SIZE_KiB": pm["FETCH_SIZE"], "WRITE_SIZE_KiB": pm["WRITE_SIZE"],
+                "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024  [gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md HBM]"})
+res["pmc"] = pm
+json.dump(res, open(os.path.join(out, "summary.json"), "w"), indent=1)
