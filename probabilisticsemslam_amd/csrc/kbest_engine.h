@@ -62,7 +62,7 @@ __host__ __device__ inline long long state_stride(int maxRow)
 
 // LDS carve-up of one workgroup (= one cost matrix).
 struct Lds {
-    int offC, offNodes, nodeStride, offFreshG, offFreshM, offPoolG, offPoolM, offPoolS, offCtrl, total;
+    int offC, offNodes, nodeStride, offFreshG, offFreshM, offPoolG, offPoolM, offPoolS, offSurv, offLbKey, offCtrl, total;
 };
 
 __host__ __device__ inline Lds lds_layout(int maxRow, int k, int spec)
@@ -75,9 +75,11 @@ __host__ __device__ inline Lds lds_layout(int maxRow, int k, int spec)
     L.offNodes = o;      o += spec * L.nodeStride;   // solved hypotheses waiting to be split
     L.offFreshG = o;     o += (spec * 64 > 16 ? spec * 64 : 16) * 8;  // surviving children of this round: gain
     L.offPoolG = o;      o += k * 8;                 // sorted candidate pool: gain
+    L.offLbKey = o;      o += spec * 64 * 8;         // first-step lower bounds of the current nodes' children
     L.offFreshM = o;     o += spec * 64 * 4;         //   (parent state, column)
     L.offPoolM = o;      o += k * 4;                 //   (parent state, column, flags)
     L.offPoolS = o;      o += k * 2;                 //   own state slot
+    L.offSurv = o;       o += spec * 64 * 2;         // children that passed the first-step filter (node, column)
     o = (o + 7) & ~7;
     L.offCtrl = o;       o += 80;                    // struct Ctrl
     L.total = (o + 15) & ~15;

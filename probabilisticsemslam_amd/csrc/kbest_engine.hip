@@ -314,6 +314,7 @@ struct Ctrl {
     int nextItem; // work queue of phase B
     int nextSid;  // next free hypothesis-state slot
     int nFresh;   // surviving children appended this round
+    int nSurv;    // children that passed the first-step filter this round
 };
 static_assert(sizeof(Ctrl) <= 80, "Ctrl must fit the LDS slot reserved by lds_layout");
 
@@ -376,6 +377,8 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
     unsigned short *PS = reinterpret_cast<unsigned short *>(smem + L.offPoolS);
     unsigned short *slotSid = p.slotSid + (long long)blockIdx.x * k;  // global: state slot of each output slot
     double *red = freshG;  // cross-wave reduction scratch of phase 0
+    unsigned short *surv = reinterpret_cast<unsigned short *>(smem + L.offSurv);
+    u64 *lbKey = reinterpret_cast<u64 *>(smem + L.offLbKey);  // first-step minima of the current nodes' children
     Ctrl *ctrl = reinterpret_cast<Ctrl *>(smem + L.offCtrl);
 
     const double *Cg = p.cost + (p.costOff ? p.costOff[b] : (long long)b * p.maxRow * p.maxCol);
@@ -423,6 +426,7 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
         cm = -wave_min_f64(-cm);
         if (lane == 0) red[wave] = cm;
         __syncthreads();
+        for (int i = tid; i < spec * 64; i += NT) lbKey[i] = ~0ull;
         if (tid == 0) {
             for (int w = 1; w < NW; w++) cm = red[w] > cm ? red[w] : cm;
             ctrl->cmax = cm;
@@ -436,6 +440,7 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
             ctrl->nextItem = 0;
             ctrl->nextSid = 1;
             ctrl->nFresh = 0;
+            ctrl->nSurv = 0;
         }
         __syncthreads();
     }
@@ -519,25 +524,97 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
         const int nOld = nqEnd - head;
         const int sidBase = uni32(ctrl->nextSid);
         const double cutG = ctrl->cutoffGain;
-        // -- B: children of the nsel solved nodes (shortestPathUpdateCPP, gain only), dynamic queue.
-        //    Work item -> (node, column): node w owns the next (M - activeCol_w) items.  The per-node data a
-        //    wave needs is cached in registers across consecutive items of the same node, and the next queue
-        //    ticket is drawn before the current child is solved so that its LDS round trip is hidden.
-        int itemEnd[8];  // spec <= 8: end of node w's item range (scalar registers)
-        int totalItems = 0;
-#pragma unroll
-        for (int w = 0; w < 8; w++) {
-            if (w < nsel)
-                totalItems += M - uni32(node_ref(smem + L.offNodes + (size_t)w * L.nodeStride, p.maxRow).info[0]);
-            itemEnd[w] = totalItems;
-        }
+        // -- B1: first-step filter.  56 % of all children (64x64, k=200) are abandoned by the early-termination
+        //    test at their very first Dijkstra step, i.e. because  min over candidate rows of (C[r,c] - u[c] - v[r])
+        //    already exceeds the bound.  That minimum is computed here for ALL children of a node at once, one wave
+        //    per node with lane = child column walking the rows (conflict-free thanks to the odd tile stride), and
+        //    only the survivors are queued for a wave of their own.  It is the same test on the same numbers as
+        //    step 1 of dijkstra<true> (delta = 0: (0 + C) - u - v), so the set of children that go on is unchanged.
+        // threshold of the pool: once it holds R candidates only children below its largest can matter
+        double T = (nOld >= R) ? PG[head + R - 1] : INF;
+        if (useCut && !maximize && cutG < T) T = cutG;
+        const double cmaxv = ctrl->cmax;
         {
-            // threshold of the pool: once it holds R candidates only children below its largest can matter
-            double T = (nOld >= R) ? PG[head + R - 1] : INF;
-            if (useCut && !maximize && cutG < T) T = cutG;
-            const double cmaxv = ctrl->cmax;
+            // all NW waves take part: node = wave % nsel, and the waves of one node split its columns j.
+            // Walking the parent's columns j >= a instead of the rows makes the candidate test a scalar lane mask:
+            // row r = row4col[j] is a candidate of child c iff c < j (rows of columns >= c, minus the row the child
+            // frees itself, cpp:480-488 / 510-516); for the child on the active column (lane 0) it is a candidate
+            // unless it is in the parent's accumulated forbidden set (cpp:490).
+            const int parts = NW / nsel;
+            const int nodeI = wave % nsel, part = wave / nsel;
+            if (part < parts) {
+                const NodeRef nd = node_ref(smem + L.offNodes + (size_t)nodeI * L.nodeStride, p.maxRow);
+                const int a = uni32(nd.info[0]);
+                const u64 nforb = uni64(nd.forb[0]);
+                const int c = a + lane;  // this lane's child column
+                const int cc = c < D ? c : D - 1;
+                const double uc = nd.u[cc];
+                const double *Ccol = Cs + cc * LDC;
+                const double vrow = (lane < D) ? nd.v[lane] : 0.0;        // lane = row
+                const int r4cP = (lane < D) ? (int)nd.r4c[lane] : 0;      // lane = column
+                const int span = D - a;
+                const int jBeg = a + (span * part) / parts, jEnd = a + (span * (part + 1)) / parts;
+                int mlo = 0, mhi = KEY_INF_HI;  // running minimum (+inf)
+                for (int j0 = jBeg; j0 < jEnd; j0 += 4) {
+                    double cv[4], vr[4];
+                    u64 lm[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {  // independent LDS reads in flight
+                        const int j = (j0 + i < jEnd) ? j0 + i : jEnd - 1;
+                        const int r = __builtin_amdgcn_readlane(r4cP, j);
+                        vr[i] = readlane_f64(vrow, r);
+                        cv[i] = Ccol[r];
+                        const int nlow = j - a;  // lanes 1 .. nlow-1 are the children c with a < c < j
+                        u64 mk = (nlow >= 64) ? ~0ull : ((1ull << nlow) - 1ull);
+                        mk &= ~1ull;
+                        if (!((nforb >> r) & 1ull)) mk |= 1ull;
+                        lm[i] = (j0 + i < jEnd) ? mk : 0ull;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const double rc = (cv[i] - uc) - vr[i];  // ((0 + C) - u) - v, cpp:313 with delta = 0
+                        const u64 upd = __ballot(rc < __hiloint2double(mhi, mlo)) & lm[i];
+                        mlo = sel32(upd, __double2loint(rc), mlo);
+                        mhi = sel32(upd, __double2hiint(rc), mhi);
+                    }
+                }
+                const double m = __hiloint2double(mhi, mlo);
+                // combine the row parts: integer min of the order-preserving key
+                int khi;
+                u32 klo;
+                to_key(m, khi, klo);
+                const u64 key = ((u64)((u32)khi ^ 0x80000000u) << 32) | klo;  // signed high word -> unsigned order
+                if (c < M) atomicMin(&lbKey[nodeI * 64 + lane], key);
+            }
+        }
+        __syncthreads();
+        if (wave < nsel) {  // one wave per node: survivors = finite minimum (else infeasible, cpp:327) within the bound
+            const NodeRef nd = node_ref(smem + L.offNodes + (size_t)wave * L.nodeStride, p.maxRow);
+            const int a = uni32(nd.info[0]);
+            const int sid = uni32(nd.info[1]);
+            const double pgain = nd.gain[0];
+            const double bound = (prune && T < INF) ? (T - pgain) + 1e-9 * (fabs(T) + cmaxv) : INF;
+            const int c = a + lane;
+            const bool live = c < M && !(sid == 0 && p.rootColStride > 1 && (c % p.rootColStride) != p.rootColOffset);
+            const u64 key = lbKey[wave * 64 + lane];
+            const double m = from_key((int)((u32)(key >> 32) ^ 0x80000000u), (u32)key);
+            lbKey[wave * 64 + lane] = ~0ull;  // ready for the next round
+            const bool keep = live && m < INF && !(m > bound);
+            const u64 km = __ballot(keep);
+            int base = 0;
+            if (lane == 0 && km) base = atomicAdd(&ctrl->nSurv, __popcll(km));
+            base = uni32(base);
+            if (keep) surv[base + __popcll(km & ((1ull << lane) - 1ull))] = (unsigned short)((wave << 8) | c);
+            KB_ACC(14, __popcll(__ballot(live)));  // [14] children before the filter
+        }
+        __syncthreads();
+        // -- B2: surviving children (shortestPathUpdateCPP, gain only), dynamic queue over the survivor list.  The
+        //    per-node data a wave needs is cached in registers across consecutive items of the same node, and the
+        //    next queue ticket is drawn before the current child is solved so that its LDS round trip is hidden.
+        const int totalItems = uni32(ctrl->nSurv);
+        {
             int npush = 0;
-            int curW = -1, a = 0, sid = 0, first = 0;
+            int curW = -1, a = 0, sid = 0;
             double v = 0.0, bound = INF;
             int c4rP = -1, r4cP = -1;
             u64 nforb = 0;
@@ -550,17 +627,13 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
                 if (item >= totalItems) break;
                 if (lane == 0) ticket = atomicAdd(&ctrl->nextItem, 1);  // prefetch the next ticket
                 KB_ACC(4, 1);  // [4] children started
-                int w = 0;
-#pragma unroll
-                for (int i = 0; i < 7; i++) w += (item >= itemEnd[i]) ? 1 : 0;
+                const int sv = uni32((int)surv[item]);
+                const int w = sv >> 8, c = sv & 255;
                 if (w != curW) {  // (re)load this node's data
                     curW = w;
                     nd = node_ref(smem + L.offNodes + (size_t)w * L.nodeStride, p.maxRow);
                     a = uni32(nd.info[0]);
                     sid = uni32(nd.info[1]);
-                    first = w ? itemEnd[0] : 0;
-#pragma unroll
-                    for (int i = 1; i < 7; i++) first = (w > i) ? itemEnd[i] : first;
                     const double pgain = nd.gain[0];
                     nforb = uni64(nd.forb[0]);
                     v = (lane < D) ? nd.v[lane] : 0.0;
@@ -570,8 +643,6 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
                     // rounding), so delta > (T - parent gain) + margin can never enter the k best.
                     bound = (prune && T < INF) ? (T - pgain) + 1e-9 * (fabs(T) + cmaxv) : INF;
                 }
-                const int c = a + (item - first);
-                if (sid == 0 && p.rootColStride > 1 && (c % p.rootColStride) != p.rootColOffset) continue;
                 const double pfx = nd.prefix[c];
                 const int fr = __builtin_amdgcn_readlane(r4cP, c);           // row freed: cpp:277-278
                 const u64 cand = __ballot(lane < D && c4rP >= c);             // rows of columns >= c: cpp:480-488, 525-527
@@ -721,6 +792,7 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
             ctrl->nextSid = sidBase + nselNew;
             ctrl->nextItem = 0;
             ctrl->nFresh = 0;
+            ctrl->nSurv = 0;
             ctrl->nq = nq;
             ctrl->head = h;
             if (stop) ctrl->stop = 1;
