@@ -23,7 +23,8 @@ struct kbest_ctx {
     int nWaves = 8;   // waves per cost matrix (workgroup = nWaves * 64 threads)
     int spec = 0;     // candidates re-solved / split per round; 0 = choose per launch (choose_spec)
     int ldsPerCU = 160 * 1024;
-    int extraStates = 64;  // state slots beyond k per matrix (room for speculative splits)
+    int extraStates = 64;  // lazy state slots beyond k per matrix (room for speculative re-solves)
+    int eagerStates = 1024; // state slots per matrix for children that are kept in full when they are found
     unsigned long long *prof = nullptr;  // diagnostic builds only (kbest_set_profile_buffer)
     std::string err;
     std::mutex mu;  // shim entry points may be called from several host threads
@@ -119,7 +120,11 @@ int kbest_create(kbest_ctx **out, int device)
         ctx->ldsLimit = lds;
     if (const char *e = getenv("KBEST_NWAVES")) {  // tuning knobs (defaults are the tuned values)
         int w = atoi(e);
-        if (w == 4 || w == 8 || w == 16) ctx->nWaves = w;
+        if (w == 4 || w == 8 || w == 10 || w == 12 || w == 16) ctx->nWaves = w;
+    }
+    if (const char *e = getenv("KBEST_EAGER")) {
+        int w = atoi(e);
+        if (w >= 0 && w <= 60000) ctx->eagerStates = w;
     }
     if (const char *e = getenv("KBEST_SPEC")) {
         int w = atoi(e);
@@ -154,7 +159,7 @@ int kbest_set_profile_buffer(kbest_ctx *ctx, void *d_buf)
 int kbest_reserve(kbest_ctx *ctx, int B, int maxRow, int k)
 {
     if (!ctx || B < 0 || maxRow < 1 || k < 1) return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_reserve: bad argument");
-    const size_t nStates = (size_t)B * (size_t)(k + ctx->extraStates) * (size_t)kb::state_stride(maxRow);
+    const size_t nStates = (size_t)B * (size_t)(k + ctx->extraStates + ctx->eagerStates) * (size_t)kb::state_stride(maxRow);
     const size_t need = nStates + (size_t)B * (size_t)k * 2 + 256;
     if (need <= ctx->statesBytes) { ctx->slotSidOffset = (nStates + 127) & ~(size_t)127; return KBEST_OK; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -177,7 +182,7 @@ int kbest_batch_f64_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRo
     if ((d_nRow == nullptr) != (d_nCol == nullptr))
         return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_batch_f64_dev: give both nRow and nCol or neither");
     if (maxRow > KBEST_MAX_DIM) return fail(ctx, KBEST_ERR_UNSUPPORTED, "numRow > KBEST_MAX_DIM");
-    if (k + ctx->extraStates > 65535) return fail(ctx, KBEST_ERR_UNSUPPORTED, "k too large");
+    if (k + ctx->extraStates + ctx->eagerStates > 65534) return fail(ctx, KBEST_ERR_UNSUPPORTED, "k too large");
     // counting the reference's pushes needs the reference's exact order of splits: no speculation
     const int spec = (opts->flags & KBEST_FLAG_COUNT_PUSHED) ? 1 : choose_spec(ctx, maxRow, k);
     if (k > 4 * ctx->nWaves * 64) return fail(ctx, KBEST_ERR_UNSUPPORTED, "k too large for the in-register pool merge");
@@ -210,7 +215,8 @@ int kbest_batch_f64_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRo
     p.pushed = reinterpret_cast<long long *>(d_pushed);
     p.states = ctx->states;
     p.stateStride = kb::state_stride(maxRow);
-    p.statesPerProblem = k + ctx->extraStates;
+    p.statesPerProblem = k + ctx->extraStates + ctx->eagerStates;
+    p.lazyStates = k + ctx->extraStates;
     p.spec = spec;
     p.prof = ctx->prof;
     p.slotSid = reinterpret_cast<unsigned short *>(ctx->states + ctx->slotSidOffset);

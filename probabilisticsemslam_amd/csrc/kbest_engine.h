@@ -34,7 +34,8 @@ struct Params {
     long long *pushed;        // [B] or nullptr
     unsigned char *states;    // workspace: [B][statesPerProblem] saved hypotheses, stateStride bytes each
     long long stateStride;
-    int statesPerProblem;     // >= k; the surplus bounds how far candidates are split speculatively
+    int statesPerProblem;     // all state slots of one matrix: [0, lazyStates) + the eager region behind it
+    int lazyStates;           // >= k: slots for the root and for candidates that are re-solved when selected
     int spec;                 // candidates re-solved / split per round (1 = the reference's order exactly)
     unsigned long long *prof; // [B][16] cycle stamps; only read by diagnostic builds (make PROFILE=1)
     unsigned short *slotSid;  // workspace: [B][k] state slot of each output slot
@@ -56,13 +57,14 @@ struct WeightParams {
 // forbidden-row mask, gain, activeCol.
 __host__ __device__ inline long long state_stride(int maxRow)
 {
-    // rounded to whole 128-byte lines: neighbouring states never share a cache line
-    return ((((long long)18 * maxRow + 7) & ~7LL) + 24 + 127) & ~127LL;
+    // u, v, prefix (fp64), row4col, col4row (u8), forbidden mask, gain, activeCol; rounded to whole 128-byte
+    // lines: neighbouring states never share a cache line
+    return ((((long long)26 * maxRow + 7) & ~7LL) + 24 + 127) & ~127LL;
 }
 
 // LDS carve-up of one workgroup (= one cost matrix).
 struct Lds {
-    int offC, offNodes, nodeStride, offFreshG, offFreshM, offPoolG, offPoolM, offPoolS, offSurv, offLbKey, offCtrl, total;
+    int offC, offNodes, nodeStride, offFreshG, offFreshM, offPoolG, offPoolM, offPoolS, offSurv, offLbKey, offFreshS, offCtrl, total;
 };
 
 __host__ __device__ inline Lds lds_layout(int maxRow, int k, int spec)
@@ -80,8 +82,9 @@ __host__ __device__ inline Lds lds_layout(int maxRow, int k, int spec)
     L.offPoolM = o;      o += k * 4;                 //   (parent state, column, flags)
     L.offPoolS = o;      o += k * 2;                 //   own state slot
     L.offSurv = o;       o += spec * 64 * 2;         // children that passed the first-step filter (node, column)
+    L.offFreshS = o;     o += spec * 64 * 2;         //   own state slot of the surviving children
     o = (o + 7) & ~7;
-    L.offCtrl = o;       o += 80;                    // struct Ctrl
+    L.offCtrl = o;       o += 144;                   // struct Ctrl
     L.total = (o + 15) & ~15;
     return L;
 }

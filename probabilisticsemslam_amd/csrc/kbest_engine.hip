@@ -245,15 +245,17 @@ __device__ __forceinline__ void dual_update_flip(double *u, int lane, double &v,
 // partial sums before each column are written there (lane = column).
 template <bool PREFIX>
 __device__ __forceinline__ double serial_gain(const double *Cs, int LDC, int lane, int r4c, int from,
-                                              int M, double acc0, double *prefixOut)
+                                              int M, double acc0, double &mine)
 {
     // lanes outside [from, M) contribute +0.0, and x + 0.0 == x exactly for the non-negative partial sums
     // here, so the chain can run in whole blocks of 8 lanes: the 16 lane reads of a block are independent
     // and issue back to back, only the 8 adds are a dependent chain, in the reference's order.
+    // PREFIX: lane j (from <= j < M) also gets the partial sum before column j in `mine`.
     double t = 0.0;
     if (lane >= from && lane < M) t = Cs[r4c + lane * LDC];
     const int tlo = __double2loint(t), thi = __double2hiint(t);
-    double acc = acc0, mine = 0.0;
+    double acc = acc0;
+    mine = acc0;
     for (int j0 = from & ~7; j0 < M; j0 += 8) {
         double term[8];
 #pragma unroll
@@ -265,7 +267,6 @@ __device__ __forceinline__ double serial_gain(const double *Cs, int LDC, int lan
             acc = acc + term[i];
         }
     }
-    if (PREFIX && lane >= from && lane < M) prefixOut[lane] = mine;
     return acc;
 }
 
@@ -305,23 +306,26 @@ struct Ctrl {
     double cutoffGain;  // workMem.cutoffGain (cpp:681/684)
     double cmax;        // largest finite shifted cost (scale of the safety margin)
     double gain0u;      // gainBest[0]
-    int nq;       // end of the valid pool range in the current buffer
-    int head;     // start of it (entries before head were emitted)
-    int emitted;  // output slots filled so far
-    int stop;     // 1: finished   2: internal error   3: infeasible root
+    int nq;        // end of the valid pool range
+    int head;      // start of it (entries before head were emitted)
+    int emitted;   // output slots filled so far
+    int stop;      // 1: finished   2: internal error   3: infeasible root
     int pushed;
-    int nsel;     // nodes solved this round = nodes to split next
-    int nextItem; // work queue of phase B
-    int nextSid;  // next free hypothesis-state slot
-    int nFresh;   // surviving children appended this round
-    int nSurv;    // children that passed the first-step filter this round
+    int nsel;      // nodes to split in this round
+    int nextItem;  // work queue of phase B
+    int nextSid;   // next free state slot of the lazy region [0, lazyStates)
+    int nextEager; // next free state slot of the eager region [lazyStates, statesPerProblem)
+    int nFresh;    // surviving children appended this round
+    int nSurv;     // children that passed the first-step filter this round
+    int pad;
+    int selIdx[8]; // pool index of each node selected in the last A phase (they are split in the next B)
+    int selSid[8]; // and its state slot
 };
-static_assert(sizeof(Ctrl) <= 80, "Ctrl must fit the LDS slot reserved by lds_layout");
+static_assert(sizeof(Ctrl) <= 144, "Ctrl must fit the LDS slot reserved by lds_layout");
 
 // pool entry: gain (fp64), meta (u32: column | parent state << 8 | flags), own state slot (u16)
-constexpr unsigned short SID_NONE = 0xFFFFu;  // not solved yet
-constexpr u32 META_SPLIT = 0x80000000u;        // solved AND children already merged
-constexpr u32 META_FRESH = 0x40000000u;        // solved in the current round (children not generated yet)
+constexpr unsigned short SID_NONE = 0xFFFFu;  // no saved state: re-solve from the parent when selected
+constexpr u32 META_SPLIT = 0x80000000u;        // children already generated and merged
 constexpr u32 META_MASK = 0x00FFFFFFu;
 
 // a solved hypothesis waiting to be split, in LDS
@@ -379,6 +383,7 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
     double *red = freshG;  // cross-wave reduction scratch of phase 0
     unsigned short *surv = reinterpret_cast<unsigned short *>(smem + L.offSurv);
     u64 *lbKey = reinterpret_cast<u64 *>(smem + L.offLbKey);  // first-step minima of the current nodes' children
+    unsigned short *freshS = reinterpret_cast<unsigned short *>(smem + L.offFreshS);
     Ctrl *ctrl = reinterpret_cast<Ctrl *>(smem + L.offCtrl);
 
     const double *Cg = p.cost + (p.costOff ? p.costOff[b] : (long long)b * p.maxRow * p.maxCol);
@@ -439,33 +444,49 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
             ctrl->nsel = 0;
             ctrl->nextItem = 0;
             ctrl->nextSid = 1;
+            ctrl->nextEager = p.lazyStates;
             ctrl->nFresh = 0;
             ctrl->nSurv = 0;
+            ctrl->selIdx[0] = -1;
+            ctrl->selSid[0] = 0;
         }
         __syncthreads();
     }
 
     unsigned char *stBase = p.states + (long long)b * maxSid * p.stateStride;
-    const int offTail = (18 * p.maxRow + 7) & ~7;
+    // saved hypothesis (HBM): u[D'] v[D'] prefix[D'] (fp64) | row4col[D'] col4row[D'] (u8) | forb, gain, activeCol
     const long long outBase = (long long)b * k;
+    const int DS = p.maxRow;
+    const int offR4C = 24 * DS, offC4R = 25 * DS, offTail = (26 * DS + 7) & ~7;
 
-    // Store the hypothesis this wave holds (u already in nd.u) as state `sid` and publish it as node nd.
-    auto save_node = [&](const NodeRef &nd, int sid, double v, int r4c, int c4r, u64 forb, double gain, int activeCol) {
+    // Write a full hypothesis to state slot `sid`.
+    auto store_state = [&](int sid, double u, double v, double pfx, int r4c, int c4r, u64 forb, double gain, int activeCol) {
         unsigned char *st = stBase + (long long)sid * p.stateStride;
-        double *su = reinterpret_cast<double *>(st);
+        double *sd = reinterpret_cast<double *>(st);
         if (lane < D) {
-            su[lane] = nd.u[lane];
-            su[p.maxRow + lane] = v;
-            st[16 * p.maxRow + lane] = (unsigned char)r4c;
-            st[17 * p.maxRow + lane] = (unsigned char)c4r;
-            nd.v[lane] = v;
-            nd.r4c[lane] = (unsigned char)r4c;
-            nd.c4r[lane] = (unsigned char)c4r;
+            sd[lane] = u;
+            sd[DS + lane] = v;
+            sd[2 * DS + lane] = pfx;
+            st[offR4C + lane] = (unsigned char)r4c;
+            st[offC4R + lane] = (unsigned char)c4r;
         }
         if (lane == 0) {
             *reinterpret_cast<u64 *>(st + offTail) = forb;
             *reinterpret_cast<double *>(st + offTail + 8) = gain;
             *reinterpret_cast<int *>(st + offTail + 16) = activeCol;
+        }
+    };
+    // Publish the hypothesis this wave holds (u already in nd.u) as node nd, and store it as state `sid`.
+    auto save_node = [&](const NodeRef &nd, int sid, double v, double pfx, int r4c, int c4r, u64 forb, double gain,
+                         int activeCol) {
+        store_state(sid, (lane < D) ? nd.u[lane] : 0.0, v, pfx, r4c, c4r, forb, gain, activeCol);
+        if (lane < D) {
+            nd.v[lane] = v;
+            nd.prefix[lane] = pfx;
+            nd.r4c[lane] = (unsigned char)r4c;
+            nd.c4r[lane] = (unsigned char)c4r;
+        }
+        if (lane == 0) {
             nd.gain[0] = gain;
             nd.forb[0] = forb;
             nd.info[0] = activeCol;
@@ -489,9 +510,10 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
         if (bad) {
             if (lane == 0) ctrl->stop = 3;
         } else {
-            const double g = serial_gain<true>(Cs, LDC, lane, r4c, 0, M, 0.0, nd.prefix);
+            double pfx;
+            const double g = serial_gain<true>(Cs, LDC, lane, r4c, 0, M, 0.0, pfx);
             const u64 forb = bit64(__builtin_amdgcn_readlane(r4c, 0));  // cpp:235
-            save_node(nd, 0, v, r4c, c4r, forb, g, 0);
+            save_node(nd, 0, v, pfx, r4c, c4r, forb, g, 0);
             if (lane == 0) {
                 ctrl->cutoffGain = maximize ? (g - p.cutoff) : (g + p.cutoff);          // cpp:681/684
                 const double gu = maximize ? (-g + ctrl->cdelta) : (g + ctrl->cdelta);  // cpp:599-603
@@ -524,6 +546,9 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
         const int nOld = nqEnd - head;
         const int sidBase = uni32(ctrl->nextSid);
         const double cutG = ctrl->cutoffGain;
+        int selIdx[8], selSid[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) { selIdx[w] = uni32(ctrl->selIdx[w]); selSid[w] = uni32(ctrl->selSid[w]); }
         // -- B1: first-step filter.  56 % of all children (64x64, k=200) are abandoned by the early-termination
         //    test at their very first Dijkstra step, i.e. because  min over candidate rows of (C[r,c] - u[c] - v[r])
         //    already exceeds the bound.  That minimum is computed here for ALL children of a node at once, one wave
@@ -660,22 +685,51 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
                 KB_ACC(5, __popcll(scanned) + (st != 0));  // [5] child Dijkstra steps (approx: scanned rows)
                 if (st != 0) continue;
                 KB_ACC(6, 1);  // [6] children completed
+                // The child survived: finish it the way shortestPathUpdateCPP does -- path flip (cpp:108-116), exact
+                // gain (calcGain, cpp:59-80, continuing the parent's partial sums: only columns >= c change) and,
+                // if a state slot is free, the dual update (cpp:92-106) -- and keep the whole hypothesis, so that it
+                // can later be split without being solved again.  Without a slot it stays a lazy candidate.
                 int r4c = (lane == c) ? -1 : r4cP;
-                int r = sink, cc, guard = 0;
-                do {  // path flip, row4col side only (cpp:108-116)
-                    cc = __builtin_amdgcn_readlane(pred, r);
-                    const int nxt = __builtin_amdgcn_readlane(r4c, cc);
-                    r4c = (lane == cc) ? r : r4c;
-                    r = nxt;
-                } while (cc != c && ++guard < 64);
-                const double g = serial_gain<false>(Cs, LDC, lane, r4c, c, M, pfx, nullptr);
+                int c4rN = c4r;
+                {
+                    int r = sink, cc, guard = 0;
+                    do {
+                        cc = __builtin_amdgcn_readlane(pred, r);
+                        const int nxt = __builtin_amdgcn_readlane(r4c, cc);
+                        c4rN = (lane == r) ? cc : c4rN;
+                        r4c = (lane == cc) ? r : r4c;
+                        r = nxt;
+                    } while (cc != c && ++guard < 64);
+                }
+                double mine;
+                const double g = serial_gain<true>(Cs, LDC, lane, r4c, c, M, pfx, mine);
                 if (useCut && (maximize ? (g < cutG) : (g > cutG))) continue;  // cutHyp, cpp:496/521
                 npush++;
-                KB_ACC(10, __builtin_readcyclecounter() - tDij1);  // [10] flip + exact gain of completed children
+                int slot = -1;
+                if (lane == 0) {
+                    const int sl = atomicAdd(&ctrl->nextEager, 1);
+                    slot = sl < maxSid ? sl : -1;
+                }
+                slot = uni32(slot);
+                if (slot >= 0) {
+                    const bool sc = ((scanned >> lane) & 1ull) != 0;
+                    const double vN = sc ? (v - delta + spc) : v;                      // cpp:102-106
+                    const int rowOfCol = (lane < D && lane != c) ? r4cP : 0;            // parent's row of this column
+                    const double spcOfRow = __hiloint2double(__shfl(__double2hiint(spc), rowOfCol),
+                                                             __shfl(__double2loint(spc), rowOfCol));
+                    double uN = (lane < D) ? nd.u[lane] : 0.0;
+                    if (lane < D && lane != c && ((scanned >> rowOfCol) & 1ull)) uN = uN + delta - spcOfRow;  // cpp:96-99
+                    if (lane == c) uN = uN + delta;                                     // cpp:92
+                    const double pfxN = (lane <= c) ? ((lane < M) ? nd.prefix[lane] : 0.0) : mine;
+                    const u64 forbN = forbm | bit64(__builtin_amdgcn_readlane(r4c, c));  // cpp:362
+                    store_state(slot, uN, vN, pfxN, r4c, c4rN, forbN, g, c);
+                }
+                KB_ACC(10, __builtin_readcyclecounter() - tDij1);  // [10] finish of completed children
                 if (lane == 0) {
                     const int pos = atomicAdd(&ctrl->nFresh, 1);
                     freshG[pos] = g;
                     freshM[pos] = ((u32)sid << 8) | (u32)c;  // (parent state, column) of this candidate
+                    freshS[pos] = slot >= 0 ? (unsigned short)slot : SID_NONE;
                 }
             }
             if ((p.flags & KBEST_FLAG_COUNT_PUSHED) && lane == 0 && npush) atomicAdd(&ctrl->pushed, npush);
@@ -703,15 +757,19 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
                 int pos = i;
                 for (int j = 0; j < nFresh; j++) pos += (freshG[j] < g) ? 1 : 0;
                 og[e] = g;
-                const u32 mv = PM[head + i];
-                os[e] = PS[head + i];
-                // every solved node was split in B: FRESH -> SPLIT
-                om[e] = (os[e] == SID_NONE) ? mv : ((mv & META_MASK) | META_SPLIT);
+                u32 mv = PM[head + i];
+                unsigned short sv = PS[head + i];
+#pragma unroll
+                for (int w = 0; w < 8; w++)  // the nodes selected in the last A phase were all split in B
+                    if (w < nsel && selIdx[w] == head + i) { mv |= META_SPLIT; sv = (unsigned short)selSid[w]; }
+                om[e] = mv;
+                os[e] = sv;
                 opos[e] = pos;
             }
         }
         double fg = 0.0;
         u32 fm = 0;
+        unsigned short fs = SID_NONE;
         int fpos = -1;
         if (tid < nFresh) {  // nFresh <= spec * 64 <= NT
             const double g = freshG[tid];
@@ -726,52 +784,64 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
                 const double g2 = freshG[j2];
                 pos += (g2 < g || (g2 == g && freshM[j2] < mj)) ? 1 : 0;
             }
-            fg = g; fm = mj; fpos = pos;
+            fg = g; fm = mj; fs = freshS[tid]; fpos = pos;
         }
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < EPT; e++)
             if (opos[e] >= 0 && opos[e] < R) { PG[opos[e]] = og[e]; PM[opos[e]] = om[e]; PS[opos[e]] = os[e]; }
-        if (fpos >= 0 && fpos < R) { PG[fpos] = fg; PM[fpos] = fm; PS[fpos] = SID_NONE; }
+        if (fpos >= 0 && fpos < R) { PG[fpos] = fg; PM[fpos] = fm; PS[fpos] = fs; }
         int nq = nOld + nFresh;
         if (nq > R) nq = R;
         __syncthreads();
         KB_T(tA0);
         KB_ACC(2, tA0 - tC0);     // [2] merge incl. its barrier
-        // -- A + D: every wave finds the unsolved candidates itself (the pool is stable now); wave w solves the
-        //    w-th of them; lane 0 of wave 0 also does the emission bookkeeping, which depends only on the pool
-        //    order and flags.  State slots: keep one in hand for every output still to come.
-        int budget = (maxSid - k) + 1 - (sidBase - emitted);
+        // -- A + D: every wave finds the candidates to split next itself (the pool is stable now and nothing
+        //    below writes to it): the first `budget` entries that have not been split yet.  Wave w brings the
+        //    w-th of them into node block w -- by loading its saved state, or, if it has none, by re-solving it
+        //    from its parent's state.  Lane 0 of wave 0 also does the emission bookkeeping, which depends only on
+        //    the pool order and flags.  Lazy state slots: keep one in hand for every output still to come.
+        int budget = (p.lazyStates - k) + 1 - (sidBase - emitted);
         if (budget > spec) budget = spec;
         if (budget < 1) budget = 1;
-        int mySel = -1, nselNew = 0;
+        int mySel = -1, mySid = 0, nselNew = 0, nLazy = 0;
+        int sIdx[8], sSid[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) { sIdx[w] = -1; sSid[w] = 0; }
         for (int base = 0; base < nq && nselNew < budget; base += 64) {
             const int i = base + lane;
-            // (an entry already flagged FRESH belongs to a wave of this round that is ahead of us: same set)
-            const bool unsolved = i < nq && (PS[i] == SID_NONE || (PM[i] & META_FRESH));
-            u64 m = __ballot(unsolved);
+            const bool open = i < nq && !(PM[i] & META_SPLIT);
+            const unsigned short ps = (i < nq) ? PS[i] : SID_NONE;
+            u64 m = __ballot(open);
+            const u64 lazyM = __ballot(open && ps == SID_NONE);
             while (m && nselNew < budget) {
-                const int bitpos = __ffsll((long long)m) - 1;
-                if (nselNew == wave) mySel = base + bitpos;
+                const int bitpos = __builtin_ctzll(m);
+                const bool lazy = (lazyM >> bitpos) & 1ull;
+                const int sidv = lazy ? sidBase + nLazy : __builtin_amdgcn_readlane((int)ps, bitpos);
+                if (nselNew == wave) { mySel = base + bitpos; mySid = sidv; }
+#pragma unroll
+                for (int w = 0; w < 8; w++) if (w == nselNew) { sIdx[w] = base + bitpos; sSid[w] = sidv; }
+                nLazy += lazy ? 1 : 0;
                 nselNew++;
                 m &= m - 1;
             }
         }
         if (wave == 0 && lane == 0) {
+            // emission: the head goes out while it has been split; a head selected in THIS round (not split yet)
+            // is emitted too but ends the run, because its children are not in the pool yet
             int e = emitted, h = 0, stop = 0, selSeen = 0;
             while (h < nq && e < k) {
-                const unsigned short sdv = PS[h];
                 int sid;
                 bool fresh = false;
-                // a candidate selected in this round reads as SID_NONE or as FRESH depending on whether its wave
-                // has finished already: both mean "solved in this round"
-                if (sdv == SID_NONE || (PM[h] & META_FRESH)) {
-                    if (selSeen >= nselNew) break;  // unsolved and not selected this round: wait
-                    sid = sidBase + selSeen;          // selection is in pool order
+                if (!(PM[h] & META_SPLIT)) {
+                    if (selSeen >= nselNew) break;  // not split and not selected this round: wait
+                    sid = sSid[0];
+#pragma unroll
+                    for (int w = 1; w < 8; w++) sid = (selSeen == w) ? sSid[w] : sid;  // selection is in pool order
                     selSeen++;
                     fresh = true;
                 } else {
-                    sid = (int)sdv;
+                    sid = (int)PS[h];
                 }
                 const double g = PG[h];
                 const double gu = maximize ? (-g + ctrl->cdelta) : (g + ctrl->cdelta);  // cpp:626-630
@@ -783,56 +853,74 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
                 }
                 e++;
                 h++;
-                if (fresh) break;  // its children are not in the pool yet
+                if (fresh) break;
             }
             if (e >= k) stop = 1;
             if (h >= nq && nselNew == 0) stop = 1;  // queue empty, nothing left to split: cpp:631-633
             ctrl->emitted = e;
             ctrl->nsel = nselNew;
-            ctrl->nextSid = sidBase + nselNew;
+            ctrl->nextSid = sidBase + nLazy;
             ctrl->nextItem = 0;
             ctrl->nFresh = 0;
             ctrl->nSurv = 0;
             ctrl->nq = nq;
             ctrl->head = h;
+#pragma unroll
+            for (int w = 0; w < 8; w++) { ctrl->selIdx[w] = sIdx[w]; ctrl->selSid[w] = sSid[w]; }
             if (stop) ctrl->stop = 1;
         }
         if (wave < nselNew) {
-            // re-solve candidate mySel in full from its parent's saved state
-            const u32 meta = (u32)uni32((int)PM[mySel]) & META_MASK;
-            const int par = (int)(meta >> 8), col = (int)(meta & 255u);
-            const int sid = sidBase + wave;
             const NodeRef nd = node_ref(smem + L.offNodes + (size_t)wave * L.nodeStride, p.maxRow);
-            const unsigned char *st = stBase + (long long)par * p.stateStride;
-            const double *su = reinterpret_cast<const double *>(st);
-            double v = 0.0;
-            int r4c = -1, c4r = -1;
-            if (lane < D) {
-                nd.u[lane] = su[lane];
-                v = su[p.maxRow + lane];
-                r4c = st[16 * p.maxRow + lane];
-                c4r = st[17 * p.maxRow + lane];
-            }
-            const u64 forbP = uni64(*reinterpret_cast<const u64 *>(st + offTail));
-            const int aP = uni32(*reinterpret_cast<const int *>(st + offTail + 16));
-            const int fr = __builtin_amdgcn_readlane(r4c, col);
-            const u64 cand = __ballot(lane < D && c4r >= col);
-            const u64 forbm = (col == aP) ? forbP : bit64(fr);
-            c4r = (lane == fr) ? -1 : c4r;
-            r4c = (lane == col) ? -1 : r4c;
-            double spc, delta;
-            int pred, sink = 0;
-            u64 scanned;
-            const int rc = dijkstra<false>(Cs, LDC, nd.u, rl, lane, v, c4r, cand, forbm, col, INF, spc, pred, scanned,
-                                           delta, sink);
-            if (rc == 0) dual_update_flip(nd.u, lane, v, c4r, r4c, spc, pred, scanned, delta, sink, col);
-            const double g = serial_gain<true>(Cs, LDC, lane, r4c, 0, M, 0.0, nd.prefix);
-            const u64 forbN = forbm | bit64(__builtin_amdgcn_readlane(r4c, col));  // cpp:362
-            save_node(nd, sid, v, r4c, c4r, forbN, g, col);
-            if (lane == 0) {
-                PS[mySel] = (unsigned short)sid;  // solved; the next merge turns FRESH into SPLIT
-                PM[mySel] = meta | META_FRESH;
-                if (rc != 0) ctrl->stop = 2;  // cannot happen: the candidate was solved before
+            const bool lazy = uni32((int)PS[mySel]) == (int)SID_NONE;
+            if (!lazy) {
+                // the hypothesis was kept when it was found: bring it in
+                const unsigned char *st = stBase + (long long)mySid * p.stateStride;
+                const double *sd = reinterpret_cast<const double *>(st);
+                if (lane < D) {
+                    nd.u[lane] = sd[lane];
+                    nd.v[lane] = sd[DS + lane];
+                    nd.prefix[lane] = sd[2 * DS + lane];
+                    nd.r4c[lane] = st[offR4C + lane];
+                    nd.c4r[lane] = st[offC4R + lane];
+                }
+                if (lane == 0) {
+                    nd.forb[0] = *reinterpret_cast<const u64 *>(st + offTail);
+                    nd.gain[0] = *reinterpret_cast<const double *>(st + offTail + 8);
+                    nd.info[0] = *reinterpret_cast<const int *>(st + offTail + 16);
+                    nd.info[1] = mySid;
+                }
+            } else {
+                // re-solve candidate mySel in full from its parent's saved state
+                const u32 meta = (u32)uni32((int)PM[mySel]) & META_MASK;
+                const int par = (int)(meta >> 8), col = (int)(meta & 255u);
+                const unsigned char *st = stBase + (long long)par * p.stateStride;
+                const double *sd = reinterpret_cast<const double *>(st);
+                double v = 0.0;
+                int r4c = -1, c4r = -1;
+                if (lane < D) {
+                    nd.u[lane] = sd[lane];
+                    v = sd[DS + lane];
+                    r4c = st[offR4C + lane];
+                    c4r = st[offC4R + lane];
+                }
+                const u64 forbP = uni64(*reinterpret_cast<const u64 *>(st + offTail));
+                const int aP = uni32(*reinterpret_cast<const int *>(st + offTail + 16));
+                const int fr = __builtin_amdgcn_readlane(r4c, col);
+                const u64 cand = __ballot(lane < D && c4r >= col);
+                const u64 forbm = (col == aP) ? forbP : bit64(fr);
+                c4r = (lane == fr) ? -1 : c4r;
+                r4c = (lane == col) ? -1 : r4c;
+                double spc, delta;
+                int pred, sink = 0;
+                u64 scanned;
+                const int rc = dijkstra<false>(Cs, LDC, nd.u, rl, lane, v, c4r, cand, forbm, col, INF, spc, pred, scanned,
+                                               delta, sink);
+                if (rc == 0) dual_update_flip(nd.u, lane, v, c4r, r4c, spc, pred, scanned, delta, sink, col);
+                double pfx;
+                const double g = serial_gain<true>(Cs, LDC, lane, r4c, 0, M, 0.0, pfx);
+                const u64 forbN = forbm | bit64(__builtin_amdgcn_readlane(r4c, col));  // cpp:362
+                save_node(nd, mySid, v, pfx, r4c, c4r, forbN, g, col);
+                if (lane == 0 && rc != 0) ctrl->stop = 2;  // cannot happen: the candidate was solved before
             }
         }
         KB_T(tA1);
@@ -846,8 +934,8 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
     for (int idx = tid; idx < nf * (N + M); idx += NT) {
         const int s = idx / (N + M), j = idx - s * (N + M);
         const unsigned char *st = stBase + (long long)slotSid[s] * p.stateStride;
-        if (j < M) p.row4col[(outBase + s) * p.maxCol + j] = st[16 * p.maxRow + j];
-        else p.col4row[(outBase + s) * p.maxRow + (j - M)] = st[17 * p.maxRow + (j - M)];
+        if (j < M) p.row4col[(outBase + s) * p.maxCol + j] = st[offR4C + j];
+        else p.col4row[(outBase + s) * p.maxRow + (j - M)] = st[offC4R + (j - M)];
     }
     if (tid == 0) {
         p.nf[b] = nf;
@@ -925,6 +1013,8 @@ hipError_t launch_kbest(const Params &p, int B, int nWaves, hipStream_t stream)
     case 1: return launch_nw<1>(p, B, stream);
     case 2: return launch_nw<2>(p, B, stream);
     case 4: return launch_nw<4>(p, B, stream);
+    case 10: return launch_nw<10>(p, B, stream);
+    case 12: return launch_nw<12>(p, B, stream);
     case 16: return launch_nw<16>(p, B, stream);
     default: return launch_nw<8>(p, B, stream);
     }
