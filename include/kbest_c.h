@@ -13,6 +13,10 @@
  *        asgnBB (assignment.cpp:750, k=1, maximize).
  *   kbest_weights_batch_f64
  *        batched form of  assignmentProb (assignment.h:11, assignment.cpp:547-683)
+ *   kbest_condition_costs_f64
+ *        batched form of  conditionCosts (assignment.h:26, assignment.cpp:439-525)
+ *   kbest_assoc_probs_batch_f64
+ *        batched form of  getAssignmentProbs from the cost matrix on (assignment.cpp:57-74)
  *
  * Conventions kept from the reference: cost matrices are column-major
  * C[row + col*numRow] with numRow >= numCol (shortestPathCPP.hpp:185-190);
@@ -120,6 +124,25 @@ int kbest_set_profile_buffer(kbest_ctx *ctx, void *d_buf);
 int kbest_weights_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM,
                             const double *cost, const int64_t *costOff, int k, double *probs,
                             const int64_t *probOff, int32_t *nf);
+
+/*
+ * Batched conditionCosts (assignment.h:26, assignment.cpp:439-525).  Problem b: nRow[b] x nCol[b] column-major
+ * at cost + costOff[b].  out receives the conditioned goodRows[b] x nCol[b] block at the same offset; rowIdx
+ * [B][maxRow] the original row of each kept row (rowIdxOut of the reference; unused tail = -1).  Host buffers.
+ */
+int kbest_condition_costs_f64(kbest_ctx *ctx, int B, const int32_t *nRow, const int32_t *nCol,
+                              const double *cost, const int64_t *costOff, double *out, int32_t *goodRows,
+                              int32_t *rowIdx, int maxRow);
+
+/*
+ * Cost block in, association probabilities out: conditionCosts -> assignmentProb(k) -> scatter back to the
+ * original landmark numbering, i.e. getAssignmentProbs (assignment.cpp:57-74) from the cost matrix on, all on
+ * the device.  Same argument layout as kbest_weights_batch_f64; cost blocks are the UNconditioned
+ * (nL+nM) x nM matrices of computeQuadricCostMatrix (assignment.cpp:705-722); probs is [nM][nL+1] per problem.
+ */
+int kbest_assoc_probs_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM,
+                                const double *cost, const int64_t *costOff, int k, double *probs,
+                                const int64_t *probOff, int32_t *nf);
 
 #ifdef __cplusplus
 }

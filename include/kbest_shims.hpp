@@ -9,6 +9,7 @@
 //   kBest2DCutoff  shortestPathCPP.hpp:256-265   (callers: assignment.cpp:594)
 //   assign2D       shortestPathCPP.hpp:144-149   (no caller in the reference)
 //   assignmentProb assignment.h:11               (callers: assignment.cpp:66, comparison.cpp:194-222)
+//   conditionCosts assignment.h:26               (callers: assignment.cpp:58, comparison.cpp:161)
 //
 // MurtyHyp / ScratchSpace keep the reference's public member names, types and
 // declaration order (shortestPathCPP.hpp:22-65, 73-142) so that objects built
@@ -82,5 +83,9 @@ int assign2D(const size_t numRow, const size_t numCol, const bool maximize, cons
              MurtyHyp *problemSol);
 
 std::vector<std::vector<double>> assignmentProb(const std::vector<double> &costMatrix, size_t nL, size_t nM, size_t k);
+
+// assignment.h:26 (assignment.cpp:439-525)
+std::vector<double> conditionCosts(const std::vector<double> &costs, size_t nRows, size_t nCols,
+                                   std::vector<ptrdiff_t> &rowIdxOut);
 
 #endif

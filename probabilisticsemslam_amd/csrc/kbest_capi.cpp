@@ -20,7 +20,7 @@ struct kbest_ctx {
     size_t statesBytes = 0;
     size_t slotSidOffset = 0;
     int ldsLimit = 65536;
-    int nWaves = 8;   // waves per cost matrix (workgroup = nWaves * 64 threads)
+    int nWaves = 0;   // waves per cost matrix (workgroup = nWaves * 64 threads); 0 = choose per launch
     int spec = 0;     // candidates re-solved / split per round; 0 = choose per launch (choose_spec)
     int ldsPerCU = 160 * 1024;
     int extraStates = 64;  // lazy state slots beyond k per matrix (room for speculative re-solves)
@@ -47,13 +47,16 @@ int fail(kbest_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess)
         if (e_ != hipSuccess) return fail(ctx, KBEST_ERR_HIP, #call, e_);    \
     } while (0)
 
-// Speculation width (candidates re-solved / split per round).  Measured on MI355X at 64x64, k=200: 4 with three
-// matrices per CU beats 2 with four per CU (fewer, fuller rounds matter more than the extra resident waves), and
-// 8 loses to 4 (the speculative splits stop paying).  Smaller problems simply have the LDS for 4.
+// Launch shape, tuned on MI355X: 8 waves per matrix and up to 8 candidates split per round
+// at more than 32 rows (two matrices per CU; 5.2 ms per 1024 64x64, k=200); 4 waves / 4 candidates below (the
+// children of a 32-row problem cannot keep 8 waves busy; 8.1 ms per 4096 32x32, k=200).
+int choose_waves(const kbest_ctx *ctx, int maxRow) { return ctx->nWaves > 0 ? ctx->nWaves : (maxRow > 32 ? 8 : 4); }
+
 int choose_spec(const kbest_ctx *ctx, int maxRow, int k)
 {
-    if (ctx->spec > 0) return ctx->spec;
-    int spec = ctx->nWaves < 4 ? ctx->nWaves : 4;
+    const int nw = choose_waves(ctx, maxRow);
+    int spec = ctx->spec > 0 ? ctx->spec : (maxRow > 32 ? 8 : 4);
+    if (spec > nw) spec = nw;
     while (spec > 1 && kb::lds_layout(maxRow, k, spec).total > ctx->ldsLimit) spec /= 2;
     return spec;
 }
@@ -130,7 +133,6 @@ int kbest_create(kbest_ctx **out, int device)
         int w = atoi(e);
         if (w >= 1 && w <= 8) ctx->spec = w;
     }
-    if (ctx->spec > ctx->nWaves) ctx->spec = ctx->nWaves;
     int ldsCU = 0;
     if (hipDeviceGetAttribute(&ldsCU, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, device) == hipSuccess &&
         ldsCU > 0)
@@ -185,7 +187,8 @@ int kbest_batch_f64_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRo
     if (k + ctx->extraStates + ctx->eagerStates > 65534) return fail(ctx, KBEST_ERR_UNSUPPORTED, "k too large");
     // counting the reference's pushes needs the reference's exact order of splits: no speculation
     const int spec = (opts->flags & KBEST_FLAG_COUNT_PUSHED) ? 1 : choose_spec(ctx, maxRow, k);
-    if (k > 4 * ctx->nWaves * 64) return fail(ctx, KBEST_ERR_UNSUPPORTED, "k too large for the in-register pool merge");
+    const int nWaves = choose_waves(ctx, maxRow);
+    if (k > 4 * nWaves * 64) return fail(ctx, KBEST_ERR_UNSUPPORTED, "k too large for the in-register pool merge");
     const kb::Lds L = kb::lds_layout(maxRow, k, spec);
     if (L.total > ctx->ldsLimit) return fail(ctx, KBEST_ERR_UNSUPPORTED, "k too large for the LDS candidate pool");
     if (B == 0) return KBEST_OK;
@@ -221,7 +224,7 @@ int kbest_batch_f64_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRo
     p.prof = ctx->prof;
     p.slotSid = reinterpret_cast<unsigned short *>(ctx->states + ctx->slotSidOffset);
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
-    hipError_t e = kb::launch_kbest(p, B, ctx->nWaves, s);
+    hipError_t e = kb::launch_kbest(p, B, nWaves, s);
     if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "kbest kernel launch", e);
     return KBEST_OK;
 }
@@ -288,19 +291,23 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
     return KBEST_OK;
 }
 
-int kbest_weights_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM,
-                            const double *cost, const int64_t *costOff, int k, double *probs,
-                            const int64_t *probOff, int32_t *nf)
+// Shared body of kbest_weights_batch_f64 (condition = false: assignmentProb on the given matrices) and
+// kbest_assoc_probs_batch_f64 (condition = true: conditionCosts -> assignmentProb -> scatter back, i.e.
+// getAssignmentProbs assignment.cpp:57-74 without the quadric cost construction).  Everything between the
+// H2D copy of the cost blocks and the D2H copy of the probabilities runs on the device, stream-ordered.
+static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM, const double *cost,
+                            const int64_t *costOff, int k, double *probs, const int64_t *probOff, int32_t *nf,
+                            bool condition)
 {
     if (!ctx) return KBEST_ERR_BAD_ARG;
     if (B < 0 || k < 1 || !nL || !nM || !cost || !costOff || !probs || !probOff)
-        return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_weights_batch_f64: bad argument");
+        return fail(ctx, KBEST_ERR_BAD_ARG, "weights: bad argument");
     if (B == 0) return KBEST_OK;
     int maxRow = 1, maxCol = 1;
     size_t nCost = 0, nProb = 0;
     std::vector<int32_t> nRow(B);
     for (int b = 0; b < B; b++) {
-        if (nM[b] < 1 || nL[b] < 0) return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_weights_batch_f64: need nM >= 1, nL >= 0");
+        if (nM[b] < 1 || nL[b] < 0) return fail(ctx, KBEST_ERR_BAD_ARG, "weights: need nM >= 1, nL >= 0");
         nRow[b] = nL[b] + nM[b];
         if (nRow[b] > maxRow) maxRow = nRow[b];
         if (nM[b] > maxCol) maxCol = nM[b];
@@ -311,7 +318,7 @@ int kbest_weights_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int3
     }
     if (maxRow > KBEST_MAX_DIM) return fail(ctx, KBEST_ERR_UNSUPPORTED, "nL + nM > KBEST_MAX_DIM");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    DevBuf dCost, dOff, dNR, dNC, dNL, dR4C, dC4R, dGain, dNf, dProbs, dPOff;
+    DevBuf dCost, dCond, dOff, dNR, dNC, dNL, dGood, dCondL, dRowIdx, dR4C, dC4R, dGain, dNf, dProbs, dPOff;
     const size_t nR4C = (size_t)B * k * maxCol, nC4R = (size_t)B * k * maxRow, nG = (size_t)B * k;
     HIP_TRY(ctx, dCost.alloc(nCost * 8));
     HIP_TRY(ctx, dOff.alloc((size_t)B * 8));
@@ -331,18 +338,42 @@ int kbest_weights_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int3
     HIP_TRY(ctx, hipMemcpy(dNL.p, nL, (size_t)B * 4, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(dPOff.p, probOff, (size_t)B * 8, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemset(dProbs.p, 0, nProb * 8));
+    const double *solveCost = dCost.as<double>();
+    const int32_t *solveRows = dNR.as<int32_t>();
+    const int *weightNL = dNL.as<int>();
+    if (condition) {
+        HIP_TRY(ctx, dCond.alloc(nCost * 8));
+        HIP_TRY(ctx, dGood.alloc((size_t)B * 4));
+        HIP_TRY(ctx, dCondL.alloc((size_t)B * 4));
+        HIP_TRY(ctx, dRowIdx.alloc((size_t)B * maxRow * 4));
+        kb::CondParams c;
+        c.cost = dCost.as<double>();
+        c.costOff = dOff.as<long long>();
+        c.nRow = dNR.as<int>();
+        c.nCol = dNC.as<int>();
+        c.out = dCond.as<double>();
+        c.goodRows = dGood.as<int>();
+        c.condL = dCondL.as<int>();
+        c.rowIdx = dRowIdx.as<int>();
+        c.maxRow = maxRow;
+        hipError_t e = kb::launch_condition(c, B, ctx->stream);
+        if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "condition kernel launch", e);
+        solveCost = dCond.as<double>();
+        solveRows = dGood.as<int32_t>();
+        weightNL = dCondL.as<int>();
+    }
     kbest_opts o;
     kbest_default_opts(&o);
     o.use_cutoff = 1;   // assignment.cpp:594: kBest2DCutoff(..., cutoff = 42)
     o.cutoff = 42.0;
-    int rc = kbest_batch_f64_dev(ctx, &o, B, maxRow, maxCol, dNR.as<int32_t>(), dNC.as<int32_t>(), dCost.as<double>(),
+    int rc = kbest_batch_f64_dev(ctx, &o, B, maxRow, maxCol, solveRows, dNC.as<int32_t>(), solveCost,
                                  dOff.as<int64_t>(), k, dR4C.as<int32_t>(), dC4R.as<int32_t>(), dGain.as<double>(),
                                  dNf.as<int32_t>(), nullptr, ctx->stream);
     if (rc != KBEST_OK) return rc;
     kb::WeightParams w;
-    w.nL = dNL.as<int>();
+    w.nL = weightNL;
     w.nM = dNC.as<int>();
-    w.cost = dCost.as<double>();
+    w.cost = solveCost;
     w.costOff = dOff.as<long long>();
     w.gain = dGain.as<double>();
     w.row4col = dR4C.as<int>();
@@ -351,6 +382,9 @@ int kbest_weights_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int3
     w.probOff = dPOff.as<long long>();
     w.k = k;
     w.maxCol = maxCol;
+    w.rowIdx = condition ? dRowIdx.as<int>() : nullptr;
+    w.nLout = dNL.as<int>();
+    w.maxRow = maxRow;
     {
         std::lock_guard<std::mutex> lock(ctx->mu);
         hipError_t e = kb::launch_weights(w, B, ctx->stream);
@@ -359,6 +393,70 @@ int kbest_weights_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int3
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(probs, dProbs.p, nProb * 8, hipMemcpyDeviceToHost));
     if (nf) HIP_TRY(ctx, hipMemcpy(nf, dNf.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+    return KBEST_OK;
+}
+
+int kbest_weights_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM, const double *cost,
+                            const int64_t *costOff, int k, double *probs, const int64_t *probOff, int32_t *nf)
+{
+    return weights_pipeline(ctx, B, nL, nM, cost, costOff, k, probs, probOff, nf, false);
+}
+
+int kbest_assoc_probs_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM, const double *cost,
+                                const int64_t *costOff, int k, double *probs, const int64_t *probOff, int32_t *nf)
+{
+    return weights_pipeline(ctx, B, nL, nM, cost, costOff, k, probs, probOff, nf, true);
+}
+
+int kbest_condition_costs_f64(kbest_ctx *ctx, int B, const int32_t *nRow, const int32_t *nCol, const double *cost,
+                              const int64_t *costOff, double *out, int32_t *goodRows, int32_t *rowIdx, int maxRow)
+{
+    if (!ctx) return KBEST_ERR_BAD_ARG;
+    if (B < 0 || !nRow || !nCol || !cost || !costOff || !out || !goodRows || !rowIdx || maxRow < 1)
+        return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_condition_costs_f64: bad argument");
+    if (B == 0) return KBEST_OK;
+    if (maxRow > KBEST_MAX_DIM) return fail(ctx, KBEST_ERR_UNSUPPORTED, "numRow > KBEST_MAX_DIM");
+    size_t nCost = 0;
+    for (int b = 0; b < B; b++) {
+        if (nRow[b] < 1 || nCol[b] < 1 || nRow[b] > maxRow || nCol[b] > KBEST_MAX_DIM)
+            return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_condition_costs_f64: shape out of range");
+        const size_t ce = (size_t)costOff[b] + (size_t)nRow[b] * nCol[b];
+        if (ce > nCost) nCost = ce;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf dCost, dOut, dOff, dNR, dNC, dGood, dRowIdx;
+    HIP_TRY(ctx, dCost.alloc(nCost * 8));
+    HIP_TRY(ctx, dOut.alloc(nCost * 8));
+    HIP_TRY(ctx, dOff.alloc((size_t)B * 8));
+    HIP_TRY(ctx, dNR.alloc((size_t)B * 4));
+    HIP_TRY(ctx, dNC.alloc((size_t)B * 4));
+    HIP_TRY(ctx, dGood.alloc((size_t)B * 4));
+    HIP_TRY(ctx, dRowIdx.alloc((size_t)B * maxRow * 4));
+    HIP_TRY(ctx, hipMemcpy(dCost.p, cost, nCost * 8, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(dOff.p, costOff, (size_t)B * 8, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(dNR.p, nRow, (size_t)B * 4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(dNC.p, nCol, (size_t)B * 4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemset(dOut.p, 0, nCost * 8));
+    HIP_TRY(ctx, hipMemset(dRowIdx.p, 0xFF, (size_t)B * maxRow * 4));
+    kb::CondParams c;
+    c.cost = dCost.as<double>();
+    c.costOff = dOff.as<long long>();
+    c.nRow = dNR.as<int>();
+    c.nCol = dNC.as<int>();
+    c.out = dOut.as<double>();
+    c.goodRows = dGood.as<int>();
+    c.condL = nullptr;
+    c.rowIdx = dRowIdx.as<int>();
+    c.maxRow = maxRow;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        hipError_t e = kb::launch_condition(c, B, ctx->stream);
+        if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "condition kernel launch", e);
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, dOut.p, nCost * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(goodRows, dGood.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(rowIdx, dRowIdx.p, (size_t)B * maxRow * 4, hipMemcpyDeviceToHost));
     return KBEST_OK;
 }
 

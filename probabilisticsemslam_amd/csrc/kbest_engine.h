@@ -41,6 +41,17 @@ struct Params {
     unsigned short *slotSid;  // workspace: [B][k] state slot of each output slot
 };
 
+struct CondParams {
+    const double *cost;       // raw (nL+nM) x nM blocks
+    const long long *costOff;
+    const int *nRow, *nCol;
+    double *out;              // conditioned blocks, same offsets (goodRows x nCol, column-major)
+    int *goodRows;            // [B]
+    int *condL;               // [B] goodRows - nCol (assignment.cpp:60), or nullptr
+    int *rowIdx;              // [B][maxRow] original row of each kept row
+    int maxRow;
+};
+
 struct WeightParams {
     const int *nL, *nM;
     const double *cost;
@@ -51,6 +62,9 @@ struct WeightParams {
     double *probs;
     const long long *probOff;
     int k, maxCol;
+    const int *rowIdx;        // [B][maxRow] or nullptr: scatter back through conditionCosts' row map
+    const int *nLout;         // [B] landmarks in the output numbering (with rowIdx)
+    int maxRow;
 };
 
 // Bytes of one saved hypothesis: u[D] v[D] (fp64), row4col[D] col4row[D] (u8),
@@ -91,6 +105,7 @@ __host__ __device__ inline Lds lds_layout(int maxRow, int k, int spec)
 
 hipError_t launch_kbest(const Params &p, int B, int nWaves, hipStream_t stream);
 hipError_t launch_weights(const WeightParams &p, int B, hipStream_t stream);
+hipError_t launch_condition(const CondParams &p, int B, hipStream_t stream);
 
 }  // namespace kb
 #endif

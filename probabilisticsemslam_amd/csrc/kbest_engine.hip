@@ -948,36 +948,77 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
 #endif
 }
 
+// ------------------------------------------------- conditionCosts prologue
+// conditionCosts (assignment.cpp:439-525): column minima (:450-458); a row is kept iff some entry is within
+// 42 of its column's minimum (:462-474); kept rows are compacted in order, entries become cost - colMin or
+// +inf beyond the gate (:476-496).  One wave per cost matrix, lane = row.
+__global__ void __launch_bounds__(64) condition_kernel(CondParams p)
+{
+    __shared__ double colMin[64];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int nR = p.nRow[b], nC = p.nCol[b];
+    const double *C = p.cost + p.costOff[b];
+    double *out = p.out + p.costOff[b];
+    const double INF = d_inf(), GATE = 42.0;  // assignment.cpp:9
+    for (int c = 0; c < nC; c++) {
+        const double x = (lane < nR) ? C[(long long)c * nR + lane] : INF;
+        const double m = wave_min_f64(x);
+        if (lane == 0) colMin[c] = m;
+    }
+    __syncthreads();
+    bool good = false;
+    for (int c = 0; c < nC; c++)
+        if (lane < nR && C[(long long)c * nR + lane] <= colMin[c] + GATE) good = true;
+    const u64 mask = __ballot(good);
+    const int g = __popcll(mask);
+    const int nr = __popcll(mask & ((1ull << lane) - 1ull));
+    for (int c = 0; c < nC; c++) {
+        const double x = (lane < nR) ? C[(long long)c * nR + lane] : INF;
+        if (good) out[(long long)c * g + nr] = (x <= colMin[c] + GATE) ? (x - colMin[c]) : INF;
+    }
+    if (good) p.rowIdx[(long long)b * p.maxRow + nr] = lane;
+    if (lane == 0) {
+        p.goodRows[b] = g;
+        if (p.condL) p.condL[b] = g - nC;  // assignment.cpp:60
+    }
+}
+
 // ------------------------------------------------- association weights epilogue
 // assignmentProb accumulate / normalise (assignment.cpp:616-648) and its
 // single-column fast path (assignment.cpp:554-570).  One wave per problem,
 // lane = measurement (column); solutions are accumulated in ascending order
 // exactly as the reference loop does, so only exp() itself can differ.
+// With rowIdx != nullptr the problem was conditioned first and the result is
+// scattered back to the original landmark numbering (getAssignmentProbs,
+// assignment.cpp:68-74): output row stride nLout[b] + 1.
 __global__ void __launch_bounds__(64) weights_kernel(WeightParams p)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int nL = p.nL[b], nM = p.nM[b];
+    const int nLo = p.rowIdx ? p.nLout[b] : nL;  // landmarks in the output numbering
+    const int *ridx = p.rowIdx ? p.rowIdx + (long long)b * p.maxRow : nullptr;
     double *probs = p.probs + p.probOff[b];
     const double GATE = 42.0;  // assignment.cpp:9
+    for (int i = lane; i < nM * (nLo + 1); i += 64) probs[i] = 0.0;
+    __syncthreads();
+    if (nL < 0) return;  // fewer kept rows than measurements: undefined in the reference (size_t underflow, :60)
     if (nM == 1) {
         const double *cost = p.cost + p.costOff[b];
         if (lane == 0) {
             double norm = 0.0;
-            for (int i = 0; i <= nL; i++) {
-                double q = 0.0;
-                if (cost[i] < GATE) { q = exp(-cost[i]); norm += q; }
-                probs[i] = q;
-            }
+            for (int i = 0; i <= nL; i++)
+                if (cost[i] < GATE) norm += exp(-cost[i]);
             norm = 1.0 / norm;
-            for (int i = 0; i <= nL; i++) probs[i] = probs[i] * norm;
+            for (int i = 0; i <= nL; i++) {
+                const double q = (cost[i] < GATE) ? exp(-cost[i]) : 0.0;
+                probs[(i >= nL) ? nLo : (ridx ? ridx[i] : i)] = q * norm;
+            }
         }
         return;
     }
     const int nf = p.nf[b];
     const double *gain = p.gain + (long long)b * p.k;
     const int *r4c = p.row4col + (long long)b * p.k * p.maxCol;
-    for (int i = lane; i < nM * (nL + 1); i += 64) probs[i] = 0.0;
-    __syncthreads();
     const double best = gain[0];
     double total = 0.0;
     for (int s = 0; s < nf; s++) {
@@ -987,12 +1028,12 @@ __global__ void __launch_bounds__(64) weights_kernel(WeightParams p)
         total += w;
         if (lane < nM) {
             const int r = r4c[(long long)s * p.maxCol + lane];
-            probs[lane * (nL + 1) + (r >= nL ? nL : r)] += w;  // :633-638
+            probs[lane * (nLo + 1) + ((r >= nL) ? nLo : (ridx ? ridx[r] : r))] += w;  // :633-638
         }
     }
     __syncthreads();
     const double norm = 1.0 / total;  // :643
-    for (int i = lane; i < nM * (nL + 1); i += 64) probs[i] *= norm;
+    for (int i = lane; i < nM * (nLo + 1); i += 64) probs[i] *= norm;
 }
 
 // ------------------------------------------------------------------- launchers
@@ -1018,6 +1059,12 @@ hipError_t launch_kbest(const Params &p, int B, int nWaves, hipStream_t stream)
     case 16: return launch_nw<16>(p, B, stream);
     default: return launch_nw<8>(p, B, stream);
     }
+}
+
+hipError_t launch_condition(const CondParams &p, int B, hipStream_t stream)
+{
+    hipLaunchKernelGGL(condition_kernel, dim3(B), dim3(64), 0, stream, p);
+    return hipGetLastError();
 }
 
 hipError_t launch_weights(const WeightParams &p, int B, hipStream_t stream)

@@ -133,3 +133,19 @@ std::vector<std::vector<double>> assignmentProb(const std::vector<double> &costM
         for (size_t j = 0; j <= nL; j++) probs[c][j] = flat[c * (nL + 1) + j];
     return probs;
 }
+
+std::vector<double> conditionCosts(const std::vector<double> &costs, size_t nRows, size_t nCols,
+                                   std::vector<ptrdiff_t> &rowIdxOut)
+{
+    kbest_ctx *ctx = global_ctx();
+    const int32_t nr = (int32_t)nRows, nc = (int32_t)nCols;
+    const int64_t zero = 0;
+    std::vector<double> out(nRows * nCols);
+    std::vector<int32_t> ridx(nRows);
+    int32_t good = 0;
+    check(ctx, kbest_condition_costs_f64(ctx, 1, &nr, &nc, costs.data(), &zero, out.data(), &good, ridx.data(), (int)nRows));
+    out.resize((size_t)good * nCols);
+    std::vector<ptrdiff_t> idx(ridx.begin(), ridx.begin() + good);
+    rowIdxOut.swap(idx);  // assignment.cpp:523
+    return out;
+}

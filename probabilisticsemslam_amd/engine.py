@@ -18,7 +18,7 @@ KBEST_MAX_DIM = 64
 C_ABI_SYMBOLS = (
     "kbest_default_opts", "kbest_create", "kbest_destroy", "kbest_strerror", "kbest_last_error",
     "kbest_device_count", "kbest_batch_f64_dev", "kbest_batch_f64", "kbest_reserve", "kbest_weights_batch_f64",
-    "kbest_set_profile_buffer",
+    "kbest_set_profile_buffer", "kbest_condition_costs_f64", "kbest_assoc_probs_batch_f64",
 )
 
 
@@ -66,6 +66,8 @@ def load_library():
     lib.kbest_batch_f64.argtypes = [vp, C.POINTER(KBestOpts), C.c_int, C.c_int, C.c_int, i32p, i32p, dp, i64p,
                                     C.c_int, i32p, i32p, dp, i32p, i64p]
     lib.kbest_weights_batch_f64.argtypes = [vp, C.c_int, i32p, i32p, dp, i64p, C.c_int, dp, i64p, i32p]
+    lib.kbest_assoc_probs_batch_f64.argtypes = [vp, C.c_int, i32p, i32p, dp, i64p, C.c_int, dp, i64p, i32p]
+    lib.kbest_condition_costs_f64.argtypes = [vp, C.c_int, i32p, i32p, dp, i64p, dp, i32p, i32p, C.c_int]
     _lib = lib
     return lib
 
@@ -139,9 +141,28 @@ class KBestEngine:
             return nf, r4c, c4r, gain, pushed
         return nf, r4c, c4r, gain
 
-    def weights(self, costs, nL, nM, k):
-        """Batched assignmentProb.  costs: list of 1-D column-major (nL+nM) x nM blocks.
-        Returns (list of [nM, nL+1] arrays, nf[B])."""
+    def condition_costs(self, costs, nRows, nCols):
+        """Batched conditionCosts.  Returns (list of conditioned 1-D blocks, list of rowIdx arrays)."""
+        nRows = np.ascontiguousarray(nRows, dtype=np.int32)
+        nCols = np.ascontiguousarray(nCols, dtype=np.int32)
+        B = len(nRows)
+        sizes = nRows.astype(np.int64) * nCols
+        off = np.zeros(B, np.int64)
+        off[1:] = np.cumsum(sizes)[:-1]
+        flat = np.concatenate([np.ascontiguousarray(c, dtype=np.float64).reshape(-1) for c in costs])
+        out = np.zeros_like(flat)
+        good = np.zeros(B, np.int32)
+        maxRow = int(nRows.max())
+        ridx = np.zeros((B, maxRow), np.int32)
+        self._check(self.lib.kbest_condition_costs_f64(self.ctx, B, _ptr(nRows), _ptr(nCols), _ptr(flat), _ptr(off),
+                                                       _ptr(out), _ptr(good), _ptr(ridx), maxRow))
+        return ([out[off[b]: off[b] + int(good[b]) * int(nCols[b])].copy() for b in range(B)],
+                [ridx[b, : good[b]].copy() for b in range(B)])
+
+    def weights(self, costs, nL, nM, k, condition=False):
+        """Batched assignmentProb (condition=False) or, with condition=True, the whole
+        conditionCosts -> assignmentProb -> scatter chain of getAssignmentProbs on raw cost blocks.
+        costs: list of 1-D column-major (nL+nM) x nM blocks.  Returns (list of [nM, nL+1] arrays, nf[B])."""
         nL = np.ascontiguousarray(nL, dtype=np.int32)
         nM = np.ascontiguousarray(nM, dtype=np.int32)
         B = len(nL)
@@ -154,8 +175,9 @@ class KBestEngine:
         flat = np.concatenate([np.ascontiguousarray(c, dtype=np.float64).reshape(-1) for c in costs])
         probs = np.zeros(int(sum(psizes)), np.float64)
         nf = np.zeros(B, np.int32)
-        self._check(self.lib.kbest_weights_batch_f64(self.ctx, B, _ptr(nL), _ptr(nM), _ptr(flat), _ptr(costOff), k,
-                                                     _ptr(probs), _ptr(probOff), _ptr(nf)))
+        fn = self.lib.kbest_assoc_probs_batch_f64 if condition else self.lib.kbest_weights_batch_f64
+        self._check(fn(self.ctx, B, _ptr(nL), _ptr(nM), _ptr(flat), _ptr(costOff), k, _ptr(probs), _ptr(probOff),
+                       _ptr(nf)))
         out = [probs[probOff[b]: probOff[b] + psizes[b]].reshape(int(nM[b]), int(nL[b]) + 1) for b in range(B)]
         return out, nf
 

@@ -222,3 +222,56 @@ def test_subtree_sharding_merges_to_global_kbest(eng):
             cand.sort(key=lambda t: t[0])
             assert [c[0] for c in cand[:k]] == g[b].tolist()
             assert [c[1] for c in cand[:k]] == [tuple(x) for x in r4c[b]]
+
+
+def test_condition_costs_device(eng):
+    # conditionCosts on the device vs the oracle restatement (assignment.cpp:439-525): bit-exact
+    frames = wl.kitti_like_frames(30) + wl.kitti_like_frames(10, nL=6, nM=3)
+    shapes = [(30, 10)] * 30 + [(9, 3)] * 10
+    conds, ridx = eng.condition_costs(frames, [s[0] for s in shapes], [s[1] for s in shapes])
+    for f, (nR, nC), c, r in zip(frames, shapes, conds, ridx):
+        oc, orx = ol.condition_costs(f, nR, nC)
+        assert (r == orx).all()
+        assert (bits(c) == bits(oc)).all()
+
+
+def test_assoc_probs_pipeline(eng):
+    """cost block in -> probabilities out on the device (conditionCosts -> assignmentProb -> scatter back),
+    against the same chain of the oracle (getAssignmentProbs, assignment.cpp:57-74)."""
+    frames = wl.kitti_like_frames(60)
+    nL, nM = 20, 10
+    probs, nf = eng.weights(frames, [nL] * len(frames), [nM] * len(frames), 200, condition=True)
+    for i, f in enumerate(frames):
+        cond, idx = ol.condition_costs(f, nL + nM, nM)
+        condL = len(idx) - nM
+        pc, onf = ol.assignment_prob(cond, condL, nM, 200)
+        want = np.zeros((nM, nL + 1))
+        want[:, idx[:condL]] = pc[:, :condL]
+        want[:, nL] = pc[:, condL]
+        assert nf[i] == onf
+        np.testing.assert_allclose(probs[i], want, rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(probs[i].sum(axis=1), 1.0, rtol=1e-12)
+
+
+def test_config5_streamed_frames(eng):
+    """BASELINE config 5: a stream of per-frame 30-row x 10-column (-> 30x30 padded) cost matrices, k = 200,
+    cutoff 42 active, processed chunk by chunk as a frame loop would hand them over.  Every 8th frame is checked
+    against the oracle chain; every frame's probabilities must be a distribution per measurement."""
+    frames = wl.kitti_like_frames(1000)
+    nL, nM, chunk = 20, 10, 125
+    for c0 in range(0, len(frames), chunk):
+        fs = frames[c0:c0 + chunk]
+        probs, nf = eng.weights(fs, [nL] * len(fs), [nM] * len(fs), 200, condition=True)
+        for i, f in enumerate(fs):
+            assert nf[i] >= 1
+            np.testing.assert_allclose(probs[i].sum(axis=1), 1.0, rtol=1e-12)
+            assert (probs[i] >= 0).all()
+            if (c0 + i) % 8 == 0:
+                cond, idx = ol.condition_costs(f, nL + nM, nM)
+                condL = len(idx) - nM
+                pc, onf = ol.assignment_prob(cond, condL, nM, 200)
+                want = np.zeros((nM, nL + 1))
+                want[:, idx[:condL]] = pc[:, :condL]
+                want[:, nL] = pc[:, condL]
+                assert nf[i] == onf
+                np.testing.assert_allclose(probs[i], want, rtol=1e-12, atol=1e-15)
