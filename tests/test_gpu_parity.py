@@ -275,3 +275,39 @@ def test_config5_streamed_frames(eng):
                 want[:, nL] = pc[:, condL]
                 assert nf[i] == onf
                 np.testing.assert_allclose(probs[i], want, rtol=1e-12, atol=1e-15)
+
+
+def test_cpp_shims_drop_in(eng, tmp_path):
+    """A C++ caller written like the reference's own call sites, compiled against include/kbest_shims.hpp and
+    linked to libkbest_amd.so (the link-level drop-in of INTEGRATION.md), gives the checker's answers."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "shim_drop_in")
+    libdir = os.path.join(root, "probabilisticsemslam_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "shim_drop_in.cpp"), "-o", exe,
+                           "-L", libdir, "-l:libkbest_amd.so", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib",
+                           "-L/opt/rocm/lib", "-lamdhip64"])
+    out = subprocess.check_output([exe, "8", "8", "10", "12345"], text=True).splitlines()
+    cs, N, M, k = wl.dense_config("c1")
+    onf, or4c, oc4r, og = ol.orc_kbest(cs[0], N, M, k)
+    assert out[0] == f"kBest2D nf {onf}"
+    for s in range(onf):
+        want = "g " + float.hex(og[s]) + " r4c " + " ".join(map(str, or4c[s])) + " c4r " + " ".join(map(str, oc4r[s]))
+        got = out[1 + s].split()
+        assert float.fromhex(got[1]) == og[s] and " ".join(got[2:]) == " ".join(want.split()[2:])
+    cnf, cr4c, _, cg = ol.orc_kbest(cs[0], N, M, k, cutoff=0.1)
+    i = 1 + onf
+    assert out[i] == f"kBest2DCutoff nf {cnf} toCut 1"
+    assert [float.fromhex(l.split()[1]) for l in out[i + 1: i + 1 + cnf]] == cg[:cnf].tolist()
+    i += 1 + cnf
+    a = out[i].split()
+    assert a[:3] == ["assign2D", "ok", "1"] and float.fromhex(a[4]) == og[0] and list(map(int, a[6:])) == or4c[0].tolist()
+    frame = wl.kitti_like_frames(1, nL=6, nM=3)[0]
+    cond, idx = ol.condition_costs(frame, 9, 3)
+    assert out[i + 1] == f"conditionCosts rows {len(idx)} idx " + " ".join(map(str, idx))
+    po, _ = ol.assignment_prob(cond, len(idx) - 3, 3, 200)
+    for m in range(3):
+        got = np.array([float.fromhex(x) for x in out[i + 2 + m].split()[1:]])
+        np.testing.assert_allclose(got, po[m], rtol=1e-12, atol=1e-15)
