@@ -351,8 +351,12 @@ __device__ __forceinline__ NodeRef node_ref(unsigned char *base, int maxRow)
     return n;
 }
 
-template <int NW>
-__global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
+// Register budget: 6 waves per SIMD (80 VGPRs) lets three 8-wave (or six 4-wave) workgroups share a CU; without the
+// bound the compiler settles at ~90-100 VGPRs and residency silently drops to two matrices per CU.
+constexpr int min_waves_per_simd(int nw) { return nw <= 12 ? 6 : 4; }
+
+template <int NW, int EPT>  // EPT: pool entries per thread held in registers across the in-place merge (k <= EPT * NW * 64)
+__global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = NW * 64;
@@ -546,9 +550,6 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
         const int nOld = nqEnd - head;
         const int sidBase = uni32(ctrl->nextSid);
         const double cutG = ctrl->cutoffGain;
-        int selIdx[8], selSid[8];
-#pragma unroll
-        for (int w = 0; w < 8; w++) { selIdx[w] = uni32(ctrl->selIdx[w]); selSid[w] = uni32(ctrl->selSid[w]); }
         // -- B1: first-step filter.  56 % of all children (64x64, k=200) are abandoned by the early-termination
         //    test at their very first Dijkstra step, i.e. because  min over candidate rows of (C[r,c] - u[c] - v[r])
         //    already exceeds the bound.  That minimum is computed here for ALL children of a node at once, one wave
@@ -743,7 +744,6 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
         //    entries into registers), keep the R smallest.  Ties in gain are ordered by (parent, column), so the
         //    result does not depend on the arrival order of the fresh list.
         const int nFresh = uni32(ctrl->nFresh);
-        constexpr int EPT = 4;  // pool entries per thread held across the barrier (k <= EPT * NT)
         double og[EPT];
         u32 om[EPT];
         unsigned short os[EPT];
@@ -759,9 +759,8 @@ __global__ void __launch_bounds__(NW * 64) kbest_kernel(Params p)
                 og[e] = g;
                 u32 mv = PM[head + i];
                 unsigned short sv = PS[head + i];
-#pragma unroll
-                for (int w = 0; w < 8; w++)  // the nodes selected in the last A phase were all split in B
-                    if (w < nsel && selIdx[w] == head + i) { mv |= META_SPLIT; sv = (unsigned short)selSid[w]; }
+                for (int w = 0; w < nsel; w++)  // the nodes selected in the last A phase were all split in B
+                    if (ctrl->selIdx[w] == head + i) { mv |= META_SPLIT; sv = (unsigned short)ctrl->selSid[w]; }
                 om[e] = mv;
                 os[e] = sv;
                 opos[e] = pos;
@@ -1037,15 +1036,21 @@ __global__ void __launch_bounds__(64) weights_kernel(WeightParams p)
 }
 
 // ------------------------------------------------------------------- launchers
+template <int NW, int EPT>
+static hipError_t launch_nw_ept(const Params &p, int B, hipStream_t stream)
+{
+    const Lds L = lds_layout(p.maxRow, p.k, p.spec);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kbest_kernel<NW, EPT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((kbest_kernel<NW, EPT>), dim3(B), dim3(NW * 64), L.total, stream, p);
+    return hipGetLastError();
+}
+
 template <int NW>
 static hipError_t launch_nw(const Params &p, int B, hipStream_t stream)
 {
-    const Lds L = lds_layout(p.maxRow, p.k, p.spec);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kbest_kernel<NW>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kbest_kernel<NW>, dim3(B), dim3(NW * 64), L.total, stream, p);
-    return hipGetLastError();
+    return (p.k <= NW * 64) ? launch_nw_ept<NW, 1>(p, B, stream) : launch_nw_ept<NW, 4>(p, B, stream);
 }
 
 hipError_t launch_kbest(const Params &p, int B, int nWaves, hipStream_t stream)
@@ -1054,7 +1059,6 @@ hipError_t launch_kbest(const Params &p, int B, int nWaves, hipStream_t stream)
     case 1: return launch_nw<1>(p, B, stream);
     case 2: return launch_nw<2>(p, B, stream);
     case 4: return launch_nw<4>(p, B, stream);
-    case 10: return launch_nw<10>(p, B, stream);
     case 12: return launch_nw<12>(p, B, stream);
     case 16: return launch_nw<16>(p, B, stream);
     default: return launch_nw<8>(p, B, stream);
