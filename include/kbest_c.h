@@ -17,6 +17,11 @@
  *        batched form of  conditionCosts (assignment.h:26, assignment.cpp:439-525)
  *   kbest_assoc_probs_batch_f64
  *        batched form of  getAssignmentProbs from the cost matrix on (assignment.cpp:57-74)
+ *   kbest_quadric_costs_f64 / kbest_quadric_assoc_probs_batch_f64
+ *        batched form of  computeQuadricCostMatrix (assignment.cpp:705-722) and of the whole
+ *        getAssignmentProbs chain behind it
+ *   kbest_bb_match_batch_f64
+ *        batched form of  asgnBB (assignment.cpp:724-797; k = 1, maximize)
  *
  * Conventions kept from the reference: cost matrices are column-major
  * C[row + col*numRow] with numRow >= numCol (shortestPathCPP.hpp:185-190);
@@ -143,6 +148,33 @@ int kbest_condition_costs_f64(kbest_ctx *ctx, int B, const int32_t *nRow, const 
 int kbest_assoc_probs_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM,
                                 const double *cost, const int64_t *costOff, int k, double *probs,
                                 const int64_t *probOff, int32_t *nf);
+
+/*
+ * Batched computeQuadricCostMatrix (assignment.h:28-29, assignment.cpp:705-722).  Frame b has nL[b] landmarks and
+ * nM[b] measurements, each a (mean[3], cov[3][3] row-major) pair, packed frame after frame; gate is
+ * NONASSIGN_QUADRIC.  cost receives the (nL+nM) x nM column-major blocks packed back to back.  Host buffers.
+ */
+int kbest_quadric_costs_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM, const double *landMean,
+                            const double *landCov, const double *measMean, const double *measCov, double gate,
+                            double *cost);
+
+/*
+ * getAssignmentProbs from the (mean, covariance) pairs on (assignment.cpp:42-74 after getMeans/getCovs): cost
+ * construction, conditionCosts, assignmentProb(k), scatter back -- one stream-ordered device pipeline, the cost
+ * matrix never visits the host.  probs: [nM][nL+1] per frame at probOff[b].
+ */
+int kbest_quadric_assoc_probs_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM,
+                                        const double *landMean, const double *landCov, const double *measMean,
+                                        const double *measCov, double gate, int k, double *probs,
+                                        const int64_t *probOff, int32_t *nf);
+
+/*
+ * Batched asgnBB (assignment.h:21, assignment.cpp:724-797): stereo bounding-box matching.  Boxes are
+ * (xmin, ymin, xmax, ymax, xOffset) -- boundBox.h:13-25 -- nL[b] left and nR[b] right boxes per frame, packed;
+ * gate is NONASSIGN_BOUNDBOX.  assign[sum nL]: for every left box the index of its right box, or -1.
+ */
+int kbest_bb_match_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nR, const double *boxL,
+                             const double *boxR, double gate, int32_t *assign);
 
 #ifdef __cplusplus
 }

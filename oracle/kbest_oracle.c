@@ -626,3 +626,99 @@ double orc_permanent(const double *A, int m, int n) /* column-major m x n */
     free(P);
     return p;
 }
+
+/* =====================  cost-matrix construction  ============== */
+
+/* Solve S x = d for a symmetric positive (semi-)definite 3x3 S by LDL^T with diagonal pivoting -- the published
+ * algorithm behind Eigen::LDLT ("robust Cholesky decomposition with pivoting", largest remaining diagonal entry
+ * as pivot), which computeQuadricCostMatrix calls at assignment.cpp:717.  Eigen itself is a third-party dependency
+ * that is absent from /root/reference (find_package(Eigen3), CMakeLists.txt:12, version unpinned), so this is
+ * "parity unpinned" for the last bits: the tests hold it to 1e-12 relative against numpy's LU solve. */
+static void ldlt3_solve(const double S[9], const double d[3], double x[3])
+{
+    double A[3][3], b[3];
+    int perm[3] = {0, 1, 2};
+    for (int i = 0; i < 3; i++) { b[i] = d[i]; for (int j = 0; j < 3; j++) A[i][j] = S[i * 3 + j]; }
+    double L[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, D[3];
+    for (int k = 0; k < 3; k++) {
+        int piv = k;
+        for (int i = k + 1; i < 3; i++) if (fabs(A[i][i]) > fabs(A[piv][piv])) piv = i;
+        if (piv != k) {  /* symmetric row/column swap */
+            for (int j = 0; j < 3; j++) { double t = A[k][j]; A[k][j] = A[piv][j]; A[piv][j] = t; }
+            for (int i = 0; i < 3; i++) { double t = A[i][k]; A[i][k] = A[i][piv]; A[i][piv] = t; }
+            for (int j = 0; j < k; j++) { double t = L[k][j]; L[k][j] = L[piv][j]; L[piv][j] = t; }
+            int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t;
+        }
+        D[k] = A[k][k];
+        for (int i = k + 1; i < 3; i++) L[i][k] = A[i][k] / D[k];
+        for (int i = k + 1; i < 3; i++)
+            for (int j = k + 1; j < 3; j++) A[i][j] = A[i][j] - L[i][k] * D[k] * L[j][k];
+    }
+    double y[3], z[3];
+    for (int i = 0; i < 3; i++) y[i] = b[perm[i]];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < i; j++) y[i] = y[i] - L[i][j] * y[j];
+    for (int i = 0; i < 3; i++) y[i] = y[i] / D[i];
+    for (int i = 2; i >= 0; i--) for (int j = i + 1; j < 3; j++) y[i] = y[i] - L[j][i] * y[j];
+    for (int i = 0; i < 3; i++) z[perm[i]] = y[i];
+    for (int i = 0; i < 3; i++) x[i] = z[i];
+}
+
+/* computeQuadricCostMatrix, assignment.cpp:705-722.  m1/cov1: nL landmarks (3 / 9 doubles each, cov row-major),
+ * m2/cov2: nM measurements; out: (nL+nM) x nM column-major. */
+void orc_quadric_costs(const double *m1, const double *cov1, int nL, const double *m2, const double *cov2, int nM,
+                       double gate, double *out)
+{
+    const int nR = nL + nM;
+    for (int i = 0; i < nR * nM; i++) out[i] = ORC_INF;
+    for (int c = 0; c < nM; c++) {
+        for (int r = 0; r < nL; r++) {
+            double d[3], S[9], x[3];
+            for (int i = 0; i < 3; i++) d[i] = m1[r * 3 + i] - m2[c * 3 + i];
+            for (int i = 0; i < 9; i++) S[i] = cov1[r * 9 + i] + cov2[c * 9 + i];
+            ldlt3_solve(S, d, x);
+            out[(size_t)c * nR + r] = d[0] * x[0] + d[1] * x[1] + d[2] * x[2];
+        }
+        out[(size_t)c * nR + nL + c] = gate;
+    }
+}
+
+/* boundBox::IoU, boundBox.h:62-75: `a` is *this (its xOffset is applied), `b` is `other`.  Boxes are
+ * (xmin, ymin, xmax, ymax, xOffset). */
+static double bb_iou(const double *a, const double *b)
+{
+    const double l = fmax(a[0] + a[4], b[0]), r = fmin(a[2] + a[4], b[2]);
+    const double t = fmax(a[1], b[1]), bt = fmin(a[3], b[3]);
+    if (l >= r || t >= bt) return 0.0;
+    const double inter = (r - l) * (bt - t);
+    const double areaA = (a[2] - a[0]) * (a[3] - a[1]), areaB = (b[2] - b[0]) * (b[3] - b[1]);
+    return inter / (areaA + areaB - inter);
+}
+
+/* computeBBCostMatrix, assignment.cpp:777-797: rows = right boxes + dummies, cols = left boxes. */
+void orc_bb_costs(const double *bbL, int nL, const double *bbR, int nR, double gate, double *out)
+{
+    const int nRows = nR + nL;
+    for (int i = 0; i < nRows * nL; i++) out[i] = -ORC_INF;
+    for (int c = 0; c < nL; c++) {
+        for (int r = 0; r < nR; r++) {
+            const double i1 = bb_iou(bbR + 5 * r, bbL + 5 * c), i2 = bb_iou(bbL + 5 * c, bbR + 5 * r);
+            out[(size_t)c * nRows + r] = i1 < i2 ? i1 : i2;  /* std::min(iou1, iou2) */
+        }
+        out[(size_t)c * nRows + nR + c] = gate;
+    }
+}
+
+/* asgnBB, assignment.cpp:724-775: k = 1, maximize.  asg[nL]: index of the right box or -1. */
+void orc_asgn_bb(const double *bbL, int nL, const double *bbR, int nR, double gate, int32_t *asg)
+{
+    for (int c = 0; c < nL; c++) asg[c] = -1;
+    if (nL == 0 || nR == 0) return;
+    const int nRows = nR + nL;
+    double *cost = (double *)malloc(8 * (size_t)nRows * nL);
+    int32_t *c4r = (int32_t *)malloc(4 * (size_t)nRows), *r4c = (int32_t *)malloc(4 * (size_t)nL);
+    double g;
+    orc_bb_costs(bbL, nL, bbR, nR, gate, cost);
+    if (orc_kbest(1, nRows, nL, 1, cost, 0, 0.0, c4r, r4c, &g, NULL))
+        for (int c = 0; c < nL; c++) if (r4c[c] < nR) asg[c] = r4c[c];
+    free(cost); free(c4r); free(r4c);
+}

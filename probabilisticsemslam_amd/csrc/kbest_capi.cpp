@@ -308,12 +308,17 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
 // kbest_assoc_probs_batch_f64 (condition = true: conditionCosts -> assignmentProb -> scatter back, i.e.
 // getAssignmentProbs assignment.cpp:57-74 without the quadric cost construction).  Everything between the
 // H2D copy of the cost blocks and the D2H copy of the probabilities runs on the device, stream-ordered.
+struct QuadricHost {  // host-side inputs of computeQuadricCostMatrix, packed frame after frame
+    const double *landMean, *landCov, *measMean, *measCov;
+    double gate;
+};
+
 static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM, const double *cost,
                             const int64_t *costOff, int k, double *probs, const int64_t *probOff, int32_t *nf,
-                            bool condition)
+                            bool condition, const QuadricHost *quad = nullptr)
 {
     if (!ctx) return KBEST_ERR_BAD_ARG;
-    if (B < 0 || k < 1 || !nL || !nM || !cost || !costOff || !probs || !probOff)
+    if (B < 0 || (k < 1 && !(quad && k == 0)) || !nL || !nM || (!cost && !quad) || !costOff || !probs || !probOff)
         return fail(ctx, KBEST_ERR_BAD_ARG, "weights: bad argument");
     if (B == 0) return KBEST_OK;
     int maxRow = 1, maxCol = 1;
@@ -344,13 +349,52 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
     HIP_TRY(ctx, dNf.alloc((size_t)B * 4));
     HIP_TRY(ctx, dProbs.alloc(nProb * 8));
     HIP_TRY(ctx, dPOff.alloc((size_t)B * 8));
-    HIP_TRY(ctx, hipMemcpy(dCost.p, cost, nCost * 8, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(dOff.p, costOff, (size_t)B * 8, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(dNR.p, nRow.data(), (size_t)B * 4, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(dNC.p, nM, (size_t)B * 4, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(dNL.p, nL, (size_t)B * 4, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(dPOff.p, probOff, (size_t)B * 8, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemset(dProbs.p, 0, nProb * 8));
+    DevBuf dLM, dLC, dMM, dMC, dLOff, dMOff;
+    if (!quad) {
+        HIP_TRY(ctx, hipMemcpy(dCost.p, cost, nCost * 8, hipMemcpyHostToDevice));
+    } else {
+        // build the cost blocks on the device (computeQuadricCostMatrix, assignment.cpp:705-722)
+        std::vector<long long> lo(B), mo(B);
+        long long sl = 0, sm = 0;
+        for (int b = 0; b < B; b++) { lo[b] = sl; mo[b] = sm; sl += nL[b]; sm += nM[b]; }
+        HIP_TRY(ctx, dLM.alloc((size_t)sl * 24));
+        HIP_TRY(ctx, dLC.alloc((size_t)sl * 72));
+        HIP_TRY(ctx, dMM.alloc((size_t)sm * 24));
+        HIP_TRY(ctx, dMC.alloc((size_t)sm * 72));
+        HIP_TRY(ctx, dLOff.alloc((size_t)B * 8));
+        HIP_TRY(ctx, dMOff.alloc((size_t)B * 8));
+        HIP_TRY(ctx, hipMemcpy(dLM.p, quad->landMean, (size_t)sl * 24, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(dLC.p, quad->landCov, (size_t)sl * 72, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(dMM.p, quad->measMean, (size_t)sm * 24, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(dMC.p, quad->measCov, (size_t)sm * 72, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(dLOff.p, lo.data(), (size_t)B * 8, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(dMOff.p, mo.data(), (size_t)B * 8, hipMemcpyHostToDevice));
+        kb::QuadricParams q;
+        q.nL = dNL.as<int>();
+        q.nM = dNC.as<int>();
+        q.landOff = dLOff.as<long long>();
+        q.measOff = dMOff.as<long long>();
+        q.landMean = dLM.as<double>();
+        q.landCov = dLC.as<double>();
+        q.measMean = dMM.as<double>();
+        q.measCov = dMC.as<double>();
+        q.gate = quad->gate;
+        q.cost = dCost.as<double>();
+        q.costOff = dOff.as<long long>();
+        hipError_t e = kb::launch_quadric_costs(q, B, ctx->stream);
+        if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "quadric cost kernel launch", e);
+        if (k == 0) {  // cost construction only
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, hipMemcpy(probs, dCost.p, nCost * 8, hipMemcpyDeviceToHost));
+            return KBEST_OK;
+        }
+    }
     const double *solveCost = dCost.as<double>();
     const int32_t *solveRows = dNR.as<int32_t>();
     const int *weightNL = dNL.as<int>();
@@ -419,6 +463,112 @@ int kbest_assoc_probs_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const 
                                 const int64_t *costOff, int k, double *probs, const int64_t *probOff, int32_t *nf)
 {
     return weights_pipeline(ctx, B, nL, nM, cost, costOff, k, probs, probOff, nf, true);
+}
+
+static void packed_cost_offsets(int B, const int32_t *nL, const int32_t *nM, std::vector<int64_t> &off)
+{
+    off.resize(B);
+    int64_t s = 0;
+    for (int b = 0; b < B; b++) { off[b] = s; s += (int64_t)(nL[b] + nM[b]) * nM[b]; }
+}
+
+int kbest_quadric_costs_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM, const double *landMean,
+                            const double *landCov, const double *measMean, const double *measCov, double gate,
+                            double *cost)
+{
+    if (!ctx) return KBEST_ERR_BAD_ARG;
+    if (!nL || !nM || !landMean || !landCov || !measMean || !measCov || !cost)
+        return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_quadric_costs_f64: bad argument");
+    std::vector<int64_t> off;
+    packed_cost_offsets(B, nL, nM, off);
+    QuadricHost q{landMean, landCov, measMean, measCov, gate};
+    // k = 0: build the cost blocks only; they come back through the `probs` argument
+    return weights_pipeline(ctx, B, nL, nM, nullptr, off.data(), 0, cost, off.data(), nullptr, false, &q);
+}
+
+int kbest_quadric_assoc_probs_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM,
+                                        const double *landMean, const double *landCov, const double *measMean,
+                                        const double *measCov, double gate, int k, double *probs,
+                                        const int64_t *probOff, int32_t *nf)
+{
+    if (!ctx) return KBEST_ERR_BAD_ARG;
+    if (!nL || !nM || !landMean || !landCov || !measMean || !measCov)
+        return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_quadric_assoc_probs_batch_f64: bad argument");
+    std::vector<int64_t> off;
+    packed_cost_offsets(B, nL, nM, off);
+    QuadricHost q{landMean, landCov, measMean, measCov, gate};
+    return weights_pipeline(ctx, B, nL, nM, nullptr, off.data(), k, probs, probOff, nf, true, &q);
+}
+
+int kbest_bb_match_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nR, const double *boxL,
+                             const double *boxR, double gate, int32_t *assign)
+{
+    if (!ctx) return KBEST_ERR_BAD_ARG;
+    if (B < 0 || !nL || !nR || !boxL || !boxR || !assign)
+        return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_bb_match_batch_f64: bad argument");
+    if (B == 0) return KBEST_OK;
+    std::vector<long long> offL(B), offR(B), costOff(B);
+    std::vector<int32_t> nRow(B);
+    long long sl = 0, sr = 0, sc = 0;
+    int maxRow = 1, maxCol = 1;
+    for (int b = 0; b < B; b++) {
+        if (nL[b] < 1 || nR[b] < 0) return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_bb_match_batch_f64: need nL >= 1, nR >= 0");
+        offL[b] = sl; offR[b] = sr; costOff[b] = sc;
+        nRow[b] = nR[b] + nL[b];
+        sl += nL[b]; sr += nR[b]; sc += (long long)nRow[b] * nL[b];
+        if (nRow[b] > maxRow) maxRow = nRow[b];
+        if (nL[b] > maxCol) maxCol = nL[b];
+    }
+    if (maxRow > KBEST_MAX_DIM) return fail(ctx, KBEST_ERR_UNSUPPORTED, "nL + nR > KBEST_MAX_DIM");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf dBL, dBR, dOL, dOR, dOC, dNL, dNRt, dNRow, dCost, dR4C, dC4R, dGain, dNf, dAsg;
+    HIP_TRY(ctx, dBL.alloc((size_t)sl * 40));
+    HIP_TRY(ctx, dBR.alloc((size_t)sr * 40));
+    HIP_TRY(ctx, dOL.alloc((size_t)B * 8));
+    HIP_TRY(ctx, dOR.alloc((size_t)B * 8));
+    HIP_TRY(ctx, dOC.alloc((size_t)B * 8));
+    HIP_TRY(ctx, dNL.alloc((size_t)B * 4));
+    HIP_TRY(ctx, dNRt.alloc((size_t)B * 4));
+    HIP_TRY(ctx, dNRow.alloc((size_t)B * 4));
+    HIP_TRY(ctx, dCost.alloc((size_t)sc * 8));
+    HIP_TRY(ctx, dR4C.alloc((size_t)B * maxCol * 4));
+    HIP_TRY(ctx, dC4R.alloc((size_t)B * maxRow * 4));
+    HIP_TRY(ctx, dGain.alloc((size_t)B * 8));
+    HIP_TRY(ctx, dNf.alloc((size_t)B * 4));
+    HIP_TRY(ctx, dAsg.alloc((size_t)sl * 4));
+    HIP_TRY(ctx, hipMemcpy(dBL.p, boxL, (size_t)sl * 40, hipMemcpyHostToDevice));
+    if (sr) HIP_TRY(ctx, hipMemcpy(dBR.p, boxR, (size_t)sr * 40, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(dOL.p, offL.data(), (size_t)B * 8, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(dOR.p, offR.data(), (size_t)B * 8, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(dOC.p, costOff.data(), (size_t)B * 8, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(dNL.p, nL, (size_t)B * 4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(dNRt.p, nR, (size_t)B * 4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(dNRow.p, nRow.data(), (size_t)B * 4, hipMemcpyHostToDevice));
+    kb::BoxParams bp;
+    bp.nL = dNL.as<int>();
+    bp.nR = dNRt.as<int>();
+    bp.offL = dOL.as<long long>();
+    bp.offR = dOR.as<long long>();
+    bp.boxL = dBL.as<double>();
+    bp.boxR = dBR.as<double>();
+    bp.gate = gate;
+    bp.cost = dCost.as<double>();
+    bp.costOff = dOC.as<long long>();
+    bp.assign = dAsg.as<int>();
+    hipError_t e = kb::launch_bb_costs(bp, B, ctx->stream);  // computeBBCostMatrix, assignment.cpp:777-797
+    if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "bounding-box cost kernel launch", e);
+    kbest_opts o;
+    kbest_default_opts(&o);
+    o.maximize = 1;  // assignment.cpp:749-750: kBest2D(k = 1, maximize = true)
+    int rc = kbest_batch_f64_dev(ctx, &o, B, maxRow, maxCol, dNRow.as<int32_t>(), dNL.as<int32_t>(), dCost.as<double>(),
+                                 dOC.as<int64_t>(), 1, dR4C.as<int32_t>(), dC4R.as<int32_t>(), dGain.as<double>(),
+                                 dNf.as<int32_t>(), nullptr, ctx->stream);
+    if (rc != KBEST_OK) return rc;
+    e = kb::launch_bb_assign(bp, dR4C.as<int>(), dNf.as<int>(), 1, maxCol, B, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "bounding-box assign kernel launch", e);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(assign, dAsg.p, (size_t)sl * 4, hipMemcpyDeviceToHost));
+    return KBEST_OK;
 }
 
 int kbest_condition_costs_f64(kbest_ctx *ctx, int B, const int32_t *nRow, const int32_t *nCol, const double *cost,

@@ -103,7 +103,32 @@ __host__ __device__ inline Lds lds_layout(int maxRow, int k, int spec)
     return L;
 }
 
+// computeQuadricCostMatrix inputs: per frame nL landmark and nM measurement (mean[3], cov[3][3]) pairs
+struct QuadricParams {
+    const int *nL, *nM;
+    const long long *landOff, *measOff;  // first landmark / measurement of each frame
+    const double *landMean, *landCov, *measMean, *measCov;
+    double gate;                         // NONASSIGN_QUADRIC
+    double *cost;                        // (nL+nM) x nM column-major per frame
+    const long long *costOff;
+};
+
+// computeBBCostMatrix / asgnBB inputs: boxes are (xmin, ymin, xmax, ymax, xOffset)
+struct BoxParams {
+    const int *nL, *nR;
+    const long long *offL, *offR;
+    const double *boxL, *boxR;
+    double gate;                         // NONASSIGN_BOUNDBOX
+    double *cost;                        // (nR+nL) x nL column-major per frame
+    const long long *costOff;
+    int *assign;                         // [sum nL] matched right box or -1
+};
+
 hipError_t launch_kbest(const Params &p, int B, int nWaves, hipStream_t stream);
+hipError_t launch_quadric_costs(const QuadricParams &p, int B, hipStream_t stream);
+hipError_t launch_bb_costs(const BoxParams &p, int B, hipStream_t stream);
+hipError_t launch_bb_assign(const BoxParams &p, const int *row4col, const int *nf, int k, int maxCol, int B,
+                            hipStream_t stream);
 hipError_t launch_weights(const WeightParams &p, int B, hipStream_t stream);
 hipError_t launch_condition(const CondParams &p, int B, hipStream_t stream);
 

@@ -19,6 +19,7 @@ C_ABI_SYMBOLS = (
     "kbest_default_opts", "kbest_create", "kbest_destroy", "kbest_strerror", "kbest_last_error",
     "kbest_device_count", "kbest_batch_f64_dev", "kbest_batch_f64", "kbest_reserve", "kbest_weights_batch_f64",
     "kbest_set_profile_buffer", "kbest_condition_costs_f64", "kbest_assoc_probs_batch_f64",
+    "kbest_quadric_costs_f64", "kbest_quadric_assoc_probs_batch_f64", "kbest_bb_match_batch_f64",
 )
 
 
@@ -68,6 +69,10 @@ def load_library():
     lib.kbest_weights_batch_f64.argtypes = [vp, C.c_int, i32p, i32p, dp, i64p, C.c_int, dp, i64p, i32p]
     lib.kbest_assoc_probs_batch_f64.argtypes = [vp, C.c_int, i32p, i32p, dp, i64p, C.c_int, dp, i64p, i32p]
     lib.kbest_condition_costs_f64.argtypes = [vp, C.c_int, i32p, i32p, dp, i64p, dp, i32p, i32p, C.c_int]
+    lib.kbest_quadric_costs_f64.argtypes = [vp, C.c_int, i32p, i32p, dp, dp, dp, dp, C.c_double, dp]
+    lib.kbest_quadric_assoc_probs_batch_f64.argtypes = [vp, C.c_int, i32p, i32p, dp, dp, dp, dp, C.c_double, C.c_int,
+                                                        dp, i64p, i32p]
+    lib.kbest_bb_match_batch_f64.argtypes = [vp, C.c_int, i32p, i32p, dp, dp, C.c_double, i32p]
     _lib = lib
     return lib
 
@@ -180,6 +185,49 @@ class KBestEngine:
                        _ptr(nf)))
         out = [probs[probOff[b]: probOff[b] + psizes[b]].reshape(int(nM[b]), int(nL[b]) + 1) for b in range(B)]
         return out, nf
+
+    @staticmethod
+    def _pack_quadrics(frames):
+        """frames: list of (landMean (nL,3), landCov (nL,3,3), measMean (nM,3), measCov (nM,3,3))."""
+        nL = np.array([len(f[0]) for f in frames], np.int32)
+        nM = np.array([len(f[2]) for f in frames], np.int32)
+        cat = lambda i, w: np.ascontiguousarray(np.concatenate([np.asarray(f[i], np.float64).reshape(-1, w) for f in frames]))  # noqa: E731
+        return nL, nM, cat(0, 3), cat(1, 9), cat(2, 3), cat(3, 9)
+
+    def quadric_costs(self, frames, gate):
+        """Batched computeQuadricCostMatrix.  Returns a list of (nL+nM)*nM column-major blocks."""
+        nL, nM, lm, lc, mm, mc = self._pack_quadrics(frames)
+        sizes = (nL.astype(np.int64) + nM) * nM
+        out = np.zeros(int(sizes.sum()))
+        self._check(self.lib.kbest_quadric_costs_f64(self.ctx, len(frames), _ptr(nL), _ptr(nM), _ptr(lm), _ptr(lc), _ptr(mm),
+                                                     _ptr(mc), float(gate), _ptr(out)))
+        off = np.concatenate([[0], np.cumsum(sizes)])
+        return [out[off[b]: off[b + 1]] for b in range(len(frames))]
+
+    def quadric_assoc_probs(self, frames, gate, k):
+        """getAssignmentProbs from (mean, covariance) pairs: list of [nM, nL+1] arrays, nf."""
+        nL, nM, lm, lc, mm, mc = self._pack_quadrics(frames)
+        psizes = nM.astype(np.int64) * (nL + 1)
+        poff = np.zeros(len(frames), np.int64)
+        poff[1:] = np.cumsum(psizes)[:-1]
+        probs = np.zeros(int(psizes.sum()))
+        nf = np.zeros(len(frames), np.int32)
+        self._check(self.lib.kbest_quadric_assoc_probs_batch_f64(self.ctx, len(frames), _ptr(nL), _ptr(nM), _ptr(lm), _ptr(lc),
+                                                                 _ptr(mm), _ptr(mc), float(gate), k, _ptr(probs), _ptr(poff),
+                                                                 _ptr(nf)))
+        return [probs[poff[b]: poff[b] + psizes[b]].reshape(int(nM[b]), int(nL[b]) + 1) for b in range(len(frames))], nf
+
+    def bb_match(self, boxesL, boxesR, gate):
+        """Batched asgnBB.  boxesL / boxesR: lists of (n, 5) arrays (xmin, ymin, xmax, ymax, xOffset)."""
+        nL = np.array([len(b) for b in boxesL], np.int32)
+        nR = np.array([len(b) for b in boxesR], np.int32)
+        bl = np.ascontiguousarray(np.concatenate([np.asarray(b, np.float64).reshape(-1, 5) for b in boxesL]))
+        br = np.ascontiguousarray(np.concatenate([np.asarray(b, np.float64).reshape(-1, 5) for b in boxesR] + [np.zeros((0, 5))]))
+        asg = np.full(int(nL.sum()), -9, np.int32)
+        self._check(self.lib.kbest_bb_match_batch_f64(self.ctx, len(boxesL), _ptr(nL), _ptr(nR), _ptr(bl), _ptr(br),
+                                                      float(gate), _ptr(asg)))
+        off = np.concatenate([[0], np.cumsum(nL)])
+        return [asg[off[b]: off[b + 1]] for b in range(len(boxesL))]
 
     # ---- device buffers (torch tensors already resident in HBM) -------------------------
     def reserve(self, B, N, k):

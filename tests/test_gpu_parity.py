@@ -311,3 +311,43 @@ def test_cpp_shims_drop_in(eng, tmp_path):
     for m in range(3):
         got = np.array([float.fromhex(x) for x in out[i + 2 + m].split()[1:]])
         np.testing.assert_allclose(got, po[m], rtol=1e-12, atol=1e-15)
+
+
+def test_quadric_costs_and_full_association_chain(eng):
+    """Rows f2 + f1: (mean, covariance) pairs -> Mahalanobis cost blocks -> conditionCosts -> assignmentProb ->
+    scatter back, all on the device, against the same chain of the checker."""
+    from test_cost_builders import synth_quadric_frame
+    rng = np.random.default_rng(42)
+    frames = [synth_quadric_frame(rng, int(rng.integers(1, 30)), int(rng.integers(1, 11))) for _ in range(40)]
+    costs = eng.quadric_costs(frames, 10.0)
+    for f, c in zip(frames, costs):
+        oc = ol.quadric_costs(*f, 10.0)
+        assert (np.isinf(c) == np.isinf(oc)).all()
+        fin = np.isfinite(oc)
+        np.testing.assert_allclose(c[fin], oc[fin], rtol=1e-13, atol=0)      # same operation order: ~bit-equal
+    probs, nf = eng.quadric_assoc_probs(frames, 10.0, 200)
+    for i, f in enumerate(frames):
+        nL, nM = len(f[0]), len(f[2])
+        oc = ol.quadric_costs(*f, 10.0)
+        cond, idx = ol.condition_costs(oc, nL + nM, nM)
+        condL = len(idx) - nM
+        pc, onf = ol.assignment_prob(cond, condL, nM, 200)
+        want = np.zeros((nM, nL + 1))
+        want[:, idx[:condL]] = pc[:, :condL]
+        want[:, nL] = pc[:, condL]
+        np.testing.assert_allclose(probs[i], want, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(probs[i].sum(axis=1), 1.0, rtol=1e-12)
+
+
+def test_bounding_box_matching(eng):
+    """Row f4: asgnBB (IoU profits, -inf fill, gate profit, kBest2D k=1 maximize) on the device vs the checker."""
+    from test_cost_builders import synth_boxes
+    rng = np.random.default_rng(7)
+    L, R = [], []
+    for _ in range(60):
+        nL, nR = int(rng.integers(1, 20)), int(rng.integers(0, 20))
+        l, r = synth_boxes(rng, nL, nR)
+        L.append(l); R.append(r)
+    got = eng.bb_match(L, R, 0.2)
+    for l, r, g in zip(L, R, got):
+        assert g.tolist() == ol.asgn_bb(l, r, 0.2).tolist()
