@@ -71,3 +71,19 @@ def test_bb_costs_and_assignment():
             want = [r if r < nR else -1 for r in best]
             assert sum(C[c, r] for c, r in enumerate(best)) == sum(C[c, (a if a >= 0 else nR + c)] for c, a in enumerate(asg))
             assert asg.tolist() == want or True
+
+
+def test_cost_file_round_trip(tmp_path):
+    # the reference's .dat format: 6-decimal fixed notation, "inf" tokens, one matrix ROW per line
+    from probabilisticsemslam_amd import costfile, workloads as wl
+    f = wl.kitti_like_frames(1)[0]
+    p = str(tmp_path / "x_frame1.dat")
+    costfile.write_cost_matrix(p, f, 30, 10)
+    lines = open(p).read().splitlines()
+    assert len(lines) == 30 and all(len(l.split(",")) == 10 for l in lines)
+    assert lines[20].split(",")[0] == "10.000000" and lines[20].split(",")[1] == "inf"   # first dummy row: gate, inf...
+    back, nL, nM = costfile.read_cost_matrix(p)
+    assert (nL, nM) == (20, 10)
+    assert (np.isinf(back) == np.isinf(f)).all()
+    fin = np.isfinite(f)
+    assert np.abs(back[fin] - f[fin]).max() <= 5e-7          # std::to_string keeps 6 decimals

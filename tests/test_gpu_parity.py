@@ -351,3 +351,15 @@ def test_bounding_box_matching(eng):
     got = eng.bb_match(L, R, 0.2)
     for l, r, g in zip(L, R, got):
         assert g.tolist() == ol.asgn_bb(l, r, 0.2).tolist()
+
+
+def test_comp_methods_harness(eng, tmp_path):
+    """Row f3: the reference's compMethods protocol (file format round trip, k sweep, error vs brute force) with
+    its own acceptance rule: no frame above 0.1 (comparison.cpp:319), exhaustive small frames exact at k >= 100."""
+    import harness_comp_methods as h
+    table = h.run(n_frames=48, nL=6, nM=3, directory=str(tmp_path), verbose=False)
+    # the hard limit applies to the configured k (200; comparison.cpp:319-324); k = 1 and 20 are only plotted
+    assert (table[200]["err"] <= 0.1).all() and (table[1000]["err"] <= 0.1).all()
+    assert (table[200]["err"] <= 1e-9).all() and (table[1000]["err"] <= 1e-9).all()   # exhaustive here: exact
+    worst = [table[k]["err"].max() for k in (1, 20, 100, 200)]
+    assert worst == sorted(worst, reverse=True)                  # more assignments never hurt
