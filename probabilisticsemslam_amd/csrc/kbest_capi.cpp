@@ -334,7 +334,12 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
         if (ce > nCost) nCost = ce;
         if (pe > nProb) nProb = pe;
     }
-    if (maxRow > KBEST_MAX_DIM) return fail(ctx, KBEST_ERR_UNSUPPORTED, "nL + nM > KBEST_MAX_DIM");
+    if (maxCol > KBEST_MAX_DIM) return fail(ctx, KBEST_ERR_UNSUPPORTED, "nM > KBEST_MAX_DIM");
+    // With conditioning the RAW matrix may have any number of rows (all landmarks of the map); only what
+    // conditionCosts keeps must fit the solver, and a frame where it does not comes back with nf = -1.
+    const int rawMaxRow = maxRow;
+    if (!condition && maxRow > KBEST_MAX_DIM) return fail(ctx, KBEST_ERR_UNSUPPORTED, "nL + nM > KBEST_MAX_DIM");
+    if (maxRow > KBEST_MAX_DIM) maxRow = KBEST_MAX_DIM;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DevBuf dCost, dCond, dOff, dNR, dNC, dNL, dGood, dCondL, dRowIdx, dR4C, dC4R, dGain, dNf, dProbs, dPOff;
     const size_t nR4C = (size_t)B * k * maxCol, nC4R = (size_t)B * k * maxRow, nG = (size_t)B * k;
@@ -402,7 +407,7 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
         HIP_TRY(ctx, dCond.alloc(nCost * 8));
         HIP_TRY(ctx, dGood.alloc((size_t)B * 4));
         HIP_TRY(ctx, dCondL.alloc((size_t)B * 4));
-        HIP_TRY(ctx, dRowIdx.alloc((size_t)B * maxRow * 4));
+        HIP_TRY(ctx, dRowIdx.alloc((size_t)B * rawMaxRow * 4));
         kb::CondParams c;
         c.cost = dCost.as<double>();
         c.costOff = dOff.as<long long>();
@@ -412,7 +417,7 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
         c.goodRows = dGood.as<int>();
         c.condL = dCondL.as<int>();
         c.rowIdx = dRowIdx.as<int>();
-        c.maxRow = maxRow;
+        c.maxRow = rawMaxRow;
         hipError_t e = kb::launch_condition(c, B, ctx->stream);
         if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "condition kernel launch", e);
         solveCost = dCond.as<double>();
@@ -441,7 +446,7 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
     w.maxCol = maxCol;
     w.rowIdx = condition ? dRowIdx.as<int>() : nullptr;
     w.nLout = dNL.as<int>();
-    w.maxRow = maxRow;
+    w.maxRow = rawMaxRow;
     {
         std::lock_guard<std::mutex> lock(ctx->mu);
         hipError_t e = kb::launch_weights(w, B, ctx->stream);
@@ -578,7 +583,6 @@ int kbest_condition_costs_f64(kbest_ctx *ctx, int B, const int32_t *nRow, const 
     if (B < 0 || !nRow || !nCol || !cost || !costOff || !out || !goodRows || !rowIdx || maxRow < 1)
         return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_condition_costs_f64: bad argument");
     if (B == 0) return KBEST_OK;
-    if (maxRow > KBEST_MAX_DIM) return fail(ctx, KBEST_ERR_UNSUPPORTED, "numRow > KBEST_MAX_DIM");
     size_t nCost = 0;
     for (int b = 0; b < B; b++) {
         if (nRow[b] < 1 || nCol[b] < 1 || nRow[b] > maxRow || nCol[b] > KBEST_MAX_DIM)

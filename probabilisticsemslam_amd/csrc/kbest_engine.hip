@@ -560,6 +560,8 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         double T = (nOld >= R) ? PG[head + R - 1] : INF;
         if (useCut && !maximize && cutG < T) T = cutG;
         const double cmaxv = ctrl->cmax;
+        KB_T(tF0);
+        KB_ACC(14, tF0 - tRound);  // [14] round prologue (control reads)
         {
             // all NW waves take part: node = wave % nsel, and the waves of one node split its columns j.
             // Walking the parent's columns j >= a instead of the rows makes the candidate test a scalar lane mask:
@@ -613,6 +615,8 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 if (c < M) atomicMin(&lbKey[nodeI * 64 + lane], key);
             }
         }
+        KB_T(tF1);
+        KB_ACC(15, tF1 - tF0);     // [15] first-step filter busy
         __syncthreads();
         if (wave < nsel) {  // one wave per node: survivors = finite minimum (else infeasible, cpp:327) within the bound
             const NodeRef nd = node_ref(smem + L.offNodes + (size_t)wave * L.nodeStride, p.maxRow);
@@ -631,7 +635,6 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             if (lane == 0 && km) base = atomicAdd(&ctrl->nSurv, __popcll(km));
             base = uni32(base);
             if (keep) surv[base + __popcll(km & ((1ull << lane) - 1ull))] = (unsigned short)((wave << 8) | c);
-            KB_ACC(14, __popcll(__ballot(live)));  // [14] children before the filter
         }
         __syncthreads();
         // -- B2: surviving children (shortestPathUpdateCPP, gain only), dynamic queue over the survivor list.  The
@@ -950,7 +953,8 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
 // ------------------------------------------------- conditionCosts prologue
 // conditionCosts (assignment.cpp:439-525): column minima (:450-458); a row is kept iff some entry is within
 // 42 of its column's minimum (:462-474); kept rows are compacted in order, entries become cost - colMin or
-// +inf beyond the gate (:476-496).  One wave per cost matrix, lane = row.
+// +inf beyond the gate (:476-496).  One wave per cost matrix walking the rows 64 at a time, so the RAW matrix
+// may have any number of rows (every landmark of the map): only the conditioned matrix has to fit the solver.
 __global__ void __launch_bounds__(64) condition_kernel(CondParams p)
 {
     __shared__ double colMin[64];
@@ -958,24 +962,40 @@ __global__ void __launch_bounds__(64) condition_kernel(CondParams p)
     const int nR = p.nRow[b], nC = p.nCol[b];
     const double *C = p.cost + p.costOff[b];
     double *out = p.out + p.costOff[b];
+    int *ridx = p.rowIdx + (long long)b * p.maxRow;
     const double INF = d_inf(), GATE = 42.0;  // assignment.cpp:9
     for (int c = 0; c < nC; c++) {
-        const double x = (lane < nR) ? C[(long long)c * nR + lane] : INF;
-        const double m = wave_min_f64(x);
+        double m = INF;
+        for (int r = lane; r < nR; r += 64) m = min_keep(m, C[(long long)c * nR + r]);
+        m = wave_min_f64(m);
         if (lane == 0) colMin[c] = m;
     }
     __syncthreads();
-    bool good = false;
-    for (int c = 0; c < nC; c++)
-        if (lane < nR && C[(long long)c * nR + lane] <= colMin[c] + GATE) good = true;
-    const u64 mask = __ballot(good);
-    const int g = __popcll(mask);
-    const int nr = __popcll(mask & ((1ull << lane) - 1ull));
-    for (int c = 0; c < nC; c++) {
-        const double x = (lane < nR) ? C[(long long)c * nR + lane] : INF;
-        if (good) out[(long long)c * g + nr] = (x <= colMin[c] + GATE) ? (x - colMin[c]) : INF;
+    int g = 0;  // kept rows
+    for (int r0 = 0; r0 < nR; r0 += 64) {
+        const int r = r0 + lane;
+        bool good = false;
+        for (int c = 0; c < nC; c++)
+            if (r < nR && C[(long long)c * nR + r] <= colMin[c] + GATE) good = true;
+        g += __popcll(__ballot(good));
     }
-    if (good) p.rowIdx[(long long)b * p.maxRow + nr] = lane;
+    int base = 0;
+    for (int r0 = 0; r0 < nR; r0 += 64) {
+        const int r = r0 + lane;
+        bool good = false;
+        for (int c = 0; c < nC; c++)
+            if (r < nR && C[(long long)c * nR + r] <= colMin[c] + GATE) good = true;
+        const u64 mask = __ballot(good);
+        const int nr = base + __popcll(mask & ((1ull << lane) - 1ull));
+        if (good) {
+            ridx[nr] = r;
+            for (int c = 0; c < nC; c++) {
+                const double x = C[(long long)c * nR + r];
+                out[(long long)c * g + nr] = (x <= colMin[c] + GATE) ? (x - colMin[c]) : INF;
+            }
+        }
+        base += __popcll(mask);
+    }
     if (lane == 0) {
         p.goodRows[b] = g;
         if (p.condL) p.condL[b] = g - nC;  // assignment.cpp:60
@@ -1001,6 +1021,7 @@ __global__ void __launch_bounds__(64) weights_kernel(WeightParams p)
     for (int i = lane; i < nM * (nLo + 1); i += 64) probs[i] = 0.0;
     __syncthreads();
     if (nL < 0) return;  // fewer kept rows than measurements: undefined in the reference (size_t underflow, :60)
+    if (nM > 1 && p.nf[b] < 0) return;  // the conditioned matrix did not fit the solver: probabilities stay 0, nf < 0
     if (nM == 1) {
         const double *cost = p.cost + p.costOff[b];
         if (lane == 0) {

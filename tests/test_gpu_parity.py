@@ -363,3 +363,40 @@ def test_comp_methods_harness(eng, tmp_path):
     assert (table[200]["err"] <= 1e-9).all() and (table[1000]["err"] <= 1e-9).all()   # exhaustive here: exact
     worst = [table[k]["err"].max() for k in (1, 20, 100, 200)]
     assert worst == sorted(worst, reverse=True)                  # more assignments never hurt
+
+
+def test_large_maps_condition_down_to_solver_size(eng):
+    """getAssignmentProbs sees EVERY landmark of the map: the raw (nL+nM) x nM matrix can have hundreds of rows.
+    conditionCosts runs on the device for any row count; only what it keeps has to fit the 64-row solver."""
+    from test_cost_builders import synth_quadric_frame
+    rng = np.random.default_rng(99)
+    frames = []
+    for _ in range(12):
+        nL, nM = int(rng.integers(150, 400)), int(rng.integers(2, 8))
+        lm, lc, mm, mc = synth_quadric_frame(rng, nL, nM)
+        frames.append((lm * 8.0, lc, mm * 8.0, mc))          # spread out: most landmarks are far from every measurement
+    probs, nf = eng.quadric_assoc_probs(frames, 10.0, 200)
+    checked = 0
+    for i, f in enumerate(frames):
+        nL, nM = len(f[0]), len(f[2])
+        oc = ol.quadric_costs(*f, 10.0)
+        cond, idx = ol.condition_costs(oc, nL + nM, nM)
+        if len(idx) > 64:
+            assert nf[i] == -1 and (probs[i] == 0).all()      # loud, not wrong
+            continue
+        condL = len(idx) - nM
+        pc, onf = ol.assignment_prob(cond, condL, nM, 200)
+        want = np.zeros((nM, nL + 1))
+        want[:, idx[:condL]] = pc[:, :condL]
+        want[:, nL] = pc[:, condL]
+        assert nf[i] == onf
+        np.testing.assert_allclose(probs[i], want, rtol=1e-9, atol=1e-12)
+        checked += 1
+    assert checked >= 8
+    # and conditionCosts alone on a tall matrix, bit-exact
+    f = frames[0]
+    oc = ol.quadric_costs(*f, 10.0)
+    nR, nC = len(f[0]) + len(f[2]), len(f[2])
+    conds, ridx = eng.condition_costs([oc], [nR], [nC])
+    wc, wi = ol.condition_costs(oc, nR, nC)
+    assert (ridx[0] == wi).all() and (bits(conds[0]) == bits(wc)).all()

@@ -40,12 +40,13 @@ ms = e0.elapsed_time(e1)
 p = prof.cpu().numpy().astype(np.float64)
 m = p.mean(axis=0)
 names = ["setup+root", "B busy", "C merge(+barrier)", "A/D busy", "children started", "child steps", "children completed",
-         "rounds", "cyc in child dijkstra", "cyc child set-up", "cyc flip+gain", "wait after B", "wait after A", "kernel cyc (sum over waves)"]
+         "rounds", "cyc in child dijkstra", "cyc child set-up", "cyc flip+gain", "wait after B", "wait after A", "kernel cyc (sum over waves)",
+         "round prologue", "first-step filter busy"]
 print(f"{cfg} B={B} NW={nw} SPEC={os.environ.get('KBEST_SPEC','4')} kernel {ms:.3f} ms (profiled build)")
 tot = m[13]
 for i, n in enumerate(names):
     extra = ""
-    if i in (0, 1, 2, 3, 8, 9, 10, 11, 12):
+    if i in (0, 1, 2, 3, 8, 9, 10, 11, 12, 14, 15):
         extra = f"  = {100*m[i]/tot:5.1f}% of wave-cycles"
     print(f"  [{i:2d}] {n:28s} {m[i]:14.1f}{extra}")
 print(f"  per wave kernel cycles {tot/nw:.0f}; cycles/step in child dijkstra {m[8]/max(m[5],1):.0f}; set-up cycles/child {m[9]/max(m[4],1):.0f}; "
