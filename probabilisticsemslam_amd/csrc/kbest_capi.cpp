@@ -50,7 +50,7 @@ int fail(kbest_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess)
 
 // Launch shape, tuned on MI355X.  Up to 32 rows: 4 waves per matrix, 4 candidates split per
 // round (the children of a small problem cannot keep more waves busy).  Above: the 32 KiB cost tile limits a CU to
-// three resident matrices, so either {8 waves, 4 candidates, 3 matrices/CU} -- the best throughput when the batch
+// three resident matrices, so either {8 waves, 6 candidates, 3 matrices/CU} -- the best throughput when the batch
 // fills whole rounds of 3 x CUs matrices -- or {12 waves, 8 candidates, 2 matrices/CU}, ~10 % less efficient per
 // matrix but without a nearly empty last round (1024 matrices on 256 CUs: 4.6 ms instead of 5.1 ms).
 struct Shape { int nWaves, spec; };
@@ -62,7 +62,7 @@ Shape choose_shape(const kbest_ctx *ctx, int B, int maxRow, int k)
     else {
         const double fa = (double)B / (3.0 * ctx->nCU), fb = (double)B / (2.0 * ctx->nCU);
         const double effA = fa / (double)(long long)(fa + 0.999999), effB = fb / (double)(long long)(fb + 0.999999);
-        if (effB * 0.9 > effA) { s.nWaves = 12; s.spec = 8; } else { s.nWaves = 8; s.spec = 4; }
+        if (effB * 0.9 > effA) { s.nWaves = 12; s.spec = 8; } else { s.nWaves = 8; s.spec = 6; }
     }
     if (ctx->nWaves > 0) s.nWaves = ctx->nWaves;
     if (ctx->spec > 0) s.spec = ctx->spec;

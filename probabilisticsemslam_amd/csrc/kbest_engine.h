@@ -78,7 +78,7 @@ __host__ __device__ inline long long state_stride(int maxRow)
 
 // LDS carve-up of one workgroup (= one cost matrix).
 struct Lds {
-    int offC, offNodes, nodeStride, offFreshG, offFreshM, offPoolG, offPoolM, offPoolS, offSurv, offLbKey, offFreshS, offCtrl, total;
+    int offC, offNodes, nodeStride, offFreshG, offFreshM, offPoolG, offPoolM, offPoolS, offSurv, offFreshS, offCtrl, total;
 };
 
 __host__ __device__ inline Lds lds_layout(int maxRow, int k, int spec)
@@ -90,8 +90,8 @@ __host__ __device__ inline Lds lds_layout(int maxRow, int k, int spec)
     L.nodeStride = (26 * maxRow + 32 + 7) & ~7;      // u, v, prefix (fp64), scalars, row4col, col4row (u8)
     L.offNodes = o;      o += spec * L.nodeStride;   // solved hypotheses waiting to be split
     L.offFreshG = o;     o += (spec * 64 > 16 ? spec * 64 : 16) * 8;  // surviving children of this round: gain
+                                                     //   (also: the first-step minima during the filter phase)
     L.offPoolG = o;      o += k * 8;                 // sorted candidate pool: gain
-    L.offLbKey = o;      o += spec * 64 * 8;         // first-step lower bounds of the current nodes' children
     L.offFreshM = o;     o += spec * 64 * 4;         //   (parent state, column)
     L.offPoolM = o;      o += k * 4;                 //   (parent state, column, flags)
     L.offPoolS = o;      o += k * 2;                 //   own state slot

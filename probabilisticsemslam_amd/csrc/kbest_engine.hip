@@ -386,7 +386,9 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     unsigned short *slotSid = p.slotSid + (long long)blockIdx.x * k;  // global: state slot of each output slot
     double *red = freshG;  // cross-wave reduction scratch of phase 0
     unsigned short *surv = reinterpret_cast<unsigned short *>(smem + L.offSurv);
-    u64 *lbKey = reinterpret_cast<u64 *>(smem + L.offLbKey);  // first-step minima of the current nodes' children
+    // first-step minima of the current nodes' children.  Shares its LDS with the fresh-gain list: the minima live
+    // from the filter to the survivor compaction (B1), the fresh gains from B2 to the first half of the merge.
+    u64 *lbKey = reinterpret_cast<u64 *>(smem + L.offFreshG);
     unsigned short *freshS = reinterpret_cast<unsigned short *>(smem + L.offFreshS);
     Ctrl *ctrl = reinterpret_cast<Ctrl *>(smem + L.offCtrl);
 
@@ -435,7 +437,6 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         cm = -wave_min_f64(-cm);
         if (lane == 0) red[wave] = cm;
         __syncthreads();
-        for (int i = tid; i < spec * 64; i += NT) lbKey[i] = ~0ull;
         if (tid == 0) {
             for (int w = 1; w < NW; w++) cm = red[w] > cm ? red[w] : cm;
             ctrl->cmax = cm;
@@ -455,6 +456,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             ctrl->selSid[0] = 0;
         }
         __syncthreads();
+        for (int i = tid; i < spec * 64; i += NT) lbKey[i] = ~0ull;  // (`red` is dead now)
     }
 
     unsigned char *stBase = p.states + (long long)b * maxSid * p.stateStride;
@@ -628,7 +630,6 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             const bool live = c < M && !(sid == 0 && p.rootColStride > 1 && (c % p.rootColStride) != p.rootColOffset);
             const u64 key = lbKey[wave * 64 + lane];
             const double m = from_key((int)((u32)(key >> 32) ^ 0x80000000u), (u32)key);
-            lbKey[wave * 64 + lane] = ~0ull;  // ready for the next round
             const bool keep = live && m < INF && !(m > bound);
             const u64 km = __ballot(keep);
             int base = 0;
@@ -789,6 +790,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             fg = g; fm = mj; fs = freshS[tid]; fpos = pos;
         }
         __syncthreads();
+        for (int i = tid; i < spec * 64; i += NT) lbKey[i] = ~0ull;  // the fresh gains are consumed: re-arm the minima
 #pragma unroll
         for (int e = 0; e < EPT; e++)
             if (opos[e] >= 0 && opos[e] < R) { PG[opos[e]] = og[e]; PM[opos[e]] = om[e]; PS[opos[e]] = os[e]; }
