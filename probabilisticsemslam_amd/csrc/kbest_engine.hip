@@ -316,8 +316,8 @@ struct Ctrl {
     int nextSid;   // next free state slot of the lazy region [0, lazyStates)
     int nextEager; // next free state slot of the eager region [lazyStates, statesPerProblem)
     int nFresh;    // surviving children appended this round
-    int nSurv;     // children that passed the first-step filter this round
-    int pad;
+    int nSurv;     // children that passed the first-step filter this round (queued from the front)
+    int nSurvBack; //   ... and those queued from the back
     int selIdx[8]; // pool index of each node selected in the last A phase (they are split in the next B)
     int selSid[8]; // and its state slot
 };
@@ -452,6 +452,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             ctrl->nextEager = p.lazyStates;
             ctrl->nFresh = 0;
             ctrl->nSurv = 0;
+            ctrl->nSurvBack = 0;
             ctrl->selIdx[0] = -1;
             ctrl->selSid[0] = 0;
         }
@@ -631,17 +632,26 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             const u64 key = lbKey[wave * 64 + lane];
             const double m = from_key((int)((u32)(key >> 32) ^ 0x80000000u), (u32)key);
             const bool keep = live && m < INF && !(m > bound);
-            const u64 km = __ballot(keep);
-            int base = 0;
-            if (lane == 0 && km) base = atomicAdd(&ctrl->nSurv, __popcll(km));
-            base = uni32(base);
-            if (keep) surv[base + __popcll(km & ((1ull << lane) - 1ull))] = (unsigned short)((wave << 8) | c);
+            // Children whose first step is far inside the bound tend to run long (they are the ones that complete):
+            // they are queued from the front, the others from the back, so that the long ones start first and the
+            // round does not end waiting for one late straggler.
+            const bool heavy = keep && !(m > 0.5 * bound);
+            const u64 kh = __ballot(heavy), kl = __ballot(keep && !heavy);
+            int baseH = 0, baseL = 0;
+            if (lane == 0 && kh) baseH = atomicAdd(&ctrl->nSurv, __popcll(kh));
+            if (lane == 0 && kl) baseL = atomicAdd(&ctrl->nSurvBack, __popcll(kl));
+            baseH = uni32(baseH);
+            baseL = uni32(baseL);
+            const u64 below = (1ull << lane) - 1ull;
+            if (heavy) surv[baseH + __popcll(kh & below)] = (unsigned short)((wave << 8) | c);
+            else if (keep) surv[spec * 64 - 1 - (baseL + __popcll(kl & below))] = (unsigned short)((wave << 8) | c);
         }
         __syncthreads();
         // -- B2: surviving children (shortestPathUpdateCPP, gain only), dynamic queue over the survivor list.  The
         //    per-node data a wave needs is cached in registers across consecutive items of the same node, and the
         //    next queue ticket is drawn before the current child is solved so that its LDS round trip is hidden.
-        const int totalItems = uni32(ctrl->nSurv);
+        const int nFront = uni32(ctrl->nSurv);
+        const int totalItems = nFront + uni32(ctrl->nSurvBack);
         {
             int npush = 0;
             int curW = -1, a = 0, sid = 0;
@@ -657,7 +667,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 if (item >= totalItems) break;
                 if (lane == 0) ticket = atomicAdd(&ctrl->nextItem, 1);  // prefetch the next ticket
                 KB_ACC(4, 1);  // [4] children started
-                const int sv = uni32((int)surv[item]);
+                const int sv = uni32((int)surv[item < nFront ? item : spec * 64 - 1 - (item - nFront)]);
                 const int w = sv >> 8, c = sv & 255;
                 if (w != curW) {  // (re)load this node's data
                     curW = w;
@@ -867,6 +877,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             ctrl->nextItem = 0;
             ctrl->nFresh = 0;
             ctrl->nSurv = 0;
+            ctrl->nSurvBack = 0;
             ctrl->nq = nq;
             ctrl->head = h;
 #pragma unroll
