@@ -1,8 +1,8 @@
-// proto_lazy.cpp -- DEV TOOL (not product, not test): host model of the
+// proto_lazy.cpp -- DEV TOOL under tests/ (it links the CPU checker, which only tests may do): host model of the
 // device algorithm used by csrc/kbest_engine.hip, to validate on the CPU that
 // "lazy children + bounded sorted pool + early termination" returns exactly
 // what the reference enumeration returns, and to count how much Dijkstra work
-// the pruning removes.  Build: see tools/Makefile (links the oracle as checker).
+// the pruning removes.  Build: g++ -O2 -ffp-contract=off -std=c++17 tests/dev/proto_lazy.cpp oracle/libkbest_oracle.so -Wl,-rpath,$PWD/oracle
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
