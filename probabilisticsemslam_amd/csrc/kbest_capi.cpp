@@ -71,6 +71,10 @@ Shape choose_shape(const kbest_ctx *ctx, int B, int maxRow, int k)
     return s;
 }
 
+// NOTE: the context's stream is created non-blocking, i.e. it does NOT order itself against the legacy default
+// stream.  Every device-side initialisation of the host-pointer entry points therefore goes through
+// hipMemsetAsync on the context's own stream (a plain hipMemset could still be in flight when the kernel runs and
+// wipe what the kernel has already written).  Host-to-device copies from pageable memory are complete on return.
 struct DevBuf {  // RAII device buffer for the host-pointer entry points
     void *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
@@ -174,7 +178,7 @@ int kbest_reserve(kbest_ctx *ctx, int B, int maxRow, int k)
 {
     if (!ctx || B < 0 || maxRow < 1 || k < 1) return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_reserve: bad argument");
     const size_t nStates = (size_t)B * (size_t)(k + ctx->extraStates + ctx->eagerStates) * (size_t)kb::state_stride(maxRow);
-    const size_t need = nStates + (size_t)B * (size_t)k * 2 + 256;
+    const size_t need = nStates + (size_t)B * (size_t)kb::slot_table_stride(k) * 2 + 256;
     if (need <= ctx->statesBytes) { ctx->slotSidOffset = (nStates + 127) & ~(size_t)127; return KBEST_OK; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->states) { HIP_TRY(ctx, hipDeviceSynchronize()); (void)hipFree(ctx->states); ctx->states = nullptr; ctx->statesBytes = 0; }
@@ -286,9 +290,9 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
     }
     if (pushed) HIP_TRY(ctx, dPushed.alloc((size_t)B * 8));
     // slots beyond nf are never written by the kernel: give them a defined value
-    HIP_TRY(ctx, hipMemset(dR4C.p, 0xFF, nR4C * 4));
-    HIP_TRY(ctx, hipMemset(dC4R.p, 0xFF, nC4R * 4));
-    HIP_TRY(ctx, hipMemset(dGain.p, 0, nG * 8));
+    HIP_TRY(ctx, hipMemsetAsync(dR4C.p, 0xFF, nR4C * 4, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(dC4R.p, 0xFF, nC4R * 4, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(dGain.p, 0, nG * 8, ctx->stream));
     int rc = kbest_batch_f64_dev(ctx, opts, B, maxRow, maxCol, nRow ? dNR.as<int32_t>() : nullptr,
                                  nRow ? dNC.as<int32_t>() : nullptr, dCost.as<double>(),
                                  costOff ? dOff.as<int64_t>() : nullptr, k, dR4C.as<int32_t>(), dC4R.as<int32_t>(),
@@ -359,7 +363,7 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
     HIP_TRY(ctx, hipMemcpy(dNC.p, nM, (size_t)B * 4, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(dNL.p, nL, (size_t)B * 4, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(dPOff.p, probOff, (size_t)B * 8, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemset(dProbs.p, 0, nProb * 8));
+    HIP_TRY(ctx, hipMemsetAsync(dProbs.p, 0, nProb * 8, ctx->stream));
     DevBuf dLM, dLC, dMM, dMC, dLOff, dMOff;
     if (!quad) {
         HIP_TRY(ctx, hipMemcpy(dCost.p, cost, nCost * 8, hipMemcpyHostToDevice));
@@ -603,8 +607,8 @@ int kbest_condition_costs_f64(kbest_ctx *ctx, int B, const int32_t *nRow, const 
     HIP_TRY(ctx, hipMemcpy(dOff.p, costOff, (size_t)B * 8, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(dNR.p, nRow, (size_t)B * 4, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(dNC.p, nCol, (size_t)B * 4, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemset(dOut.p, 0, nCost * 8));
-    HIP_TRY(ctx, hipMemset(dRowIdx.p, 0xFF, (size_t)B * maxRow * 4));
+    HIP_TRY(ctx, hipMemsetAsync(dOut.p, 0, nCost * 8, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(dRowIdx.p, 0xFF, (size_t)B * maxRow * 4, ctx->stream));
     kb::CondParams c;
     c.cost = dCost.as<double>();
     c.costOff = dOff.as<long long>();

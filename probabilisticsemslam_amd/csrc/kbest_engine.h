@@ -38,7 +38,7 @@ struct Params {
     int lazyStates;           // >= k: slots for the root and for candidates that are re-solved when selected
     int spec;                 // candidates re-solved / split per round (1 = the reference's order exactly)
     unsigned long long *prof; // [B][16] cycle stamps; only read by diagnostic builds (make PROFILE=1)
-    unsigned short *slotSid;  // workspace: [B][k] state slot of each output slot
+    unsigned short *slotSid;  // workspace: [B][slot_table_stride(k)] state slot of each output slot
 };
 
 struct CondParams {
@@ -75,6 +75,9 @@ __host__ __device__ inline long long state_stride(int maxRow)
     // lines: neighbouring states never share a cache line
     return ((((long long)26 * maxRow + 7) & ~7LL) + 24 + 127) & ~127LL;
 }
+
+// u16 entries of one matrix's slot -> state table, rounded to whole 128-byte lines
+__host__ __device__ inline long long slot_table_stride(int k) { return (((long long)k * 2 + 127) & ~127LL) / 2; }
 
 // LDS carve-up of one workgroup (= one cost matrix).
 struct Lds {

@@ -383,7 +383,10 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     double *PG = reinterpret_cast<double *>(smem + L.offPoolG);
     u32 *PM = reinterpret_cast<u32 *>(smem + L.offPoolM);
     unsigned short *PS = reinterpret_cast<unsigned short *>(smem + L.offPoolS);
-    unsigned short *slotSid = p.slotSid + (long long)blockIdx.x * k;  // global: state slot of each output slot
+    // global: state slot of each output slot.  One whole number of 128-byte lines per matrix: the table is written
+    // and later re-read by this workgroup through its CU's L1, and a line shared with a neighbouring matrix could
+    // have been pulled into that L1 earlier by another workgroup of the same CU (stale bytes for our half).
+    unsigned short *slotSid = p.slotSid + (long long)blockIdx.x * slot_table_stride(k);
     double *red = freshG;  // cross-wave reduction scratch of phase 0
     unsigned short *surv = reinterpret_cast<unsigned short *>(smem + L.offSurv);
     // first-step minima of the current nodes' children.  Shares its LDS with the fresh-gain list: the minima live
