@@ -95,8 +95,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # KBEST_BENCH_FORCE_DIST=1 runs the RCCL code path (init, all-gather, all-reduce) even with one rank: the only
+    # way to exercise it on a 1-GPU box
+    use_dist = world > 1 or os.environ.get("KBEST_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     Bc, N, M, k, seed = wl.DENSE_CONFIGS[args.config]
@@ -108,7 +114,7 @@ def main():
     d_gain = torch.empty((B, k), dtype=torch.float64, device=dev)
     d_nf = torch.empty(B, dtype=torch.int32, device=dev)
     d_pushed = torch.zeros(B, dtype=torch.int64, device=dev)
-    d_allgain = torch.empty((world * B, k), dtype=torch.float64, device=dev) if world > 1 else None
+    d_allgain = torch.empty((world * B, k), dtype=torch.float64, device=dev) if use_dist else None
 
     eng = pk.KBestEngine(local)
     eng.reserve(B, N, k)
@@ -118,6 +124,7 @@ def main():
     stream = tstream.cuda_stream
     assert stream != 0
 
+    torch.cuda.synchronize()  # the allocations / fills above ran on the default stream
     # untimed: the reference's push count P per matrix (no-prune mode), for the algorithmic byte count
     eng.kbest_dev(d_cost, B, N, M, k, d_r4c, d_c4r, d_gain, d_nf, d_pushed=d_pushed, prune=False, stream=stream)
     torch.cuda.synchronize()
@@ -127,12 +134,12 @@ def main():
 
     def step():
         eng.kbest_dev(d_cost, B, N, M, k, d_r4c, d_c4r, d_gain, d_nf, stream=stream)
-        if world > 1:  # global table of per-rank top-k gains (RCCL over xGMI)
+        if use_dist:  # global table of per-rank top-k gains (RCCL over xGMI)
             dist.all_gather_into_tensor(d_allgain, d_gain)
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -141,9 +148,9 @@ def main():
         ev[i][0].record()
         eng.kbest_dev(d_cost, B, N, M, k, d_r4c, d_c4r, d_gain, d_nf, stream=stream)
         ev[i][1].record()
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(d_allgain, d_gain)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -158,7 +165,7 @@ def main():
 
     t = torch.tensor([dt, kern_ms], dtype=torch.float64, device=dev)
     tot = torch.tensor([found, balg], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     dt_max, kern_ms_max = float(t[0]), float(t[1])
@@ -205,7 +212,9 @@ def main():
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_1core"] = out["value"] / cb["value"]
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
+        if world > 1:  # every rank must hold the same global table
+            assert torch.equal(d_allgain[rank * B:(rank + 1) * B], d_gain)
         dist.destroy_process_group()
 
 
