@@ -13,18 +13,24 @@
 //     lane, the arg-min is a DPP min-reduction + ballot/ff1 (lowest row index
 //     wins, as the ascending Row2Scan walk of the reference does), the
 //     scanned / candidate / forbidden row sets are 64-bit scalar masks;
-//   * lazy children: a child is solved for its assignment and its exact gain
-//     only (no dual update); the queue keeps (gain, parent, column).  The
-//     child that is eventually popped is re-solved from its parent's saved
-//     state (k-1 extra single augmentations per problem) -- same arithmetic,
-//     same result as the reference's eager child;
-//   * bounded queue: only the (k - emitted) smallest candidates can ever be
-//     output, so the queue is a sorted LDS array of at most k entries, merged
-//     by rank each sweep;
+//   * first-step filter: the minimum first-step reduced cost of ALL children
+//     of a node is computed in one vector pass (lane = child column); children
+//     whose first Dijkstra step would already exceed the bound never get a wave;
 //   * early termination: Dijkstra's running distance `delta` is a lower
 //     bound of the child's gain (parent gain + delta), so a child is dropped
 //     as soon as that bound exceeds the current k-th best candidate (with a
-//     safety margin far above rounding error).
+//     safety margin far above rounding error);
+//   * bounded pool: only the (k - emitted) smallest candidates can ever be
+//     output, so the queue is a sorted LDS array of at most k entries, merged
+//     by rank each round;
+//   * surviving children are finished like the reference finishes them (flip,
+//     dual update, exact gain) and their whole state is kept in HBM; when the
+//     state slots run out a child stays lazy -- (gain, parent, column) only --
+//     and is re-solved from its parent's state if it is ever selected: the
+//     same function of the same inputs, hence the same result;
+//   * batched frontier: per round the first `spec` unsplit candidates of the
+//     pool are split together (speculatively, except the minimum), which turns
+//     199 sequential sweeps into a few dozen rounds of wave-parallel work.
 //
 // Results are identical to the reference for every hypothesis that is output:
 // the same assignments in the same order, gains bit-identical (serial
