@@ -64,6 +64,9 @@ Shape choose_shape(const kbest_ctx *ctx, int B, int maxRow, int k)
         const double effA = fa / (double)(long long)(fa + 0.999999), effB = fb / (double)(long long)(fb + 0.999999);
         if (effB * 0.9 > effA) { s.nWaves = 12; s.spec = 8; } else { s.nWaves = 8; s.spec = 6; }
     }
+    // the in-place pool merge holds at most 4 entries per thread: a long pool (bruteForceProb-style k in the
+    // thousands, assignment.cpp:868) needs a bigger workgroup
+    while (k > 4 * s.nWaves * 64 && s.nWaves < 16) s.nWaves = (s.nWaves < 8) ? 8 : 16;
     if (ctx->nWaves > 0) s.nWaves = ctx->nWaves;
     if (ctx->spec > 0) s.spec = ctx->spec;
     if (s.spec > s.nWaves) s.spec = s.nWaves;

@@ -400,3 +400,19 @@ def test_large_maps_condition_down_to_solver_size(eng):
     conds, ridx = eng.condition_costs([oc], [nR], [nC])
     wc, wi = ol.condition_costs(oc, nR, nC)
     assert (ridx[0] == wi).all() and (bits(conds[0]) == bits(wc)).all()
+
+
+def test_large_k_brute_force_style(eng):
+    """bruteForceProb drives kBest2D with k in the thousands on small matrices (assignment.cpp:858-880): the pool
+    then exceeds one entry per thread and the launch shape has to grow with k."""
+    rng = np.random.default_rng(17)
+    for N, M, k in ((9, 4, 1500), (12, 5, 3000), (7, 7, 4000), (30, 6, 2500)):
+        costs = rng.random((3, N * M)) * 8
+        nf, r4c, c4r, g = eng.kbest(costs, N, M, k)
+        onf, or4c, oc4r, og, _ = ol.orc_kbest_batch(costs, N, M, k)
+        assert (nf == onf).all(), (N, M, k)
+        for b in range(3):
+            n = nf[b]
+            assert (r4c[b, :n] == or4c[b, :n]).all() and (bits(g[b, :n]) == bits(og[b, :n])).all(), (N, M, k)
+    with pytest.raises(pk.KBestError):
+        eng.kbest(rng.random((1, 64 * 64)), 64, 64, 20000)      # beyond the LDS pool: loud, not wrong
