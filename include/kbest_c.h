@@ -131,6 +131,15 @@ int kbest_weights_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int3
                             const int64_t *probOff, int32_t *nf);
 
 /*
+ * The accumulation of bruteForceProb (assignment.h:43, assignment.cpp:880-945): plain kBest2D with the caller's k
+ * (the reference derives it from a Minc-type bound, :858-868 -- the shim in kbest_shims.hpp does the same) and the
+ * weights summed WITHOUT the best+42 mask.  Same layout as kbest_weights_batch_f64.
+ */
+int kbest_bruteforce_probs_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM,
+                                     const double *cost, const int64_t *costOff, int k, double *probs,
+                                     const int64_t *probOff, int32_t *nf);
+
+/*
  * Batched conditionCosts (assignment.h:26, assignment.cpp:439-525).  Problem b: nRow[b] x nCol[b] column-major
  * at cost + costOff[b].  out receives the conditioned goodRows[b] x nCol[b] block at the same offset; rowIdx
  * [B][maxRow] the original row of each kept row (rowIdxOut of the reference; unused tail = -1).  Host buffers.

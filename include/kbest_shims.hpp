@@ -84,6 +84,9 @@ int assign2D(const size_t numRow, const size_t numCol, const bool maximize, cons
 
 std::vector<std::vector<double>> assignmentProb(const std::vector<double> &costMatrix, size_t nL, size_t nM, size_t k);
 
+// assignment.h:43 (assignment.cpp:835-963): every assignment up to a Minc-type bound (at most 20000), no 42-gate
+std::vector<std::vector<double>> bruteForceProb(const std::vector<double> &costMatrix, size_t nL, size_t nM);
+
 // assignment.h:26 (assignment.cpp:439-525)
 std::vector<double> conditionCosts(const std::vector<double> &costs, size_t nRows, size_t nCols,
                                    std::vector<ptrdiff_t> &rowIdxOut);

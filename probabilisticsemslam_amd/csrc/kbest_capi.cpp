@@ -322,7 +322,7 @@ struct QuadricHost {  // host-side inputs of computeQuadricCostMatrix, packed fr
 
 static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM, const double *cost,
                             const int64_t *costOff, int k, double *probs, const int64_t *probOff, int32_t *nf,
-                            bool condition, const QuadricHost *quad = nullptr)
+                            bool condition, const QuadricHost *quad = nullptr, bool bruteForce = false)
 {
     if (!ctx) return KBEST_ERR_BAD_ARG;
     if (B < 0 || (k < 1 && !(quad && k == 0)) || !nL || !nM || (!cost && !quad) || !costOff || !probs || !probOff)
@@ -433,7 +433,7 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
     }
     kbest_opts o;
     kbest_default_opts(&o);
-    o.use_cutoff = 1;   // assignment.cpp:594: kBest2DCutoff(..., cutoff = 42)
+    o.use_cutoff = bruteForce ? 0 : 1;  // assignment.cpp:594: kBest2DCutoff(..., cutoff = 42); :880: plain kBest2D
     o.cutoff = 42.0;
     int rc = kbest_batch_f64_dev(ctx, &o, B, maxRow, maxCol, solveRows, dNC.as<int32_t>(), solveCost,
                                  dOff.as<int64_t>(), k, dR4C.as<int32_t>(), dC4R.as<int32_t>(), dGain.as<double>(),
@@ -454,6 +454,7 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
     w.rowIdx = condition ? dRowIdx.as<int>() : nullptr;
     w.nLout = dNL.as<int>();
     w.maxRow = rawMaxRow;
+    w.gate = bruteForce ? 0 : 1;
     {
         std::lock_guard<std::mutex> lock(ctx->mu);
         hipError_t e = kb::launch_weights(w, B, ctx->stream);
@@ -469,6 +470,12 @@ int kbest_weights_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int3
                             const int64_t *costOff, int k, double *probs, const int64_t *probOff, int32_t *nf)
 {
     return weights_pipeline(ctx, B, nL, nM, cost, costOff, k, probs, probOff, nf, false);
+}
+
+int kbest_bruteforce_probs_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM, const double *cost,
+                                     const int64_t *costOff, int k, double *probs, const int64_t *probOff, int32_t *nf)
+{
+    return weights_pipeline(ctx, B, nL, nM, cost, costOff, k, probs, probOff, nf, false, nullptr, true);
 }
 
 int kbest_assoc_probs_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM, const double *cost,

@@ -65,6 +65,7 @@ struct WeightParams {
     const int *rowIdx;        // [B][maxRow] or nullptr: scatter back through conditionCosts' row map
     const int *nLout;         // [B] landmarks in the output numbering (with rowIdx)
     int maxRow;
+    int gate;                 // 1: assignmentProb (skip solutions beyond best + 42, :622-626); 0: bruteForceProb (:918-923)
 };
 
 // Bytes of one saved hypothesis: u[D] v[D] (fp64), row4col[D] col4row[D] (u8),

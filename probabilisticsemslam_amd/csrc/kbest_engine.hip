@@ -1065,7 +1065,7 @@ __global__ void __launch_bounds__(64) weights_kernel(WeightParams p)
     double total = 0.0;
     for (int s = 0; s < nf; s++) {
         const double g = gain[s];
-        if (!(best + GATE > g)) continue;  // :622-626
+        if (p.gate && !(best + GATE > g)) continue;  // :622-626 (bruteForceProb sums every solution, :918-923)
         const double w = exp(best - g);
         total += w;
         if (lane < nM) {

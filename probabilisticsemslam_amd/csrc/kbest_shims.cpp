@@ -2,7 +2,9 @@
 // forwarding to the C ABI with B = 1 on a lazily created process-global context.
 #include "kbest_shims.hpp"
 
+#include <cmath>
 #include <cstdint>
+#include <limits>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -148,4 +150,35 @@ std::vector<double> conditionCosts(const std::vector<double> &costs, size_t nRow
     std::vector<ptrdiff_t> idx(ridx.begin(), ridx.begin() + good);
     rowIdxOut.swap(idx);  // assignment.cpp:523
     return out;
+}
+
+std::vector<std::vector<double>> bruteForceProb(const std::vector<double> &costMatrix, size_t nL, size_t nM)
+{
+    kbest_ctx *ctx = global_ctx();
+    const size_t nRows = nL + nM;
+    const int32_t l = (int32_t)nL, m = (int32_t)nM;
+    const int64_t zero = 0;
+    const size_t width = (nM == 1) ? costMatrix.size() : nL + 1;  // single-column path, assignment.cpp:843
+    // number of assignments to ask for: the Minc-type bound of assignment.cpp:28-36, 858-868, capped at 20000
+    size_t upperK = 1;
+    if (nM > 1) {
+        const double tau = 6.2831853071, n = (double)nRows, mm = (double)nM;
+        double bound = std::pow(tau, (mm - n) / (2 * n)) * std::pow(n / mm, mm) * std::exp(mm / (12 * n * n) - 1 / (12 * mm + 1));
+        for (size_t r = 0; r < nRows; r++) {
+            size_t card = 1;
+            for (size_t c = 0; c < nM; c++)
+                if (costMatrix[c * nRows + r] < std::numeric_limits<double>::infinity()) card++;
+            const double cn = (double)card;
+            bound *= std::pow(tau * cn, 1.0 / (2.0 * cn)) * cn * std::exp(-1 + 1.0 / (12 * cn * cn));
+        }
+        upperK = (bound < 1.8e19) ? (size_t)bound + 1 : 20000;
+        if (upperK > 20000) upperK = 20000;
+    }
+    std::vector<double> flat(nM * (nL + 1), 0.0);
+    check(ctx, kbest_bruteforce_probs_batch_f64(ctx, 1, &l, &m, costMatrix.data(), &zero, (int)upperK, flat.data(), &zero,
+                                                nullptr));
+    std::vector<std::vector<double>> probs(nM, std::vector<double>(width, 0.0));
+    for (size_t c = 0; c < nM; c++)
+        for (size_t j = 0; j <= nL; j++) probs[c][j] = flat[c * (nL + 1) + j];
+    return probs;
 }

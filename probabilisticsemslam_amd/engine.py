@@ -20,6 +20,7 @@ C_ABI_SYMBOLS = (
     "kbest_device_count", "kbest_batch_f64_dev", "kbest_batch_f64", "kbest_reserve", "kbest_weights_batch_f64",
     "kbest_set_profile_buffer", "kbest_condition_costs_f64", "kbest_assoc_probs_batch_f64",
     "kbest_quadric_costs_f64", "kbest_quadric_assoc_probs_batch_f64", "kbest_bb_match_batch_f64",
+    "kbest_bruteforce_probs_batch_f64",
 )
 
 
@@ -68,6 +69,7 @@ def load_library():
                                     C.c_int, i32p, i32p, dp, i32p, i64p]
     lib.kbest_weights_batch_f64.argtypes = [vp, C.c_int, i32p, i32p, dp, i64p, C.c_int, dp, i64p, i32p]
     lib.kbest_assoc_probs_batch_f64.argtypes = [vp, C.c_int, i32p, i32p, dp, i64p, C.c_int, dp, i64p, i32p]
+    lib.kbest_bruteforce_probs_batch_f64.argtypes = [vp, C.c_int, i32p, i32p, dp, i64p, C.c_int, dp, i64p, i32p]
     lib.kbest_condition_costs_f64.argtypes = [vp, C.c_int, i32p, i32p, dp, i64p, dp, i32p, i32p, C.c_int]
     lib.kbest_quadric_costs_f64.argtypes = [vp, C.c_int, i32p, i32p, dp, dp, dp, dp, C.c_double, dp]
     lib.kbest_quadric_assoc_probs_batch_f64.argtypes = [vp, C.c_int, i32p, i32p, dp, dp, dp, dp, C.c_double, C.c_int,
@@ -164,7 +166,7 @@ class KBestEngine:
         return ([out[off[b]: off[b] + int(good[b]) * int(nCols[b])].copy() for b in range(B)],
                 [ridx[b, : good[b]].copy() for b in range(B)])
 
-    def weights(self, costs, nL, nM, k, condition=False):
+    def weights(self, costs, nL, nM, k, condition=False, brute_force=False):
         """Batched assignmentProb (condition=False) or, with condition=True, the whole
         conditionCosts -> assignmentProb -> scatter chain of getAssignmentProbs on raw cost blocks.
         costs: list of 1-D column-major (nL+nM) x nM blocks.  Returns (list of [nM, nL+1] arrays, nf[B])."""
@@ -180,7 +182,8 @@ class KBestEngine:
         flat = np.concatenate([np.ascontiguousarray(c, dtype=np.float64).reshape(-1) for c in costs])
         probs = np.zeros(int(sum(psizes)), np.float64)
         nf = np.zeros(B, np.int32)
-        fn = self.lib.kbest_assoc_probs_batch_f64 if condition else self.lib.kbest_weights_batch_f64
+        fn = (self.lib.kbest_bruteforce_probs_batch_f64 if brute_force else
+              self.lib.kbest_assoc_probs_batch_f64 if condition else self.lib.kbest_weights_batch_f64)
         self._check(fn(self.ctx, B, _ptr(nL), _ptr(nM), _ptr(flat), _ptr(costOff), k, _ptr(probs), _ptr(probOff),
                        _ptr(nf)))
         out = [probs[probOff[b]: probOff[b] + psizes[b]].reshape(int(nM[b]), int(nL[b]) + 1) for b in range(B)]

@@ -416,3 +416,17 @@ def test_large_k_brute_force_style(eng):
             assert (r4c[b, :n] == or4c[b, :n]).all() and (bits(g[b, :n]) == bits(og[b, :n])).all(), (N, M, k)
     with pytest.raises(pk.KBestError):
         eng.kbest(rng.random((1, 64 * 64)), 64, 64, 20000)      # beyond the LDS pool: loud, not wrong
+
+
+def test_brute_force_probs(eng):
+    # bruteForceProb's accumulation (no 42-gate) on the GPU with the k the reference derives, vs the checker
+    frames = wl.kitti_like_frames(24, nL=6, nM=3)
+    conds, nLs, ks, want = [], [], [], []
+    for f in frames:
+        cond, idx = ol.condition_costs(f, 9, 3)
+        p, nf, uk = ol.brute_force_prob(cond, len(idx) - 3, 3)
+        conds.append(cond); nLs.append(len(idx) - 3); ks.append(uk); want.append(p)
+    k = max(ks)
+    probs, nf = eng.weights(conds, nLs, [3] * len(conds), k, brute_force=True)
+    for p, w in zip(probs, want):
+        np.testing.assert_allclose(p, w, rtol=1e-12, atol=1e-15)
