@@ -51,12 +51,14 @@ enum {
     KBEST_OK = 0,
     KBEST_ERR_NO_DEVICE = -1,   /* no HIP device / HIP runtime error at create    */
     KBEST_ERR_BAD_ARG = -2,     /* null pointer, k < 1, numRow < numCol, ...      */
-    KBEST_ERR_UNSUPPORTED = -3, /* numRow > KBEST_MAX_DIM or k beyond LDS pool    */
+    KBEST_ERR_UNSUPPORTED = -3, /* numRow > KBEST_MAX_DIM_WIDE                    */
     KBEST_ERR_HIP = -4,         /* a HIP call failed; see kbest_last_error()      */
     KBEST_ERR_NOMEM = -5
 };
 
-#define KBEST_MAX_DIM 64 /* rows per problem handled by the wave-per-child kernels */
+#define KBEST_MAX_DIM 64       /* rows per problem handled by the LDS-resident kernel (the fast path)      */
+#define KBEST_MAX_DIM_WIDE 512 /* rows per problem handled at all: beyond KBEST_MAX_DIM, or with a k beyond */
+                               /* the LDS candidate pool, the general-size kernel (HBM work space) runs      */
 
 /* flags */
 #define KBEST_FLAG_NO_PRUNE 1u     /* disable early termination (for counting P)   */
@@ -89,7 +91,7 @@ int kbest_device_count(void);
  *   d_cost    packed column-major cost blocks; problem b starts at
  *             d_costOff[b] doubles (or b*maxRow*maxCol when d_costOff is NULL)
  *   d_row4col [B][k][maxCol] int32   col -> row   (row4colBest, hpp:228-229)
- *   d_col4row [B][k][maxRow] int32   row -> col   (col4rowBest, hpp:226-227)
+ *   d_col4row [B][k][maxRow] int32   row -> col   (col4rowBest, hpp:226-227); NULL = not wanted
  *   d_gain    [B][k] double                       (gainBest,    hpp:230-231)
  *   d_nf      [B] int32   number found, 0 = infeasible (return value of kBest2D)
  *   d_pushed  [B] int64 or NULL; with KBEST_FLAG_COUNT_PUSHED the number of

@@ -19,6 +19,8 @@ struct kbest_ctx {
     unsigned char *states = nullptr;  // hypothesis-state workspace (+ the slot -> state table behind it)
     size_t statesBytes = 0;
     size_t slotSidOffset = 0;
+    unsigned char *wide = nullptr;    // work space of the general-size kernel (kbest_wide.hip)
+    size_t wideBytes = 0;
     int ldsLimit = 65536;
     int nWaves = 0;   // waves per cost matrix (workgroup = nWaves * 64 threads); 0 = choose per launch
     int spec = 0;     // candidates re-solved / split per round; 0 = choose per launch (choose_spec)
@@ -165,6 +167,7 @@ int kbest_destroy(kbest_ctx *ctx)
     if (!ctx) return KBEST_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->states) (void)hipFree(ctx->states);
+    if (ctx->wide) (void)hipFree(ctx->wide);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return KBEST_OK;
@@ -192,60 +195,156 @@ int kbest_reserve(kbest_ctx *ctx, int B, int maxRow, int k)
     return KBEST_OK;
 }
 
+// Work space of the general-size kernel: one slot per workgroup of its (persistent) grid.
+struct WidePlan {
+    int grid;
+    size_t cw, states, pool, freeL, perSlot;  // bytes per slot
+    int statesPerProblem;
+    long long poolStride, freeStride;
+};
+
+static WidePlan plan_wide(const kbest_ctx *ctx, int B, int maxRow, int maxCol, int k)
+{
+    auto up = [](size_t x) { return (x + 127) & ~(size_t)127; };
+    WidePlan w;
+    w.statesPerProblem = k + maxCol + 2;
+    w.poolStride = (long long)((k + 1 + 15) & ~15);
+    w.freeStride = (long long)((w.statesPerProblem + 31) & ~31);
+    w.cw = up((size_t)maxRow * maxRow * 8);
+    w.states = (size_t)w.statesPerProblem * (size_t)kb::wide_state_stride(maxRow);
+    w.pool = up((size_t)2 * w.poolStride * 8);
+    w.freeL = up((size_t)w.freeStride * 4);
+    w.perSlot = w.cw + w.states + w.pool + up((size_t)2 * w.poolStride * 4) + w.freeL;
+    const size_t budget = (size_t)8 << 30;  // the grid strides over the batch: more slots than this buys nothing
+    long long g = (long long)(budget / w.perSlot);
+    if (g > 2LL * ctx->nCU) g = 2LL * ctx->nCU;
+    if (g > B) g = B;
+    if (g < 1) g = 1;
+    w.grid = (int)g;
+    return w;
+}
+
+static int reserve_wide(kbest_ctx *ctx, const WidePlan &w)
+{
+    const size_t need = w.perSlot * (size_t)w.grid + 256;
+    if (need <= ctx->wideBytes) return KBEST_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->wide) { HIP_TRY(ctx, hipDeviceSynchronize()); (void)hipFree(ctx->wide); ctx->wide = nullptr; ctx->wideBytes = 0; }
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->wide), need);
+    if (e != hipSuccess) return fail(ctx, KBEST_ERR_NOMEM, "hipMalloc(general-size work space)", e);
+    ctx->wideBytes = need;
+    return KBEST_OK;
+}
+
 int kbest_batch_f64_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, int maxCol,
                         const int32_t *d_nRow, const int32_t *d_nCol, const double *d_cost,
                         const int64_t *d_costOff, int k, int32_t *d_row4col, int32_t *d_col4row,
                         double *d_gain, int32_t *d_nf, int64_t *d_pushed, void *stream)
 {
     if (!ctx) return KBEST_ERR_BAD_ARG;
-    if (!opts || B < 0 || k < 1 || maxCol < 1 || maxRow < maxCol || !d_cost || !d_row4col || !d_col4row || !d_gain || !d_nf)
+    if (!opts || B < 0 || k < 1 || maxCol < 1 || maxRow < maxCol || !d_cost || !d_row4col || !d_gain || !d_nf)
         return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_batch_f64_dev: bad argument");
     if ((d_nRow == nullptr) != (d_nCol == nullptr))
         return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_batch_f64_dev: give both nRow and nCol or neither");
-    if (maxRow > KBEST_MAX_DIM) return fail(ctx, KBEST_ERR_UNSUPPORTED, "numRow > KBEST_MAX_DIM");
-    if (k + ctx->extraStates + ctx->eagerStates > 65534) return fail(ctx, KBEST_ERR_UNSUPPORTED, "k too large");
+    if (maxRow > KBEST_MAX_DIM_WIDE) return fail(ctx, KBEST_ERR_UNSUPPORTED, "numRow > KBEST_MAX_DIM_WIDE");
+    if (B == 0) return KBEST_OK;
+    // Two kernels share the work.  The LDS kernel (kbest_engine.hip) takes every problem of up to KBEST_MAX_DIM
+    // rows as long as the candidate pool for k fits its LDS; the general-size kernel (kbest_wide.hip) takes the
+    // rest: larger problems of a mixed batch (shapes on the device: both are launched, each skips the other's
+    // problems), a uniform batch of larger problems, or any shape when k is beyond the LDS pool.
+    const int fastRow = maxRow < KBEST_MAX_DIM ? maxRow : KBEST_MAX_DIM;
+    const int fastCol = maxCol < fastRow ? maxCol : fastRow;
     // counting the reference's pushes needs the reference's exact order of splits: no speculation
-    const Shape shape = choose_shape(ctx, B, maxRow, k);
+    const Shape shape = choose_shape(ctx, B, fastRow, k);
     const int spec = (opts->flags & KBEST_FLAG_COUNT_PUSHED) ? 1 : shape.spec;
     const int nWaves = shape.nWaves;
-    if (k > 4 * nWaves * 64) return fail(ctx, KBEST_ERR_UNSUPPORTED, "k too large for the in-register pool merge");
-    const kb::Lds L = kb::lds_layout(maxRow, k, spec);
-    if (L.total > ctx->ldsLimit) return fail(ctx, KBEST_ERR_UNSUPPORTED, "k too large for the LDS candidate pool");
-    if (B == 0) return KBEST_OK;
+    const bool kFits = k + ctx->extraStates + ctx->eagerStates <= 65534 && k <= 4 * nWaves * 64 &&
+                       kb::lds_layout(fastRow, k, spec).total <= ctx->ldsLimit;
+    const bool forceWide = getenv("KBEST_FORCE_WIDE") != nullptr;  // test hook: everything through the general-size kernel
+    const bool runFast = !forceWide && kFits && (maxRow <= KBEST_MAX_DIM || d_nRow != nullptr);
+    const bool runWide = forceWide || !kFits || maxRow > KBEST_MAX_DIM;
     std::lock_guard<std::mutex> lock(ctx->mu);
-    int rc = kbest_reserve(ctx, B, maxRow, k);
-    if (rc != KBEST_OK) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-
-    kb::Params p;
-    p.cost = d_cost;
-    p.costOff = reinterpret_cast<const long long *>(d_costOff);
-    p.nRow = d_nRow;
-    p.nCol = d_nCol;
-    p.maxRow = maxRow;
-    p.maxCol = maxCol;
-    p.k = k;
-    p.maximize = opts->maximize;
-    p.useCutoff = opts->use_cutoff;
-    p.flags = opts->flags;
-    p.cutoff = opts->cutoff;
-    p.rootColOffset = opts->root_col_offset;
-    p.rootColStride = opts->root_col_stride;
-    p.row4col = d_row4col;
-    p.col4row = d_col4row;
-    p.gain = d_gain;
-    p.nf = d_nf;
-    p.pushed = reinterpret_cast<long long *>(d_pushed);
-    p.states = ctx->states;
-    p.stateStride = kb::state_stride(maxRow);
-    p.statesPerProblem = k + ctx->extraStates + ctx->eagerStates;
-    p.lazyStates = k + ctx->extraStates;
-    p.spec = spec;
-    p.prof = ctx->prof;
-    p.slotSid = reinterpret_cast<unsigned short *>(ctx->states + ctx->slotSidOffset);
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
-    hipError_t e = kb::launch_kbest(p, B, nWaves, s);
-    if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "kbest kernel launch", e);
+
+    if (runFast) {
+        int rc = kbest_reserve(ctx, B, fastRow, k);
+        if (rc != KBEST_OK) return rc;
+        kb::Params p;
+        p.cost = d_cost;
+        p.costOff = reinterpret_cast<const long long *>(d_costOff);
+        p.nRow = d_nRow;
+        p.nCol = d_nCol;
+        p.maxRow = fastRow;
+        p.maxCol = fastCol;
+        p.ldRow = maxRow;
+        p.ldCol = maxCol;
+        p.k = k;
+        p.maximize = opts->maximize;
+        p.useCutoff = opts->use_cutoff;
+        p.flags = opts->flags;
+        p.cutoff = opts->cutoff;
+        p.rootColOffset = opts->root_col_offset;
+        p.rootColStride = opts->root_col_stride;
+        p.row4col = d_row4col;
+        p.col4row = d_col4row;
+        p.gain = d_gain;
+        p.nf = d_nf;
+        p.pushed = reinterpret_cast<long long *>(d_pushed);
+        p.states = ctx->states;
+        p.stateStride = kb::state_stride(fastRow);
+        p.statesPerProblem = k + ctx->extraStates + ctx->eagerStates;
+        p.lazyStates = k + ctx->extraStates;
+        p.spec = spec;
+        p.prof = ctx->prof;
+        p.slotSid = reinterpret_cast<unsigned short *>(ctx->states + ctx->slotSidOffset);
+        hipError_t e = kb::launch_kbest(p, B, nWaves, s);
+        if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "kbest kernel launch", e);
+    }
+    if (runWide) {
+        const WidePlan w = plan_wide(ctx, B, maxRow, maxCol, k);
+        if (kb::wide_lds_layout(maxRow, maxCol).total > ctx->ldsLimit)
+            return fail(ctx, KBEST_ERR_UNSUPPORTED, "problem too large for the general-size kernel's LDS");
+        int rc = reserve_wide(ctx, w);
+        if (rc != KBEST_OK) return rc;
+        kb::WideParams p;
+        p.cost = d_cost;
+        p.costOff = reinterpret_cast<const long long *>(d_costOff);
+        p.nRow = d_nRow;
+        p.nCol = d_nCol;
+        p.B = B;
+        p.maxRow = maxRow;
+        p.maxCol = maxCol;
+        p.ldRow = maxRow;
+        p.ldCol = maxCol;
+        p.minRows = runFast ? KBEST_MAX_DIM + 1 : 0;
+        p.k = k;
+        p.maximize = opts->maximize;
+        p.useCutoff = opts->use_cutoff;
+        p.flags = opts->flags;
+        p.cutoff = opts->cutoff;
+        p.rootColOffset = opts->root_col_offset;
+        p.rootColStride = opts->root_col_stride;
+        p.row4col = d_row4col;
+        p.col4row = d_col4row;
+        p.gain = d_gain;
+        p.nf = d_nf;
+        p.pushed = reinterpret_cast<long long *>(d_pushed);
+        unsigned char *base = ctx->wide;
+        const size_t G = (size_t)w.grid;
+        p.Cw = reinterpret_cast<double *>(base);                  base += w.cw * G;
+        p.cwStride = (long long)(w.cw / 8);
+        p.states = base;                                          base += w.states * G;
+        p.stateStride = kb::wide_state_stride(maxRow);
+        p.statesPerProblem = w.statesPerProblem;
+        p.poolG = reinterpret_cast<double *>(base);               base += w.pool * G;
+        p.poolStride = w.poolStride;
+        p.poolS = reinterpret_cast<int *>(base);                  base += ((size_t)2 * w.poolStride * 4 + 127) / 128 * 128 * G;
+        p.freeList = reinterpret_cast<int *>(base);
+        p.freeStride = w.freeStride;
+        hipError_t e = kb::launch_kbest_wide(p, w.grid, s);
+        if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "general-size kbest kernel launch", e);
+    }
     return KBEST_OK;
 }
 
@@ -341,23 +440,18 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
         if (ce > nCost) nCost = ce;
         if (pe > nProb) nProb = pe;
     }
-    if (maxCol > KBEST_MAX_DIM) return fail(ctx, KBEST_ERR_UNSUPPORTED, "nM > KBEST_MAX_DIM");
+    if (maxCol > KBEST_MAX_DIM_WIDE) return fail(ctx, KBEST_ERR_UNSUPPORTED, "nM > KBEST_MAX_DIM_WIDE");
     // With conditioning the RAW matrix may have any number of rows (all landmarks of the map); only what
     // conditionCosts keeps must fit the solver, and a frame where it does not comes back with nf = -1.
     const int rawMaxRow = maxRow;
-    if (!condition && maxRow > KBEST_MAX_DIM) return fail(ctx, KBEST_ERR_UNSUPPORTED, "nL + nM > KBEST_MAX_DIM");
-    if (maxRow > KBEST_MAX_DIM) maxRow = KBEST_MAX_DIM;
+    if (!condition && maxRow > KBEST_MAX_DIM_WIDE) return fail(ctx, KBEST_ERR_UNSUPPORTED, "nL + nM > KBEST_MAX_DIM_WIDE");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    DevBuf dCost, dCond, dOff, dNR, dNC, dNL, dGood, dCondL, dRowIdx, dR4C, dC4R, dGain, dNf, dProbs, dPOff;
-    const size_t nR4C = (size_t)B * k * maxCol, nC4R = (size_t)B * k * maxRow, nG = (size_t)B * k;
+    DevBuf dCost, dCond, dOff, dNR, dNC, dNL, dGood, dCondL, dRowIdx, dR4C, dGain, dNf, dProbs, dPOff;
     HIP_TRY(ctx, dCost.alloc(nCost * 8));
     HIP_TRY(ctx, dOff.alloc((size_t)B * 8));
     HIP_TRY(ctx, dNR.alloc((size_t)B * 4));
     HIP_TRY(ctx, dNC.alloc((size_t)B * 4));
     HIP_TRY(ctx, dNL.alloc((size_t)B * 4));
-    HIP_TRY(ctx, dR4C.alloc(nR4C * 4));
-    HIP_TRY(ctx, dC4R.alloc(nC4R * 4));
-    HIP_TRY(ctx, dGain.alloc(nG * 8));
     HIP_TRY(ctx, dNf.alloc((size_t)B * 4));
     HIP_TRY(ctx, dProbs.alloc(nProb * 8));
     HIP_TRY(ctx, dPOff.alloc((size_t)B * 8));
@@ -430,13 +524,25 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
         solveCost = dCond.as<double>();
         solveRows = dGood.as<int32_t>();
         weightNL = dCondL.as<int>();
+        // size the solver for what conditionCosts kept, not for the raw map
+        std::vector<int32_t> good(B);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMemcpy(good.data(), dGood.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+        maxRow = maxCol;
+        for (int b = 0; b < B; b++)
+            if (good[b] > maxRow) maxRow = good[b];
+        if (maxRow > KBEST_MAX_DIM_WIDE) maxRow = KBEST_MAX_DIM_WIDE;  // frames beyond it come back with nf = -1
     }
+    const size_t nR4C = (size_t)B * k * maxCol, nG = (size_t)B * k;
+    HIP_TRY(ctx, dR4C.alloc(nR4C * 4));
+    HIP_TRY(ctx, dGain.alloc(nG * 8));
     kbest_opts o;
     kbest_default_opts(&o);
     o.use_cutoff = bruteForce ? 0 : 1;  // assignment.cpp:594: kBest2DCutoff(..., cutoff = 42); :880: plain kBest2D
     o.cutoff = 42.0;
+    // the weights only need row4col: no col4row table
     int rc = kbest_batch_f64_dev(ctx, &o, B, maxRow, maxCol, solveRows, dNC.as<int32_t>(), solveCost,
-                                 dOff.as<int64_t>(), k, dR4C.as<int32_t>(), dC4R.as<int32_t>(), dGain.as<double>(),
+                                 dOff.as<int64_t>(), k, dR4C.as<int32_t>(), nullptr, dGain.as<double>(),
                                  dNf.as<int32_t>(), nullptr, ctx->stream);
     if (rc != KBEST_OK) return rc;
     kb::WeightParams w;
@@ -538,7 +644,7 @@ int kbest_bb_match_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int
         if (nRow[b] > maxRow) maxRow = nRow[b];
         if (nL[b] > maxCol) maxCol = nL[b];
     }
-    if (maxRow > KBEST_MAX_DIM) return fail(ctx, KBEST_ERR_UNSUPPORTED, "nL + nR > KBEST_MAX_DIM");
+    if (maxRow > KBEST_MAX_DIM_WIDE) return fail(ctx, KBEST_ERR_UNSUPPORTED, "nL + nR > KBEST_MAX_DIM_WIDE");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DevBuf dBL, dBR, dOL, dOR, dOC, dNL, dNRt, dNRow, dCost, dR4C, dC4R, dGain, dNf, dAsg;
     HIP_TRY(ctx, dBL.alloc((size_t)sl * 40));
@@ -599,7 +705,7 @@ int kbest_condition_costs_f64(kbest_ctx *ctx, int B, const int32_t *nRow, const 
     if (B == 0) return KBEST_OK;
     size_t nCost = 0;
     for (int b = 0; b < B; b++) {
-        if (nRow[b] < 1 || nCol[b] < 1 || nRow[b] > maxRow || nCol[b] > KBEST_MAX_DIM)
+        if (nRow[b] < 1 || nCol[b] < 1 || nRow[b] > maxRow || nCol[b] > KBEST_MAX_DIM_WIDE)
             return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_condition_costs_f64: shape out of range");
         const size_t ce = (size_t)costOff[b] + (size_t)nRow[b] * nCol[b];
         if (ce > nCost) nCost = ce;

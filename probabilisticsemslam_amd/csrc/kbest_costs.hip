@@ -126,9 +126,9 @@ __global__ void __launch_bounds__(256) bb_cost_kernel(BoxParams p)
 // asgnBB epilogue (assignment.cpp:769-773): column c matched to right box row4col[c] unless that is a dummy.
 __global__ void __launch_bounds__(64) bb_assign_kernel(BoxParams p, const int *row4col, const int *nf, int k, int maxCol)
 {
-    const int b = blockIdx.x, c = threadIdx.x;
+    const int b = blockIdx.x;
     const int nL = p.nL[b], nR = p.nR[b];
-    if (c < nL) {
+    for (int c = threadIdx.x; c < nL; c += 64) {
         int a = -1;
         if (nf[b] > 0) { const int r = row4col[(long long)b * k * maxCol + c]; if (r < nR) a = r; }
         p.assign[p.offL[b] + c] = a;

@@ -21,7 +21,8 @@ struct Params {
     const long long *costOff; // per-problem offset in doubles, or nullptr (uniform)
     const int *nRow;          // per-problem shapes, or nullptr (uniform maxRow x maxCol)
     const int *nCol;
-    int maxRow, maxCol;       // shape bounds = leading dimensions of the outputs
+    int maxRow, maxCol;       // capacity of this launch: larger problems get nf = -1
+    int ldRow, ldCol;         // leading dimensions of the outputs / of the default cost packing (>= maxRow, maxCol)
     int k;
     int maximize, useCutoff;
     unsigned flags;
@@ -128,7 +129,65 @@ struct BoxParams {
     int *assign;                         // [sum nL] matched right box or -1
 };
 
+// ---- general-size kernel (kbest_wide.hip): numRow up to 64 * 8, any k; hypotheses and pool in HBM work space ----
+constexpr int WIDE_NW = 8;         // waves per problem
+constexpr int WIDE_MAX_DIM = 512;  // rows per problem
+
+struct WideParams {
+    const double *cost;
+    const long long *costOff;
+    const int *nRow, *nCol;
+    int B;                    // problems in the batch (the grid strides over them)
+    int maxRow, maxCol;       // capacity of this launch (work space, LDS, rows per lane)
+    int ldRow, ldCol;         // leading dimensions of the outputs / of the default cost packing
+    int minRows;              // problems with fewer rows are left to the LDS kernel (mixed batches); 0 = take all
+    int k;
+    int maximize, useCutoff;
+    unsigned flags;
+    double cutoff;
+    int rootColOffset, rootColStride;
+    int *row4col;             // [B][k][ldCol]
+    int *col4row;             // [B][k][ldRow] or nullptr
+    double *gain;             // [B][k]
+    int *nf;                  // [B]
+    long long *pushed;        // [B] or nullptr
+    // work space, one slot per workgroup of the grid
+    double *Cw;               // shifted, zero-padded square copy of the cost matrix
+    long long cwStride;       // doubles per slot
+    unsigned char *states;    // [statesPerProblem] saved hypotheses, stateStride bytes each
+    long long stateStride;
+    int statesPerProblem;     // k + maxCol + 2: pool + children of one sweep + the hypothesis being split
+    double *poolG;            // two buffers of poolStride gains (sorted candidate pool, ping-pong)
+    int *poolS;               //   ... and their state slots
+    long long poolStride;
+    int *freeList;            // stack of free state slots
+    long long freeStride;
+};
+
+// bytes of one saved hypothesis of the general-size kernel: u[D] v[D] (fp64), row4col[D] col4row[D] (i32),
+// forbidden rows (u32 per lane), gain, activeCol; whole 128-byte lines
+__host__ __device__ inline long long wide_state_stride(int maxRow) { return (24LL * maxRow + 256 + 16 + 127) & ~127LL; }
+
+struct WideLds { int offWave, waveStride, offChildG, offChildS, offChildC, offRed, offCtrl, total; };
+
+__host__ __device__ inline WideLds wide_lds_layout(int maxRow, int maxCol)
+{
+    WideLds L;
+    int o = 0;
+    L.waveStride = (20 * maxRow + 15) & ~15;       // per wave: u (fp64), col4row, row4col, pred (i32)
+    L.offWave = o;       o += WIDE_NW * L.waveStride;
+    L.offChildG = o;     o += maxCol * 8;           // surviving children of the sweep: gain, state slot, column
+    L.offChildS = o;     o += maxCol * 4;
+    L.offChildC = o;     o += maxCol * 4;
+    o = (o + 7) & ~7;
+    L.offRed = o;        o += WIDE_NW * 8;
+    L.offCtrl = o;       o += 96;                   // struct WideCtrl
+    L.total = (o + 15) & ~15;
+    return L;
+}
+
 hipError_t launch_kbest(const Params &p, int B, int nWaves, hipStream_t stream);
+hipError_t launch_kbest_wide(const WideParams &p, int grid, hipStream_t stream);
 hipError_t launch_quadric_costs(const QuadricParams &p, int B, hipStream_t stream);
 hipError_t launch_bb_costs(const BoxParams &p, int B, hipStream_t stream);
 hipError_t launch_bb_assign(const BoxParams &p, const int *row4col, const int *nf, int k, int maxCol, int B,

@@ -44,106 +44,9 @@
 #include <cstdint>
 
 #include "kbest_engine.h"
+#include "kbest_wave.h"
 
 namespace kb {
-
-__device__ __forceinline__ double d_inf() { return __longlong_as_double(0x7ff0000000000000LL); }
-
-// ---------------------------------------------------------------- wave tools
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ double dpp_f64(double x)
-{
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWMASK, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ double min_keep(double a, double b) { return b < a ? b : a; }
-
-__device__ __forceinline__ double readlane_f64(double x, int l)
-{
-    int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
-    int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
-    return __hiloint2double(hi, lo);
-}
-
-// fp64 min over the 64 lanes, returned wave-uniform (set-up code only; the hot
-// loop uses the integer-key form below).  All lanes must be active.
-__device__ __forceinline__ double wave_min_f64(double x)
-{
-    x = min_keep(x, dpp_f64<0xB1, 0xF>(x));   // quad_perm [1,0,3,2]
-    x = min_keep(x, dpp_f64<0x4E, 0xF>(x));   // quad_perm [2,3,0,1]
-    x = min_keep(x, dpp_f64<0x141, 0xF>(x));  // row_half_mirror
-    x = min_keep(x, dpp_f64<0x140, 0xF>(x));  // row_mirror
-    x = min_keep(x, dpp_f64<0x142, 0xA>(x));  // row_bcast:15 -> rows 1,3
-    x = min_keep(x, dpp_f64<0x143, 0xC>(x));  // row_bcast:31 -> rows 2,3
-    return readlane_f64(x, 63);
-}
-
-// Order-preserving integer key of a double: (khi as int32, klo as uint32)
-// compared lexicographically == IEEE '<' on the doubles (no NaNs; -0.0 cannot
-// occur in a reduced cost).  Negative values (rounding can make a
-// tight arc's reduced cost -1e-17) have their magnitude bits flipped.
-__device__ __forceinline__ void to_key(double x, int &khi, u32 &klo)
-{
-    const int hi = __double2hiint(x), lo = __double2loint(x);
-    const int s = hi >> 31;
-    khi = hi ^ (int)((u32)s >> 1);
-    klo = (u32)(lo ^ s);
-}
-__device__ __forceinline__ double from_key(int khi, u32 klo)  // same involution
-{
-    const int s = khi >> 31;
-    return __hiloint2double(khi ^ (int)((u32)s >> 1), (int)klo ^ s);
-}
-constexpr int KEY_INF_HI = 0x7ff00000;  // key of +inf is (0x7ff00000, 0)
-
-// One VOP2+DPP instruction per butterfly stage; `s_nop 1` covers the two wait
-// states a DPP read needs after a VALU write of the same VGPR (the assembler
-// does not pad inline asm).  The result lands in lane 63 and is read into an
-// SGPR.  EXEC must be all ones.
-#define KB_DPP_MIN_CHAIN(OP)                                                             \
-    "s_nop 1\n\t" OP " %1, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"     \
-    "s_nop 1\n\t" OP " %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"     \
-    "s_nop 1\n\t" OP " %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"         \
-    "s_nop 1\n\t" OP " %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"              \
-    "s_nop 1\n\t" OP " %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"            \
-    "s_nop 1\n\t" OP " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"            \
-    "s_nop 1\n\t" "v_readlane_b32 %0, %1, 63\n\t"
-
-__device__ __forceinline__ int wave_min_i32(int x)
-{
-    int r, t;
-    asm volatile(KB_DPP_MIN_CHAIN("v_min_i32_dpp") : "=s"(r), "=&v"(t) : "v"(x));
-    return r;
-}
-__device__ __forceinline__ u32 wave_min_u32(u32 x)
-{
-    u32 r, t;
-    asm volatile(KB_DPP_MIN_CHAIN("v_min_u32_dpp") : "=s"(r), "=&v"(t) : "v"(x));
-    return r;
-}
-
-// force a wave-uniform 64-bit value into SGPRs (values loaded from LDS live in VGPRs)
-__device__ __forceinline__ u64 uni64(u64 x)
-{
-    const u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)x);
-    const u32 hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(x >> 32));
-    return ((u64)hi << 32) | lo;
-}
-
-__device__ __forceinline__ int uni32(int x) { return __builtin_amdgcn_readfirstlane(x); }
-
-// per-lane select driven directly by a 64-bit scalar lane mask
-__device__ __forceinline__ int sel32(u64 mask, int ifset, int ifclear)
-{
-    int r;
-    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(ifclear), "v"(ifset), "s"(mask));
-    return r;
-}
-
-__device__ __forceinline__ u64 bit64(int i) { return 1ull << (i & 63); }
 
 // ------------------------------------------------------------ one augmentation
 // Shortest augmenting path from column `start` (lane = row).  Restates the
@@ -401,7 +304,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     unsigned short *freshS = reinterpret_cast<unsigned short *>(smem + L.offFreshS);
     Ctrl *ctrl = reinterpret_cast<Ctrl *>(smem + L.offCtrl);
 
-    const double *Cg = p.cost + (p.costOff ? p.costOff[b] : (long long)b * p.maxRow * p.maxCol);
+    const double *Cg = p.cost + (p.costOff ? p.costOff[b] : (long long)b * p.ldRow * p.ldCol);
     const bool maximize = p.maximize != 0, useCut = p.useCutoff != 0;
     const bool prune = (p.flags & KBEST_FLAG_NO_PRUNE) == 0;
     const int rl = lane < D ? lane : D - 1;
@@ -958,8 +861,8 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     for (int idx = tid; idx < nf * (N + M); idx += NT) {
         const int s = idx / (N + M), j = idx - s * (N + M);
         const unsigned char *st = stBase + (long long)slotSid[s] * p.stateStride;
-        if (j < M) p.row4col[(outBase + s) * p.maxCol + j] = st[offR4C + j];
-        else p.col4row[(outBase + s) * p.maxRow + (j - M)] = st[offC4R + (j - M)];
+        if (j < M) p.row4col[(outBase + s) * p.ldCol + j] = st[offR4C + j];
+        else if (p.col4row) p.col4row[(outBase + s) * p.ldRow + (j - M)] = st[offC4R + (j - M)];
     }
     if (tid == 0) {
         p.nf[b] = nf;
@@ -979,7 +882,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
 // may have any number of rows (every landmark of the map): only the conditioned matrix has to fit the solver.
 __global__ void __launch_bounds__(64) condition_kernel(CondParams p)
 {
-    __shared__ double colMin[64];
+    __shared__ double colMin[WIDE_MAX_DIM];
     const int b = blockIdx.x, lane = threadIdx.x;
     const int nR = p.nRow[b], nC = p.nCol[b];
     const double *C = p.cost + p.costOff[b];
@@ -1068,9 +971,9 @@ __global__ void __launch_bounds__(64) weights_kernel(WeightParams p)
         if (p.gate && !(best + GATE > g)) continue;  // :622-626 (bruteForceProb sums every solution, :918-923)
         const double w = exp(best - g);
         total += w;
-        if (lane < nM) {
-            const int r = r4c[(long long)s * p.maxCol + lane];
-            probs[lane * (nLo + 1) + ((r >= nL) ? nLo : (ridx ? ridx[r] : r))] += w;  // :633-638
+        for (int m = lane; m < nM; m += 64) {
+            const int r = r4c[(long long)s * p.maxCol + m];
+            probs[m * (nLo + 1) + ((r >= nL) ? nLo : (ridx ? ridx[r] : r))] += w;  // :633-638
         }
     }
     __syncthreads();

@@ -1,0 +1,506 @@
+// kbest_wide.hip -- the general-size form of the k-best enumeration for gfx950.
+//
+// kbest_engine.hip keeps a whole problem in LDS and covers numRow <= 64 with a
+// candidate pool of a few thousand entries.  The reference has no such limits
+// (kBest2D, shortestPathCPP.cpp:571-644, takes any numRow >= numCol and any k;
+// bruteForceProb, assignment.cpp:868, asks for up to 20 000 assignments), so
+// this kernel handles everything beyond them -- numRow up to 64 * R (R rows per
+// lane, R <= 8) and any k -- with the SAME arithmetic in the same order:
+//   * cost copy, duals, hypotheses and the candidate pool live in HBM work
+//     space (L2-resident for the sizes in question), only the hypothesis a
+//     wave is working on sits in LDS / registers;
+//   * one workgroup per problem, persistent over a grid-stride loop of
+//     problems, so the work space is bounded by the grid, not by the batch;
+//   * per sweep the popped hypothesis' children (split, cpp:455-532) are solved
+//     by the waves in parallel (shortestPathUpdateCPP, cpp:240-365), with the
+//     same early termination against the pool's (k - emitted)-th gain as the
+//     LDS kernel, then rank-merged into the sorted pool (ties in gain: pool
+//     entries before new children, children by column);
+//   * the order of operations is the reference's: pop the minimum, split it,
+//     emit the new minimum (kBest2D cpp:607-634, kBest2DCutoff cpp:690-722).
+// Gains are the serial column-order sum (calcGain cpp:59-80), the reduced cost
+// is ((delta + C) - u) - v left to right (cpp:183, 313), the arg-min takes the
+// lowest row index (cpp:191, 320): results are identical to the reference's.
+//
+// fp64 add/sub/compare only; compiled WITHOUT fast-math.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "kbest_engine.h"
+#include "kbest_wave.h"
+
+namespace kb {
+
+namespace {
+
+struct WideCtrl {
+    double cdelta;      // CDelta * numCol (cpp:583)
+    double cutoffGain;  // workMem.cutoffGain (cpp:681/684)
+    double cmax;        // largest finite shifted cost
+    double gain0u;      // gainBest[0]
+    int n;           // pool entries (entry 0 = the hypothesis emitted last, popped next)
+    int cur;         // which of the two pool buffers is current
+    int emitted;     // output slots filled
+    int stop;        // 1: finished  2: internal error  3: infeasible root
+    int pushed;
+    int nFree;       // free state slots (stack in freeList)
+    int nChild;      // children that survived this sweep
+    int nextTicket;  // work queue over the children of the sweep
+    int emitSid;     // state to copy to the output slot `emitted - 1`, or -1
+};
+static_assert(sizeof(WideCtrl) <= 96, "WideCtrl must fit the LDS slot reserved by wide_lds_layout");
+
+__device__ __forceinline__ void wave_fence()
+{
+    // LDS traffic between the lanes of one wave: program order is enough in hardware, the fence only keeps the
+    // compiler from moving the accesses across it
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Shortest augmenting path from column `start`; lane owns rows lane + 64*i.  Same contract as dijkstra<> of
+// kbest_engine.hip (cpp:168-226 / cpp:297-356) with per-lane bit sets: cand bit i = row lane+64i still in
+// Row2Scan, forb = rows skipped while the start column itself is scanned (cpp:310).
+// Returns 0 = path found, 1 = infeasible (cpp:197, 327), 2 = abandoned (delta beyond `bound`, EARLY only).
+template <int R, bool EARLY>
+__device__ __forceinline__ int wide_dijkstra(const double *Cw, int D, const double *uW, const int *c4rW, int lane,
+                                             const double (&v)[R], u32 cand, u32 forb, int start, double bound,
+                                             double (&spc)[R], int (&pred)[R], u32 &scannedOut, double &deltaOut,
+                                             int &sinkOut)
+{
+    const double INF = d_inf();
+#pragma unroll
+    for (int i = 0; i < R; i++) { spc[i] = INF; pred[i] = 0; }
+    u32 act = cand & ~forb, scanned = 0;
+    int cur = uni32(start);
+    bound = __hiloint2double(uni32(__double2hiint(bound)), uni32(__double2loint(bound)));
+    double delta = 0.0;
+    for (;;) {
+        const double ucur = uW[cur];
+        const double *col = Cw + (long long)cur * D;
+        double best = INF;
+        int brow = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            if ((act >> i) & 1u) {
+                const double rc = ((delta + col[lane + 64 * i]) - ucur) - v[i];  // cpp:183 / cpp:313, left to right
+                if (rc < spc[i]) { spc[i] = rc; pred[i] = cur; }                  // strict '<': cpp:185, 314
+                if (spc[i] < best) { best = spc[i]; brow = lane + 64 * i; }       // lowest row first: cpp:191, 320
+            }
+        }
+        const double m = wave_min_f64(best);
+        if (!(m < INF)) { scannedOut = scanned; return 1; }
+        if (EARLY && m > bound) { scannedOut = scanned; return 2; }
+        const int closest = wave_min_i32(best == m ? brow : 0x7fffffff);
+        delta = m;
+        if (lane == (closest & 63)) { cand &= ~(1u << (closest >> 6)); scanned |= 1u << (closest >> 6); }
+        act = cand;
+        const int cc = uni32(c4rW[closest]);
+        if (cc < 0) { sinkOut = closest; break; }
+        cur = cc;
+    }
+    scannedOut = scanned;
+    deltaOut = delta;
+    return 0;
+}
+
+// updateDualAndAugment (cpp:82-117) on the wave's working hypothesis (u, col4row, row4col in LDS; v in registers)
+template <int R>
+__device__ __forceinline__ void wide_update(double *uW, int *c4rW, int *r4cW, int *predW, int lane, double (&v)[R],
+                                            const double (&spc)[R], const int (&pred)[R], u32 scanned, double delta,
+                                            int sink, int start, int D)
+{
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        if ((scanned >> i) & 1u) {
+            const int r = lane + 64 * i;
+            predW[r] = pred[i];
+            if (r != sink) {  // scanned columns other than start: cpp:96-99
+                const int c = c4rW[r];
+                uW[c] = uW[c] + delta - spc[i];
+            }
+            v[i] = v[i] - delta + spc[i];  // cpp:102-106
+        }
+    }
+    if (lane == 0) uW[start] = uW[start] + delta;  // cpp:92
+    wave_fence();
+    if (lane == 0) {  // cpp:108-116
+        int r = sink, c, guard = 0;
+        do {
+            c = predW[r];
+            c4rW[r] = c;
+            const int nxt = r4cW[c];
+            r4cW[c] = r;
+            r = nxt;
+        } while (c != start && ++guard < D);
+    }
+    wave_fence();
+}
+
+// calcGain (cpp:59-80): serial left-to-right sum over the M real columns, from 0.0
+template <int R>
+__device__ __forceinline__ double wide_gain(const double *Cw, int D, int M, const int *r4cW, int lane)
+{
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        if (64 * i < M) {
+            const int c = lane + 64 * i;
+            double t = 0.0;  // columns >= M add +0.0: exact for the non-negative partial sums
+            if (c < M) t = Cw[r4cW[c] + (long long)c * D];
+            const int tlo = __double2loint(t), thi = __double2hiint(t);
+            for (int j0 = 0; j0 < 64 && 64 * i + j0 < M; j0 += 8) {
+                double term[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++)
+                    term[e] = __hiloint2double(__builtin_amdgcn_readlane(thi, j0 + e), __builtin_amdgcn_readlane(tlo, j0 + e));
+#pragma unroll
+                for (int e = 0; e < 8; e++) acc = acc + term[e];
+            }
+        }
+    }
+    return acc;
+}
+
+}  // namespace
+
+template <int R>
+__global__ void __launch_bounds__(WIDE_NW * 64) kbest_wide_kernel(WideParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NT = WIDE_NW * 64;
+    const double INF = d_inf();
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int DS = p.maxRow;
+    const WideLds L = wide_lds_layout(DS, p.maxCol);
+    double *uW = reinterpret_cast<double *>(smem + L.offWave + (size_t)wave * L.waveStride);
+    int *c4rW = reinterpret_cast<int *>(uW + DS);
+    int *r4cW = c4rW + DS;
+    int *predW = r4cW + DS;
+    double *childG = reinterpret_cast<double *>(smem + L.offChildG);
+    int *childS = reinterpret_cast<int *>(smem + L.offChildS);
+    int *childC = reinterpret_cast<int *>(smem + L.offChildC);
+    double *red = reinterpret_cast<double *>(smem + L.offRed);
+    WideCtrl *ctrl = reinterpret_cast<WideCtrl *>(smem + L.offCtrl);
+
+    // work space of this workgroup (whole 128-byte lines, never shared with another workgroup)
+    const long long ws = blockIdx.x;
+    double *Cw = p.Cw + ws * p.cwStride;
+    unsigned char *stBase = p.states + ws * (long long)p.statesPerProblem * p.stateStride;
+    double *poolG = p.poolG + ws * 2 * p.poolStride;
+    int *poolS = p.poolS + ws * 2 * p.poolStride;
+    int *freeList = p.freeList + ws * p.freeStride;
+    const int S = p.statesPerProblem;
+    const int k = p.k;
+    const bool maximize = p.maximize != 0, useCut = p.useCutoff != 0;
+    const bool prune = (p.flags & KBEST_FLAG_NO_PRUNE) == 0;
+    // saved hypothesis: u[DS] v[DS] (fp64) | row4col[DS] col4row[DS] (i32) | forbidden rows (u32 per lane) | gain, activeCol
+    const long long offV = 8LL * DS, offR4C = 16LL * DS, offC4R = 20LL * DS, offForb = 24LL * DS, offTail = 24LL * DS + 256;
+
+    for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
+        __syncthreads();  // the previous problem of this workgroup is finished
+        const int N = p.nRow ? p.nRow[b] : p.maxRow;
+        const int M = p.nCol ? p.nCol[b] : p.maxCol;
+        if (N >= 1 && M >= 1 && N >= M && N < p.minRows) continue;  // the LDS kernel's share of a mixed batch
+        if (N < 1 || M < 1 || N < M || N > p.maxRow || M > p.maxCol || N > 64 * R) {  // undefined in the reference
+            if (tid == 0) p.nf[b] = -1;
+            continue;
+        }
+        const int D = N;
+        const double *Cg = p.cost + (p.costOff ? p.costOff[b] : (long long)b * p.ldRow * p.ldCol);
+        const long long outBase = (long long)b * k;
+
+        // ---- phase 0: makeCostMatrixSafe + zero padding (cpp:534-569, 582-585) ----
+        {
+            double mn = INF;
+            for (int i = tid; i < N * M; i += NT) {
+                double x = Cg[i];
+                x = maximize ? -x : x;
+                mn = min_keep(mn, x);
+            }
+            mn = wave_min_f64(mn);
+            if (lane == 0) red[wave] = mn;
+            __syncthreads();
+            mn = red[0];
+            for (int w = 1; w < WIDE_NW; w++) mn = min_keep(mn, red[w]);
+            const double cdel = maximize ? -mn : mn;
+            __syncthreads();
+            double cm = 0.0;
+            for (int i = tid; i < D * D; i += NT) {
+                double val = 0.0;
+                if (i < N * M) {
+                    const double x = Cg[i];
+                    val = maximize ? (-x + cdel) : (x - cdel);  // cpp:558 / cpp:564
+                    if (val != val) val = INF;                   // inf - inf: behaves like +inf in every comparison
+                    if (val < INF && val > cm) cm = val;
+                }
+                Cw[i] = val;
+            }
+            cm = -wave_min_f64(-cm);
+            if (lane == 0) red[wave] = cm;
+            for (int i = tid; i < S - 1; i += NT) freeList[i] = S - 1 - i;  // slot 0 is the root's
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 1; w < WIDE_NW; w++) cm = red[w] > cm ? red[w] : cm;
+                ctrl->cmax = cm;
+                ctrl->cdelta = cdel * (double)M;  // cpp:583
+                ctrl->stop = 0;
+                ctrl->pushed = 0;
+                ctrl->n = 0;
+                ctrl->cur = 0;
+                ctrl->emitted = 0;
+                ctrl->nFree = S - 1;
+                ctrl->nChild = 0;
+                ctrl->nextTicket = 0;
+                ctrl->emitSid = -1;
+            }
+            __syncthreads();
+        }
+
+        auto store_state = [&](int sid, const double (&v)[R], u32 forb, double gain, int activeCol) {
+            unsigned char *st = stBase + (long long)sid * p.stateStride;
+            double *su = reinterpret_cast<double *>(st), *sv = reinterpret_cast<double *>(st + offV);
+            int *sr = reinterpret_cast<int *>(st + offR4C), *sc = reinterpret_cast<int *>(st + offC4R);
+#pragma unroll
+            for (int i = 0; i < R; i++) {
+                const int r = lane + 64 * i;
+                if (r < D) { su[r] = uW[r]; sv[r] = v[i]; sr[r] = r4cW[r]; sc[r] = c4rW[r]; }
+            }
+            reinterpret_cast<u32 *>(st + offForb)[lane] = forb;
+            if (lane == 0) {
+                *reinterpret_cast<double *>(st + offTail) = gain;
+                *reinterpret_cast<int *>(st + offTail + 8) = activeCol;
+            }
+        };
+
+        // ---- phase 1: root LAP (shortestPathCPP, cpp:119-238) on wave 0 -> state 0, output slot 0 ----
+        if (wave == 0) {
+            double v[R], spc[R];
+            int pred[R];
+            u32 all = 0;
+#pragma unroll
+            for (int i = 0; i < R; i++) {
+                const int r = lane + 64 * i;
+                v[i] = 0.0;
+                if (r < D) { uW[r] = 0.0; c4rW[r] = -1; r4cW[r] = -1; all |= 1u << i; }
+            }
+            wave_fence();
+            bool bad = false;
+            for (int c = 0; c < D; c++) {
+                u32 scanned;
+                double delta;
+                int sink = 0;
+                if (wide_dijkstra<R, false>(Cw, D, uW, c4rW, lane, v, all, 0u, c, INF, spc, pred, scanned, delta, sink)) {
+                    bad = true;
+                    break;
+                }
+                wide_update<R>(uW, c4rW, r4cW, predW, lane, v, spc, pred, scanned, delta, sink, c, D);
+            }
+            if (bad) {
+                if (lane == 0) ctrl->stop = 3;
+            } else {
+                const double g = wide_gain<R>(Cw, D, M, r4cW, lane);
+                const int r0 = uni32(r4cW[0]);
+                const u32 forb = (lane == (r0 & 63)) ? (1u << (r0 >> 6)) : 0u;  // cpp:235
+                store_state(0, v, forb, g, 0);
+                for (int j = lane; j < M; j += 64) p.row4col[outBase * p.ldCol + j] = r4cW[j];
+                if (p.col4row)
+                    for (int j = lane; j < N; j += 64) p.col4row[outBase * p.ldRow + j] = c4rW[j];
+                if (lane == 0) {
+                    ctrl->cutoffGain = maximize ? (g - p.cutoff) : (g + p.cutoff);          // cpp:681/684
+                    const double gu = maximize ? (-g + ctrl->cdelta) : (g + ctrl->cdelta);  // cpp:599-603
+                    ctrl->gain0u = gu;
+                    p.gain[outBase] = gu;
+                    poolG[0] = g;
+                    poolS[0] = 0;
+                    ctrl->n = 1;
+                    ctrl->emitted = 1;
+                    if (k == 1) ctrl->stop = 1;
+                }
+            }
+        }
+        __syncthreads();
+        if (uni32(ctrl->stop) == 3) {  // infeasible: kBest2D returns 0 (cpp:588-593)
+            if (tid == 0) { p.nf[b] = 0; if (p.pushed) p.pushed[b] = 0; }
+            continue;
+        }
+
+        // ---- phase 2: sweeps (cpp:607-634) ----
+        while (uni32(ctrl->stop) == 0) {
+            const int cur = uni32(ctrl->cur), n = uni32(ctrl->n), emitted = uni32(ctrl->emitted);
+            const double *srcG = poolG + (long long)cur * p.poolStride;
+            const int *srcS = poolS + (long long)cur * p.poolStride;
+            double *dstG = poolG + (long long)(1 - cur) * p.poolStride;
+            int *dstS = poolS + (long long)(1 - cur) * p.poolStride;
+            const int ps = uni32(srcS[0]);  // the hypothesis to split: the minimum, emitted in the previous sweep
+            const double pgain = srcG[0];
+            const int nOld = n - 1, Rk = k - emitted;  // Rk: candidates that can still be output
+            double T = (nOld >= Rk) ? srcG[Rk] : INF;   // the Rk-th best of the others
+            const double cutG = ctrl->cutoffGain;
+            if (useCut && !maximize && cutG < T) T = cutG;
+            const double bound = (prune && T < INF) ? (T - pgain) + 1e-9 * (fabs(T) + ctrl->cmax) : INF;
+            const unsigned char *P = stBase + (long long)ps * p.stateStride;
+            const double *Pu = reinterpret_cast<const double *>(P), *Pv = reinterpret_cast<const double *>(P + offV);
+            const int *Pr4c = reinterpret_cast<const int *>(P + offR4C), *Pc4r = reinterpret_cast<const int *>(P + offC4R);
+            const u32 pforb = reinterpret_cast<const u32 *>(P + offForb)[lane];
+            const int a = uni32(*reinterpret_cast<const int *>(P + offTail + 8));
+
+            // -- children of the popped hypothesis (split, cpp:455-532), one wave each, dynamic queue
+            int npush = 0;
+            for (;;) {
+                int t = 0;
+                if (lane == 0) t = atomicAdd(&ctrl->nextTicket, 1);
+                const int c = a + uni32(t);
+                if (c >= M) break;
+                if (emitted == 1 && p.rootColStride > 1 && (c % p.rootColStride) != p.rootColOffset) continue;  // root: first sweep
+                double v[R], spc[R];
+                int pred[R];
+                u32 cand = 0;
+#pragma unroll
+                for (int i = 0; i < R; i++) {
+                    const int r = lane + 64 * i;
+                    v[i] = 0.0;
+                    if (r < D) {
+                        uW[r] = Pu[r];
+                        v[i] = Pv[r];
+                        const int cr = Pc4r[r];
+                        c4rW[r] = cr;
+                        r4cW[r] = Pr4c[r];
+                        if (cr >= c) cand |= 1u << i;  // rows of columns >= c: cpp:480-488, 525-527
+                    }
+                }
+                const int fr = uni32(Pr4c[c]);  // row freed: cpp:277-278
+                const u32 frBit = (lane == (fr & 63)) ? (1u << (fr >> 6)) : 0u;
+                const u32 forbm = (c == a) ? pforb : frBit;  // cpp:490 / cpp:510-516
+                wave_fence();
+                if (lane == 0) { c4rW[fr] = -1; r4cW[c] = -1; }
+                wave_fence();
+                u32 scanned;
+                double delta;
+                int sink = 0;
+                if (wide_dijkstra<R, true>(Cw, D, uW, c4rW, lane, v, cand, forbm, c, bound, spc, pred, scanned, delta, sink))
+                    continue;
+                wide_update<R>(uW, c4rW, r4cW, predW, lane, v, spc, pred, scanned, delta, sink, c, D);
+                const double g = wide_gain<R>(Cw, D, M, r4cW, lane);
+                if (useCut && (maximize ? (g < cutG) : (g > cutG))) continue;  // cutHyp, cpp:496/521
+                npush++;
+                int sid = -1;
+                if (lane == 0) {
+                    const int idx = atomicSub(&ctrl->nFree, 1) - 1;
+                    if (idx >= 0) sid = freeList[idx];
+                }
+                sid = uni32(sid);
+                if (sid < 0) {  // cannot happen: S = k + maxCol + 2 covers pool + children + parent
+                    if (lane == 0) ctrl->stop = 2;
+                    break;
+                }
+                const int rn = uni32(r4cW[c]);
+                const u32 forbN = forbm | ((lane == (rn & 63)) ? (1u << (rn >> 6)) : 0u);  // cpp:362
+                store_state(sid, v, forbN, g, c);
+                if (lane == 0) {
+                    const int pos = atomicAdd(&ctrl->nChild, 1);
+                    childG[pos] = g;
+                    childS[pos] = sid;
+                    childC[pos] = c;
+                }
+            }
+            if ((p.flags & KBEST_FLAG_COUNT_PUSHED) && lane == 0 && npush) atomicAdd(&ctrl->pushed, npush);
+            __syncthreads();
+            if (uni32(ctrl->stop) != 0) break;
+
+            // -- merge: the old entries (without the popped head) and the children, sorted, first Rk kept
+            const int nChild = uni32(ctrl->nChild);
+            for (int i = tid; i < nOld; i += NT) {
+                const double g = srcG[1 + i];
+                const int s = srcS[1 + i];
+                int pos = i;
+                for (int j = 0; j < nChild; j++) pos += (childG[j] < g) ? 1 : 0;
+                if (pos < Rk) { dstG[pos] = g; dstS[pos] = s; }
+                else freeList[atomicAdd(&ctrl->nFree, 1)] = s;
+            }
+            for (int j = tid; j < nChild; j += NT) {
+                const double g = childG[j];
+                const int cj = childC[j];
+                int lo = 0, hi = nOld;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (srcG[1 + mid] <= g) lo = mid + 1; else hi = mid;
+                }
+                int pos = lo;
+                for (int j2 = 0; j2 < nChild; j2++) {
+                    const double g2 = childG[j2];
+                    pos += (g2 < g || (g2 == g && childC[j2] < cj)) ? 1 : 0;
+                }
+                if (pos < Rk) { dstG[pos] = g; dstS[pos] = childS[j]; }
+                else freeList[atomicAdd(&ctrl->nFree, 1)] = childS[j];
+            }
+            __syncthreads();
+            if (tid == 0) {
+                freeList[ctrl->nFree++] = ps;  // the split hypothesis is done
+                int nNew = nOld + nChild;
+                if (nNew > Rk) nNew = Rk;
+                int e = emitted, stop = 0, emitSid = -1;
+                if (nNew == 0) {
+                    stop = 1;  // queue empty: cpp:631-633
+                } else {
+                    const double g = dstG[0];
+                    const double gu = maximize ? (-g + ctrl->cdelta) : (g + ctrl->cdelta);  // cpp:626-630
+                    p.gain[outBase + e] = gu;
+                    if (useCut && (maximize ? (gu < ctrl->gain0u - p.cutoff) : (gu > ctrl->gain0u + p.cutoff))) {
+                        stop = 1;  // cpp:709-719: slot written, not counted
+                    } else {
+                        emitSid = dstS[0];
+                        e++;
+                        if (e >= k) stop = 1;
+                    }
+                }
+                ctrl->emitted = e;
+                ctrl->emitSid = emitSid;
+                ctrl->n = nNew;
+                ctrl->cur = 1 - cur;
+                ctrl->nChild = 0;
+                ctrl->nextTicket = 0;
+                if (stop) ctrl->stop = 1;
+            }
+            __syncthreads();
+            const int es = uni32(ctrl->emitSid);
+            if (es >= 0) {  // the new minimum goes to output slot `emitted` (cpp:618-630)
+                const unsigned char *E = stBase + (long long)es * p.stateStride;
+                const int *Er4c = reinterpret_cast<const int *>(E + offR4C), *Ec4r = reinterpret_cast<const int *>(E + offC4R);
+                for (int j = tid; j < M; j += NT) p.row4col[(outBase + emitted) * p.ldCol + j] = Er4c[j];
+                if (p.col4row)
+                    for (int j = tid; j < N; j += NT) p.col4row[(outBase + emitted) * p.ldRow + j] = Ec4r[j];
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            p.nf[b] = (ctrl->stop == 2) ? -3 : ctrl->emitted;
+            if (p.pushed) p.pushed[b] = ctrl->pushed;
+        }
+    }
+}
+
+template <int R>
+static hipError_t launch_wide_r(const WideParams &p, int grid, hipStream_t stream)
+{
+    const WideLds L = wide_lds_layout(p.maxRow, p.maxCol);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kbest_wide_kernel<R>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((kbest_wide_kernel<R>), dim3(grid), dim3(WIDE_NW * 64), L.total, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_kbest_wide(const WideParams &p, int grid, hipStream_t stream)
+{
+    if (p.maxRow <= 64) return launch_wide_r<1>(p, grid, stream);
+    if (p.maxRow <= 128) return launch_wide_r<2>(p, grid, stream);
+    if (p.maxRow <= 256) return launch_wide_r<4>(p, grid, stream);
+    return launch_wide_r<8>(p, grid, stream);
+}
+
+}  // namespace kb

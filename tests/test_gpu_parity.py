@@ -203,7 +203,7 @@ def test_reference_named_mirrors(eng):
 
 def test_unsupported_and_bad_args(eng):
     with pytest.raises(pk.KBestError):
-        eng.kbest(np.zeros((1, 65 * 65)), 65, 65, 2)        # beyond KBEST_MAX_DIM: loud, no fallback
+        eng.kbest(np.zeros((1, 513 * 2)), 513, 2, 2)        # beyond KBEST_MAX_DIM_WIDE: loud, no fallback
     with pytest.raises(pk.KBestError):
         eng.kbest(np.zeros((1, 6)), 2, 3, 2)                # numRow < numCol
 
@@ -367,7 +367,8 @@ def test_comp_methods_harness(eng, tmp_path):
 
 def test_large_maps_condition_down_to_solver_size(eng):
     """getAssignmentProbs sees EVERY landmark of the map: the raw (nL+nM) x nM matrix can have hundreds of rows.
-    conditionCosts runs on the device for any row count; only what it keeps has to fit the 64-row solver."""
+    conditionCosts runs on the device for any row count; what it keeps goes to the LDS kernel (<= 64 rows) or to
+    the general-size kernel (<= 512 rows) of the same launch."""
     from test_cost_builders import synth_quadric_frame
     rng = np.random.default_rng(99)
     frames = []
@@ -381,7 +382,7 @@ def test_large_maps_condition_down_to_solver_size(eng):
         nL, nM = len(f[0]), len(f[2])
         oc = ol.quadric_costs(*f, 10.0)
         cond, idx = ol.condition_costs(oc, nL + nM, nM)
-        if len(idx) > 64:
+        if len(idx) > 512:
             assert nf[i] == -1 and (probs[i] == 0).all()      # loud, not wrong
             continue
         condL = len(idx) - nM
@@ -414,8 +415,80 @@ def test_large_k_brute_force_style(eng):
         for b in range(3):
             n = nf[b]
             assert (r4c[b, :n] == or4c[b, :n]).all() and (bits(g[b, :n]) == bits(og[b, :n])).all(), (N, M, k)
-    with pytest.raises(pk.KBestError):
-        eng.kbest(rng.random((1, 64 * 64)), 64, 64, 20000)      # beyond the LDS pool: loud, not wrong
+
+
+def _same_as_oracle(eng, costs, N, M, k, maximize=False, cutoff=None, tag=None, **kw):
+    nf, r4c, c4r, g = eng.kbest(costs, N, M, k, maximize, cutoff, **kw)[:4]
+    onf, or4c, oc4r, og, _ = ol.orc_kbest_batch(np.asarray(costs).reshape(len(nf), -1), N, M, k, maximize, cutoff)
+    assert (nf == onf).all(), (tag, nf, onf)
+    for b in range(len(nf)):
+        n = nf[b]
+        assert (r4c[b, :n] == or4c[b, :n]).all(), tag
+        assert (c4r[b, :n] == oc4r[b, :n]).all(), tag
+        assert (bits(g[b, :n]) == bits(og[b, :n])).all(), tag
+
+
+def test_general_size_kernel_on_small_problems(eng, golden, monkeypatch):
+    """kbest_wide.hip (hypotheses and pool in HBM, R rows per lane) forced onto problems the LDS kernel normally
+    takes: golden vectors of the reference and random shapes, bit-exact, and the reference's push count."""
+    monkeypatch.setenv("KBEST_FORCE_WIDE", "1")
+    for name in golden.names:
+        c = golden.case(name)
+        nf, r4c, c4r, g, pushed = eng.kbest(c["cost"].reshape(1, -1), c["N"], c["M"], c["k"], c["maximize"],
+                                            c["cutoff"], count_pushed=True, prune=False)
+        check_against((int(nf[0]), r4c[0], c4r[0], g[0]), c["nf"], c["row4col"], c["col4row"], c["gain"], name)
+        st = ol.orc_kbest(c["cost"], c["N"], c["M"], c["k"], c["maximize"], c["cutoff"], want_stats=True)[4]
+        assert int(pushed[0]) == st.children_pushed, name
+        nf, r4c, c4r, g = eng.kbest(c["cost"].reshape(1, -1), c["N"], c["M"], c["k"], c["maximize"], c["cutoff"])
+        check_against((int(nf[0]), r4c[0], c4r[0], g[0]), c["nf"], c["row4col"], c["col4row"], c["gain"], name)
+    rng = np.random.default_rng(77)
+    for trial in range(24):
+        N = int(rng.integers(1, 65)); M = int(rng.integers(1, N + 1)); k = int(rng.integers(1, 60)); B = int(rng.integers(1, 5))
+        costs = rng.random((B, N * M)) * 20 - 5
+        mode = trial % 4
+        if mode == 1:
+            costs[rng.random((B, N * M)) < 0.4] = np.inf
+        _same_as_oracle(eng, costs, N, M, k, mode == 2, [None, None, None, 4.0][mode], tag=trial)
+
+
+def test_more_than_64_rows(eng):
+    """numRow beyond the LDS kernel (the reference has no size limit): 2, 4 and 8 rows per lane."""
+    rng = np.random.default_rng(4242)
+    for N, M, k, B in ((65, 65, 12, 2), (100, 37, 40, 3), (128, 128, 25, 2), (130, 5, 200, 2), (200, 90, 15, 2),
+                       (257, 20, 30, 1), (300, 300, 4, 1), (512, 16, 20, 1)):
+        costs = rng.random((B, N * M)) * 30
+        if N == 100:
+            costs[rng.random((B, N * M)) < 0.5] = np.inf
+        _same_as_oracle(eng, costs, N, M, k, maximize=(N == 200), cutoff=(2.0 if N == 130 else None), tag=(N, M, k))
+
+
+def test_mixed_batch_small_and_large_rows(eng):
+    """one ragged launch with problems on both sides of 64 rows: the LDS kernel and the general-size kernel each
+    take their share and write into the same output tables."""
+    rng = np.random.default_rng(31)
+    shapes = [(10, 4), (70, 9), (64, 64), (96, 50), (3, 3), (65, 2), (40, 11), (150, 30)]
+    k = 30
+    nRow = np.array([s[0] for s in shapes], np.int32); nCol = np.array([s[1] for s in shapes], np.int32)
+    blocks = [rng.random(n * m) * 10 for n, m in shapes]
+    off = np.zeros(len(shapes), np.int64); off[1:] = np.cumsum([len(x) for x in blocks])[:-1]
+    N, M = int(nRow.max()), int(nCol.max())
+    nf, r4c, c4r, g = eng.kbest(np.concatenate(blocks), N, M, k, nRow=nRow, nCol=nCol, costOff=off)
+    for i, (n, m) in enumerate(shapes):
+        onf, or4c, oc4r, og = ol.orc_kbest(blocks[i], n, m, k)
+        check_against((int(nf[i]), r4c[i][:, :m], c4r[i][:, :n], g[i]), onf, or4c, oc4r, og, (n, m))
+
+
+def test_k_beyond_the_lds_pool(eng):
+    """bruteForceProb asks kBest2D for up to 20 000 assignments (assignment.cpp:868): the pool then lives in HBM."""
+    rng = np.random.default_rng(8)
+    for N, M, k in ((8, 8, 20000), (10, 6, 20000), (64, 64, 6000)):
+        costs = rng.random((1, N * M)) * 6
+        _same_as_oracle(eng, costs, N, M, k, tag=(N, M, k))
+    # every assignment of a 7 x 7 problem (5040 of them): the enumeration ends by itself
+    costs = rng.random((1, 49)) * 3
+    nf, r4c, c4r, g = eng.kbest(costs, 7, 7, 20000)
+    assert nf[0] == 5040 and len({tuple(r) for r in r4c[0, :5040].tolist()}) == 5040
+    assert (np.diff(g[0, :5040]) >= 0).all()
 
 
 def test_brute_force_probs(eng):
