@@ -12,7 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 KBEST_FLAG_NO_PRUNE = 1
 KBEST_FLAG_COUNT_PUSHED = 2
-KBEST_MAX_DIM = 64
+KBEST_MAX_DIM = 64        # rows handled by the LDS-resident kernel
+KBEST_MAX_DIM_WIDE = 512  # rows handled at all (general-size kernel beyond KBEST_MAX_DIM)
 
 # every symbol include/kbest_c.h declares
 C_ABI_SYMBOLS = (
