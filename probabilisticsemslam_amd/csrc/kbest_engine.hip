@@ -85,38 +85,60 @@ __device__ __forceinline__ int dijkstra(const double *Cs, int LDC, const double 
     u32 bndLo;
     to_key(EARLY ? bound : d_inf(), bndHi, bndLo);  // bndHi <= KEY_INF_HI: one compare catches "+inf" too
     double delta = 0.0;
-    int closest, cc;
+    int closest = 0, cc = 0;
     pred = 0;
-    // One conditional exit in the common path and one back edge; everything rare sits behind the exit test.
-    do {
-        const double cval = Cs[rl + cur * LDC];
-        const double ucur = u[cur];
-        const double rc = ((delta + cval) - ucur) - v;  // cpp:183 / cpp:313, left to right
-        const u64 upd = __ballot(rc < __hiloint2double(shi, slo)) & act;  // strict '<': cpp:185, 314
-        slo = sel32(upd, __double2loint(rc), slo);
-        shi = sel32(upd, __double2hiint(rc), shi);
-        pred = sel32(upd, cur, pred);
-        const int sg = shi >> 31;
-        const int khi = sel32(act, shi ^ (int)((u32)sg >> 1), KEY_INF_HI);  // candidates only
-        const int mhi = wave_min_i32(khi);
-        u64 eq = __ballot(khi == mhi);
-        if (__builtin_expect(__popcll(eq) > 1, 0)) {  // several rows share the high word: decide on the low word
-            const u32 t = (u32)sel32(eq, slo ^ sg, -1);
-            const u32 mlo = wave_min_u32(t);
-            eq &= __ballot(t == mlo);
-        }
-        closest = __builtin_ctzll(eq);  // lowest row index: cpp:191, 320 (eq != 0: some lane holds the minimum)
-        delta = __hiloint2double(__builtin_amdgcn_readlane(shi, closest), __builtin_amdgcn_readlane(slo, closest));
+    // The scalar unit issues one instruction per wave turn just like the vector unit, and with six waves per SIMD
+    // it is the scalar instruction count of this loop that bounds the step rate: the inner loop has ONE exit test
+    // (sink reached, or the minimum's key has reached the bound's) and everything rare is decided outside it.
+    int mhi;
+    for (;;) {
+        do {
+            const double cval = Cs[rl + cur * LDC];
+            const double ucur = u[cur];
+            const double rc = ((delta + cval) - ucur) - v;  // cpp:183 / cpp:313, left to right
+            const u64 upd = __ballot(rc < __hiloint2double(shi, slo)) & act;  // strict '<': cpp:185, 314
+            slo = sel32(upd, __double2loint(rc), slo);
+            shi = sel32(upd, __double2hiint(rc), shi);
+            pred = sel32(upd, cur, pred);
+            // Reduced costs are non-negative up to rounding (a tight arc can come out as -1e-17), and for
+            // non-negative doubles the high word itself is the order-preserving key: the common path skips the key
+            // conversion and takes delta's high word straight from the minimum.
+            int khi = sel32(act, shi, KEY_INF_HI);  // candidates only
+            mhi = wave_min_i32(khi);
+            u64 eq = __ballot(khi == mhi);
+            if (__builtin_expect(mhi < 0, 0)) {  // some candidate is negative: redo with the real key
+                const int sg = shi >> 31;
+                khi = sel32(act, shi ^ (int)((u32)sg >> 1), KEY_INF_HI);
+                mhi = wave_min_i32(khi);
+                eq = __ballot(khi == mhi);
+                if (__popcll(eq) > 1) {
+                    const u32 t = (u32)sel32(eq, slo ^ sg, -1);
+                    const u32 mlo = wave_min_u32(t);
+                    eq &= __ballot(t == mlo);
+                }
+                closest = __builtin_ctzll(eq);
+                delta = __hiloint2double(__builtin_amdgcn_readlane(shi, closest), __builtin_amdgcn_readlane(slo, closest));
+            } else {
+                if (__builtin_expect(__popcll(eq) > 1, 0)) {  // several rows share the high word: decide on the low word
+                    const u32 t = (u32)sel32(eq, slo, -1);
+                    const u32 mlo = wave_min_u32(t);
+                    eq &= __ballot(t == mlo);
+                }
+                closest = __builtin_ctzll(eq);  // lowest row index: cpp:191, 320 (eq != 0: some lane holds the minimum)
+                delta = __hiloint2double(mhi, __builtin_amdgcn_readlane(slo, closest));
+            }
+            cand &= ~(1ull << closest);
+            act = cand;
+            cc = __builtin_amdgcn_readlane(c4r, closest);
+            cur = cc;
+            // continue while cc >= 0 (not a sink) and mhi < bndHi: the sign bit of (mhi - bndHi) & ~cc
+        } while (__builtin_expect((((mhi - bndHi) & ~cc) < 0), 1));
         if (__builtin_expect(mhi >= bndHi, 0)) {
-            scannedOut = cand0 & ~cand;
-            if (mhi >= KEY_INF_HI) return 1;                        // minimum is +inf: infeasible (cpp:197, 327)
-            if (EARLY && (mhi > bndHi || delta > bound)) return 2;  // cannot enter the k best any more
+            if (mhi >= KEY_INF_HI) { scannedOut = cand0 & ~cand; return 1; }  // minimum is +inf: infeasible (cpp:197, 327)
+            if (EARLY && (mhi > bndHi || delta > bound)) { scannedOut = cand0 & ~cand; return 2; }  // beyond the k best
         }
-        cand &= ~(1ull << closest);
-        act = cand;
-        cc = __builtin_amdgcn_readlane(c4r, closest);
-        cur = cc;
-    } while (cc >= 0);
+        if (cc < 0) break;
+    }
     sinkOut = closest;
     spc = __hiloint2double(shi, slo);
     scannedOut = cand0 & ~cand;
