@@ -119,13 +119,22 @@ __device__ __forceinline__ int dijkstra(const double *Cs, int LDC, const double 
                 closest = __builtin_ctzll(eq);
                 delta = __hiloint2double(__builtin_amdgcn_readlane(shi, closest), __builtin_amdgcn_readlane(slo, closest));
             } else {
-                if (__builtin_expect(__popcll(eq) > 1, 0)) {  // several rows share the high word: decide on the low word
-                    const u32 t = (u32)sel32(eq, slo, -1);
-                    const u32 mlo = wave_min_u32(t);
-                    eq &= __ballot(t == mlo);
-                }
                 closest = __builtin_ctzll(eq);  // lowest row index: cpp:191, 320 (eq != 0: some lane holds the minimum)
-                delta = __hiloint2double(mhi, __builtin_amdgcn_readlane(slo, closest));
+                int dlo = __builtin_amdgcn_readlane(slo, closest);
+                if (__popcll(eq) > 1) {
+                    // Several rows share the high word.  One step in five is like that, nearly always because several
+                    // reduced costs are exactly 0.0 (tight arcs): if no other of those rows has a smaller low word
+                    // the first one is the minimum (equal values: lowest row), and only otherwise a second chain
+                    // over the low words is needed.
+                    const u64 less = __ballot((u32)slo < (u32)dlo) & eq;
+                    if (__builtin_expect(less != 0, 0)) {
+                        const u32 t = (u32)sel32(eq, slo, -1);
+                        const u32 mlo = wave_min_u32(t);
+                        closest = __builtin_ctzll(eq & __ballot(t == mlo));
+                        dlo = (int)mlo;
+                    }
+                }
+                delta = __hiloint2double(mhi, dlo);
             }
             cand &= ~(1ull << closest);
             act = cand;
