@@ -72,7 +72,7 @@ template <bool EARLY>
 __device__ __forceinline__ int dijkstra(const double *Cs, int LDC, const double *u, int rl, int lane,
                                         double v, int c4r, u64 cand, u64 forb, int start, double bound,
                                         double &spc, int &pred, u64 &scannedOut, double &deltaOut,
-                                        int &sinkOut)
+                                        int &sinkOut, double minIn = 0.0, int sinkRow = 0)
 {
     int slo = 0, shi = KEY_INF_HI;  // spc = +inf
     cand = uni64(cand);
@@ -81,9 +81,17 @@ __device__ __forceinline__ int dijkstra(const double *Cs, int LDC, const double 
     int cur = uni32(start);
     // the bound is computed from LDS values (VGPRs): make it provably uniform or the loop turns divergent
     bound = __hiloint2double(uni32(__double2hiint(bound)), uni32(__double2loint(bound)));
+    // EARLY with minIn > 0: the only unassigned row of a child problem is the row it freed (sinkRow), so the path
+    // must END with an arc into that row, and minIn is a lower bound of the reduced cost of every such arc.  The
+    // final distance is therefore at least min(spc[sinkRow], delta + minIn): the loop runs against the tighter
+    // bound - minIn, and when that is reached the child is given up unless the sink is already within the bound
+    // through a scanned column (then the loop goes on against the plain bound).
+    minIn = __hiloint2double(uni32(__double2hiint(minIn)), uni32(__double2loint(minIn)));
+    double tight = bound - minIn;
+    bool useTight = EARLY && minIn > 0.0;
     int bndHi;
     u32 bndLo;
-    to_key(EARLY ? bound : d_inf(), bndHi, bndLo);  // bndHi <= KEY_INF_HI: one compare catches "+inf" too
+    to_key(EARLY ? (useTight ? tight : bound) : d_inf(), bndHi, bndLo);  // bndHi <= KEY_INF_HI: one compare catches "+inf" too
     double delta = 0.0;
     int closest = 0, cc = 0;
     pred = 0;
@@ -144,7 +152,13 @@ __device__ __forceinline__ int dijkstra(const double *Cs, int LDC, const double 
         } while (__builtin_expect((((mhi - bndHi) & ~cc) < 0), 1));
         if (__builtin_expect(mhi >= bndHi, 0)) {
             if (mhi >= KEY_INF_HI) { scannedOut = cand0 & ~cand; return 1; }  // minimum is +inf: infeasible (cpp:197, 327)
-            if (EARLY && (mhi > bndHi || delta > bound)) { scannedOut = cand0 & ~cand; return 2; }  // beyond the k best
+            if (EARLY && delta > bound) { scannedOut = cand0 & ~cand; return 2; }  // beyond the k best
+            if (EARLY && useTight && delta > tight) {
+                const double sfr = __hiloint2double(__builtin_amdgcn_readlane(shi, sinkRow), __builtin_amdgcn_readlane(slo, sinkRow));
+                if (sfr > bound) { scannedOut = cand0 & ~cand; return 2; }  // the sink cannot come within the bound
+                useTight = false;
+                to_key(bound, bndHi, bndLo);
+            }
         }
         if (cc < 0) break;
     }
@@ -634,10 +648,22 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 double spc, delta;
                 int pred, sink = 0;
                 u64 scanned;
+                // backward bound: the path ends with an arc (row fr, column j), j a later column; the smallest
+                // reduced cost of those arcs (high word only: rounded down) bounds the child's distance from below
+                double minIn = 0.0;
+                if (bound < INF) {
+                    const int jj = lane < D ? lane : D - 1;
+                    const double rin = (Cs[fr + jj * LDC] - nd.u[jj]) - readlane_f64(v, fr);
+                    int h = __double2hiint(rin);
+                    h = h < 0 ? 0 : h;  // -1e-17 from rounding: no information
+                    const int mk = wave_min_i32((lane > c && lane < D) ? h : KEY_INF_HI);
+                    minIn = __hiloint2double(mk, 0);
+                    if (minIn > bound) { KB_ACC(9, __builtin_readcyclecounter() - tItem); continue; }  // dead before its first step
+                }
                 KB_T(tDij0);
                 KB_ACC(9, tDij0 - tItem);  // [9] per-child set-up cycles
                 const int st = dijkstra<true>(Cs, LDC, nd.u, rl, lane, v, c4r, cand, forbm, c, bound, spc, pred,
-                                              scanned, delta, sink);
+                                              scanned, delta, sink, minIn, fr);
                 KB_T(tDij1);
                 KB_ACC(8, tDij1 - tDij0);  // [8] cycles inside child Dijkstra
                 KB_ACC(5, __popcll(scanned) + (st != 0));  // [5] child Dijkstra steps (approx: scanned rows)
