@@ -73,9 +73,9 @@ struct WeightParams {
 // forbidden-row mask, gain, activeCol.
 __host__ __device__ inline long long state_stride(int maxRow)
 {
-    // u, v, prefix (fp64), row4col, col4row (u8), forbidden mask, gain, activeCol; rounded to whole 128-byte
+    // u, v (fp64), row4col, col4row (u8), forbidden mask, gain, activeCol; rounded to whole 128-byte
     // lines: neighbouring states never share a cache line
-    return ((((long long)26 * maxRow + 7) & ~7LL) + 24 + 127) & ~127LL;
+    return ((((long long)18 * maxRow + 7) & ~7LL) + 24 + 127) & ~127LL;
 }
 
 // u16 entries of one matrix's slot -> state table, rounded to whole 128-byte lines
@@ -92,7 +92,7 @@ __host__ __device__ inline Lds lds_layout(int maxRow, int k, int spec)
     const int ldc = maxRow | 1;
     int o = 0;
     L.offC = o;          o += maxRow * ldc * 8;      // shifted, zero-padded cost tile
-    L.nodeStride = (26 * maxRow + 32 + 7) & ~7;      // u, v, prefix (fp64), scalars, row4col, col4row (u8)
+    L.nodeStride = (18 * maxRow + 32 + 7) & ~7;      // u, v (fp64), scalars, row4col, col4row (u8)
     L.offNodes = o;      o += spec * L.nodeStride;   // solved hypotheses waiting to be split
     L.offFreshG = o;     o += (spec * 64 > 16 ? spec * 64 : 16) * 8;  // surviving children of this round: gain
                                                      //   (also: the first-step minima during the filter phase)

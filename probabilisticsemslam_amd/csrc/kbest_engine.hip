@@ -193,33 +193,23 @@ __device__ __forceinline__ void dual_update_flip(double *u, int lane, double &v,
     } while (c != start && ++guard < 64);
 }
 
-// calcGain (cpp:59-80): serial left-to-right fp64 sum over columns.  Columns
-// < from are taken from the caller's partial sum acc0 (the parent's prefix:
-// a child on column c only changes columns >= c).  If prefixOut != nullptr the
-// partial sums before each column are written there (lane = column).
-template <bool PREFIX>
-__device__ __forceinline__ double serial_gain(const double *Cs, int LDC, int lane, int r4c, int from,
-                                              int M, double acc0, double &mine)
+// calcGain (cpp:59-80): serial left-to-right fp64 sum over the M real columns, from 0.0.  Lanes >= M contribute
+// +0.0, and x + 0.0 == x exactly for the non-negative partial sums here, so the chain runs in whole blocks of 8
+// lanes: the 16 lane reads of a block are independent and issue back to back, only the 8 adds are a dependent
+// chain, in the reference's order.
+__device__ __forceinline__ double serial_gain(const double *Cs, int LDC, int lane, int r4c, int M)
 {
-    // lanes outside [from, M) contribute +0.0, and x + 0.0 == x exactly for the non-negative partial sums
-    // here, so the chain can run in whole blocks of 8 lanes: the 16 lane reads of a block are independent
-    // and issue back to back, only the 8 adds are a dependent chain, in the reference's order.
-    // PREFIX: lane j (from <= j < M) also gets the partial sum before column j in `mine`.
     double t = 0.0;
-    if (lane >= from && lane < M) t = Cs[r4c + lane * LDC];
+    if (lane < M) t = Cs[r4c + lane * LDC];
     const int tlo = __double2loint(t), thi = __double2hiint(t);
-    double acc = acc0;
-    mine = acc0;
-    for (int j0 = from & ~7; j0 < M; j0 += 8) {
+    double acc = 0.0;
+    for (int j0 = 0; j0 < M; j0 += 8) {
         double term[8];
 #pragma unroll
         for (int i = 0; i < 8; i++)
             term[i] = __hiloint2double(__builtin_amdgcn_readlane(thi, j0 + i), __builtin_amdgcn_readlane(tlo, j0 + i));
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            if (PREFIX && lane == j0 + i) mine = acc;
-            acc = acc + term[i];
-        }
+        for (int i = 0; i < 8; i++) acc = acc + term[i];
     }
     return acc;
 }
@@ -284,7 +274,7 @@ constexpr u32 META_MASK = 0x00FFFFFFu;
 
 // a solved hypothesis waiting to be split, in LDS
 struct NodeRef {
-    double *u, *v, *prefix;
+    double *u, *v;
     double *gain;  // [0] shifted gain
     u64 *forb;
     int *info;     // [0] activeCol, [1] sid
@@ -296,8 +286,7 @@ __device__ __forceinline__ NodeRef node_ref(unsigned char *base, int maxRow)
     NodeRef n;
     n.u = reinterpret_cast<double *>(base);
     n.v = n.u + maxRow;
-    n.prefix = n.v + maxRow;
-    n.gain = n.prefix + maxRow;
+    n.gain = n.v + maxRow;
     n.forb = reinterpret_cast<u64 *>(n.gain + 1);
     n.info = reinterpret_cast<int *>(n.forb + 1);
     n.r4c = reinterpret_cast<unsigned char *>(n.info + 4);
@@ -418,19 +407,18 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     }
 
     unsigned char *stBase = p.states + (long long)b * maxSid * p.stateStride;
-    // saved hypothesis (HBM): u[D'] v[D'] prefix[D'] (fp64) | row4col[D'] col4row[D'] (u8) | forb, gain, activeCol
+    // saved hypothesis (HBM): u[D'] v[D'] (fp64) | row4col[D'] col4row[D'] (u8) | forb, gain, activeCol
     const long long outBase = (long long)b * k;
     const int DS = p.maxRow;
-    const int offR4C = 24 * DS, offC4R = 25 * DS, offTail = (26 * DS + 7) & ~7;
+    const int offR4C = 16 * DS, offC4R = 17 * DS, offTail = (18 * DS + 7) & ~7;
 
     // Write a full hypothesis to state slot `sid`.
-    auto store_state = [&](int sid, double u, double v, double pfx, int r4c, int c4r, u64 forb, double gain, int activeCol) {
+    auto store_state = [&](int sid, double u, double v, int r4c, int c4r, u64 forb, double gain, int activeCol) {
         unsigned char *st = stBase + (long long)sid * p.stateStride;
         double *sd = reinterpret_cast<double *>(st);
         if (lane < D) {
             sd[lane] = u;
             sd[DS + lane] = v;
-            sd[2 * DS + lane] = pfx;
             st[offR4C + lane] = (unsigned char)r4c;
             st[offC4R + lane] = (unsigned char)c4r;
         }
@@ -441,12 +429,11 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         }
     };
     // Publish the hypothesis this wave holds (u already in nd.u) as node nd, and store it as state `sid`.
-    auto save_node = [&](const NodeRef &nd, int sid, double v, double pfx, int r4c, int c4r, u64 forb, double gain,
+    auto save_node = [&](const NodeRef &nd, int sid, double v, int r4c, int c4r, u64 forb, double gain,
                          int activeCol) {
-        store_state(sid, (lane < D) ? nd.u[lane] : 0.0, v, pfx, r4c, c4r, forb, gain, activeCol);
+        store_state(sid, (lane < D) ? nd.u[lane] : 0.0, v, r4c, c4r, forb, gain, activeCol);
         if (lane < D) {
             nd.v[lane] = v;
-            nd.prefix[lane] = pfx;
             nd.r4c[lane] = (unsigned char)r4c;
             nd.c4r[lane] = (unsigned char)c4r;
         }
@@ -474,10 +461,9 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         if (bad) {
             if (lane == 0) ctrl->stop = 3;
         } else {
-            double pfx;
-            const double g = serial_gain<true>(Cs, LDC, lane, r4c, 0, M, 0.0, pfx);
+            const double g = serial_gain(Cs, LDC, lane, r4c, M);
             const u64 forb = bit64(__builtin_amdgcn_readlane(r4c, 0));  // cpp:235
-            save_node(nd, 0, v, pfx, r4c, c4r, forb, g, 0);
+            save_node(nd, 0, v, r4c, c4r, forb, g, 0);
             if (lane == 0) {
                 ctrl->cutoffGain = maximize ? (g - p.cutoff) : (g + p.cutoff);          // cpp:681/684
                 const double gu = maximize ? (-g + ctrl->cdelta) : (g + ctrl->cdelta);  // cpp:599-603
@@ -640,7 +626,6 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                     // rounding), so delta > (T - parent gain) + margin can never enter the k best.
                     bound = (prune && T < INF) ? (T - pgain) + 1e-9 * (fabs(T) + cmaxv) : INF;
                 }
-                const double pfx = nd.prefix[c];
                 const int fr = __builtin_amdgcn_readlane(r4cP, c);           // row freed: cpp:277-278
                 const u64 cand = __ballot(lane < D && c4rP >= c);             // rows of columns >= c: cpp:480-488, 525-527
                 const u64 forbm = (c == a) ? nforb : bit64(fr);                // cpp:490 / cpp:510-516
@@ -670,7 +655,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 if (st != 0) continue;
                 KB_ACC(6, 1);  // [6] children completed
                 // The child survived: finish it the way shortestPathUpdateCPP does -- path flip (cpp:108-116), exact
-                // gain (calcGain, cpp:59-80, continuing the parent's partial sums: only columns >= c change) and,
+                // gain (calcGain, cpp:59-80) and,
                 // if a state slot is free, the dual update (cpp:92-106) -- and keep the whole hypothesis, so that it
                 // can later be split without being solved again.  Without a slot it stays a lazy candidate.
                 int r4c = (lane == c) ? -1 : r4cP;
@@ -685,8 +670,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                         r = nxt;
                     } while (cc != c && ++guard < 64);
                 }
-                double mine;
-                const double g = serial_gain<true>(Cs, LDC, lane, r4c, c, M, pfx, mine);
+                const double g = serial_gain(Cs, LDC, lane, r4c, M);
                 if (useCut && (maximize ? (g < cutG) : (g > cutG))) continue;  // cutHyp, cpp:496/521
                 npush++;
                 int slot = -1;
@@ -704,9 +688,8 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                     double uN = (lane < D) ? nd.u[lane] : 0.0;
                     if (lane < D && lane != c && ((scanned >> rowOfCol) & 1ull)) uN = uN + delta - spcOfRow;  // cpp:96-99
                     if (lane == c) uN = uN + delta;                                     // cpp:92
-                    const double pfxN = (lane <= c) ? ((lane < M) ? nd.prefix[lane] : 0.0) : mine;
                     const u64 forbN = forbm | bit64(__builtin_amdgcn_readlane(r4c, c));  // cpp:362
-                    store_state(slot, uN, vN, pfxN, r4c, c4rN, forbN, g, c);
+                    store_state(slot, uN, vN, r4c, c4rN, forbN, g, c);
                 }
                 KB_ACC(10, __builtin_readcyclecounter() - tDij1);  // [10] finish of completed children
                 if (lane == 0) {
@@ -863,7 +846,6 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 if (lane < D) {
                     nd.u[lane] = sd[lane];
                     nd.v[lane] = sd[DS + lane];
-                    nd.prefix[lane] = sd[2 * DS + lane];
                     nd.r4c[lane] = st[offR4C + lane];
                     nd.c4r[lane] = st[offC4R + lane];
                 }
@@ -900,10 +882,9 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 const int rc = dijkstra<false>(Cs, LDC, nd.u, rl, lane, v, c4r, cand, forbm, col, INF, spc, pred, scanned,
                                                delta, sink);
                 if (rc == 0) dual_update_flip(nd.u, lane, v, c4r, r4c, spc, pred, scanned, delta, sink, col);
-                double pfx;
-                const double g = serial_gain<true>(Cs, LDC, lane, r4c, 0, M, 0.0, pfx);
+                const double g = serial_gain(Cs, LDC, lane, r4c, M);
                 const u64 forbN = forbm | bit64(__builtin_amdgcn_readlane(r4c, col));  // cpp:362
-                save_node(nd, mySid, v, pfx, r4c, c4r, forbN, g, col);
+                save_node(nd, mySid, v, r4c, c4r, forbN, g, col);
                 if (lane == 0 && rc != 0) ctrl->stop = 2;  // cannot happen: the candidate was solved before
             }
         }
