@@ -74,7 +74,6 @@ __device__ __forceinline__ int dijkstra(const double *Cs, int LDC, const double 
                                         double &spc, int &pred, u64 &scannedOut, double &deltaOut,
                                         int &sinkOut, double minIn = 0.0, int sinkRow = 0)
 {
-    int slo = 0, shi = KEY_INF_HI;  // spc = +inf
     cand = uni64(cand);
     u64 act = cand & ~uni64(forb);
     const u64 cand0 = cand;
@@ -87,34 +86,114 @@ __device__ __forceinline__ int dijkstra(const double *Cs, int LDC, const double 
     // bound - minIn, and when that is reached the child is given up unless the sink is already within the bound
     // through a scanned column (then the loop goes on against the plain bound).
     minIn = __hiloint2double(uni32(__double2hiint(minIn)), uni32(__double2loint(minIn)));
-    double tight = bound - minIn;
+    const double tight = bound - minIn;
     bool useTight = EARLY && minIn > 0.0;
     int bndHi;
     u32 bndLo;
     to_key(EARLY ? (useTight ? tight : bound) : d_inf(), bndHi, bndLo);  // bndHi <= KEY_INF_HI: one compare catches "+inf" too
-    double delta = 0.0;
-    int closest = 0, cc = 0;
+    u64 dbits = 0;         // delta (0.0) as a bit pattern: it lives in a scalar register pair
+    double sp = d_inf();  // this row's shortestPathCost
+    int closest = 0, khi = 0, status = 0;
+    u64 eq = 0;
     pred = 0;
-    // The scalar unit issues one instruction per wave turn just like the vector unit, and with six waves per SIMD
-    // it is the scalar instruction count of this loop that bounds the step rate: the inner loop has ONE exit test
-    // (sink reached, or the minimum's key has reached the bound's) and everything rare is decided outside it.
-    int mhi;
+    // LDS byte addresses (the low word of a flat LDS address is the LDS offset)
+    const u32 rowAddr = (u32)reinterpret_cast<uintptr_t>(Cs + rl);
+    const u32 uBase = (u32)__builtin_amdgcn_readfirstlane((int)(u32)reinterpret_cast<uintptr_t>(u));
+    const int ldc8 = __builtin_amdgcn_readfirstlane(LDC * 8);
+    const int keyInf = KEY_INF_HI;
+    // The step loop, hand-written: at six waves per SIMD the kernel runs at the SIMD's aggregate issue rate, so every
+    // instruction of this loop counts.  21 VALU + 13 SALU + 2 LDS, ONE exit test:
+    //   * reduced costs are non-negative up to rounding, and for non-negative doubles the high word itself is the
+    //     order-preserving key: no key conversion, and delta's high word IS the wave minimum (s81);
+    //   * one step in five has several rows on the same high word, nearly always exact zeros (tight arcs): if no
+    //     other of them has a smaller low word than the first, the first is the minimum (equal values: lowest row,
+    //     cpp:191, 320) -- one more compare, inside the loop;
+    //   * the loop goes on while (sink not reached) and (minimum key < bound key): sign bit of (mhi - bndHi) & ~cc;
+    //   * the truly rare cases -- a negative candidate (-1e-17 from rounding), a high-word tie that needs the low
+    //     words reduced -- leave the loop in mid-step (status 1) and are finished below in C++, which re-enters.
+    // Fixed registers: v[60:61] spc, v62 pred, v63 key, s[80:81] delta, s82 cur / col4row of the chosen row, s83
+    // chosen row, s[84:85] rows still to scan, s[86:87] rows scanned against this column, s[88:89] rows at the minimum.
+    // Wait states (gfx950): VALU write -> DPP read 2, VALU VGPR write -> readlane 1, VALU SGPR write -> VALU read 2.
     for (;;) {
-        do {
-            const double cval = Cs[rl + cur * LDC];
-            const double ucur = u[cur];
-            const double rc = ((delta + cval) - ucur) - v;  // cpp:183 / cpp:313, left to right
-            const u64 upd = __ballot(rc < __hiloint2double(shi, slo)) & act;  // strict '<': cpp:185, 314
-            slo = sel32(upd, __double2loint(rc), slo);
-            shi = sel32(upd, __double2hiint(rc), shi);
-            pred = sel32(upd, cur, pred);
-            // Reduced costs are non-negative up to rounding (a tight arc can come out as -1e-17), and for
-            // non-negative doubles the high word itself is the order-preserving key: the common path skips the key
-            // conversion and takes delta's high word straight from the minimum.
-            int khi = sel32(act, shi, KEY_INF_HI);  // candidates only
-            mhi = wave_min_i32(khi);
-            u64 eq = __ballot(khi == mhi);
-            if (__builtin_expect(mhi < 0, 0)) {  // some candidate is negative: redo with the real key
+        asm volatile(
+            "L_step%=:\n\t"
+            "s_mul_i32 s94, s82, s91\n\t"
+            "s_lshl3_add_u32 s95, s82, s92\n\t"
+            "v_add_u32_e32 v72, s94, v56\n\t"
+            "v_mov_b32_e32 v75, s95\n\t"
+            "ds_read_b64 v[68:69], v72\n\t"
+            "ds_read_b64 v[70:71], v75\n\t"
+            "v_mov_b32_e32 v73, s82\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_add_f64 v[66:67], s[80:81], v[68:69]\n\t"
+            "v_add_f64 v[66:67], v[66:67], -v[70:71]\n\t"
+            "v_add_f64 v[66:67], v[66:67], -v[58:59]\n\t"
+            "v_cmp_lt_f64_e32 vcc, v[66:67], v[60:61]\n\t"
+            "s_and_b64 vcc, vcc, s[86:87]\n\t"
+            "v_cndmask_b32_e32 v61, v61, v67, vcc\n\t"
+            "v_cndmask_b32_e64 v63, v74, v61, s[86:87]\n\t"
+            "v_cndmask_b32_e32 v60, v60, v66, vcc\n\t"
+            "v_cndmask_b32_e32 v62, v62, v73, vcc\n\t"
+            "v_min_i32_dpp v64, v63, v63 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_min_i32_dpp v64, v64, v64 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_min_i32_dpp v64, v64, v64 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_min_i32_dpp v64, v64, v64 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_min_i32_dpp v64, v64, v64 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_min_i32_dpp v64, v64, v64 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+            "s_nop 0\n\t"
+            "v_readlane_b32 s81, v64, 63\n\t"
+            "s_nop 1\n\t"
+            "v_cmp_eq_u32_e64 s[88:89], s81, v63\n\t"
+            "s_cmp_lt_i32 s81, 0\n\t"
+            "s_cbranch_scc1 L_slow%=\n\t"
+            "s_ff1_i32_b64 s83, s[88:89]\n\t"
+            "s_bcnt1_i32_b64 s94, s[88:89]\n\t"
+            "v_readlane_b32 s80, v60, s83\n\t"
+            "s_cmp_gt_u32 s94, 1\n\t"
+            "s_cbranch_scc1 L_tie%=\n\t"
+            "L_tail%=:\n\t"
+            "s_sub_i32 s94, s81, s93\n\t"
+            "v_readlane_b32 s82, v57, s83\n\t"
+            "s_bitset0_b64 s[84:85], s83\n\t"
+            "s_mov_b64 s[86:87], s[84:85]\n\t"
+            "s_andn2_b32 s94, s94, s82\n\t"
+            "s_cmp_lt_i32 s94, 0\n\t"
+            "s_cbranch_scc1 L_step%=\n\t"
+            "s_mov_b32 s95, 0\n\t"
+            "s_branch L_done%=\n\t"
+            "L_tie%=:\n\t"
+            "s_nop 1\n\t"
+            "v_cmp_lt_u32_e64 s[76:77], v60, s80\n\t"
+            "s_and_b64 s[76:77], s[76:77], s[88:89]\n\t"
+            "s_cmp_eq_u64 s[76:77], 0\n\t"
+            "s_cbranch_scc1 L_tail%=\n\t"
+            "L_slow%=:\n\t"
+            "s_mov_b32 s95, 1\n\t"
+            "L_done%=:\n\t"
+            : "+{s[80:81]}"(dbits), "+{s82}"(cur), "+{s[84:85]}"(cand), "+{s[86:87]}"(act), "+{v[60:61]}"(sp),
+              "+{v62}"(pred), "={v63}"(khi), "={s83}"(closest), "={s[88:89]}"(eq), "={s95}"(status)
+            : "{v56}"(rowAddr), "{v57}"(c4r), "{v[58:59]}"(v), "{v74}"(keyInf), "{s91}"(ldc8), "{s92}"(uBase),
+              "{s93}"(bndHi)
+            : "v64", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v75", "s76", "s77", "s94", "vcc", "scc",
+              "memory");
+        // (the compiler does not know that outputs bound to physical scalar registers are wave-uniform)
+        dbits = uni64(dbits);
+        cur = uni32(cur);
+        cand = uni64(cand);
+        act = uni64(act);
+        closest = uni32(closest);
+        status = uni32(status);
+        int mhi = (int)(u32)(dbits >> 32);  // the wave minimum's key (s81)
+        if (__builtin_expect(status != 0, 0)) {
+            // finish the step here: the selects are done, khi / mhi / eq hold the high-word minimum
+            const int slo = __double2loint(sp), shi = __double2hiint(sp);
+            eq = uni64(eq);
+            if (mhi < 0) {  // some candidate is negative: redo with the real order-preserving key
                 const int sg = shi >> 31;
                 khi = sel32(act, shi ^ (int)((u32)sg >> 1), KEY_INF_HI);
                 mhi = wave_min_i32(khi);
@@ -125,47 +204,36 @@ __device__ __forceinline__ int dijkstra(const double *Cs, int LDC, const double 
                     eq &= __ballot(t == mlo);
                 }
                 closest = __builtin_ctzll(eq);
-                delta = __hiloint2double(__builtin_amdgcn_readlane(shi, closest), __builtin_amdgcn_readlane(slo, closest));
-            } else {
-                closest = __builtin_ctzll(eq);  // lowest row index: cpp:191, 320 (eq != 0: some lane holds the minimum)
-                int dlo = __builtin_amdgcn_readlane(slo, closest);
-                if (__popcll(eq) > 1) {
-                    // Several rows share the high word.  One step in five is like that, nearly always because several
-                    // reduced costs are exactly 0.0 (tight arcs): if no other of those rows has a smaller low word
-                    // the first one is the minimum (equal values: lowest row), and only otherwise a second chain
-                    // over the low words is needed.
-                    const u64 less = __ballot((u32)slo < (u32)dlo) & eq;
-                    if (__builtin_expect(less != 0, 0)) {
-                        const u32 t = (u32)sel32(eq, slo, -1);
-                        const u32 mlo = wave_min_u32(t);
-                        closest = __builtin_ctzll(eq & __ballot(t == mlo));
-                        dlo = (int)mlo;
-                    }
-                }
-                delta = __hiloint2double(mhi, dlo);
+                dbits = ((u64)(u32)__builtin_amdgcn_readlane(shi, closest) << 32) | (u32)__builtin_amdgcn_readlane(slo, closest);
+            } else {  // rows on the same high word, and the first of them is not the smallest: reduce the low words
+                const u32 t = (u32)sel32(eq, slo, -1);
+                const u32 mlo = wave_min_u32(t);
+                closest = __builtin_ctzll(eq & __ballot(t == mlo));  // lowest row index: cpp:191, 320
+                dbits = ((u64)(u32)mhi << 32) | mlo;
             }
             cand &= ~(1ull << closest);
             act = cand;
-            cc = __builtin_amdgcn_readlane(c4r, closest);
-            cur = cc;
-            // continue while cc >= 0 (not a sink) and mhi < bndHi: the sign bit of (mhi - bndHi) & ~cc
-        } while (__builtin_expect((((mhi - bndHi) & ~cc) < 0), 1));
+            cur = __builtin_amdgcn_readlane(c4r, closest);
+            if (((mhi - bndHi) & ~cur) < 0) continue;  // not a sink, below the bound: next step
+        }
         if (__builtin_expect(mhi >= bndHi, 0)) {
+            const double delta = __longlong_as_double((long long)dbits);
             if (mhi >= KEY_INF_HI) { scannedOut = cand0 & ~cand; return 1; }  // minimum is +inf: infeasible (cpp:197, 327)
             if (EARLY && delta > bound) { scannedOut = cand0 & ~cand; return 2; }  // beyond the k best
             if (EARLY && useTight && delta > tight) {
+                const int slo = __double2loint(sp), shi = __double2hiint(sp);
                 const double sfr = __hiloint2double(__builtin_amdgcn_readlane(shi, sinkRow), __builtin_amdgcn_readlane(slo, sinkRow));
                 if (sfr > bound) { scannedOut = cand0 & ~cand; return 2; }  // the sink cannot come within the bound
                 useTight = false;
                 to_key(bound, bndHi, bndLo);
             }
         }
-        if (cc < 0) break;
+        if (cur < 0) break;
     }
     sinkOut = closest;
-    spc = __hiloint2double(shi, slo);
+    spc = sp;
     scannedOut = cand0 & ~cand;
-    deltaOut = delta;
+    deltaOut = __longlong_as_double((long long)dbits);
     return 0;
 }
 
