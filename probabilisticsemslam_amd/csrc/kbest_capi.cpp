@@ -72,7 +72,7 @@ Shape choose_shape(const kbest_ctx *ctx, int B, int maxRow, int k)
     if (ctx->nWaves > 0) s.nWaves = ctx->nWaves;
     if (ctx->spec > 0) s.spec = ctx->spec;
     if (s.spec > s.nWaves) s.spec = s.nWaves;
-    while (s.spec > 1 && kb::lds_layout(maxRow, k, s.spec).total > ctx->ldsLimit) s.spec /= 2;
+    while (s.spec > 1 && kb::lds_layout(maxRow, k, s.spec, s.nWaves).total > ctx->ldsLimit) s.spec /= 2;
     return s;
 }
 
@@ -259,7 +259,7 @@ int kbest_batch_f64_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRo
     const int spec = (opts->flags & KBEST_FLAG_COUNT_PUSHED) ? 1 : shape.spec;
     const int nWaves = shape.nWaves;
     const bool kFits = k + ctx->extraStates + ctx->eagerStates <= 65534 && k <= 4 * nWaves * 64 &&
-                       kb::lds_layout(fastRow, k, spec).total <= ctx->ldsLimit;
+                       kb::lds_layout(fastRow, k, spec, nWaves).total <= ctx->ldsLimit;
     const bool forceWide = getenv("KBEST_FORCE_WIDE") != nullptr;  // test hook: everything through the general-size kernel
     const bool runFast = !forceWide && kFits && (maxRow <= KBEST_MAX_DIM || d_nRow != nullptr);
     const bool runWide = forceWide || !kFits || maxRow > KBEST_MAX_DIM;

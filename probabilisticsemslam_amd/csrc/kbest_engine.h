@@ -83,10 +83,10 @@ __host__ __device__ inline long long slot_table_stride(int k) { return (((long l
 
 // LDS carve-up of one workgroup (= one cost matrix).
 struct Lds {
-    int offC, offNodes, nodeStride, offFreshG, offFreshM, offPoolG, offPoolM, offPoolS, offSurv, offFreshS, offCtrl, total;
+    int offC, offNodes, nodeStride, offFreshG, offFreshM, offPoolG, offPoolM, offPoolS, offSurv, offFreshS, offCtrl, offGainW, total;
 };
 
-__host__ __device__ inline Lds lds_layout(int maxRow, int k, int spec)
+__host__ __device__ inline Lds lds_layout(int maxRow, int k, int spec, int nWaves)
 {
     Lds L;
     const int ldc = maxRow | 1;
@@ -104,6 +104,8 @@ __host__ __device__ inline Lds lds_layout(int maxRow, int k, int spec)
     L.offFreshS = o;     o += spec * 64 * 2;         //   own state slot of the surviving children
     o = (o + 7) & ~7;
     L.offCtrl = o;       o += 144;                   // struct Ctrl
+    o = (o + 15) & ~15;
+    L.offGainW = o;      o += nWaves * 512;          // one line of gain terms per wave (calcGain)
     L.total = (o + 15) & ~15;
     return L;
 }

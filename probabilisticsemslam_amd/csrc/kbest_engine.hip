@@ -261,24 +261,30 @@ __device__ __forceinline__ void dual_update_flip(double *u, int lane, double &v,
     } while (c != start && ++guard < 64);
 }
 
-// calcGain (cpp:59-80): serial left-to-right fp64 sum over the M real columns, from 0.0.  Lanes >= M contribute
-// +0.0, and x + 0.0 == x exactly for the non-negative partial sums here, so the chain runs in whole blocks of 8
-// lanes: the 16 lane reads of a block are independent and issue back to back, only the 8 adds are a dependent
-// chain, in the reference's order.
-__device__ __forceinline__ double serial_gain(const double *Cs, int LDC, int lane, int r4c, int M)
+// calcGain (cpp:59-80): serial left-to-right fp64 sum over the M real columns, from 0.0.  Every lane fetches its
+// column's term and parks it in the wave's LDS scratch line; the chain of adds then reads the terms back as
+// broadcast 16-byte reads (two terms per LDS instruction, no lane reads on the vector unit), in the reference's
+// order.  Lanes >= M contribute +0.0, and x + 0.0 == x exactly for the non-negative partial sums here.
+__device__ __forceinline__ double serial_gain(const double *Cs, int LDC, int lane, int r4c, int M, double *scratch)
 {
     double t = 0.0;
     if (lane < M) t = Cs[r4c + lane * LDC];
-    const int tlo = __double2loint(t), thi = __double2hiint(t);
+    scratch[lane] = t;
+    wave_fence();
     double acc = 0.0;
+    const double2 *terms = reinterpret_cast<const double2 *>(scratch);
     for (int j0 = 0; j0 < M; j0 += 8) {
-        double term[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-            term[i] = __hiloint2double(__builtin_amdgcn_readlane(thi, j0 + i), __builtin_amdgcn_readlane(tlo, j0 + i));
-#pragma unroll
-        for (int i = 0; i < 8; i++) acc = acc + term[i];
+        const double2 a = terms[(j0 >> 1)], b = terms[(j0 >> 1) + 1], c = terms[(j0 >> 1) + 2], d = terms[(j0 >> 1) + 3];
+        acc = acc + a.x;
+        acc = acc + a.y;
+        acc = acc + b.x;
+        acc = acc + b.y;
+        acc = acc + c.x;
+        acc = acc + c.y;
+        acc = acc + d.x;
+        acc = acc + d.y;
     }
+    wave_fence();
     return acc;
 }
 
@@ -387,7 +393,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     // both bank-conflict free
     const int D = N, LDC = D | 1;
     const int spec = p.spec < NW ? p.spec : NW;  // nodes solved / split per round
-    const Lds L = lds_layout(p.maxRow, k, p.spec);
+    const Lds L = lds_layout(p.maxRow, k, p.spec, NW);
     double *Cs = reinterpret_cast<double *>(smem + L.offC);
     double *freshG = reinterpret_cast<double *>(smem + L.offFreshG);
     u32 *freshM = reinterpret_cast<u32 *>(smem + L.offFreshM);
@@ -405,6 +411,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     u64 *lbKey = reinterpret_cast<u64 *>(smem + L.offFreshG);
     unsigned short *freshS = reinterpret_cast<unsigned short *>(smem + L.offFreshS);
     Ctrl *ctrl = reinterpret_cast<Ctrl *>(smem + L.offCtrl);
+    double *gainW = reinterpret_cast<double *>(smem + L.offGainW) + wave * 64;  // this wave's line of gain terms
 
     const double *Cg = p.cost + (p.costOff ? p.costOff[b] : (long long)b * p.ldRow * p.ldCol);
     const bool maximize = p.maximize != 0, useCut = p.useCutoff != 0;
@@ -529,7 +536,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         if (bad) {
             if (lane == 0) ctrl->stop = 3;
         } else {
-            const double g = serial_gain(Cs, LDC, lane, r4c, M);
+            const double g = serial_gain(Cs, LDC, lane, r4c, M, gainW);
             const u64 forb = bit64(__builtin_amdgcn_readlane(r4c, 0));  // cpp:235
             save_node(nd, 0, v, r4c, c4r, forb, g, 0);
             if (lane == 0) {
@@ -738,7 +745,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                         r = nxt;
                     } while (cc != c && ++guard < 64);
                 }
-                const double g = serial_gain(Cs, LDC, lane, r4c, M);
+                const double g = serial_gain(Cs, LDC, lane, r4c, M, gainW);
                 if (useCut && (maximize ? (g < cutG) : (g > cutG))) continue;  // cutHyp, cpp:496/521
                 npush++;
                 int slot = -1;
@@ -950,7 +957,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 const int rc = dijkstra<false>(Cs, LDC, nd.u, rl, lane, v, c4r, cand, forbm, col, INF, spc, pred, scanned,
                                                delta, sink);
                 if (rc == 0) dual_update_flip(nd.u, lane, v, c4r, r4c, spc, pred, scanned, delta, sink, col);
-                const double g = serial_gain(Cs, LDC, lane, r4c, M);
+                const double g = serial_gain(Cs, LDC, lane, r4c, M, gainW);
                 const u64 forbN = forbm | bit64(__builtin_amdgcn_readlane(r4c, col));  // cpp:362
                 save_node(nd, mySid, v, r4c, c4r, forbN, g, col);
                 if (lane == 0 && rc != 0) ctrl->stop = 2;  // cannot happen: the candidate was solved before
@@ -1091,7 +1098,7 @@ __global__ void __launch_bounds__(64) weights_kernel(WeightParams p)
 template <int NW, int EPT>
 static hipError_t launch_nw_ept(const Params &p, int B, hipStream_t stream)
 {
-    const Lds L = lds_layout(p.maxRow, p.k, p.spec);
+    const Lds L = lds_layout(p.maxRow, p.k, p.spec, NW);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kbest_kernel<NW, EPT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
     if (e != hipSuccess) return e;

@@ -104,6 +104,15 @@ __device__ __forceinline__ int sel32(u64 mask, int ifset, int ifclear)
     return r;
 }
 
+__device__ __forceinline__ void wave_fence()
+{
+    // LDS traffic between the lanes of one wave: program order is enough in hardware, the fence only keeps the
+    // compiler from moving the accesses across it
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ u64 bit64(int i) { return 1ull << (i & 63); }
 
 }  // namespace kb

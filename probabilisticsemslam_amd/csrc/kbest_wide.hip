@@ -51,15 +51,6 @@ struct WideCtrl {
 };
 static_assert(sizeof(WideCtrl) <= 96, "WideCtrl must fit the LDS slot reserved by wide_lds_layout");
 
-__device__ __forceinline__ void wave_fence()
-{
-    // LDS traffic between the lanes of one wave: program order is enough in hardware, the fence only keeps the
-    // compiler from moving the accesses across it
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // Shortest augmenting path from column `start`; lane owns rows lane + 64*i.  Same contract as dijkstra<> of
 // kbest_engine.hip (cpp:168-226 / cpp:297-356) with per-lane bit sets: cand bit i = row lane+64i still in
 // Row2Scan, forb = rows skipped while the start column itself is scanned (cpp:310).
