@@ -604,28 +604,39 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 const int span = D - a;
                 const int jBeg = a + (span * part) / parts, jEnd = a + (span * (part + 1)) / parts;
                 int mlo = 0, mhi = KEY_INF_HI;  // running minimum (+inf)
-                for (int j0 = jBeg; j0 < jEnd; j0 += 4) {
+                // Column a itself contributes nothing: its row is in the forbidden set of the child on a, and no
+                // other child keeps it.  From a + 1 on the mask of the lanes 1 .. (j - a) - 1 grows by one bit per
+                // column (s_bitset1_b64), and lane 0 joins unless the row is forbidden for the active column.
+                const u64 nallow = ~nforb;
+                int j = jBeg > a ? jBeg : a + 1;
+                u64 low = (j - a >= 64) ? ~1ull : (((1ull << (j - a)) - 1ull) & ~1ull);
+                auto fetch = [&](int jj, double &cv, double &vr, u64 &mk) {
+                    const int r = __builtin_amdgcn_readlane(r4cP, jj);
+                    vr = readlane_f64(vrow, r);
+                    cv = Ccol[r];
+                    const u32 lo = (u32)low | ((u32)(nallow >> r) & 1u);
+                    mk = (low & 0xffffffff00000000ull) | lo;
+                    asm("s_bitset1_b64 %0, %1" : "+s"(low) : "s"(jj - a));
+                };
+                auto apply = [&](double cv, double vr, u64 mk) {
+                    const double rc = (cv - uc) - vr;  // ((0 + C) - u) - v, cpp:313 with delta = 0
+                    const u64 upd = __ballot(rc < __hiloint2double(mhi, mlo)) & mk;
+                    mlo = sel32(upd, __double2loint(rc), mlo);
+                    mhi = sel32(upd, __double2hiint(rc), mhi);
+                };
+                for (; j + 4 <= jEnd; j += 4) {  // four independent LDS reads in flight
                     double cv[4], vr[4];
                     u64 lm[4];
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {  // independent LDS reads in flight
-                        const int j = (j0 + i < jEnd) ? j0 + i : jEnd - 1;
-                        const int r = __builtin_amdgcn_readlane(r4cP, j);
-                        vr[i] = readlane_f64(vrow, r);
-                        cv[i] = Ccol[r];
-                        const int nlow = j - a;  // lanes 1 .. nlow-1 are the children c with a < c < j
-                        u64 mk = (nlow >= 64) ? ~0ull : ((1ull << nlow) - 1ull);
-                        mk &= ~1ull;
-                        if (!((nforb >> r) & 1ull)) mk |= 1ull;
-                        lm[i] = (j0 + i < jEnd) ? mk : 0ull;
-                    }
+                    for (int i = 0; i < 4; i++) fetch(j + i, cv[i], vr[i], lm[i]);
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const double rc = (cv[i] - uc) - vr[i];  // ((0 + C) - u) - v, cpp:313 with delta = 0
-                        const u64 upd = __ballot(rc < __hiloint2double(mhi, mlo)) & lm[i];
-                        mlo = sel32(upd, __double2loint(rc), mlo);
-                        mhi = sel32(upd, __double2hiint(rc), mhi);
-                    }
+                    for (int i = 0; i < 4; i++) apply(cv[i], vr[i], lm[i]);
+                }
+                for (; j < jEnd; j++) {
+                    double cv, vr;
+                    u64 mk;
+                    fetch(j, cv, vr, mk);
+                    apply(cv, vr, mk);
                 }
                 const double m = __hiloint2double(mhi, mlo);
                 // combine the row parts: integer min of the order-preserving key
