@@ -319,6 +319,9 @@ __device__ __forceinline__ double serial_gain(const double *Cs, int LDC, int lan
 // split speculatively; the pool always holds a partition of the not yet
 // emitted assignments, so the emitted sequence -- assignments in increasing
 // gain -- is unchanged (tie-free inputs).
+// ceil(65536 / d), d = 1..16: (x * RCP16[d]) >> 16 == x / d for 0 <= x < 4096
+__constant__ const int RCP16[17] = {0, 65536, 32768, 21846, 16384, 13108, 10923, 9363, 8192, 7282, 6554, 5958, 5462, 5042, 4682, 4370, 4096};
+
 struct Ctrl {
     double cdelta;      // CDelta * numCol (cpp:583)
     double cutoffGain;  // workMem.cutoffGain (cpp:681/684)
@@ -589,8 +592,11 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             // row r = row4col[j] is a candidate of child c iff c < j (rows of columns >= c, minus the row the child
             // frees itself, cpp:480-488 / 510-516); for the child on the active column (lane 0) it is a candidate
             // unless it is in the parent's accumulated forbidden set (cpp:490).
-            const int parts = NW / nsel;
-            const int nodeI = wave % nsel, part = wave / nsel;
+            // (nsel <= 8, NW <= 16: quotients by a 16-bit reciprocal, exact for these ranges -- an integer division
+            //  costs ~25 scalar instructions, and every wave does three of them per round)
+            const int rcpSel = RCP16[nsel];
+            const int parts = (NW * rcpSel) >> 16;
+            const int part = (wave * rcpSel) >> 16, nodeI = wave - part * nsel;
             if (part < parts) {
                 const NodeRef nd = node_ref(smem + L.offNodes + (size_t)nodeI * L.nodeStride, p.maxRow);
                 const int a = uni32(nd.info[0]);
@@ -602,7 +608,8 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 const double vrow = (lane < D) ? nd.v[lane] : 0.0;        // lane = row
                 const int r4cP = (lane < D) ? (int)nd.r4c[lane] : 0;      // lane = column
                 const int span = D - a;
-                const int jBeg = a + (span * part) / parts, jEnd = a + (span * (part + 1)) / parts;
+                const int rcpParts = RCP16[parts];
+                const int jBeg = a + ((span * part * rcpParts) >> 16), jEnd = a + ((span * (part + 1) * rcpParts) >> 16);
                 int mlo = 0, mhi = KEY_INF_HI;  // running minimum (+inf)
                 // Column a itself contributes nothing: its row is in the forbidden set of the child on a, and no
                 // other child keeps it.  From a + 1 on the mask of the lanes 1 .. (j - a) - 1 grows by one bit per
@@ -860,19 +867,23 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         int sIdx[8], sSid[8];
 #pragma unroll
         for (int w = 0; w < 8; w++) { sIdx[w] = -1; sSid[w] = 0; }
-        for (int base = 0; base < nq && nselNew < budget; base += 64) {
+        // wave 0 walks the whole selection (it writes the control block); wave w only as far as its own, the w-th
+        const int walk = (wave == 0 || budget <= wave) ? budget : wave + 1;
+        for (int base = 0; base < nq && nselNew < walk; base += 64) {
             const int i = base + lane;
             const bool open = i < nq && !(PM[i] & META_SPLIT);
             const unsigned short ps = (i < nq) ? PS[i] : SID_NONE;
             u64 m = __ballot(open);
             const u64 lazyM = __ballot(open && ps == SID_NONE);
-            while (m && nselNew < budget) {
+            while (m && nselNew < walk) {
                 const int bitpos = __builtin_ctzll(m);
                 const bool lazy = (lazyM >> bitpos) & 1ull;
                 const int sidv = lazy ? sidBase + nLazy : __builtin_amdgcn_readlane((int)ps, bitpos);
                 if (nselNew == wave) { mySel = base + bitpos; mySid = sidv; }
+                if (wave == 0) {
 #pragma unroll
-                for (int w = 0; w < 8; w++) if (w == nselNew) { sIdx[w] = base + bitpos; sSid[w] = sidv; }
+                    for (int w = 0; w < 8; w++) if (w == nselNew) { sIdx[w] = base + bitpos; sSid[w] = sidv; }
+                }
                 nLazy += lazy ? 1 : 0;
                 nselNew++;
                 m &= m - 1;
