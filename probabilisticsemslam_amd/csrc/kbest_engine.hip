@@ -574,6 +574,12 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         const int nOld = nqEnd - head;
         const int sidBase = uni32(ctrl->nextSid);
         const double cutG = ctrl->cutoffGain;
+        // the candidates selected in the last A phase are split in this round: flag them in the pool now (nobody
+        // reads the pool's meta words before the merge, which is behind the barrier after B)
+        if (wave == 0 && lane < nsel) {
+            const int idx = ctrl->selIdx[lane];
+            if (idx >= 0) { PM[idx] |= META_SPLIT; PS[idx] = (unsigned short)ctrl->selSid[lane]; }
+        }
         // -- B1: first-step filter.  56 % of all children (64x64, k=200) are abandoned by the early-termination
         //    test at their very first Dijkstra step, i.e. because  min over candidate rows of (C[r,c] - u[c] - v[r])
         //    already exceeds the bound.  That minimum is computed here for ALL children of a node at once, one wave
@@ -816,12 +822,8 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 int pos = i;
                 for (int j = 0; j < nFresh; j++) pos += (freshG[j] < g) ? 1 : 0;
                 og[e] = g;
-                u32 mv = PM[head + i];
-                unsigned short sv = PS[head + i];
-                for (int w = 0; w < nsel; w++)  // the nodes selected in the last A phase were all split in B
-                    if (ctrl->selIdx[w] == head + i) { mv |= META_SPLIT; sv = (unsigned short)ctrl->selSid[w]; }
-                om[e] = mv;
-                os[e] = sv;
+                om[e] = PM[head + i];
+                os[e] = PS[head + i];
                 opos[e] = pos;
             }
         }
@@ -840,7 +842,8 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             int pos = lo;
             for (int j2 = 0; j2 < nFresh; j2++) {
                 const double g2 = freshG[j2];
-                pos += (g2 < g || (g2 == g && freshM[j2] < mj)) ? 1 : 0;
+                pos += (g2 < g) ? 1 : 0;
+                if (__builtin_expect(g2 == g, 0)) pos += (freshM[j2] < mj) ? 1 : 0;  // (itself included: not less)
             }
             fg = g; fm = mj; fs = freshS[tid]; fpos = pos;
         }
