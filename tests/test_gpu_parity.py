@@ -503,3 +503,16 @@ def test_brute_force_probs(eng):
     probs, nf = eng.weights(conds, nLs, [3] * len(conds), k, brute_force=True)
     for p, w in zip(probs, want):
         np.testing.assert_allclose(p, w, rtol=1e-12, atol=1e-15)
+
+
+@pytest.mark.parametrize("nw,spec", [(4, 4), (8, 6), (12, 8), (16, 8), (8, 1)])
+def test_every_launch_shape(monkeypatch, nw, spec):
+    """small batches now pick the latency shape (16 waves); every workgroup size / speculation depth the library can
+    choose is pinned here against the oracle, whatever the batch size."""
+    monkeypatch.setenv("KBEST_NWAVES", str(nw))
+    monkeypatch.setenv("KBEST_SPEC", str(spec))
+    e = pk.KBestEngine(0)
+    rng = np.random.default_rng(100 + nw)
+    for N, M, k, B in ((64, 64, 200, 6), (40, 17, 120, 5), (12, 12, 60, 9)):
+        costs = rng.random((B, N * M)) * 25
+        _same_as_oracle(e, costs, N, M, k, tag=(nw, spec, N, M))
