@@ -132,28 +132,51 @@ def main():
     nf_ref = d_nf.cpu().numpy().copy()
     g_ref = d_gain.cpu().numpy().copy()
 
-    def step():
-        eng.kbest_dev(d_cost, B, N, M, k, d_r4c, d_c4r, d_gain, d_nf, stream=stream)
-        if use_dist:  # global table of per-rank top-k gains (RCCL over xGMI)
-            dist.all_gather_into_tensor(d_allgain, d_gain)
+    # Multi-GPU: the per-rank top-k gains of step i are all-gathered (RCCL over xGMI) WHILE the kernel of step i+1
+    # runs: two gain tables alternate, and a table is only written again once the gather that read it has finished
+    # (stream-level wait on its work handle).  Every gather completes inside the timed region.
+    d_gain2 = torch.empty_like(d_gain) if use_dist else None
+    d_allgain2 = torch.empty_like(d_allgain) if use_dist else None
+    gains = (d_gain, d_gain2)
+    allgains = (d_allgain, d_allgain2)
+    pending = [None, None]
 
-    for _ in range(args.warmup):
-        step()
+    def step(i, ev=None):
+        b = i & 1 if use_dist else 0
+        if pending[b] is not None:
+            pending[b].wait()  # the gather of step i-2 has read gains[b]
+            pending[b] = None
+        if ev is not None:
+            ev[0].record()
+        eng.kbest_dev(d_cost, B, N, M, k, d_r4c, d_c4r, gains[b], d_nf, stream=stream)
+        if ev is not None:
+            ev[1].record()
+        if use_dist:
+            pending[b] = dist.all_gather_into_tensor(allgains[b], gains[b], async_op=True)
+
+    def drain():
+        for b in (0, 1):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
+
+    for i in range(args.warmup):
+        step(i)
+    drain()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ev[i][0].record()
-        eng.kbest_dev(d_cost, B, N, M, k, d_r4c, d_c4r, d_gain, d_nf, stream=stream)
-        ev[i][1].record()
-        if use_dist:
-            dist.all_gather_into_tensor(d_allgain, d_gain)
+        step(i, ev[i])
+    drain()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if use_dist and ((args.steps - 1) & 1) == 1:
+        d_gain, d_allgain = d_gain2, d_allgain2  # the last step wrote (and gathered) the second pair of tables
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
     nf = d_nf.cpu().numpy()
@@ -211,11 +234,21 @@ def main():
                 cb["pushed_matches_gpu"] = bool((p_cpu[:ns] == pushed[:ns]).all())
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_1core"] = out["value"] / cb["value"]
-        print(json.dumps(out))
+        line = json.dumps(out)
     if use_dist:
         if world > 1:  # every rank must hold the same global table
             assert torch.equal(d_allgain[rank * B:(rank + 1) * B], d_gain)
         dist.destroy_process_group()
+    # RCCL prints a banner through C stdio, which is flushed at exit, i.e. AFTER anything Python has printed: push
+    # it out first so that the JSON line is the last line of stdout
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if rank == 0:
+        sys.stdout.flush()
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
