@@ -820,7 +820,15 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             if (i < nOld) {
                 const double g = PG[head + i];
                 int pos = i;
-                for (int j = 0; j < nFresh; j++) pos += (freshG[j] < g) ? 1 : 0;
+                {   // four fresh gains per pair of 16-byte broadcast reads: the loop is latency, not arithmetic
+                    const double2 *f2 = reinterpret_cast<const double2 *>(freshG);
+                    int j = 0;
+                    for (; j + 4 <= nFresh; j += 4) {
+                        const double2 a = f2[j >> 1], b = f2[(j >> 1) + 1];
+                        pos += ((a.x < g) ? 1 : 0) + ((a.y < g) ? 1 : 0) + ((b.x < g) ? 1 : 0) + ((b.y < g) ? 1 : 0);
+                    }
+                    for (; j < nFresh; j++) pos += (freshG[j] < g) ? 1 : 0;
+                }
                 og[e] = g;
                 om[e] = PM[head + i];
                 os[e] = PS[head + i];
@@ -840,10 +848,21 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 if (PG[head + mid] <= g) lo = mid + 1; else hi = mid;
             }
             int pos = lo;
-            for (int j2 = 0; j2 < nFresh; j2++) {
-                const double g2 = freshG[j2];
-                pos += (g2 < g) ? 1 : 0;
-                if (__builtin_expect(g2 == g, 0)) pos += (freshM[j2] < mj) ? 1 : 0;  // (itself included: not less)
+            {
+                const double2 *f2 = reinterpret_cast<const double2 *>(freshG);
+                int nEq = 0, j2 = 0;
+                for (; j2 + 4 <= nFresh; j2 += 4) {
+                    const double2 a = f2[j2 >> 1], b = f2[(j2 >> 1) + 1];
+                    pos += ((a.x < g) ? 1 : 0) + ((a.y < g) ? 1 : 0) + ((b.x < g) ? 1 : 0) + ((b.y < g) ? 1 : 0);
+                    nEq += ((a.x == g) ? 1 : 0) + ((a.y == g) ? 1 : 0) + ((b.x == g) ? 1 : 0) + ((b.y == g) ? 1 : 0);
+                }
+                for (; j2 < nFresh; j2++) {
+                    const double g2 = freshG[j2];
+                    pos += (g2 < g) ? 1 : 0;
+                    nEq += (g2 == g) ? 1 : 0;
+                }
+                if (__builtin_expect(nEq > 1, 0))  // another fresh candidate with the same gain: order by (parent, column)
+                    for (int j3 = 0; j3 < nFresh; j3++) pos += (freshG[j3] == g && freshM[j3] < mj) ? 1 : 0;
             }
             fg = g; fm = mj; fs = freshS[tid]; fpos = pos;
         }
