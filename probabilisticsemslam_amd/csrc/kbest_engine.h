@@ -92,18 +92,18 @@ __host__ __device__ inline Lds lds_layout(int maxRow, int k, int spec, int nWave
     const int ldc = maxRow | 1;
     int o = 0;
     L.offC = o;          o += maxRow * ldc * 8;      // shifted, zero-padded cost tile
-    L.nodeStride = (18 * maxRow + 32 + 7) & ~7;      // u, v (fp64), scalars, row4col, col4row (u8)
+    L.nodeStride = (18 * maxRow + 24 + 7) & ~7;      // u, v (fp64), scalars, row4col, col4row (u8)
     L.offNodes = o;      o += spec * L.nodeStride;   // solved hypotheses waiting to be split
     L.offFreshG = o;     o += (spec * 64 > 16 ? spec * 64 : 16) * 8;  // surviving children of this round: gain
                                                      //   (also: the first-step minima during the filter phase)
     L.offPoolG = o;      o += k * 8;                 // sorted candidate pool: gain
-    L.offFreshM = o;     o += spec * 64 * 4;         //   (parent state, column)
+    L.offFreshM = o;     o += spec * 64 * 4;         //   (parent state, column); during the filter: last-arc minima
     L.offPoolM = o;      o += k * 4;                 //   (parent state, column, flags)
     L.offPoolS = o;      o += k * 2;                 //   own state slot
-    L.offSurv = o;       o += spec * 64 * 2;         // children that passed the first-step filter (node, column)
+    L.offSurv = o;       o += spec * 64 * 2;         // children that passed the filter: (last-arc bound / 7 bits, node, column)
     L.offFreshS = o;     o += spec * 64 * 2;         //   own state slot of the surviving children
     o = (o + 7) & ~7;
-    L.offCtrl = o;       o += 144;                   // struct Ctrl
+    L.offCtrl = o;       o += 112;                   // struct Ctrl
     o = (o + 15) & ~15;
     L.offGainW = o;      o += nWaves * 512;          // one line of gain terms per wave (calcGain)
     L.total = (o + 15) & ~15;

@@ -42,6 +42,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "kbest_engine.h"
 #include "kbest_wave.h"
@@ -339,10 +340,10 @@ struct Ctrl {
     int nFresh;    // surviving children appended this round
     int nSurv;     // children that passed the first-step filter this round (queued from the front)
     int nSurvBack; //   ... and those queued from the back
-    int selIdx[8]; // pool index of each node selected in the last A phase (they are split in the next B)
-    int selSid[8]; // and its state slot
+    short selIdx[8];          // pool index of each node selected in the last A phase (they are split in the next B)
+    unsigned short selSid[8]; // and its state slot
 };
-static_assert(sizeof(Ctrl) <= 144, "Ctrl must fit the LDS slot reserved by lds_layout");
+static_assert(sizeof(Ctrl) <= 112, "Ctrl must fit the LDS slot reserved by lds_layout");
 
 // pool entry: gain (fp64), meta (u32: column | parent state << 8 | flags), own state slot (u16)
 constexpr unsigned short SID_NONE = 0xFFFFu;  // no saved state: re-solve from the parent when selected
@@ -366,7 +367,7 @@ __device__ __forceinline__ NodeRef node_ref(unsigned char *base, int maxRow)
     n.gain = n.v + maxRow;
     n.forb = reinterpret_cast<u64 *>(n.gain + 1);
     n.info = reinterpret_cast<int *>(n.forb + 1);
-    n.r4c = reinterpret_cast<unsigned char *>(n.info + 4);
+    n.r4c = reinterpret_cast<unsigned char *>(n.info + 2);
     n.c4r = n.r4c + maxRow;
     return n;
 }
@@ -409,6 +410,9 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     unsigned short *slotSid = p.slotSid + (long long)blockIdx.x * slot_table_stride(k);
     double *red = freshG;  // cross-wave reduction scratch of phase 0
     unsigned short *surv = reinterpret_cast<unsigned short *>(smem + L.offSurv);
+    // last-arc minima of the current nodes' children (high words).  Shares its LDS with the fresh list's meta words,
+    // which are only written in B2 and consumed in the first half of the merge.
+    u32 *lbIn = reinterpret_cast<u32 *>(smem + L.offFreshM);
     // first-step minima of the current nodes' children.  Shares its LDS with the fresh-gain list: the minima live
     // from the filter to the survivor compaction (B1), the fresh gains from B2 to the first half of the merge.
     u64 *lbKey = reinterpret_cast<u64 *>(smem + L.offFreshG);
@@ -481,7 +485,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             ctrl->selSid[0] = 0;
         }
         __syncthreads();
-        for (int i = tid; i < spec * 64; i += NT) lbKey[i] = ~0ull;  // (`red` is dead now)
+        for (int i = tid; i < spec * 64; i += NT) { lbKey[i] = ~0ull; lbIn[i] = ~0u; }  // (`red` is dead now)
     }
 
     unsigned char *stBase = p.states + (long long)b * maxSid * p.stateStride;
@@ -578,7 +582,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         // reads the pool's meta words before the merge, which is behind the barrier after B)
         if (wave == 0 && lane < nsel) {
             const int idx = ctrl->selIdx[lane];
-            if (idx >= 0) { PM[idx] |= META_SPLIT; PS[idx] = (unsigned short)ctrl->selSid[lane]; }
+            if (idx >= 0) { PM[idx] |= META_SPLIT; PS[idx] = ctrl->selSid[lane]; }
         }
         // -- B1: first-step filter.  56 % of all children (64x64, k=200) are abandoned by the early-termination
         //    test at their very first Dijkstra step, i.e. because  min over candidate rows of (C[r,c] - u[c] - v[r])
@@ -658,6 +662,28 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 to_key(m, khi, klo);
                 const u64 key = ((u64)((u32)khi ^ 0x80000000u) << 32) | klo;  // signed high word -> unsigned order
                 if (c < M) atomicMin(&lbKey[nodeI * 64 + lane], key);
+                // Second pass, the other end of the path: the only unassigned row of child c is the row it frees,
+                // fr = row4col[c], so its path ENDS with an arc (fr, j), j a later column.  minIn[c] = min over j > c
+                // of (C[fr,j] - u[j]) - v[fr] (high word, clamped at 0: a lower bound) -- first arc and last arc are
+                // different arcs of the same path and all reduced costs are >= 0, so first + last > bound kills the
+                // child here, and what survives starts its search against bound - minIn.
+                if (prune && T < INF) {
+                    const int fr = (int)nd.r4c[cc];
+                    const double vfr = nd.v[fr];
+                    const double *Crow = Cs + fr;
+                    int inHi = KEY_INF_HI;
+                    int j2 = jBeg > a ? jBeg : a + 1;
+                    u64 mk = (j2 - a >= 64) ? ~0ull : ((1ull << (j2 - a)) - 1ull);  // lanes 0 .. (j - a) - 1: children before column j
+                    for (; j2 < jEnd; j2++) {
+                        const double rin = (Crow[j2 * LDC] - nd.u[j2]) - vfr;
+                        int h = __double2hiint(rin);
+                        h = h < 0 ? 0 : h;  // -1e-17 from rounding: no information
+                        h = sel32(mk, h, KEY_INF_HI);
+                        inHi = h < inHi ? h : inHi;
+                        asm("s_bitset1_b64 %0, %1" : "+s"(mk) : "s"(j2 - a));
+                    }
+                    if (c < M) atomicMin(&lbIn[nodeI * 64 + lane], (u32)inHi);
+                }
             }
         }
         KB_T(tF1);
@@ -673,7 +699,9 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             const bool live = c < M && !(sid == 0 && p.rootColStride > 1 && (c % p.rootColStride) != p.rootColOffset);
             const u64 key = lbKey[wave * 64 + lane];
             const double m = from_key((int)((u32)(key >> 32) ^ 0x80000000u), (u32)key);
-            const bool keep = live && m < INF && !(m > bound);
+            const u32 inH = lbIn[wave * 64 + lane];
+            const double minIn = (prune && T < INF) ? __hiloint2double((int)inH, 0) : 0.0;  // +inf: no last arc at all
+            const bool keep = live && m < INF && !(m + minIn > bound);
             // Children whose first step is far inside the bound tend to run long (they are the ones that complete):
             // they are queued from the front, the others from the back, so that the long ones start first and the
             // round does not end waiting for one late straggler.
@@ -685,8 +713,16 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             baseH = uni32(baseH);
             baseL = uni32(baseL);
             const u64 below = (1ull << lane) - 1ull;
-            if (heavy) surv[baseH + __popcll(kh & below)] = (unsigned short)((wave << 8) | c);
-            else if (keep) surv[spec * 64 - 1 - (baseL + __popcll(kl & below))] = (unsigned short)((wave << 8) | c);
+            // survivor entry (16 bits): column (6), node (3) and the last-arc bound as a fraction of the node's bound in
+            // 127ths, rounded down (7): what survived has minIn <= bound
+            int q = 0;
+            if (keep && bound < INF && bound > 0.0) {
+                const double f = (minIn / bound) * 127.0;
+                q = f >= 127.0 ? 127 : (int)f;
+            }
+            const unsigned short entry = (unsigned short)((q << 9) | (wave << 6) | c);
+            if (heavy) surv[baseH + __popcll(kh & below)] = entry;
+            else if (keep) surv[spec * 64 - 1 - (baseL + __popcll(kl & below))] = entry;
         }
         __syncthreads();
         // -- B2: surviving children (shortestPathUpdateCPP, gain only), dynamic queue over the survivor list.  The
@@ -710,7 +746,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 if (lane == 0) ticket = atomicAdd(&ctrl->nextItem, 1);  // prefetch the next ticket
                 KB_ACC(4, 1);  // [4] children started
                 const int sv = uni32((int)surv[item < nFront ? item : spec * 64 - 1 - (item - nFront)]);
-                const int w = sv >> 8, c = sv & 255;
+                const int w = (sv >> 6) & 7, c = sv & 63;
                 if (w != curW) {  // (re)load this node's data
                     curW = w;
                     nd = node_ref(smem + L.offNodes + (size_t)w * L.nodeStride, p.maxRow);
@@ -732,18 +768,8 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 double spc, delta;
                 int pred, sink = 0;
                 u64 scanned;
-                // backward bound: the path ends with an arc (row fr, column j), j a later column; the smallest
-                // reduced cost of those arcs (high word only: rounded down) bounds the child's distance from below
-                double minIn = 0.0;
-                if (bound < INF) {
-                    const int jj = lane < D ? lane : D - 1;
-                    const double rin = (Cs[fr + jj * LDC] - nd.u[jj]) - readlane_f64(v, fr);
-                    int h = __double2hiint(rin);
-                    h = h < 0 ? 0 : h;  // -1e-17 from rounding: no information
-                    const int mk = wave_min_i32((lane > c && lane < D) ? h : KEY_INF_HI);
-                    minIn = __hiloint2double(mk, 0);
-                    if (minIn > bound) { KB_ACC(9, __builtin_readcyclecounter() - tItem); continue; }  // dead before its first step
-                }
+                // backward bound from the filter (in 127ths of the bound, rounded down): the loop runs against bound - minIn
+                const double minIn = (bound < INF) ? (double)(sv >> 9) * (bound * (1.0 / 127.0)) : 0.0;
                 KB_T(tDij0);
                 KB_ACC(9, tDij0 - tItem);  // [9] per-child set-up cycles
                 const int st = dijkstra<true>(Cs, LDC, nd.u, rl, lane, v, c4r, cand, forbm, c, bound, spc, pred,
@@ -867,7 +893,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             fg = g; fm = mj; fs = freshS[tid]; fpos = pos;
         }
         __syncthreads();
-        for (int i = tid; i < spec * 64; i += NT) lbKey[i] = ~0ull;  // the fresh gains are consumed: re-arm the minima
+        for (int i = tid; i < spec * 64; i += NT) { lbKey[i] = ~0ull; lbIn[i] = ~0u; }  // the fresh lists are consumed: re-arm the minima
 #pragma unroll
         for (int e = 0; e < EPT; e++)
             if (opos[e] >= 0 && opos[e] < R) { PG[opos[e]] = og[e]; PM[opos[e]] = om[e]; PS[opos[e]] = os[e]; }
@@ -952,7 +978,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             ctrl->nq = nq;
             ctrl->head = h;
 #pragma unroll
-            for (int w = 0; w < 8; w++) { ctrl->selIdx[w] = sIdx[w]; ctrl->selSid[w] = sSid[w]; }
+            for (int w = 0; w < 8; w++) { ctrl->selIdx[w] = (short)sIdx[w]; ctrl->selSid[w] = (unsigned short)sSid[w]; }
             if (stop) ctrl->stop = 1;
         }
         if (wave < nselNew) {
@@ -1143,10 +1169,11 @@ template <int NW, int EPT>
 static hipError_t launch_nw_ept(const Params &p, int B, hipStream_t stream)
 {
     const Lds L = lds_layout(p.maxRow, p.k, p.spec, NW);
+    static const int pad = getenv("KBEST_LDS_PAD") ? atoi(getenv("KBEST_LDS_PAD")) : 0;  // residency experiments only
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kbest_kernel<NW, EPT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, L.total + pad);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((kbest_kernel<NW, EPT>), dim3(B), dim3(NW * 64), L.total, stream, p);
+    hipLaunchKernelGGL((kbest_kernel<NW, EPT>), dim3(B), dim3(NW * 64), L.total + pad, stream, p);
     return hipGetLastError();
 }
 
