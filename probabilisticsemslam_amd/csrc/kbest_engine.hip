@@ -674,14 +674,22 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                     int inHi = KEY_INF_HI;
                     int j2 = jBeg > a ? jBeg : a + 1;
                     u64 mk = (j2 - a >= 64) ? ~0ull : ((1ull << (j2 - a)) - 1ull);  // lanes 0 .. (j - a) - 1: children before column j
-                    for (; j2 < jEnd; j2++) {
-                        const double rin = (Crow[j2 * LDC] - nd.u[j2]) - vfr;
+                    auto last_arc = [&](int jj, double cin, double uj) {
+                        const double rin = (cin - uj) - vfr;
                         int h = __double2hiint(rin);
                         h = h < 0 ? 0 : h;  // -1e-17 from rounding: no information
                         h = sel32(mk, h, KEY_INF_HI);
                         inHi = h < inHi ? h : inHi;
-                        asm("s_bitset1_b64 %0, %1" : "+s"(mk) : "s"(j2 - a));
+                        asm("s_bitset1_b64 %0, %1" : "+s"(mk) : "s"(jj - a));
+                    };
+                    for (; j2 + 4 <= jEnd; j2 += 4) {  // four independent pairs of LDS reads in flight
+                        double cin[4], uj[4];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) { cin[i] = Crow[(j2 + i) * LDC]; uj[i] = nd.u[j2 + i]; }
+#pragma unroll
+                        for (int i = 0; i < 4; i++) last_arc(j2 + i, cin[i], uj[i]);
                     }
+                    for (; j2 < jEnd; j2++) last_arc(j2, Crow[j2 * LDC], nd.u[j2]);
                     if (c < M) atomicMin(&lbIn[nodeI * 64 + lane], (u32)inHi);
                 }
             }
