@@ -143,6 +143,7 @@ struct WideParams {
     int maxRow, maxCol;       // capacity of this launch (work space, LDS, rows per lane)
     int ldRow, ldCol;         // leading dimensions of the outputs / of the default cost packing
     int minRows;              // problems with fewer rows are left to the LDS kernel (mixed batches); 0 = take all
+    int tile;                 // 1: the square cost copy lives in LDS (it fits), Cw is not used
     int k;
     int maximize, useCutoff;
     unsigned flags;
@@ -170,9 +171,10 @@ struct WideParams {
 // forbidden rows (u32 per lane), gain, activeCol; whole 128-byte lines
 __host__ __device__ inline long long wide_state_stride(int maxRow) { return (24LL * maxRow + 256 + 16 + 127) & ~127LL; }
 
-struct WideLds { int offWave, waveStride, offChildG, offChildS, offChildC, offRed, offCtrl, total; };
+struct WideLds { int offWave, waveStride, offChildG, offChildS, offChildC, offRed, offCtrl, offTile, total; };
 
-__host__ __device__ inline WideLds wide_lds_layout(int maxRow, int maxCol)
+// tile: keep the shifted square cost copy in LDS instead of the HBM work space (when maxRow^2 * 8 bytes fit)
+__host__ __device__ inline WideLds wide_lds_layout(int maxRow, int maxCol, bool tile)
 {
     WideLds L;
     int o = 0;
@@ -184,6 +186,8 @@ __host__ __device__ inline WideLds wide_lds_layout(int maxRow, int maxCol)
     o = (o + 7) & ~7;
     L.offRed = o;        o += WIDE_NW * 8;
     L.offCtrl = o;       o += 96;                   // struct WideCtrl
+    o = (o + 15) & ~15;
+    L.offTile = o;       if (tile) o += maxRow * maxRow * 8;
     L.total = (o + 15) & ~15;
     return L;
 }

@@ -81,10 +81,25 @@ __device__ __forceinline__ int wide_dijkstra(const double *Cw, int D, const doub
                 if (spc[i] < best) { best = spc[i]; brow = lane + 64 * i; }       // lowest row first: cpp:191, 320
             }
         }
-        const double m = wave_min_f64(best);
+        // wave arg-min.  Reduced costs are non-negative up to rounding, and for non-negative doubles the high word is
+        // an order-preserving key: one integer DPP chain finds it, and when a single lane holds it (four steps in
+        // five) that lane's row is the answer.  Otherwise -- a negative candidate, or several lanes on the same high
+        // word (mostly exact zeros on tight arcs) -- the full fp64 minimum and the lowest row among its holders.
+        const int bhi = __double2hiint(best);
+        const int mhi = wave_min_i32(bhi);
+        const u64 eq = __ballot(bhi == mhi);
+        double m;
+        int closest;
+        if (mhi >= 0 && (eq & (eq - 1)) == 0) {
+            const int ln = __builtin_ctzll(eq);
+            m = __hiloint2double(mhi, __builtin_amdgcn_readlane(__double2loint(best), ln));
+            closest = __builtin_amdgcn_readlane(brow, ln);
+        } else {
+            m = wave_min_f64(best);
+            closest = wave_min_i32(best == m ? brow : 0x7fffffff);
+        }
         if (!(m < INF)) { scannedOut = scanned; return 1; }
         if (EARLY && m > bound) { scannedOut = scanned; return 2; }
-        const int closest = wave_min_i32(best == m ? brow : 0x7fffffff);
         delta = m;
         if (lane == (closest & 63)) { cand &= ~(1u << (closest >> 6)); scanned |= 1u << (closest >> 6); }
         act = cand;
@@ -157,7 +172,7 @@ __device__ __forceinline__ double wide_gain(const double *Cw, int D, int M, cons
 
 }  // namespace
 
-template <int R>
+template <int R, bool TILE>
 __global__ void __launch_bounds__(WIDE_NW * 64) kbest_wide_kernel(WideParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -167,7 +182,7 @@ __global__ void __launch_bounds__(WIDE_NW * 64) kbest_wide_kernel(WideParams p)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int DS = p.maxRow;
-    const WideLds L = wide_lds_layout(DS, p.maxCol);
+    const WideLds L = wide_lds_layout(DS, p.maxCol, TILE);
     double *uW = reinterpret_cast<double *>(smem + L.offWave + (size_t)wave * L.waveStride);
     int *c4rW = reinterpret_cast<int *>(uW + DS);
     int *r4cW = c4rW + DS;
@@ -180,7 +195,9 @@ __global__ void __launch_bounds__(WIDE_NW * 64) kbest_wide_kernel(WideParams p)
 
     // work space of this workgroup (whole 128-byte lines, never shared with another workgroup)
     const long long ws = blockIdx.x;
-    double *Cw = p.Cw + ws * p.cwStride;
+    double *Cw;  // shifted, zero-padded square cost copy: LDS when it fits (TILE), else this workgroup's HBM slot
+    if constexpr (TILE) Cw = reinterpret_cast<double *>(smem + L.offTile);
+    else Cw = p.Cw + ws * p.cwStride;
     unsigned char *stBase = p.states + ws * (long long)p.statesPerProblem * p.stateStride;
     double *poolG = p.poolG + ws * 2 * p.poolStride;
     int *poolS = p.poolS + ws * 2 * p.poolStride;
@@ -475,23 +492,29 @@ __global__ void __launch_bounds__(WIDE_NW * 64) kbest_wide_kernel(WideParams p)
     }
 }
 
+template <int R, bool TILE>
+static hipError_t launch_wide_rt(const WideParams &p, int grid, hipStream_t stream)
+{
+    const WideLds L = wide_lds_layout(p.maxRow, p.maxCol, TILE);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kbest_wide_kernel<R, TILE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((kbest_wide_kernel<R, TILE>), dim3(grid), dim3(WIDE_NW * 64), L.total, stream, p);
+    return hipGetLastError();
+}
+
 template <int R>
 static hipError_t launch_wide_r(const WideParams &p, int grid, hipStream_t stream)
 {
-    const WideLds L = wide_lds_layout(p.maxRow, p.maxCol);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kbest_wide_kernel<R>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((kbest_wide_kernel<R>), dim3(grid), dim3(WIDE_NW * 64), L.total, stream, p);
-    return hipGetLastError();
+    return p.tile ? launch_wide_rt<R, true>(p, grid, stream) : launch_wide_rt<R, false>(p, grid, stream);
 }
 
 hipError_t launch_kbest_wide(const WideParams &p, int grid, hipStream_t stream)
 {
     if (p.maxRow <= 64) return launch_wide_r<1>(p, grid, stream);
     if (p.maxRow <= 128) return launch_wide_r<2>(p, grid, stream);
-    if (p.maxRow <= 256) return launch_wide_r<4>(p, grid, stream);
-    return launch_wide_r<8>(p, grid, stream);
+    if (p.maxRow <= 256) return launch_wide_rt<4, false>(p, grid, stream);  // 256^2 doubles never fit
+    return launch_wide_rt<8, false>(p, grid, stream);
 }
 
 }  // namespace kb
