@@ -132,6 +132,19 @@ struct Sub {  // a slice of a DevBuf
     template <class T> T *as() { return static_cast<T *>(p); }
 };
 
+// State slots per matrix for children that are kept in full when they are found: the context's setting (1024), cut
+// down for very large batches so that the whole state work space stays within 16 GiB.  With fewer slots more
+// candidates stay lazy (re-solved when selected): slower, same results.
+int eager_states(const kbest_ctx *ctx, int B, int maxRow, int k)
+{
+    const size_t stride = (size_t)kb::state_stride(maxRow), budget = (size_t)16 << 30;
+    const size_t perMatrix = budget / ((size_t)(B > 0 ? B : 1) * stride);
+    long long e = (long long)perMatrix - k - ctx->extraStates;
+    if (e > ctx->eagerStates) e = ctx->eagerStates;
+    if (e < 64) e = ctx->eagerStates < 64 ? ctx->eagerStates : 64;
+    return (int)e;
+}
+
 }  // namespace
 
 extern "C" {
@@ -229,7 +242,7 @@ int kbest_set_profile_buffer(kbest_ctx *ctx, void *d_buf)
 int kbest_reserve(kbest_ctx *ctx, int B, int maxRow, int k)
 {
     if (!ctx || B < 0 || maxRow < 1 || k < 1) return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_reserve: bad argument");
-    const size_t nStates = (size_t)B * (size_t)(k + ctx->extraStates + ctx->eagerStates) * (size_t)kb::state_stride(maxRow);
+    const size_t nStates = (size_t)B * (size_t)(k + ctx->extraStates + eager_states(ctx, B, maxRow, k)) * (size_t)kb::state_stride(maxRow);
     const size_t need = nStates + (size_t)B * (size_t)kb::slot_table_stride(k) * 2 + 256;
     if (need <= ctx->statesBytes) { ctx->slotSidOffset = (nStates + 127) & ~(size_t)127; return KBEST_OK; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -339,7 +352,7 @@ int kbest_batch_f64_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRo
         p.pushed = reinterpret_cast<long long *>(d_pushed);
         p.states = ctx->states;
         p.stateStride = kb::state_stride(fastRow);
-        p.statesPerProblem = k + ctx->extraStates + ctx->eagerStates;
+        p.statesPerProblem = k + ctx->extraStates + eager_states(ctx, B, fastRow, k);
         p.lazyStates = k + ctx->extraStates;
         p.spec = spec;
         p.prof = ctx->prof;
