@@ -55,11 +55,9 @@ int fail(kbest_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess)
         if (e_ != hipSuccess) return fail(ctx, KBEST_ERR_HIP, #call, e_);    \
     } while (0)
 
-// Launch shape, tuned on MI355X.  Up to 32 rows: 4 waves per matrix, 4 candidates split per
-// round (the children of a small problem cannot keep more waves busy).  Above: the 32 KiB cost tile limits a CU to
-// three resident matrices, so either {8 waves, 6 candidates, 3 matrices/CU} -- the best throughput when the batch
-// fills whole rounds of 3 x CUs matrices -- or {12 waves, 8 candidates, 2 matrices/CU}, ~10 % less efficient per
-// matrix but without a nearly empty last round (1024 matrices on 256 CUs: 4.6 ms instead of 5.1 ms).
+// Launch shape, tuned on MI355X (DESIGN.md sections 3, 8).  The 32 KiB cost tile of a 64-row problem limits a CU to three
+// resident matrices and 80 VGPRs limit it to 24 waves: {8 waves, 6 candidates, 3 matrices/CU} is the throughput shape,
+// {12 waves, 8 candidates, 2/CU} and {16 waves, 8 candidates, 1/CU} trade throughput for latency when the batch is small.
 struct Shape { int nWaves, spec; };
 
 Shape choose_shape(const kbest_ctx *ctx, int B, int maxRow, int k)
@@ -72,9 +70,10 @@ Shape choose_shape(const kbest_ctx *ctx, int B, int maxRow, int k)
     else if (B <= 2 * ctx->nCU) { s.nWaves = 12; s.spec = 8; }
     else if (maxRow <= 32) { s.nWaves = 4; s.spec = 4; }
     else {
-        const double fa = (double)B / (3.0 * ctx->nCU), fb = (double)B / (2.0 * ctx->nCU);
-        const double effA = fa / (double)(long long)(fa + 0.999999), effB = fb / (double)(long long)(fb + 0.999999);
-        if (effB * 0.9 > effA) { s.nWaves = 12; s.spec = 8; } else { s.nWaves = 8; s.spec = 6; }
+        // measured (64x64, k = 200, ms for 8 / 12 waves): B = 600: 2.28 / 2.48, 900: 3.35 / 3.05, 1024: 4.0 / 3.2,
+        // 1100: 3.57 / 3.74, 1536: 4.27 / 4.60, 2048: 5.62 / 5.98, 8192: 19.4 / 21.9 -- three 8-wave matrices per CU win
+        // except where they would leave a nearly empty second generation and two generations of 12-wave pairs fit
+        if (B > 3 * ctx->nCU && B <= 4 * ctx->nCU) { s.nWaves = 12; s.spec = 8; } else { s.nWaves = 8; s.spec = 6; }
     }
     // the in-place pool merge holds at most 4 entries per thread: a long pool (bruteForceProb-style k in the
     // thousands, assignment.cpp:868) needs a bigger workgroup

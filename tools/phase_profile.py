@@ -51,3 +51,6 @@ for i, n in enumerate(names):
     print(f"  [{i:2d}] {n:28s} {m[i]:14.1f}{extra}")
 print(f"  per wave kernel cycles {tot/nw:.0f}; cycles/step in child dijkstra {m[8]/max(m[5],1):.0f}; set-up cycles/child {m[9]/max(m[4],1):.0f}; "
       f"flip+gain cycles/completed child {m[10]/max(m[6],1):.0f}; steps/child {m[5]/max(m[4],1):.2f}")
+w = p[:, 13] / nw  # per-matrix lifetime (cycles, mean over its waves)
+print(f"  per-matrix lifetime: mean {w.mean():.0f} std {w.std():.0f} ({100*w.std()/w.mean():.1f}%) min {w.min():.0f} max {w.max():.0f} (max/mean {w.max()/w.mean():.2f}); "
+      f"steps: mean {p[:,5].mean():.0f} std {p[:,5].std():.0f} max {p[:,5].max():.0f}; rounds mean {p[:,7].mean()/nw:.1f} max {p[:,7].max()/nw:.0f}")
