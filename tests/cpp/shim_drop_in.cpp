@@ -1,5 +1,5 @@
 // A caller written the way the reference's own callers are (assignment.cpp:583-594, 742-750): ScratchSpace,
-// caller-owned output arrays, kBest2D / kBest2DCutoff / assign2D / assignmentProb / conditionCosts by name.
+// caller-owned output arrays, kBest2D / kBest2DCutoff / assign2D / assignmentProb / conditionCosts / bruteForceProb by name.
 // Compiled against include/kbest_shims.hpp and linked to libkbest_amd.so; prints everything in hex floats so
 // that tests/test_gpu_parity.py can compare bit-for-bit with the checker.
 #include <cstdint>
@@ -73,6 +73,13 @@ int main(int argc, char **argv)
     for (size_t m = 0; m < nM; m++) {
         printf("p");
         for (double x : p[m]) printf(" %a", x);
+        printf("\n");
+    }
+    // the reference's "truth" generator on the same conditioned block (assignment.cpp:835-963)
+    std::vector<std::vector<double>> q = bruteForceProb(cond, condL, nM);
+    for (size_t m = 0; m < nM; m++) {
+        printf("q");
+        for (double x : q[m]) printf(" %a", x);
         printf("\n");
     }
     return 0;

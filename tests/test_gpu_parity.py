@@ -311,6 +311,11 @@ def test_cpp_shims_drop_in(eng, tmp_path):
     for m in range(3):
         got = np.array([float.fromhex(x) for x in out[i + 2 + m].split()[1:]])
         np.testing.assert_allclose(got, po[m], rtol=1e-12, atol=1e-15)
+    qo, _, _ = ol.brute_force_prob(cond, len(idx) - 3, 3)
+    for m in range(3):
+        assert out[i + 5 + m].startswith("q")
+        got = np.array([float.fromhex(x) for x in out[i + 5 + m].split()[1:]])
+        np.testing.assert_allclose(got, qo[m], rtol=1e-12, atol=1e-15)
 
 
 def test_quadric_costs_and_full_association_chain(eng):
