@@ -275,7 +275,8 @@ static WidePlan plan_wide(const kbest_ctx *ctx, int B, int maxRow, int maxCol, i
     w.perSlot = w.cw + w.states + w.pool + up((size_t)2 * w.poolStride * 4) + w.freeL;
     const size_t budget = (size_t)8 << 30;  // the grid strides over the batch: more slots than this buys nothing
     long long g = (long long)(budget / w.perSlot);
-    if (g > 2LL * ctx->nCU) g = 2LL * ctx->nCU;
+    const long long perCU = maxRow <= 128 ? 3 : 2;  // resident workgroups per CU (80 VGPRs up to 128 rows, 128 beyond)
+    if (g > perCU * ctx->nCU) g = perCU * ctx->nCU;
     if (g > B) g = B;
     if (g < 1) g = 1;
     w.grid = (int)g;

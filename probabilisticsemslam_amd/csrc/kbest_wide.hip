@@ -172,8 +172,9 @@ __device__ __forceinline__ double wide_gain(const double *Cw, int D, int M, cons
 
 }  // namespace
 
+// up to 128 rows the working set fits 80 VGPRs: three 8-wave workgroups per CU instead of two
 template <int R, bool TILE>
-__global__ void __launch_bounds__(WIDE_NW * 64) kbest_wide_kernel(WideParams p)
+__global__ void __launch_bounds__(WIDE_NW * 64, (R <= 2 ? 6 : 4)) kbest_wide_kernel(WideParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = WIDE_NW * 64;
