@@ -66,7 +66,7 @@ Shape choose_shape(const kbest_ctx *ctx, int B, int maxRow, int k)
     // A batch that cannot fill the chip is a latency problem: the reference calls assignmentProb once per frame.
     // With at most one (two) matrices per CU the whole CU (half of it) goes to each: 16 (12) waves, 8 candidates per
     // round -- 64x64, k = 200 alone: 1.25 ms instead of 1.80; one 30x10 frame: 0.63 ms instead of 0.99.
-    if (B <= ctx->nCU) { s.nWaves = 16; s.spec = 8; }
+    if (B <= ctx->nCU) { s.nWaves = 16; s.spec = maxRow <= 32 ? 16 : 8; }  // small frames: 16 candidates (0.63 -> 0.57 ms), 64 rows: 8
     else if (B <= 2 * ctx->nCU) { s.nWaves = 12; s.spec = 8; }
     else if (maxRow <= 32) { s.nWaves = 4; s.spec = 4; }
     else {
@@ -81,6 +81,7 @@ Shape choose_shape(const kbest_ctx *ctx, int B, int maxRow, int k)
     if (ctx->nWaves > 0) s.nWaves = ctx->nWaves;
     if (ctx->spec > 0) s.spec = ctx->spec;
     if (s.spec > s.nWaves) s.spec = s.nWaves;
+    if (s.spec > 8 && s.nWaves < 16) s.spec = 8;  // only the 16-wave kernel carries 16 selection slots
     while (s.spec > 1 && kb::lds_layout(maxRow, k, s.spec, s.nWaves).total > ctx->ldsLimit) s.spec /= 2;
     return s;
 }
@@ -207,7 +208,7 @@ int kbest_create(kbest_ctx **out, int device)
     }
     if (const char *e = getenv("KBEST_SPEC")) {
         int w = atoi(e);
-        if (w >= 1 && w <= 8) ctx->spec = w;
+        if (w >= 1 && w <= 16) ctx->spec = w;
     }
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->nCU = cus;

@@ -340,10 +340,10 @@ struct Ctrl {
     int nFresh;    // surviving children appended this round
     int nSurv;     // children that passed the first-step filter this round (queued from the front)
     int nSurvBack; //   ... and those queued from the back
-    short selIdx[8];          // pool index of each node selected in the last A phase (they are split in the next B)
-    unsigned short selSid[8]; // and its state slot
+    short selIdx[16];          // pool index of each node selected in the last A phase (they are split in the next B)
+    unsigned short selSid[16]; // and its state slot
 };
-static_assert(sizeof(Ctrl) <= 112, "Ctrl must fit the LDS slot reserved by lds_layout");
+static_assert(sizeof(Ctrl) <= 144, "Ctrl must fit the LDS slot reserved by lds_layout");
 
 // pool entry: gain (fp64), meta (u32: column | parent state << 8 | flags), own state slot (u16)
 constexpr unsigned short SID_NONE = 0xFFFFu;  // no saved state: re-solve from the parent when selected
@@ -721,14 +721,14 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             baseH = uni32(baseH);
             baseL = uni32(baseL);
             const u64 below = (1ull << lane) - 1ull;
-            // survivor entry (16 bits): column (6), node (3) and the last-arc bound as a fraction of the node's bound in
-            // 127ths, rounded down (7): what survived has minIn <= bound
+            // survivor entry (16 bits): column (6), node (4) and the last-arc bound as a fraction of the node's bound in
+            // 63ths, rounded down (6 bits): what survived has minIn <= bound
             int q = 0;
             if (keep && bound < INF && bound > 0.0) {
-                const double f = (minIn / bound) * 127.0;
-                q = f >= 127.0 ? 127 : (int)f;
+                const double f = (minIn / bound) * 63.0;
+                q = f >= 63.0 ? 63 : (int)f;
             }
-            const unsigned short entry = (unsigned short)((q << 9) | (wave << 6) | c);
+            const unsigned short entry = (unsigned short)((q << 10) | (wave << 6) | c);
             if (heavy) surv[baseH + __popcll(kh & below)] = entry;
             else if (keep) surv[spec * 64 - 1 - (baseL + __popcll(kl & below))] = entry;
         }
@@ -754,7 +754,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 if (lane == 0) ticket = atomicAdd(&ctrl->nextItem, 1);  // prefetch the next ticket
                 KB_ACC(4, 1);  // [4] children started
                 const int sv = uni32((int)surv[item < nFront ? item : spec * 64 - 1 - (item - nFront)]);
-                const int w = (sv >> 6) & 7, c = sv & 63;
+                const int w = (sv >> 6) & 15, c = sv & 63;
                 if (w != curW) {  // (re)load this node's data
                     curW = w;
                     nd = node_ref(smem + L.offNodes + (size_t)w * L.nodeStride, p.maxRow);
@@ -776,8 +776,8 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 double spc, delta;
                 int pred, sink = 0;
                 u64 scanned;
-                // backward bound from the filter (in 127ths of the bound, rounded down): the loop runs against bound - minIn
-                const double minIn = (bound < INF) ? (double)(sv >> 9) * (bound * (1.0 / 127.0)) : 0.0;
+                // backward bound from the filter (in 63ths of the bound, rounded down): the loop runs against bound - minIn
+                const double minIn = (bound < INF) ? (double)(sv >> 10) * (bound * (1.0 / 63.0)) : 0.0;
                 KB_T(tDij0);
                 KB_ACC(9, tDij0 - tItem);  // [9] per-child set-up cycles
                 const int st = dijkstra<true>(Cs, LDC, nd.u, rl, lane, v, c4r, cand, forbm, c, bound, spc, pred,
@@ -920,9 +920,10 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         if (budget > spec) budget = spec;
         if (budget < 1) budget = 1;
         int mySel = -1, mySid = 0, nselNew = 0, nLazy = 0;
-        int sIdx[8], sSid[8];
+        constexpr int MS = (NW >= 16) ? 16 : 8;  // candidates split per round at most (16 only in the 16-wave latency shape)
+        int sIdx[MS], sSid[MS];
 #pragma unroll
-        for (int w = 0; w < 8; w++) { sIdx[w] = -1; sSid[w] = 0; }
+        for (int w = 0; w < MS; w++) { sIdx[w] = -1; sSid[w] = 0; }
         // wave 0 walks the whole selection (it writes the control block); wave w only as far as its own, the w-th
         const int walk = (wave == 0 || budget <= wave) ? budget : wave + 1;
         for (int base = 0; base < nq && nselNew < walk; base += 64) {
@@ -938,7 +939,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 if (nselNew == wave) { mySel = base + bitpos; mySid = sidv; }
                 if (wave == 0) {
 #pragma unroll
-                    for (int w = 0; w < 8; w++) if (w == nselNew) { sIdx[w] = base + bitpos; sSid[w] = sidv; }
+                    for (int w = 0; w < MS; w++) if (w == nselNew) { sIdx[w] = base + bitpos; sSid[w] = sidv; }
                 }
                 nLazy += lazy ? 1 : 0;
                 nselNew++;
@@ -956,7 +957,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                     if (selSeen >= nselNew) break;  // not split and not selected this round: wait
                     sid = sSid[0];
 #pragma unroll
-                    for (int w = 1; w < 8; w++) sid = (selSeen == w) ? sSid[w] : sid;  // selection is in pool order
+                    for (int w = 1; w < MS; w++) sid = (selSeen == w) ? sSid[w] : sid;  // selection is in pool order
                     selSeen++;
                     fresh = true;
                 } else {
@@ -986,7 +987,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             ctrl->nq = nq;
             ctrl->head = h;
 #pragma unroll
-            for (int w = 0; w < 8; w++) { ctrl->selIdx[w] = (short)sIdx[w]; ctrl->selSid[w] = (unsigned short)sSid[w]; }
+            for (int w = 0; w < MS; w++) { ctrl->selIdx[w] = (short)sIdx[w]; ctrl->selSid[w] = (unsigned short)sSid[w]; }
             if (stop) ctrl->stop = 1;
         }
         if (wave < nselNew) {

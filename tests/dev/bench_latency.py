@@ -33,3 +33,11 @@ t0 = time.perf_counter()
 for _ in range(20):
     eng.kbest(costs, 64, 64, 200)
 print(f"kBest2D 64x64 k=200, B=1: {(time.perf_counter()-t0)/20*1e3:.3f} ms per call")
+# the solver alone on the same frames (what the weights epilogue adds)
+cs = [c for c, _ in conds[:1]]; nL1 = conds[0][1]
+c0 = np.asarray(cs[0]).reshape(1, -1)
+eng.kbest(c0, nL1 + 10, 10, 200, cutoff=42.0)
+t0 = time.perf_counter()
+for _ in range(20):
+    eng.kbest(c0, nL1 + 10, 10, 200, cutoff=42.0)
+print(f"kBest2DCutoff on the same frame, B=1: {(time.perf_counter()-t0)/20*1e3:.3f} ms per call")
