@@ -35,6 +35,7 @@ struct kbest_ctx {
     // frame, and a dozen hipMalloc/hipFree pairs per call cost more than the kernels of a 30 x 10 problem.
     struct Block { void *p; size_t n; bool used; };
     std::vector<Block> cache;
+    size_t cacheBytes = 0;  // all blocks, idle or in use
     std::mutex cacheMu;
 };
 
@@ -99,8 +100,14 @@ struct DevBuf {  // RAII device buffer of the host-pointer entry points, drawn f
         std::lock_guard<std::mutex> lock(owner->cacheMu);
         for (auto it = owner->cache.begin(); it != owner->cache.end(); ++it)
             if (it->p == p) {
-                if (it->n > ((size_t)256 << 20)) { (void)hipFree(p); owner->cache.erase(it); }  // one-off giants are not kept
-                else it->used = false;
+                // one-off giants are not kept, and the cache as a whole stays below 4 GiB
+                if (it->n > ((size_t)256 << 20) || owner->cacheBytes > ((size_t)4 << 30)) {
+                    owner->cacheBytes -= it->n;
+                    (void)hipFree(p);
+                    owner->cache.erase(it);
+                } else {
+                    it->used = false;
+                }
                 return;
             }
     }
@@ -117,11 +124,12 @@ struct DevBuf {  // RAII device buffer of the host-pointer entry points, drawn f
         hipError_t e = hipMalloc(&p, cap);
         if (e != hipSuccess) {  // make room: drop every idle block and try once more
             for (auto it = ctx->cache.begin(); it != ctx->cache.end();)
-                if (!it->used) { (void)hipFree(it->p); it = ctx->cache.erase(it); } else ++it;
+                if (!it->used) { ctx->cacheBytes -= it->n; (void)hipFree(it->p); it = ctx->cache.erase(it); } else ++it;
             e = hipMalloc(&p, cap);
             if (e != hipSuccess) { p = nullptr; return e; }
         }
         ctx->cache.push_back({p, cap, true});
+        ctx->cacheBytes += cap;
         return hipSuccess;
     }
     template <class T> T *as() { return static_cast<T *>(p); }
