@@ -13,6 +13,8 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "libkbest_oracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libref_kbest.so")
 REF_OFAST_SO = os.path.join(ORACLE_DIR, "_ref", "libref_kbest_ofast.so")
+REF_ASSIGN_SO = os.path.join(ORACLE_DIR, "_ref", "libref_assign.so")
+REF_ASSIGN_OFAST_SO = os.path.join(ORACLE_DIR, "_ref", "libref_assign_ofast.so")
 
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
@@ -89,6 +91,52 @@ def ref(ofast: bool = False):
                                           _i64p, _i64p, _dp, _i64p]
         _ref[path] = lib
     return _ref[path]
+
+
+def have_ref_assign() -> bool:
+    return os.path.exists(REF_ASSIGN_SO)
+
+
+def ref_assign(ofast: bool = False):
+    """The reference's own weights functions (verbatim slices of assignment.cpp, oracle/ref_assign_shim.cpp)."""
+    path = REF_ASSIGN_OFAST_SO if ofast else REF_ASSIGN_SO
+    if path not in _ref:
+        lib = C.CDLL(path)
+        lib.ref_assignment_prob.restype = C.c_int
+        lib.ref_assignment_prob.argtypes = [_dp, C.c_int, C.c_int, C.c_int, _dp]
+        lib.ref_brute_force_prob.restype = C.c_int
+        lib.ref_brute_force_prob.argtypes = [_dp, C.c_int, C.c_int, _dp]
+        lib.ref_condition_costs.restype = C.c_int
+        lib.ref_condition_costs.argtypes = [_dp, C.c_int, C.c_int, _dp, _i64p]
+        lib.ref_to_probs.restype = None
+        lib.ref_to_probs.argtypes = [_dp, C.c_int]
+        lib.ref_minc_constant.restype = C.c_double
+        lib.ref_minc_constant.argtypes = [C.c_int, C.c_int]
+        _ref[path] = lib
+    return _ref[path]
+
+
+def ref_condition_costs(cost, nRows, nCols):
+    cost = np.ascontiguousarray(cost, dtype=np.float64).reshape(-1)
+    out = np.empty(nRows * nCols)
+    idx = np.empty(nRows, np.int64)
+    good = ref_assign().ref_condition_costs(cost, nRows, nCols, out, idx)
+    return out[: good * nCols].copy(), idx[:good].copy()
+
+
+def ref_assignment_prob(cost, nL, nM, k, ofast=False):
+    """Reference assignmentProb: [nM][nL+1] (nM == 1: 1 x len(cost), assignment.cpp:557)."""
+    cost = np.ascontiguousarray(cost, dtype=np.float64).reshape(-1)
+    probs = np.zeros(max(nM * (nL + 1), cost.size) + 8)
+    w = ref_assign(ofast).ref_assignment_prob(cost, nL, nM, k, probs)
+    return probs[: nM * w].reshape(nM, w).copy()
+
+
+def ref_brute_force_prob(cost, nL, nM):
+    cost = np.ascontiguousarray(cost, dtype=np.float64).reshape(-1)
+    probs = np.zeros(max(nM * (nL + 1), cost.size) + 8)
+    w = ref_assign().ref_brute_force_prob(cost, nL, nM, probs)
+    return probs[: nM * w].reshape(nM, w).copy()
 
 
 # ---------------------------------------------------------------- wrappers

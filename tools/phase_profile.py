@@ -13,18 +13,32 @@ import probabilisticsemslam_amd as pk
 from probabilisticsemslam_amd import workloads as wl
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c4"
-Bc, N, M, k, seed = wl.DENSE_CONFIGS[cfg]
-B = int(sys.argv[2]) if len(sys.argv) > 2 else Bc
-nw = int(os.environ.get("KBEST_NWAVES", "8"))
 dev = torch.device("cuda", 0)
-costs = wl.dense_batch(B, N, M, seed)
-d_cost = torch.from_numpy(costs).to(dev)
+eng = pk.KBestEngine(0)
+kw = {}
+if cfg == "c5":  # conditioned KITTI-like frames, kBest2DCutoff(42) as assignmentProb calls it
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    k = 200
+    frames = wl.kitti_like_frames(B)
+    conds, idxs = eng.condition_costs(frames, [30] * B, [10] * B)
+    nrow = np.array([len(i) for i in idxs], np.int32)
+    N, M = int(nrow.max()), 10
+    off = np.zeros(B, np.int64)
+    off[1:] = np.cumsum(nrow[:-1].astype(np.int64) * M)
+    d_cost = torch.from_numpy(np.concatenate(conds)).to(dev)
+    kw = dict(cutoff=42.0, d_nRow=torch.from_numpy(nrow).to(dev), d_nCol=torch.full((B,), M, dtype=torch.int32, device=dev),
+              d_costOff=torch.from_numpy(off).to(dev))
+else:
+    Bc, N, M, k, seed = wl.DENSE_CONFIGS[cfg]
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else Bc
+    costs = wl.dense_batch(B, N, M, seed)
+    d_cost = torch.from_numpy(costs).to(dev)
+nw = int(os.environ.get("KBEST_NWAVES", "8"))
 d_r4c = torch.empty((B, k, M), dtype=torch.int32, device=dev)
 d_c4r = torch.empty((B, k, N), dtype=torch.int32, device=dev)
 d_gain = torch.empty((B, k), dtype=torch.float64, device=dev)
 d_nf = torch.empty(B, dtype=torch.int32, device=dev)
 prof = torch.zeros((B, 16), dtype=torch.int64, device=dev)
-eng = pk.KBestEngine(0)
 eng.lib.kbest_set_profile_buffer(eng.ctx, C.c_void_p(prof.data_ptr()))
 s = torch.cuda.Stream()
 for it in range(2):
@@ -33,7 +47,7 @@ for it in range(2):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     with torch.cuda.stream(s):
         e0.record()
-        eng.kbest_dev(d_cost, B, N, M, k, d_r4c, d_c4r, d_gain, d_nf, stream=s.cuda_stream)
+        eng.kbest_dev(d_cost, B, N, M, k, d_r4c, d_c4r, d_gain, d_nf, stream=s.cuda_stream, **kw)
         e1.record()
     torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
@@ -51,6 +65,7 @@ for i, n in enumerate(names):
     print(f"  [{i:2d}] {n:28s} {m[i]:14.1f}{extra}")
 print(f"  per wave kernel cycles {tot/nw:.0f}; cycles/step in child dijkstra {m[8]/max(m[5],1):.0f}; set-up cycles/child {m[9]/max(m[4],1):.0f}; "
       f"flip+gain cycles/completed child {m[10]/max(m[6],1):.0f}; steps/child {m[5]/max(m[4],1):.2f}")
+print("  nf:", d_nf.cpu().numpy()[:8])
 w = p[:, 13] / nw  # per-matrix lifetime (cycles, mean over its waves)
 print(f"  per-matrix lifetime: mean {w.mean():.0f} std {w.std():.0f} ({100*w.std()/w.mean():.1f}%) min {w.min():.0f} max {w.max():.0f} (max/mean {w.max()/w.mean():.2f}); "
       f"steps: mean {p[:,5].mean():.0f} std {p[:,5].std():.0f} max {p[:,5].max():.0f}; rounds mean {p[:,7].mean()/nw:.1f} max {p[:,7].max()/nw:.0f}")
