@@ -53,7 +53,9 @@ enum {
     KBEST_ERR_BAD_ARG = -2,     /* null pointer, k < 1, numRow < numCol, ...      */
     KBEST_ERR_UNSUPPORTED = -3, /* numRow > KBEST_MAX_DIM_WIDE                    */
     KBEST_ERR_HIP = -4,         /* a HIP call failed; see kbest_last_error()      */
-    KBEST_ERR_NOMEM = -5
+    KBEST_ERR_NOMEM = -5,
+    KBEST_ERR_NOT_RESERVED = -6, /* kbest_batch_f64_dev: workspace too small, call kbest_reserve first   */
+    KBEST_ERR_INTERNAL = -7     /* a problem came back with nf < 0 although its shape was accepted       */
 };
 
 #define KBEST_MAX_DIM 64       /* rows per problem handled by the LDS-resident kernel (the fast path)      */
@@ -63,6 +65,8 @@ enum {
 /* flags */
 #define KBEST_FLAG_NO_PRUNE 1u     /* disable early termination (for counting P)   */
 #define KBEST_FLAG_COUNT_PUSHED 2u /* fill `pushed` with the reference's push count */
+#define KBEST_FLAG_RECT_ROOT 4u    /* internal (kbest_assign_batch_f64): numCol augmentations on the rectangular problem */
+#define KBEST_FLAG_NO_SHIFT 8u     /* internal (kbest_assign_batch_f64): the cost matrix is already non-negative         */
 
 typedef struct kbest_opts {
     int32_t  maximize;     /* reference `maximize` argument                       */
@@ -97,7 +101,14 @@ int kbest_device_count(void);
  *   d_pushed  [B] int64 or NULL; with KBEST_FLAG_COUNT_PUSHED the number of
  *             feasible children the reference would push (SURVEY 8(d) "P")
  *   stream    hipStream_t (NULL = the context's own stream).  Asynchronous:
- *             returns after enqueueing; no host synchronisation inside.
+ *             returns after enqueueing; no host synchronisation and no allocation
+ *             inside -- the workspace must have been sized by kbest_reserve(B, maxRow, k)
+ *             beforehand (else KBEST_ERR_NOT_RESERVED), which keeps the entry legal
+ *             inside a graph capture.
+ * ONE hypothesis workspace per context: launches of one context execute one after the
+ * other.  A launch on a different stream than the previous one is ordered behind it
+ * with an event (so results stay correct), but there is no overlap to be had -- use one
+ * context per stream (or per host thread) for concurrent launches.
  */
 int kbest_batch_f64_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, int maxCol,
                         const int32_t *d_nRow, const int32_t *d_nCol, const double *d_cost,
@@ -110,9 +121,30 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
                     const int64_t *costOff, int k, int32_t *row4col, int32_t *col4row, double *gain,
                     int32_t *nf, int64_t *pushed);
 
-/* Make sure the context's workspace can hold a (B, maxRow, k) launch.  Called
- * implicitly by the batch functions; call it up front to keep allocation out
- * of a timed / graph-captured region. */
+/*
+ * Batched assign2D (shortestPathCPP.hpp:144-149, cpp:735-762) and shortestPathCPP (hpp:178-182, cpp:119-238): the
+ * single best assignment of each numRow x numCol problem by numCol shortest-augmenting-path steps on the
+ * RECTANGULAR matrix (no zero-padded columns), with the dual variables.
+ *   shift      1: assign2D -- the matrix is made non-negative first (makeCostMatrixSafe) and the gain is un-shifted;
+ *              0: shortestPathCPP -- the matrix is used as it is (it must be non-negative; maximize must be 0)
+ *   gainCols   numCol4Gain of shortestPathCPP (the gain sums the first gainCols columns, cpp:232); 0 = numCol
+ *   row4col    [B][maxCol]  col -> row          col4row [B][maxRow]  row -> col, -1 = unassigned (cpp:134)
+ *   u          [B][maxCol] MurtyHyp::u (per column), v [B][maxRow] MurtyHyp::v (per row); either may be NULL
+ *   feasible   [B] 1, or 0 = infeasible (then gain = -1, cpp:197-203, and the index outputs are -1)
+ * numRow <= KBEST_MAX_DIM.  Host buffers.
+ */
+int kbest_assign_batch_f64(kbest_ctx *ctx, int B, int maxRow, int maxCol, const int32_t *nRow, const int32_t *nCol,
+                           const double *cost, const int64_t *costOff, int maximize, int shift, int gainCols,
+                           int32_t *row4col, int32_t *col4row, double *gain, double *u, double *v,
+                           int32_t *feasible);
+
+/* toProbs (assignment.h:19, assignment.cpp:527-542): x[i] <- exp(min(x) - x[i]) where min(x) + 42 > x[i], else 0;
+ * in place on a host buffer of n doubles. */
+int kbest_to_probs_f64(kbest_ctx *ctx, double *x, int64_t n);
+
+/* Size the context's workspace for launches of up to B problems of up to maxRow rows and k solutions.
+ * Required before kbest_batch_f64_dev; the host-pointer entries call it implicitly.  When it has to
+ * grow the workspace it waits for the device to go idle (hipDeviceSynchronize) and reallocates. */
 int kbest_reserve(kbest_ctx *ctx, int B, int maxRow, int k);
 
 /* Diagnostic builds only (make -C probabilisticsemslam_amd/csrc PROFILE=1): device buffer of B*16 uint64

@@ -8,6 +8,8 @@
 //   kBest2D        shortestPathCPP.hpp:204-212   (callers: assignment.cpp:880)
 //   kBest2DCutoff  shortestPathCPP.hpp:256-265   (callers: assignment.cpp:594)
 //   assign2D       shortestPathCPP.hpp:144-149   (no caller in the reference)
+//   shortestPathCPP shortestPathCPP.hpp:178-182  (callers: cpp:587, 668, 749)
+//   toProbs        assignment.h:19               (callers: assignment.cpp:164)
 //   assignmentProb assignment.h:11               (callers: assignment.cpp:66, comparison.cpp:194-222)
 //   conditionCosts assignment.h:26               (callers: assignment.cpp:58, comparison.cpp:161)
 //
@@ -82,10 +84,19 @@ size_t kBest2DCutoff(const size_t k, const size_t numRow, const size_t numCol, c
 int assign2D(const size_t numRow, const size_t numCol, const bool maximize, const double *C, ScratchSpace &workMem,
              MurtyHyp *problemSol);
 
+// shortestPathCPP.hpp:178-182 (cpp:119-238): the root LAP on workMem.C (numRow x numCol, already non-negative);
+// fills problemSol (col4row, row4col, u, v, gain over the first numCol4Gain columns, forbiddenActiveRows);
+// returns 1 with gain = -1 when infeasible, else 0
+int shortestPathCPP(MurtyHyp *problemSol, ScratchSpace &workMem, const size_t numRow, const size_t numCol,
+                    const size_t numCol4Gain);
+
 std::vector<std::vector<double>> assignmentProb(const std::vector<double> &costMatrix, size_t nL, size_t nM, size_t k);
 
 // assignment.h:43 (assignment.cpp:835-963): every assignment up to a Minc-type bound (at most 20000), no 42-gate
 std::vector<std::vector<double>> bruteForceProb(const std::vector<double> &costMatrix, size_t nL, size_t nM);
+
+// assignment.h:19 (assignment.cpp:527-542): exp(min - c) with the 42 gate, in place
+void toProbs(std::vector<double> &costMatrix);
 
 // assignment.h:26 (assignment.cpp:439-525)
 std::vector<double> conditionCosts(const std::vector<double> &costs, size_t nRows, size_t nCols,

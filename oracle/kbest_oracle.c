@@ -452,6 +452,47 @@ int orc_assign2d(int N, int M, int maximize, const double *C, int32_t *col4row,
     return bad ? 0 : 1;
 }
 
+/*
+ * assign2D (cpp:735-762, shift = 1) or shortestPathCPP on an already non-negative matrix (cpp:119-238, shift = 0;
+ * gain over the first gainCols columns, numCol4Gain of cpp:232), with the dual variables the reference leaves in the
+ * MurtyHyp: u[M] per column, v[N] per row.  Returns 1 = solved, 0 = infeasible (then *gain = -1, cpp:200).
+ */
+int orc_assign2d_ex(int N, int M, int maximize, int shift, int gainCols, const double *C, int32_t *col4row,
+                    int32_t *row4col, double *gain, double *u, double *v)
+{
+    orc_ws w;
+    ws_init(&w, N);
+    double CDelta = 0.0;
+    if (shift) {
+        CDelta = load_costs(&w, C, N, M, maximize) * (double)M;
+    } else {
+        for (size_t i = 0; i < (size_t)N * (size_t)M; i++) w.C[i] = C[i];
+        for (size_t i = (size_t)N * (size_t)M; i < (size_t)N * (size_t)N; i++) w.C[i] = 0.0;
+    }
+    orc_hyp *h = hyp_new(N);
+    for (int i = 0; i < N; i++) {
+        h->col4row[i] = -1; h->row4col[i] = -1; h->u[i] = 0; h->v[i] = 0; h->forb[i] = 0;
+    }
+    int bad = 0;
+    for (int c = 0; c < M && !bad; c++) {
+        memset(w.inScan, 1, (size_t)N);
+        bad = augment(&w, h, c, NULL, NULL, NULL);
+    }
+    if (!bad) {
+        const double g = gain_of(&w, h, gainCols > 0 && gainCols < M ? gainCols : M);
+        *gain = shift ? (maximize ? (-g + CDelta) : (g + CDelta)) : g;
+        memcpy(col4row, h->col4row, 4 * (size_t)N);
+        memcpy(row4col, h->row4col, 4 * (size_t)M);
+        memcpy(u, h->u, 8 * (size_t)M);
+        memcpy(v, h->v, 8 * (size_t)N);
+    } else {
+        *gain = -1.0;
+    }
+    free(h);
+    ws_free(&w);
+    return bad ? 0 : 1;
+}
+
 /* =====================  association weights (assignment.cpp)  ============ */
 
 #define ORC_GATE 42.0 /* `cutoff`, assignment.cpp:9 (size_t 42, promoted) */

@@ -52,6 +52,29 @@ int ref_assign2d(int64_t numRow, int64_t numCol, int maximize, const double *C,
     return ok;
 }
 
+// assign2D (shift = 1) or shortestPathCPP on ws.C as it is (shift = 0), with everything the reference leaves in the
+// MurtyHyp: col4row, row4col, gain, u (per column), v (per row).  Returns 1 = solved, 0 = infeasible.
+int ref_assign2d_ex(int64_t numRow, int64_t numCol, int maximize, int shift, int64_t gainCols, const double *C,
+                    int64_t *col4row, int64_t *row4col, double *gain, double *u, double *v)
+{
+    ScratchSpace ws;
+    ws.init((size_t)numRow, (size_t)numRow);
+    MurtyHyp sol((size_t)numRow, (size_t)numRow);
+    int ok;
+    if (shift) {
+        ok = assign2D((size_t)numRow, (size_t)numCol, maximize != 0, C, ws, &sol);
+    } else {
+        for (int64_t i = 0; i < numRow * numCol; i++) ws.C[i] = C[i];
+        ok = shortestPathCPP(&sol, ws, (size_t)numRow, (size_t)numCol, (size_t)(gainCols > 0 ? gainCols : numCol)) == 0;
+    }
+    *gain = sol.gain;
+    if (ok) {
+        for (int64_t r = 0; r < numRow; r++) { col4row[r] = sol.col4row[r]; v[r] = sol.v[r]; }
+        for (int64_t c = 0; c < numCol; c++) { row4col[c] = sol.row4col[c]; u[c] = sol.u[c]; }
+    }
+    return ok;
+}
+
 // B equally-shaped problems packed back to back, one kBest2D call each with a
 // fresh ScratchSpace and fresh outputs -- exactly how assignmentProb drives the
 // solver (assignment.cpp:583-594).  Single thread.  Used for the CPU baseline.

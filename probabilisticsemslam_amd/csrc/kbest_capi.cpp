@@ -18,8 +18,7 @@ struct kbest_ctx {
     hipStream_t stream = nullptr;
     unsigned char *states = nullptr;  // hypothesis-state workspace (+ the slot -> state table behind it)
     size_t statesBytes = 0;
-    size_t slotSidOffset = 0;
-    unsigned char *wide = nullptr;    // work space of the general-size kernel (kbest_wide.hip)
+        unsigned char *wide = nullptr;    // work space of the general-size kernel (kbest_wide.hip)
     size_t wideBytes = 0;
     int ldsLimit = 65536;
     int nWaves = 0;   // waves per cost matrix (workgroup = nWaves * 64 threads); 0 = choose per launch
@@ -30,7 +29,13 @@ struct kbest_ctx {
     int eagerStates = 1024; // state slots per matrix for children that are kept in full when they are found
     unsigned long long *prof = nullptr;  // diagnostic builds only (kbest_set_profile_buffer)
     std::string err;
-    std::mutex mu;  // shim entry points may be called from several host threads
+    std::mutex errMu;  // entry points may be called from several host threads
+    std::mutex mu;     // serialises launches: the hypothesis workspace is shared by every launch of this context
+    // The workspace is per context, not per stream: a launch on another stream than the previous one must wait for it
+    // (an event recorded on the previous stream when the switch is detected).
+    hipStream_t lastStream = nullptr;
+    bool haveLast = false;
+    hipEvent_t lastEvent = nullptr;
     // Device buffers of the host-pointer entry points are recycled: the reference calls assignmentProb once per
     // frame, and a dozen hipMalloc/hipFree pairs per call cost more than the kernels of a 30 x 10 problem.
     struct Block { void *p; size_t n; bool used; };
@@ -44,6 +49,7 @@ namespace {
 int fail(kbest_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess)
 {
     if (ctx) {
+        std::lock_guard<std::mutex> lock(ctx->errMu);
         ctx->err = what;
         if (e != hipSuccess) { ctx->err += ": "; ctx->err += hipGetErrorString(e); }
     }
@@ -177,11 +183,20 @@ const char *kbest_strerror(int code)
     case KBEST_ERR_UNSUPPORTED: return "problem size not supported by the device kernels";
     case KBEST_ERR_HIP: return "HIP runtime error";
     case KBEST_ERR_NOMEM: return "out of device memory";
+    case KBEST_ERR_NOT_RESERVED: return "workspace too small: call kbest_reserve(B, maxRow, k) before the device-pointer entry";
+    case KBEST_ERR_INTERNAL: return "internal error in the device kernels (a problem came back with nf < 0)";
     default: return "unknown error";
     }
 }
 
-const char *kbest_last_error(const kbest_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+const char *kbest_last_error(const kbest_ctx *ctx)
+{
+    if (!ctx) return "null context";
+    static thread_local std::string copy;  // the caller's view must not change under it when another thread fails
+    std::lock_guard<std::mutex> lock(const_cast<kbest_ctx *>(ctx)->errMu);
+    copy = ctx->err;
+    return copy.c_str();
+}
 
 int kbest_device_count(void)
 {
@@ -199,7 +214,9 @@ int kbest_create(kbest_ctx **out, int device)
     if (hipSetDevice(device) != hipSuccess) return KBEST_ERR_NO_DEVICE;
     kbest_ctx *ctx = new kbest_ctx;
     ctx->device = device;
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->lastEvent, hipEventDisableTiming) != hipSuccess) {
+        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return KBEST_ERR_NO_DEVICE;
     }
@@ -235,6 +252,7 @@ int kbest_destroy(kbest_ctx *ctx)
     if (ctx->states) (void)hipFree(ctx->states);
     if (ctx->wide) (void)hipFree(ctx->wide);
     for (auto &b : ctx->cache) (void)hipFree(b.p);
+    if (ctx->lastEvent) (void)hipEventDestroy(ctx->lastEvent);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return KBEST_OK;
@@ -244,21 +262,6 @@ int kbest_set_profile_buffer(kbest_ctx *ctx, void *d_buf)
 {
     if (!ctx) return KBEST_ERR_BAD_ARG;
     ctx->prof = static_cast<unsigned long long *>(d_buf);
-    return KBEST_OK;
-}
-
-int kbest_reserve(kbest_ctx *ctx, int B, int maxRow, int k)
-{
-    if (!ctx || B < 0 || maxRow < 1 || k < 1) return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_reserve: bad argument");
-    const size_t nStates = (size_t)B * (size_t)(k + ctx->extraStates + eager_states(ctx, B, maxRow, k)) * (size_t)kb::state_stride(maxRow);
-    const size_t need = nStates + (size_t)B * (size_t)kb::slot_table_stride(k) * 2 + 256;
-    if (need <= ctx->statesBytes) { ctx->slotSidOffset = (nStates + 127) & ~(size_t)127; return KBEST_OK; }
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (ctx->states) { HIP_TRY(ctx, hipDeviceSynchronize()); (void)hipFree(ctx->states); ctx->states = nullptr; ctx->statesBytes = 0; }
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->states), need);
-    if (e != hipSuccess) return fail(ctx, KBEST_ERR_NOMEM, "hipMalloc(state workspace)", e);
-    ctx->statesBytes = need;
-    ctx->slotSidOffset = (nStates + 127) & ~(size_t)127;
     return KBEST_OK;
 }
 
@@ -292,10 +295,11 @@ static WidePlan plan_wide(const kbest_ctx *ctx, int B, int maxRow, int maxCol, i
     return w;
 }
 
-static int reserve_wide(kbest_ctx *ctx, const WidePlan &w)
+static int reserve_wide(kbest_ctx *ctx, const WidePlan &w, bool grow)
 {
     const size_t need = w.perSlot * (size_t)w.grid + 256;
     if (need <= ctx->wideBytes) return KBEST_OK;
+    if (!grow) return fail(ctx, KBEST_ERR_NOT_RESERVED, "general-size work space too small: call kbest_reserve first");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->wide) { HIP_TRY(ctx, hipDeviceSynchronize()); (void)hipFree(ctx->wide); ctx->wide = nullptr; ctx->wideBytes = 0; }
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->wide), need);
@@ -304,10 +308,83 @@ static int reserve_wide(kbest_ctx *ctx, const WidePlan &w)
     return KBEST_OK;
 }
 
-int kbest_batch_f64_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, int maxCol,
-                        const int32_t *d_nRow, const int32_t *d_nCol, const double *d_cost,
-                        const int64_t *d_costOff, int k, int32_t *d_row4col, int32_t *d_col4row,
-                        double *d_gain, int32_t *d_nf, int64_t *d_pushed, void *stream)
+// Bytes of the LDS kernel's workspace for a (B, maxRow, k) launch, and where the slot table starts in it.
+static size_t states_need(const kbest_ctx *ctx, int B, int maxRow, int k, size_t *slotOff)
+{
+    const size_t nStates = (size_t)B * (size_t)(k + ctx->extraStates + eager_states(ctx, B, maxRow, k)) * (size_t)kb::state_stride(maxRow);
+    if (slotOff) *slotOff = (nStates + 127) & ~(size_t)127;
+    return nStates + (size_t)B * (size_t)kb::slot_table_stride(k) * 2 + 256;
+}
+
+static bool k_fits_fast(const kbest_ctx *ctx, int B, int fastRow, int k, unsigned flags, Shape *shapeOut)
+{
+    Shape shape = choose_shape(ctx, B, fastRow, k);
+    if (flags & KBEST_FLAG_COUNT_PUSHED) shape.spec = 1;  // counting the reference's pushes needs its exact order of splits
+    if (shapeOut) *shapeOut = shape;
+    return k + ctx->extraStates + ctx->eagerStates <= 65534 && k <= 4 * shape.nWaves * 64 &&
+           kb::lds_layout(fastRow, k, shape.spec, shape.nWaves).total <= ctx->ldsLimit;
+}
+
+static int reserve_states(kbest_ctx *ctx, int B, int maxRow, int k, bool grow)
+{
+    if (maxRow > KBEST_MAX_DIM) maxRow = KBEST_MAX_DIM;
+    const size_t need = states_need(ctx, B, maxRow, k, nullptr);
+    if (need <= ctx->statesBytes) return KBEST_OK;
+    if (!grow) return fail(ctx, KBEST_ERR_NOT_RESERVED, "hypothesis workspace too small: call kbest_reserve first");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->states) { HIP_TRY(ctx, hipDeviceSynchronize()); (void)hipFree(ctx->states); ctx->states = nullptr; ctx->statesBytes = 0; }
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->states), need);
+    if (e != hipSuccess) return fail(ctx, KBEST_ERR_NOMEM, "hipMalloc(state workspace)", e);
+    ctx->statesBytes = need;
+    return KBEST_OK;
+}
+
+int kbest_reserve(kbest_ctx *ctx, int B, int maxRow, int k)
+{
+    if (!ctx || B < 0 || maxRow < 1 || k < 1) return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_reserve: bad argument");
+    if (maxRow > KBEST_MAX_DIM_WIDE) return fail(ctx, KBEST_ERR_UNSUPPORTED, "numRow > KBEST_MAX_DIM_WIDE");
+    if (B == 0) return KBEST_OK;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    const int fastRow = maxRow < KBEST_MAX_DIM ? maxRow : KBEST_MAX_DIM;
+    const bool kFits = k_fits_fast(ctx, B, fastRow, k, 0, nullptr) || k_fits_fast(ctx, B, fastRow, k, KBEST_FLAG_COUNT_PUSHED, nullptr);
+    if (kFits) {
+        int rc = reserve_states(ctx, B, fastRow, k, true);
+        if (rc != KBEST_OK) return rc;
+    }
+    if (!kFits || maxRow > KBEST_MAX_DIM || getenv("KBEST_FORCE_WIDE"))  // (numCol <= numRow bounds the general-size plan)
+        return reserve_wide(ctx, plan_wide(ctx, B, maxRow, maxRow, k), true);
+    return KBEST_OK;
+}
+
+struct DevExtra {  // optional outputs / modes of kbest_assign_batch_f64 (root solution only)
+    double *dualU = nullptr, *dualV = nullptr;
+    int gainCols = 0;
+};
+
+// Order this launch (on stream s) behind the previous launch of the context when that ran on another stream: both
+// use the context's one hypothesis workspace.  Called with ctx->mu held.
+static int order_behind_last(kbest_ctx *ctx, hipStream_t s)
+{
+    if (ctx->haveLast && ctx->lastStream != s) {
+        if (hipEventRecord(ctx->lastEvent, ctx->lastStream) == hipSuccess) {
+            HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->lastEvent, 0));
+        } else {  // the previous stream is gone (destroyed by its owner): wait for everything
+            (void)hipGetLastError();
+            HIP_TRY(ctx, hipDeviceSynchronize());
+        }
+    }
+    ctx->lastStream = s;
+    ctx->haveLast = true;
+    return KBEST_OK;
+}
+
+// grow: the host-pointer entries (which synchronise anyway) let the workspace grow on demand; the asynchronous
+// device-pointer entry never allocates or synchronises -- it needs kbest_reserve up front.
+static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, int maxCol,
+                          const int32_t *d_nRow, const int32_t *d_nCol, const double *d_cost,
+                          const int64_t *d_costOff, int k, int32_t *d_row4col, int32_t *d_col4row,
+                          double *d_gain, int32_t *d_nf, int64_t *d_pushed, void *stream, bool grow,
+                          const DevExtra *extra = nullptr)
 {
     if (!ctx) return KBEST_ERR_BAD_ARG;
     if (!opts || B < 0 || k < 1 || maxCol < 1 || maxRow < maxCol || !d_cost || !d_row4col || !d_gain || !d_nf)
@@ -322,22 +399,26 @@ int kbest_batch_f64_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRo
     // problems), a uniform batch of larger problems, or any shape when k is beyond the LDS pool.
     const int fastRow = maxRow < KBEST_MAX_DIM ? maxRow : KBEST_MAX_DIM;
     const int fastCol = maxCol < fastRow ? maxCol : fastRow;
-    // counting the reference's pushes needs the reference's exact order of splits: no speculation
-    const Shape shape = choose_shape(ctx, B, fastRow, k);
-    const int spec = (opts->flags & KBEST_FLAG_COUNT_PUSHED) ? 1 : shape.spec;
-    const int nWaves = shape.nWaves;
-    const bool kFits = k + ctx->extraStates + ctx->eagerStates <= 65534 && k <= 4 * nWaves * 64 &&
-                       kb::lds_layout(fastRow, k, spec, nWaves).total <= ctx->ldsLimit;
-    const bool forceWide = getenv("KBEST_FORCE_WIDE") != nullptr;  // test hook: everything through the general-size kernel
+    Shape shape;
+    const bool kFits = k_fits_fast(ctx, B, fastRow, k, opts->flags, &shape);
+    const int spec = shape.spec, nWaves = shape.nWaves;
+    const bool forceWide = getenv("KBEST_FORCE_WIDE") != nullptr && !extra;  // test hook: everything through the general-size kernel
     const bool runFast = !forceWide && kFits && (maxRow <= KBEST_MAX_DIM || d_nRow != nullptr);
     const bool runWide = forceWide || !kFits || maxRow > KBEST_MAX_DIM;
+    if (extra && runWide) return fail(ctx, KBEST_ERR_UNSUPPORTED, "assign2D / shortestPathCPP entry: numRow > KBEST_MAX_DIM");
     std::lock_guard<std::mutex> lock(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    {
+        int rc = order_behind_last(ctx, s);
+        if (rc != KBEST_OK) return rc;
+    }
 
     if (runFast) {
-        int rc = kbest_reserve(ctx, B, fastRow, k);
+        int rc = reserve_states(ctx, B, fastRow, k, grow);
         if (rc != KBEST_OK) return rc;
+        size_t slotOff = 0;
+        (void)states_need(ctx, B, fastRow, k, &slotOff);
         kb::Params p;
         p.cost = d_cost;
         p.costOff = reinterpret_cast<const long long *>(d_costOff);
@@ -365,7 +446,10 @@ int kbest_batch_f64_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRo
         p.lazyStates = k + ctx->extraStates;
         p.spec = spec;
         p.prof = ctx->prof;
-        p.slotSid = reinterpret_cast<unsigned short *>(ctx->states + ctx->slotSidOffset);
+        p.slotSid = reinterpret_cast<unsigned short *>(ctx->states + slotOff);
+        p.dualU = extra ? extra->dualU : nullptr;
+        p.dualV = extra ? extra->dualV : nullptr;
+        p.gainCols = extra ? extra->gainCols : 0;
         hipError_t e = kb::launch_kbest(p, B, nWaves, s);
         if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "kbest kernel launch", e);
     }
@@ -377,7 +461,7 @@ int kbest_batch_f64_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRo
         // from LDS instead of L2 at every Dijkstra step.  It costs residency (one workgroup per CU instead of two), so
         // only a batch that leaves CUs idle anyway takes it (256 x 128x128: 16 ms instead of 19; 512: 38 instead of 37).
         const bool tile = B <= ctx->nCU && maxRow <= 128 && kb::wide_lds_layout(maxRow, maxCol, true).total <= ctx->ldsLimit;
-        int rc = reserve_wide(ctx, w);
+        int rc = reserve_wide(ctx, w, grow);
         if (rc != KBEST_OK) return rc;
         kb::WideParams p;
         p.cost = d_cost;
@@ -421,14 +505,26 @@ int kbest_batch_f64_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRo
     return KBEST_OK;
 }
 
+int kbest_batch_f64_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, int maxCol,
+                        const int32_t *d_nRow, const int32_t *d_nCol, const double *d_cost,
+                        const int64_t *d_costOff, int k, int32_t *d_row4col, int32_t *d_col4row,
+                        double *d_gain, int32_t *d_nf, int64_t *d_pushed, void *stream)
+{
+    if (opts && (opts->flags & (KBEST_FLAG_RECT_ROOT | KBEST_FLAG_NO_SHIFT)))
+        return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_batch_f64_dev: internal flag");
+    return batch_dev_impl(ctx, opts, B, maxRow, maxCol, d_nRow, d_nCol, d_cost, d_costOff, k, d_row4col, d_col4row,
+                          d_gain, d_nf, d_pushed, stream, false);
+}
+
 int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, int maxCol,
                     const int32_t *nRow, const int32_t *nCol, const double *cost,
                     const int64_t *costOff, int k, int32_t *row4col, int32_t *col4row, double *gain,
                     int32_t *nf, int64_t *pushed)
 {
     if (!ctx) return KBEST_ERR_BAD_ARG;
-    if (!opts || B < 0 || k < 1 || !cost || !row4col || !col4row || !gain || !nf)
+    if (!opts || B < 0 || k < 1 || maxCol < 1 || maxRow < maxCol || !cost || !row4col || !col4row || !gain || !nf)
         return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_batch_f64: bad argument");
+    if (opts->flags & (KBEST_FLAG_RECT_ROOT | KBEST_FLAG_NO_SHIFT)) return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_batch_f64: internal flag");
     if ((nRow == nullptr) != (nCol == nullptr))
         return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_batch_f64: give both nRow and nCol or neither");
     if (B == 0) return KBEST_OK;
@@ -468,11 +564,11 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
     HIP_TRY(ctx, hipMemsetAsync(dR4C.p, 0xFF, nR4C * 4, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(dC4R.p, 0xFF, nC4R * 4, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(dGain.p, 0, nG * 8, ctx->stream));
-    int rc = kbest_batch_f64_dev(ctx, opts, B, maxRow, maxCol, nRow ? dNR.as<int32_t>() : nullptr,
-                                 nRow ? dNC.as<int32_t>() : nullptr, dCost.as<double>(),
-                                 costOff ? dOff.as<int64_t>() : nullptr, k, dR4C.as<int32_t>(), dC4R.as<int32_t>(),
-                                 dGain.as<double>(), dNf.as<int32_t>(), pushed ? dPushed.as<int64_t>() : nullptr,
-                                 ctx->stream);
+    int rc = batch_dev_impl(ctx, opts, B, maxRow, maxCol, nRow ? dNR.as<int32_t>() : nullptr,
+                            nRow ? dNC.as<int32_t>() : nullptr, dCost.as<double>(),
+                            costOff ? dOff.as<int64_t>() : nullptr, k, dR4C.as<int32_t>(), dC4R.as<int32_t>(),
+                            dGain.as<double>(), dNf.as<int32_t>(), pushed ? dPushed.as<int64_t>() : nullptr,
+                            ctx->stream, true);
     if (rc != KBEST_OK) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(row4col, dR4C.p, nR4C * 4, hipMemcpyDeviceToHost));
@@ -480,6 +576,95 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
     HIP_TRY(ctx, hipMemcpy(gain, dGain.p, nG * 8, hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemcpy(nf, dNf.p, (size_t)B * 4, hipMemcpyDeviceToHost));
     if (pushed) HIP_TRY(ctx, hipMemcpy(pushed, dPushed.p, (size_t)B * 8, hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; b++)  // shapes were validated above: a negative count can only be an engine failure
+        if (nf[b] < 0) return fail(ctx, nf[b] == -1 ? KBEST_ERR_UNSUPPORTED : KBEST_ERR_INTERNAL, "kbest_batch_f64: a problem came back with nf < 0");
+    return KBEST_OK;
+}
+
+int kbest_assign_batch_f64(kbest_ctx *ctx, int B, int maxRow, int maxCol, const int32_t *nRow, const int32_t *nCol,
+                           const double *cost, const int64_t *costOff, int maximize, int shift, int gainCols,
+                           int32_t *row4col, int32_t *col4row, double *gain, double *u, double *v, int32_t *feasible)
+{
+    if (!ctx) return KBEST_ERR_BAD_ARG;
+    if (B < 0 || maxCol < 1 || maxRow < maxCol || !cost || !row4col || !col4row || !gain || !feasible || gainCols < 0 ||
+        (!shift && maximize))
+        return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_assign_batch_f64: bad argument");
+    if ((nRow == nullptr) != (nCol == nullptr) || (costOff && !nRow))
+        return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_assign_batch_f64: give nRow, nCol (and costOff) together");
+    if (maxRow > KBEST_MAX_DIM) return fail(ctx, KBEST_ERR_UNSUPPORTED, "kbest_assign_batch_f64: numRow > KBEST_MAX_DIM");
+    if (B == 0) return KBEST_OK;
+    size_t nCost = (size_t)B * maxRow * maxCol;
+    if (nRow) {
+        nCost = 0;
+        for (int b = 0; b < B; b++) {
+            if (nCol[b] < 1 || nRow[b] < nCol[b] || nRow[b] > maxRow || nCol[b] > maxCol)
+                return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_assign_batch_f64: shape out of range (need 1 <= numCol <= numRow <= maxRow)");
+            const size_t end = (costOff ? (size_t)costOff[b] : (size_t)b * maxRow * maxCol) + (size_t)nRow[b] * nCol[b];
+            if (end > nCost) nCost = end;
+        }
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf dCost, dMeta, dOut;
+    // one block in (shapes, offsets), one block out (row4col, col4row, nf | gain, u, v)
+    const size_t B4 = ((size_t)B * 4 + 15) & ~(size_t)15, B8 = ((size_t)B * 8 + 15) & ~(size_t)15;
+    std::vector<unsigned char> meta(2 * B4 + B8);
+    if (nRow) { memcpy(meta.data(), nRow, (size_t)B * 4); memcpy(meta.data() + B4, nCol, (size_t)B * 4); }
+    if (costOff) memcpy(meta.data() + 2 * B4, costOff, (size_t)B * 8);
+    const size_t oR4C = 0, oC4R = oR4C + (((size_t)B * maxCol * 4 + 15) & ~(size_t)15),
+                 oNf = oC4R + (((size_t)B * maxRow * 4 + 15) & ~(size_t)15), oGain = oNf + B4, oU = oGain + B8,
+                 oV = oU + (size_t)B * maxCol * 8, oEnd = oV + (size_t)B * maxRow * 8;
+    HIP_TRY(ctx, dCost.alloc(ctx, nCost * 8));
+    HIP_TRY(ctx, dMeta.alloc(ctx, meta.size()));
+    HIP_TRY(ctx, dOut.alloc(ctx, oEnd));
+    HIP_TRY(ctx, hipMemcpy(dCost.p, cost, nCost * 8, hipMemcpyHostToDevice));
+    if (nRow) HIP_TRY(ctx, hipMemcpy(dMeta.p, meta.data(), meta.size(), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemsetAsync(dOut.p, 0xFF, oGain, ctx->stream));          // indices of infeasible problems: -1
+    HIP_TRY(ctx, hipMemsetAsync(dOut.as<unsigned char>() + oGain, 0, oEnd - oGain, ctx->stream));
+    unsigned char *ob = dOut.as<unsigned char>(), *mb = dMeta.as<unsigned char>();
+    kbest_opts o;
+    kbest_default_opts(&o);
+    o.maximize = maximize ? 1 : 0;
+    o.flags = KBEST_FLAG_RECT_ROOT | (shift ? 0u : KBEST_FLAG_NO_SHIFT);
+    DevExtra ex;
+    ex.dualU = reinterpret_cast<double *>(ob + oU);
+    ex.dualV = reinterpret_cast<double *>(ob + oV);
+    ex.gainCols = gainCols;
+    int rc = batch_dev_impl(ctx, &o, B, maxRow, maxCol, nRow ? reinterpret_cast<int32_t *>(mb) : nullptr,
+                            nRow ? reinterpret_cast<int32_t *>(mb + B4) : nullptr, dCost.as<double>(),
+                            costOff ? reinterpret_cast<int64_t *>(mb + 2 * B4) : nullptr, 1,
+                            reinterpret_cast<int32_t *>(ob + oR4C), reinterpret_cast<int32_t *>(ob + oC4R),
+                            reinterpret_cast<double *>(ob + oGain), reinterpret_cast<int32_t *>(ob + oNf), nullptr,
+                            ctx->stream, true, &ex);
+    if (rc != KBEST_OK) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<unsigned char> out(oEnd);
+    HIP_TRY(ctx, hipMemcpy(out.data(), dOut.p, oEnd, hipMemcpyDeviceToHost));
+    memcpy(row4col, out.data() + oR4C, (size_t)B * maxCol * 4);
+    memcpy(col4row, out.data() + oC4R, (size_t)B * maxRow * 4);
+    memcpy(feasible, out.data() + oNf, (size_t)B * 4);
+    memcpy(gain, out.data() + oGain, (size_t)B * 8);
+    if (u) memcpy(u, out.data() + oU, (size_t)B * maxCol * 8);
+    if (v) memcpy(v, out.data() + oV, (size_t)B * maxRow * 8);
+    for (int b = 0; b < B; b++) {
+        if (feasible[b] < 0) return fail(ctx, KBEST_ERR_INTERNAL, "kbest_assign_batch_f64: a problem came back with nf < 0");
+        if (feasible[b] == 0) gain[b] = -1.0;  // shortestPathCPP's infeasibility marker (cpp:200)
+    }
+    return KBEST_OK;
+}
+
+int kbest_to_probs_f64(kbest_ctx *ctx, double *x, int64_t n)
+{
+    if (!ctx) return KBEST_ERR_BAD_ARG;
+    if (n < 0 || (n > 0 && !x)) return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_to_probs_f64: bad argument");
+    if (n == 0) return KBEST_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf d;
+    HIP_TRY(ctx, d.alloc(ctx, (size_t)n * 8));
+    HIP_TRY(ctx, hipMemcpy(d.p, x, (size_t)n * 8, hipMemcpyHostToDevice));
+    hipError_t e = kb::launch_to_probs(d.as<double>(), (long long)n, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "toProbs kernel launch", e);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(x, d.p, (size_t)n * 8, hipMemcpyDeviceToHost));
     return KBEST_OK;
 }
 
@@ -618,9 +803,9 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
     o.use_cutoff = bruteForce ? 0 : 1;  // assignment.cpp:594: kBest2DCutoff(..., cutoff = 42); :880: plain kBest2D
     o.cutoff = 42.0;
     // the weights only need row4col: no col4row table
-    int rc = kbest_batch_f64_dev(ctx, &o, B, maxRow, maxCol, solveRows, dNC.as<int32_t>(), solveCost,
-                                 dOff.as<int64_t>(), k, dR4C.as<int32_t>(), nullptr, dGain.as<double>(),
-                                 dNf.as<int32_t>(), nullptr, ctx->stream);
+    int rc = batch_dev_impl(ctx, &o, B, maxRow, maxCol, solveRows, dNC.as<int32_t>(), solveCost,
+                            dOff.as<int64_t>(), k, dR4C.as<int32_t>(), nullptr, dGain.as<double>(),
+                            dNf.as<int32_t>(), nullptr, ctx->stream, true);
     if (rc != KBEST_OK) return rc;
     kb::WeightParams w;
     w.nL = weightNL;
@@ -685,8 +870,9 @@ int kbest_quadric_costs_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int3
                             double *cost)
 {
     if (!ctx) return KBEST_ERR_BAD_ARG;
-    if (!nL || !nM || !landMean || !landCov || !measMean || !measCov || !cost)
+    if (B < 0 || !nL || !nM || !landMean || !landCov || !measMean || !measCov || !cost)
         return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_quadric_costs_f64: bad argument");
+    if (B == 0) return KBEST_OK;
     std::vector<int64_t> off;
     packed_cost_offsets(B, nL, nM, off);
     QuadricHost q{landMean, landCov, measMean, measCov, gate};
@@ -700,8 +886,9 @@ int kbest_quadric_assoc_probs_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL
                                         const int64_t *probOff, int32_t *nf)
 {
     if (!ctx) return KBEST_ERR_BAD_ARG;
-    if (!nL || !nM || !landMean || !landCov || !measMean || !measCov)
+    if (B < 0 || !nL || !nM || !landMean || !landCov || !measMean || !measCov)
         return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_quadric_assoc_probs_batch_f64: bad argument");
+    if (B == 0) return KBEST_OK;
     std::vector<int64_t> off;
     packed_cost_offsets(B, nL, nM, off);
     QuadricHost q{landMean, landCov, measMean, measCov, gate};
@@ -768,9 +955,9 @@ int kbest_bb_match_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int
     kbest_opts o;
     kbest_default_opts(&o);
     o.maximize = 1;  // assignment.cpp:749-750: kBest2D(k = 1, maximize = true)
-    int rc = kbest_batch_f64_dev(ctx, &o, B, maxRow, maxCol, dNRow.as<int32_t>(), dNL.as<int32_t>(), dCost.as<double>(),
-                                 dOC.as<int64_t>(), 1, dR4C.as<int32_t>(), dC4R.as<int32_t>(), dGain.as<double>(),
-                                 dNf.as<int32_t>(), nullptr, ctx->stream);
+    int rc = batch_dev_impl(ctx, &o, B, maxRow, maxCol, dNRow.as<int32_t>(), dNL.as<int32_t>(), dCost.as<double>(),
+                            dOC.as<int64_t>(), 1, dR4C.as<int32_t>(), dC4R.as<int32_t>(), dGain.as<double>(),
+                            dNf.as<int32_t>(), nullptr, ctx->stream, true);
     if (rc != KBEST_OK) return rc;
     e = kb::launch_bb_assign(bp, dR4C.as<int>(), dNf.as<int>(), 1, maxCol, B, ctx->stream);
     if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "bounding-box assign kernel launch", e);

@@ -154,4 +154,33 @@ hipError_t launch_bb_assign(const BoxParams &p, const int *row4col, const int *n
     return hipGetLastError();
 }
 
+
+// toProbs (assignment.h:19, assignment.cpp:527-542): m = min of the vector; x -> exp(m - x) where m + 42 > x, else 0.
+// One workgroup; in place.  (The reference uses it on the permanent path only; it is elementwise, so this is all of it.)
+__global__ void __launch_bounds__(256) to_probs_kernel(double *x, long long n)
+{
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    double m = c_inf();
+    for (long long i = tid; i < n; i += 256) m = x[i] < m ? x[i] : m;  // std::min_element: first minimum, same value
+    red[tid] = m;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w) red[tid] = red[tid + w] < red[tid] ? red[tid + w] : red[tid];
+        __syncthreads();
+    }
+    m = red[0];
+    const double GATE = 42.0;  // assignment.cpp:9
+    for (long long i = tid; i < n; i += 256) {
+        const double c = x[i];
+        x[i] = (m + GATE > c) ? exp(m - c) : 0.0;  // :536-540
+    }
+}
+
+hipError_t launch_to_probs(double *x, long long n, hipStream_t stream)
+{
+    hipLaunchKernelGGL(to_probs_kernel, dim3(1), dim3(256), 0, stream, x, n);
+    return hipGetLastError();
+}
+
 }  // namespace kb

@@ -40,6 +40,9 @@ struct Params {
     int spec;                 // candidates re-solved / split per round (1 = the reference's order exactly)
     unsigned long long *prof; // [B][16] cycle stamps; only read by diagnostic builds (make PROFILE=1)
     unsigned short *slotSid;  // workspace: [B][slot_table_stride(k)] state slot of each output slot
+    double *dualU;            // [B][ldCol] duals of the root solution per column (MurtyHyp::u), or nullptr
+    double *dualV;            // [B][ldRow] ... per row (MurtyHyp::v), or nullptr
+    int gainCols;             // numCol4Gain of shortestPathCPP (cpp:232); 0 = numCol
 };
 
 struct CondParams {
@@ -200,6 +203,7 @@ hipError_t launch_bb_assign(const BoxParams &p, const int *row4col, const int *n
                             hipStream_t stream);
 hipError_t launch_weights(const WeightParams &p, int B, hipStream_t stream);
 hipError_t launch_condition(const CondParams &p, int B, hipStream_t stream);
+hipError_t launch_to_probs(double *x, long long n, hipStream_t stream);
 
 }  // namespace kb
 #endif

@@ -423,6 +423,12 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     const double *Cg = p.cost + (p.costOff ? p.costOff[b] : (long long)b * p.ldRow * p.ldCol);
     const bool maximize = p.maximize != 0, useCut = p.useCutoff != 0;
     const bool prune = (p.flags & KBEST_FLAG_NO_PRUNE) == 0;
+    // assign2D / shortestPathCPP semantics (cpp:119-238, 735-762): numCol augmentations on the rectangular problem,
+    // unassigned rows stay -1, no zero-padded columns; NO_SHIFT: the matrix is already "safe" (shortestPathCPP is
+    // called on workMem.C as it is)
+    const bool rect = (p.flags & KBEST_FLAG_RECT_ROOT) != 0;
+    const bool noShift = (p.flags & KBEST_FLAG_NO_SHIFT) != 0;
+    const int gainCols = (p.gainCols > 0 && p.gainCols < M) ? p.gainCols : M;  // numCol4Gain (cpp:232)
     const int rl = lane < D ? lane : D - 1;
     const u64 allRows = (D >= 64) ? ~0ull : ((1ull << D) - 1ull);
     const int maxSid = p.statesPerProblem;
@@ -445,7 +451,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         __syncthreads();
         mn = red[0];
         for (int w = 1; w < NW; w++) mn = min_keep(mn, red[w]);
-        const double cdel = maximize ? -mn : mn;
+        const double cdel = noShift ? 0.0 : (maximize ? -mn : mn);
         __syncthreads();
         double cm = 0.0;
         for (int c = wave; c < D; c += NW)
@@ -453,7 +459,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 double val = 0.0;
                 if (c < M) {
                     const double x = Cg[r + (long long)c * N];
-                    val = maximize ? (-x + cdel) : (x - cdel);  // cpp:558 / cpp:564
+                    val = noShift ? x : (maximize ? (-x + cdel) : (x - cdel));  // cpp:558 / cpp:564
                     // inf - inf (e.g. an all-inf matrix) gives NaN; every comparison the reference makes with
                     // a NaN reduced cost is false (cpp:185, 314), i.e. the arc behaves exactly like +inf.  The
                     // integer-key compare of the Dijkstra step needs that made explicit.
@@ -535,7 +541,8 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         int c4r = -1, r4c = -1, pred, sink = 0;
         u64 scanned;
         bool bad = false;
-        for (int c = 0; c < D; c++) {
+        const int nAug = rect ? M : D;
+        for (int c = 0; c < nAug; c++) {
             if (dijkstra<false>(Cs, LDC, nd.u, rl, lane, v, c4r, allRows, 0ull, c, INF, spc, pred, scanned, delta,
                                 sink)) { bad = true; break; }
             dual_update_flip(nd.u, lane, v, c4r, r4c, spc, pred, scanned, delta, sink, c);
@@ -543,9 +550,11 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         if (bad) {
             if (lane == 0) ctrl->stop = 3;
         } else {
-            const double g = serial_gain(Cs, LDC, lane, r4c, M, gainW);
+            const double g = serial_gain(Cs, LDC, lane, r4c, gainCols, gainW);
             const u64 forb = bit64(__builtin_amdgcn_readlane(r4c, 0));  // cpp:235
             save_node(nd, 0, v, r4c, c4r, forb, g, 0);
+            if (p.dualU && lane < M) p.dualU[(long long)b * p.ldCol + lane] = nd.u[lane];  // MurtyHyp::u, per column (hpp:53)
+            if (p.dualV && lane < N) p.dualV[(long long)b * p.ldRow + lane] = v;           // MurtyHyp::v, per row (hpp:55)
             if (lane == 0) {
                 ctrl->cutoffGain = maximize ? (g - p.cutoff) : (g + p.cutoff);          // cpp:681/684
                 const double gu = maximize ? (-g + ctrl->cdelta) : (g + ctrl->cdelta);  // cpp:599-603
@@ -1054,7 +1063,10 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         const int s = idx / (N + M), j = idx - s * (N + M);
         const unsigned char *st = stBase + (long long)slotSid[s] * p.stateStride;
         if (j < M) p.row4col[(outBase + s) * p.ldCol + j] = st[offR4C + j];
-        else if (p.col4row) p.col4row[(outBase + s) * p.ldRow + (j - M)] = st[offC4R + (j - M)];
+        else if (p.col4row) {
+            const int cv = st[offC4R + (j - M)];
+            p.col4row[(outBase + s) * p.ldRow + (j - M)] = (rect && cv == 255) ? -1 : cv;  // unassigned row (cpp:134)
+        }
     }
     if (tid == 0) {
         p.nf[b] = nf;

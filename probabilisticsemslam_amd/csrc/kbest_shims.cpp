@@ -106,19 +106,52 @@ size_t kBest2DCutoff(const size_t k, const size_t numRow, const size_t numCol, c
     return n;
 }
 
+namespace {
+
+// Root solution of one rectangular problem with duals (kbest_assign_batch_f64), written into a MurtyHyp the way
+// shortestPathCPP leaves it (cpp:134-139, 228-237).  Returns feasible (1/0).
+int assign_one(const size_t numRow, const size_t numCol, const bool maximize, const bool shift, const size_t numCol4Gain,
+               const double *C, MurtyHyp *sol)
+{
+    kbest_ctx *ctx = global_ctx();
+    std::vector<int32_t> r4c(numCol), c4r(numRow);
+    std::vector<double> u(numCol), v(numRow);
+    double g = 0.0;
+    int32_t ok = 0;
+    check(ctx, kbest_assign_batch_f64(ctx, 1, (int)numRow, (int)numCol, nullptr, nullptr, C, nullptr, maximize ? 1 : 0,
+                                      shift ? 1 : 0, (int)numCol4Gain, r4c.data(), c4r.data(), &g, u.data(), v.data(), &ok));
+    sol->activeCol = 0;
+    sol->solved = true;
+    sol->gain = g;  // -1 when infeasible (cpp:200)
+    if (!ok) return 0;
+    for (size_t r = 0; r < numRow; r++) { sol->col4row[r] = c4r[r]; sol->v[r] = v[r]; sol->forbiddenActiveRows[r] = false; }
+    for (size_t c = 0; c < numCol; c++) { sol->row4col[c] = r4c[c]; sol->u[c] = u[c]; }
+    sol->forbiddenActiveRows[sol->row4col[0]] = true;  // cpp:235
+    return 1;
+}
+
+}  // namespace
+
 int assign2D(const size_t numRow, const size_t numCol, const bool maximize, const double *C, ScratchSpace &,
              MurtyHyp *problemSol)
 {
-    // Best assignment of the numRow x numCol problem (cpp:735-762).  The engine solves the zero-padded
-    // square problem; rows it parks on padded columns are the reference's unassigned rows (-1).
-    std::vector<ptrdiff_t> c4r(numRow), r4c(numCol);
-    double g = 0.0;
-    if (kbest_one(1, numRow, numCol, maximize, C, false, 0.0, c4r.data(), r4c.data(), &g) == 0) return 0;
-    for (size_t r = 0; r < numRow; r++) problemSol->col4row[r] = c4r[r] >= (ptrdiff_t)numCol ? -1 : c4r[r];
-    for (size_t c = 0; c < numCol; c++) problemSol->row4col[c] = r4c[c];
-    problemSol->gain = g;
-    problemSol->solved = true;
-    return 1;
+    // cpp:735-762: makeCostMatrixSafe, numCol augmentations on the RECTANGULAR problem (unassigned rows stay -1),
+    // gain un-shifted; problemSol also receives the dual variables, as in the reference
+    return assign_one(numRow, numCol, maximize, true, numCol, C, problemSol);
+}
+
+int shortestPathCPP(MurtyHyp *problemSol, ScratchSpace &workMem, const size_t numRow, const size_t numCol,
+                    const size_t numCol4Gain)
+{
+    // hpp:178-182 / cpp:119-238: the root LAP on the (already non-negative) matrix in workMem.C; returns 1 and
+    // gain = -1 when infeasible (cpp:197-203)
+    return assign_one(numRow, numCol, false, false, numCol4Gain, workMem.C, problemSol) ? 0 : 1;
+}
+
+void toProbs(std::vector<double> &costMatrix)
+{
+    kbest_ctx *ctx = global_ctx();
+    check(ctx, kbest_to_probs_f64(ctx, costMatrix.data(), (int64_t)costMatrix.size()));
 }
 
 std::vector<std::vector<double>> assignmentProb(const std::vector<double> &costMatrix, size_t nL, size_t nM, size_t k)

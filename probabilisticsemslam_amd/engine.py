@@ -21,7 +21,7 @@ C_ABI_SYMBOLS = (
     "kbest_device_count", "kbest_batch_f64_dev", "kbest_batch_f64", "kbest_reserve", "kbest_weights_batch_f64",
     "kbest_set_profile_buffer", "kbest_condition_costs_f64", "kbest_assoc_probs_batch_f64",
     "kbest_quadric_costs_f64", "kbest_quadric_assoc_probs_batch_f64", "kbest_bb_match_batch_f64",
-    "kbest_bruteforce_probs_batch_f64",
+    "kbest_bruteforce_probs_batch_f64", "kbest_assign_batch_f64", "kbest_to_probs_f64",
 )
 
 
@@ -76,6 +76,9 @@ def load_library():
     lib.kbest_quadric_assoc_probs_batch_f64.argtypes = [vp, C.c_int, i32p, i32p, dp, dp, dp, dp, C.c_double, C.c_int,
                                                         dp, i64p, i32p]
     lib.kbest_bb_match_batch_f64.argtypes = [vp, C.c_int, i32p, i32p, dp, dp, C.c_double, i32p]
+    lib.kbest_assign_batch_f64.argtypes = [vp, C.c_int, C.c_int, C.c_int, i32p, i32p, dp, i64p, C.c_int, C.c_int, C.c_int,
+                                           i32p, i32p, dp, dp, dp, i32p]
+    lib.kbest_to_probs_f64.argtypes = [vp, dp, C.c_int64]
     _lib = lib
     return lib
 
@@ -148,6 +151,24 @@ class KBestEngine:
         if count_pushed:
             return nf, r4c, c4r, gain, pushed
         return nf, r4c, c4r, gain
+
+    def assign(self, costs, N, M, maximize=False, shift=True, gain_cols=0):
+        """Batched assign2D (shift=True) / shortestPathCPP (shift=False) on uniform N x M problems, costs (B, N*M).
+        Returns (feasible[B], row4col[B,M], col4row[B,N] (-1 = unassigned), gain[B], u[B,M], v[B,N])."""
+        costs = np.ascontiguousarray(costs, dtype=np.float64).reshape(-1, N * M)
+        B = costs.shape[0]
+        r4c = np.empty((B, M), np.int32); c4r = np.empty((B, N), np.int32)
+        g = np.empty(B); u = np.empty((B, M)); v = np.empty((B, N)); ok = np.empty(B, np.int32)
+        self._check(self.lib.kbest_assign_batch_f64(self.ctx, B, N, M, None, None, _ptr(costs), None, int(bool(maximize)),
+                                                    int(bool(shift)), int(gain_cols), _ptr(r4c), _ptr(c4r), _ptr(g), _ptr(u),
+                                                    _ptr(v), _ptr(ok)))
+        return ok, r4c, c4r, g, u, v
+
+    def to_probs(self, x):
+        """toProbs (assignment.h:19): returns exp(min - x) with the 42 gate."""
+        x = np.array(x, dtype=np.float64).reshape(-1)
+        self._check(self.lib.kbest_to_probs_f64(self.ctx, _ptr(x), x.size))
+        return x
 
     def condition_costs(self, costs, nRows, nCols):
         """Batched conditionCosts.  Returns (list of conditioned 1-D blocks, list of rowIdx arrays)."""
@@ -243,6 +264,8 @@ class KBestEngine:
         torch.cuda.current_stream().cuda_stream).  All d_* are torch CUDA tensors."""
         flags = (KBEST_FLAG_COUNT_PUSHED if d_pushed is not None else 0) | (0 if prune else KBEST_FLAG_NO_PRUNE)
         o = self._opts(maximize, cutoff, flags, root_shard)
+        # the C entry never allocates (kbest_c.h): size the workspace here (a no-op once it is large enough)
+        self.reserve(B, N, k)
 
         def dp(t):
             return None if t is None else C.c_void_p(t.data_ptr())

@@ -82,5 +82,62 @@ int main(int argc, char **argv)
         for (double x : q[m]) printf(" %a", x);
         printf("\n");
     }
+    // toProbs (assignment.h:19) on the conditioned block
+    std::vector<double> tp = cond;
+    toProbs(tp);
+    printf("t");
+    for (double x : tp) printf(" %a", x);
+    printf("\n");
+
+    // assign2D on a rectangular maximise problem, with everything the reference leaves in the MurtyHyp
+    // (cpp:735-762): 12 x 5, costs 10 * u01 - 3 of stream 201 (= tests/golden/assign_golden.npz "rect_12x5_max")
+    {
+        const size_t R = 12, Cc = 5;
+        sm_state = 201;
+        std::vector<double> A(R * Cc);
+        for (auto &x : A) x = u01() * 10 - 3;
+        ScratchSpace ws;
+        ws.init(R, R);
+        MurtyHyp h(R, R);
+        int ok2 = assign2D(R, Cc, true, A.data(), ws, &h);
+        printf("assign2D_rect ok %d g %a solved %d activeCol %zu r4c", ok2, h.gain, (int)h.solved, h.activeCol);
+        for (size_t c = 0; c < Cc; c++) printf(" %td", h.row4col[c]);
+        printf(" c4r");
+        for (size_t r = 0; r < R; r++) printf(" %td", h.col4row[r]);
+        printf(" u");
+        for (size_t c = 0; c < Cc; c++) printf(" %a", h.u[c]);
+        printf(" v");
+        for (size_t r = 0; r < R; r++) printf(" %a", h.v[r]);
+        printf(" forb");
+        for (size_t r = 0; r < R; r++) printf(" %d", (int)h.forbiddenActiveRows[r]);
+        printf("\n");
+        // infeasible: one column all +inf ("infeasible_6x4": stream 208, entries 6..11)
+        sm_state = 208;
+        std::vector<double> I(6 * 4);
+        for (auto &x : I) x = u01();
+        for (int i = 6; i < 12; i++) I[i] = std::numeric_limits<double>::infinity();
+        MurtyHyp hi(6, 6);
+        ws.init(6, 6);
+        printf("assign2D_infeasible ok %d\n", assign2D(6, 4, false, I.data(), ws, &hi));
+        // shortestPathCPP on workMem.C as it is, gain over 4 of 10 columns ("spc_10x10_g4": stream 209)
+        sm_state = 209;
+        ws.init(10, 10);
+        for (size_t i = 0; i < 100; i++) ws.C[i] = u01();
+        MurtyHyp hs(10, 10);
+        int rc = shortestPathCPP(&hs, ws, 10, 10, 4);
+        printf("shortestPathCPP rc %d g %a r4c", rc, hs.gain);
+        for (size_t c = 0; c < 10; c++) printf(" %td", hs.row4col[c]);
+        printf(" u");
+        for (size_t c = 0; c < 10; c++) printf(" %a", hs.u[c]);
+        printf("\n");
+        // infeasible: column 1 all +inf ("spc_infeasible_4x4": stream 212)
+        ws.init(4, 4);
+        sm_state = 212;
+        for (size_t i = 0; i < 16; i++) ws.C[i] = u01();
+        for (int i = 4; i < 8; i++) ws.C[i] = std::numeric_limits<double>::infinity();
+        MurtyHyp h4(4, 4);
+        rc = shortestPathCPP(&h4, ws, 4, 4, 4);
+        printf("shortestPathCPP_infeasible rc %d g %a\n", rc, h4.gain);
+    }
     return 0;
 }

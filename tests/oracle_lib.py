@@ -48,6 +48,8 @@ def oracle():
                                         _i32p, _i32p, _dp, _i32p, C.c_void_p]
         lib.orc_assign2d.restype = C.c_int
         lib.orc_assign2d.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _i32p, _i32p, _dp]
+        lib.orc_assign2d_ex.restype = C.c_int
+        lib.orc_assign2d_ex.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _i32p, _i32p, _dp, _dp, _dp]
         lib.orc_condition_costs.restype = C.c_int
         lib.orc_condition_costs.argtypes = [_dp, C.c_int, C.c_int, _dp, _i32p]
         lib.orc_to_probs.restype = None
@@ -86,6 +88,9 @@ def ref(ofast: bool = False):
                                            C.c_double]
         lib.ref_assign2d.restype = C.c_int
         lib.ref_assign2d.argtypes = [C.c_int64, C.c_int64, C.c_int, _dp, _i64p, _i64p, _dp]
+        if hasattr(lib, "ref_assign2d_ex"):
+            lib.ref_assign2d_ex.restype = C.c_int
+            lib.ref_assign2d_ex.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64, _dp, _i64p, _i64p, _dp, _dp, _dp]
         lib.ref_kbest2d_batch.restype = C.c_int64
         lib.ref_kbest2d_batch.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, _dp,
                                           _i64p, _i64p, _dp, _i64p]
@@ -183,6 +188,24 @@ def ref_kbest(cost, N, M, k, maximize=False, cutoff=None, ofast=False):
         nf = lib.ref_kbest2d_cutoff(k, N, M, int(maximize), cost, c4r.reshape(-1), r4c.reshape(-1), g,
                                     float(cutoff))
     return int(nf), r4c, c4r, g
+
+
+def orc_assign2d_ex(cost, N, M, maximize=False, shift=True, gain_cols=0):
+    """Oracle assign2D / shortestPathCPP with duals: (ok, row4col[M], col4row[N], gain, u[M], v[N])."""
+    cost = np.ascontiguousarray(cost, dtype=np.float64).reshape(-1)
+    c4r = np.full(N, -1, np.int32); r4c = np.full(M, -1, np.int32)
+    g = np.zeros(1); u = np.zeros(M); v = np.zeros(N)
+    ok = oracle().orc_assign2d_ex(N, M, int(maximize), int(shift), gain_cols, cost, c4r, r4c, g, u, v)
+    return ok, r4c, c4r, float(g[0]), u, v
+
+
+def ref_assign2d_ex(cost, N, M, maximize=False, shift=True, gain_cols=0):
+    """The compiled reference's assign2D (shift) / shortestPathCPP (no shift) with duals."""
+    cost = np.ascontiguousarray(cost, dtype=np.float64).reshape(-1)
+    c4r = np.full(N, -1, np.int64); r4c = np.full(M, -1, np.int64)
+    g = np.zeros(1); u = np.zeros(M); v = np.zeros(N)
+    ok = ref().ref_assign2d_ex(N, M, int(maximize), int(shift), gain_cols, cost, c4r, r4c, g, u, v)
+    return ok, r4c, c4r, float(g[0]), u, v
 
 
 def canon_col4row(c4r, M):

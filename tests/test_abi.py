@@ -34,7 +34,8 @@ def test_reference_named_cpp_shims_exported():
     out = subprocess.check_output(["nm", "-D", "--defined-only", pk.lib_path()], text=True)
     for sym in ("_Z7kBest2DmmmbPKdR12ScratchSpacePlS3_Pd", "_Z13kBest2DCutoffmmmbPKdR12ScratchSpacePlS3_Pdd",
                 "_Z8assign2DmmbPKdR12ScratchSpaceP8MurtyHyp", "_Z14assignmentProbRKSt6vectorIdSaIdEEmmm",
-                "_Z14conditionCostsRKSt6vectorIdSaIdEEmmRS_IlSaIlEE", "_Z14bruteForceProbRKSt6vectorIdSaIdEEmm"):
+                "_Z14conditionCostsRKSt6vectorIdSaIdEEmmRS_IlSaIlEE", "_Z14bruteForceProbRKSt6vectorIdSaIdEEmm",
+                "_Z15shortestPathCPPP8MurtyHypR12ScratchSpacemmm", "_Z7toProbsRSt6vectorIdSaIdEE"):
         assert sym in out, sym
 
 

@@ -316,6 +316,41 @@ def test_cpp_shims_drop_in(eng, tmp_path):
         assert out[i + 5 + m].startswith("q")
         got = np.array([float.fromhex(x) for x in out[i + 5 + m].split()[1:]])
         np.testing.assert_allclose(got, qo[m], rtol=1e-12, atol=1e-15)
+    # toProbs, assign2D (rectangular / maximise / infeasible, with duals), shortestPathCPP: against the goldens
+    # recorded from the reference itself
+    zw = np.load(os.path.join(root, "tests", "golden", "weights_golden.npz"))
+    za = np.load(os.path.join(root, "tests", "golden", "assign_golden.npz"))
+    i += 8
+    assert out[i].startswith("t ")
+    tp = cond.copy()
+    ol.oracle().orc_to_probs(tp, tp.size)
+    np.testing.assert_allclose([float.fromhex(x) for x in out[i].split()[1:]], tp, rtol=1e-14, atol=0)
+    assert zw["small_f0/toProbs"].tolist() == tp.tolist()  # (the block is golden frame small_f0)
+
+    def fields(line, keys):
+        toks = line.split()
+        pos = {k: toks.index(k) for k in keys}
+        order = sorted(pos.values()) + [len(toks)]
+        return {k: toks[pos[k] + 1: order[order.index(pos[k]) + 1]] for k in keys}
+
+    f = fields(out[i + 1], ["ok", "g", "solved", "activeCol", "r4c", "c4r", "u", "v", "forb"])
+    assert out[i + 1].startswith("assign2D_rect") and f["ok"] == ["1"] and f["solved"] == ["1"] and f["activeCol"] == ["0"]
+    assert float.fromhex(f["g"][0]) == float(za["rect_12x5_max/gain"][0])
+    assert list(map(int, f["r4c"])) == za["rect_12x5_max/row4col"].tolist()
+    assert list(map(int, f["c4r"])) == za["rect_12x5_max/col4row"].tolist()
+    assert [float.fromhex(x) for x in f["u"]] == za["rect_12x5_max/u"].tolist()
+    assert [float.fromhex(x) for x in f["v"]] == za["rect_12x5_max/v"].tolist()
+    forb = [0] * 12
+    forb[int(za["rect_12x5_max/row4col"][0])] = 1
+    assert list(map(int, f["forb"])) == forb                     # cpp:235
+    assert out[i + 2] == "assign2D_infeasible ok 0"
+    f = fields(out[i + 3], ["rc", "g", "r4c", "u"])
+    assert out[i + 3].startswith("shortestPathCPP ") and f["rc"] == ["0"]
+    assert float.fromhex(f["g"][0]) == float(za["spc_10x10_g4/gain"][0])
+    assert list(map(int, f["r4c"])) == za["spc_10x10_g4/row4col"].tolist()
+    assert [float.fromhex(x) for x in f["u"]] == za["spc_10x10_g4/u"].tolist()
+    f = fields(out[i + 4], ["rc", "g"])
+    assert f["rc"] == ["1"] and float.fromhex(f["g"][0]) == -1.0   # cpp:197-203
 
 
 def test_quadric_costs_and_full_association_chain(eng):

@@ -1,8 +1,9 @@
 #!/bin/bash
-# tools/gpu_check.sh [tag] -- on the GPU box: GPU parity tests, then the default bench line.
+# tools/gpu_check.sh [tag] [pytest-args] -- on the GPU box: GPU parity tests, then the default bench line.
 tag=${1:-check}
+shift
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests -x -q -m gpu > gpurun_out/pytest_gpu_$tag.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/pytest_gpu_$tag.log
+timeout 1500 python -m pytest tests -x -q -m gpu "$@" > gpurun_out/pytest_gpu_$tag.log 2>&1; echo "pytest rc=$?"; tail -15 gpurun_out/pytest_gpu_$tag.log
 timeout 300 python bench.py --steps 10 --warmup 2 > gpurun_out/bench_$tag.log 2>&1; echo "bench rc=$?"; tail -1 gpurun_out/bench_$tag.log | python3 -c "
 import sys, json
 try:
