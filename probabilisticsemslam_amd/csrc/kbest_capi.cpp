@@ -25,6 +25,8 @@ struct kbest_ctx {
     int spec = 0;     // candidates re-solved / split per round; 0 = choose per launch (choose_spec)
     int ldsPerCU = 160 * 1024;
     int nCU = 256;
+    int smallWaves = 0;  // waves per problem of the small-problem kernel; 0 = choose per launch (KBEST_SMALL_NW)
+    bool noSmall = false;  // KBEST_NO_SMALL: problems of <= 32 rows through the 64-row kernel as well (A/B tests)
     int extraStates = 64;  // lazy state slots beyond k per matrix (room for speculative re-solves)
     int eagerStates = 1024; // state slots per matrix for children that are kept in full when they are found
     unsigned long long *prof = nullptr;  // diagnostic builds only (kbest_set_profile_buffer)
@@ -231,6 +233,11 @@ int kbest_create(kbest_ctx **out, int device)
         int w = atoi(e);
         if (w >= 0 && w <= 60000) ctx->eagerStates = w;
     }
+    if (const char *e = getenv("KBEST_SMALL_NW")) {
+        int w = atoi(e);
+        if (w == 2 || w == 4 || w == 8 || w == 16) ctx->smallWaves = w;
+    }
+    ctx->noSmall = getenv("KBEST_NO_SMALL") != nullptr;
     if (const char *e = getenv("KBEST_SPEC")) {
         int w = atoi(e);
         if (w >= 1 && w <= 16) ctx->spec = w;
@@ -325,10 +332,41 @@ static bool k_fits_fast(const kbest_ctx *ctx, int B, int fastRow, int k, unsigne
            kb::lds_layout(fastRow, k, shape.spec, shape.nWaves).total <= ctx->ldsLimit;
 }
 
+static int ensure_states(kbest_ctx *ctx, size_t need, bool grow);
+
 static int reserve_states(kbest_ctx *ctx, int B, int maxRow, int k, bool grow)
 {
     if (maxRow > KBEST_MAX_DIM) maxRow = KBEST_MAX_DIM;
-    const size_t need = states_need(ctx, B, maxRow, k, nullptr);
+    return ensure_states(ctx, states_need(ctx, B, maxRow, k, nullptr), grow);
+}
+
+// Waves per problem of the small-problem kernel (kbest_small.hip): a batch that cannot fill the chip gets a whole
+// workgroup of 16 waves (32 half-wave workers) per problem -- latency; a large batch small workgroups -- throughput.
+static int small_waves(const kbest_ctx *ctx, int B)
+{
+    if (ctx->smallWaves > 0) return ctx->smallWaves;
+    if (B <= ctx->nCU) return 16;
+    if (B <= 2 * ctx->nCU) return 8;
+    return 4;
+}
+
+static bool small_fits(const kbest_ctx *ctx, int B, int maxRow, int maxCol, int k, bool weights, int *nwOut)
+{
+    if (ctx->noSmall || maxRow > kb::SMALL_MAX_DIM || maxCol > kb::SMALL_MAX_DIM || k > kb::SMALL_MAX_K) return false;
+    int nw = small_waves(ctx, B);
+    while (nw > 2 && kb::small_lds_layout(maxRow, maxCol, k, nw, weights).total > ctx->ldsLimit) nw /= 2;
+    if (kb::small_lds_layout(maxRow, maxCol, k, nw, weights).total > ctx->ldsLimit) return false;
+    if (nwOut) *nwOut = nw;
+    return true;
+}
+
+static size_t small_states_need(int B, int maxRow, int maxCol, int k, int nw)
+{
+    return (size_t)B * (size_t)kb::small_states_per_problem(k, nw, maxCol) * (size_t)kb::small_state_stride(maxRow, maxCol) + 256;
+}
+
+static int ensure_states(kbest_ctx *ctx, size_t need, bool grow)
+{
     if (need <= ctx->statesBytes) return KBEST_OK;
     if (!grow) return fail(ctx, KBEST_ERR_NOT_RESERVED, "hypothesis workspace too small: call kbest_reserve first");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -347,6 +385,11 @@ int kbest_reserve(kbest_ctx *ctx, int B, int maxRow, int k)
     std::lock_guard<std::mutex> lock(ctx->mu);
     const int fastRow = maxRow < KBEST_MAX_DIM ? maxRow : KBEST_MAX_DIM;
     const bool kFits = k_fits_fast(ctx, B, fastRow, k, 0, nullptr) || k_fits_fast(ctx, B, fastRow, k, KBEST_FLAG_COUNT_PUSHED, nullptr);
+    int snw = 0;
+    if (small_fits(ctx, B, maxRow, maxRow, k, false, &snw)) {
+        int rc = ensure_states(ctx, small_states_need(B, maxRow, maxRow, k, snw), true);
+        if (rc != KBEST_OK) return rc;
+    }
     if (kFits) {
         int rc = reserve_states(ctx, B, fastRow, k, true);
         if (rc != KBEST_OK) return rc;
@@ -412,6 +455,39 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
     {
         int rc = order_behind_last(ctx, s);
         if (rc != KBEST_OK) return rc;
+    }
+    // Problems of up to 32 rows: the small-problem kernel (half-wave workers, implicit zero columns).  The modes that
+    // need the reference's exact order of splits (push counting), no pruning, subtree sharding or the duals of the
+    // padded formulation stay on the 64-row kernel.
+    int snw = 0;
+    if (!extra && !forceWide && !(opts->flags & (KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_PRUNE)) && opts->root_col_stride <= 1 &&
+        small_fits(ctx, B, maxRow, maxCol, k, false, &snw)) {
+        int rc = ensure_states(ctx, small_states_need(B, maxRow, maxCol, k, snw), grow);
+        if (rc != KBEST_OK) return rc;
+        kb::SmallParams sp;
+        memset(&sp, 0, sizeof(sp));
+        sp.cost = d_cost;
+        sp.costOff = reinterpret_cast<const long long *>(d_costOff);
+        sp.nRow = d_nRow;
+        sp.nCol = d_nCol;
+        sp.maxRow = maxRow;
+        sp.maxCol = maxCol;
+        sp.ldRow = maxRow;
+        sp.ldCol = maxCol;
+        sp.k = k;
+        sp.maximize = opts->maximize;
+        sp.useCutoff = opts->use_cutoff;
+        sp.cutoff = opts->cutoff;
+        sp.row4col = d_row4col;
+        sp.col4row = d_col4row;
+        sp.gain = d_gain;
+        sp.nf = d_nf;
+        sp.states = ctx->states;
+        sp.stateStride = kb::small_state_stride(maxRow, maxCol);
+        sp.statesPerProblem = kb::small_states_per_problem(k, snw, maxCol);
+        hipError_t e = kb::launch_kbest_small(sp, B, snw, s);
+        if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "small-problem kbest kernel launch", e);
+        return KBEST_OK;
     }
 
     if (runFast) {

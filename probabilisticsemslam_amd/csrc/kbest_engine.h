@@ -195,6 +195,82 @@ __host__ __device__ inline WideLds wide_lds_layout(int maxRow, int maxCol, bool 
     return L;
 }
 
+// ---- small-problem kernel (kbest_small.hip): numRow <= 32.  Half-wave workers (two children per wavefront), the
+//      zero-padded columns of the reference kept implicit, two barriers per round, optional fused
+//      conditionCosts prologue and assignmentProb epilogue (cost block in -> probabilities out, one launch) ----
+constexpr int SMALL_MAX_DIM = 32;
+constexpr int SMALL_MAX_K = 1024;
+constexpr int SMALL_MAX_RAW_ROWS = 2048;  // rows of the unconditioned block (assoc mode)
+
+struct SmallParams {
+    const double *cost;       // packed column-major blocks
+    const long long *costOff; // per-problem offset in doubles, or nullptr (uniform ldRow x ldCol packing)
+    const int *nRow;          // rows per problem, or nullptr (uniform maxRow).  assoc mode: nL + nM of the RAW block
+    const int *nCol;          // columns per problem, or nullptr (uniform maxCol)
+    int maxRow, maxCol;       // solver capacity of this launch (<= 32): LDS tile, state layout
+    int ldRow, ldCol;         // leading dimensions of row4col / col4row outputs and of the default cost packing
+    int k;
+    int maximize, useCutoff;
+    double cutoff;
+    int *row4col;             // [B][k][ldCol] or nullptr
+    int *col4row;             // [B][k][ldRow] or nullptr
+    double *gain;             // [B][k] or nullptr
+    int *nf;                  // [B]; -1 shape error, -2 "does not fit this kernel" (the host re-runs it on the general path)
+    unsigned char *states;    // workspace [B][statesPerProblem] x stateStride
+    long long stateStride;
+    int statesPerProblem;
+    // association weights (assignment.cpp:547-683) fused behind the enumeration
+    int weights;              // 1: write probabilities instead of / besides the assignments
+    int condition;            // 1: conditionCosts first (assignment.cpp:439-525) and scatter back through its row map (:68-74)
+    int gate;                 // 1: assignmentProb (solutions beyond best + 42 are skipped, :622-626); 0: bruteForceProb (:918-923)
+    const int *nL;            // [B] landmarks (weights mode; nRow = nL + nM)
+    double *probs;            // packed [nM][nL+1] per problem
+    const long long *probOff;
+    unsigned long long *prof; // diagnostic builds only
+};
+
+__host__ __device__ inline long long small_state_stride(int maxRow, int maxCol)
+{
+    // u[maxCol] v[maxRow] (fp64), row4col[maxCol] col4row[maxRow] (u8), forbidden-row mask (u32), activeCol, gain; whole 128-byte lines
+    return ((((long long)9 * (maxRow + maxCol) + 7) & ~7LL) + 16 + 127) & ~127LL;
+}
+
+__host__ __device__ inline int small_states_per_problem(int k, int nWaves, int maxCol) { return 2 * k + 2 * nWaves * maxCol + 4; }
+
+struct SmallLds {
+    int offC, offNodes, nodeStride, offPoolG, offPoolM, offPoolS, offFreshG, offFreshM, offFreshS, offFree, offEmitG, offEmitS,
+        offProb, offRowIdx, offColMin, offKeep, offCtrl, total;
+};
+
+__host__ __device__ inline SmallLds small_lds_layout(int maxRow, int maxCol, int k, int nWaves, bool weights)
+{
+    SmallLds L;
+    const int W = 2 * nWaves, S = small_states_per_problem(k, nWaves, maxCol);
+    const int ldc = maxRow | 1;
+    int o = 0;
+    L.offC = o;        o += maxCol * ldc * 8;            // cost tile: the real columns only
+    L.nodeStride = 2 * 256 + 64 + 256;                   // per worker: u[32] v[32] (fp64), col4row[32] row4col[32] (u8), gain-term line
+    L.offNodes = o;    o += W * L.nodeStride;
+    L.offPoolG = o;    o += 2 * k * 8;                   // sorted candidate pool, two buffers: gain
+    L.offEmitG = o;    o += k * 8;                       // gains of the emitted solutions (un-shifted)
+    L.offFreshG = o;   o += W * maxCol * 8;              // children completed in this round
+    L.offProb = o;     o += weights ? maxCol * 33 * 8 : 0;  // probability accumulators [nM][condL + 1]
+    L.offColMin = o;   o += weights ? maxCol * 8 : 0;
+    L.offKeep = o;     o += weights ? (SMALL_MAX_RAW_ROWS / 64) * 8 : 0;  // kept-row bits of conditionCosts
+    L.offPoolM = o;    o += 2 * k * 4;                   //   (parent state, column, flags)
+    L.offFreshM = o;   o += W * maxCol * 4;
+    L.offPoolS = o;    o += 2 * k * 2;                   //   own state slot
+    L.offFreshS = o;   o += W * maxCol * 2;
+    L.offEmitS = o;    o += k * 2;
+    L.offFree = o;     o += S * 2;                       // stack of free state slots
+    L.offRowIdx = o;   o += weights ? 32 * 2 : 0;        // original row of each kept row
+    o = (o + 15) & ~15;
+    L.offCtrl = o;     o += 96;
+    L.total = (o + 15) & ~15;
+    return L;
+}
+
+hipError_t launch_kbest_small(const SmallParams &p, int B, int nWaves, hipStream_t stream);
 hipError_t launch_kbest(const Params &p, int B, int nWaves, hipStream_t stream);
 hipError_t launch_kbest_wide(const WideParams &p, int grid, hipStream_t stream);
 hipError_t launch_quadric_costs(const QuadricParams &p, int B, hipStream_t stream);

@@ -1,0 +1,798 @@
+// kbest_small.hip -- MI355X (gfx950) k-best assignment kernel for problems of up to 32 rows, and the fused
+// association path (cost block in -> probabilities out in ONE launch) built on it.
+//
+// The reference's production caller (getAssignmentProbs, assignment.cpp:38-74, once per frame from
+// system.cpp:268) solves (nL + nM) x nM problems with a few dozen rows: conditionCosts (assignment.cpp:439-525) ->
+// kBest2DCutoff(k, cutoff 42) (shortestPathCPP.cpp:646-733) -> exp-weights (assignment.cpp:616-648).  For these the
+// 64-row kernel of kbest_engine.hip leaves half of every wavefront idle and pays five workgroup barriers per round.
+// This kernel is organised around them instead:
+//
+//   * half-wave workers: a wavefront is two independent 32-lane workers (lane = row).  The Dijkstra step of
+//     shortestPathUpdateCPP (cpp:307-325) runs for two children at once: DPP min-reductions stop at 32 lanes, the
+//     row sets of both children share one 64-bit scalar mask (low / high word), per-child scalars are lane values
+//     that are uniform within a half;
+//   * implicit zero columns: the reference pads an N x M problem to N x N with zero columns (cpp:582-585) so that
+//     inherited duals stay valid when a child frees a row.  Dual feasibility forces every row on a padded column
+//     ("parked") to carry the same v, and all padded columns the same u = -v: once the search has settled ONE parked
+//     row at distance d, every other parked row is at distance d too and scanning their columns changes nothing.
+//     The kernel therefore keeps the padded columns implicit -- when the first parked row is settled all parked rows
+//     are settled with it and one "hub" relaxation (d + v_parked - v[r], no cost column to read) stands for all their
+//     columns.  The root is solved on the rectangular problem (M augmentations instead of N: the reference's root
+//     needs ~N^2/2 Dijkstra steps on a 28 x 10 frame because of the ties on the zero columns), children take 3-4
+//     steps instead of ~10.  In exact arithmetic this is the same shortest-path computation; the assignments,
+//     their order and the gains -- re-summed in the reference's column order from the cost matrix (calcGain,
+//     cpp:59-80) -- are identical; only the internal dual variables differ in the last bits, and col4row numbers the
+//     parked rows M, M+1, ... in ascending row order (values >= M are "padded", not compared);
+//   * owner rounds, two barriers: per round every worker takes one not-yet-split candidate of the sorted pool
+//     (found by ballot walks, redundantly per wave -- no control block to wait for), brings its saved hypothesis in,
+//     filters its children by their first-step minimum, solves the survivors, and appends them to the fresh list;
+//     barrier; rank merge into the other pool buffer; barrier.  Emission bookkeeping is recomputed by every wave
+//     from the pool order, so nothing serial sits between the merge and the next split;
+//   * all completed children are kept in full (no lazy re-solve): hypothesis states live in HBM slots drawn from an
+//     LDS free list, slots of candidates that drop out of the pool are recycled, so 2k + (children of one round)
+//     slots are enough;
+//   * fused association: with `condition` the workgroup runs conditionCosts on the raw block while it loads the
+//     tile; with `weights` the epilogue accumulates exp(best - g) per emitted solution in the reference's order
+//     (assignment.cpp:620-640), normalises and scatters back to the original landmark numbering (:68-74): only
+//     [nM][nL+1] doubles leave the kernel.
+//
+// fp64 add / sub / compare (and exp in the weights) only -- no MFMA.  Compiled without fast-math.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "kbest_engine.h"
+#include "kbest_wave.h"
+
+namespace kb {
+
+namespace {
+
+constexpr int SM_PARKED = 64;  // col4row value of a row that sits on one of the (implicit) zero columns
+constexpr int SM_HUB = 65;     // "column" of the hub relaxation / pred marker "reached through the zero columns"
+constexpr u64 SM_LO = 0x00000000FFFFFFFFull, SM_HI = 0xFFFFFFFF00000000ull;
+constexpr u32 SM_SPLIT = 0x80000000u;  // pool meta: children already generated
+constexpr double SM_GATE = 42.0;       // assignment.cpp:9
+
+__device__ __forceinline__ double sel_f64(u64 mask, double ifset, double ifclear)
+{
+    return __hiloint2double(sel32(mask, __double2hiint(ifset), __double2hiint(ifclear)),
+                            sel32(mask, __double2loint(ifset), __double2loint(ifclear)));
+}
+
+// value for the lower half-wave, value for the upper one -> one lane value
+__device__ __forceinline__ int pick(int forLow, int forHigh) { return sel32(SM_HI, forHigh, forLow); }
+
+// min over each 32-lane half, returned in every lane of that half.  EXEC must be all ones.
+#define KB_HALF_MIN_CHAIN(OP)                                                          \
+    "s_nop 1\n\t" OP " %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"   \
+    "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"   \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"       \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"            \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"          \
+    "s_nop 1\n\t"
+
+__device__ __forceinline__ int half_min_i32(int x)
+{
+    int t;
+    asm volatile(KB_HALF_MIN_CHAIN("v_min_i32_dpp") : "=&v"(t) : "v"(x));
+    return pick(__builtin_amdgcn_readlane(t, 31), __builtin_amdgcn_readlane(t, 63));
+}
+__device__ __forceinline__ u32 half_min_u32(u32 x)
+{
+    u32 t;
+    asm volatile(KB_HALF_MIN_CHAIN("v_min_u32_dpp") : "=&v"(t) : "v"(x));
+    return (u32)pick(__builtin_amdgcn_readlane((int)t, 31), __builtin_amdgcn_readlane((int)t, 63));
+}
+
+// lane `idxLow` of the lower half / lane `idxHigh` of the upper half, broadcast to the respective half
+__device__ __forceinline__ int half_bcast_i32(int x, int idxLow, int idxHigh)
+{
+    return pick(__builtin_amdgcn_readlane(x, idxLow & 31), __builtin_amdgcn_readlane(x, 32 + (idxHigh & 31)));
+}
+__device__ __forceinline__ double half_bcast_f64(double x, int idxLow, int idxHigh)
+{
+    return __hiloint2double(half_bcast_i32(__double2hiint(x), idxLow, idxHigh), half_bcast_i32(__double2loint(x), idxLow, idxHigh));
+}
+
+// Two shortest augmenting paths at once, one per half-wave (lane & 31 = row).  Restates the do{}while of
+// shortestPathCPP (cpp:168-226) / shortestPathUpdateCPP (cpp:297-356) for each half, with the zero-padded columns
+// implicit (file header).  Values named ..v are lane values that are uniform within a half.
+//   Cs, LDC     cost tile (LDS), real columns only
+//   uArr        this half's column duals (LDS pointer, differs between the halves)
+//   v, c4r      this lane's row dual and row -> column (-1 = unassigned: a sink; SM_PARKED = on a zero column)
+//   cand        rows still to scan (bit = lane); forb: rows skipped while the start column itself is scanned (cpp:310)
+//   live        lanes of the halves that take part (all 32 bits of a half, or none)
+//   boundv      early termination (EARLY): a half gives up as soon as its settled distance exceeds it
+// Out per half: spc / pred per row, scanned rows, final distance, sink row, the parked row through which the zero
+// columns were entered (or -1), status 0 = path found, 1 = infeasible (cpp:197, 327), 2 = abandoned.
+template <bool EARLY>
+__device__ __forceinline__ void dijkstra2(const double *Cs, int LDC, const double *uArr, int rl, double v, int c4r, u64 cand,
+                                          u64 forb, u64 live, int startv, double boundv, double &spOut, int &predOut,
+                                          u64 &scannedOut, double &deltaOut, int &sinkOut, int &hubRowOut, int &statusOut)
+{
+    live = uni64(live);
+    cand = uni64(cand) & live;
+    const u64 cand0 = cand;
+    u64 act = cand & ~uni64(forb);
+    u64 liveNow = live;
+    const u64 parked = __ballot(c4r == SM_PARKED);
+    int curv = startv;
+    double delta = 0.0, vk = 0.0;
+    double sp = d_inf();
+    int pred = 0, status = 0, sink = 0, hubRow = -1;
+    while (liveNow) {
+        const bool hub = curv == SM_HUB;
+        const int cc = hub ? 0 : curv;
+        double Cval = Cs[rl + cc * LDC];
+        double uval = uArr[cc];
+        Cval = hub ? 0.0 : Cval;  // a zero column ...
+        uval = hub ? -vk : uval;   // ... whose dual is minus the (common) dual of the parked rows
+        const double rc = ((delta + Cval) - uval) - v;  // cpp:183 / cpp:313, evaluated left to right
+        const u64 upd = __ballot(rc < sp) & act;        // strict '<': cpp:185, 314
+        sp = sel_f64(upd, rc, sp);
+        pred = sel32(upd, curv, pred);
+        // arg-min over the rows still to scan (cpp:191-194, 320-323): lowest row index among equal values
+        int khi;
+        u32 klo;
+        to_key(sp, khi, klo);
+        const u64 candL = cand & liveNow;
+        khi = sel32(candL, khi, 0x7fffffff);
+        const int mhi = half_min_i32(khi);
+        u64 eq = __ballot(khi == mhi) & candL;
+        if (__popc((u32)eq) > 1 || __popc((u32)(eq >> 32)) > 1) {  // several rows on the same high word: compare the low words
+            const u32 t = (u32)sel32(eq, (int)klo, -1);
+            const u32 mlo = half_min_u32(t);
+            eq &= __ballot(t == mlo);
+        }
+        const u32 e0 = (u32)eq, e1 = (u32)(eq >> 32);
+        const int c0 = e0 ? __builtin_ctz(e0) : 0, c1 = e1 ? __builtin_ctz(e1) : 0;
+        const int closest = pick(c0, c1);
+        const double dnew = half_bcast_f64(sp, c0, c1);
+        const int cn = half_bcast_i32(c4r, c0, c1);
+        cand &= ~(((u64)e0 & (0u - e0)) | ((u64)(e1 & (0u - e1)) << 32));  // the chosen rows leave Row2Scan (cpp:208-210)
+        const bool infeas = mhi >= KEY_INF_HI;  // minimum is +inf, or nothing left to scan
+        const bool over = EARLY && !infeas && dnew > boundv;
+        const bool atSink = !infeas && !over && cn < 0;
+        const bool atPark = !infeas && !over && cn == SM_PARKED;
+        const u64 mInf = __ballot(infeas) & liveNow, mOver = __ballot(over) & liveNow;
+        const u64 mSink = __ballot(atSink) & liveNow, mPark = __ballot(atPark) & liveNow;
+        delta = sel_f64(liveNow & ~mInf, dnew, delta);
+        status = sel32(mInf, 1, status);
+        status = sel32(mOver, 2, status);
+        sink = sel32(mSink, closest, sink);
+        if (mPark) {
+            // the first parked row is settled: every parked row is at this distance (equal duals), and their columns
+            // all offer the other rows the same reduced costs -- settle them together, one hub relaxation follows
+            vk = sel_f64(mPark, half_bcast_f64(v, c0, c1), vk);
+            hubRow = sel32(mPark, closest, hubRow);
+            const u64 pk = parked & cand & mPark;
+            sp = sel_f64(pk, dnew, sp);
+            cand &= ~pk;
+        }
+        curv = sel32(liveNow, sel32(mPark, SM_HUB, cn), curv);
+        liveNow &= ~(mInf | mOver | mSink);
+        act = cand & liveNow;
+    }
+    spOut = sp;
+    predOut = pred;
+    scannedOut = cand0 & ~cand;
+    deltaOut = delta;
+    sinkOut = sink;
+    hubRowOut = hubRow;
+    statusOut = status;
+}
+
+// updateDualAndAugment (cpp:82-117) for the halves in `ok`: path flip sink -> start through pred (through the hub:
+// the sink parks, the walk goes on from the parked row the zero columns were entered by), row duals in place,
+// column duals returned (lane & 31 = column; the parent's array must stay intact for its next child).
+__device__ __forceinline__ void augment2(u64 ok, int l, int startv, double sp, int pred, u64 scanned, double delta, int sinkv,
+                                         int hubRowv, const double *uArr, int r4cP, int M, double &v, int &c4r, int &r4c,
+                                         double &uNew)
+{
+    const int hiOff = (int)(__lane_id() & 32u);
+    // duals first (they use the pre-flip column -> row map r4cP)
+    const u64 myBit = 1ull << __lane_id();
+    const bool sc = (scanned & myBit) != 0;
+    if (sc) v = v - delta + sp;  // cpp:102-106
+    {
+        const int rowOfCol = (l < M && r4cP >= 0 && r4cP < 32) ? r4cP : 0;
+        const double spOfRow = __hiloint2double(__shfl(__double2hiint(sp), hiOff + rowOfCol), __shfl(__double2loint(sp), hiOff + rowOfCol));
+        const bool rowScanned = ((scanned >> (hiOff + rowOfCol)) & 1ull) != 0;
+        double un = (l < M) ? uArr[l] : 0.0;
+        if (l < M && l != startv && r4cP >= 0 && rowScanned) un = un + delta - spOfRow;  // cpp:96-99
+        if (l == startv) un = un + delta;                                                // cpp:92
+        uNew = un;
+    }
+    int rv = sinkv;
+    u64 going = uni64(ok);
+    for (int guard = 0; going && guard < 80; guard++) {  // cpp:108-116
+        const int r0 = __builtin_amdgcn_readlane(rv, 0), r1 = __builtin_amdgcn_readlane(rv, 32);
+        const int cv = half_bcast_i32(pred, r0, r1);
+        const bool viaHub = cv == SM_HUB;
+        const int q0 = __builtin_amdgcn_readlane(cv, 0), q1 = __builtin_amdgcn_readlane(cv, 32);
+        const int nxt = half_bcast_i32(r4c, q0 & 31, q1 & 31);
+        const bool mine = ((going >> __lane_id()) & 1ull) != 0;
+        if (mine && l == rv) c4r = viaHub ? SM_PARKED : cv;
+        if (mine && !viaHub && l == cv) r4c = rv;
+        const u64 done = __ballot(!viaHub && cv == startv);
+        rv = viaHub ? hubRowv : nxt;
+        going &= ~done;
+    }
+}
+
+}  // namespace
+
+struct SCtrl {
+    double cdelta;      // CDelta * numCol (cpp:583)
+    double cmax;        // largest finite shifted cost (scale of the pruning margin)
+    unsigned long long cmaxBits;
+    int nFresh[2];      // children appended in the current round (by round parity)
+    int freeTop;        // free state slots on the stack
+    int status;         // 0 ok, 3 infeasible root, -2 does not fit this kernel
+    int N, condL;
+};
+static_assert(sizeof(SCtrl) <= 96, "SCtrl must fit the LDS slot reserved by small_lds_layout");
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NT = NW * 64, W = 2 * NW;
+    const double INF = d_inf();
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int l = lane & 31;
+    const int half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int worker = wave * 2 + half;
+    const u64 myHalf = half ? SM_HI : SM_LO;
+    const int b = blockIdx.x;
+    const int k = p.k;
+    const int M = p.nCol ? p.nCol[b] : p.maxCol;
+    const int NR = p.nRow ? p.nRow[b] : p.maxRow;  // rows of the block as given (condition: of the RAW block)
+    const bool maximize = p.maximize != 0, useCut = p.useCutoff != 0;
+    const SmallLds L = small_lds_layout(p.maxRow, p.maxCol, k, NW, p.weights != 0);
+    const int LDC = p.maxRow | 1;
+    const int S = p.statesPerProblem;
+    double *Cs = reinterpret_cast<double *>(smem + L.offC);
+    double *PG = reinterpret_cast<double *>(smem + L.offPoolG);
+    u32 *PM = reinterpret_cast<u32 *>(smem + L.offPoolM);
+    unsigned short *PS = reinterpret_cast<unsigned short *>(smem + L.offPoolS);
+    double *FG = reinterpret_cast<double *>(smem + L.offFreshG);
+    u32 *FM = reinterpret_cast<u32 *>(smem + L.offFreshM);
+    unsigned short *FS = reinterpret_cast<unsigned short *>(smem + L.offFreshS);
+    unsigned short *freeStack = reinterpret_cast<unsigned short *>(smem + L.offFree);
+    double *EG = reinterpret_cast<double *>(smem + L.offEmitG);
+    unsigned short *ES = reinterpret_cast<unsigned short *>(smem + L.offEmitS);
+    double *prob = reinterpret_cast<double *>(smem + L.offProb);
+    unsigned short *rowIdx = reinterpret_cast<unsigned short *>(smem + L.offRowIdx);
+    double *colMin = reinterpret_cast<double *>(smem + L.offColMin);
+    u64 *keepBits = reinterpret_cast<u64 *>(smem + L.offKeep);
+    SCtrl *ctrl = reinterpret_cast<SCtrl *>(smem + L.offCtrl);
+    // this worker's node block
+    unsigned char *nodeBase = smem + L.offNodes + (size_t)worker * L.nodeStride;
+    double *uArr = reinterpret_cast<double *>(nodeBase);
+    double *nodeV = uArr + 32;
+    unsigned char *nodeC4R = nodeBase + 512;
+    double *gainW = reinterpret_cast<double *>(nodeBase + 576);
+
+    const long long costBase = p.costOff ? p.costOff[b] : (long long)b * p.ldRow * p.ldCol;
+    const double *Cg = p.cost + costBase;
+    const long long outBase = (long long)b * k;
+    double *probOut = p.weights ? p.probs + p.probOff[b] : nullptr;
+    const int nLout = p.weights ? p.nL[b] : 0;  // landmarks in the caller's numbering
+
+    // ---- shapes ---------------------------------------------------------------------------------------------
+    if (M == 0 || NR == 0) {  // an empty frame (getAssignmentProbs returns an empty result, assignment.cpp:50-51)
+        if (tid == 0) p.nf[b] = 0;
+        return;
+    }
+    if (M < 0 || NR < 0 || M > p.maxCol || M > SMALL_MAX_DIM || (!p.condition && (NR > p.maxRow || NR < M)) ||
+        (p.condition && NR > SMALL_MAX_RAW_ROWS)) {
+        if (tid == 0) p.nf[b] = (p.condition && NR > SMALL_MAX_RAW_ROWS) ? -2 : -1;
+        return;
+    }
+    if (p.weights)
+        for (int i = tid; i < M * (nLout + 1); i += NT) probOut[i] = 0.0;
+
+    // ---- phase 0: the cost tile -------------------------------------------------------------------------------
+    if (tid == 0) {
+        ctrl->cmaxBits = 0ull;
+        ctrl->status = 0;
+        ctrl->nFresh[0] = 0;
+        ctrl->nFresh[1] = 0;
+        ctrl->freeTop = S - 1;
+    }
+    int N;  // rows of the problem that is solved
+    double cdel = 0.0;
+    if (p.condition) {
+        // conditionCosts (assignment.cpp:439-525): column minima (:450-458) ...
+        for (int c = wave; c < M; c += NW) {
+            double m = INF;
+            for (int r = lane; r < NR; r += 64) m = min_keep(m, Cg[(long long)c * NR + r]);
+            m = wave_min_f64(m);
+            if (lane == 0) colMin[c] = m;
+        }
+        __syncthreads();
+        // ... a row is kept iff some entry is within 42 of its column's minimum (:462-474) ...
+        const int nChunk = (NR + 63) >> 6;
+        for (int ch = wave; ch < nChunk; ch += NW) {
+            const int r = ch * 64 + lane;
+            bool good = false;
+            if (r < NR)
+                for (int c = 0; c < M; c++) good = good || (Cg[(long long)c * NR + r] <= colMin[c] + SM_GATE);
+            const u64 m = __ballot(good);
+            if (lane == 0) keepBits[ch] = m;
+        }
+        __syncthreads();
+        int g = 0;
+        for (int ch = 0; ch < nChunk; ch++) g += __popcll(keepBits[ch]);
+        if (g > p.maxRow || g < M) {  // does not fit (or undefined in the reference: size_t underflow at :60)
+            if (tid == 0) p.nf[b] = -2;
+            return;
+        }
+        N = g;
+        // ... kept rows are compacted in order; entries become cost - colMin, or +inf beyond the gate (:476-496)
+        double cm = 0.0;
+        for (int r = tid; r < NR; r += NT) {
+            const int ch = r >> 6;
+            const u64 word = keepBits[ch];
+            if (!((word >> (r & 63)) & 1ull)) continue;
+            int nr = __popcll(word & ((1ull << (r & 63)) - 1ull));
+            for (int c2 = 0; c2 < ch; c2++) nr += __popcll(keepBits[c2]);
+            rowIdx[nr] = (unsigned short)r;
+            for (int c = 0; c < M; c++) {
+                const double x = Cg[(long long)c * NR + r];
+                const double val = (x <= colMin[c] + SM_GATE) ? (x - colMin[c]) : INF;
+                // makeCostMatrixSafe (cpp:534-569) on the conditioned matrix: every column holds an exact zero (its
+                // minimum's row is kept), all entries are >= 0, so CDelta = 0 and the shift is the identity
+                Cs[nr + c * LDC] = val;
+                if (val < INF && val > cm) cm = val;
+            }
+        }
+        if (cm > 0.0) atomicMax(&ctrl->cmaxBits, (unsigned long long)__double_as_longlong(cm));
+    } else {
+        N = NR;
+        // makeCostMatrixSafe (cpp:534-569): min of C, or of -C when maximising
+        double *red = FG;
+        double mn = INF;
+        for (int i = tid; i < N * M; i += NT) {
+            double x = Cg[i];
+            x = maximize ? -x : x;
+            mn = min_keep(mn, x);
+        }
+        mn = wave_min_f64(mn);
+        if (lane == 0) red[wave] = mn;
+        __syncthreads();
+        mn = red[0];
+        for (int w = 1; w < NW; w++) mn = min_keep(mn, red[w]);
+        cdel = maximize ? -mn : mn;
+        double cm = 0.0;
+        for (int i = tid; i < N * M; i += NT) {
+            const int c = i / N, r = i - c * N;
+            const double x = Cg[i];
+            double val = maximize ? (-x + cdel) : (x - cdel);  // cpp:558 / cpp:564
+            if (val != val) val = INF;  // inf - inf: every comparison the reference makes with it is false, like +inf
+            if (val < INF && val > cm) cm = val;
+            Cs[r + c * LDC] = val;
+        }
+        if (cm > 0.0) atomicMax(&ctrl->cmaxBits, (unsigned long long)__double_as_longlong(cm));
+    }
+    // free list: slot 0 is the root
+    for (int i = tid; i < S - 1; i += NT) freeStack[i] = (unsigned short)(S - 1 - i);
+    __syncthreads();
+    const double cmaxv = __longlong_as_double((long long)ctrl->cmaxBits);
+    const int nLc = N - M;  // landmarks of the solved problem (condL of assignment.cpp:60)
+
+    // ---- single column: assignmentProb's fast path (assignment.cpp:554-570), no enumeration --------------------
+    if (p.weights && M == 1) {
+        if (tid == 0) {
+            double norm = 0.0;
+            int cnt = 0;
+            for (int i = 0; i <= nLc; i++) {
+                const double c = p.condition ? Cs[i] : Cg[i];
+                if (c < SM_GATE) { norm += exp(-c); cnt++; }
+            }
+            norm = 1.0 / norm;
+            for (int i = 0; i <= nLc; i++) {
+                const double c = p.condition ? Cs[i] : Cg[i];
+                const double q = (c < SM_GATE) ? exp(-c) : 0.0;
+                probOut[(i >= nLc) ? nLout : (p.condition ? (int)rowIdx[i] : i)] = q * norm;
+            }
+            p.nf[b] = cnt < k ? cnt : k;
+        }
+        return;
+    }
+
+    // hypothesis states in HBM: u[MC] v[MR] (fp64) | row4col[MC] col4row[MR] (u8) | forbidden rows (u32), activeCol, gain
+    const int MC = p.maxCol, MR = p.maxRow;
+    unsigned char *stBase = p.states + (long long)b * S * p.stateStride;
+    const int offV = 8 * MC, offR4C = 8 * (MC + MR), offC4R = offR4C + MC, offTail = (9 * (MC + MR) + 7) & ~7;
+    // store the hypothesis the half holds (lane & 31 = column for u / r4c, = row for v / c4r) for the halves in `ok`
+    auto store_state2 = [&](u64 ok, int sidv, double un, double v, int r4c, int c4r, u32 forbv, double g, int av) {
+        if ((ok >> lane) & 1ull) {
+            unsigned char *st = stBase + (long long)sidv * p.stateStride;
+            if (l < M) {
+                reinterpret_cast<double *>(st)[l] = un;
+                st[offR4C + l] = (unsigned char)r4c;
+            }
+            if (l < N) {
+                reinterpret_cast<double *>(st + offV)[l] = v;
+                st[offC4R + l] = (unsigned char)c4r;
+            }
+            if (l == 0) {
+                *reinterpret_cast<u32 *>(st + offTail) = forbv;
+                *reinterpret_cast<int *>(st + offTail + 4) = av;
+                *reinterpret_cast<double *>(st + offTail + 8) = g;
+            }
+        }
+    };
+    // calcGain (cpp:59-80) for both halves: serial left-to-right fp64 sum over the M columns from 0.0
+    auto serial_gain2 = [&](int r4c) -> double {
+        double t = 0.0;
+        if (l < M && r4c >= 0) t = Cs[r4c + l * LDC];
+        gainW[l] = t;
+        wave_fence();
+        double acc = 0.0;
+        for (int j = 0; j < M; j++) acc = acc + gainW[j];
+        wave_fence();
+        return acc;
+    };
+    const int rl = l < N ? l : N - 1;
+    const u32 rowsMask = (N >= 32) ? 0xffffffffu : ((1u << N) - 1u);
+
+    // ---- phase 1: root LAP on the rectangular problem, worker 0 -------------------------------------------------
+    if (wave == 0) {
+        if (l < 32) uArr[l] = 0.0;
+        wave_fence();
+        double v = 0.0, un = 0.0;
+        int c4r = -1, r4c = -1;
+        bool bad = false;
+        for (int c = 0; c < M; c++) {
+            double sp, delta;
+            int pred, sink, hubRow, status;
+            u64 scanned;
+            dijkstra2<false>(Cs, LDC, uArr, rl, v, c4r, (u64)rowsMask, 0ull, SM_LO, c, INF, sp, pred, scanned, delta, sink,
+                             hubRow, status);
+            if (__builtin_amdgcn_readlane(status, 0) != 0) { bad = true; break; }
+            const int r4cBefore = r4c;
+            augment2(SM_LO, l, c, sp, pred, scanned, delta, sink, hubRow, uArr, r4cBefore, M, v, c4r, r4c, un);
+            wave_fence();
+            if (half == 0 && l < M) uArr[l] = un;
+            wave_fence();
+        }
+        if (bad) {
+            if (lane == 0) ctrl->status = 3;
+        } else {
+            if (c4r < 0) c4r = SM_PARKED;  // the free rows sit on the zero columns (all with v = 0)
+            const double g = serial_gain2(r4c);
+            const int r0 = __builtin_amdgcn_readlane(r4c, 0);
+            store_state2(SM_LO, 0, un, v, r4c, c4r, 1u << r0, g, 0);  // cpp:235: forbiddenActiveRows[row4col[0]]
+            if (lane == 0) {
+                PG[0] = g;
+                PM[0] = 0u;
+                PS[0] = 0;
+                ctrl->cdelta = cdel * (double)M;  // cpp:583
+            }
+        }
+    }
+    __syncthreads();
+    if (uni32(ctrl->status) == 3) {  // infeasible: kBest2D returns 0 (cpp:588-593); assignmentProb then divides by zero
+        if (tid == 0) p.nf[b] = 0;
+        return;
+    }
+    const double cdelta = ctrl->cdelta;
+
+    // ---- phase 2: rounds ---------------------------------------------------------------------------------------
+    int cur = 0;         // pool buffer in use
+    int nq = 1;          // entries in it
+    int E = 0;           // solutions emitted so far
+    double gain0u = 0.0; // gainBest[0]
+    double cutG = INF;   // workMem.cutoffGain (cpp:681/684), shifted
+    int extraSlot = 0;   // 1: the slot behind the last counted one was written (cutoff break, cpp:709-719)
+    for (int round = 0; round < 2 * k + 8; round++) {  // (every round emits at least one solution; the cap is a safety net)
+        const double *pg = PG + cur * k;
+        const u32 *pm = PM + cur * k;
+        const unsigned short *ps = PS + cur * k;
+        // -- select: the first W not-yet-split candidates, in pool order; this wave's two are the (2 wave)-th and the next
+        int cnt = 0, firstU = -1, idx0 = -1, idx1 = -1;
+        for (int base = 0; base < nq && cnt < W; base += 64) {
+            const int i = base + lane;
+            const bool open = i < nq && !(pm[i] & SM_SPLIT);
+            const u64 m = __ballot(open);
+            if (m) {
+                const int rank = cnt + __popcll(m & ((1ull << lane) - 1ull));
+                if (firstU < 0) firstU = base + __builtin_ctzll(m);
+                const u64 h0 = __ballot(open && rank == 2 * wave), h1 = __ballot(open && rank == 2 * wave + 1);
+                if (h0) idx0 = base + __builtin_ctzll(h0);
+                if (h1) idx1 = base + __builtin_ctzll(h1);
+                cnt += __popcll(m);
+            }
+        }
+        const int nsel = cnt < W ? cnt : W;
+        // the last selected entry (the nsel-th open one): every open entry up to it is selected
+        int lastSel = -1;
+        if (nsel > 0) {
+            int c2 = 0;
+            for (int base = 0; base < nq && lastSel < 0; base += 64) {
+                const int i = base + lane;
+                const bool open = i < nq && !(pm[i] & SM_SPLIT);
+                const u64 m = __ballot(open);
+                const int rank = c2 + __popcll(m & ((1ull << lane) - 1ull));
+                const u64 h = __ballot(open && rank == nsel - 1);
+                if (h) lastSel = base + __builtin_ctzll(h);
+                c2 += __popcll(m);
+            }
+        }
+        // -- emission (kBest2D cpp:607-634): the head goes out while it has been split; the first not yet split one
+        //    is split in THIS round: it is emitted too, but ends the run (its children are not in the pool yet)
+        int run = (nsel > 0) ? firstU + 1 : nq;
+        if (run > k - E) run = k - E;
+        if (round == 0) {
+            const double g0 = pg[0];
+            gain0u = maximize ? (-g0 + cdelta) : (g0 + cdelta);           // cpp:599-603
+            cutG = maximize ? (g0 - p.cutoff) : (g0 + p.cutoff);           // cpp:681/684
+        }
+        bool cutStop = false;
+        int nEmit = run;
+        if (useCut) {  // cpp:709-719: the first slot beyond gainBest[0] +- cutoff is written but not counted, and ends the call
+            for (int base = 0; base < run && !cutStop; base += 64) {
+                const int j = base + lane;
+                bool beyond = false;
+                if (j < run) {
+                    const double g = pg[j];
+                    const double gu = maximize ? (-g + cdelta) : (g + cdelta);
+                    beyond = maximize ? (gu < gain0u - p.cutoff) : (gu > gain0u + p.cutoff);
+                }
+                const u64 m = __ballot(beyond);
+                if (m) { cutStop = true; nEmit = base + __builtin_ctzll(m); }
+            }
+        }
+        if (wave == 0) {
+            for (int j = lane; j < nEmit + (cutStop ? 1 : 0); j += 64) {
+                if (E + j < k) {
+                    const double g = pg[j];
+                    EG[E + j] = maximize ? (-g + cdelta) : (g + cdelta);  // cpp:626-630
+                    ES[E + j] = ps[j];
+                }
+            }
+        }
+        const int headNew = nEmit;
+        E += nEmit;
+        const bool stop = cutStop || E >= k || nsel == 0;
+        if (cutStop && E < k) extraSlot = 1;
+        if (stop) break;
+
+        // -- this worker's node
+        const int myIdx = half ? idx1 : idx0;
+        const bool haveNode = worker < nsel;
+        const u64 nodeMask = __ballot(haveNode);  // whole halves
+        // threshold of the pool (after this round's emission): once R candidates are waiting only children below the
+        // largest of them can matter
+        const int R = k - E;
+        const int nOld = nq - headNew;
+        double T = (nOld >= R) ? pg[headNew + R - 1] : INF;
+        if (useCut && !maximize && cutG < T) T = cutG;
+        const int par = round & 1;
+        if (nodeMask) {
+            const int sidv = haveNode ? (int)ps[myIdx] : 0;
+            const unsigned char *st = stBase + (long long)sidv * p.stateStride;
+            double uP = 0.0, vP = 0.0;
+            int r4cP = -1, c4rP = -1;
+            if (haveNode) {
+                if (l < M) { uP = reinterpret_cast<const double *>(st)[l]; r4cP = st[offR4C + l]; }
+                if (l < N) { vP = reinterpret_cast<const double *>(st + offV)[l]; c4rP = st[offC4R + l]; }
+            }
+            u32 forbP = 0;
+            int aP = 0;
+            double gP = 0.0;
+            if (haveNode) {
+                forbP = *reinterpret_cast<const u32 *>(st + offTail);
+                aP = *reinterpret_cast<const int *>(st + offTail + 4);
+                gP = *reinterpret_cast<const double *>(st + offTail + 8);
+            }
+            uArr[l] = uP;
+            nodeV[l] = vP;
+            nodeC4R[l] = (unsigned char)c4rP;
+            wave_fence();
+            const double boundv = (T < INF) ? (T - gP) + 1e-9 * (fabs(T) + cmaxv) : INF;
+            // -- first-step filter: the minimum first-step reduced cost of each child (lane & 31 = child column - a)
+            //    over its candidate rows: rows of later columns and the parked rows, minus the row the child frees
+            //    itself (cpp:480-488, 510-516) -- for the child on the active column minus the accumulated forbidden
+            //    rows instead (cpp:490).  Same numbers as step 1 of the child's own search ((0 + C) - u) - v.
+            const int cL = aP + l;
+            const int cc = cL < M ? cL : M - 1;
+            const double uc = uArr[cc];
+            double m = INF;
+            for (int r = 0; r < N; r++) {
+                const double vr = nodeV[r];
+                const int cr = nodeC4R[r];
+                const double cv = Cs[r + cc * LDC];
+                const double rc = (cv - uc) - vr;
+                const bool valid = (cL == aP) ? ((cr >= aP) && !((forbP >> r) & 1u)) : (cr > cL);  // (SM_PARKED > every column)
+                if (valid && rc < m) m = rc;
+            }
+            const bool keep = haveNode && cL < M && m < INF && !(m > boundv);
+            u64 surv = __ballot(keep);
+            const int a0 = __builtin_amdgcn_readlane(aP, 0), a1 = __builtin_amdgcn_readlane(aP, 32);  // (readlane indices are scalars)
+            // -- surviving children, one after the other per half (shortestPathUpdateCPP cpp:240-365)
+            while (surv) {
+                const u32 s0 = (u32)surv, s1 = (u32)(surv >> 32);
+                const int j0 = s0 ? __builtin_ctz(s0) : 0, j1 = s1 ? __builtin_ctz(s1) : 0;
+                surv &= ~(((u64)(s0 & (0u - s0))) | ((u64)(s1 & (0u - s1)) << 32));
+                const u64 liveH = (s0 ? SM_LO : 0ull) | (s1 ? SM_HI : 0ull);
+                const int cv = aP + pick(j0, j1);                       // this half's child column
+                const int frv = half_bcast_i32(r4cP, a0 + j0, a1 + j1);  // row freed (cpp:277-278)
+                const u64 cand = __ballot(l < N && c4rP >= cv);          // rows of columns >= c and the parked rows
+                const u64 forbm = __ballot((cv == aP) ? (((forbP >> l) & 1u) != 0) : (l == frv));
+                int c4r = (l == frv) ? -1 : c4rP;
+                double sp, delta;
+                int pred, sink, hubRow, status;
+                u64 scanned;
+                dijkstra2<true>(Cs, LDC, uArr, rl, vP, c4r, cand, forbm, liveH, cv, boundv, sp, pred, scanned, delta, sink,
+                                hubRow, status);
+                u64 ok = __ballot(status == 0) & liveH;
+                if (!ok) continue;
+                int r4c = (l == cv) ? -1 : r4cP;
+                double vN = vP, uN;
+                augment2(ok, l, cv, sp, pred, scanned, delta, sink, hubRow, uArr, r4cP, M, vN, c4r, r4c, uN);
+                const double g = serial_gain2(r4c);
+                if (useCut) ok &= ~__ballot(maximize ? (g < cutG) : (g > cutG));  // cutHyp, cpp:496/521
+                if (!ok) continue;
+                int slot = 0, pos = 0;
+                if (l == 0 && ((ok >> lane) & 1ull)) {
+                    const int t = atomicAdd(&ctrl->freeTop, -1) - 1;
+                    slot = freeStack[t];
+                    pos = atomicAdd(&ctrl->nFresh[par], 1);
+                }
+                slot = pick(__builtin_amdgcn_readlane(slot, 0), __builtin_amdgcn_readlane(slot, 32));
+                pos = pick(__builtin_amdgcn_readlane(pos, 0), __builtin_amdgcn_readlane(pos, 32));
+                const int rnew = half_bcast_i32(r4c, a0 + j0, a1 + j1);
+                const u32 forbN = ((cv == aP) ? forbP : (1u << frv)) | (1u << rnew);  // cpp:362
+                store_state2(ok, slot, uN, vN, r4c, c4r, forbN, g, cv);
+                if (l == 0 && ((ok >> lane) & 1ull)) {
+                    FG[pos] = g;
+                    FM[pos] = ((u32)sidv << 8) | (u32)cv;
+                    FS[pos] = (unsigned short)slot;
+                }
+            }
+        }
+        __syncthreads();
+        // -- merge: old candidates that were not emitted + this round's children -> the other buffer, by rank; the
+        //    R smallest stay.  Ties in gain: old before fresh, fresh by (parent, column).
+        const int nFresh = uni32(ctrl->nFresh[par]);
+        if (tid == 0) ctrl->nFresh[par ^ 1] = 0;
+        double *ng = PG + (cur ^ 1) * k;
+        u32 *nm = PM + (cur ^ 1) * k;
+        unsigned short *nsd = PS + (cur ^ 1) * k;
+        for (int i = tid; i < nOld + nFresh; i += NT) {
+            double g;
+            u32 meta;
+            unsigned short sid;
+            int pos;
+            if (i < nOld) {
+                const int j = headNew + i;
+                g = pg[j];
+                meta = pm[j] | ((j <= lastSel) ? SM_SPLIT : 0u);
+                sid = ps[j];
+                pos = i;
+                for (int f = 0; f < nFresh; f++) pos += (FG[f] < g) ? 1 : 0;
+            } else {
+                const int f = i - nOld;
+                g = FG[f];
+                meta = FM[f];
+                sid = FS[f];
+                int lo = 0, hiB = nOld;
+                while (lo < hiB) {
+                    const int mid = (lo + hiB) >> 1;
+                    if (pg[headNew + mid] <= g) lo = mid + 1; else hiB = mid;
+                }
+                pos = lo;
+                for (int f2 = 0; f2 < nFresh; f2++) {
+                    const double g2 = FG[f2];
+                    pos += (g2 < g || (g2 == g && FM[f2] < meta)) ? 1 : 0;
+                }
+            }
+            if (pos < R) {
+                ng[pos] = g;
+                nm[pos] = meta;
+                nsd[pos] = sid;
+            } else {
+                const int t = atomicAdd(&ctrl->freeTop, 1);  // dropped for good: recycle its state slot
+                freeStack[t] = sid;
+            }
+        }
+        nq = nOld + nFresh;
+        if (nq > R) nq = R;
+        cur ^= 1;
+        __syncthreads();
+    }
+    __syncthreads();
+    const int nf = E;
+
+    // ---- phase 3: outputs ------------------------------------------------------------------------------------------
+    if (p.row4col || p.col4row || p.gain) {
+        for (int s = worker; s < nf; s += W) {  // one half-wave per solution
+            const unsigned char *st = stBase + (long long)ES[s] * p.stateStride;
+            if (p.row4col && l < M) p.row4col[(outBase + s) * p.ldCol + l] = st[offR4C + l];
+            if (p.col4row) {
+                const int c = (l < N) ? (int)st[offC4R + l] : 0;
+                const u64 pk = __ballot(l < N && c == SM_PARKED) & myHalf;
+                const int rank = __popcll(pk & ((1ull << lane) - 1ull));
+                if (l < N) p.col4row[(outBase + s) * p.ldRow + l] = (c == SM_PARKED) ? M + rank : c;
+            }
+        }
+        if (p.gain)
+            for (int s = tid; s < nf + extraSlot; s += NT) p.gain[outBase + s] = EG[s];
+    }
+    if (p.weights) {
+        // assignmentProb's accumulation (assignment.cpp:616-648), in the reference's order: solutions ascending,
+        // total and every probs[col][row] summed sequentially.  The row maps of the emitted hypotheses are gathered
+        // into LDS first (one parallel pass over HBM), then lane = column walks the solutions.
+        unsigned char *rTab = smem + L.offNodes;                    // [nf][M] rows (the node blocks are dead now)
+        double *wts = PG;                                           // [nf] weights (the pool is dead now)
+        const int tabCap = (W * L.nodeStride) / (M > 0 ? M : 1);
+        const double best = EG[0];
+        for (int s = tid; s < nf; s += NT) {
+            const double g = EG[s];
+            wts[s] = (p.gate && !(best + SM_GATE > g)) ? -1.0 : exp(best - g);  // :622-626 (-1: skipped)
+        }
+        for (int i = tid; i < M * (nLc + 1); i += NT) prob[i] = 0.0;
+        double total = 0.0;
+        for (int s0 = 0; s0 < nf; s0 += tabCap) {
+            const int ns = (nf - s0) < tabCap ? (nf - s0) : tabCap;
+            __syncthreads();
+            for (int i = tid; i < ns * M; i += NT) {
+                const int s = i / M, c = i - s * M;
+                rTab[i] = stBase[(long long)ES[s0 + s] * p.stateStride + offR4C + c];
+            }
+            __syncthreads();
+            if (wave == 0) {
+                for (int s = 0; s < ns; s++) {
+                    const double w = wts[s0 + s];
+                    if (w < 0.0) continue;
+                    total += w;
+                    if (lane < M) {
+                        const int r = rTab[s * M + lane];
+                        prob[lane * (nLc + 1) + ((r >= nLc) ? nLc : r)] += w;  // :633-638
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const double norm = 1.0 / total;  // :643
+            for (int i = lane; i < M * (nLc + 1); i += 64) {
+                const int c = i / (nLc + 1), r = i - c * (nLc + 1);
+                // scatter back to the caller's landmark numbering (getAssignmentProbs, assignment.cpp:68-74)
+                const int ro = (r >= nLc) ? nLout : (p.condition ? (int)rowIdx[r] : r);
+                probOut[c * (nLout + 1) + ro] = prob[i] * norm;
+            }
+        }
+    }
+    if (tid == 0) p.nf[b] = nf;
+}
+
+template <int NW>
+static hipError_t launch_small_nw(const SmallParams &p, int B, hipStream_t stream)
+{
+    const SmallLds L = small_lds_layout(p.maxRow, p.maxCol, p.k, NW, p.weights != 0);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kbest_small_kernel<NW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((kbest_small_kernel<NW>), dim3(B), dim3(NW * 64), L.total, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_kbest_small(const SmallParams &p, int B, int nWaves, hipStream_t stream)
+{
+    switch (nWaves) {
+    case 2: return launch_small_nw<2>(p, B, stream);
+    case 4: return launch_small_nw<4>(p, B, stream);
+    case 8: return launch_small_nw<8>(p, B, stream);
+    default: return launch_small_nw<16>(p, B, stream);
+    }
+}
+
+}  // namespace kb

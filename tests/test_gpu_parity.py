@@ -25,7 +25,13 @@ def check_against(eng_out, want_nf, want_r4c, want_c4r, want_g, tag=""):
     nf, r4c, c4r, g = eng_out
     assert nf == want_nf, (tag, nf, want_nf)
     assert (r4c[:nf] == want_r4c[:nf]).all(), tag
-    assert (c4r[:nf] == want_c4r[:nf]).all(), tag
+    # which zero-padded column a left-over row sits on is an artefact of exact-tie resolution
+    # among identical columns -- col4row is compared after mapping every value >= numCol to -1 ...
+    M = r4c.shape[-1]
+    assert (ol.canon_col4row(c4r[:nf], M) == ol.canon_col4row(want_c4r[:nf], M)).all(), tag
+    # ... and must still be a complete assignment of the padded square problem: a permutation of 0..numRow-1
+    if nf:
+        assert (np.sort(np.asarray(c4r[:nf]), axis=-1) == np.arange(c4r.shape[-1])).all(), tag
     assert (bits(g[:nf]) == bits(want_g[:nf])).all(), tag
 
 
@@ -95,9 +101,7 @@ def test_random_shapes_vs_oracle(eng):
         assert (nf == onf).all(), trial
         for b in range(B):
             n = nf[b]
-            assert (r4c[b, :n] == or4c[b, :n]).all(), trial
-            assert (c4r[b, :n] == oc4r[b, :n]).all(), trial
-            assert (bits(g[b, :n]) == bits(og[b, :n])).all(), trial
+            check_against((n, r4c[b], c4r[b], g[b]), onf[b], or4c[b], oc4r[b], og[b], trial)
 
 
 def test_ties_multiset(eng):
@@ -463,9 +467,7 @@ def _same_as_oracle(eng, costs, N, M, k, maximize=False, cutoff=None, tag=None, 
     assert (nf == onf).all(), (tag, nf, onf)
     for b in range(len(nf)):
         n = nf[b]
-        assert (r4c[b, :n] == or4c[b, :n]).all(), tag
-        assert (c4r[b, :n] == oc4r[b, :n]).all(), tag
-        assert (bits(g[b, :n]) == bits(og[b, :n])).all(), tag
+        check_against((n, r4c[b], c4r[b], g[b]), onf[b], or4c[b], oc4r[b], og[b], tag)
 
 
 def test_general_size_kernel_on_small_problems(eng, golden, monkeypatch):
