@@ -485,6 +485,7 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         sp.states = ctx->states;
         sp.stateStride = kb::small_state_stride(maxRow, maxCol);
         sp.statesPerProblem = kb::small_states_per_problem(k, snw, maxCol);
+        sp.prof = ctx->prof;
         hipError_t e = kb::launch_kbest_small(sp, B, snw, s);
         if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "small-problem kbest kernel launch", e);
         return KBEST_OK;

@@ -238,7 +238,7 @@ __host__ __device__ inline long long small_state_stride(int maxRow, int maxCol)
 __host__ __device__ inline int small_states_per_problem(int k, int nWaves, int maxCol) { return 2 * k + 2 * nWaves * maxCol + 4; }
 
 struct SmallLds {
-    int offC, offNodes, nodeStride, offPoolG, offPoolM, offPoolS, offFreshG, offFreshM, offFreshS, offFree, offEmitG, offEmitS,
+    int offC, offNodes, nodeStride, offPoolG, offPoolM, offPoolS, offFreshG, offFreshM, offFreshS, offFree, offEmitG, offEmitS, offSurv,
         offProb, offRowIdx, offColMin, offKeep, offCtrl, total;
 };
 
@@ -246,14 +246,15 @@ __host__ __device__ inline SmallLds small_lds_layout(int maxRow, int maxCol, int
 {
     SmallLds L;
     const int W = 2 * nWaves, S = small_states_per_problem(k, nWaves, maxCol);
-    const int ldc = maxRow | 1;
     int o = 0;
-    L.offC = o;        o += maxCol * ldc * 8;            // cost tile: the real columns only
-    L.nodeStride = 2 * 256 + 64 + 256;                   // per worker: u[32] v[32] (fp64), col4row[32] row4col[32] (u8), gain-term line
+    L.offC = o;        o += maxCol * 33 * 8;             // cost tile: the real columns only, column stride 33
+    L.nodeStride = 2 * 256 + 64 + 32 + 256;              // per worker: u[32] v[32] (fp64), col4row[32] row4col[32] (u8), scalars, gain-term line
+    o = (o + 15) & ~15;
     L.offNodes = o;    o += W * L.nodeStride;
     L.offPoolG = o;    o += 2 * k * 8;                   // sorted candidate pool, two buffers: gain
     L.offEmitG = o;    o += k * 8;                       // gains of the emitted solutions (un-shifted)
-    L.offFreshG = o;   o += W * maxCol * 8;              // children completed in this round
+    o = (o + 15) & ~15;
+    L.offFreshG = o;   o += W * maxCol * 8;              // children completed in this round (16-byte aligned: read as double2)
     L.offProb = o;     o += weights ? maxCol * 33 * 8 : 0;  // probability accumulators [nM][condL + 1]
     L.offColMin = o;   o += weights ? maxCol * 8 : 0;
     L.offKeep = o;     o += weights ? (SMALL_MAX_RAW_ROWS / 64) * 8 : 0;  // kept-row bits of conditionCosts
@@ -262,6 +263,7 @@ __host__ __device__ inline SmallLds small_lds_layout(int maxRow, int maxCol, int
     L.offPoolS = o;    o += 2 * k * 2;                   //   own state slot
     L.offFreshS = o;   o += W * maxCol * 2;
     L.offEmitS = o;    o += k * 2;
+    L.offSurv = o;     o += W * 32 * 2;                  // children that passed the filter: (node, column)
     L.offFree = o;     o += S * 2;                       // stack of free state slots
     L.offRowIdx = o;   o += weights ? 32 * 2 : 0;        // original row of each kept row
     o = (o + 15) & ~15;

@@ -108,79 +108,134 @@ __device__ __forceinline__ double half_bcast_f64(double x, int idxLow, int idxHi
 // columns were entered (or -1), status 0 = path found, 1 = infeasible (cpp:197, 327), 2 = abandoned.
 template <bool EARLY>
 __device__ __forceinline__ void dijkstra2(const double *Cs, int LDC, const double *uArr, int rl, double v, int c4r, u64 cand,
-                                          u64 forb, u64 live, int startv, double boundv, double &spOut, int &predOut,
-                                          u64 &scannedOut, double &deltaOut, int &sinkOut, int &hubRowOut, int &statusOut)
+                                          u64 forb, bool liveA, bool liveB, int startA, int startB, double boundA,
+                                          double boundB, double &spOut, int &predOut, u64 &scannedOut, double &deltaOut,
+                                          int &sinkOut, int &hubRowOut, int &statusOut)
 {
-    live = uni64(live);
-    cand = uni64(cand) & live;
+    // Everything that is uniform within a half lives in SCALAR registers here (suffix A = lower half, B = upper half):
+    // the step is bound by its instruction count, and scalar bookkeeping is the cheapest kind.
+    u64 liveMask = (liveA ? SM_LO : 0ull) | (liveB ? SM_HI : 0ull);
+    cand = uni64(cand) & liveMask;
     const u64 cand0 = cand;
     u64 act = cand & ~uni64(forb);
-    u64 liveNow = live;
     const u64 parked = __ballot(c4r == SM_PARKED);
-    int curv = startv;
-    double delta = 0.0, vk = 0.0;
-    double sp = d_inf();
-    int pred = 0, status = 0, sink = 0, hubRow = -1;
-    while (liveNow) {
-        const bool hub = curv == SM_HUB;
-        const int cc = hub ? 0 : curv;
-        double Cval = Cs[rl + cc * LDC];
-        double uval = uArr[cc];
-        Cval = hub ? 0.0 : Cval;  // a zero column ...
-        uval = hub ? -vk : uval;   // ... whose dual is minus the (common) dual of the parked rows
-        const double rc = ((delta + Cval) - uval) - v;  // cpp:183 / cpp:313, evaluated left to right
-        const u64 upd = __ballot(rc < sp) & act;        // strict '<': cpp:185, 314
-        sp = sel_f64(upd, rc, sp);
-        pred = sel32(upd, curv, pred);
-        // arg-min over the rows still to scan (cpp:191-194, 320-323): lowest row index among equal values
-        int khi;
-        u32 klo;
-        to_key(sp, khi, klo);
-        const u64 candL = cand & liveNow;
-        khi = sel32(candL, khi, 0x7fffffff);
-        const int mhi = half_min_i32(khi);
-        u64 eq = __ballot(khi == mhi) & candL;
-        if (__popc((u32)eq) > 1 || __popc((u32)(eq >> 32)) > 1) {  // several rows on the same high word: compare the low words
-            const u32 t = (u32)sel32(eq, (int)klo, -1);
-            const u32 mlo = half_min_u32(t);
-            eq &= __ballot(t == mlo);
+    int curA = uni32(startA), curB = uni32(startB);
+    int dHiA = 0, dLoA = 0, dHiB = 0, dLoB = 0;          // settled distance (delta) of each half, as bits
+    int vkHiA = 0, vkLoA = 0, vkHiB = 0, vkLoB = 0;      // dual of the parked rows (hub relaxation)
+    bool hubA = false, hubB = false;
+    int stA = 0, stB = 0, sinkA = 0, sinkB = 0, hubRowA = -1, hubRowB = -1;
+    const int bHiA = uni32(__double2hiint(boundA)), bHiB = uni32(__double2hiint(boundB));
+    const u32 bLoA = (u32)uni32(__double2loint(boundA)), bLoB = (u32)uni32(__double2loint(boundB));
+    int spHi = KEY_INF_HI, spLo = 0, pred = 0;
+    while (liveMask) {
+        const int curv = pick(curA, curB);
+        const double delta = __hiloint2double(pick(dHiA, dHiB), pick(dLoA, dLoB));
+        double Cval = Cs[rl + curv * LDC];
+        double uval = uArr[curv];
+        int predv = curv;
+        if (hubA | hubB) {  // a zero column, whose dual is minus the (common) dual of the parked rows
+            const u64 hubMask = (hubA ? SM_LO : 0ull) | (hubB ? SM_HI : 0ull);
+            const double nvk = -__hiloint2double(pick(vkHiA, vkHiB), pick(vkLoA, vkLoB));
+            Cval = sel_f64(hubMask, 0.0, Cval);
+            uval = sel_f64(hubMask, nvk, uval);
+            predv = sel32(hubMask, SM_HUB, curv);
         }
-        const u32 e0 = (u32)eq, e1 = (u32)(eq >> 32);
-        const int c0 = e0 ? __builtin_ctz(e0) : 0, c1 = e1 ? __builtin_ctz(e1) : 0;
-        const int closest = pick(c0, c1);
-        const double dnew = half_bcast_f64(sp, c0, c1);
-        const int cn = half_bcast_i32(c4r, c0, c1);
-        cand &= ~(((u64)e0 & (0u - e0)) | ((u64)(e1 & (0u - e1)) << 32));  // the chosen rows leave Row2Scan (cpp:208-210)
-        const bool infeas = mhi >= KEY_INF_HI;  // minimum is +inf, or nothing left to scan
-        const bool over = EARLY && !infeas && dnew > boundv;
-        const bool atSink = !infeas && !over && cn < 0;
-        const bool atPark = !infeas && !over && cn == SM_PARKED;
-        const u64 mInf = __ballot(infeas) & liveNow, mOver = __ballot(over) & liveNow;
-        const u64 mSink = __ballot(atSink) & liveNow, mPark = __ballot(atPark) & liveNow;
-        delta = sel_f64(liveNow & ~mInf, dnew, delta);
-        status = sel32(mInf, 1, status);
-        status = sel32(mOver, 2, status);
-        sink = sel32(mSink, closest, sink);
-        if (mPark) {
-            // the first parked row is settled: every parked row is at this distance (equal duals), and their columns
-            // all offer the other rows the same reduced costs -- settle them together, one hub relaxation follows
-            vk = sel_f64(mPark, half_bcast_f64(v, c0, c1), vk);
-            hubRow = sel32(mPark, closest, hubRow);
-            const u64 pk = parked & cand & mPark;
-            sp = sel_f64(pk, dnew, sp);
+        const double rc = ((delta + Cval) - uval) - v;                                      // cpp:183 / cpp:313, left to right
+        const u64 upd = __ballot(rc < __hiloint2double(spHi, spLo)) & act;                   // strict '<': cpp:185, 314
+        spHi = sel32(upd, __double2hiint(rc), spHi);
+        spLo = sel32(upd, __double2loint(rc), spLo);
+        pred = sel32(upd, predv, pred);
+        // arg-min over the rows still to scan (cpp:191-194, 320-323): lowest row index among equal values.  Reduced costs
+        // are >= 0 up to rounding, and for non-negative doubles the high word itself is an order-preserving key.
+        const u64 candL = cand & liveMask;
+        const int key = sel32(candL, spHi, KEY_INF_HI);
+        int t;
+        asm volatile(KB_HALF_MIN_CHAIN("v_min_i32_dpp") : "=&v"(t) : "v"(key));
+        int m0 = __builtin_amdgcn_readlane(t, 31), m1 = __builtin_amdgcn_readlane(t, 63);
+        u64 eq = __ballot(key == pick(m0, m1)) & candL;
+        u32 e0 = (u32)eq, e1 = (u32)(eq >> 32);
+        int c0 = e0 ? __builtin_ctz(e0) : 0, c1 = e1 ? __builtin_ctz(e1) : 0;
+        int dlo0 = __builtin_amdgcn_readlane(spLo, c0), dlo1 = __builtin_amdgcn_readlane(spLo, 32 + c1);
+        bool exact = (m0 | m1) < 0;  // a negative candidate (-1e-17 from rounding): needs the real key
+        if (!exact && ((e0 & (e0 - 1)) | (e1 & (e1 - 1)))) {
+            // several rows on the same high word (nearly always exact zeros): the first is the minimum unless another one
+            // has a smaller low word
+            exact = (__ballot((u32)spLo < (u32)pick(dlo0, dlo1)) & eq) != 0;
+        }
+        if (__builtin_expect(exact, 0)) {
+            int khi;
+            u32 klo;
+            to_key(__hiloint2double(spHi, spLo), khi, klo);
+            khi = sel32(candL, khi, 0x7fffffff);
+            const int mh = half_min_i32(khi);
+            eq = __ballot(khi == mh) & candL;
+            const u32 tl = (u32)sel32(eq, (int)klo, -1);
+            const u32 ml = half_min_u32(tl);
+            eq &= __ballot(tl == ml);
+            e0 = (u32)eq;
+            e1 = (u32)(eq >> 32);
+            c0 = e0 ? __builtin_ctz(e0) : 0;
+            c1 = e1 ? __builtin_ctz(e1) : 0;
+            m0 = e0 ? __builtin_amdgcn_readlane(spHi, c0) : KEY_INF_HI;
+            m1 = e1 ? __builtin_amdgcn_readlane(spHi, 32 + c1) : KEY_INF_HI;
+            dlo0 = __builtin_amdgcn_readlane(spLo, c0);
+            dlo1 = __builtin_amdgcn_readlane(spLo, 32 + c1);
+        }
+        u64 park = 0ull;  // halves that enter the zero columns in this step
+        if (liveA) {
+            cand &= ~(1ull << c0);  // the chosen row leaves Row2Scan (cpp:208-210)
+            if (e0 == 0 || (m0 & 0x7fffffff) >= KEY_INF_HI) { stA = 1; liveA = false; }  // minimum is +inf: infeasible (cpp:197, 327)
+            else {
+                dHiA = m0;
+                dLoA = dlo0;
+                if (EARLY && (m0 > bHiA || (m0 == bHiA && (u32)dlo0 > bLoA))) { stA = 2; liveA = false; }  // beyond the bound
+                else {
+                    const int cn = __builtin_amdgcn_readlane(c4r, c0);
+                    if (cn < 0) { sinkA = c0; liveA = false; }
+                    else if (cn == SM_PARKED) {
+                        hubA = true; hubRowA = c0; curA = 0; park |= SM_LO;
+                        vkHiA = __builtin_amdgcn_readlane(__double2hiint(v), c0);
+                        vkLoA = __builtin_amdgcn_readlane(__double2loint(v), c0);
+                    } else { hubA = false; curA = cn; }
+                }
+            }
+        }
+        if (liveB) {
+            cand &= ~(1ull << (32 + c1));
+            if (e1 == 0 || (m1 & 0x7fffffff) >= KEY_INF_HI) { stB = 1; liveB = false; }
+            else {
+                dHiB = m1;
+                dLoB = dlo1;
+                if (EARLY && (m1 > bHiB || (m1 == bHiB && (u32)dlo1 > bLoB))) { stB = 2; liveB = false; }
+                else {
+                    const int cn = __builtin_amdgcn_readlane(c4r, 32 + c1);
+                    if (cn < 0) { sinkB = c1; liveB = false; }
+                    else if (cn == SM_PARKED) {
+                        hubB = true; hubRowB = c1; curB = 0; park |= SM_HI;
+                        vkHiB = __builtin_amdgcn_readlane(__double2hiint(v), 32 + c1);
+                        vkLoB = __builtin_amdgcn_readlane(__double2loint(v), 32 + c1);
+                    } else { hubB = false; curB = cn; }
+                }
+            }
+        }
+        if (park) {
+            // the first parked row is settled: every parked row is at this distance (equal duals), and their columns all
+            // offer the other rows the same reduced costs -- settle them together, one hub relaxation follows
+            const u64 pk = parked & cand & park;
+            spHi = sel32(pk, pick(dHiA, dHiB), spHi);
+            spLo = sel32(pk, pick(dLoA, dLoB), spLo);
             cand &= ~pk;
         }
-        curv = sel32(liveNow, sel32(mPark, SM_HUB, cn), curv);
-        liveNow &= ~(mInf | mOver | mSink);
-        act = cand & liveNow;
+        liveMask = (liveA ? SM_LO : 0ull) | (liveB ? SM_HI : 0ull);
+        act = cand & liveMask;
     }
-    spOut = sp;
+    spOut = __hiloint2double(spHi, spLo);
     predOut = pred;
     scannedOut = cand0 & ~cand;
-    deltaOut = delta;
-    sinkOut = sink;
-    hubRowOut = hubRow;
-    statusOut = status;
+    deltaOut = __hiloint2double(pick(dHiA, dHiB), pick(dLoA, dLoB));
+    sinkOut = pick(sinkA, sinkB);
+    hubRowOut = pick(hubRowA, hubRowB);
+    statusOut = pick(stA, stB);
 }
 
 // updateDualAndAugment (cpp:82-117) for the halves in `ok`: path flip sink -> start through pred (through the hub:
@@ -223,12 +278,22 @@ __device__ __forceinline__ void augment2(u64 ok, int l, int startv, double sp, i
 
 }  // namespace
 
+#ifdef KB_PROFILE
+#define KS_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define KS_ACC(slot, expr) do { profAcc[slot] += (unsigned long long)(expr); } while (0)
+#else
+#define KS_T(var) do { } while (0)
+#define KS_ACC(slot, expr) do { } while (0)
+#endif
+
 struct SCtrl {
     double cdelta;      // CDelta * numCol (cpp:583)
     double cmax;        // largest finite shifted cost (scale of the pruning margin)
     unsigned long long cmaxBits;
     int nFresh[2];      // children appended in the current round (by round parity)
     int freeTop;        // free state slots on the stack
+    int nSurv;          // children that passed the filter in this round
+    int nextItem;       // work queue over them
     int status;         // 0 ok, 3 infeasible root, -2 does not fit this kernel
     int N, condL;
 };
@@ -253,7 +318,7 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
     const int NR = p.nRow ? p.nRow[b] : p.maxRow;  // rows of the block as given (condition: of the RAW block)
     const bool maximize = p.maximize != 0, useCut = p.useCutoff != 0;
     const SmallLds L = small_lds_layout(p.maxRow, p.maxCol, k, NW, p.weights != 0);
-    const int LDC = p.maxRow | 1;
+    constexpr int LDC = 33;  // odd: lane = row and lane = column walks are both bank-conflict free; rows beyond N hold +inf
     const int S = p.statesPerProblem;
     double *Cs = reinterpret_cast<double *>(smem + L.offC);
     double *PG = reinterpret_cast<double *>(smem + L.offPoolG);
@@ -275,7 +340,9 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
     double *uArr = reinterpret_cast<double *>(nodeBase);
     double *nodeV = uArr + 32;
     unsigned char *nodeC4R = nodeBase + 512;
-    double *gainW = reinterpret_cast<double *>(nodeBase + 576);
+    unsigned char *nodeR4C = nodeBase + 544;  // (+576: scalars of the node: forbidden rows, active column, state, bound)
+    double *gainW = reinterpret_cast<double *>(nodeBase + 608);  // this worker's line of gain terms
+    unsigned short *surv = reinterpret_cast<unsigned short *>(smem + L.offSurv);
 
     const long long costBase = p.costOff ? p.costOff[b] : (long long)b * p.ldRow * p.ldCol;
     const double *Cg = p.cost + costBase;
@@ -283,6 +350,10 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
     double *probOut = p.weights ? p.probs + p.probOff[b] : nullptr;
     const int nLout = p.weights ? p.nL[b] : 0;  // landmarks in the caller's numbering
 
+#ifdef KB_PROFILE
+    unsigned long long profAcc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long profT0 = __builtin_readcyclecounter();
+#endif
     // ---- shapes ---------------------------------------------------------------------------------------------
     if (M == 0 || NR == 0) {  // an empty frame (getAssignmentProbs returns an empty result, assignment.cpp:50-51)
         if (tid == 0) p.nf[b] = 0;
@@ -297,12 +368,15 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
         for (int i = tid; i < M * (nLout + 1); i += NT) probOut[i] = 0.0;
 
     // ---- phase 0: the cost tile -------------------------------------------------------------------------------
+    for (int i = tid; i < p.maxCol * LDC; i += NT) Cs[i] = INF;  // rows beyond N never win a minimum
     if (tid == 0) {
         ctrl->cmaxBits = 0ull;
         ctrl->status = 0;
         ctrl->nFresh[0] = 0;
         ctrl->nFresh[1] = 0;
         ctrl->freeTop = S - 1;
+        ctrl->nSurv = 0;
+        ctrl->nextItem = 0;
     }
     int N;  // rows of the problem that is solved
     double cdel = 0.0;
@@ -442,6 +516,8 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
     const int rl = l < N ? l : N - 1;
     const u32 rowsMask = (N >= 32) ? 0xffffffffu : ((1u << N) - 1u);
 
+    KS_ACC(0, __builtin_readcyclecounter() - profT0);  // [0] tile set-up
+    KS_T(tRoot);
     // ---- phase 1: root LAP on the rectangular problem, worker 0 -------------------------------------------------
     if (wave == 0) {
         if (l < 32) uArr[l] = 0.0;
@@ -453,8 +529,8 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
             double sp, delta;
             int pred, sink, hubRow, status;
             u64 scanned;
-            dijkstra2<false>(Cs, LDC, uArr, rl, v, c4r, (u64)rowsMask, 0ull, SM_LO, c, INF, sp, pred, scanned, delta, sink,
-                             hubRow, status);
+            dijkstra2<false>(Cs, LDC, uArr, rl, v, c4r, (u64)rowsMask, 0ull, true, false, c, 0, INF, INF, sp, pred, scanned,
+                             delta, sink, hubRow, status);
             if (__builtin_amdgcn_readlane(status, 0) != 0) { bad = true; break; }
             const int r4cBefore = r4c;
             augment2(SM_LO, l, c, sp, pred, scanned, delta, sink, hubRow, uArr, r4cBefore, M, v, c4r, r4c, un);
@@ -483,6 +559,7 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
         return;
     }
     const double cdelta = ctrl->cdelta;
+    KS_ACC(1, __builtin_readcyclecounter() - tRoot);  // [1] root (incl. barrier)
 
     // ---- phase 2: rounds ---------------------------------------------------------------------------------------
     int cur = 0;         // pool buffer in use
@@ -495,6 +572,8 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
         const double *pg = PG + cur * k;
         const u32 *pm = PM + cur * k;
         const unsigned short *ps = PS + cur * k;
+        KS_T(tSel);
+        KS_ACC(2, 1);  // [2] rounds
         // -- select: the first W not-yet-split candidates, in pool order; this wave's two are the (2 wave)-th and the next
         int cnt = 0, firstU = -1, idx0 = -1, idx1 = -1;
         for (int base = 0; base < nq && cnt < W; base += 64) {
@@ -564,7 +643,9 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
         if (cutStop && E < k) extraSlot = 1;
         if (stop) break;
 
-        // -- this worker's node
+        KS_T(tNode);
+        KS_ACC(3, tNode - tSel);  // [3] select + emission
+        // -- this worker's node: the saved hypothesis comes into its LDS block, its children are filtered
         const int myIdx = half ? idx1 : idx0;
         const bool haveNode = worker < nsel;
         const u64 nodeMask = __ballot(haveNode);  // whole halves
@@ -579,24 +660,31 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
             const int sidv = haveNode ? (int)ps[myIdx] : 0;
             const unsigned char *st = stBase + (long long)sidv * p.stateStride;
             double uP = 0.0, vP = 0.0;
-            int r4cP = -1, c4rP = -1;
-            if (haveNode) {
-                if (l < M) { uP = reinterpret_cast<const double *>(st)[l]; r4cP = st[offR4C + l]; }
-                if (l < N) { vP = reinterpret_cast<const double *>(st + offV)[l]; c4rP = st[offC4R + l]; }
-            }
+            int r4cP = 0, c4rP = 0;
             u32 forbP = 0;
             int aP = 0;
             double gP = 0.0;
             if (haveNode) {
+                if (l < M) { uP = reinterpret_cast<const double *>(st)[l]; r4cP = st[offR4C + l]; }
+                if (l < N) { vP = reinterpret_cast<const double *>(st + offV)[l]; c4rP = st[offC4R + l]; }
                 forbP = *reinterpret_cast<const u32 *>(st + offTail);
                 aP = *reinterpret_cast<const int *>(st + offTail + 4);
                 gP = *reinterpret_cast<const double *>(st + offTail + 8);
             }
+            const double boundv = (T < INF) ? (T - gP) + 1e-9 * (fabs(T) + cmaxv) : INF;
             uArr[l] = uP;
             nodeV[l] = vP;
             nodeC4R[l] = (unsigned char)c4rP;
+            nodeR4C[l] = (unsigned char)r4cP;
+            if (l == 0) {
+                *reinterpret_cast<u32 *>(nodeBase + 584) = forbP;
+                *reinterpret_cast<int *>(nodeBase + 588) = aP;
+                *reinterpret_cast<int *>(nodeBase + 592) = sidv;
+                *reinterpret_cast<double *>(nodeBase + 600) = boundv;
+            }
             wave_fence();
-            const double boundv = (T < INF) ? (T - gP) + 1e-9 * (fabs(T) + cmaxv) : INF;
+            KS_T(tFil);
+            KS_ACC(4, tFil - tNode);  // [4] node load
             // -- first-step filter: the minimum first-step reduced cost of each child (lane & 31 = child column - a)
             //    over its candidate rows: rows of later columns and the parked rows, minus the row the child frees
             //    itself (cpp:480-488, 510-516) -- for the child on the active column minus the accumulated forbidden
@@ -604,51 +692,97 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
             const int cL = aP + l;
             const int cc = cL < M ? cL : M - 1;
             const double uc = uArr[cc];
+            const double *Ccol = Cs + cc * LDC;
+            const bool first = cL == aP;
+            const int thr = first ? aP : cL + 1;       // a candidate row sits on a column >= thr (SM_PARKED > every column)
+            const u32 fmask = first ? forbP : 0u;      // ... and is not forbidden for the child on the active column
             double m = INF;
-            for (int r = 0; r < N; r++) {
-                const double vr = nodeV[r];
-                const int cr = nodeC4R[r];
-                const double cv = Cs[r + cc * LDC];
-                const double rc = (cv - uc) - vr;
-                const bool valid = (cL == aP) ? ((cr >= aP) && !((forbP >> r) & 1u)) : (cr > cL);  // (SM_PARKED > every column)
-                if (valid && rc < m) m = rc;
+            for (int r0 = 0; r0 < N; r0 += 4) {  // four independent sets of LDS reads in flight; straight-line selects only
+                double vr[4], cvv[4];
+                int cr[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {  // (rows N .. 31: +inf in the tile, never the minimum)
+                    vr[i] = nodeV[r0 + i];
+                    cr[i] = nodeC4R[r0 + i];
+                    cvv[i] = Ccol[r0 + i];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const double rc = (cvv[i] - uc) - vr[i];
+                    const bool valid = (cr[i] >= thr) & (((fmask >> (r0 + i)) & 1u) == 0u);
+                    const double rcv = valid ? rc : INF;
+                    m = rcv < m ? rcv : m;
+                }
             }
             const bool keep = haveNode && cL < M && m < INF && !(m > boundv);
-            u64 surv = __ballot(keep);
-            const int a0 = __builtin_amdgcn_readlane(aP, 0), a1 = __builtin_amdgcn_readlane(aP, 32);  // (readlane indices are scalars)
-            // -- surviving children, one after the other per half (shortestPathUpdateCPP cpp:240-365)
-            while (surv) {
-                const u32 s0 = (u32)surv, s1 = (u32)(surv >> 32);
-                const int j0 = s0 ? __builtin_ctz(s0) : 0, j1 = s1 ? __builtin_ctz(s1) : 0;
-                surv &= ~(((u64)(s0 & (0u - s0))) | ((u64)(s1 & (0u - s1)) << 32));
-                const u64 liveH = (s0 ? SM_LO : 0ull) | (s1 ? SM_HI : 0ull);
-                const int cv = aP + pick(j0, j1);                       // this half's child column
-                const int frv = half_bcast_i32(r4cP, a0 + j0, a1 + j1);  // row freed (cpp:277-278)
-                const u64 cand = __ballot(l < N && c4rP >= cv);          // rows of columns >= c and the parked rows
+            const u64 survM = __ballot(keep);
+            const u64 mine = survM & myHalf;
+            int base = 0;
+            if (l == 0 && mine) base = atomicAdd(&ctrl->nSurv, __popcll(mine));
+            base = pick(__builtin_amdgcn_readlane(base, 0), __builtin_amdgcn_readlane(base, 32));
+            if (keep) surv[base + __popcll(mine & ((1ull << lane) - 1ull))] = (unsigned short)((worker << 5) | cL);
+            KS_ACC(5, __builtin_readcyclecounter() - tFil);  // [5] filter
+        }
+        KS_T(tBA);
+        __syncthreads();
+        KS_T(tCh);
+        KS_ACC(9, tCh - tBA);  // [9] wait at the barrier after the filter
+        // -- surviving children (shortestPathUpdateCPP cpp:240-365): every wave draws them in pairs from one list, one child
+        //    per half; a child's parent is whichever node block its entry names
+        const int nItems = uni32(ctrl->nSurv);
+        {
+            int ticket = 0;
+            if (lane == 0) ticket = atomicAdd(&ctrl->nextItem, 2);
+            for (;;) {
+                const int t = uni32(ticket);
+                if (t >= nItems) break;
+                if (lane == 0) ticket = atomicAdd(&ctrl->nextItem, 2);  // the next ticket is drawn while this pair is solved
+                const bool hasB = t + 1 < nItems;
+                const int itA = uni32((int)surv[t]), itB = uni32((int)surv[hasB ? t + 1 : t]);
+                const int cA = itA & 31, cB = itB & 31;
+                unsigned char *blk = smem + L.offNodes + (size_t)(pick(itA, itB) >> 5) * L.nodeStride;
+                const double *uBlk = reinterpret_cast<const double *>(blk);
+                const double vP = reinterpret_cast<const double *>(blk + 256)[l];
+                const int c4rP = blk[512 + l];
+                const int r4cP = (l < M) ? (int)blk[544 + l] : -1;
+                const u32 forbP = *reinterpret_cast<const u32 *>(blk + 584);
+                const int aP = *reinterpret_cast<const int *>(blk + 588);
+                const int sidv = *reinterpret_cast<const int *>(blk + 592);
+                const double boundv = *reinterpret_cast<const double *>(blk + 600);
+                const double bound0 = readlane_f64(boundv, 0), bound1 = readlane_f64(boundv, 32);
+                const u64 liveH = hasB ? ~0ull : SM_LO;
+                const int cv = pick(cA, cB);                   // this half's child column
+                const int frv = half_bcast_i32(r4cP, cA, cB);  // row freed (cpp:277-278)
+                const u64 cand = __ballot(l < N && c4rP >= cv);  // rows of columns >= c and the parked rows
                 const u64 forbm = __ballot((cv == aP) ? (((forbP >> l) & 1u) != 0) : (l == frv));
                 int c4r = (l == frv) ? -1 : c4rP;
                 double sp, delta;
                 int pred, sink, hubRow, status;
                 u64 scanned;
-                dijkstra2<true>(Cs, LDC, uArr, rl, vP, c4r, cand, forbm, liveH, cv, boundv, sp, pred, scanned, delta, sink,
-                                hubRow, status);
+                KS_T(tD0);
+                dijkstra2<true>(Cs, LDC, uBlk, rl, vP, c4r, cand, forbm, true, hasB, cA, cB, bound0, bound1, sp, pred, scanned,
+                                delta, sink, hubRow, status);
+                KS_T(tD1);
+                KS_ACC(6, tD1 - tD0);  // [6] child dijkstra (pairs)
+                KS_ACC(10, __popcll(scanned));  // [10] rows scanned (both halves)
+                KS_ACC(11, 1);  // [11] child passes
                 u64 ok = __ballot(status == 0) & liveH;
                 if (!ok) continue;
                 int r4c = (l == cv) ? -1 : r4cP;
                 double vN = vP, uN;
-                augment2(ok, l, cv, sp, pred, scanned, delta, sink, hubRow, uArr, r4cP, M, vN, c4r, r4c, uN);
+                augment2(ok, l, cv, sp, pred, scanned, delta, sink, hubRow, uBlk, r4cP, M, vN, c4r, r4c, uN);
                 const double g = serial_gain2(r4c);
                 if (useCut) ok &= ~__ballot(maximize ? (g < cutG) : (g > cutG));  // cutHyp, cpp:496/521
                 if (!ok) continue;
                 int slot = 0, pos = 0;
                 if (l == 0 && ((ok >> lane) & 1ull)) {
-                    const int t = atomicAdd(&ctrl->freeTop, -1) - 1;
-                    slot = freeStack[t];
+                    const int tt = atomicAdd(&ctrl->freeTop, -1) - 1;
+                    slot = freeStack[tt];
                     pos = atomicAdd(&ctrl->nFresh[par], 1);
                 }
                 slot = pick(__builtin_amdgcn_readlane(slot, 0), __builtin_amdgcn_readlane(slot, 32));
                 pos = pick(__builtin_amdgcn_readlane(pos, 0), __builtin_amdgcn_readlane(pos, 32));
-                const int rnew = half_bcast_i32(r4c, a0 + j0, a1 + j1);
+                const int rnew = half_bcast_i32(r4c, cA, cB);
                 const u32 forbN = ((cv == aP) ? forbP : (1u << frv)) | (1u << rnew);  // cpp:362
                 store_state2(ok, slot, uN, vN, r4c, c4r, forbN, g, cv);
                 if (l == 0 && ((ok >> lane) & 1ull)) {
@@ -656,43 +790,54 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
                     FM[pos] = ((u32)sidv << 8) | (u32)cv;
                     FS[pos] = (unsigned short)slot;
                 }
+                KS_ACC(7, __builtin_readcyclecounter() - tD1);  // [7] finish of completed children
             }
         }
+        KS_T(tB1);
         __syncthreads();
+        KS_T(tMg);
+        KS_ACC(8, tMg - tB1);  // [8] wait at the barrier after the children
         // -- merge: old candidates that were not emitted + this round's children -> the other buffer, by rank; the
         //    R smallest stay.  Ties in gain: old before fresh, fresh by (parent, column).
         const int nFresh = uni32(ctrl->nFresh[par]);
-        if (tid == 0) ctrl->nFresh[par ^ 1] = 0;
+        if (tid == 0) { ctrl->nFresh[par ^ 1] = 0; ctrl->nSurv = 0; ctrl->nextItem = 0; }
         double *ng = PG + (cur ^ 1) * k;
         u32 *nm = PM + (cur ^ 1) * k;
         unsigned short *nsd = PS + (cur ^ 1) * k;
         for (int i = tid; i < nOld + nFresh; i += NT) {
-            double g;
-            u32 meta;
-            unsigned short sid;
+            const bool isOld = i < nOld;
+            const int j = headNew + i, f = i - nOld;
+            const double g = isOld ? pg[j] : FG[f];
+            const u32 meta = isOld ? (pm[j] | ((j <= lastSel) ? SM_SPLIT : 0u)) : FM[f];
+            const unsigned short sid = isOld ? ps[j] : FS[f];
+            // fresh gains below g (and, for a fresh entry, equal to it): four per pair of 16-byte broadcast reads
+            int below = 0, equal = 0;
+            {
+                const double2 *f2 = reinterpret_cast<const double2 *>(FG);
+                int q = 0;
+                for (; q + 4 <= nFresh; q += 4) {
+                    const double2 a = f2[q >> 1], c = f2[(q >> 1) + 1];
+                    below += ((a.x < g) ? 1 : 0) + ((a.y < g) ? 1 : 0) + ((c.x < g) ? 1 : 0) + ((c.y < g) ? 1 : 0);
+                    equal += ((a.x == g) ? 1 : 0) + ((a.y == g) ? 1 : 0) + ((c.x == g) ? 1 : 0) + ((c.y == g) ? 1 : 0);
+                }
+                for (; q < nFresh; q++) {
+                    const double g2 = FG[q];
+                    below += (g2 < g) ? 1 : 0;
+                    equal += (g2 == g) ? 1 : 0;
+                }
+            }
             int pos;
-            if (i < nOld) {
-                const int j = headNew + i;
-                g = pg[j];
-                meta = pm[j] | ((j <= lastSel) ? SM_SPLIT : 0u);
-                sid = ps[j];
-                pos = i;
-                for (int f = 0; f < nFresh; f++) pos += (FG[f] < g) ? 1 : 0;
+            if (isOld) {
+                pos = i + below;  // old before fresh among equal gains
             } else {
-                const int f = i - nOld;
-                g = FG[f];
-                meta = FM[f];
-                sid = FS[f];
                 int lo = 0, hiB = nOld;
                 while (lo < hiB) {
                     const int mid = (lo + hiB) >> 1;
                     if (pg[headNew + mid] <= g) lo = mid + 1; else hiB = mid;
                 }
-                pos = lo;
-                for (int f2 = 0; f2 < nFresh; f2++) {
-                    const double g2 = FG[f2];
-                    pos += (g2 < g || (g2 == g && FM[f2] < meta)) ? 1 : 0;
-                }
+                pos = lo + below;
+                if (__builtin_expect(equal > 1, 0))  // another fresh candidate with the same gain: order by (parent, column)
+                    for (int q = 0; q < nFresh; q++) pos += (FG[q] == g && FM[q] < meta) ? 1 : 0;
             }
             if (pos < R) {
                 ng[pos] = g;
@@ -706,8 +851,12 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
         nq = nOld + nFresh;
         if (nq > R) nq = R;
         cur ^= 1;
+        KS_T(tB2);
+        KS_ACC(12, tB2 - tMg);  // [12] merge
         __syncthreads();
+        KS_ACC(13, __builtin_readcyclecounter() - tB2);  // [13] ... and after the merge
     }
+    KS_T(tOut);
     __syncthreads();
     const int nf = E;
 
@@ -772,6 +921,12 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
         }
     }
     if (tid == 0) p.nf[b] = nf;
+#ifdef KB_PROFILE
+    profAcc[14] = __builtin_readcyclecounter() - tOut;   // [14] outputs / weights epilogue
+    profAcc[15] = __builtin_readcyclecounter() - profT0;  // [15] whole kernel (this wave)
+    if (p.prof && lane == 0)
+        for (int i = 0; i < 16; i++) atomicAdd(p.prof + (long long)b * 16 + i, profAcc[i]);
+#endif
 }
 
 template <int NW>

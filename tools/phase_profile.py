@@ -53,6 +53,20 @@ for it in range(2):
 ms = e0.elapsed_time(e1)
 p = prof.cpu().numpy().astype(np.float64)
 m = p.mean(axis=0)
+small = N <= 32 and not os.environ.get("KBEST_NO_SMALL")
+if small:
+    nw = int(os.environ.get("KBEST_SMALL_NW", "16" if B <= 256 else ("8" if B <= 512 else "4")))
+    names = ["tile set-up", "root (+barrier)", "rounds", "select+emission", "node load", "filter", "child dijkstra", "finish completed",
+             "wait after children", "wait after filter", "rows scanned", "child passes", "merge", "wait after merge", "epilogue", "kernel cyc (sum over waves)"]
+    tot = m[15]
+    print(f"{cfg} B={B} small kernel NW={nw} kernel {ms:.3f} ms (profiled build)")
+    for i, n in enumerate(names):
+        extra = f"  = {100*m[i]/tot:5.1f}% of wave-cycles, {m[i]/nw:9.0f} cyc/wave" if i not in (2, 10, 11) else ""
+        print(f"  [{i:2d}] {n:28s} {m[i]:14.1f}{extra}")
+    rounds = m[2] / nw
+    print(f"  rounds {rounds:.1f}; per wave kernel cycles {tot/nw:.0f} = {tot/nw/max(rounds,1):.0f} per round; dijkstra cycles per pass {m[6]/max(m[11],1):.0f}; rows scanned per pass {m[10]/max(m[11],1):.1f}")
+    print("  nf:", d_nf.cpu().numpy()[:8])
+    sys.exit(0)
 names = ["setup+root", "B busy", "C merge(+barrier)", "A/D busy", "children started", "child steps", "children completed",
          "rounds", "cyc in child dijkstra", "cyc child set-up", "cyc flip+gain", "wait after B", "wait after A", "kernel cyc (sum over waves)",
          "round prologue", "first-step filter busy"]
