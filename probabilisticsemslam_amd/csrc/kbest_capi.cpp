@@ -13,6 +13,8 @@
 #include "kbest_c.h"
 #include "kbest_engine.h"
 
+struct DevBufRaw { void *p = nullptr; size_t bytes = 0; };
+
 struct kbest_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -38,6 +40,13 @@ struct kbest_ctx {
     hipStream_t lastStream = nullptr;
     bool haveLast = false;
     hipEvent_t lastEvent = nullptr;
+    // Pinned, device-mapped staging of the per-frame association path: the reference calls getAssignmentProbs once
+    // per frame (system.cpp:268), so a call must cost one launch, not a dozen copies.  Small calls are zero-copy (the
+    // kernel reads the cost block from and writes the probabilities to this host memory directly); larger ones go
+    // through one asynchronous copy each way.
+    struct Arena { void *host = nullptr; void *dev = nullptr; size_t bytes = 0; };
+    Arena pinIn, pinOut;
+    DevBufRaw stageIn, stageOut;
     // Device buffers of the host-pointer entry points are recycled: the reference calls assignmentProb once per
     // frame, and a dozen hipMalloc/hipFree pairs per call cost more than the kernels of a 30 x 10 problem.
     struct Block { void *p; size_t n; bool used; };
@@ -259,6 +268,10 @@ int kbest_destroy(kbest_ctx *ctx)
     if (ctx->states) (void)hipFree(ctx->states);
     if (ctx->wide) (void)hipFree(ctx->wide);
     for (auto &b : ctx->cache) (void)hipFree(b.p);
+    if (ctx->pinIn.host) (void)hipHostFree(ctx->pinIn.host);
+    if (ctx->pinOut.host) (void)hipHostFree(ctx->pinOut.host);
+    if (ctx->stageIn.p) (void)hipFree(ctx->stageIn.p);
+    if (ctx->stageOut.p) (void)hipFree(ctx->stageOut.p);
     if (ctx->lastEvent) (void)hipEventDestroy(ctx->lastEvent);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -754,6 +767,123 @@ struct QuadricHost {  // host-side inputs of computeQuadricCostMatrix, packed fr
     double gate;
 };
 
+static int arena_reserve(kbest_ctx *ctx, kbest_ctx::Arena &a, size_t need)
+{
+    if (need <= a.bytes) return KBEST_OK;
+    size_t cap = 1 << 16;
+    while (cap < need) cap <<= 1;
+    if (a.host) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipHostFree(a.host); a.host = nullptr; a.bytes = 0; }
+    hipError_t e = hipHostMalloc(&a.host, cap, hipHostMallocMapped);
+    if (e != hipSuccess) return fail(ctx, KBEST_ERR_NOMEM, "hipHostMalloc(staging)", e);
+    e = hipHostGetDevicePointer(&a.dev, a.host, 0);
+    if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "hipHostGetDevicePointer", e);
+    a.bytes = cap;
+    return KBEST_OK;
+}
+
+static int raw_reserve(kbest_ctx *ctx, DevBufRaw &d, size_t need)
+{
+    if (need <= d.bytes) return KBEST_OK;
+    size_t cap = 1 << 16;
+    while (cap < need) cap <<= 1;
+    if (d.p) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(d.p); d.p = nullptr; d.bytes = 0; }
+    hipError_t e = hipMalloc(&d.p, cap);
+    if (e != hipSuccess) return fail(ctx, KBEST_ERR_NOMEM, "hipMalloc(staging)", e);
+    d.bytes = cap;
+    return KBEST_OK;
+}
+
+// The association path on the small-problem kernel (kbest_small.hip): conditionCosts -> kBest2DCutoff(42) -> weights
+// -> scatter back, ONE launch, only [nM][nL+1] doubles per frame come back.  Returns 1 when some frame does not fit
+// that kernel (more than 32 kept rows, ...): the caller then runs the general pipeline.
+struct QuadricHost;
+static int weights_small(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM, const int32_t *nRow, const double *cost,
+                         const double *d_cost, const int64_t *costOff, int k, double *probs, const int64_t *probOff,
+                         int32_t *nf, bool condition, bool bruteForce, int rawMaxRow, int maxCol, size_t nCost, size_t nProb)
+{
+    const int capRow = rawMaxRow < kb::SMALL_MAX_DIM ? rawMaxRow : kb::SMALL_MAX_DIM;
+    int nw = 0;
+    if (!small_fits(ctx, B, capRow, maxCol, k, true, &nw)) return 1;
+    if (!condition && rawMaxRow > kb::SMALL_MAX_DIM) return 1;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    {
+        int rc = order_behind_last(ctx, ctx->stream);
+        if (rc != KBEST_OK) return rc;
+        rc = ensure_states(ctx, small_states_need(B, capRow, maxCol, k, nw), true);
+        if (rc != KBEST_OK) return rc;
+    }
+    // in: [costOff | probOff | nRow | nM | nL] [cost blocks]      out: [probabilities] [nf]
+    const size_t B8 = ((size_t)B * 8 + 15) & ~(size_t)15, B4 = ((size_t)B * 4 + 15) & ~(size_t)15;
+    const size_t metaBytes = 2 * B8 + 3 * B4;
+    const size_t inBytes = metaBytes + (d_cost ? 0 : nCost * 8);
+    const size_t probBytes = (nProb * 8 + 15) & ~(size_t)15;
+    const size_t outBytes = probBytes + (size_t)B * 4;
+    {
+        int rc = arena_reserve(ctx, ctx->pinIn, inBytes);
+        if (rc == KBEST_OK) rc = arena_reserve(ctx, ctx->pinOut, outBytes);
+        if (rc != KBEST_OK) return rc;
+    }
+    unsigned char *hin = static_cast<unsigned char *>(ctx->pinIn.host);
+    memcpy(hin, costOff, (size_t)B * 8);
+    memcpy(hin + B8, probOff, (size_t)B * 8);
+    memcpy(hin + 2 * B8, nRow, (size_t)B * 4);
+    memcpy(hin + 2 * B8 + B4, nM, (size_t)B * 4);
+    memcpy(hin + 2 * B8 + 2 * B4, nL, (size_t)B * 4);
+    if (!d_cost) memcpy(hin + metaBytes, cost, nCost * 8);
+    const bool zeroCopy = inBytes + outBytes <= ((size_t)192 << 10);  // a few frames: no copy engine round trips at all
+    unsigned char *din, *dout;
+    if (zeroCopy) {
+        din = static_cast<unsigned char *>(ctx->pinIn.dev);
+        dout = static_cast<unsigned char *>(ctx->pinOut.dev);
+    } else {
+        int rc = raw_reserve(ctx, ctx->stageIn, inBytes);
+        if (rc == KBEST_OK) rc = raw_reserve(ctx, ctx->stageOut, outBytes);
+        if (rc != KBEST_OK) return rc;
+        din = static_cast<unsigned char *>(ctx->stageIn.p);
+        dout = static_cast<unsigned char *>(ctx->stageOut.p);
+        HIP_TRY(ctx, hipMemcpyAsync(din, hin, inBytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    kb::SmallParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.cost = d_cost ? d_cost : reinterpret_cast<const double *>(din + metaBytes);
+    sp.costOff = reinterpret_cast<const long long *>(din);
+    sp.probOff = reinterpret_cast<const long long *>(din + B8);
+    sp.nRow = reinterpret_cast<const int *>(din + 2 * B8);
+    sp.nCol = reinterpret_cast<const int *>(din + 2 * B8 + B4);
+    sp.nL = reinterpret_cast<const int *>(din + 2 * B8 + 2 * B4);
+    sp.maxRow = capRow;
+    sp.maxCol = maxCol;
+    sp.ldRow = capRow;
+    sp.ldCol = maxCol;
+    sp.k = k;
+    sp.maximize = 0;
+    sp.useCutoff = bruteForce ? 0 : 1;  // assignment.cpp:594: kBest2DCutoff(..., cutoff = 42); :880: plain kBest2D
+    sp.cutoff = 42.0;
+    sp.nf = reinterpret_cast<int *>(dout + probBytes);
+    sp.states = ctx->states;
+    sp.stateStride = kb::small_state_stride(capRow, maxCol);
+    sp.statesPerProblem = kb::small_states_per_problem(k, nw, maxCol);
+    sp.weights = 1;
+    sp.condition = condition ? 1 : 0;
+    sp.gate = bruteForce ? 0 : 1;
+    sp.probs = reinterpret_cast<double *>(dout);
+    sp.prof = ctx->prof;
+    hipError_t e = kb::launch_kbest_small(sp, B, nw, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "association kernel launch", e);
+    unsigned char *hout = static_cast<unsigned char *>(ctx->pinOut.host);
+    if (!zeroCopy) HIP_TRY(ctx, hipMemcpyAsync(hout, dout, outBytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const int32_t *hnf = reinterpret_cast<const int32_t *>(hout + probBytes);
+    for (int b = 0; b < B; b++)
+        if (hnf[b] == -2) return 1;  // a frame that keeps more rows than this kernel takes: general pipeline
+    memcpy(probs, hout, nProb * 8);
+    if (nf) memcpy(nf, hnf, (size_t)B * 4);
+    for (int b = 0; b < B; b++)
+        if (hnf[b] < 0) return fail(ctx, KBEST_ERR_INTERNAL, "association kernel: a frame came back with nf < 0");
+    return KBEST_OK;
+}
+
 static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM, const double *cost,
                             const int64_t *costOff, int k, double *probs, const int64_t *probOff, int32_t *nf,
                             bool condition, const QuadricHost *quad = nullptr, bool bruteForce = false)
@@ -766,7 +896,8 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
     size_t nCost = 0, nProb = 0;
     std::vector<int32_t> nRow(B);
     for (int b = 0; b < B; b++) {
-        if (nM[b] < 1 || nL[b] < 0) return fail(ctx, KBEST_ERR_BAD_ARG, "weights: need nM >= 1, nL >= 0");
+        // (a frame without measurements is legal and empty: getAssignmentProbs returns nothing for it, assignment.cpp:50-51)
+        if (nM[b] < 0 || nL[b] < 0) return fail(ctx, KBEST_ERR_BAD_ARG, "weights: need nM >= 0, nL >= 0");
         nRow[b] = nL[b] + nM[b];
         if (nRow[b] > maxRow) maxRow = nRow[b];
         if (nM[b] > maxCol) maxCol = nM[b];
@@ -781,6 +912,12 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
     const int rawMaxRow = maxRow;
     if (!condition && maxRow > KBEST_MAX_DIM_WIDE) return fail(ctx, KBEST_ERR_UNSUPPORTED, "nL + nM > KBEST_MAX_DIM_WIDE");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!quad && k >= 1 && maxCol <= kb::SMALL_MAX_DIM && rawMaxRow <= kb::SMALL_MAX_RAW_ROWS) {
+        // the frame-sized case: one fused launch (kbest_small.hip)
+        const int rc = weights_small(ctx, B, nL, nM, nRow.data(), cost, nullptr, costOff, k, probs, probOff, nf, condition,
+                                     bruteForce, rawMaxRow, maxCol, nCost, nProb);
+        if (rc != 1) return rc;
+    }
     // The five per-problem index arrays travel as ONE block (one copy instead of five), and nf sits right behind
     // the probabilities (one copy back instead of two): per-frame calls are dominated by call overheads.
     DevBuf dCost, dCond, dMeta, dGood, dCondL, dRowIdx, dR4C, dGain, dOut;

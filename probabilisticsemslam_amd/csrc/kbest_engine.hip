@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     const int M = p.nCol ? p.nCol[b] : p.maxCol;
     const int k = p.k;
     if (N < 1 || M < 1 || N < M || N > p.maxRow || M > p.maxCol) {  // undefined in the reference
-        if (tid == 0) p.nf[b] = -1;
+        if (tid == 0) p.nf[b] = (M == 0 || N == 0) ? 0 : -1;            // (an empty frame: nothing to assign, nothing found)
         return;
     }
     // odd column stride of the LDS cost tile: row-wise (lane = row) and column-wise (lane = column) walks are
