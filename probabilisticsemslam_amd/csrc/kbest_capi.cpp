@@ -28,6 +28,7 @@ struct kbest_ctx {
     int ldsPerCU = 160 * 1024;
     int nCU = 256;
     int smallWaves = 0;  // waves per problem of the small-problem kernel; 0 = choose per launch (KBEST_SMALL_NW)
+    bool forceSmall = false;  // KBEST_FORCE_SMALL: every batch of <= 32-row problems through the small-problem kernel
     bool noSmall = false;  // KBEST_NO_SMALL: problems of <= 32 rows through the 64-row kernel as well (A/B tests)
     int extraStates = 64;  // lazy state slots beyond k per matrix (room for speculative re-solves)
     int eagerStates = 1024; // state slots per matrix for children that are kept in full when they are found
@@ -247,6 +248,7 @@ int kbest_create(kbest_ctx **out, int device)
         if (w == 2 || w == 4 || w == 8 || w == 16) ctx->smallWaves = w;
     }
     ctx->noSmall = getenv("KBEST_NO_SMALL") != nullptr;
+    ctx->forceSmall = getenv("KBEST_FORCE_SMALL") != nullptr;
     if (const char *e = getenv("KBEST_SPEC")) {
         int w = atoi(e);
         if (w >= 1 && w <= 16) ctx->spec = w;
@@ -472,9 +474,13 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
     // Problems of up to 32 rows: the small-problem kernel (half-wave workers, implicit zero columns).  The modes that
     // need the reference's exact order of splits (push counting), no pruning, subtree sharding or the duals of the
     // padded formulation stay on the 64-row kernel.
+    // Which of the two wins was measured: the small kernel on rectangular problems (implicit zero columns:
+    // a third of the Dijkstra steps) and on batches that cannot fill the chip (latency: 32 workers per problem, two
+    // barriers per round); the 64-row kernel with its hand-written step loop on large batches of square problems.
     int snw = 0;
-    if (!extra && !forceWide && !(opts->flags & (KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_PRUNE)) && opts->root_col_stride <= 1 &&
-        small_fits(ctx, B, maxRow, maxCol, k, false, &snw)) {
+    const bool smallWins = ctx->forceSmall || maxCol < maxRow || B <= 2 * ctx->nCU;
+    if (!extra && !forceWide && smallWins && !(opts->flags & (KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_PRUNE)) &&
+        opts->root_col_stride <= 1 && small_fits(ctx, B, maxRow, maxCol, k, false, &snw)) {
         int rc = ensure_states(ctx, small_states_need(B, maxRow, maxCol, k, snw), grow);
         if (rc != KBEST_OK) return rc;
         kb::SmallParams sp;

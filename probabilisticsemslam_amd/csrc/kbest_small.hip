@@ -508,8 +508,21 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
         if (l < M && r4c >= 0) t = Cs[r4c + l * LDC];
         gainW[l] = t;
         wave_fence();
+        // the chain of adds reads the terms back as 16-byte reads, eight per round trip, in the reference's order; the
+        // lanes beyond M parked +0.0, and x + 0.0 == x exactly for the non-negative partial sums here
         double acc = 0.0;
-        for (int j = 0; j < M; j++) acc = acc + gainW[j];
+        const double2 *terms = reinterpret_cast<const double2 *>(gainW);
+        for (int j0 = 0; j0 < M; j0 += 8) {
+            const double2 a = terms[(j0 >> 1)], bq = terms[(j0 >> 1) + 1], c = terms[(j0 >> 1) + 2], d = terms[(j0 >> 1) + 3];
+            acc = acc + a.x;
+            acc = acc + a.y;
+            acc = acc + bq.x;
+            acc = acc + bq.y;
+            acc = acc + c.x;
+            acc = acc + c.y;
+            acc = acc + d.x;
+            acc = acc + d.y;
+        }
         wave_fence();
         return acc;
     };
@@ -575,7 +588,7 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
         KS_T(tSel);
         KS_ACC(2, 1);  // [2] rounds
         // -- select: the first W not-yet-split candidates, in pool order; this wave's two are the (2 wave)-th and the next
-        int cnt = 0, firstU = -1, idx0 = -1, idx1 = -1;
+        int cnt = 0, firstU = -1, idx0 = -1, idx1 = -1, idxW = -1, lastOpen = -1;
         for (int base = 0; base < nq && cnt < W; base += 64) {
             const int i = base + lane;
             const bool open = i < nq && !(pm[i] & SM_SPLIT);
@@ -583,27 +596,18 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
             if (m) {
                 const int rank = cnt + __popcll(m & ((1ull << lane) - 1ull));
                 if (firstU < 0) firstU = base + __builtin_ctzll(m);
-                const u64 h0 = __ballot(open && rank == 2 * wave), h1 = __ballot(open && rank == 2 * wave + 1);
+                const u64 h0 = __ballot(open & (rank == 2 * wave)), h1 = __ballot(open & (rank == 2 * wave + 1));
+                const u64 hW = __ballot(open & (rank == W - 1));
                 if (h0) idx0 = base + __builtin_ctzll(h0);
                 if (h1) idx1 = base + __builtin_ctzll(h1);
+                if (hW) idxW = base + __builtin_ctzll(hW);
+                lastOpen = base + 63 - __builtin_clzll(m);
                 cnt += __popcll(m);
             }
         }
         const int nsel = cnt < W ? cnt : W;
         // the last selected entry (the nsel-th open one): every open entry up to it is selected
-        int lastSel = -1;
-        if (nsel > 0) {
-            int c2 = 0;
-            for (int base = 0; base < nq && lastSel < 0; base += 64) {
-                const int i = base + lane;
-                const bool open = i < nq && !(pm[i] & SM_SPLIT);
-                const u64 m = __ballot(open);
-                const int rank = c2 + __popcll(m & ((1ull << lane) - 1ull));
-                const u64 h = __ballot(open && rank == nsel - 1);
-                if (h) lastSel = base + __builtin_ctzll(h);
-                c2 += __popcll(m);
-            }
-        }
+        const int lastSel = (cnt >= W) ? idxW : lastOpen;
         // -- emission (kBest2D cpp:607-634): the head goes out while it has been split; the first not yet split one
         //    is split in THIS round: it is emitted too, but ends the run (its children are not in the pool yet)
         int run = (nsel > 0) ? firstU + 1 : nq;
