@@ -1,26 +1,37 @@
 #!/usr/bin/env python3
-"""bench.py -- k-best assignments/sec of the MI355X engine on BASELINE.json's workload.
+"""bench.py -- k-best assignments/sec of the MI355X engine on BASELINE.json's workloads.
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path (one batched kernel launch) over one batch of synthetic cost
-matrices that already live in HBM.  Workload (config.workload): BASELINE.json configs[3] shape --
-1024 dense 64x64 cost matrices, k = 200 -- PER GPU (weak scaling: every rank gets its own 1024
-matrices of the same seeded stream; no data-path collective is needed because the matrices are
-independent; with N > 1 each step ends with the RCCL all-gather of the per-rank top-k gains that
-assembles the global result table).
+One "step" = one pass of the hot path (one batched kernel launch) over one batch of synthetic inputs that already
+live in HBM.  Headline workload (config.workload): BASELINE.json configs[3] shape -- 1024 dense 64x64 cost matrices,
+k = 200.  `--scaling weak` (default): PER GPU (every rank gets its own 1024 matrices of the same seeded stream);
+`--scaling strong`: configs[3] literally -- 1024 matrices in all, a contiguous block per rank.  The matrices are
+independent, so there is no data-path collective; with N > 1 each step ends with the RCCL all-gather of the packed
+per-rank result table (gain[k], row4col[k*M], nf per matrix -- SURVEY 8(e)) that assembles the global table, overlapped
+with the next step's kernel.
 
-Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes per launch (SURVEY 8(d)
-B_alg, with P counted by the engine itself in its no-prune mode and cross-checked against the oracle
-on the cpu_baseline sample) / average kernel duration measured with HIP events on the launch stream.
-`cpu_baseline` = the reference solver (oracle/_ref, built from the unmodified reference source with
-its own -Ofast) timed on one host core on a bounded sample of the same workload; falls back to the
-oracle restatement ("port") when oracle/_ref is absent.
+Prints ONE JSON line (rank 0):
+  roofline.achieved   = algorithmic bytes per launch (SURVEY 8(d) B_alg, with P counted by the engine itself in its
+                        no-prune mode and cross-checked against the reference on the cpu_baseline sample) / average
+                        kernel duration measured with HIP events on the launch stream; roofline.traffic = HBM bytes per
+                        launch from the committed rocprofv3 PMC passes (profiles/);
+  issue               = what actually bounds the kernel (vector-unit busy fraction etc.) from the same profiles;
+  cpu_baseline        = the reference solver (oracle/_ref, built from the unmodified reference source with its own
+                        -Ofast) timed on one host core on a bounded sample of the same workload; "port" (the oracle
+                        restatement) when oracle/_ref is absent;
+  value_host_inclusive= the same batch through the host-pointer entry (H2D of the cost blocks and D2H of the result
+                        tables included -- SURVEY 8(d)'s metric definition; never `value`);
+  configs             = the other BASELINE configs measured in the same run: c2 (1024 x 16x16, k=50), c3 (4096 x
+                        32x32, k=200), c5 (1000 streamed 30x10 KITTI-like frames through the fused association kernel:
+                        batched throughput AND one-frame-per-call latency, weights checked against the reference).
+`--config c2|c3|c5` makes that configuration the headline of the line instead.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -33,18 +44,77 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+CLOCK_HZ = 2.4e9       # peak shader clock (MI355X_MICROARCH.md); 256 CUs x 4 SIMDs
+N_SIMD = 1024
+
+
+def state_bytes(D):
+    """one hypothesis = u, v (fp64), row4col, col4row (u8), forbidden bitmask, gain/activeCol/flags."""
+    return 16 * D + 2 * D + (D + 7) // 8 + 16
 
 
 def algorithmic_bytes(N, M, k, nf, pushed):
     """B_alg = 8NM + nf(8+4N+4M) + (P + nf - 1) * state(D)."""
-    D = N
-    state = 16 * D + 2 * D + (D + 7) // 8 + 16
     nf = np.asarray(nf, dtype=np.int64)
     pushed = np.asarray(pushed, dtype=np.int64)
-    return 8 * N * M * len(nf) + int((nf * (8 + 4 * N + 4 * M)).sum()) + int(((pushed + nf - 1) * state).sum())
+    return 8 * N * M * len(nf) + int((nf * (8 + 4 * N + 4 * M)).sum()) + int(((pushed + nf - 1) * state_bytes(N)).sum())
 
 
-def cpu_baseline(costs, N, M, k, sample):
+def profile_summary(cfg):
+    """profiles/r02_<cfg>_summary.json (tools/prof.sh + tools/prof_summary.py on the GPU box): HBM traffic and the
+    instruction-issue counters of the dominant kernel for this configuration, or None."""
+    for rnd in ("r02",):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{cfg}_summary.json")
+        if os.path.exists(path):
+            try:
+                j = json.load(open(path))
+                j["_file"] = os.path.relpath(path, ROOT)
+                return j
+            except Exception:
+                pass
+    return None
+
+
+def issue_block(cfg):
+    """The bound that is real for this path: instruction issue.  VALU-busy = SQ_INSTS_VALU x 4 cycles (fp64 / 16 lanes
+    per clock per SIMD) / (1024 SIMDs x kernel cycles)."""
+    j = profile_summary(cfg)
+    if not j or "pmc" not in j or "kernel_avg_us_timed" not in j:
+        return None
+    pm, us = j["pmc"], j["kernel_avg_us_timed"]
+    cyc = N_SIMD * us * 1e-6 * CLOCK_HZ
+    out = {"source": j["_file"], "kernel_us": us}
+    if "SQ_INSTS_VALU" in pm:
+        out["valu_busy_frac"] = pm["SQ_INSTS_VALU"] * 4.0 / cyc
+        out["valu_insts"] = pm["SQ_INSTS_VALU"]
+    if "SQ_INSTS_SALU" in pm:
+        out["salu_insts"] = pm["SQ_INSTS_SALU"]
+    if "SQ_INSTS_LDS" in pm:
+        out["lds_insts"] = pm["SQ_INSTS_LDS"]
+    if "SQ_WAIT_ANY" in pm and "SQ_WAVE_CYCLES" in pm and pm["SQ_WAVE_CYCLES"]:
+        out["wave_wait_frac"] = pm["SQ_WAIT_ANY"] / pm["SQ_WAVE_CYCLES"]
+    out["bound"] = "instruction issue / latency (not HBM): see DESIGN.md section 8"
+    return out
+
+
+def roofline_block(cfg, B, balg, kern_ms, extra=None):
+    ach = balg / (kern_ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+         "achieved_basis": "algorithmic bytes per launch (SURVEY 8(d) B_alg) / mean kernel time (HIP events)",
+         "traffic": None, "algorithmic_bytes_per_launch": balg}
+    j = profile_summary(cfg)
+    if j and j.get("batch") == B and "bytes_per_launch" in j:  # PMC-measured HBM bytes per launch (profiles/README.md)
+        r["traffic"] = j["bytes_per_launch"]
+        r["traffic_GBps"] = j["bytes_per_launch"] / (kern_ms * 1e-3) / 1e9
+        r["traffic_frac_of_peak"] = r["traffic_GBps"] / HBM_PEAK_GBS
+        r["traffic_source"] = j["_file"]
+    if extra:
+        r.update(extra)
+    return r
+
+
+# ------------------------------------------------------------------------------------------------ CPU baselines
+def cpu_dense(costs, N, M, k, sample):
     """Reference solver on ONE host core over `sample` problems of the same batch."""
     import oracle_lib as ol
     sample = min(sample, costs.shape[0])
@@ -110,15 +180,259 @@ def cpu_all_cores(costs, N, M, k):
             "sample": f"all {B} matrices of rank 0's batch, one kBest2D call each, {T} threads, {dt:.1f} s"}
 
 
+# ------------------------------------------------------------------------------------------------ dense configs
+def run_dense(eng, torch, dist, cfg, B, steps, warmup, rank, world, dev, tstream, use_dist, first):
+    """C2 / C3 / C4: B dense matrices resident in HBM, one launch per step.  Returns the measurements of this rank."""
+    from probabilisticsemslam_amd import workloads as wl
+    _, N, M, k, seed = wl.DENSE_CONFIGS[cfg]
+    costs = wl.dense_batch(B, N, M, seed, first=first)  # rank-private slice of the one seeded stream
+    stream = tstream.cuda_stream
+    d_cost = torch.from_numpy(costs).to(dev)
+    d_c4r = torch.empty((B, k, N), dtype=torch.int32, device=dev)
+    d_pushed = torch.zeros(B, dtype=torch.int64, device=dev)
+    nbuf = 2 if use_dist else 1
+    d_r4c = [torch.empty((B, k, M), dtype=torch.int32, device=dev) for _ in range(nbuf)]
+    d_gain = [torch.empty((B, k), dtype=torch.float64, device=dev) for _ in range(nbuf)]
+    d_nf = [torch.empty(B, dtype=torch.int32, device=dev) for _ in range(nbuf)]
+    # global result table of the all-gather (SURVEY 8(e): gain[k] + row4col[k*M] + nf per matrix)
+    g_r4c = [torch.empty((world * B, k, M), dtype=torch.int32, device=dev) for _ in range(nbuf)] if use_dist else None
+    g_gain = [torch.empty((world * B, k), dtype=torch.float64, device=dev) for _ in range(nbuf)] if use_dist else None
+    g_nf = [torch.empty(world * B, dtype=torch.int32, device=dev) for _ in range(nbuf)] if use_dist else None
+    eng.reserve(B, N, k)
+    torch.cuda.synchronize()  # the allocations / fills above ran on the default stream
+    # untimed: the reference's push count P per matrix (no-prune mode), for the algorithmic byte count
+    eng.kbest_dev(d_cost, B, N, M, k, d_r4c[0], d_c4r, d_gain[0], d_nf[0], d_pushed=d_pushed, prune=False, stream=stream)
+    torch.cuda.synchronize()
+    pushed = d_pushed.cpu().numpy()
+    nf_ref = d_nf[0].cpu().numpy().copy()
+    g_ref = d_gain[0].cpu().numpy().copy()
+    pending = [None] * nbuf
+
+    def step(i, ev=None):
+        b = i % nbuf
+        if pending[b] is not None:
+            for w in pending[b]:
+                w.wait()  # the gathers of step i-2 have read this set of tables
+            pending[b] = None
+        if ev is not None:
+            ev[0].record()
+        eng.kbest_dev(d_cost, B, N, M, k, d_r4c[b], d_c4r, d_gain[b], d_nf[b], stream=stream)
+        if ev is not None:
+            ev[1].record()
+        if use_dist:  # the packed per-rank table travels while the next step's kernel runs
+            pending[b] = [dist.all_gather_into_tensor(g_gain[b], d_gain[b], async_op=True),
+                          dist.all_gather_into_tensor(g_r4c[b], d_r4c[b], async_op=True),
+                          dist.all_gather_into_tensor(g_nf[b], d_nf[b], async_op=True)]
+
+    def drain():
+        for b in range(nbuf):
+            if pending[b] is not None:
+                for w in pending[b]:
+                    w.wait()
+                pending[b] = None
+
+    for i in range(warmup):
+        step(i)
+    drain()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i, ev[i])
+    drain()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    last = (steps - 1) % nbuf
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    nf = d_nf[last].cpu().numpy()
+    g = d_gain[last].cpu().numpy()
+    r4c = d_r4c[last].cpu().numpy()
+    # the timed (pruning) path must reproduce the no-prune run bit for bit
+    parity_self = bool((nf == nf_ref).all() and (g.view(np.int64) == g_ref.view(np.int64)).all())
+    if use_dist and world > 1:  # every rank must hold the same global table
+        assert torch.equal(g_gain[last][rank * B:(rank + 1) * B], d_gain[last])
+        assert torch.equal(g_r4c[last][rank * B:(rank + 1) * B], d_r4c[last])
+        chk = torch.stack([g_gain[last].sum(), g_r4c[last].double().sum(), g_nf[last].double().sum()])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert torch.equal(lo, hi), "ranks hold different global tables"
+    return dict(costs=costs, N=N, M=M, k=k, seed=seed, B=B, dt=dt, kern_ms=kern_ms, nf=nf, g=g, r4c=r4c, pushed=pushed,
+                parity_self=parity_self, found=int(nf.sum()), balg=algorithmic_bytes(N, M, k, nf, pushed))
+
+
+def host_inclusive_dense(eng, costs, N, M, k):
+    """The same batch through the host-pointer entry: pageable H2D of the cost blocks, launch, D2H of all tables."""
+    eng.kbest(costs, N, M, k)
+    t0 = time.perf_counter()
+    nf = eng.kbest(costs, N, M, k)[0]
+    dt = time.perf_counter() - t0
+    return {"value": float(nf.sum()) / dt, "unit": "assignments/s", "ms": 1e3 * dt,
+            "includes": "H2D of the cost blocks (pageable), kernel, D2H of row4col / col4row / gain / nf (pageable)"}
+
+
+def dense_entry(eng, torch, cfg, steps, warmup, dev, tstream, cpu_sample, no_cpu):
+    """One BASELINE config as an entry of the `configs` block (single GPU)."""
+    from probabilisticsemslam_amd import workloads as wl
+    Bc = wl.DENSE_CONFIGS[cfg][0]
+    m = run_dense(eng, torch, None, cfg, Bc, steps, warmup, 0, 1, dev, tstream, False, 0)
+    N, M, k = m["N"], m["M"], m["k"]
+    e = {"workload": f"{Bc} dense {N}x{M} cost matrices, k={k} (splitmix64 seed {m['seed']:#x}), kBest2D semantics",
+         "steps": steps, "ms_per_step": 1e3 * m["dt"] / steps, "kernel_ms": m["kern_ms"],
+         "value": m["found"] * steps / m["dt"], "unit": "assignments/s", "problems_per_s": Bc * steps / m["dt"],
+         "parity_prune_vs_noprune": m["parity_self"], "mean_pushed_per_matrix": float(m["pushed"].mean()),
+         "roofline": roofline_block(cfg, Bc, m["balg"], m["kern_ms"])}
+    iss = issue_block(cfg)
+    if iss:
+        e["issue"] = iss
+    if not no_cpu:
+        cb, r4c_cpu, g_cpu, p_cpu = cpu_dense(m["costs"], N, M, k, cpu_sample)
+        ns = min(cpu_sample, Bc)
+        cb["parity_vs_gpu"] = bool((g_cpu.reshape(-1, k)[:ns].view(np.int64) == m["g"][:ns].view(np.int64)).all()
+                                   and (np.asarray(r4c_cpu).reshape(-1, k, M)[:ns] == m["r4c"][:ns]).all())
+        e["cpu_baseline"] = cb
+        e["speedup_vs_cpu_1core"] = e["value"] / cb["value"]
+    return e
+
+
+# ------------------------------------------------------------------------------------------------ config 5
+def run_c5(eng, torch, steps, warmup, dev, tstream, no_cpu, F=1000, k=200, nL=20, nM=10, kernel_only=False):
+    """C5: F streamed KITTI-like frames, (nL+nM) x nM raw cost blocks, through the fused association
+    kernel (conditionCosts -> kBest2DCutoff(k, 42) -> weights -> scatter back).  Batched throughput with the blocks
+    resident in HBM, the host-inclusive batched call, and the reference's own call pattern: one frame per call."""
+    from probabilisticsemslam_amd import workloads as wl
+    import oracle_lib as ol
+    frames = wl.kitti_like_frames(F, nL=nL, nM=nM)
+    nR = nL + nM
+    stream = tstream.cuda_stream
+    raw = np.ascontiguousarray(np.concatenate(frames))
+    h_nL = np.full(F, nL, np.int32)
+    h_nM = np.full(F, nM, np.int32)
+    h_nRow = np.full(F, nR, np.int32)
+    h_coff = (np.arange(F, dtype=np.int64) * nR * nM)
+    h_poff = (np.arange(F, dtype=np.int64) * nM * (nL + 1))
+    d_cost = torch.from_numpy(raw).to(dev)
+    d_nL, d_nM, d_nRow = (torch.from_numpy(a).to(dev) for a in (h_nL, h_nM, h_nRow))
+    d_coff, d_poff = torch.from_numpy(h_coff).to(dev), torch.from_numpy(h_poff).to(dev)
+    d_probs = torch.zeros(F * nM * (nL + 1), dtype=torch.float64, device=dev)
+    d_nf = torch.zeros(F, dtype=torch.int32, device=dev)
+    eng.reserve_assoc(F, nR, nM, k)
+    torch.cuda.synchronize()
+
+    def launch():
+        eng.assoc_probs_dev(F, nR, nM, d_nL, d_nM, d_nRow, d_cost, d_coff, k, d_probs, d_poff, d_nf, stream=stream)
+
+    for _ in range(warmup):
+        launch()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ev[i][0].record()
+        launch()
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    nf = d_nf.cpu().numpy()
+    probs = d_probs.cpu().numpy().reshape(F, nM, nL + 1)
+    assert (nf >= 0).all(), "a frame did not fit the fused kernel"
+    if kernel_only:  # under the profiler: only the timed launches
+        return {"workload": f"{F} streamed frames (kernel only)", "frames": F, "steps": steps, "ms_per_step": 1e3 * dt / steps,
+                "kernel_ms": kern_ms, "value": float(nf.sum()) * steps / dt, "unit": "assignments/s"}
+    # -- the host-pointer entry: all frames in one call, and the reference's call pattern, one frame per call
+    lib, ctx = eng.lib, eng.ctx
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    hp = np.zeros(F * nM * (nL + 1))
+    hnf = np.zeros(F, np.int32)
+    for _ in range(2):
+        t1 = time.perf_counter()
+        rc = lib.kbest_assoc_probs_batch_f64(ctx, F, p(h_nL), p(h_nM), p(raw), p(h_coff), k, p(hp), p(h_poff), p(hnf))
+        host_ms = 1e3 * (time.perf_counter() - t1)
+    assert rc == 0 and (hnf == nf).all() and np.array_equal(hp.reshape(probs.shape), probs)
+    one_l, one_m, zero = np.array([nL], np.int32), np.array([nM], np.int32), np.zeros(1, np.int64)
+    op, onf = np.zeros(nM * (nL + 1)), np.zeros(1, np.int32)
+    ncall = min(F, 400)
+    lat = np.empty(ncall)
+    for i in range(-20, ncall):  # 20 untimed calls first
+        f = frames[i % F]
+        t1 = time.perf_counter()
+        lib.kbest_assoc_probs_batch_f64(ctx, 1, p(one_l), p(one_m), p(f), p(zero), k, p(op), p(zero), p(onf))
+        if i >= 0:
+            lat[i] = time.perf_counter() - t1
+            if i < 8:
+                assert np.array_equal(op.reshape(nM, nL + 1), probs[i])
+    # -- algorithmic bytes: raw block in, probabilities out, hypothesis states (P counted by the engine on the
+    #    conditioned blocks in its no-prune mode, D = rows conditionCosts keeps)
+    conds, idxs = eng.condition_costs(frames, [nR] * F, [nM] * F)
+    D = np.array([len(i) for i in idxs], np.int32)
+    coff = np.zeros(F, np.int64)
+    coff[1:] = np.cumsum(D[:-1].astype(np.int64) * nM)
+    _, _, _, _, pushed = eng.kbest(np.concatenate(conds), int(D.max()), nM, k, cutoff=42.0, nRow=D,
+                                   nCol=np.full(F, nM, np.int32), costOff=coff, count_pushed=True, prune=False)
+    balg = int(8 * nR * nM * F + 8 * nM * (nL + 1) * F + sum((int(pushed[i]) + int(nf[i]) - 1) * state_bytes(int(D[i])) for i in range(F)))
+    out = {"workload": f"{F} streamed KITTI-like frames, raw ({nL}+{nM})x{nM} cost blocks (SURVEY 8(d) C5 generator, seed 0xc0ffee), "
+                       f"conditionCosts -> kBest2DCutoff(k={k}, 42) -> weights -> scatter back, one fused launch",
+           "frames": F, "steps": steps, "ms_per_step": 1e3 * dt / steps, "kernel_ms": kern_ms,
+           "value": float(nf.sum()) * steps / dt, "unit": "assignments/s", "frames_per_s": F * steps / dt,
+           "kernel_us_per_frame_batched": 1e3 * kern_ms / F,
+           "host_inclusive_batched": {"ms": host_ms, "us_per_frame": 1e3 * host_ms / F,
+                                      "includes": "pinned staging copy, one launch, copy back: kbest_assoc_probs_batch_f64 with all frames"},
+           "one_frame_per_call": {"us_mean": 1e6 * float(lat.mean()), "us_median": 1e6 * float(np.median(lat)),
+                                  "us_p95": 1e6 * float(np.percentile(lat, 95)), "calls": ncall,
+                                  "what": "kbest_assoc_probs_batch_f64(B=1) per frame, host buffers in and out (the reference's "
+                                          "call pattern, system.cpp:268): zero-copy pinned staging, one launch, one stream sync"},
+           "mean_rows_kept": float(D.mean()), "mean_pushed_per_frame": float(pushed.mean()),
+           "roofline": roofline_block("c5", F, balg, kern_ms)}
+    iss = issue_block("c5")
+    if iss:
+        out["issue"] = iss
+    if not no_cpu:
+        # the reference's own conditionCosts + assignmentProb (verbatim slices of assignment.cpp, -Ofast), one core
+        kind = "reference" if os.path.exists(ol.REF_ASSIGN_OFAST_SO) else "port"
+        ref_p = np.zeros_like(probs)
+        tot = 0
+        t1 = time.perf_counter()
+        for i, f in enumerate(frames):
+            if kind == "reference":
+                c, ridx = ol.ref_condition_costs(f, nR, nM)
+                q = ol.ref_assignment_prob(c, len(ridx) - nM, nM, k, ofast=True)
+            else:
+                c, ridx = ol.condition_costs(f, nR, nM)
+                q, _ = ol.assignment_prob(c, len(ridx) - nM, nM, k)
+            cl = len(ridx) - nM
+            ref_p[i][:, np.asarray(ridx[:cl], dtype=np.int64)] = q[:, :cl]
+            ref_p[i][:, nL] = q[:, cl]
+        cpu_dt = time.perf_counter() - t1
+        tot = int(nf.sum())
+        err = float(np.abs(ref_p - probs).max())
+        out["cpu_baseline"] = {"value": tot / cpu_dt, "unit": "assignments/s", "cores": 1, "kind": kind,
+                               "us_per_frame": 1e6 * cpu_dt / F,
+                               "sample": f"all {F} frames, conditionCosts + assignmentProb(k={k}) per frame as getAssignmentProbs "
+                                         f"calls them (assignment.cpp:57-74), single thread, {cpu_dt:.2f} s",
+                               "weights_max_abs_err_vs_gpu": err, "parity_vs_gpu": bool(err <= 1e-12)}
+        out["speedup_vs_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]
+        out["one_frame_per_call"]["speedup_vs_cpu_per_frame"] = out["cpu_baseline"]["us_per_frame"] / out["one_frame_per_call"]["us_mean"]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="c4", choices=["c2", "c3", "c4"])
+    ap.add_argument("--config", default="c4", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--batch", type=int, default=None, help="matrices per GPU (default: the config's B)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: the config's batch PER GPU; strong: the config's batch in all (BASELINE configs[3] literally)")
     ap.add_argument("--cpu-sample", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the `configs` block (c2, c3, c5 in the same run)")
+    ap.add_argument("--kernel-only", action="store_true", help="c5 under the profiler: only the timed launches of the fused kernel")
     args = ap.parse_args()
 
     import torch
@@ -143,150 +457,96 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
-
-    Bc, N, M, k, seed = wl.DENSE_CONFIGS[args.config]
-    B = args.batch or Bc
-    costs = wl.dense_batch(B, N, M, seed, first=rank * B)  # rank-private slice of the one seeded stream
-    d_cost = torch.from_numpy(costs).to(dev)
-    d_r4c = torch.empty((B, k, M), dtype=torch.int32, device=dev)
-    d_c4r = torch.empty((B, k, N), dtype=torch.int32, device=dev)
-    d_gain = torch.empty((B, k), dtype=torch.float64, device=dev)
-    d_nf = torch.empty(B, dtype=torch.int32, device=dev)
-    d_pushed = torch.zeros(B, dtype=torch.int64, device=dev)
-    d_allgain = torch.empty((world * B, k), dtype=torch.float64, device=dev) if use_dist else None
-
     eng = pk.KBestEngine(local)
-    eng.reserve(B, N, k)
     # a dedicated (non-null) HIP stream: the kernel, the timing events and the collective all go through it
     tstream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(tstream)
-    stream = tstream.cuda_stream
-    assert stream != 0
+    assert tstream.cuda_stream != 0
+    cpu_samples = {"c4": 512, "c3": 1024, "c2": 1024}
 
-    torch.cuda.synchronize()  # the allocations / fills above ran on the default stream
-    # untimed: the reference's push count P per matrix (no-prune mode), for the algorithmic byte count
-    eng.kbest_dev(d_cost, B, N, M, k, d_r4c, d_c4r, d_gain, d_nf, d_pushed=d_pushed, prune=False, stream=stream)
-    torch.cuda.synchronize()
-    pushed = d_pushed.cpu().numpy()
-    nf_ref = d_nf.cpu().numpy().copy()
-    g_ref = d_gain.cpu().numpy().copy()
-
-    # Multi-GPU: the per-rank top-k gains of step i are all-gathered (RCCL over xGMI) WHILE the kernel of step i+1
-    # runs: two gain tables alternate, and a table is only written again once the gather that read it has finished
-    # (stream-level wait on its work handle).  Every gather completes inside the timed region.
-    d_gain2 = torch.empty_like(d_gain) if use_dist else None
-    d_allgain2 = torch.empty_like(d_allgain) if use_dist else None
-    gains = (d_gain, d_gain2)
-    allgains = (d_allgain, d_allgain2)
-    pending = [None, None]
-
-    def step(i, ev=None):
-        b = i & 1 if use_dist else 0
-        if pending[b] is not None:
-            pending[b].wait()  # the gather of step i-2 has read gains[b]
-            pending[b] = None
-        if ev is not None:
-            ev[0].record()
-        eng.kbest_dev(d_cost, B, N, M, k, d_r4c, d_c4r, gains[b], d_nf, stream=stream)
-        if ev is not None:
-            ev[1].record()
-        if use_dist:
-            pending[b] = dist.all_gather_into_tensor(allgains[b], gains[b], async_op=True)
-
-    def drain():
-        for b in (0, 1):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
-
-    for i in range(args.warmup):
-        step(i)
-    drain()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, ev[i])
-    drain()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if use_dist and ((args.steps - 1) & 1) == 1:
-        d_gain, d_allgain = d_gain2, d_allgain2  # the last step wrote (and gathered) the second pair of tables
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-
-    nf = d_nf.cpu().numpy()
-    g = d_gain.cpu().numpy()
-    # the timed (pruning) path must reproduce the no-prune run bit for bit
-    parity_self = bool((nf == nf_ref).all() and (g.view(np.int64) == g_ref.view(np.int64)).all())
-    found = int(nf.sum())
-    balg = algorithmic_bytes(N, M, k, nf, pushed)
-
-    t = torch.tensor([dt, kern_ms], dtype=torch.float64, device=dev)
-    tot = torch.tensor([found, balg], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    dt_max, kern_ms_max = float(t[0]), float(t[1])
-    found_all, balg_all = float(tot[0]), float(tot[1])
-
-    if rank == 0:
-        out = {
-            "metric": "k-best assignments/sec (batched NxN cost matrices, k=200)",
-            "value": found_all * args.steps / dt_max,
-            "unit": "assignments/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt_max / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{B} dense {N}x{M} cost matrices per GPU, k={k} (BASELINE configs[3] shape, "
-                                   f"splitmix64 seed {seed:#x}), kBest2D semantics", "matrices_per_gpu": B,
-                       "numRow": N, "numCol": M, "k": k, "parallelism": f"batch-sharded x{world}"},
-            "problems_per_s": B * world * args.steps / dt_max,
-            "kernel_ms": kern_ms_max,
-            "parity_prune_vs_noprune": parity_self,
-            "roofline": {"bound": "hbm", "achieved": (balg_all / world) / (kern_ms_max * 1e-3) / 1e9,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (balg_all / world) / (kern_ms_max * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "traffic": None,
-                         "algorithmic_bytes_per_launch": balg_all / world,
-                         "mean_pushed_per_matrix": float(pushed.mean())},
-        }
-        tr = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tr):  # PMC-measured HBM bytes per launch of this workload (see profiles/README.md)
-            try:
-                j = json.load(open(tr))
-                if j.get("config") == args.config and j.get("batch") == B:
-                    out["roofline"]["traffic"] = j["bytes_per_launch"]
-            except Exception:
-                pass
-        if world == 1 and not args.no_cpu:
-            sample = args.cpu_sample or {"c4": 512, "c3": 2048, "c2": 1024}[args.config]
-            cb, r4c_cpu, g_cpu, p_cpu = cpu_baseline(costs, N, M, k, sample)
-            ns = min(sample, B)
-            cb["parity_vs_gpu"] = bool((g_cpu.reshape(-1, k)[:ns].view(np.int64) == g[:ns].view(np.int64)).all()
-                                       and (np.asarray(r4c_cpu).reshape(-1, k, M)[:ns] == d_r4c.cpu().numpy()[:ns]).all())
-            if p_cpu is not None:
-                cb["pushed_matches_gpu"] = bool((p_cpu[:ns] == pushed[:ns]).all())
-            out["cpu_baseline"] = cb
-            out["speedup_vs_cpu_1core"] = out["value"] / cb["value"]
-            ca = cpu_all_cores(costs, N, M, k)
-            if ca is not None:
-                out["cpu_baseline_all_cores"] = ca
-                out["speedup_vs_cpu_all_cores"] = out["value"] / ca["value"]
+    line = None
+    if args.config == "c5":
+        if world != 1:
+            raise SystemExit("--config c5 is a single-GPU stream (frames are independent: run one stream per GPU)")
+        e = run_c5(eng, torch, args.steps, args.warmup, dev, tstream, args.no_cpu, kernel_only=args.kernel_only)
+        out = {"metric": "k-best assignments/sec (batched NxN cost matrices, k=200)", "value": e["value"], "unit": "assignments/s",
+               "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": e["ms_per_step"], "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": e["workload"], "frames_per_gpu": e["frames"], "k": 200, "parallelism": "single stream"}}
+        out.update({kk: vv for kk, vv in e.items() if kk not in ("workload", "value", "unit", "steps", "ms_per_step", "frames")})
         line = json.dumps(out)
+    else:
+        Bc, N, M, k, seed = wl.DENSE_CONFIGS[args.config]
+        if args.scaling == "strong":
+            Btot = args.batch or Bc
+            if Btot % world:
+                raise SystemExit(f"strong scaling: {Btot} matrices do not divide over {world} ranks")
+            B = Btot // world
+        else:
+            B = args.batch or Bc
+        m = run_dense(eng, torch, dist if use_dist else None, args.config, B, args.steps, args.warmup, rank, world, dev, tstream,
+                      use_dist, rank * B)
+        t = torch.tensor([m["dt"], m["kern_ms"]], dtype=torch.float64, device=dev)
+        tot = torch.tensor([m["found"], m["balg"]], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dt_max, kern_ms_max = float(t[0]), float(t[1])
+        found_all, balg_all = float(tot[0]), float(tot[1])
+        if rank == 0:
+            what = "per GPU" if args.scaling == "weak" else f"in all, {B} per GPU"
+            out = {
+                "metric": "k-best assignments/sec (batched NxN cost matrices, k=200)",
+                "value": found_all * args.steps / dt_max,
+                "unit": "assignments/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": 1e3 * dt_max / args.steps,
+                "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+                "dtype": "f64", "data": "synthetic",
+                "config": {"workload": f"{B if args.scaling == 'weak' else B * world} dense {N}x{M} cost matrices {what}, k={k} "
+                                       f"(BASELINE configs[3] shape, splitmix64 seed {seed:#x}), kBest2D semantics",
+                           "matrices_per_gpu": B, "numRow": N, "numCol": M, "k": k, "parallelism": f"batch-sharded x{world}",
+                           "collective": "all-gather of (gain[k], row4col[k*M], nf) per matrix, overlapped with the next step"
+                                         if use_dist else "none (one GPU)"},
+                "problems_per_s": B * world * args.steps / dt_max,
+                "kernel_ms": kern_ms_max,
+                "parity_prune_vs_noprune": m["parity_self"],
+                "roofline": roofline_block(args.config, B, balg_all / world, kern_ms_max,
+                                           {"mean_pushed_per_matrix": float(m["pushed"].mean())}),
+            }
+            iss = issue_block(args.config)
+            if iss:
+                out["issue"] = iss
+            if world == 1:
+                out["value_host_inclusive"] = host_inclusive_dense(eng, m["costs"], N, M, k)
+            if world == 1 and not args.no_cpu:
+                sample = args.cpu_sample or cpu_samples[args.config]
+                cb, r4c_cpu, g_cpu, p_cpu = cpu_dense(m["costs"], N, M, k, sample)
+                ns = min(sample, B)
+                cb["parity_vs_gpu"] = bool((g_cpu.reshape(-1, k)[:ns].view(np.int64) == m["g"][:ns].view(np.int64)).all()
+                                           and (np.asarray(r4c_cpu).reshape(-1, k, M)[:ns] == m["r4c"][:ns]).all())
+                if p_cpu is not None:
+                    cb["pushed_matches_gpu"] = bool((p_cpu[:ns] == m["pushed"][:ns]).all())
+                out["cpu_baseline"] = cb
+                out["speedup_vs_cpu_1core"] = out["value"] / cb["value"]
+                ca = cpu_all_cores(m["costs"], N, M, k)
+                if ca is not None:
+                    out["cpu_baseline_all_cores"] = ca
+                    out["speedup_vs_cpu_all_cores"] = out["value"] / ca["value"]
+            if world == 1 and not args.no_extra and args.config == "c4" and args.batch is None:
+                # the other BASELINE configs, measured in the same run (fewer steps each: the default run stays short)
+                extra = {}
+                for cfg in ("c2", "c3"):
+                    extra[cfg] = dense_entry(eng, torch, cfg, 5, 1, dev, tstream, cpu_samples[cfg], args.no_cpu)
+                extra["c5"] = run_c5(eng, torch, 5, 1, dev, tstream, args.no_cpu)
+                out["configs"] = extra
+            line = json.dumps(out)
     if use_dist:
-        if world > 1:  # every rank must hold the same global table
-            assert torch.equal(d_allgain[rank * B:(rank + 1) * B], d_gain)
         dist.destroy_process_group()
     # RCCL prints a banner through C stdio, which is flushed at exit, i.e. AFTER anything Python has printed: push
     # it out first so that the JSON line is the last line of stdout
     try:
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
+        C.CDLL(None).fflush(None)
     except Exception:
         pass
     if rank == 0:

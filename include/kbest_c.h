@@ -193,6 +193,21 @@ int kbest_assoc_probs_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const 
                                 const int64_t *probOff, int32_t *nf);
 
 /*
+ * The same on device buffers, asynchronous on `stream` (NULL = the context's stream): ONE launch of the fused
+ * association kernel (kbest_small.hip) -- conditionCosts while the cost tile is loaded, kBest2DCutoff(k, 42), the
+ * exp-weights, the scatter back -- for callers whose cost blocks are produced on the GPU.
+ *   d_nRow[b] = d_nL[b] + d_nM[b] rows of the cost block of frame b; condition = 0: the blocks are already
+ *   conditioned (assignmentProb only).  Limits of the fused kernel: nM <= 32, k <= 1024, at most 32 rows kept by
+ *   conditionCosts (a frame beyond that comes back with d_nf[b] = -2 and zero probabilities: re-run it through the
+ *   host-pointer entry, which falls back to the general pipeline by itself).  Needs kbest_reserve_assoc first.
+ */
+int kbest_assoc_probs_batch_f64_dev(kbest_ctx *ctx, int B, int maxRawRow, int maxCol, const int32_t *d_nL,
+                                    const int32_t *d_nM, const int32_t *d_nRow, const double *d_cost,
+                                    const int64_t *d_costOff, int k, int condition, double *d_probs,
+                                    const int64_t *d_probOff, int32_t *d_nf, void *stream);
+int kbest_reserve_assoc(kbest_ctx *ctx, int B, int maxRawRow, int maxCol, int k);
+
+/*
  * Batched computeQuadricCostMatrix (assignment.h:28-29, assignment.cpp:705-722).  Frame b has nL[b] landmarks and
  * nM[b] measurements, each a (mean[3], cov[3][3] row-major) pair, packed frame after frame; gate is
  * NONASSIGN_QUADRIC.  cost receives the (nL+nM) x nM column-major blocks packed back to back.  Host buffers.

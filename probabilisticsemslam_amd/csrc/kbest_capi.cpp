@@ -890,6 +890,70 @@ static int weights_small(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t
     return KBEST_OK;
 }
 
+extern "C" int kbest_assoc_probs_batch_f64_dev(kbest_ctx *ctx, int B, int maxRawRow, int maxCol, const int32_t *d_nL,
+                                               const int32_t *d_nM, const int32_t *d_nRow, const double *d_cost,
+                                               const int64_t *d_costOff, int k, int condition, double *d_probs,
+                                               const int64_t *d_probOff, int32_t *d_nf, void *stream)
+{
+    if (!ctx) return KBEST_ERR_BAD_ARG;
+    if (B < 0 || k < 1 || maxCol < 1 || maxRawRow < maxCol || !d_nL || !d_nM || !d_nRow || !d_cost || !d_costOff || !d_probs ||
+        !d_probOff || !d_nf)
+        return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_assoc_probs_batch_f64_dev: bad argument");
+    if (B == 0) return KBEST_OK;
+    const int capRow = maxRawRow < kb::SMALL_MAX_DIM ? maxRawRow : kb::SMALL_MAX_DIM;
+    int nw = 0;
+    if (maxCol > kb::SMALL_MAX_DIM || k > kb::SMALL_MAX_K || maxRawRow > kb::SMALL_MAX_RAW_ROWS ||
+        (!condition && maxRawRow > kb::SMALL_MAX_DIM) || !small_fits(ctx, B, capRow, maxCol, k, true, &nw))
+        return fail(ctx, KBEST_ERR_UNSUPPORTED, "kbest_assoc_probs_batch_f64_dev: frames beyond the fused association kernel "
+                                                "(nM <= 32, k <= 1024; without conditioning nL + nM <= 32)");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    int rc = order_behind_last(ctx, s);
+    if (rc != KBEST_OK) return rc;
+    rc = ensure_states(ctx, small_states_need(B, capRow, maxCol, k, nw), false);  // asynchronous entry: never allocates
+    if (rc != KBEST_OK) return rc;
+    kb::SmallParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.cost = d_cost;
+    sp.costOff = reinterpret_cast<const long long *>(d_costOff);
+    sp.probOff = reinterpret_cast<const long long *>(d_probOff);
+    sp.nRow = d_nRow;
+    sp.nCol = d_nM;
+    sp.nL = d_nL;
+    sp.maxRow = capRow;
+    sp.maxCol = maxCol;
+    sp.ldRow = capRow;
+    sp.ldCol = maxCol;
+    sp.k = k;
+    sp.useCutoff = 1;  // assignment.cpp:594
+    sp.cutoff = 42.0;
+    sp.nf = d_nf;
+    sp.states = ctx->states;
+    sp.stateStride = kb::small_state_stride(capRow, maxCol);
+    sp.statesPerProblem = kb::small_states_per_problem(k, nw, maxCol);
+    sp.weights = 1;
+    sp.condition = condition ? 1 : 0;
+    sp.gate = 1;
+    sp.probs = d_probs;
+    sp.prof = ctx->prof;
+    hipError_t e = kb::launch_kbest_small(sp, B, nw, s);
+    if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "association kernel launch", e);
+    return KBEST_OK;
+}
+
+extern "C" int kbest_reserve_assoc(kbest_ctx *ctx, int B, int maxRawRow, int maxCol, int k)
+{
+    if (!ctx || B < 0 || maxCol < 1 || maxRawRow < maxCol || k < 1) return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_reserve_assoc: bad argument");
+    if (B == 0) return KBEST_OK;
+    const int capRow = maxRawRow < kb::SMALL_MAX_DIM ? maxRawRow : kb::SMALL_MAX_DIM;
+    int nw = 0;
+    if (maxCol > kb::SMALL_MAX_DIM || !small_fits(ctx, B, capRow, maxCol, k, true, &nw))
+        return fail(ctx, KBEST_ERR_UNSUPPORTED, "kbest_reserve_assoc: frames beyond the fused association kernel");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    return ensure_states(ctx, small_states_need(B, capRow, maxCol, k, nw), true);
+}
+
 static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM, const double *cost,
                             const int64_t *costOff, int k, double *probs, const int64_t *probOff, int32_t *nf,
                             bool condition, const QuadricHost *quad = nullptr, bool bruteForce = false)

@@ -22,6 +22,7 @@ C_ABI_SYMBOLS = (
     "kbest_set_profile_buffer", "kbest_condition_costs_f64", "kbest_assoc_probs_batch_f64",
     "kbest_quadric_costs_f64", "kbest_quadric_assoc_probs_batch_f64", "kbest_bb_match_batch_f64",
     "kbest_bruteforce_probs_batch_f64", "kbest_assign_batch_f64", "kbest_to_probs_f64",
+    "kbest_assoc_probs_batch_f64_dev", "kbest_reserve_assoc",
 )
 
 
@@ -79,6 +80,9 @@ def load_library():
     lib.kbest_assign_batch_f64.argtypes = [vp, C.c_int, C.c_int, C.c_int, i32p, i32p, dp, i64p, C.c_int, C.c_int, C.c_int,
                                            i32p, i32p, dp, dp, dp, i32p]
     lib.kbest_to_probs_f64.argtypes = [vp, dp, C.c_int64]
+    lib.kbest_assoc_probs_batch_f64_dev.argtypes = [vp, C.c_int, C.c_int, C.c_int, i32p, i32p, i32p, dp, i64p, C.c_int, C.c_int,
+                                                    dp, i64p, i32p, vp]
+    lib.kbest_reserve_assoc.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
     _lib = lib
     return lib
 
@@ -273,6 +277,19 @@ class KBestEngine:
         self._check(self.lib.kbest_batch_f64_dev(self.ctx, C.byref(o), B, N, M, dp(d_nRow), dp(d_nCol), dp(d_cost),
                                                  dp(d_costOff), k, dp(d_row4col), dp(d_col4row), dp(d_gain), dp(d_nf),
                                                  dp(d_pushed), C.c_void_p(stream) if stream else None))
+
+
+    def reserve_assoc(self, B, maxRawRow, maxCol, k):
+        self._check(self.lib.kbest_reserve_assoc(self.ctx, B, maxRawRow, maxCol, k))
+
+    def assoc_probs_dev(self, B, maxRawRow, maxCol, d_nL, d_nM, d_nRow, d_cost, d_costOff, k, d_probs, d_probOff, d_nf,
+                        condition=True, stream=None):
+        """Fused association on device buffers (torch CUDA tensors), asynchronous on `stream`: one launch."""
+        def dp(t):
+            return None if t is None else C.c_void_p(t.data_ptr())
+        self._check(self.lib.kbest_assoc_probs_batch_f64_dev(self.ctx, B, maxRawRow, maxCol, dp(d_nL), dp(d_nM), dp(d_nRow),
+                                                             dp(d_cost), dp(d_costOff), k, int(bool(condition)), dp(d_probs),
+                                                             dp(d_probOff), dp(d_nf), C.c_void_p(stream) if stream else None))
 
 
 # ---- reference-named conveniences (B = 1), mirroring shortestPathCPP.hpp / assignment.h -------------

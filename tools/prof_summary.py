@@ -10,6 +10,8 @@ from collections import defaultdict
 
 out = sys.argv[1]
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+cfg = sys.argv[3] if len(sys.argv) > 3 else "c4"
+BATCH = {"c2": 1024, "c3": 4096, "c4": 1024, "c5": 1000}.get(cfg)
 
 
 def rows(pattern):
@@ -23,12 +25,15 @@ dur = defaultdict(list)
 for r in rows("trace/**/*kernel_trace.csv"):
     dur[r["Kernel_Name"][:60]].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
 print("== kernel durations (us) from --kernel-trace --stats")
-res = {}
+res = {"config": cfg, "batch": BATCH}
+# the measured kernel = the k-best kernel with the largest total time in the trace
+main = max((k for k in dur if "kbest" in k), key=lambda k: sum(d for _, d in dur[k]), default=None)
+res["kernel"] = main
 for k, v in sorted(dur.items(), key=lambda kv: -sum(d for _, d in kv[1])):
     v.sort()
     d = [x for _, x in v]
     line = f"{k:60s} n={len(d):4d} avg={sum(d)/len(d):12.1f} min={min(d):12.1f} max={max(d):12.1f} total={sum(d):12.1f}"
-    if "kbest_kernel" in k:
+    if k == main:
         last = d[-K:]
         line += f"  | last {K} (timed workload): avg={sum(last)/len(last):.1f}"
         res["kernel_avg_us_timed"] = sum(last) / len(last)
@@ -41,7 +46,7 @@ for d in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
     if acc:
         print(f"== {d}: mean over the last {K} dispatches of the k-best kernel")
     for k, cs in acc.items():
-        if "kbest" not in k:
+        if main is None or k[:40] != main[:40]:
             continue
         for c, v in sorted(cs.items()):
             v.sort()
