@@ -234,6 +234,28 @@ int kbest_quadric_assoc_probs_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL
 int kbest_bb_match_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nR, const double *boxL,
                              const double *boxR, double gate, int32_t *assign);
 
+/*
+ * Multi-device entries (BASELINE.json config 4): one engine context + one stream per GPU and an
+ * RCCL communicator over them (ncclCommInitAll; xGMI inside a node).  kbest_batch_f64_multi shards the batch in
+ * contiguous blocks (device g solves matrices [g*ceil(B/G), ...)), each device solving its block with the kernels of
+ * the single-device entries straight into its slice of a global table; ONE in-place all-gather of the packed
+ * (gain[k], row4col[k*M], nf) per matrix then leaves EVERY device with the same global k-best table (there is no
+ * other collective: the matrices are independent).  The host outputs are read back from device 0; col4row is not part
+ * of the exchange and comes from the device that solved the block.  Same argument meaning as kbest_batch_f64
+ * (uniform packing b*maxRow*maxCol; nRow/nCol optional).  RCCL is bound at run time (dlopen): without it
+ * kbest_create_multi returns KBEST_ERR_NO_DEVICE and every single-device entry still works.
+ */
+typedef struct kbest_multi kbest_multi;
+int kbest_create_multi(kbest_multi **m, const int *device_ids, int nDev);
+int kbest_destroy_multi(kbest_multi *m);
+int kbest_multi_size(const kbest_multi *m);
+const char *kbest_multi_last_error(const kbest_multi *m);
+int kbest_batch_f64_multi(kbest_multi *m, const kbest_opts *opts, int B, int maxRow, int maxCol, const int32_t *nRow,
+                          const int32_t *nCol, const double *cost, int k, int32_t *row4col, int32_t *col4row, double *gain,
+                          int32_t *nf);
+/* 1 when every device holds the same global table after the last kbest_batch_f64_multi call, 0 when not (test aid). */
+int kbest_multi_tables_agree(kbest_multi *m);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,4 +8,4 @@ surface (``kBest2D``, ``kBest2DCutoff``, ``assignmentProb``) plus a device-
 pointer entry for buffers that already live in HBM (torch is only the
 allocator / stream / process-group plumbing).
 """
-from .engine import (KBestEngine, KBestError, assignmentProb, kBest2D, kBest2DCutoff, lib_path, load_library)  # noqa: F401
+from .engine import (KBestEngine, KBestError, KBestMulti, assignmentProb, kBest2D, kBest2DCutoff, lib_path, load_library)  # noqa: F401

@@ -1191,7 +1191,9 @@ int kbest_bb_match_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int
     long long sl = 0, sr = 0, sc = 0;
     int maxRow = 1, maxCol = 1;
     for (int b = 0; b < B; b++) {
-        if (nL[b] < 1 || nR[b] < 0) return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_bb_match_batch_f64: need nL >= 1, nR >= 0");
+        // (asgnBB returns an empty vector for a frame without left boxes and all -1 for one without right boxes,
+        //  assignment.cpp:730-732: both are legal frames, not errors)
+        if (nL[b] < 0 || nR[b] < 0) return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_bb_match_batch_f64: need nL >= 0, nR >= 0");
         offL[b] = sl; offR[b] = sr; costOff[b] = sc;
         nRow[b] = nR[b] + nL[b];
         sl += nL[b]; sr += nR[b]; sc += (long long)nRow[b] * nL[b];

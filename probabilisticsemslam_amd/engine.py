@@ -23,6 +23,8 @@ C_ABI_SYMBOLS = (
     "kbest_quadric_costs_f64", "kbest_quadric_assoc_probs_batch_f64", "kbest_bb_match_batch_f64",
     "kbest_bruteforce_probs_batch_f64", "kbest_assign_batch_f64", "kbest_to_probs_f64",
     "kbest_assoc_probs_batch_f64_dev", "kbest_reserve_assoc",
+    "kbest_create_multi", "kbest_destroy_multi", "kbest_multi_size", "kbest_multi_last_error", "kbest_batch_f64_multi",
+    "kbest_multi_tables_agree",
 )
 
 
@@ -83,6 +85,14 @@ def load_library():
     lib.kbest_assoc_probs_batch_f64_dev.argtypes = [vp, C.c_int, C.c_int, C.c_int, i32p, i32p, i32p, dp, i64p, C.c_int, C.c_int,
                                                     dp, i64p, i32p, vp]
     lib.kbest_reserve_assoc.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.kbest_create_multi.argtypes = [C.POINTER(vp), i32p, C.c_int]
+    lib.kbest_destroy_multi.argtypes = [vp]
+    lib.kbest_multi_size.argtypes = [vp]
+    lib.kbest_multi_last_error.argtypes = [vp]
+    lib.kbest_multi_last_error.restype = C.c_char_p
+    lib.kbest_batch_f64_multi.argtypes = [vp, C.POINTER(KBestOpts), C.c_int, C.c_int, C.c_int, i32p, i32p, dp, C.c_int, i32p,
+                                          i32p, dp, i32p]
+    lib.kbest_multi_tables_agree.argtypes = [vp]
     _lib = lib
     return lib
 
@@ -290,6 +300,49 @@ class KBestEngine:
         self._check(self.lib.kbest_assoc_probs_batch_f64_dev(self.ctx, B, maxRawRow, maxCol, dp(d_nL), dp(d_nM), dp(d_nRow),
                                                              dp(d_cost), dp(d_costOff), k, int(bool(condition)), dp(d_probs),
                                                              dp(d_probOff), dp(d_nf), C.c_void_p(stream) if stream else None))
+
+
+class KBestMulti:
+    """Multi-device engine of include/kbest_c.h: one context per GPU in ONE process, contiguous block sharding, RCCL
+    all-gather of the packed result tables (kbest_multi.cpp)."""
+
+    def __init__(self, device_ids):
+        self.lib = load_library()
+        ids = np.ascontiguousarray(device_ids, dtype=np.int32)
+        self.m = C.c_void_p()
+        rc = self.lib.kbest_create_multi(C.byref(self.m), _ptr(ids), len(ids))
+        if rc != 0:
+            raise KBestError(f"kbest_create_multi({list(ids)}): {self.lib.kbest_strerror(rc).decode()}")
+
+    def close(self):
+        if getattr(self, "m", None):
+            self.lib.kbest_destroy_multi(self.m)
+            self.m = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def kbest(self, costs, N, M, k, maximize=False, cutoff=None, nRow=None, nCol=None):
+        costs = np.ascontiguousarray(costs, dtype=np.float64).reshape(-1, N * M)
+        B = costs.shape[0]
+        r4c = np.empty((B, k, M), np.int32); c4r = np.empty((B, k, N), np.int32)
+        gain = np.empty((B, k)); nf = np.empty(B, np.int32)
+        o = KBestOpts()
+        self.lib.kbest_default_opts(C.byref(o))
+        o.maximize = int(bool(maximize)); o.use_cutoff = int(cutoff is not None); o.cutoff = float(cutoff or 0.0)
+        if nRow is not None:
+            nRow = np.ascontiguousarray(nRow, dtype=np.int32); nCol = np.ascontiguousarray(nCol, dtype=np.int32)
+        rc = self.lib.kbest_batch_f64_multi(self.m, C.byref(o), B, N, M, _ptr(nRow), _ptr(nCol), _ptr(costs), k, _ptr(r4c),
+                                            _ptr(c4r), _ptr(gain), _ptr(nf))
+        if rc != 0:
+            raise KBestError(f"{self.lib.kbest_strerror(rc).decode()}: {self.lib.kbest_multi_last_error(self.m).decode()}")
+        return nf, r4c, c4r, gain
+
+    def tables_agree(self):
+        return self.lib.kbest_multi_tables_agree(self.m) == 1
 
 
 # ---- reference-named conveniences (B = 1), mirroring shortestPathCPP.hpp / assignment.h -------------

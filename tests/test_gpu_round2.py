@@ -1,0 +1,201 @@
+"""GPU tests added in round 2: the multi-device C entry (RCCL all-gather), empty frames inside a batch, ties at the
+k boundary through the association path, the threaded host-API stress, the device-pointer fused association entry and
+cross-stream ordering on one context."""
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import probabilisticsemslam_amd as pk
+from probabilisticsemslam_amd import workloads as wl
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.int64)
+
+
+def test_multi_device_entry_single_gpu(engine):
+    """kbest_create_multi / kbest_batch_f64_multi with nDev = 1: same kernels, RCCL communicator over one device,
+    in-place all-gather; results = the single-device entry = the oracle.  (More than one device: same code, the driver's
+    multi-GPU box; the sharding + merge logic is covered by the world-2 gloo tests.)"""
+    m = pk.KBestMulti([0])
+    for name, nb in (("c2", 37), ("c4", 5)):
+        costs, N, M, k = wl.dense_config(name, B=nb)
+        nf, r4c, c4r, g = m.kbest(costs, N, M, k)
+        onf, or4c, oc4r, og, _ = ol.orc_kbest_batch(costs, N, M, k)
+        assert (nf == onf).all() and (r4c == or4c).all() and (c4r == oc4r).all() and (bits(g) == bits(og)).all()
+        assert m.tables_agree()
+    # ragged shapes, cutoff
+    rng = np.random.default_rng(5)
+    N, M, k = 20, 8, 30
+    costs = rng.random((9, N * M)) * 6
+    nRow = rng.integers(8, N + 1, 9).astype(np.int32)
+    nCol = np.minimum(rng.integers(1, M + 1, 9), nRow).astype(np.int32)
+    nf, r4c, c4r, g = m.kbest(costs, N, M, k, cutoff=1.5, nRow=nRow, nCol=nCol)
+    for b in range(9):
+        n, mm = int(nRow[b]), int(nCol[b])
+        onf, or4c, _, og = ol.orc_kbest(costs[b][: n * mm], n, mm, k, cutoff=1.5)
+        assert nf[b] == onf and (r4c[b, :onf, :mm] == or4c[:onf]).all() and (bits(g[b, :onf]) == bits(og[:onf])).all()
+    m.close()
+
+
+def test_empty_frames_inside_a_batch(engine):
+    """Frames without measurements are normal in a KITTI stream (getAssignmentProbs returns an empty result,
+    assignment.cpp:50-51) and frames without landmarks give every measurement probability 1 of being new (:52-54):
+    neither may fail the batch."""
+    frames = wl.kitti_like_frames(3)
+    nL = [20, 5, 20, 0, 20]
+    nM = [10, 0, 10, 3, 10]
+    gate = 10.0
+    noland = np.full(3 * 3, np.inf)
+    for c in range(3):
+        noland[c * 3 + c] = gate
+    costs = [frames[0], np.zeros(0), frames[1], noland, frames[2]]
+    out, nf = engine.weights(costs, nL, nM, 200, condition=True)
+    assert out[1].shape == (0, 6) and nf[1] == 0
+    np.testing.assert_allclose(out[3], np.ones((3, 1)), rtol=0, atol=1e-15)
+    for i, f in ((0, 0), (2, 1), (4, 2)):
+        cond, idx = ol.condition_costs(frames[f], 30, 10)
+        po, _ = ol.assignment_prob(cond, len(idx) - 10, 10, 200)
+        want = np.zeros((10, 21))
+        want[:, idx[: len(idx) - 10]] = po[:, : len(idx) - 10]
+        want[:, 20] = po[:, len(idx) - 10]
+        np.testing.assert_allclose(out[i], want, rtol=0, atol=1e-12)
+    # stereo boxes: a frame without left boxes has no output, one without right boxes matches nothing
+    bl = [np.array([[0, 0, 10, 10, 0.0], [20, 20, 30, 30, 0.0]]), np.zeros((0, 5)), np.array([[0, 0, 10, 10, 0.0]])]
+    br = [np.array([[1, 0, 11, 10, 0.0]]), np.array([[1, 0, 11, 10, 0.0]]), np.zeros((0, 5))]
+    asg = engine.bb_match(bl, br, 0.05)
+    assert len(asg[1]) == 0 and asg[2].tolist() == [-1]
+    assert asg[0].tolist() == ol.asgn_bb(bl[0], br[0], 0.05).tolist()
+
+
+def test_ties_at_the_k_boundary_through_the_association_path(engine):
+    """conditionCosts produces exact zeros, so exact ties between hypotheses are realistic.  The engine orders exact ties
+    by (parent, column), the reference by heap order: when a tie group straddles slot k the
+    EMITTED SETS may differ.  What must hold: the multiset of gains is the reference's, every emitted assignment is
+    valid, and the probabilities agree whenever the tie group lies inside the first k (here: k large enough)."""
+    nL, nM = 6, 4
+    nR = nL + nM
+    C = np.full(nR * nM, np.inf)
+    for c in range(nM):
+        for r in range(nL):
+            C[c * nR + r] = float((r + c) % 3)      # integer costs: masses of exact ties
+        C[c * nR + nL + c] = 2.0
+    cond, idx = ol.condition_costs(C, nR, nM)
+    cl = len(idx) - nM
+    for k in (5, 17, 40):
+        nf, r4c, c4r, g = engine.kbest(cond.reshape(1, -1), len(idx), nM, k, cutoff=42.0)
+        onf, or4c, oc4r, og = ol.orc_kbest(cond, len(idx), nM, k, cutoff=42.0)
+        assert nf[0] == onf
+        assert sorted(g[0][:onf].tolist()) == sorted(og[:onf].tolist())
+        for s in range(onf):  # valid, and the gain is the sum of its entries
+            rows = r4c[0][s]
+            assert len(set(rows.tolist())) == nM
+            assert g[0][s] == sum(cond[c * len(idx) + rows[c]] for c in range(nM))
+    # exhaustive k: the tie order cannot matter for the probabilities
+    pb, nfb, uk = ol.brute_force_prob(cond, cl, nM)
+    out, nf = engine.weights([cond], [cl], [nM], uk, brute_force=True)  # the reference's own k (Minc-type bound)
+    assert nfb < uk  # ... which enumerates everything here
+    np.testing.assert_allclose(out[0], pb, rtol=0, atol=1e-12)
+
+
+def test_threaded_host_api_stress(engine):
+    """The host-pointer entries may be called from several host threads on ONE context (shim functions are global):
+    launches share the context's workspace and stream, so they execute one after the other, and every thread must get
+    its own answers."""
+    cs2, N2, M2, k2 = wl.dense_config("c2", B=24)
+    cs4, N4, M4, k4 = wl.dense_config("c4", B=6)
+    frames = wl.kitti_like_frames(12)
+    want2 = ol.orc_kbest_batch(cs2, N2, M2, k2)
+    want4 = ol.orc_kbest_batch(cs4, N4, M4, k4)
+    wantp = []
+    for f in frames:
+        cond, idx = ol.condition_costs(f, 30, 10)
+        po, _ = ol.assignment_prob(cond, len(idx) - 10, 10, 200)
+        w = np.zeros((10, 21))
+        w[:, idx[: len(idx) - 10]] = po[:, : len(idx) - 10]
+        w[:, 20] = po[:, len(idx) - 10]
+        wantp.append(w)
+    errs = []
+
+    def worker(t):
+        try:
+            for it in range(6):
+                if (t + it) % 3 == 0:
+                    nf, r4c, c4r, g = engine.kbest(cs2, N2, M2, k2)
+                    assert (nf == want2[0]).all() and (r4c == want2[1]).all() and (bits(g) == bits(want2[3])).all()
+                elif (t + it) % 3 == 1:
+                    nf, r4c, c4r, g = engine.kbest(cs4, N4, M4, k4)
+                    assert (nf == want4[0]).all() and (r4c == want4[1]).all() and (bits(g) == bits(want4[3])).all()
+                else:
+                    i = (t * 7 + it) % len(frames)
+                    out, _ = engine.weights([frames[i]], [20], [10], 200, condition=True)
+                    assert np.abs(out[0] - wantp[i]).max() <= 1e-12
+        except Exception as e:  # noqa: BLE001
+            errs.append((t, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs
+
+
+def test_device_pointer_entries_on_two_streams_of_one_context(engine):
+    """One hypothesis workspace per context: a launch on another stream than the previous one is ordered behind it
+    (kbest_c.h) -- results stay right; and the asynchronous entry refuses to allocate (KBEST_ERR_NOT_RESERVED)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    eng = pk.KBestEngine(0)
+    costs, N, M, k = wl.dense_config("c4", B=64)
+    d_cost = torch.from_numpy(costs).to(dev)
+    outs = []
+    for _ in range(2):
+        outs.append((torch.empty((64, k, M), dtype=torch.int32, device=dev), torch.empty((64, k, N), dtype=torch.int32, device=dev),
+                     torch.empty((64, k), dtype=torch.float64, device=dev), torch.empty(64, dtype=torch.int32, device=dev)))
+    o = eng._opts(False, None)
+    import ctypes as C
+    rc = eng.lib.kbest_batch_f64_dev(eng.ctx, C.byref(o), 64, N, M, None, None, C.c_void_p(d_cost.data_ptr()), None, k,
+                                     C.c_void_p(outs[0][0].data_ptr()), C.c_void_p(outs[0][1].data_ptr()),
+                                     C.c_void_p(outs[0][2].data_ptr()), C.c_void_p(outs[0][3].data_ptr()), None, None)
+    assert rc == -6  # KBEST_ERR_NOT_RESERVED: no kbest_reserve yet
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    for it in range(4):
+        for s, (r4c, c4r, g, nf) in zip((s1, s2), outs):
+            eng.kbest_dev(d_cost, 64, N, M, k, r4c, c4r, g, nf, stream=s.cuda_stream)
+    torch.cuda.synchronize()
+    onf, or4c, oc4r, og, _ = ol.orc_kbest_batch(costs, N, M, k)
+    for r4c, c4r, g, nf in outs:
+        assert (nf.cpu().numpy() == onf).all() and (r4c.cpu().numpy() == or4c).all() and (bits(g.cpu().numpy()) == bits(og)).all()
+
+
+def test_fused_association_device_entry(engine):
+    import torch
+    dev = torch.device("cuda", 0)
+    F, nL, nM, k = 300, 20, 10, 200
+    frames = wl.kitti_like_frames(F)
+    nR = nL + nM
+    raw = np.concatenate(frames)
+    t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    d_probs = torch.zeros(F * nM * (nL + 1), dtype=torch.float64, device=dev)
+    d_nf = torch.zeros(F, dtype=torch.int32, device=dev)
+    engine.reserve_assoc(F, nR, nM, k)
+    engine.assoc_probs_dev(F, nR, nM, t(np.full(F, nL, np.int32)), t(np.full(F, nM, np.int32)), t(np.full(F, nR, np.int32)), t(raw),
+                           t(np.arange(F, dtype=np.int64) * nR * nM), k, d_probs, t(np.arange(F, dtype=np.int64) * nM * (nL + 1)), d_nf,
+                           stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    probs = d_probs.cpu().numpy().reshape(F, nM, nL + 1)
+    nf = d_nf.cpu().numpy()
+    for i in range(0, F, 7):
+        cond, idx = ol.condition_costs(frames[i], nR, nM)
+        po, onf = ol.assignment_prob(cond, len(idx) - nM, nM, k)
+        want = np.zeros((nM, nL + 1))
+        want[:, idx[: len(idx) - nM]] = po[:, : len(idx) - nM]
+        want[:, nL] = po[:, len(idx) - nM]
+        np.testing.assert_allclose(probs[i], want, rtol=0, atol=1e-12)
+        assert nf[i] == onf
