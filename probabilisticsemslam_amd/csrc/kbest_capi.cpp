@@ -3,6 +3,8 @@
 // every compute entry point needs a HIP device and fails loudly without one.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -28,6 +30,7 @@ struct kbest_ctx {
     int ldsPerCU = 160 * 1024;
     int nCU = 256;
     int smallWaves = 0;  // waves per problem of the small-problem kernel; 0 = choose per launch (KBEST_SMALL_NW)
+    bool noPoll = false;      // KBEST_NO_POLL: zero-copy calls wait for the stream instead of polling the completion counter
     bool forceSmall = false;  // KBEST_FORCE_SMALL: every batch of <= 32-row problems through the small-problem kernel
     bool noSmall = false;  // KBEST_NO_SMALL: problems of <= 32 rows through the 64-row kernel as well (A/B tests)
     int extraStates = 64;  // lazy state slots beyond k per matrix (room for speculative re-solves)
@@ -249,6 +252,7 @@ int kbest_create(kbest_ctx **out, int device)
     }
     ctx->noSmall = getenv("KBEST_NO_SMALL") != nullptr;
     ctx->forceSmall = getenv("KBEST_FORCE_SMALL") != nullptr;
+    ctx->noPoll = getenv("KBEST_NO_POLL") != nullptr;
     if (const char *e = getenv("KBEST_SPEC")) {
         int w = atoi(e);
         if (w >= 1 && w <= 16) ctx->spec = w;
@@ -824,10 +828,10 @@ static int weights_small(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t
     const size_t metaBytes = 2 * B8 + 3 * B4;
     const size_t inBytes = metaBytes + (d_cost ? 0 : nCost * 8);
     const size_t probBytes = (nProb * 8 + 15) & ~(size_t)15;
-    const size_t outBytes = probBytes + (size_t)B * 4;
+    const size_t outBytes = probBytes + (((size_t)B * 4 + 15) & ~(size_t)15);
     {
         int rc = arena_reserve(ctx, ctx->pinIn, inBytes);
-        if (rc == KBEST_OK) rc = arena_reserve(ctx, ctx->pinOut, outBytes);
+        if (rc == KBEST_OK) rc = arena_reserve(ctx, ctx->pinOut, outBytes + 64);  // (+ the completion counter of zero-copy calls)
         if (rc != KBEST_OK) return rc;
     }
     unsigned char *hin = static_cast<unsigned char *>(ctx->pinIn.host);
@@ -875,11 +879,37 @@ static int weights_small(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t
     sp.gate = bruteForce ? 0 : 1;
     sp.probs = reinterpret_cast<double *>(dout);
     sp.prof = ctx->prof;
+    if (B == 1 && costOff[0] == 0 && probOff[0] == 0) {  // the per-frame call: shape in the kernel arguments
+        sp.imm = 1;
+        sp.immRow = nRow[0];
+        sp.immCol = nM[0];
+        sp.immL = nL[0];
+        sp.costOff = nullptr;
+        sp.probOff = nullptr;
+    }
+    unsigned char *hout = static_cast<unsigned char *>(ctx->pinOut.host);
+    volatile int *hdone = reinterpret_cast<volatile int *>(hout + outBytes);
+    if (zeroCopy && !ctx->noPoll) {
+        *hdone = 0;
+        sp.done = reinterpret_cast<int *>(dout + outBytes);
+    }
     hipError_t e = kb::launch_kbest_small(sp, B, nw, ctx->stream);
     if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "association kernel launch", e);
-    unsigned char *hout = static_cast<unsigned char *>(ctx->pinOut.host);
     if (!zeroCopy) HIP_TRY(ctx, hipMemcpyAsync(hout, dout, outBytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (sp.done) {
+        // The results land in this host memory; every workgroup bumps the counter (system-scope release) when its last
+        // byte is written.  Polling it skips the runtime's completion path (interrupt / wake-up), which is a tenth of a
+        // one-frame call.  After ~2 ms without completion the ordinary wait takes over (it also reports device errors).
+        const auto t0 = std::chrono::steady_clock::now();
+        int spins = 0;
+        while (*hdone != B) {
+            if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (*hdone != B) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    } else {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     const int32_t *hnf = reinterpret_cast<const int32_t *>(hout + probBytes);
     for (int b = 0; b < B; b++)
         if (hnf[b] == -2) return 1;  // a frame that keeps more rows than this kernel takes: general pipeline

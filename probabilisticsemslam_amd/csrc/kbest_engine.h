@@ -227,6 +227,8 @@ struct SmallParams {
     double *probs;            // packed [nM][nL+1] per problem
     const long long *probOff;
     unsigned long long *prof; // diagnostic builds only
+    int imm, immRow, immCol, immL;  // imm = 1 (B = 1): the shape of the one problem travels in the kernel arguments
+    int *done;                // host-mapped completion counter (zero-copy calls) or nullptr
 };
 
 __host__ __device__ inline long long small_state_stride(int maxRow, int maxCol)

@@ -314,8 +314,9 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
     const u64 myHalf = half ? SM_HI : SM_LO;
     const int b = blockIdx.x;
     const int k = p.k;
-    const int M = p.nCol ? p.nCol[b] : p.maxCol;
-    const int NR = p.nRow ? p.nRow[b] : p.maxRow;  // rows of the block as given (condition: of the RAW block)
+    // (a one-frame call carries its shape in the kernel arguments: no dependent loads over PCIe before the first byte of work)
+    const int M = p.imm ? p.immCol : (p.nCol ? p.nCol[b] : p.maxCol);
+    const int NR = p.imm ? p.immRow : (p.nRow ? p.nRow[b] : p.maxRow);  // rows of the block as given (condition: of the RAW block)
     const bool maximize = p.maximize != 0, useCut = p.useCutoff != 0;
     const SmallLds L = small_lds_layout(p.maxRow, p.maxCol, k, NW, p.weights != 0);
     constexpr int LDC = 33;  // odd: lane = row and lane = column walks are both bank-conflict free; rows beyond N hold +inf
@@ -347,21 +348,34 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
     const long long costBase = p.costOff ? p.costOff[b] : (long long)b * p.ldRow * p.ldCol;
     const double *Cg = p.cost + costBase;
     const long long outBase = (long long)b * k;
-    double *probOut = p.weights ? p.probs + p.probOff[b] : nullptr;
-    const int nLout = p.weights ? p.nL[b] : 0;  // landmarks in the caller's numbering
+    double *probOut = p.weights ? p.probs + (p.probOff ? p.probOff[b] : 0) : nullptr;
+    const int nLout = p.weights ? (p.imm ? p.immL : p.nL[b]) : 0;  // landmarks in the caller's numbering
 
 #ifdef KB_PROFILE
     unsigned long long profAcc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long profT0 = __builtin_readcyclecounter();
 #endif
+    // A zero-copy call polls this host-mapped counter instead of waiting for the stream: one system-scope add per
+    // workgroup, behind a system-scope fence, once everything the workgroup writes has been written.
+    auto signal_done = [&]() {
+        if (p.done) {
+            __syncthreads();
+            if (tid == 0) {
+                __threadfence_system();
+                __hip_atomic_fetch_add(p.done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    };
     // ---- shapes ---------------------------------------------------------------------------------------------
     if (M == 0 || NR == 0) {  // an empty frame (getAssignmentProbs returns an empty result, assignment.cpp:50-51)
         if (tid == 0) p.nf[b] = 0;
+        signal_done();
         return;
     }
     if (M < 0 || NR < 0 || M > p.maxCol || M > SMALL_MAX_DIM || (!p.condition && (NR > p.maxRow || NR < M)) ||
         (p.condition && NR > SMALL_MAX_RAW_ROWS)) {
         if (tid == 0) p.nf[b] = (p.condition && NR > SMALL_MAX_RAW_ROWS) ? -2 : -1;
+        signal_done();
         return;
     }
     if (p.weights)
@@ -380,11 +394,21 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
     }
     int N;  // rows of the problem that is solved
     double cdel = 0.0;
+    // The block is read two or three times below (minima, kept rows, tile).  A frame-sized block is brought into LDS
+    // once (the candidate pool's space is free until the root is solved): with zero-copy host input that is ONE trip
+    // over PCIe instead of three.
+    const double *Cr = Cg;
+    if ((long long)NR * M <= 3LL * k) {
+        double *stage = PG;
+        for (int i = tid; i < NR * M; i += NT) stage[i] = Cg[i];
+        Cr = stage;
+    }
+    __syncthreads();
     if (p.condition) {
         // conditionCosts (assignment.cpp:439-525): column minima (:450-458) ...
         for (int c = wave; c < M; c += NW) {
             double m = INF;
-            for (int r = lane; r < NR; r += 64) m = min_keep(m, Cg[(long long)c * NR + r]);
+            for (int r = lane; r < NR; r += 64) m = min_keep(m, Cr[(long long)c * NR + r]);
             m = wave_min_f64(m);
             if (lane == 0) colMin[c] = m;
         }
@@ -395,7 +419,7 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
             const int r = ch * 64 + lane;
             bool good = false;
             if (r < NR)
-                for (int c = 0; c < M; c++) good = good || (Cg[(long long)c * NR + r] <= colMin[c] + SM_GATE);
+                for (int c = 0; c < M; c++) good = good | (Cr[(long long)c * NR + r] <= colMin[c] + SM_GATE);
             const u64 m = __ballot(good);
             if (lane == 0) keepBits[ch] = m;
         }
@@ -404,6 +428,7 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
         for (int ch = 0; ch < nChunk; ch++) g += __popcll(keepBits[ch]);
         if (g > p.maxRow || g < M) {  // does not fit (or undefined in the reference: size_t underflow at :60)
             if (tid == 0) p.nf[b] = -2;
+            signal_done();
             return;
         }
         N = g;
@@ -417,7 +442,7 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
             for (int c2 = 0; c2 < ch; c2++) nr += __popcll(keepBits[c2]);
             rowIdx[nr] = (unsigned short)r;
             for (int c = 0; c < M; c++) {
-                const double x = Cg[(long long)c * NR + r];
+                const double x = Cr[(long long)c * NR + r];
                 const double val = (x <= colMin[c] + SM_GATE) ? (x - colMin[c]) : INF;
                 // makeCostMatrixSafe (cpp:534-569) on the conditioned matrix: every column holds an exact zero (its
                 // minimum's row is kept), all entries are >= 0, so CDelta = 0 and the shift is the identity
@@ -432,7 +457,7 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
         double *red = FG;
         double mn = INF;
         for (int i = tid; i < N * M; i += NT) {
-            double x = Cg[i];
+            double x = Cr[i];
             x = maximize ? -x : x;
             mn = min_keep(mn, x);
         }
@@ -445,7 +470,7 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
         double cm = 0.0;
         for (int i = tid; i < N * M; i += NT) {
             const int c = i / N, r = i - c * N;
-            const double x = Cg[i];
+            const double x = Cr[i];
             double val = maximize ? (-x + cdel) : (x - cdel);  // cpp:558 / cpp:564
             if (val != val) val = INF;  // inf - inf: every comparison the reference makes with it is false, like +inf
             if (val < INF && val > cm) cm = val;
@@ -465,17 +490,18 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
             double norm = 0.0;
             int cnt = 0;
             for (int i = 0; i <= nLc; i++) {
-                const double c = p.condition ? Cs[i] : Cg[i];
+                const double c = p.condition ? Cs[i] : Cr[i];
                 if (c < SM_GATE) { norm += exp(-c); cnt++; }
             }
             norm = 1.0 / norm;
             for (int i = 0; i <= nLc; i++) {
-                const double c = p.condition ? Cs[i] : Cg[i];
+                const double c = p.condition ? Cs[i] : Cr[i];
                 const double q = (c < SM_GATE) ? exp(-c) : 0.0;
                 probOut[(i >= nLc) ? nLout : (p.condition ? (int)rowIdx[i] : i)] = q * norm;
             }
             p.nf[b] = cnt < k ? cnt : k;
         }
+        signal_done();
         return;
     }
 
@@ -569,6 +595,7 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
     __syncthreads();
     if (uni32(ctrl->status) == 3) {  // infeasible: kBest2D returns 0 (cpp:588-593); assignmentProb then divides by zero
         if (tid == 0) p.nf[b] = 0;
+        signal_done();
         return;
     }
     const double cdelta = ctrl->cdelta;
@@ -925,6 +952,7 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
         }
     }
     if (tid == 0) p.nf[b] = nf;
+    signal_done();
 #ifdef KB_PROFILE
     profAcc[14] = __builtin_readcyclecounter() - tOut;   // [14] outputs / weights epilogue
     profAcc[15] = __builtin_readcyclecounter() - profT0;  // [15] whole kernel (this wave)
