@@ -249,8 +249,8 @@ __host__ __device__ inline SmallLds small_lds_layout(int maxRow, int maxCol, int
     SmallLds L;
     const int W = 2 * nWaves, S = small_states_per_problem(k, nWaves, maxCol);
     int o = 0;
-    L.offC = o;        o += maxCol * 33 * 8;             // cost tile: the real columns only, column stride 33
-    L.nodeStride = 2 * 256 + 64 + 32 + 256;              // per worker: u[32] v[32] (fp64), col4row[32] row4col[32] (u8), scalars, gain-term line
+    L.offC = o;        o += (maxCol + 1) * 33 * 8;       // cost tile: the real columns + ONE zero column (the padded ones), column stride 33
+    L.nodeStride = 2 * 256 + 64 + 32 + 256 + 272;        // per worker: u[32] v[32] (fp64), col4row[32] row4col[32] (u8), scalars, gain-term line, private u[33]
     o = (o + 15) & ~15;
     L.offNodes = o;    o += W * L.nodeStride;
     L.offPoolG = o;    o += 2 * k * 8;                   // sorted candidate pool, two buffers: gain

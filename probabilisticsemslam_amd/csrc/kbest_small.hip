@@ -49,7 +49,6 @@ namespace kb {
 namespace {
 
 constexpr int SM_PARKED = 64;  // col4row value of a row that sits on one of the (implicit) zero columns
-constexpr int SM_HUB = 65;     // "column" of the hub relaxation / pred marker "reached through the zero columns"
 constexpr u64 SM_LO = 0x00000000FFFFFFFFull, SM_HI = 0xFFFFFFFF00000000ull;
 constexpr u32 SM_SPLIT = 0x80000000u;  // pool meta: children already generated
 constexpr double SM_GATE = 42.0;       // assignment.cpp:9
@@ -107,13 +106,16 @@ __device__ __forceinline__ double half_bcast_f64(double x, int idxLow, int idxHi
 // Out per half: spc / pred per row, scanned rows, final distance, sink row, the parked row through which the zero
 // columns were entered (or -1), status 0 = path found, 1 = infeasible (cpp:197, 327), 2 = abandoned.
 template <bool EARLY>
-__device__ __forceinline__ void dijkstra2(const double *Cs, int LDC, const double *uArr, int rl, double v, int c4r, u64 cand,
+__device__ __forceinline__ void dijkstra2(const double *Cs, double *uW, int hubCol, int rl, double v, int c4r, u64 cand,
                                           u64 forb, bool liveA, bool liveB, int startA, int startB, double boundA,
                                           double boundB, double &spOut, int &predOut, u64 &scannedOut, double &deltaOut,
                                           int &sinkOut, int &hubRowOut, int &statusOut)
 {
-    // Everything that is uniform within a half lives in SCALAR registers here (suffix A = lower half, B = upper half):
-    // the step is bound by its instruction count, and scalar bookkeeping is the cheapest kind.
+    // Everything that is uniform within a half lives in SCALAR registers here (suffix A = lower half, B = upper half).
+    //   Cs       cost tile, column stride 33 doubles, plus one all-zero column at index hubCol
+    //   uW       this half's PRIVATE copy of the column duals (LDS; differs between the halves); uW[hubCol] is the hub's
+    //            dual: the zero columns are one more column of the tile as far as the step is concerned
+    constexpr int LDC = 33;
     u64 liveMask = (liveA ? SM_LO : 0ull) | (liveB ? SM_HI : 0ull);
     cand = uni64(cand) & liveMask;
     const u64 cand0 = cand;
@@ -121,48 +123,164 @@ __device__ __forceinline__ void dijkstra2(const double *Cs, int LDC, const doubl
     const u64 parked = __ballot(c4r == SM_PARKED);
     int curA = uni32(startA), curB = uni32(startB);
     int dHiA = 0, dLoA = 0, dHiB = 0, dLoB = 0;          // settled distance (delta) of each half, as bits
-    int vkHiA = 0, vkLoA = 0, vkHiB = 0, vkLoB = 0;      // dual of the parked rows (hub relaxation)
-    bool hubA = false, hubB = false;
     int stA = 0, stB = 0, sinkA = 0, sinkB = 0, hubRowA = -1, hubRowB = -1;
+    int finHiA = 0, finLoA = 0, finHiB = 0, finLoB = 0;  // distance at which each half ended (the loop's registers run on)
+    u64 unscanned = 0ull;                                // rows an ended half never settled
     const int bHiA = uni32(__double2hiint(boundA)), bHiB = uni32(__double2hiint(boundB));
     const u32 bLoA = (u32)uni32(__double2loint(boundA)), bLoB = (u32)uni32(__double2loint(boundB));
     int spHi = KEY_INF_HI, spLo = 0, pred = 0;
+    const u32 rowAddr = (u32)reinterpret_cast<uintptr_t>(Cs + rl);   // LDS byte addresses (the low word of a flat LDS
+    const u32 uBase = (u32)reinterpret_cast<uintptr_t>(uW);           //   address is the LDS offset)
+    const int keyInf = KEY_INF_HI;
     while (liveMask) {
-        const int curv = pick(curA, curB);
-        const double delta = __hiloint2double(pick(dHiA, dHiB), pick(dLoA, dLoB));
-        double Cval = Cs[rl + curv * LDC];
-        double uval = uArr[curv];
-        int predv = curv;
-        if (hubA | hubB) {  // a zero column, whose dual is minus the (common) dual of the parked rows
-            const u64 hubMask = (hubA ? SM_LO : 0ull) | (hubB ? SM_HI : 0ull);
-            const double nvk = -__hiloint2double(pick(vkHiA, vkHiB), pick(vkLoA, vkLoB));
-            Cval = sel_f64(hubMask, 0.0, Cval);
-            uval = sel_f64(hubMask, nvk, uval);
-            predv = sel32(hubMask, SM_HUB, curv);
+        int status, c0, c1, m0, m1, dlo0, dlo1, cnA, cnB;
+        u64 eq;
+        {
+            // The step loop, hand-written (the kernel runs at the instruction issue rate of lone waves: every instruction
+            // of this loop counts).  One pass = one Dijkstra step of BOTH halves: two LDS reads, three fp64 adds, the strict
+            // '<' update of spc / pred (cpp:183-188, 313-318), a 5-stage DPP min over each 32-lane half on the raw high
+            // word (reduced costs are >= 0 up to rounding: the high word is an order-preserving key), lowest row among
+            // equal values (cpp:191-194, 320-323).  The loop goes on while both halves simply move to the next column;
+            // everything else -- a sink, a parked row, the bound, an empty or negative minimum, a high-word tie that the
+            // first row does not win, a half that is finished -- leaves it: status 0 = the step's choice is made (rows
+            // c0 / c1, their keys, low words and columns are in the out registers), nothing committed; status 1 = the
+            // choice itself needs the exact path.  A finished half (liveMask) takes part inertly.
+            // Fixed registers: v54 +inf key, v55 u base, v56 row address, v57 c4r, v[58:59] v, v[60:61] spc, v62 pred;
+            // s[70:71] live lanes, s[80:83] delta A / B, s84/s85 column A / B, s[86:87] rows to scan, s[88:89] rows to relax,
+            // s[90:91] upper-half mask, s92 column stride in bytes, s93/s94 bound high words.
+            int dAlo = dLoA, dAhi = dHiA, dBlo = dLoB, dBhi = dHiB;
+            asm volatile(
+                "L_pstep%=:\n\t"
+                "v_mov_b32_e32 v72, s84\n\t"
+                "v_mov_b32_e32 v73, s85\n\t"
+                "v_cndmask_b32_e64 v72, v72, v73, s[90:91]\n\t"
+                "v_mad_u32_u24 v74, v72, s92, v56\n\t"
+                "v_lshl_add_u32 v75, v72, 3, v55\n\t"
+                "ds_read_b64 v[68:69], v74\n\t"
+                "ds_read_b64 v[70:71], v75\n\t"
+                "v_mov_b32_e32 v76, s80\n\t"
+                "v_mov_b32_e32 v73, s82\n\t"
+                "v_cndmask_b32_e64 v76, v76, v73, s[90:91]\n\t"
+                "v_mov_b32_e32 v77, s81\n\t"
+                "v_mov_b32_e32 v73, s83\n\t"
+                "v_cndmask_b32_e64 v77, v77, v73, s[90:91]\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_add_f64 v[66:67], v[76:77], v[68:69]\n\t"
+                "v_add_f64 v[66:67], v[66:67], -v[70:71]\n\t"
+                "v_add_f64 v[66:67], v[66:67], -v[58:59]\n\t"
+                "v_cmp_lt_f64_e32 vcc, v[66:67], v[60:61]\n\t"
+                "s_and_b64 vcc, vcc, s[88:89]\n\t"
+                "v_cndmask_b32_e32 v61, v61, v67, vcc\n\t"
+                "v_cndmask_b32_e32 v60, v60, v66, vcc\n\t"
+                "v_cndmask_b32_e32 v62, v62, v72, vcc\n\t"
+                "s_and_b64 s[76:77], s[86:87], s[70:71]\n\t"
+                "v_cndmask_b32_e64 v63, v54, v61, s[76:77]\n\t"
+                "s_nop 1\n\t"
+                "v_min_i32_dpp v64, v63, v63 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                "s_nop 1\n\t"
+                "v_min_i32_dpp v64, v64, v64 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                "s_nop 1\n\t"
+                "v_min_i32_dpp v64, v64, v64 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                "s_nop 1\n\t"
+                "v_min_i32_dpp v64, v64, v64 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                "s_nop 1\n\t"
+                "v_min_i32_dpp v64, v64, v64 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                "s_nop 1\n\t"
+                "v_readlane_b32 s72, v64, 31\n\t"
+                "v_readlane_b32 s73, v64, 63\n\t"
+                "s_nop 0\n\t"
+                "v_mov_b32_e32 v65, s72\n\t"
+                "v_mov_b32_e32 v73, s73\n\t"
+                "v_cndmask_b32_e64 v65, v65, v73, s[90:91]\n\t"
+                "v_cmp_eq_u32_e64 s[98:99], v65, v63\n\t"
+                "s_and_b64 s[98:99], s[98:99], s[76:77]\n\t"
+                "s_or_b32 s76, s72, s73\n\t"
+                "s_cmp_lt_i32 s76, 0\n\t"
+                "s_cbranch_scc1 L_pslow%=\n\t"
+                // first row of each half at the minimum (0 for a half without one), and "a LIVE half has none"
+                "s_ff1_i32_b32 s96, s98\n\t"
+                "s_ff1_i32_b32 s97, s99\n\t"
+                "s_cmp_eq_u32 s98, 0\n\t"
+                "s_cselect_b32 s96, 0, s96\n\t"
+                "s_cselect_b32 s76, s70, 0\n\t"
+                "s_cmp_eq_u32 s99, 0\n\t"
+                "s_cselect_b32 s97, 0, s97\n\t"
+                "s_cselect_b32 s77, s71, 0\n\t"
+                "s_or_b32 s76, s76, s77\n\t"
+                "s_add_u32 s97, s97, 32\n\t"
+                "s_cmp_lg_u32 s76, 0\n\t"
+                "s_cbranch_scc1 L_pslow%=\n\t"
+                "v_readlane_b32 s74, v60, s96\n\t"
+                "v_readlane_b32 s75, v60, s97\n\t"
+                "s_bcnt1_i32_b32 s76, s98\n\t"
+                "s_bcnt1_i32_b32 s77, s99\n\t"
+                "s_max_u32 s76, s76, s77\n\t"
+                "s_cmp_gt_u32 s76, 1\n\t"
+                "s_cbranch_scc1 L_ptie%=\n\t"
+                "L_pchoice%=:\n\t"
+                "v_readlane_b32 s78, v57, s96\n\t"
+                "v_readlane_b32 s79, v57, s97\n\t"
+                // go on iff, for each half: finished, or (key below the bound's high word, column >= 0, column < 64)
+                "s_sub_i32 s76, s72, s93\n\t"
+                "s_andn2_b32 s76, s76, s78\n\t"
+                "s_sub_i32 s77, s78, 64\n\t"
+                "s_and_b32 s76, s76, s77\n\t"
+                "s_orn2_b32 s76, s76, s70\n\t"
+                "s_sub_i32 s77, s73, s94\n\t"
+                "s_andn2_b32 s77, s77, s79\n\t"
+                "s_sub_i32 vcc_lo, s79, 64\n\t"
+                "s_and_b32 s77, s77, vcc_lo\n\t"
+                "s_orn2_b32 s77, s77, s71\n\t"
+                "s_and_b32 s76, s76, s77\n\t"
+                "s_cmp_lt_i32 s76, 0\n\t"
+                "s_cbranch_scc0 L_pevent%=\n\t"
+                // commit: the chosen rows leave the rows to scan, their distances and columns become current
+                "s_mov_b32 s80, s74\n\t"
+                "s_mov_b32 s81, s72\n\t"
+                "s_mov_b32 s82, s75\n\t"
+                "s_mov_b32 s83, s73\n\t"
+                "s_cmp_lg_u32 s70, 0\n\t"
+                "s_cselect_b32 s84, s78, 0\n\t"
+                "s_cmp_lg_u32 s71, 0\n\t"
+                "s_cselect_b32 s85, s79, 0\n\t"
+                "s_bitset0_b64 s[86:87], s96\n\t"
+                "s_bitset0_b64 s[86:87], s97\n\t"
+                "s_and_b64 s[88:89], s[86:87], s[70:71]\n\t"
+                "s_branch L_pstep%=\n\t"
+                "L_ptie%=:\n\t"
+                "v_mov_b32_e32 v73, s74\n\t"
+                "v_mov_b32_e32 v74, s75\n\t"
+                "v_cndmask_b32_e64 v73, v73, v74, s[90:91]\n\t"
+                "v_cmp_lt_u32_e64 s[76:77], v60, v73\n\t"
+                "s_and_b64 s[76:77], s[76:77], s[98:99]\n\t"
+                "s_cmp_eq_u64 s[76:77], 0\n\t"
+                "s_cbranch_scc1 L_pchoice%=\n\t"
+                "L_pslow%=:\n\t"
+                "s_mov_b32 s95, 1\n\t"
+                "s_branch L_pdone%=\n\t"
+                "L_pevent%=:\n\t"
+                "s_mov_b32 s95, 0\n\t"
+                "L_pdone%=:\n\t"
+                : "+{s80}"(dAlo), "+{s81}"(dAhi), "+{s82}"(dBlo), "+{s83}"(dBhi), "+{s84}"(curA), "+{s85}"(curB),
+                  "+{s[86:87]}"(cand), "+{s[88:89]}"(act), "+{v60}"(spLo), "+{v61}"(spHi), "+{v62}"(pred), "={s95}"(status),
+                  "={s96}"(c0), "={s97}"(c1), "={s72}"(m0), "={s73}"(m1), "={s74}"(dlo0), "={s75}"(dlo1), "={s78}"(cnA),
+                  "={s79}"(cnB), "={s[98:99]}"(eq)
+                : "{v54}"(keyInf), "{v55}"(uBase), "{v56}"(rowAddr), "{v57}"(c4r), "{v[58:59]}"(v), "{s[70:71]}"(liveMask),
+                  "{s[90:91]}"(SM_HI), "{s92}"(LDC * 8), "{s93}"(bHiA), "{s94}"(bHiB)
+                : "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77",
+                  "s76", "s77", "vcc", "scc", "memory");
+            // (the compiler does not know that outputs bound to physical scalar registers are wave-uniform)
+            dLoA = uni32(dAlo); dHiA = uni32(dAhi); dLoB = uni32(dBlo); dHiB = uni32(dBhi);
+            curA = uni32(curA); curB = uni32(curB);
+            cand = uni64(cand); act = uni64(act); eq = uni64(eq);
+            status = uni32(status); c0 = uni32(c0); c1 = uni32(c1) - 32; m0 = uni32(m0); m1 = uni32(m1);
+            dlo0 = uni32(dlo0); dlo1 = uni32(dlo1); cnA = uni32(cnA); cnB = uni32(cnB);
         }
-        const double rc = ((delta + Cval) - uval) - v;                                      // cpp:183 / cpp:313, left to right
-        const u64 upd = __ballot(rc < __hiloint2double(spHi, spLo)) & act;                   // strict '<': cpp:185, 314
-        spHi = sel32(upd, __double2hiint(rc), spHi);
-        spLo = sel32(upd, __double2loint(rc), spLo);
-        pred = sel32(upd, predv, pred);
-        // arg-min over the rows still to scan (cpp:191-194, 320-323): lowest row index among equal values.  Reduced costs
-        // are >= 0 up to rounding, and for non-negative doubles the high word itself is an order-preserving key.
-        const u64 candL = cand & liveMask;
-        const int key = sel32(candL, spHi, KEY_INF_HI);
-        int t;
-        asm volatile(KB_HALF_MIN_CHAIN("v_min_i32_dpp") : "=&v"(t) : "v"(key));
-        int m0 = __builtin_amdgcn_readlane(t, 31), m1 = __builtin_amdgcn_readlane(t, 63);
-        u64 eq = __ballot(key == pick(m0, m1)) & candL;
         u32 e0 = (u32)eq, e1 = (u32)(eq >> 32);
-        int c0 = e0 ? __builtin_ctz(e0) : 0, c1 = e1 ? __builtin_ctz(e1) : 0;
-        int dlo0 = __builtin_amdgcn_readlane(spLo, c0), dlo1 = __builtin_amdgcn_readlane(spLo, 32 + c1);
-        bool exact = (m0 | m1) < 0;  // a negative candidate (-1e-17 from rounding): needs the real key
-        if (!exact && ((e0 & (e0 - 1)) | (e1 & (e1 - 1)))) {
-            // several rows on the same high word (nearly always exact zeros): the first is the minimum unless another one
-            // has a smaller low word
-            exact = (__ballot((u32)spLo < (u32)pick(dlo0, dlo1)) & eq) != 0;
-        }
-        if (__builtin_expect(exact, 0)) {
+        if (__builtin_expect(status != 0, 0)) {
+            // the selects of this step are done; make the choice on the real order-preserving key (negative values,
+            // +inf, low words)
+            const u64 candL = cand & liveMask;
             int khi;
             u32 klo;
             to_key(__hiloint2double(spHi, spLo), khi, klo);
@@ -180,59 +298,59 @@ __device__ __forceinline__ void dijkstra2(const double *Cs, int LDC, const doubl
             m1 = e1 ? __builtin_amdgcn_readlane(spHi, 32 + c1) : KEY_INF_HI;
             dlo0 = __builtin_amdgcn_readlane(spLo, c0);
             dlo1 = __builtin_amdgcn_readlane(spLo, 32 + c1);
+            cnA = __builtin_amdgcn_readlane(c4r, c0);
+            cnB = __builtin_amdgcn_readlane(c4r, 32 + c1);
         }
+        // bookkeeping of the step (cpp:197-224, 327-354), per half
         u64 park = 0ull;  // halves that enter the zero columns in this step
         if (liveA) {
             cand &= ~(1ull << c0);  // the chosen row leaves Row2Scan (cpp:208-210)
             if (e0 == 0 || (m0 & 0x7fffffff) >= KEY_INF_HI) { stA = 1; liveA = false; }  // minimum is +inf: infeasible (cpp:197, 327)
             else {
-                dHiA = m0;
-                dLoA = dlo0;
+                dHiA = finHiA = m0;
+                dLoA = finLoA = dlo0;
                 if (EARLY && (m0 > bHiA || (m0 == bHiA && (u32)dlo0 > bLoA))) { stA = 2; liveA = false; }  // beyond the bound
-                else {
-                    const int cn = __builtin_amdgcn_readlane(c4r, c0);
-                    if (cn < 0) { sinkA = c0; liveA = false; }
-                    else if (cn == SM_PARKED) {
-                        hubA = true; hubRowA = c0; curA = 0; park |= SM_LO;
-                        vkHiA = __builtin_amdgcn_readlane(__double2hiint(v), c0);
-                        vkLoA = __builtin_amdgcn_readlane(__double2loint(v), c0);
-                    } else { hubA = false; curA = cn; }
-                }
+                else if (cnA < 0) { sinkA = c0; liveA = false; }
+                else if (cnA == SM_PARKED) { hubRowA = c0; curA = hubCol; park |= SM_LO; }
+                else curA = cnA;
             }
         }
         if (liveB) {
             cand &= ~(1ull << (32 + c1));
             if (e1 == 0 || (m1 & 0x7fffffff) >= KEY_INF_HI) { stB = 1; liveB = false; }
             else {
-                dHiB = m1;
-                dLoB = dlo1;
+                dHiB = finHiB = m1;
+                dLoB = finLoB = dlo1;
                 if (EARLY && (m1 > bHiB || (m1 == bHiB && (u32)dlo1 > bLoB))) { stB = 2; liveB = false; }
-                else {
-                    const int cn = __builtin_amdgcn_readlane(c4r, 32 + c1);
-                    if (cn < 0) { sinkB = c1; liveB = false; }
-                    else if (cn == SM_PARKED) {
-                        hubB = true; hubRowB = c1; curB = 0; park |= SM_HI;
-                        vkHiB = __builtin_amdgcn_readlane(__double2hiint(v), 32 + c1);
-                        vkLoB = __builtin_amdgcn_readlane(__double2loint(v), 32 + c1);
-                    } else { hubB = false; curB = cn; }
-                }
+                else if (cnB < 0) { sinkB = c1; liveB = false; }
+                else if (cnB == SM_PARKED) { hubRowB = c1; curB = hubCol; park |= SM_HI; }
+                else curB = cnB;
             }
         }
         if (park) {
             // the first parked row is settled: every parked row is at this distance (equal duals), and their columns all
-            // offer the other rows the same reduced costs -- settle them together, one hub relaxation follows
+            // offer the other rows the same reduced costs -- settle them together; ONE relaxation through "the" zero column
+            // follows, whose dual is minus the (common) dual of the parked rows
             const u64 pk = parked & cand & park;
             spHi = sel32(pk, pick(dHiA, dHiB), spHi);
             spLo = sel32(pk, pick(dLoA, dLoB), spLo);
             cand &= ~pk;
+            const double vk = half_bcast_f64(v, hubRowA, hubRowB);
+            if ((__lane_id() & 31u) == 0 && ((park >> __lane_id()) & 1ull)) uW[hubCol] = -vk;
+            wave_fence();
         }
         liveMask = (liveA ? SM_LO : 0ull) | (liveB ? SM_HI : 0ull);
-        act = cand & liveMask;
+        // a half that has ended takes its rows out of the loop's registers (the loop's commit clears "the chosen row" of
+        // both halves; for an ended half that must not touch anything)
+        const u64 ended = ~liveMask & cand;
+        unscanned |= ended;
+        cand &= liveMask;
+        act = cand;
     }
     spOut = __hiloint2double(spHi, spLo);
     predOut = pred;
-    scannedOut = cand0 & ~cand;
-    deltaOut = __hiloint2double(pick(dHiA, dHiB), pick(dLoA, dLoB));
+    scannedOut = cand0 & ~(cand | unscanned);
+    deltaOut = __hiloint2double(pick(finHiA, finHiB), pick(finLoA, finLoB));
     sinkOut = pick(sinkA, sinkB);
     hubRowOut = pick(hubRowA, hubRowB);
     statusOut = pick(stA, stB);
@@ -242,8 +360,8 @@ __device__ __forceinline__ void dijkstra2(const double *Cs, int LDC, const doubl
 // the sink parks, the walk goes on from the parked row the zero columns were entered by), row duals in place,
 // column duals returned (lane & 31 = column; the parent's array must stay intact for its next child).
 __device__ __forceinline__ void augment2(u64 ok, int l, int startv, double sp, int pred, u64 scanned, double delta, int sinkv,
-                                         int hubRowv, const double *uArr, int r4cP, int M, double &v, int &c4r, int &r4c,
-                                         double &uNew)
+                                         int hubRowv, const double *uArr, int hubCol, int r4cP, int M, double &v, int &c4r,
+                                         int &r4c, double &uNew)
 {
     const int hiOff = (int)(__lane_id() & 32u);
     // duals first (they use the pre-flip column -> row map r4cP)
@@ -264,7 +382,7 @@ __device__ __forceinline__ void augment2(u64 ok, int l, int startv, double sp, i
     for (int guard = 0; going && guard < 80; guard++) {  // cpp:108-116
         const int r0 = __builtin_amdgcn_readlane(rv, 0), r1 = __builtin_amdgcn_readlane(rv, 32);
         const int cv = half_bcast_i32(pred, r0, r1);
-        const bool viaHub = cv == SM_HUB;
+        const bool viaHub = cv == hubCol;
         const int q0 = __builtin_amdgcn_readlane(cv, 0), q1 = __builtin_amdgcn_readlane(cv, 32);
         const int nxt = half_bcast_i32(r4c, q0 & 31, q1 & 31);
         const bool mine = ((going >> __lane_id()) & 1ull) != 0;
@@ -343,6 +461,8 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
     unsigned char *nodeC4R = nodeBase + 512;
     unsigned char *nodeR4C = nodeBase + 544;  // (+576: scalars of the node: forbidden rows, active column, state, bound)
     double *gainW = reinterpret_cast<double *>(nodeBase + 608);  // this worker's line of gain terms
+    double *uW = reinterpret_cast<double *>(nodeBase + 864);     // this worker's private column duals of the child it solves (+ hub slot)
+    const int hubCol = p.maxCol;                                 // the all-zero column of the tile that stands for the padded ones
     unsigned short *surv = reinterpret_cast<unsigned short *>(smem + L.offSurv);
 
     const long long costBase = p.costOff ? p.costOff[b] : (long long)b * p.ldRow * p.ldCol;
@@ -382,7 +502,7 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
         for (int i = tid; i < M * (nLout + 1); i += NT) probOut[i] = 0.0;
 
     // ---- phase 0: the cost tile -------------------------------------------------------------------------------
-    for (int i = tid; i < p.maxCol * LDC; i += NT) Cs[i] = INF;  // rows beyond N never win a minimum
+    for (int i = tid; i < (p.maxCol + 1) * LDC; i += NT) Cs[i] = (i < p.maxCol * LDC) ? INF : 0.0;  // rows beyond N never win a minimum; column maxCol: zeros
     if (tid == 0) {
         ctrl->cmaxBits = 0ull;
         ctrl->status = 0;
@@ -568,11 +688,11 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
             double sp, delta;
             int pred, sink, hubRow, status;
             u64 scanned;
-            dijkstra2<false>(Cs, LDC, uArr, rl, v, c4r, (u64)rowsMask, 0ull, true, false, c, 0, INF, INF, sp, pred, scanned,
+            dijkstra2<false>(Cs, uArr, hubCol, rl, v, c4r, (u64)rowsMask, 0ull, true, false, c, 0, INF, INF, sp, pred, scanned,
                              delta, sink, hubRow, status);
             if (__builtin_amdgcn_readlane(status, 0) != 0) { bad = true; break; }
             const int r4cBefore = r4c;
-            augment2(SM_LO, l, c, sp, pred, scanned, delta, sink, hubRow, uArr, r4cBefore, M, v, c4r, r4c, un);
+            augment2(SM_LO, l, c, sp, pred, scanned, delta, sink, hubRow, uArr, hubCol, r4cBefore, M, v, c4r, r4c, un);
             wave_fence();
             if (half == 0 && l < M) uArr[l] = un;
             wave_fence();
@@ -772,7 +892,7 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
                 const int itA = uni32((int)surv[t]), itB = uni32((int)surv[hasB ? t + 1 : t]);
                 const int cA = itA & 31, cB = itB & 31;
                 unsigned char *blk = smem + L.offNodes + (size_t)(pick(itA, itB) >> 5) * L.nodeStride;
-                const double *uBlk = reinterpret_cast<const double *>(blk);
+                uW[l] = reinterpret_cast<const double *>(blk)[l];  // private copy of the parent's column duals (+ the hub slot)
                 const double vP = reinterpret_cast<const double *>(blk + 256)[l];
                 const int c4rP = blk[512 + l];
                 const int r4cP = (l < M) ? (int)blk[544 + l] : -1;
@@ -791,7 +911,8 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
                 int pred, sink, hubRow, status;
                 u64 scanned;
                 KS_T(tD0);
-                dijkstra2<true>(Cs, LDC, uBlk, rl, vP, c4r, cand, forbm, true, hasB, cA, cB, bound0, bound1, sp, pred, scanned,
+                wave_fence();
+                dijkstra2<true>(Cs, uW, hubCol, rl, vP, c4r, cand, forbm, true, hasB, cA, cB, bound0, bound1, sp, pred, scanned,
                                 delta, sink, hubRow, status);
                 KS_T(tD1);
                 KS_ACC(6, tD1 - tD0);  // [6] child dijkstra (pairs)
@@ -801,7 +922,7 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
                 if (!ok) continue;
                 int r4c = (l == cv) ? -1 : r4cP;
                 double vN = vP, uN;
-                augment2(ok, l, cv, sp, pred, scanned, delta, sink, hubRow, uBlk, r4cP, M, vN, c4r, r4c, uN);
+                augment2(ok, l, cv, sp, pred, scanned, delta, sink, hubRow, uW, hubCol, r4cP, M, vN, c4r, r4c, uN);
                 const double g = serial_gain2(r4c);
                 if (useCut) ok &= ~__ballot(maximize ? (g < cutG) : (g > cutG));  // cutHyp, cpp:496/521
                 if (!ok) continue;
