@@ -266,13 +266,25 @@ def run_dense(eng, torch, dist, cfg, B, steps, warmup, rank, world, dev, tstream
 
 
 def host_inclusive_dense(eng, costs, N, M, k):
-    """The same batch through the host-pointer entry: pageable H2D of the cost blocks, launch, D2H of all tables."""
-    eng.kbest(costs, N, M, k)
-    t0 = time.perf_counter()
-    nf = eng.kbest(costs, N, M, k)[0]
-    dt = time.perf_counter() - t0
-    return {"value": float(nf.sum()) / dt, "unit": "assignments/s", "ms": 1e3 * dt,
-            "includes": "H2D of the cost blocks (pageable), kernel, D2H of row4col / col4row / gain / nf (pageable)"}
+    """The same batch through the host-pointer entry: H2D of the cost blocks, launch, D2H of all tables, into
+    caller-owned buffers that are allocated (and touched) once, as a caller that runs frame after frame would."""
+    import probabilisticsemslam_amd.engine as E
+    B = costs.shape[0]
+    r4c = np.zeros((B, k, M), np.int32)
+    c4r = np.zeros((B, k, N), np.int32)
+    gain = np.zeros((B, k))
+    nf = np.zeros(B, np.int32)
+    o = eng._opts(False, None)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        rc = eng.lib.kbest_batch_f64(eng.ctx, C.byref(o), B, N, M, None, None, p(costs), None, k, p(r4c), p(c4r), p(gain), p(nf), None)
+        dt = time.perf_counter() - t0
+        assert rc == 0
+        best = dt if best is None or dt < best else best
+    return {"value": float(nf.sum()) / best, "unit": "assignments/s", "ms": 1e3 * best,
+            "includes": "H2D of the cost blocks, kernel, D2H of row4col / col4row / gain / nf (host buffers in and out: kbest_batch_f64)"}
 
 
 def dense_entry(eng, torch, cfg, steps, warmup, dev, tstream, cpu_sample, no_cpu):

@@ -1076,6 +1076,12 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
             HIP_TRY(ctx, hipMemcpy(probs, dCost.p, nCost * 8, hipMemcpyDeviceToHost));
             return KBEST_OK;
         }
+        if (maxCol <= kb::SMALL_MAX_DIM && rawMaxRow <= kb::SMALL_MAX_RAW_ROWS) {
+            // frame-sized: the cost blocks the quadric kernel just built go straight into the fused association kernel
+            const int rc = weights_small(ctx, B, nL, nM, nRow.data(), nullptr, dCost.as<double>(), costOff, k, probs, probOff, nf,
+                                         condition, bruteForce, rawMaxRow, maxCol, nCost, nProb);
+            if (rc != 1) return rc;
+        }
     }
     const double *solveCost = dCost.as<double>();
     const int32_t *solveRows = dNR.as<int32_t>();
@@ -1100,14 +1106,19 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
         solveCost = dCond.as<double>();
         solveRows = dGood.as<int32_t>();
         weightNL = dCondL.as<int>();
-        // size the solver for what conditionCosts kept, not for the raw map
-        std::vector<int32_t> good(B);
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, hipMemcpy(good.data(), dGood.p, (size_t)B * 4, hipMemcpyDeviceToHost));
-        maxRow = maxCol;
-        for (int b = 0; b < B; b++)
-            if (good[b] > maxRow) maxRow = good[b];
-        if (maxRow > KBEST_MAX_DIM_WIDE) maxRow = KBEST_MAX_DIM_WIDE;  // frames beyond it come back with nf = -1
+        if (rawMaxRow > KBEST_MAX_DIM) {
+            // size the solver for what conditionCosts kept, not for the raw map (the general-size kernel is several
+            // times slower per row than the LDS kernels: worth one round trip)
+            std::vector<int32_t> good(B);
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, hipMemcpy(good.data(), dGood.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+            maxRow = maxCol;
+            for (int b = 0; b < B; b++)
+                if (good[b] > maxRow) maxRow = good[b];
+            if (maxRow > KBEST_MAX_DIM_WIDE) maxRow = KBEST_MAX_DIM_WIDE;  // frames beyond it come back with nf = -1
+        }
+        // (up to 64 raw rows the LDS kernel takes whatever is kept: the launch is sized from the raw row count and
+        //  nothing waits for the conditioning kernel)
     }
     const size_t nR4C = (size_t)B * k * maxCol, nG = (size_t)B * k;
     HIP_TRY(ctx, dR4C.alloc(ctx, nR4C * 4));

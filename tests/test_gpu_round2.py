@@ -199,3 +199,24 @@ def test_fused_association_device_entry(engine):
         want[:, nL] = po[:, len(idx) - nM]
         np.testing.assert_allclose(probs[i], want, rtol=0, atol=1e-12)
         assert nf[i] == onf
+
+
+def test_mid_size_frames_take_the_general_pipeline_without_a_host_round_trip(engine):
+    """Frames whose conditioned block has more than 32 rows do not fit the fused kernel (nf = -2 inside): the host entry
+    re-runs the batch on condition kernel -> 64-row kernel -> weights kernel, sized from the RAW row count (<= 64), and
+    mixed batches (some frames fit, some do not) give the same answers."""
+    fr_big = wl.kitti_like_frames(6, nL=50, nM=14, seed=0xD00D01)
+    fr_small = wl.kitti_like_frames(6, nL=20, nM=10, seed=0xD00D02)
+    costs, nL, nM = [], [], []
+    for a, b in zip(fr_big, fr_small):
+        costs += [a, b]; nL += [50, 20]; nM += [14, 10]
+    kept = [len(ol.condition_costs(c, l + m, m)[1]) for c, l, m in zip(costs, nL, nM)]
+    assert max(kept) > 32, kept  # (otherwise this test does not test what it says)
+    out, nf = engine.weights(costs, nL, nM, 150, condition=True)
+    for c, l, m, p in zip(costs, nL, nM, out):
+        cond, idx = ol.condition_costs(c, l + m, m)
+        po, _ = ol.assignment_prob(cond, len(idx) - m, m, 150)
+        want = np.zeros((m, l + 1))
+        want[:, idx[: len(idx) - m]] = po[:, : len(idx) - m]
+        want[:, l] = po[:, len(idx) - m]
+        np.testing.assert_allclose(p, want, rtol=0, atol=1e-12)
