@@ -29,6 +29,14 @@
  * "row sits on a zero-padded column" (SURVEY 8(a) quirk 6); the number of
  * solutions found is returned per problem, 0 = infeasible (cpp:588-593).
  * The solver never throws; negative return values are engine errors.
+ *
+ * Order of exact ties.  Hypotheses with EXACTLY equal gain have no defined relative order in the reference (it is
+ * an artefact of std::priority_queue's binary heap, cpp:574).  The engine orders them deterministically -- old pool
+ * entries before fresh ones, fresh ones by (parent hypothesis, column) -- which is in general NOT the reference's
+ * order.  For continuous costs ties have probability zero and every output is bit-identical; for integer-like costs
+ * (conditionCosts produces exact zeros) the multiset of gains and the validity of every assignment are the
+ * reference's, but when a tie group straddles slot k (or the best + cutoff gate) the emitted SET, and with it
+ * assignmentProb's weights, may differ from the reference's by more than rounding.
  * Index outputs are int32 (the reference ABI uses ptrdiff_t; the C++ shims in
  * include/kbest_shims.hpp widen on the host).
  *

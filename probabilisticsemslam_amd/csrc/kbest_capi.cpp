@@ -1154,13 +1154,17 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
         if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "weights kernel launch", e);
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (nf) {  // probabilities and counts come back in one copy
+    {   // probabilities and counts come back in one copy
         std::vector<unsigned char> out(probBytes + (size_t)B * 4);
         HIP_TRY(ctx, hipMemcpy(out.data(), dOut.p, out.size(), hipMemcpyDeviceToHost));
         memcpy(probs, out.data(), nProb * 8);
-        memcpy(nf, out.data() + probBytes, (size_t)B * 4);
-    } else {
-        HIP_TRY(ctx, hipMemcpy(probs, dProbs.p, nProb * 8, hipMemcpyDeviceToHost));
+        const int32_t *hnf = reinterpret_cast<const int32_t *>(out.data() + probBytes);
+        if (nf) memcpy(nf, hnf, (size_t)B * 4);
+        // a caller without an nf array (the reference-named shims) must not get all-zero probabilities silently:
+        // -3 is an engine failure; -1 (the conditioned block is beyond every kernel) is reported through nf when there is one
+        for (int b = 0; b < B; b++)
+            if (hnf[b] == -3 || (hnf[b] < 0 && !nf))
+                return fail(ctx, hnf[b] == -3 ? KBEST_ERR_INTERNAL : KBEST_ERR_UNSUPPORTED, "association weights: a frame came back with nf < 0");
     }
     return KBEST_OK;
 }

@@ -67,9 +67,17 @@ def merge_subtree_topk(gain: torch.Tensor, row4col: torch.Tensor, nf: torch.Tens
     slot = torch.arange(kk, device=G.device).view(1, 1, kk)
     valid = (slot >= 1) & (slot < Nf.unsqueeze(-1))
     cand = torch.where(valid, G, torch.full_like(G, bad)).permute(1, 0, 2).reshape(B, W * kk)
-    order = torch.argsort(cand, dim=1, descending=maximize, stable=True)[:, : k - 1]
-    cg = torch.gather(cand, 1, order)
     rows = R.permute(1, 0, 2, 3).reshape(B, W * kk, -1)
+    # Exact ties in gain (integer-like costs; the reference's own order is a heap artefact) are
+    # ordered by the assignment itself, so the merged table does not depend on which rank a hypothesis came from or on
+    # the number of ranks: first a stable sort by a mixing key of row4col, then the stable sort by gain.
+    mix = torch.zeros((B, W * kk), dtype=torch.int64, device=G.device)
+    for c in range(rows.shape[-1]):
+        mix = mix * 1000003 + rows[..., c].to(torch.int64) + 1
+    o1 = torch.argsort(mix, dim=1, stable=True)
+    o2 = torch.argsort(torch.gather(cand, 1, o1), dim=1, descending=maximize, stable=True)
+    order = torch.gather(o1, 1, o2)[:, : k - 1]
+    cg = torch.gather(cand, 1, order)
     cr = torch.gather(rows, 1, order.unsqueeze(-1).expand(-1, -1, rows.shape[-1]))
     out_g = torch.cat([G[0, :, :1], cg], 1)
     out_r = torch.cat([R[0, :, :1], cr], 1)
