@@ -30,6 +30,7 @@ struct kbest_ctx {
     int ldsPerCU = 160 * 1024;
     int nCU = 256;
     int smallWaves = 0;  // waves per problem of the small-problem kernel; 0 = choose per launch (KBEST_SMALL_NW)
+    bool exactRoot = false;   // KBEST_EXACT_ROOT: the 64-row kernel's root without the column-reduction start (A/B tests)
     bool noPoll = false;      // KBEST_NO_POLL: zero-copy calls wait for the stream instead of polling the completion counter
     bool forceSmall = false;  // KBEST_FORCE_SMALL: every batch of <= 32-row problems through the small-problem kernel
     bool noSmall = false;  // KBEST_NO_SMALL: problems of <= 32 rows through the 64-row kernel as well (A/B tests)
@@ -253,6 +254,7 @@ int kbest_create(kbest_ctx **out, int device)
     ctx->noSmall = getenv("KBEST_NO_SMALL") != nullptr;
     ctx->forceSmall = getenv("KBEST_FORCE_SMALL") != nullptr;
     ctx->noPoll = getenv("KBEST_NO_POLL") != nullptr;
+    ctx->exactRoot = getenv("KBEST_EXACT_ROOT") != nullptr;
     if (const char *e = getenv("KBEST_SPEC")) {
         int w = atoi(e);
         if (w >= 1 && w <= 16) ctx->spec = w;
@@ -531,7 +533,7 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         p.k = k;
         p.maximize = opts->maximize;
         p.useCutoff = opts->use_cutoff;
-        p.flags = opts->flags;
+        p.flags = opts->flags | (ctx->exactRoot ? KBEST_FLAG_EXACT_ROOT : 0u);
         p.cutoff = opts->cutoff;
         p.rootColOffset = opts->root_col_offset;
         p.rootColStride = opts->root_col_stride;

@@ -542,7 +542,48 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         u64 scanned;
         bool bad = false;
         const int nAug = rect ? M : D;
-        for (int c = 0; c < nAug; c++) {
+        u64 todo = (nAug >= 64) ? ~0ull : ((1ull << nAug) - 1ull);  // columns still to be augmented from
+        if (!rect && !(p.flags & KBEST_FLAG_EXACT_ROOT)) {
+            // Column reduction first (the initialisation of Jonker-Volgenant): u[c] = min of column c, and a row that is
+            // the arg-min of exactly one column -- or of several: the lowest column wins -- is assigned to it.  All
+            // reduced costs stay >= 0 and the assigned arcs are tight, so this is a valid starting point for the
+            // shortest-augmenting-path steps below, which then run only from the columns left over (about a third of them
+            // on dense problems instead of all: the 64 sequential augmentations of the reference's root, cpp:139-230,
+            // cost 9 % of a 64x64 matrix' lifetime on one wave while eleven wait).  The optimal assignment the root ends
+            // with is the same (it is unique for tie-free costs); its dual variables are another optimal pair than the
+            // reference's, which no output depends on.  assign2D / shortestPathCPP (rect) keep the reference's own order:
+            // their duals ARE an output.
+            int *owner = reinterpret_cast<int *>(gainW);
+            owner[lane] = 64;
+            wave_fence();
+            const int cc = lane < D ? lane : D - 1;
+            const double *Ccol = Cs + cc * LDC;
+            double m = INF;
+            int am = 0;
+            for (int r0 = 0; r0 < D; r0 += 4) {
+                double x[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) x[i] = Ccol[(r0 + i < D) ? r0 + i : D - 1];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const bool better = (r0 + i < D) & (x[i] < m);  // strict '<': the lowest row among equal minima
+                    m = better ? x[i] : m;
+                    am = better ? r0 + i : am;
+                }
+            }
+            const bool can = lane < D && m < INF;
+            if (can) atomicMin(&owner[am], lane);
+            wave_fence();
+            if (lane < D) nd.u[lane] = can ? m : 0.0;
+            r4c = (can && owner[am] == lane) ? am : -1;
+            const int ow = owner[lane];
+            c4r = (lane < D && ow < 64) ? ow : -1;
+            wave_fence();
+            todo &= __ballot(lane < D && r4c < 0);
+        }
+        while (todo) {
+            const int c = __builtin_ctzll(todo);
+            todo &= todo - 1;
             if (dijkstra<false>(Cs, LDC, nd.u, rl, lane, v, c4r, allRows, 0ull, c, INF, spc, pred, scanned, delta,
                                 sink)) { bad = true; break; }
             dual_update_flip(nd.u, lane, v, c4r, r4c, spc, pred, scanned, delta, sink, c);
