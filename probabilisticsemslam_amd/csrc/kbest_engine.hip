@@ -342,8 +342,9 @@ struct Ctrl {
     int nSurvBack; //   ... and those queued from the back
     short selIdx[16];          // pool index of each node selected in the last A phase (they are split in the next B)
     unsigned short selSid[16]; // and its state slot
+    int partsDone[16];         // waves that have finished their part of a node's first-step filter (the last one compacts)
 };
-static_assert(sizeof(Ctrl) <= 144, "Ctrl must fit the LDS slot reserved by lds_layout");
+static_assert(sizeof(Ctrl) <= 208, "Ctrl must fit the LDS slot reserved by lds_layout");
 
 // pool entry: gain (fp64), meta (u32: column | parent state << 8 | flags), own state slot (u16)
 constexpr unsigned short SID_NONE = 0xFFFFu;  // no saved state: re-solve from the parent when selected
@@ -489,6 +490,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             ctrl->nSurvBack = 0;
             ctrl->selIdx[0] = -1;
             ctrl->selSid[0] = 0;
+            for (int i = 0; i < 16; i++) ctrl->partsDone[i] = 0;
         }
         __syncthreads();
         for (int i = tid; i < spec * 64; i += NT) { lbKey[i] = ~0ull; lbIn[i] = ~0u; }  // (`red` is dead now)
@@ -646,6 +648,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         const double cmaxv = ctrl->cmax;
         KB_T(tF0);
         KB_ACC(14, tF0 - tRound);  // [14] round prologue (control reads)
+        int myNode = -1, myParts = 1;  // the node whose filter this wave took part in
         {
             // all NW waves take part: node = wave % nsel, and the waves of one node split its columns j.
             // Walking the parent's columns j >= a instead of the rows makes the candidate test a scalar lane mask:
@@ -658,6 +661,8 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             const int parts = (NW * rcpSel) >> 16;
             const int part = (wave * rcpSel) >> 16, nodeI = wave - part * nsel;
             if (part < parts) {
+                myNode = nodeI;
+                myParts = parts;
                 const NodeRef nd = node_ref(smem + L.offNodes + (size_t)nodeI * L.nodeStride, p.maxRow);
                 const int a = uni32(nd.info[0]);
                 const u64 nforb = uni64(nd.forb[0]);
@@ -746,18 +751,28 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         }
         KB_T(tF1);
         KB_ACC(15, tF1 - tF0);     // [15] first-step filter busy
-        __syncthreads();
-        if (wave < nsel) {  // one wave per node: survivors = finite minimum (else infeasible, cpp:327) within the bound
-            const NodeRef nd = node_ref(smem + L.offNodes + (size_t)wave * L.nodeStride, p.maxRow);
+        // The wave that finishes a node's filter LAST compacts its survivors (no barrier between the two): the minima of
+        // all parts are in LDS once every part has bumped the node's counter (a wave's LDS operations execute in order).
+        bool compactor = false;
+        if (myNode >= 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            int old = 0;
+            if (lane == 0) old = atomicAdd(&ctrl->partsDone[myNode], 1);
+            compactor = uni32(old) == myParts - 1;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        if (compactor) {  // one wave per node: survivors = finite minimum (else infeasible, cpp:327) within the bound
+            if (lane == 0) ctrl->partsDone[myNode] = 0;
+            const NodeRef nd = node_ref(smem + L.offNodes + (size_t)myNode * L.nodeStride, p.maxRow);
             const int a = uni32(nd.info[0]);
             const int sid = uni32(nd.info[1]);
             const double pgain = nd.gain[0];
             const double bound = (prune && T < INF) ? (T - pgain) + 1e-9 * (fabs(T) + cmaxv) : INF;
             const int c = a + lane;
             const bool live = c < M && !(sid == 0 && p.rootColStride > 1 && (c % p.rootColStride) != p.rootColOffset);
-            const u64 key = lbKey[wave * 64 + lane];
+            const u64 key = lbKey[myNode * 64 + lane];
             const double m = from_key((int)((u32)(key >> 32) ^ 0x80000000u), (u32)key);
-            const u32 inH = lbIn[wave * 64 + lane];
+            const u32 inH = lbIn[myNode * 64 + lane];
             const double minIn = (prune && T < INF) ? __hiloint2double((int)inH, 0) : 0.0;  // +inf: no last arc at all
             const bool keep = live && m < INF && !(m + minIn > bound);
             // Children whose first step is far inside the bound tend to run long (they are the ones that complete):
@@ -778,7 +793,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 const double f = (minIn / bound) * 63.0;
                 q = f >= 63.0 ? 63 : (int)f;
             }
-            const unsigned short entry = (unsigned short)((q << 10) | (wave << 6) | c);
+            const unsigned short entry = (unsigned short)((q << 10) | (myNode << 6) | c);
             if (heavy) surv[baseH + __popcll(kh & below)] = entry;
             else if (keep) surv[spec * 64 - 1 - (baseL + __popcll(kl & below))] = entry;
         }
