@@ -105,6 +105,12 @@ __device__ __forceinline__ double half_bcast_f64(double x, int idxLow, int idxHi
 //   boundv      early termination (EARLY): a half gives up as soon as its settled distance exceeds it
 // Out per half: spc / pred per row, scanned rows, final distance, sink row, the parked row through which the zero
 // columns were entered (or -1), status 0 = path found, 1 = infeasible (cpp:197, 327), 2 = abandoned.
+#ifdef KS_TRUST_SGPR
+#define KS_UNI(x) (x)
+#else
+#define KS_UNI(x) uni32(x)
+#endif
+
 template <bool EARLY>
 __device__ __forceinline__ void dijkstra2(const double *Cs, double *uW, int hubCol, int rl, double v, int c4r, u64 cand,
                                           u64 forb, bool liveA, bool liveB, int startA, int startB, double boundA,
@@ -131,6 +137,7 @@ __device__ __forceinline__ void dijkstra2(const double *Cs, double *uW, int hubC
     int spHi = KEY_INF_HI, spLo = 0, pred = 0;
     const u32 rowAddr = (u32)reinterpret_cast<uintptr_t>(Cs + rl);   // LDS byte addresses (the low word of a flat LDS
     const u32 uBase = (u32)reinterpret_cast<uintptr_t>(uW);           //   address is the LDS offset)
+    const u32 hubAddr = uBase + (u32)hubCol * 8u;
     const int keyInf = KEY_INF_HI;
     while (liveMask) {
         int status, c0, c1, m0, m1, dlo0, dlo1, cnA, cnB;
@@ -220,6 +227,60 @@ __device__ __forceinline__ void dijkstra2(const double *Cs, double *uW, int hubC
                 "L_pchoice%=:\n\t"
                 "v_readlane_b32 s78, v57, s96\n\t"
                 "v_readlane_b32 s79, v57, s97\n\t"
+                // the chosen row of a live half is PARKED (on a zero column) and its key is below the bound: enter the zero
+                // columns here -- all parked rows of the half are settled at this distance, the hub's dual slot becomes
+                // -v[row], the next column is the hub column
+                "s_cmp_eq_u32 s78, 64\n\t"
+                "s_cbranch_scc0 L_pnoparkA%=\n\t"
+                "s_cmp_eq_u32 s70, 0\n\t"
+                "s_cbranch_scc1 L_pnoparkA%=\n\t"
+                "s_cmp_ge_i32 s72, s93\n\t"
+                "s_cbranch_scc1 L_pnoparkA%=\n\t"
+                "v_readlane_b32 s76, v58, s96\n\t"
+                "v_readlane_b32 s77, v59, s96\n\t"
+                "s_xor_b32 s77, s77, 0x80000000\n\t"
+                "s_mov_b64 vcc, exec\n\t"
+                "s_mov_b64 exec, 1\n\t"
+                "v_mov_b32_e32 v74, s76\n\t"
+                "v_mov_b32_e32 v75, s77\n\t"
+                "ds_write_b64 v53, v[74:75]\n\t"
+                "s_mov_b64 exec, vcc\n\t"
+                "s_and_b32 s76, s68, s86\n\t"
+                "s_mov_b32 s77, 0\n\t"
+                "v_mov_b32_e32 v73, s72\n\t"
+                "v_cndmask_b32_e64 v61, v61, v73, s[76:77]\n\t"
+                "v_mov_b32_e32 v73, s74\n\t"
+                "v_cndmask_b32_e64 v60, v60, v73, s[76:77]\n\t"
+                "s_andn2_b32 s86, s86, s76\n\t"
+                "s_mov_b32 s66, s96\n\t"
+                "s_mov_b32 s78, s67\n\t"
+                "L_pnoparkA%=:\n\t"
+                "s_cmp_eq_u32 s79, 64\n\t"
+                "s_cbranch_scc0 L_pnoparkB%=\n\t"
+                "s_cmp_eq_u32 s71, 0\n\t"
+                "s_cbranch_scc1 L_pnoparkB%=\n\t"
+                "s_cmp_ge_i32 s73, s94\n\t"
+                "s_cbranch_scc1 L_pnoparkB%=\n\t"
+                "v_readlane_b32 s76, v58, s97\n\t"
+                "v_readlane_b32 s77, v59, s97\n\t"
+                "s_xor_b32 s77, s77, 0x80000000\n\t"
+                "s_mov_b64 vcc, exec\n\t"
+                "s_mov_b32 exec_lo, 0\n\t"
+                "s_mov_b32 exec_hi, 1\n\t"
+                "v_mov_b32_e32 v74, s76\n\t"
+                "v_mov_b32_e32 v75, s77\n\t"
+                "ds_write_b64 v53, v[74:75]\n\t"
+                "s_mov_b64 exec, vcc\n\t"
+                "s_mov_b32 s76, 0\n\t"
+                "s_and_b32 s77, s69, s87\n\t"
+                "v_mov_b32_e32 v73, s73\n\t"
+                "v_cndmask_b32_e64 v61, v61, v73, s[76:77]\n\t"
+                "v_mov_b32_e32 v73, s75\n\t"
+                "v_cndmask_b32_e64 v60, v60, v73, s[76:77]\n\t"
+                "s_andn2_b32 s87, s87, s77\n\t"
+                "s_sub_u32 s65, s97, 32\n\t"
+                "s_mov_b32 s79, s67\n\t"
+                "L_pnoparkB%=:\n\t"
                 // go on iff, for each half: finished, or (key below the bound's high word, column >= 0, column < 64)
                 "s_sub_i32 s76, s72, s93\n\t"
                 "s_andn2_b32 s76, s76, s78\n\t"
@@ -264,17 +325,20 @@ __device__ __forceinline__ void dijkstra2(const double *Cs, double *uW, int hubC
                 : "+{s80}"(dAlo), "+{s81}"(dAhi), "+{s82}"(dBlo), "+{s83}"(dBhi), "+{s84}"(curA), "+{s85}"(curB),
                   "+{s[86:87]}"(cand), "+{s[88:89]}"(act), "+{v60}"(spLo), "+{v61}"(spHi), "+{v62}"(pred), "={s95}"(status),
                   "={s96}"(c0), "={s97}"(c1), "={s72}"(m0), "={s73}"(m1), "={s74}"(dlo0), "={s75}"(dlo1), "={s78}"(cnA),
-                  "={s79}"(cnB), "={s[98:99]}"(eq)
-                : "{v54}"(keyInf), "{v55}"(uBase), "{v56}"(rowAddr), "{v57}"(c4r), "{v[58:59]}"(v), "{s[70:71]}"(liveMask),
-                  "{s[90:91]}"(SM_HI), "{s92}"(LDC * 8), "{s93}"(bHiA), "{s94}"(bHiB)
+                  "={s79}"(cnB), "={s[98:99]}"(eq), "+{s66}"(hubRowA), "+{s65}"(hubRowB)
+                : "{v53}"(hubAddr), "{v54}"(keyInf), "{v55}"(uBase), "{v56}"(rowAddr), "{v57}"(c4r), "{v[58:59]}"(v),
+                  "{s67}"(hubCol), "{s[68:69]}"(parked), "{s[70:71]}"(liveMask), "{s[90:91]}"(SM_HI), "{s92}"(LDC * 8),
+                  "{s93}"(bHiA), "{s94}"(bHiB)
                 : "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77",
                   "s76", "s77", "vcc", "scc", "memory");
-            // (the compiler does not know that outputs bound to physical scalar registers are wave-uniform)
-            dLoA = uni32(dAlo); dHiA = uni32(dAhi); dLoB = uni32(dBlo); dHiB = uni32(dBhi);
-            curA = uni32(curA); curB = uni32(curB);
+            // (outputs bound to physical scalar registers: the values ARE wave-uniform; KS_UNI decides whether the compiler is
+            //  told so by a readfirstlane round trip)
+            dLoA = KS_UNI(dAlo); dHiA = KS_UNI(dAhi); dLoB = KS_UNI(dBlo); dHiB = KS_UNI(dBhi);
+            curA = KS_UNI(curA); curB = KS_UNI(curB);
+            hubRowA = KS_UNI(hubRowA); hubRowB = KS_UNI(hubRowB);
             cand = uni64(cand); act = uni64(act); eq = uni64(eq);
-            status = uni32(status); c0 = uni32(c0); c1 = uni32(c1) - 32; m0 = uni32(m0); m1 = uni32(m1);
-            dlo0 = uni32(dlo0); dlo1 = uni32(dlo1); cnA = uni32(cnA); cnB = uni32(cnB);
+            status = uni32(status); c0 = KS_UNI(c0); c1 = KS_UNI(c1) - 32; m0 = KS_UNI(m0); m1 = KS_UNI(m1);
+            dlo0 = KS_UNI(dlo0); dlo1 = KS_UNI(dlo1); cnA = KS_UNI(cnA); cnB = KS_UNI(cnB);
         }
         u32 e0 = (u32)eq, e1 = (u32)(eq >> 32);
         if (__builtin_expect(status != 0, 0)) {
