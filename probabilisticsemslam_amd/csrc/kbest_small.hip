@@ -929,7 +929,39 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
                     m = rcv < m ? rcv : m;
                 }
             }
-            const bool keep = haveNode && cL < M && m < INF && !(m > boundv);
+            // Backward bound, the other end of the path: the only sink of child c is the row it frees, fr = row4col[c],
+            // and every arc into fr comes from a later column j > c -- reduced cost (C[fr,j] - u[j]) - v[fr] -- (or from the
+            // zero columns, v_parked - v[fr], see below).  First arc and last arc are different arcs of the same path and all
+            // reduced costs are >= 0 up to rounding, so the child's distance is at least m + minIn: beyond the bound
+            // (which carries the safety margin), no wave is spent on it.
+            // (Only on square problems: with zero columns the arc from them into fr is nearly always tight, the bound
+            //  buys nothing and the pass costs as much as the first one -- measured on the 28 x 10 frames: 3 % fewer
+            //  children, 11 % more time.)
+            double minIn = 0.0;
+            if (N == M) {
+                minIn = INF;
+                const int fr = nodeR4C[cc];
+                const double vfr = nodeV[fr];
+                const double *Crow = Cs + fr;
+                for (int j0 = 1; j0 < M; j0 += 4) {
+                    double cin[4], uj[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int j = (j0 + i < M) ? j0 + i : M - 1;
+                        cin[i] = Crow[j * LDC];
+                        uj[i] = uArr[j];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        double rin = (cin[i] - uj[i]) - vfr;
+                        rin = rin < 0.0 ? 0.0 : rin;  // -1e-17 from rounding: no information
+                        const bool ok = (j0 + i < M) & (j0 + i > cL);
+                        const double rv = ok ? rin : INF;
+                        minIn = rv < minIn ? rv : minIn;
+                    }
+                }
+            }
+            const bool keep = haveNode && cL < M && m < INF && !(m + minIn > boundv);
             const u64 survM = __ballot(keep);
             const u64 mine = survM & myHalf;
             int base = 0;
