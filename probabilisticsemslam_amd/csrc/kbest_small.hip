@@ -39,6 +39,7 @@
 // fp64 add / sub / compare (and exp in the weights) only -- no MFMA.  Compiled without fast-math.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 
 #include "kbest_engine.h"
@@ -1182,9 +1183,17 @@ template <int NW>
 static hipError_t launch_small_nw(const SmallParams &p, int B, hipStream_t stream)
 {
     const SmallLds L = small_lds_layout(p.maxRow, p.maxCol, p.k, NW, p.weights != 0);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kbest_small_kernel<NW>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
-    if (e != hipSuccess) return e;
+    // (raising the dynamic LDS limit is a runtime call of several microseconds: only when this launch needs more than
+    //  any before it -- a one-frame call is a single launch and nothing else; per device, as the attribute is)
+    static std::atomic<int> granted[16];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (L.total > granted[dev & 15].load(std::memory_order_relaxed)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kbest_small_kernel<NW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
+        if (e != hipSuccess) return e;
+        granted[dev & 15].store(L.total, std::memory_order_relaxed);
+    }
     hipLaunchKernelGGL((kbest_small_kernel<NW>), dim3(B), dim3(NW * 64), L.total, stream, p);
     return hipGetLastError();
 }
