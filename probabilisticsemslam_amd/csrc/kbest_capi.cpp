@@ -811,7 +811,8 @@ static int raw_reserve(kbest_ctx *ctx, DevBufRaw &d, size_t need)
 struct QuadricHost;
 static int weights_small(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM, const int32_t *nRow, const double *cost,
                          const double *d_cost, const int64_t *costOff, int k, double *probs, const int64_t *probOff,
-                         int32_t *nf, bool condition, bool bruteForce, int rawMaxRow, int maxCol, size_t nCost, size_t nProb)
+                         int32_t *nf, bool condition, bool bruteForce, int rawMaxRow, int maxCol, size_t nCost, size_t nProb,
+                         std::vector<int> *unfit = nullptr)
 {
     const int capRow = rawMaxRow < kb::SMALL_MAX_DIM ? rawMaxRow : kb::SMALL_MAX_DIM;
     int nw = 0;
@@ -913,13 +914,18 @@ static int weights_small(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     const int32_t *hnf = reinterpret_cast<const int32_t *>(hout + probBytes);
+    bool anyUnfit = false;
     for (int b = 0; b < B; b++)
-        if (hnf[b] == -2) return 1;  // a frame that keeps more rows than this kernel takes: general pipeline
+        if (hnf[b] == -2) {  // a frame that keeps more rows than this kernel takes: general pipeline
+            anyUnfit = true;
+            if (unfit) unfit->push_back(b);
+        }
+    if (anyUnfit && !unfit) return 1;
     memcpy(probs, hout, nProb * 8);
     if (nf) memcpy(nf, hnf, (size_t)B * 4);
     for (int b = 0; b < B; b++)
-        if (hnf[b] < 0) return fail(ctx, KBEST_ERR_INTERNAL, "association kernel: a frame came back with nf < 0");
-    return KBEST_OK;
+        if (hnf[b] < 0 && hnf[b] != -2) return fail(ctx, KBEST_ERR_INTERNAL, "association kernel: a frame came back with nf < 0");
+    return anyUnfit ? 1 : KBEST_OK;
 }
 
 extern "C" int kbest_assoc_probs_batch_f64_dev(kbest_ctx *ctx, int B, int maxRawRow, int maxCol, const int32_t *d_nL,
@@ -988,7 +994,7 @@ extern "C" int kbest_reserve_assoc(kbest_ctx *ctx, int B, int maxRawRow, int max
 
 static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM, const double *cost,
                             const int64_t *costOff, int k, double *probs, const int64_t *probOff, int32_t *nf,
-                            bool condition, const QuadricHost *quad = nullptr, bool bruteForce = false)
+                            bool condition, const QuadricHost *quad = nullptr, bool bruteForce = false, bool allowSmall = true)
 {
     if (!ctx) return KBEST_ERR_BAD_ARG;
     if (B < 0 || (k < 1 && !(quad && k == 0)) || !nL || !nM || (!cost && !quad) || !costOff || !probs || !probOff)
@@ -1014,11 +1020,24 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
     const int rawMaxRow = maxRow;
     if (!condition && maxRow > KBEST_MAX_DIM_WIDE) return fail(ctx, KBEST_ERR_UNSUPPORTED, "nL + nM > KBEST_MAX_DIM_WIDE");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (!quad && k >= 1 && maxCol <= kb::SMALL_MAX_DIM && rawMaxRow <= kb::SMALL_MAX_RAW_ROWS) {
-        // the frame-sized case: one fused launch (kbest_small.hip)
+    if (allowSmall && !quad && k >= 1 && maxCol <= kb::SMALL_MAX_DIM && rawMaxRow <= kb::SMALL_MAX_RAW_ROWS) {
+        // the frame-sized case: one fused launch (kbest_small.hip); the frames that keep more rows than it takes -- and
+        // only those -- go through the general pipeline below
+        std::vector<int> unfit;
         const int rc = weights_small(ctx, B, nL, nM, nRow.data(), cost, nullptr, costOff, k, probs, probOff, nf, condition,
-                                     bruteForce, rawMaxRow, maxCol, nCost, nProb);
+                                     bruteForce, rawMaxRow, maxCol, nCost, nProb, &unfit);
         if (rc != 1) return rc;
+        if (!unfit.empty()) {
+            const int Bs = (int)unfit.size();
+            std::vector<int32_t> sL(Bs), sM(Bs), sNf(Bs);
+            std::vector<int64_t> sCo(Bs), sPo(Bs);
+            for (int i = 0; i < Bs; i++) { sL[i] = nL[unfit[i]]; sM[i] = nM[unfit[i]]; sCo[i] = costOff[unfit[i]]; sPo[i] = probOff[unfit[i]]; }
+            const int rc2 = weights_pipeline(ctx, Bs, sL.data(), sM.data(), cost, sCo.data(), k, probs, sPo.data(), sNf.data(), condition,
+                                             nullptr, bruteForce, false);
+            if (rc2 != KBEST_OK) return rc2;
+            if (nf) for (int i = 0; i < Bs; i++) nf[unfit[i]] = sNf[i];
+            return KBEST_OK;
+        }
     }
     // The five per-problem index arrays travel as ONE block (one copy instead of five), and nf sits right behind
     // the probabilities (one copy back instead of two): per-frame calls are dominated by call overheads.
@@ -1159,7 +1178,12 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
     {   // probabilities and counts come back in one copy
         std::vector<unsigned char> out(probBytes + (size_t)B * 4);
         HIP_TRY(ctx, hipMemcpy(out.data(), dOut.p, out.size(), hipMemcpyDeviceToHost));
-        memcpy(probs, out.data(), nProb * 8);
+        if (allowSmall) {
+            memcpy(probs, out.data(), nProb * 8);
+        } else {  // a subset of a larger batch (the frames the fused kernel passed on): only their own blocks come back
+            for (int b = 0; b < B; b++)
+                memcpy(probs + probOff[b], out.data() + (size_t)probOff[b] * 8, (size_t)nM[b] * (nL[b] + 1) * 8);
+        }
         const int32_t *hnf = reinterpret_cast<const int32_t *>(out.data() + probBytes);
         if (nf) memcpy(nf, hnf, (size_t)B * 4);
         // a caller without an nf array (the reference-named shims) must not get all-zero probabilities silently:
