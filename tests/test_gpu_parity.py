@@ -553,8 +553,31 @@ def test_every_launch_shape(monkeypatch, nw, spec):
     choose is pinned here against the oracle, whatever the batch size."""
     monkeypatch.setenv("KBEST_NWAVES", str(nw))
     monkeypatch.setenv("KBEST_SPEC", str(spec))
+    monkeypatch.setenv("KBEST_NO_SMALL", "1")  # (problems of <= 32 rows through this kernel as well)
     e = pk.KBestEngine(0)
     rng = np.random.default_rng(100 + nw)
     for N, M, k, B in ((64, 64, 200, 6), (40, 17, 120, 5), (12, 12, 60, 9)):
         costs = rng.random((B, N * M)) * 25
         _same_as_oracle(e, costs, N, M, k, tag=(nw, spec, N, M))
+
+
+
+@pytest.mark.parametrize("nw", [2, 4, 8, 16])
+def test_every_shape_of_the_small_problem_kernel(monkeypatch, nw):
+    """kbest_small.hip in every workgroup size it can be launched with (2 ... 16 waves = 4 ... 32 half-wave workers),
+    whatever the batch size: square and rectangular (implicit zero columns), +inf entries, cutoff, maximise, k up to
+    its limit -- nf, row4col, gains bit-for-bit, col4row up to the numbering of the padded columns."""
+    monkeypatch.setenv("KBEST_SMALL_NW", str(nw))
+    monkeypatch.setenv("KBEST_FORCE_SMALL", "1")
+    e = pk.KBestEngine(0)
+    rng = np.random.default_rng(500 + nw)
+    for N, M, k, B, mode in ((32, 32, 200, 7, 0), (28, 10, 200, 40, 1), (17, 17, 64, 9, 2), (32, 5, 300, 11, 3),
+                             (9, 9, 1, 5, 0), (20, 1, 30, 4, 1), (31, 30, 1000, 2, 0), (2, 2, 5, 3, 2)):
+        costs = rng.random((B, N * M)) * 12
+        if mode == 1:  # gate structure: sparse finite entries + one finite dummy per column
+            costs[rng.random((B, N * M)) < 0.55] = np.inf
+            for c in range(M):
+                costs[:, c * N + (N - M + c)] = 10.0
+        maximize = mode == 2
+        cutoff = 42.0 if mode == 1 else (3.0 if mode == 3 else None)
+        _same_as_oracle(e, costs, N, M, k, maximize, cutoff, tag=(nw, N, M, k, mode))
