@@ -30,6 +30,7 @@ struct kbest_ctx {
     int ldsPerCU = 160 * 1024;
     int nCU = 256;
     int smallWaves = 0;  // waves per problem of the small-problem kernel; 0 = choose per launch (KBEST_SMALL_NW)
+    int wideSpec = 0;         // KBEST_WIDE_SPEC: hypotheses split per round by the general-size kernel (A/B tests)
     bool exactRoot = false;   // KBEST_EXACT_ROOT: the 64-row kernel's root without the column-reduction start (A/B tests)
     bool noPoll = false;      // KBEST_NO_POLL: zero-copy calls wait for the stream instead of polling the completion counter
     bool forceSmall = false;  // KBEST_FORCE_SMALL: every batch of <= 32-row problems through the small-problem kernel
@@ -255,6 +256,7 @@ int kbest_create(kbest_ctx **out, int device)
     ctx->forceSmall = getenv("KBEST_FORCE_SMALL") != nullptr;
     ctx->noPoll = getenv("KBEST_NO_POLL") != nullptr;
     ctx->exactRoot = getenv("KBEST_EXACT_ROOT") != nullptr;
+    if (const char *e = getenv("KBEST_WIDE_SPEC")) { const int w = atoi(e); if (w >= 1 && w <= 8) ctx->wideSpec = w; }
     if (const char *e = getenv("KBEST_SPEC")) {
         int w = atoi(e);
         if (w >= 1 && w <= 16) ctx->spec = w;
@@ -301,11 +303,13 @@ struct WidePlan {
     long long poolStride, freeStride;
 };
 
-static WidePlan plan_wide(const kbest_ctx *ctx, int B, int maxRow, int maxCol, int k)
+static WidePlan plan_wide(const kbest_ctx *ctx, int B, int maxRow, int maxCol, int k, bool anyCols = false)
 {
     auto up = [](size_t x) { return (x + 127) & ~(size_t)127; };
     WidePlan w;
-    w.statesPerProblem = k + maxCol + 2;
+    // pool + children of one round + slack (anyCols: kbest_reserve does not know numCol -- the largest round over numCol <= maxRow)
+    const int perRound = anyCols ? (maxRow > 160 ? maxRow : (8 * maxRow < 160 ? 8 * maxRow : 160)) : kb::wide_spec(maxCol) * maxCol;
+    w.statesPerProblem = k + perRound + 2;
     w.poolStride = (long long)((k + 1 + 15) & ~15);
     w.freeStride = (long long)((w.statesPerProblem + 31) & ~31);
     w.cw = up((size_t)maxRow * maxRow * 8);
@@ -416,7 +420,7 @@ int kbest_reserve(kbest_ctx *ctx, int B, int maxRow, int k)
         if (rc != KBEST_OK) return rc;
     }
     if (!kFits || maxRow > KBEST_MAX_DIM || getenv("KBEST_FORCE_WIDE"))  // (numCol <= numRow bounds the general-size plan)
-        return reserve_wide(ctx, plan_wide(ctx, B, maxRow, maxRow, k), true);
+        return reserve_wide(ctx, plan_wide(ctx, B, maxRow, maxRow, k, true), true);
     return KBEST_OK;
 }
 
@@ -577,6 +581,9 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         p.ldCol = maxCol;
         p.minRows = runFast ? KBEST_MAX_DIM + 1 : 0;
         p.tile = tile ? 1 : 0;
+        // counting the reference's pushes needs the reference's exact order of splits: no speculation
+        p.spec = (opts->flags & KBEST_FLAG_COUNT_PUSHED) ? 1 : (ctx->wideSpec > 0 ? ctx->wideSpec : kb::wide_spec(maxCol));
+        if (p.spec > kb::wide_spec(maxCol)) p.spec = kb::wide_spec(maxCol);
         p.k = k;
         p.maximize = opts->maximize;
         p.useCutoff = opts->use_cutoff;

@@ -147,6 +147,7 @@ struct WideParams {
     int ldRow, ldCol;         // leading dimensions of the outputs / of the default cost packing
     int minRows;              // problems with fewer rows are left to the LDS kernel (mixed batches); 0 = take all
     int tile;                 // 1: the square cost copy lives in LDS (it fits), Cw is not used
+    int spec;                 // hypotheses split per round (1 = the reference's order of operations exactly), <= 8
     int k;
     int maximize, useCutoff;
     unsigned flags;
@@ -177,18 +178,25 @@ __host__ __device__ inline long long wide_state_stride(int maxRow) { return (24L
 struct WideLds { int offWave, waveStride, offChildG, offChildS, offChildC, offRed, offCtrl, offTile, total; };
 
 // tile: keep the shifted square cost copy in LDS instead of the HBM work space (when maxRow^2 * 8 bytes fit)
+// hypotheses split per round by the general-size kernel.  Measured (kernel ms, 1 / 2 / 4 / 8 per round): 1024 x 100x20
+// 26.4 / 20.8 / 17.4 / 16.0, 256 x 64x64 4.1 / 3.8 / 3.7 / 3.9, 512 x 128x128 18.5 / 18.1 / 18.7 / 20.3, 256 x 256x256
+// 66 / 67 / 71 / 82: with few columns a round is a handful of children and the sweeps' latency dominates (speculation
+// pays); with many columns one split already fills the eight waves and speculative splits are wasted work.
+__host__ __device__ inline int wide_spec(int maxCol) { const int s = 160 / (maxCol > 0 ? maxCol : 1); return s >= 8 ? 8 : (s >= 1 ? s : 1); }
+
 __host__ __device__ inline WideLds wide_lds_layout(int maxRow, int maxCol, bool tile)
 {
     WideLds L;
+    const int nc = wide_spec(maxCol) * maxCol;     // children of one round at most
     int o = 0;
     L.waveStride = (20 * maxRow + 15) & ~15;       // per wave: u (fp64), col4row, row4col, pred (i32)
     L.offWave = o;       o += WIDE_NW * L.waveStride;
-    L.offChildG = o;     o += maxCol * 8;           // surviving children of the sweep: gain, state slot, column
-    L.offChildS = o;     o += maxCol * 4;
-    L.offChildC = o;     o += maxCol * 4;
+    L.offChildG = o;     o += nc * 8;               // surviving children of the round: gain, state slot, (parent, column)
+    L.offChildS = o;     o += nc * 4;
+    L.offChildC = o;     o += nc * 4;
     o = (o + 7) & ~7;
     L.offRed = o;        o += WIDE_NW * 8;
-    L.offCtrl = o;       o += 96;                   // struct WideCtrl
+    L.offCtrl = o;       o += 320;                  // struct WideCtrl
     o = (o + 15) & ~15;
     L.offTile = o;       if (tile) o += maxRow * maxRow * 8;
     L.total = (o + 15) & ~15;

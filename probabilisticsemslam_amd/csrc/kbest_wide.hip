@@ -46,10 +46,16 @@ struct WideCtrl {
     int pushed;
     int nFree;       // free state slots (stack in freeList)
     int nChild;      // children that survived this sweep
-    int nextTicket;  // work queue over the children of the sweep
-    int emitSid;     // state to copy to the output slot `emitted - 1`, or -1
+    int nextTicket;  // work queue over the children of the round
+    int nsel;        // hypotheses split in this round
+    int nEmit;       // pool entries emitted in this round (the first nEmit)
+    int lastSel;     // pool index of the last selected entry: every not yet split entry up to it is selected
+    int selIdx[8], selSid[8], selA[8], selOff[9];  // the selected entries: pool index, state slot, active column, first ticket
+    double selG[8];  //   and gain
 };
-static_assert(sizeof(WideCtrl) <= 96, "WideCtrl must fit the LDS slot reserved by wide_lds_layout");
+static_assert(sizeof(WideCtrl) <= 320, "WideCtrl must fit the LDS slot reserved by wide_lds_layout");
+constexpr int WIDE_SPLIT = 0x40000000;      // pool entry flag: children already generated
+constexpr int WIDE_SID_MASK = 0x3FFFFFFF;
 
 // Shortest augmenting path from column `start`; lane owns rows lane + 64*i.  Same contract as dijkstra<> of
 // kbest_engine.hip (cpp:168-226 / cpp:297-356) with per-lane bit sets: cand bit i = row lane+64i still in
@@ -265,7 +271,6 @@ __global__ void __launch_bounds__(WIDE_NW * 64, (R <= 2 ? 6 : 4)) kbest_wide_ker
                 ctrl->nFree = S - 1;
                 ctrl->nChild = 0;
                 ctrl->nextTicket = 0;
-                ctrl->emitSid = -1;
             }
             __syncthreads();
         }
@@ -316,19 +321,11 @@ __global__ void __launch_bounds__(WIDE_NW * 64, (R <= 2 ? 6 : 4)) kbest_wide_ker
                 const int r0 = uni32(r4cW[0]);
                 const u32 forb = (lane == (r0 & 63)) ? (1u << (r0 >> 6)) : 0u;  // cpp:235
                 store_state(0, v, forb, g, 0);
-                for (int j = lane; j < M; j += 64) p.row4col[outBase * p.ldCol + j] = r4cW[j];
-                if (p.col4row)
-                    for (int j = lane; j < N; j += 64) p.col4row[outBase * p.ldRow + j] = c4rW[j];
-                if (lane == 0) {
-                    ctrl->cutoffGain = maximize ? (g - p.cutoff) : (g + p.cutoff);          // cpp:681/684
-                    const double gu = maximize ? (-g + ctrl->cdelta) : (g + ctrl->cdelta);  // cpp:599-603
-                    ctrl->gain0u = gu;
-                    p.gain[outBase] = gu;
+                if (lane == 0) {  // the pool starts with the root, not yet emitted, not yet split
                     poolG[0] = g;
                     poolS[0] = 0;
                     ctrl->n = 1;
-                    ctrl->emitted = 1;
-                    if (k == 1) ctrl->stop = 1;
+                    ctrl->emitted = 0;
                 }
             }
         }
@@ -338,34 +335,124 @@ __global__ void __launch_bounds__(WIDE_NW * 64, (R <= 2 ? 6 : 4)) kbest_wide_ker
             continue;
         }
 
-        // ---- phase 2: sweeps (cpp:607-634) ----
-        while (uni32(ctrl->stop) == 0) {
+        // ---- phase 2: rounds (kBest2D cpp:607-634 + split cpp:455-532 as a batched frontier) ----
+        // The pool holds the candidates that are NOT yet emitted, sorted by gain; an entry = (gain, state slot | SPLIT).
+        // Per round the first `spec` not-yet-split entries are split together (speculatively, except the minimum): the
+        // pool always holds a partition of the not yet emitted assignments, so the emitted sequence is the reference's
+        // (point 5).  With spec = 1 this is the reference's order of operations exactly (that mode
+        // counts its pushes).  The head goes out while it has been split; the first entry that has not been split is
+        // split in this round: it is emitted too, but ends the run (its children are not in the pool yet).
+        const int spec = p.spec;
+        for (int round = 0;; round++) {
             const int cur = uni32(ctrl->cur), n = uni32(ctrl->n), emitted = uni32(ctrl->emitted);
             const double *srcG = poolG + (long long)cur * p.poolStride;
             const int *srcS = poolS + (long long)cur * p.poolStride;
             double *dstG = poolG + (long long)(1 - cur) * p.poolStride;
             int *dstS = poolS + (long long)(1 - cur) * p.poolStride;
-            const int ps = uni32(srcS[0]);  // the hypothesis to split: the minimum, emitted in the previous sweep
-            const double pgain = srcG[0];
-            const int nOld = n - 1, Rk = k - emitted;  // Rk: candidates that can still be output
-            double T = (nOld >= Rk) ? srcG[Rk] : INF;   // the Rk-th best of the others
+            // -- select + emission bookkeeping (wave 0)
+            if (wave == 0) {
+                int cnt = 0, firstU = -1;
+                for (int base = 0; base < n && cnt < spec; base += 64) {
+                    const int i = base + lane;
+                    const bool open = i < n && !(srcS[i] & WIDE_SPLIT);
+                    const u64 m = __ballot(open);
+                    if (m) {
+                        const int rank = cnt + __popcll(m & ((1ull << lane) - 1ull));
+                        if (firstU < 0) firstU = base + __builtin_ctzll(m);
+                        if (open && rank < spec) ctrl->selIdx[rank] = i;
+                        cnt += __popcll(m);
+                    }
+                }
+                const int nsel = cnt < spec ? cnt : spec;
+                int run = (nsel > 0) ? firstU + 1 : n;
+                if (run > k - emitted) run = k - emitted;
+                if (round == 0 && lane == 0) {
+                    const double g0 = srcG[0];
+                    ctrl->cutoffGain = maximize ? (g0 - p.cutoff) : (g0 + p.cutoff);          // cpp:681/684
+                    ctrl->gain0u = maximize ? (-g0 + ctrl->cdelta) : (g0 + ctrl->cdelta);    // cpp:599-603
+                }
+                wave_fence();
+                const double gain0u = ctrl->gain0u;
+                bool cutStop = false;
+                int nEmit = run;
+                if (useCut) {  // cpp:709-719: the first slot beyond gainBest[0] +- cutoff is written, not counted, and ends the call
+                    for (int base = 0; base < run && !cutStop; base += 64) {
+                        const int j = base + lane;
+                        bool beyond = false;
+                        if (j < run) {
+                            const double g = srcG[j];
+                            const double gu = maximize ? (-g + ctrl->cdelta) : (g + ctrl->cdelta);
+                            beyond = maximize ? (gu < gain0u - p.cutoff) : (gu > gain0u + p.cutoff);
+                        }
+                        const u64 m = __ballot(beyond);
+                        if (m) { cutStop = true; nEmit = base + __builtin_ctzll(m); }
+                    }
+                }
+                for (int j = lane; j < nEmit + (cutStop ? 1 : 0); j += 64)
+                    if (emitted + j < k) {
+                        const double g = srcG[j];
+                        p.gain[outBase + emitted + j] = maximize ? (-g + ctrl->cdelta) : (g + ctrl->cdelta);  // cpp:626-630
+                    }
+                wave_fence();
+                if (lane < nsel) {  // the nodes of this round: state slot, gain, active column
+                    const int idx = ctrl->selIdx[lane];
+                    const int sid = srcS[idx] & WIDE_SID_MASK;
+                    ctrl->selSid[lane] = sid;
+                    ctrl->selG[lane] = srcG[idx];
+                    ctrl->selA[lane] = *reinterpret_cast<const int *>(stBase + (long long)sid * p.stateStride + offTail + 8);
+                }
+                wave_fence();
+                if (lane == 0) {
+                    int off = 0;
+                    for (int s2 = 0; s2 < nsel; s2++) { ctrl->selOff[s2] = off; off += M - ctrl->selA[s2]; }
+                    ctrl->selOff[nsel] = off;
+                    ctrl->nsel = nsel;
+                    ctrl->nEmit = nEmit;
+                    ctrl->lastSel = nsel > 0 ? ctrl->selIdx[nsel - 1] : -1;
+                    if (cutStop || emitted + nEmit >= k || nsel == 0) ctrl->stop = 1;
+                }
+            }
+            __syncthreads();
+            const int nsel = uni32(ctrl->nsel), nEmit = uni32(ctrl->nEmit), lastSel = uni32(ctrl->lastSel);
+            // -- outputs of the hypotheses emitted in this round (cpp:618-630): from their saved states
+            for (int idx = tid; idx < nEmit * (N + M); idx += NT) {
+                const int j = idx / (N + M), q = idx - j * (N + M);
+                const unsigned char *E = stBase + (long long)(srcS[j] & WIDE_SID_MASK) * p.stateStride;
+                if (q < M) p.row4col[(outBase + emitted + j) * p.ldCol + q] = reinterpret_cast<const int *>(E + offR4C)[q];
+                else if (p.col4row) p.col4row[(outBase + emitted + j) * p.ldRow + (q - M)] = reinterpret_cast<const int *>(E + offC4R)[q - M];
+            }
+            if (uni32(ctrl->stop) != 0) {
+                __syncthreads();
+                if (tid == 0 && ctrl->stop == 1) ctrl->emitted = emitted + nEmit;
+                break;
+            }
+            const int eNew = emitted + nEmit;
+            const int nOld = n - nEmit, Rk = k - eNew;  // Rk: candidates that can still be output
+            double T = (nOld >= Rk) ? srcG[nEmit + Rk - 1] : INF;
             const double cutG = ctrl->cutoffGain;
             if (useCut && !maximize && cutG < T) T = cutG;
-            const double bound = (prune && T < INF) ? (T - pgain) + 1e-9 * (fabs(T) + ctrl->cmax) : INF;
-            const unsigned char *P = stBase + (long long)ps * p.stateStride;
-            const double *Pu = reinterpret_cast<const double *>(P), *Pv = reinterpret_cast<const double *>(P + offV);
-            const int *Pr4c = reinterpret_cast<const int *>(P + offR4C), *Pc4r = reinterpret_cast<const int *>(P + offC4R);
-            const u32 pforb = reinterpret_cast<const u32 *>(P + offForb)[lane];
-            const int a = uni32(*reinterpret_cast<const int *>(P + offTail + 8));
+            const double cmaxv = ctrl->cmax;
+            const int totalItems = uni32(ctrl->selOff[nsel]);
 
-            // -- children of the popped hypothesis (split, cpp:455-532), one wave each, dynamic queue
+            // -- children of the selected hypotheses (split, cpp:455-532), one wave each, dynamic queue over (node, column)
             int npush = 0;
             for (;;) {
                 int t = 0;
                 if (lane == 0) t = atomicAdd(&ctrl->nextTicket, 1);
-                const int c = a + uni32(t);
-                if (c >= M) break;
-                if (emitted == 1 && p.rootColStride > 1 && (c % p.rootColStride) != p.rootColOffset) continue;  // root: first sweep
+                t = uni32(t);
+                if (t >= totalItems) break;
+                int s2 = 0;
+                while (s2 + 1 < nsel && t >= ctrl->selOff[s2 + 1]) s2++;
+                s2 = uni32(s2);
+                const int a = uni32(ctrl->selA[s2]), ps = uni32(ctrl->selSid[s2]);
+                const int c = a + (t - uni32(ctrl->selOff[s2]));
+                if (round == 0 && p.rootColStride > 1 && (c % p.rootColStride) != p.rootColOffset) continue;  // the root's children
+                const double pgain = ctrl->selG[s2];
+                const double bound = (prune && T < INF) ? (T - pgain) + 1e-9 * (fabs(T) + cmaxv) : INF;
+                const unsigned char *P = stBase + (long long)ps * p.stateStride;
+                const double *Pu = reinterpret_cast<const double *>(P), *Pv = reinterpret_cast<const double *>(P + offV);
+                const int *Pr4c = reinterpret_cast<const int *>(P + offR4C), *Pc4r = reinterpret_cast<const int *>(P + offC4R);
+                const u32 pforb = reinterpret_cast<const u32 *>(P + offForb)[lane];
                 double v[R], spc[R];
                 int pred[R];
                 u32 cand = 0;
@@ -403,7 +490,7 @@ __global__ void __launch_bounds__(WIDE_NW * 64, (R <= 2 ? 6 : 4)) kbest_wide_ker
                     if (idx >= 0) sid = freeList[idx];
                 }
                 sid = uni32(sid);
-                if (sid < 0) {  // cannot happen: S = k + maxCol + 2 covers pool + children + parent
+                if (sid < 0) {  // cannot happen: S = k + spec * maxCol + 2 covers pool + children of a round
                     if (lane == 0) ctrl->stop = 2;
                     break;
                 }
@@ -414,22 +501,25 @@ __global__ void __launch_bounds__(WIDE_NW * 64, (R <= 2 ? 6 : 4)) kbest_wide_ker
                     const int pos = atomicAdd(&ctrl->nChild, 1);
                     childG[pos] = g;
                     childS[pos] = sid;
-                    childC[pos] = c;
+                    childC[pos] = (ps << 10) | c;  // (parent, column): the order of exact ties
                 }
             }
             if ((p.flags & KBEST_FLAG_COUNT_PUSHED) && lane == 0 && npush) atomicAdd(&ctrl->pushed, npush);
             __syncthreads();
             if (uni32(ctrl->stop) != 0) break;
 
-            // -- merge: the old entries (without the popped head) and the children, sorted, first Rk kept
+            // -- merge: the old entries that were not emitted and the children, sorted, first Rk kept; the entries selected
+            //    in this round are split now; the states of the emitted ones (all of them split by now) are released
             const int nChild = uni32(ctrl->nChild);
+            for (int j = tid; j < nEmit; j += NT) freeList[atomicAdd(&ctrl->nFree, 1)] = srcS[j] & WIDE_SID_MASK;
             for (int i = tid; i < nOld; i += NT) {
-                const double g = srcG[1 + i];
-                const int s = srcS[1 + i];
+                const int j = nEmit + i;
+                const double g = srcG[j];
+                const int s2 = srcS[j] | ((j <= lastSel) ? WIDE_SPLIT : 0);
                 int pos = i;
-                for (int j = 0; j < nChild; j++) pos += (childG[j] < g) ? 1 : 0;
-                if (pos < Rk) { dstG[pos] = g; dstS[pos] = s; }
-                else freeList[atomicAdd(&ctrl->nFree, 1)] = s;
+                for (int q = 0; q < nChild; q++) pos += (childG[q] < g) ? 1 : 0;
+                if (pos < Rk) { dstG[pos] = g; dstS[pos] = s2; }
+                else freeList[atomicAdd(&ctrl->nFree, 1)] = s2 & WIDE_SID_MASK;
             }
             for (int j = tid; j < nChild; j += NT) {
                 const double g = childG[j];
@@ -437,7 +527,7 @@ __global__ void __launch_bounds__(WIDE_NW * 64, (R <= 2 ? 6 : 4)) kbest_wide_ker
                 int lo = 0, hi = nOld;
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1;
-                    if (srcG[1 + mid] <= g) lo = mid + 1; else hi = mid;
+                    if (srcG[nEmit + mid] <= g) lo = mid + 1; else hi = mid;
                 }
                 int pos = lo;
                 for (int j2 = 0; j2 < nChild; j2++) {
@@ -449,41 +539,15 @@ __global__ void __launch_bounds__(WIDE_NW * 64, (R <= 2 ? 6 : 4)) kbest_wide_ker
             }
             __syncthreads();
             if (tid == 0) {
-                freeList[ctrl->nFree++] = ps;  // the split hypothesis is done
                 int nNew = nOld + nChild;
                 if (nNew > Rk) nNew = Rk;
-                int e = emitted, stop = 0, emitSid = -1;
-                if (nNew == 0) {
-                    stop = 1;  // queue empty: cpp:631-633
-                } else {
-                    const double g = dstG[0];
-                    const double gu = maximize ? (-g + ctrl->cdelta) : (g + ctrl->cdelta);  // cpp:626-630
-                    p.gain[outBase + e] = gu;
-                    if (useCut && (maximize ? (gu < ctrl->gain0u - p.cutoff) : (gu > ctrl->gain0u + p.cutoff))) {
-                        stop = 1;  // cpp:709-719: slot written, not counted
-                    } else {
-                        emitSid = dstS[0];
-                        e++;
-                        if (e >= k) stop = 1;
-                    }
-                }
-                ctrl->emitted = e;
-                ctrl->emitSid = emitSid;
+                ctrl->emitted = eNew;
                 ctrl->n = nNew;
                 ctrl->cur = 1 - cur;
                 ctrl->nChild = 0;
                 ctrl->nextTicket = 0;
-                if (stop) ctrl->stop = 1;
             }
             __syncthreads();
-            const int es = uni32(ctrl->emitSid);
-            if (es >= 0) {  // the new minimum goes to output slot `emitted` (cpp:618-630)
-                const unsigned char *E = stBase + (long long)es * p.stateStride;
-                const int *Er4c = reinterpret_cast<const int *>(E + offR4C), *Ec4r = reinterpret_cast<const int *>(E + offC4R);
-                for (int j = tid; j < M; j += NT) p.row4col[(outBase + emitted) * p.ldCol + j] = Er4c[j];
-                if (p.col4row)
-                    for (int j = tid; j < N; j += NT) p.col4row[(outBase + emitted) * p.ldRow + j] = Ec4r[j];
-            }
         }
         __syncthreads();
         if (tid == 0) {
