@@ -573,7 +573,8 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                     am = better ? r0 + i : am;
                 }
             }
-            const bool can = lane < D && m < INF;
+            // (only the REAL columns take part: the zero-padded ones are dealt with after the loop below)
+            const bool can = lane < M && m < INF;
             if (can) atomicMin(&owner[am], lane);
             wave_fence();
             if (lane < D) nd.u[lane] = can ? m : 0.0;
@@ -581,7 +582,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             const int ow = owner[lane];
             c4r = (lane < D && ow < 64) ? ow : -1;
             wave_fence();
-            todo &= __ballot(lane < D && r4c < 0);
+            todo &= __ballot(lane < M && r4c < 0);
         }
         while (todo) {
             const int c = __builtin_ctzll(todo);
@@ -589,6 +590,22 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             if (dijkstra<false>(Cs, LDC, nd.u, rl, lane, v, c4r, allRows, 0ull, c, INF, spc, pred, scanned, delta,
                                 sink)) { bad = true; break; }
             dual_update_flip(nd.u, lane, v, c4r, r4c, spc, pred, scanned, delta, sink, c);
+        }
+        if (!bad && !rect && !(p.flags & KBEST_FLAG_EXACT_ROOT) && M < D) {
+            // The zero-padded columns (cpp:582-585).  With the real columns assigned, every row that is still free has
+            // v = 0 (only scanned rows ever change v, and a scanned free row is the sink: unchanged) and every other row
+            // v <= 0, so "padded column M + j <- the j-th free row, u = 0" is tight on the assigned arcs and leaves every
+            // reduced cost 0 - 0 - v[r] >= 0: an optimal solution of the padded square problem without the N - M
+            // augmentations over tied zero columns that the reference's root spends most of its steps on (334 of them on
+            // a 28 x 10 frame).  Which padded column a free row sits on is immaterial.
+            const u64 freeRows = __ballot(lane < D && c4r < 0);
+            if (lane < D && c4r < 0) c4r = M + __popcll(freeRows & ((1ull << lane) - 1ull));
+            int *slot = reinterpret_cast<int *>(gainW);  // row of each padded column, through LDS
+            wave_fence();
+            if (lane < D && c4r >= M) slot[c4r - M] = lane;
+            wave_fence();
+            if (lane >= M && lane < D) { r4c = slot[lane - M]; nd.u[lane] = 0.0; }
+            wave_fence();
         }
         if (bad) {
             if (lane == 0) ctrl->stop = 3;
