@@ -304,7 +304,15 @@ __global__ void __launch_bounds__(WIDE_NW * 64, (R <= 2 ? 6 : 4)) kbest_wide_ker
             }
             wave_fence();
             bool bad = false;
-            for (int c = 0; c < D; c++) {
+            // The REAL columns by shortest augmenting paths (cpp:139-230); the zero-padded ones (cpp:582-585) are filled
+            // directly afterwards: every row that is still free has v = 0 (only scanned rows change v, a scanned free row
+            // is the sink: unchanged), every other row v <= 0, so "padded column M + j <- the j-th free row, u = 0" is tight
+            // on the assigned arcs and leaves every reduced cost 0 - 0 - v[r] >= 0 -- an optimal solution of the padded
+            // problem without the N - M augmentations over tied zero columns (about N^2 / 2 Dijkstra steps on a map of
+            // 100 landmarks x 20 measurements).  Which padded column a free row sits on is immaterial (SURVEY 8(a)
+            // quirk 6); the duals are another optimal pair than the reference's, which no output depends on.
+            const int nAug = (p.flags & KBEST_FLAG_EXACT_ROOT) ? D : M;
+            for (int c = 0; c < nAug; c++) {
                 u32 scanned;
                 double delta;
                 int sink = 0;
@@ -313,6 +321,22 @@ __global__ void __launch_bounds__(WIDE_NW * 64, (R <= 2 ? 6 : 4)) kbest_wide_ker
                     break;
                 }
                 wide_update<R>(uW, c4rW, r4cW, predW, lane, v, spc, pred, scanned, delta, sink, c, D);
+            }
+            if (!bad && nAug < D) {
+                int before = 0;
+#pragma unroll
+                for (int i = 0; i < R; i++) {
+                    const int r = lane + 64 * i;
+                    const bool fre = r < D && c4rW[r] < 0;
+                    const u64 m = __ballot(fre);
+                    if (fre) {
+                        const int j = before + __popcll(m & ((1ull << lane) - 1ull));
+                        c4rW[r] = M + j;
+                        r4cW[M + j] = r;
+                    }
+                    before += __popcll(m);
+                }
+                wave_fence();
             }
             if (bad) {
                 if (lane == 0) ctrl->stop = 3;
