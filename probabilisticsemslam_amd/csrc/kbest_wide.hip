@@ -65,8 +65,13 @@ template <int R, bool EARLY>
 __device__ __forceinline__ int wide_dijkstra(const double *Cw, int D, const double *uW, const int *c4rW, int lane,
                                              const double (&v)[R], u32 cand, u32 forb, int start, double bound,
                                              double (&spc)[R], int (&pred)[R], u32 &scannedOut, double &deltaOut,
-                                             int &sinkOut)
+                                             int &sinkOut, int M = 0x7fffffff)
 {
+    // M < D (children of a rectangular problem): rows on the zero-padded columns M .. D-1 ("parked") all carry the same
+    // dual, and so do those columns, in every dual-feasible solution -- once the search has settled ONE parked row at
+    // distance d every other parked row is at distance d too and scanning their columns changes nothing (kbest_small.hip,
+    // file header).  So when the first parked row is settled, all of them are: one step instead of one per parked row.
+    bool parkedOpen = true;
     const double INF = d_inf();
 #pragma unroll
     for (int i = 0; i < R; i++) { spc[i] = INF; pred[i] = 0; }
@@ -111,6 +116,19 @@ __device__ __forceinline__ int wide_dijkstra(const double *Cw, int D, const doub
         act = cand;
         const int cc = uni32(c4rW[closest]);
         if (cc < 0) { sinkOut = closest; break; }
+        if (cc >= M && parkedOpen) {
+            parkedOpen = false;
+#pragma unroll
+            for (int i = 0; i < R; i++) {
+                if (((cand >> i) & 1u) && c4rW[lane + 64 * i] >= M) {
+                    spc[i] = delta;  // (what the relaxation through column cc gives them: equal duals, zero costs)
+                    pred[i] = cc;
+                    cand &= ~(1u << i);
+                    scanned |= 1u << i;
+                }
+            }
+            act = cand;
+        }
         cur = cc;
     }
     scannedOut = scanned;
@@ -502,7 +520,8 @@ __global__ void __launch_bounds__(WIDE_NW * 64, (R <= 2 ? 6 : 4)) kbest_wide_ker
                 u32 scanned;
                 double delta;
                 int sink = 0;
-                if (wide_dijkstra<R, true>(Cw, D, uW, c4rW, lane, v, cand, forbm, c, bound, spc, pred, scanned, delta, sink))
+                if (wide_dijkstra<R, true>(Cw, D, uW, c4rW, lane, v, cand, forbm, c, bound, spc, pred, scanned, delta, sink,
+                                           (p.flags & KBEST_FLAG_EXACT_ROOT) ? 0x7fffffff : M))
                     continue;
                 wide_update<R>(uW, c4rW, r4cW, predW, lane, v, spc, pred, scanned, delta, sink, c, D);
                 const double g = wide_gain<R>(Cw, D, M, r4cW, lane);
