@@ -73,8 +73,14 @@ template <bool EARLY>
 __device__ __forceinline__ int dijkstra(const double *Cs, int LDC, const double *u, int rl, int lane,
                                         double v, int c4r, u64 cand, u64 forb, int start, double bound,
                                         double &spc, int &pred, u64 &scannedOut, double &deltaOut,
-                                        int &sinkOut, double minIn = 0.0, int sinkRow = 0)
+                                        int &sinkOut, double minIn = 0.0, int sinkRow = 0, int parkFrom = 64)
 {
+    // parkFrom < 64 (children of a rectangular problem): rows on the zero-padded columns parkFrom .. D-1 ("parked") all
+    // carry the same dual, and so do those columns, in every dual-feasible solution -- once the search has settled ONE
+    // parked row at distance d every other parked row is at distance d too and scanning their columns changes nothing
+    // (kbest_small.hip, file header).  The loop leaves when the chosen row's column is >= parkThr; the first time all
+    // parked rows are settled with it, then parkThr is lifted.
+    int parkThr = __builtin_amdgcn_readfirstlane(parkFrom);
     cand = uni64(cand);
     u64 act = cand & ~uni64(forb);
     const u64 cand0 = cand;
@@ -163,6 +169,8 @@ __device__ __forceinline__ int dijkstra(const double *Cs, int LDC, const double 
             "s_bitset0_b64 s[84:85], s83\n\t"
             "s_mov_b64 s[86:87], s[84:85]\n\t"
             "s_andn2_b32 s94, s94, s82\n\t"
+            "s_sub_i32 s97, s82, s96\n\t"
+            "s_and_b32 s94, s94, s97\n\t"
             "s_cmp_lt_i32 s94, 0\n\t"
             "s_cbranch_scc1 L_step%=\n\t"
             "s_mov_b32 s95, 0\n\t"
@@ -179,8 +187,8 @@ __device__ __forceinline__ int dijkstra(const double *Cs, int LDC, const double 
             : "+{s[80:81]}"(dbits), "+{s82}"(cur), "+{s[84:85]}"(cand), "+{s[86:87]}"(act), "+{v[60:61]}"(sp),
               "+{v62}"(pred), "={v63}"(khi), "={s83}"(closest), "={s[88:89]}"(eq), "={s95}"(status)
             : "{v56}"(rowAddr), "{v57}"(c4r), "{v[58:59]}"(v), "{v74}"(keyInf), "{s91}"(ldc8), "{s92}"(uBase),
-              "{s93}"(bndHi)
-            : "v64", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v75", "s76", "s77", "s94", "vcc", "scc",
+              "{s93}"(bndHi), "{s96}"(parkThr)
+            : "v64", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v75", "s76", "s77", "s94", "s97", "vcc", "scc",
               "memory");
         // (the compiler does not know that outputs bound to physical scalar registers are wave-uniform)
         dbits = uni64(dbits);
@@ -215,7 +223,7 @@ __device__ __forceinline__ int dijkstra(const double *Cs, int LDC, const double 
             cand &= ~(1ull << closest);
             act = cand;
             cur = __builtin_amdgcn_readlane(c4r, closest);
-            if (((mhi - bndHi) & ~cur) < 0) continue;  // not a sink, below the bound: next step
+            if (((mhi - bndHi) & ~cur & (cur - parkThr)) < 0) continue;  // not a sink, not parked, below the bound: next step
         }
         if (__builtin_expect(mhi >= bndHi, 0)) {
             const double delta = __longlong_as_double((long long)dbits);
@@ -230,6 +238,14 @@ __device__ __forceinline__ int dijkstra(const double *Cs, int LDC, const double 
             }
         }
         if (cur < 0) break;
+        if (cur >= parkThr) {  // the first parked row is settled: so are all of them, at this distance
+            const u64 pk = __ballot(c4r >= parkThr) & cand;
+            sp = __hiloint2double(sel32(pk, (int)(u32)(dbits >> 32), __double2hiint(sp)), sel32(pk, (int)(u32)dbits, __double2loint(sp)));
+            pred = sel32(pk, cur, pred);
+            cand &= ~pk;
+            act = cand;
+            parkThr = 64;
+        }
     }
     sinkOut = closest;
     spc = sp;
@@ -430,6 +446,8 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     const bool rect = (p.flags & KBEST_FLAG_RECT_ROOT) != 0;
     const bool noShift = (p.flags & KBEST_FLAG_NO_SHIFT) != 0;
     const int gainCols = (p.gainCols > 0 && p.gainCols < M) ? p.gainCols : M;  // numCol4Gain (cpp:232)
+    // rows on the zero-padded columns M .. D-1 are settled together in a child's search (dijkstra<>); 64 = never
+    const int parkFrom = (!rect && !(p.flags & KBEST_FLAG_EXACT_ROOT) && M < N) ? M : 64;
     const int rl = lane < D ? lane : D - 1;
     const u64 allRows = (D >= 64) ? ~0ull : ((1ull << D) - 1ull);
     const int maxSid = p.statesPerProblem;
@@ -863,7 +881,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 KB_T(tDij0);
                 KB_ACC(9, tDij0 - tItem);  // [9] per-child set-up cycles
                 const int st = dijkstra<true>(Cs, LDC, nd.u, rl, lane, v, c4r, cand, forbm, c, bound, spc, pred,
-                                              scanned, delta, sink, minIn, fr);
+                                              scanned, delta, sink, minIn, fr, parkFrom);
                 KB_T(tDij1);
                 KB_ACC(8, tDij1 - tDij0);  // [8] cycles inside child Dijkstra
                 KB_ACC(5, __popcll(scanned) + (st != 0));  // [5] child Dijkstra steps (approx: scanned rows)
@@ -1116,7 +1134,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 int pred, sink = 0;
                 u64 scanned;
                 const int rc = dijkstra<false>(Cs, LDC, nd.u, rl, lane, v, c4r, cand, forbm, col, INF, spc, pred, scanned,
-                                               delta, sink);
+                                               delta, sink, 0.0, 0, parkFrom);
                 if (rc == 0) dual_update_flip(nd.u, lane, v, c4r, r4c, spc, pred, scanned, delta, sink, col);
                 const double g = serial_gain(Cs, LDC, lane, r4c, M, gainW);
                 const u64 forbN = forbm | bit64(__builtin_amdgcn_readlane(r4c, col));  // cpp:362
