@@ -749,7 +749,42 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
         double v = 0.0, un = 0.0;
         int c4r = -1, r4c = -1;
         bool bad = false;
-        for (int c = 0; c < M; c++) {
+        // Column reduction first (Jonker-Volgenant's initialisation, as in kbest_engine.hip): u[c] = min of column c, a row
+        // that is the arg-min of some column goes to the lowest such column; reduced costs stay >= 0, assigned arcs are
+        // tight.  The augmentations below then start only from the columns left over.
+        u32 todo = (M >= 32) ? 0xffffffffu : ((1u << M) - 1u);
+        {
+            int *owner = reinterpret_cast<int *>(gainW);
+            if (half == 0) owner[l] = 64;
+            wave_fence();
+            const int cc = l < M ? l : M - 1;
+            const double *Ccol = Cs + cc * LDC;
+            double m = INF;
+            int am = 0;
+            for (int r0 = 0; r0 < N; r0 += 4) {
+                double x[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) x[i] = Ccol[r0 + i];  // (rows N .. 31 of the tile hold +inf)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const bool better = x[i] < m;  // strict '<': the lowest row among equal minima
+                    m = better ? x[i] : m;
+                    am = better ? r0 + i : am;
+                }
+            }
+            const bool can = half == 0 && l < M && m < INF;
+            if (can) atomicMin(&owner[am], l);
+            wave_fence();
+            if (half == 0) uArr[l] = can ? m : 0.0;
+            r4c = (can && owner[am] == l) ? am : -1;
+            const int ow = (half == 0) ? owner[l] : 64;
+            c4r = (half == 0 && l < N && ow < 64) ? ow : -1;
+            wave_fence();
+            todo &= (u32)__ballot(half == 0 && l < M && r4c < 0);
+        }
+        while (todo) {
+            const int c = __builtin_ctz(todo);
+            todo &= todo - 1;
             double sp, delta;
             int pred, sink, hubRow, status;
             u64 scanned;
@@ -762,6 +797,7 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
             if (half == 0 && l < M) uArr[l] = un;
             wave_fence();
         }
+        un = uArr[l];
         if (bad) {
             if (lane == 0) ctrl->status = 3;
         } else {
