@@ -7,27 +7,31 @@
 // 64-row kernel of kbest_engine.hip leaves half of every wavefront idle and pays five workgroup barriers per round.
 // This kernel is organised around them instead:
 //
-//   * half-wave workers: a wavefront is two independent 32-lane workers (lane = row).  The Dijkstra step of
-//     shortestPathUpdateCPP (cpp:307-325) runs for two children at once: DPP min-reductions stop at 32 lanes, the
-//     row sets of both children share one 64-bit scalar mask (low / high word), per-child scalars are lane values
-//     that are uniform within a half;
+//   * half-wave workers: a wavefront is two independent 32-lane workers (lane & 31 = row).  The Dijkstra step of
+//     shortestPathUpdateCPP (cpp:307-325) runs for two children at once in a hand-written loop (dijkstra2): the DPP
+//     min-reductions stop at 32 lanes, the row sets of both children share one 64-bit scalar mask (low / high word),
+//     everything that is uniform within a half (column, distance, chosen row, bound) lives in scalar registers;
 //   * implicit zero columns: the reference pads an N x M problem to N x N with zero columns (cpp:582-585) so that
 //     inherited duals stay valid when a child frees a row.  Dual feasibility forces every row on a padded column
 //     ("parked") to carry the same v, and all padded columns the same u = -v: once the search has settled ONE parked
 //     row at distance d, every other parked row is at distance d too and scanning their columns changes nothing.
 //     The kernel therefore keeps the padded columns implicit -- when the first parked row is settled all parked rows
-//     are settled with it and one "hub" relaxation (d + v_parked - v[r], no cost column to read) stands for all their
-//     columns.  The root is solved on the rectangular problem (M augmentations instead of N: the reference's root
-//     needs ~N^2/2 Dijkstra steps on a 28 x 10 frame because of the ties on the zero columns), children take 3-4
-//     steps instead of ~10.  In exact arithmetic this is the same shortest-path computation; the assignments,
-//     their order and the gains -- re-summed in the reference's column order from the cost matrix (calcGain,
-//     cpp:59-80) -- are identical; only the internal dual variables differ in the last bits, and col4row numbers the
-//     parked rows M, M+1, ... in ascending row order (values >= M are "padded", not compared);
-//   * owner rounds, two barriers: per round every worker takes one not-yet-split candidate of the sorted pool
-//     (found by ballot walks, redundantly per wave -- no control block to wait for), brings its saved hypothesis in,
-//     filters its children by their first-step minimum, solves the survivors, and appends them to the fresh list;
-//     barrier; rank merge into the other pool buffer; barrier.  Emission bookkeeping is recomputed by every wave
-//     from the pool order, so nothing serial sits between the merge and the next split;
+//     are settled with it and ONE relaxation through an all-zero tile column (index maxCol; its dual, -v of the parked
+//     rows, sits in a private slot of the worker) stands for all their columns.  The root is solved on the rectangular
+//     problem (M augmentations instead of N: the reference's root needs ~N^2/2 Dijkstra steps on a 28 x 10 frame
+//     because of the ties on the zero columns), children take 3-4 steps instead of ~10.  In exact arithmetic this is
+//     the same shortest-path computation; the assignments, their order and the gains -- re-summed in the reference's
+//     column order from the cost matrix (calcGain, cpp:59-80) -- are identical; only the internal dual variables
+//     differ in the last bits, and col4row numbers the parked rows M, M+1, ... in ascending row order (SURVEY 8(a)
+//     quirk 6: values >= M are "padded", not compared);
+//   * rounds with three barriers and no control block: per round every worker takes one not-yet-split candidate of
+//     the sorted pool (found by ballot walks, redundantly per wave), brings its saved hypothesis into its LDS node
+//     block and filters its children by their first-step minimum (on square problems also by the last-arc bound);
+//     barrier; all waves draw the surviving children in pairs from one list (one child per half; the parent is
+//     whichever node block the entry names), solve them, keep the completed ones in full and append them to the fresh
+//     list; barrier; rank merge of the old pool and the fresh list into the other pool buffer; barrier.  Emission
+//     bookkeeping is recomputed by every wave from the pool order, so nothing serial sits between the merge and the
+//     next split;
 //   * all completed children are kept in full (no lazy re-solve): hypothesis states live in HBM slots drawn from an
 //     LDS free list, slots of candidates that drop out of the pool are recycled, so 2k + (children of one round)
 //     slots are enough;
