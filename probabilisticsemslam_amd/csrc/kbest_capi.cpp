@@ -1176,6 +1176,7 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
     w.nLout = dNL.as<int>();
     w.maxRow = rawMaxRow;
     w.gate = bruteForce ? 0 : 1;
+    w.solveRows = maxRow;
     {
         std::lock_guard<std::mutex> lock(ctx->mu);
         hipError_t e = kb::launch_weights(w, B, ctx->stream);

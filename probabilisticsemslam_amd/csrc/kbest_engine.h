@@ -70,6 +70,9 @@ struct WeightParams {
     const int *nLout;         // [B] landmarks in the output numbering (with rowIdx)
     int maxRow;
     int gate;                 // 1: assignmentProb (skip solutions beyond best + 42, :622-626); 0: bruteForceProb (:918-923)
+    int solveRows;            // rows of the largest solved problem (bounds nL + 1: sizes the LDS accumulator)
+    int chunk, ldsAcc;        // set by launch_weights: solutions per LDS chunk; 1: the [nM][nL+1] table accumulates in LDS
+    long long accBytes;
 };
 
 // Bytes of one saved hypothesis: u[D] v[D] (fp64), row4col[D] col4row[D] (u8),

@@ -41,6 +41,7 @@
 // Compiled WITHOUT fast-math: ((delta + C) - u) - v must not be reassociated.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdlib>
 
@@ -1230,21 +1231,23 @@ __global__ void __launch_bounds__(64) condition_kernel(CondParams p)
 // With rowIdx != nullptr the problem was conditioned first and the result is
 // scattered back to the original landmark numbering (getAssignmentProbs,
 // assignment.cpp:68-74): output row stride nLout[b] + 1.
-__global__ void __launch_bounds__(64) weights_kernel(WeightParams p)
+__global__ void __launch_bounds__(256) weights_kernel(WeightParams p)
 {
-    const int b = blockIdx.x, lane = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
+    constexpr int NT = 256;
+    const int b = blockIdx.x, tid = threadIdx.x;
     const int nL = p.nL[b], nM = p.nM[b];
     const int nLo = p.rowIdx ? p.nLout[b] : nL;  // landmarks in the output numbering
     const int *ridx = p.rowIdx ? p.rowIdx + (long long)b * p.maxRow : nullptr;
     double *probs = p.probs + p.probOff[b];
     const double GATE = 42.0;  // assignment.cpp:9
-    for (int i = lane; i < nM * (nLo + 1); i += 64) probs[i] = 0.0;
+    for (int i = tid; i < nM * (nLo + 1); i += NT) probs[i] = 0.0;
     __syncthreads();
     if (nL < 0) return;  // fewer kept rows than measurements: undefined in the reference (size_t underflow, :60)
     if (nM > 1 && p.nf[b] < 0) return;  // the conditioned matrix did not fit the solver: probabilities stay 0, nf < 0
     if (nM == 1) {
         const double *cost = p.cost + p.costOff[b];
-        if (lane == 0) {
+        if (tid == 0) {
             double norm = 0.0;
             for (int i = 0; i <= nL; i++)
                 if (cost[i] < GATE) norm += exp(-cost[i]);
@@ -1260,20 +1263,55 @@ __global__ void __launch_bounds__(64) weights_kernel(WeightParams p)
     const double *gain = p.gain + (long long)b * p.k;
     const int *r4c = p.row4col + (long long)b * p.k * p.maxCol;
     const double best = gain[0];
+    // The sums run in the reference's order -- solutions ascending, `total` and every probs[col][row] sequentially -- but
+    // everything around them is parallel: per chunk of solutions the weights exp(best - g) are computed by all threads,
+    // the chunk's row maps come into LDS in one coalesced pass, then thread = column walks the chunk (LDS reads only),
+    // accumulating in LDS when the [nM][nL+1] table fits (ldsAcc), else in the output block.
+    double *wts = reinterpret_cast<double *>(wsm);                       // [chunk]
+    int *rows = reinterpret_cast<int *>(wsm + p.chunk * 8);               // [chunk][nM]
+    double *acc = reinterpret_cast<double *>(wsm + p.chunk * 8 + (size_t)p.chunk * p.maxCol * 4);  // [nM][nL+1] (ldsAcc)
+    const bool ldsAcc = p.ldsAcc != 0 && (size_t)nM * (nL + 1) * 8 <= (size_t)p.accBytes;
+    if (ldsAcc)
+        for (int i = tid; i < nM * (nL + 1); i += NT) acc[i] = 0.0;
     double total = 0.0;
-    for (int s = 0; s < nf; s++) {
-        const double g = gain[s];
-        if (p.gate && !(best + GATE > g)) continue;  // :622-626 (bruteForceProb sums every solution, :918-923)
-        const double w = exp(best - g);
-        total += w;
-        for (int m = lane; m < nM; m += 64) {
-            const int r = r4c[(long long)s * p.maxCol + m];
-            probs[m * (nLo + 1) + ((r >= nL) ? nLo : (ridx ? ridx[r] : r))] += w;  // :633-638
+    for (int s0 = 0; s0 < nf; s0 += p.chunk) {
+        const int ns = (nf - s0) < p.chunk ? (nf - s0) : p.chunk;
+        __syncthreads();
+        for (int s = tid; s < ns; s += NT) {
+            const double g = gain[s0 + s];
+            wts[s] = (p.gate && !(best + GATE > g)) ? -1.0 : exp(best - g);  // :622-626 (bruteForceProb sums every solution)
+        }
+        for (int i = tid; i < ns * nM; i += NT) {
+            const int s = i / nM, m = i - s * nM;
+            rows[i] = r4c[(long long)(s0 + s) * p.maxCol + m];
+        }
+        __syncthreads();
+        if (tid == 0)
+            for (int s = 0; s < ns; s++)
+                if (wts[s] >= 0.0) total += wts[s];
+        for (int m = tid; m < nM; m += NT) {
+            for (int s = 0; s < ns; s++) {
+                const double w = wts[s];
+                if (w < 0.0) continue;
+                const int r = rows[s * nM + m];
+                if (ldsAcc) acc[m * (nL + 1) + ((r >= nL) ? nL : r)] += w;                         // :633-638
+                else probs[m * (nLo + 1) + ((r >= nL) ? nLo : (ridx ? ridx[r] : r))] += w;
+            }
         }
     }
     __syncthreads();
-    const double norm = 1.0 / total;  // :643
-    for (int i = lane; i < nM * (nLo + 1); i += 64) probs[i] *= norm;
+    double *tot = wts;
+    if (tid == 0) tot[0] = total;
+    __syncthreads();
+    const double norm = 1.0 / tot[0];  // :643
+    if (ldsAcc) {
+        for (int i = tid; i < nM * (nL + 1); i += NT) {
+            const int m = i / (nL + 1), r = i - m * (nL + 1);
+            probs[m * (nLo + 1) + ((r >= nL) ? nLo : (ridx ? ridx[r] : r))] = acc[i] * norm;  // scatter back (:68-74)
+        }
+    } else {
+        for (int i = tid; i < nM * (nLo + 1); i += NT) probs[i] *= norm;
+    }
 }
 
 // ------------------------------------------------------------------- launchers
@@ -1313,9 +1351,25 @@ hipError_t launch_condition(const CondParams &p, int B, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t launch_weights(const WeightParams &p, int B, hipStream_t stream)
+hipError_t launch_weights(const WeightParams &p0, int B, hipStream_t stream)
 {
-    hipLaunchKernelGGL(weights_kernel, dim3(B), dim3(64), 0, stream, p);
+    WeightParams p = p0;
+    // LDS: weights and row maps of one chunk of solutions, and -- when it fits -- the accumulator table
+    int chunk = 8192 / (p.maxCol > 0 ? p.maxCol : 1);
+    chunk = chunk > 256 ? 256 : (chunk < 8 ? 8 : chunk);
+    const size_t base = (size_t)chunk * 8 + (size_t)chunk * p.maxCol * 4;
+    const size_t accWant = (size_t)p.maxCol * (size_t)(p.solveRows > 0 ? p.solveRows : 1) * 8;
+    p.chunk = chunk;
+    p.ldsAcc = (base + accWant <= 96 * 1024) ? 1 : 0;
+    p.accBytes = p.ldsAcc ? (long long)accWant : 0;
+    const size_t lds = ((base + (p.ldsAcc ? accWant : 0)) + 15) & ~(size_t)15;
+    static std::atomic<size_t> granted{0};
+    if (lds > granted.load(std::memory_order_relaxed)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(weights_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        granted.store(lds, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(weights_kernel, dim3(B), dim3(256), lds, stream, p);
     return hipGetLastError();
 }
 
