@@ -30,6 +30,8 @@ struct kbest_ctx {
     int ldsPerCU = 160 * 1024;
     int nCU = 256;
     int smallWaves = 0;  // waves per problem of the small-problem kernel; 0 = choose per launch (KBEST_SMALL_NW)
+    int wideNw = 0;           // KBEST_WIDE_NW: waves per problem of the general-size kernel (8 / 16; A/B tests)
+    int wideTile = -1;        // KBEST_WIDE_TILE: 0 / 1 force the cost copy out of / into LDS (A/B tests)
     int wideSpec = 0;         // KBEST_WIDE_SPEC: hypotheses split per round by the general-size kernel (A/B tests)
     bool exactRoot = false;   // KBEST_EXACT_ROOT: the 64-row kernel's root without the column-reduction start (A/B tests)
     bool noPoll = false;      // KBEST_NO_POLL: zero-copy calls wait for the stream instead of polling the completion counter
@@ -256,6 +258,8 @@ int kbest_create(kbest_ctx **out, int device)
     ctx->forceSmall = getenv("KBEST_FORCE_SMALL") != nullptr;
     ctx->noPoll = getenv("KBEST_NO_POLL") != nullptr;
     ctx->exactRoot = getenv("KBEST_EXACT_ROOT") != nullptr;
+    if (const char *e = getenv("KBEST_WIDE_NW")) { const int w = atoi(e); if (w == 8 || w == 16) ctx->wideNw = w; }
+    if (const char *e = getenv("KBEST_WIDE_TILE")) ctx->wideTile = atoi(e) ? 1 : 0;
     if (const char *e = getenv("KBEST_WIDE_SPEC")) { const int w = atoi(e); if (w >= 1 && w <= 8) ctx->wideSpec = w; }
     if (const char *e = getenv("KBEST_SPEC")) {
         int w = atoi(e);
@@ -308,7 +312,7 @@ static WidePlan plan_wide(const kbest_ctx *ctx, int B, int maxRow, int maxCol, i
     auto up = [](size_t x) { return (x + 127) & ~(size_t)127; };
     WidePlan w;
     // pool + children of one round + slack (anyCols: kbest_reserve does not know numCol -- the largest round over numCol <= maxRow)
-    const int perRound = anyCols ? (maxRow > 160 ? maxRow : (8 * maxRow < 160 ? 8 * maxRow : 160)) : kb::wide_spec(maxCol) * maxCol;
+    const int perRound = anyCols ? (maxRow > 1024 ? maxRow : (8 * maxRow < 1024 ? 8 * maxRow : 1024)) : kb::wide_spec_cap(maxCol) * maxCol;
     w.statesPerProblem = k + perRound + 2;
     w.poolStride = (long long)((k + 1 + 15) & ~15);
     w.freeStride = (long long)((w.statesPerProblem + 31) & ~31);
@@ -566,7 +570,11 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         // up to ~128 rows the square cost copy fits LDS next to the waves' working sets: a cost column then comes
         // from LDS instead of L2 at every Dijkstra step.  It costs residency (one workgroup per CU instead of two), so
         // only a batch that leaves CUs idle anyway takes it (256 x 128x128: 16 ms instead of 19; 512: 38 instead of 37).
-        const bool tile = B <= ctx->nCU && maxRow <= 128 && kb::wide_lds_layout(maxRow, maxCol, true).total <= ctx->ldsLimit;
+        const bool tileFits = maxRow <= 128 && kb::wide_lds_layout(maxRow, maxCol, true, 16).total <= ctx->ldsLimit;
+        const bool tile = tileFits && (ctx->wideTile >= 0 ? ctx->wideTile == 1 : B <= ctx->nCU);
+        int nw = (tile || B <= ctx->nCU) ? 16 : 8;
+        if (ctx->wideNw) nw = ctx->wideNw;
+        if (kb::wide_lds_layout(maxRow, maxCol, tile, nw).total > ctx->ldsLimit) nw = 8;
         int rc = reserve_wide(ctx, w, grow);
         if (rc != KBEST_OK) return rc;
         kb::WideParams p;
@@ -581,9 +589,10 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         p.ldCol = maxCol;
         p.minRows = runFast ? KBEST_MAX_DIM + 1 : 0;
         p.tile = tile ? 1 : 0;
+        p.nw = nw;
         // counting the reference's pushes needs the reference's exact order of splits: no speculation
-        p.spec = (opts->flags & KBEST_FLAG_COUNT_PUSHED) ? 1 : (ctx->wideSpec > 0 ? ctx->wideSpec : kb::wide_spec(maxCol));
-        if (p.spec > kb::wide_spec(maxCol)) p.spec = kb::wide_spec(maxCol);
+        p.spec = (opts->flags & KBEST_FLAG_COUNT_PUSHED) ? 1 : (ctx->wideSpec > 0 ? ctx->wideSpec : kb::wide_spec(maxCol, nw));
+        if (p.spec > kb::wide_spec_cap(maxCol)) p.spec = kb::wide_spec_cap(maxCol);
         p.k = k;
         p.maximize = opts->maximize;
         p.useCutoff = opts->use_cutoff;
@@ -608,6 +617,7 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         p.poolS = reinterpret_cast<int *>(base);                  base += ((size_t)2 * w.poolStride * 4 + 127) / 128 * 128 * G;
         p.freeList = reinterpret_cast<int *>(base);
         p.freeStride = w.freeStride;
+        p.prof = ctx->prof;
         hipError_t e = kb::launch_kbest_wide(p, w.grid, s);
         if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "general-size kbest kernel launch", e);
     }

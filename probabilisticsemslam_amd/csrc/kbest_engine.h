@@ -138,7 +138,7 @@ struct BoxParams {
 };
 
 // ---- general-size kernel (kbest_wide.hip): numRow up to 64 * 8, any k; hypotheses and pool in HBM work space ----
-constexpr int WIDE_NW = 8;         // waves per problem
+constexpr int WIDE_NW = 8;         // waves per problem (16 in the one-workgroup-per-CU shapes: WideParams::nw)
 constexpr int WIDE_MAX_DIM = 512;  // rows per problem
 
 struct WideParams {
@@ -151,6 +151,7 @@ struct WideParams {
     int minRows;              // problems with fewer rows are left to the LDS kernel (mixed batches); 0 = take all
     int tile;                 // 1: the square cost copy lives in LDS (it fits), Cw is not used
     int spec;                 // hypotheses split per round (1 = the reference's order of operations exactly), <= 8
+    int nw;                   // waves per problem: 8 or 16
     int k;
     int maximize, useCutoff;
     unsigned flags;
@@ -172,6 +173,7 @@ struct WideParams {
     long long poolStride;
     int *freeList;            // stack of free state slots
     long long freeStride;
+    unsigned long long *prof; // diagnostic builds (KB_PROFILE): [B][16] cycle sums over the waves
 };
 
 // bytes of one saved hypothesis of the general-size kernel: u[D] v[D] (fp64), row4col[D] col4row[D] (i32),
@@ -181,24 +183,32 @@ __host__ __device__ inline long long wide_state_stride(int maxRow) { return (24L
 struct WideLds { int offWave, waveStride, offChildG, offChildS, offChildC, offRed, offCtrl, offTile, total; };
 
 // tile: keep the shifted square cost copy in LDS instead of the HBM work space (when maxRow^2 * 8 bytes fit)
-// hypotheses split per round by the general-size kernel.  Measured (kernel ms, 1 / 2 / 4 / 8 per round): 1024 x 100x20
-// 26.4 / 20.8 / 17.4 / 16.0, 256 x 64x64 4.1 / 3.8 / 3.7 / 3.9, 512 x 128x128 18.5 / 18.1 / 18.7 / 20.3, 256 x 256x256
-// 66 / 67 / 71 / 82: with few columns a round is a handful of children and the sweeps' latency dominates (speculation
-// pays); with many columns one split already fills the eight waves and speculative splits are wasted work.
-__host__ __device__ inline int wide_spec(int maxCol) { const int s = 160 / (maxCol > 0 ? maxCol : 1); return s >= 8 ? 8 : (s >= 1 ? s : 1); }
+// hypotheses split per round by the general-size kernel.  Measured (kernel ms at 1 / 2 / 4 / 8 per round).  Eight waves
+// per problem, two or three problems per CU: 1024 x 100x20 4.1 / 3.2 / 2.7 / 2.5, 512 x 128x128 18.5 / 18.2 / 18.6 / 20.2,
+// 512 x 96x96 12.0 / 11.5 / 11.7 / 12.3.  Sixteen waves, one problem per CU: 256 x 64x64 3.7 / 3.0 / 2.6 / 2.5,
+// 256 x 128x128 10.5 / 9.3 / 8.8 / 9.1, 256 x 256x256 44.6 / 42.4 / 43.1 / 43.1.  With few columns a round is a handful of
+// children and the rounds' latency dominates (speculation pays); with many columns one split already fills eight waves
+// and speculative splits are wasted work; sixteen waves want twice the children per round.
+__host__ __device__ inline int wide_spec(int maxCol, int nw = 8)
+{
+    const int s = (nw == 16 ? 512 : 256) / (maxCol > 0 ? maxCol : 1), lo = nw == 16 ? 2 : 1;
+    return s >= 8 ? 8 : (s >= lo ? s : lo);
+}
+// capacity (LDS arrays, state slots): what KBEST_WIDE_SPEC may ask for
+__host__ __device__ inline int wide_spec_cap(int maxCol) { const int s = 1024 / (maxCol > 0 ? maxCol : 1); return s >= 8 ? 8 : (s >= 1 ? s : 1); }
 
-__host__ __device__ inline WideLds wide_lds_layout(int maxRow, int maxCol, bool tile)
+__host__ __device__ inline WideLds wide_lds_layout(int maxRow, int maxCol, bool tile, int nw = WIDE_NW)
 {
     WideLds L;
-    const int nc = wide_spec(maxCol) * maxCol;     // children of one round at most
+    const int nc = wide_spec_cap(maxCol) * maxCol; // children of one round at most
     int o = 0;
     L.waveStride = (20 * maxRow + 15) & ~15;       // per wave: u (fp64), col4row, row4col, pred (i32)
-    L.offWave = o;       o += WIDE_NW * L.waveStride;
+    L.offWave = o;       o += nw * L.waveStride;
     L.offChildG = o;     o += nc * 8;               // surviving children of the round: gain, state slot, (parent, column)
     L.offChildS = o;     o += nc * 4;
     L.offChildC = o;     o += nc * 4;
     o = (o + 7) & ~7;
-    L.offRed = o;        o += WIDE_NW * 8;
+    L.offRed = o;        o += nw * 8;
     L.offCtrl = o;       o += 320;                  // struct WideCtrl
     o = (o + 15) & ~15;
     L.offTile = o;       if (tile) o += maxRow * maxRow * 8;

@@ -65,7 +65,7 @@ template <int R, bool EARLY>
 __device__ __forceinline__ int wide_dijkstra(const double *Cw, int D, const double *uW, const int *c4rW, int lane,
                                              const double (&v)[R], u32 cand, u32 forb, int start, double bound,
                                              double (&spc)[R], int (&pred)[R], u32 &scannedOut, double &deltaOut,
-                                             int &sinkOut, int M = 0x7fffffff)
+                                             int &sinkOut, int M = 0x7fffffff, int *stepsOut = nullptr)
 {
     // M < D (children of a rectangular problem): rows on the zero-padded columns M .. D-1 ("parked") all carry the same
     // dual, and so do those columns, in every dual-feasible solution -- once the search has settled ONE parked row at
@@ -79,7 +79,8 @@ __device__ __forceinline__ int wide_dijkstra(const double *Cw, int D, const doub
     int cur = uni32(start);
     bound = __hiloint2double(uni32(__double2hiint(bound)), uni32(__double2loint(bound)));
     double delta = 0.0;
-    for (;;) {
+    for (int step = 1;; step++) {
+        if (stepsOut) *stepsOut = step;
         const double ucur = uW[cur];
         const double *col = Cw + (long long)cur * D;
         double best = INF;
@@ -196,18 +197,26 @@ __device__ __forceinline__ double wide_gain(const double *Cw, int D, int M, cons
 
 }  // namespace
 
+#ifdef KB_PROFILE
+#define KW_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define KW_ACC(slot, expr) do { profAcc[slot] += (unsigned long long)(expr); } while (0)
+#else
+#define KW_T(var) do { } while (0)
+#define KW_ACC(slot, expr) do { } while (0)
+#endif
+
 // up to 128 rows the working set fits 80 VGPRs: three 8-wave workgroups per CU instead of two
-template <int R, bool TILE>
-__global__ void __launch_bounds__(WIDE_NW * 64, (R <= 2 ? 6 : 4)) kbest_wide_kernel(WideParams p)
+template <int R, bool TILE, int NWV>
+__global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) kbest_wide_kernel(WideParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NT = WIDE_NW * 64;
+    constexpr int NT = NWV * 64;
     const double INF = d_inf();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int DS = p.maxRow;
-    const WideLds L = wide_lds_layout(DS, p.maxCol, TILE);
+    const WideLds L = wide_lds_layout(DS, p.maxCol, TILE, NWV);
     double *uW = reinterpret_cast<double *>(smem + L.offWave + (size_t)wave * L.waveStride);
     int *c4rW = reinterpret_cast<int *>(uW + DS);
     int *r4cW = c4rW + DS;
@@ -246,6 +255,10 @@ __global__ void __launch_bounds__(WIDE_NW * 64, (R <= 2 ? 6 : 4)) kbest_wide_ker
         const int D = N;
         const double *Cg = p.cost + (p.costOff ? p.costOff[b] : (long long)b * p.ldRow * p.ldCol);
         const long long outBase = (long long)b * k;
+#ifdef KB_PROFILE
+        unsigned long long profAcc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const unsigned long long profT0 = __builtin_readcyclecounter();
+#endif
 
         // ---- phase 0: makeCostMatrixSafe + zero padding (cpp:534-569, 582-585) ----
         {
@@ -259,7 +272,7 @@ __global__ void __launch_bounds__(WIDE_NW * 64, (R <= 2 ? 6 : 4)) kbest_wide_ker
             if (lane == 0) red[wave] = mn;
             __syncthreads();
             mn = red[0];
-            for (int w = 1; w < WIDE_NW; w++) mn = min_keep(mn, red[w]);
+            for (int w = 1; w < NWV; w++) mn = min_keep(mn, red[w]);
             const double cdel = maximize ? -mn : mn;
             __syncthreads();
             double cm = 0.0;
@@ -278,7 +291,7 @@ __global__ void __launch_bounds__(WIDE_NW * 64, (R <= 2 ? 6 : 4)) kbest_wide_ker
             for (int i = tid; i < S - 1; i += NT) freeList[i] = S - 1 - i;  // slot 0 is the root's
             __syncthreads();
             if (tid == 0) {
-                for (int w = 1; w < WIDE_NW; w++) cm = red[w] > cm ? red[w] : cm;
+                for (int w = 1; w < NWV; w++) cm = red[w] > cm ? red[w] : cm;
                 ctrl->cmax = cm;
                 ctrl->cdelta = cdel * (double)M;  // cpp:583
                 ctrl->stop = 0;
@@ -293,6 +306,8 @@ __global__ void __launch_bounds__(WIDE_NW * 64, (R <= 2 ? 6 : 4)) kbest_wide_ker
             __syncthreads();
         }
 
+        KW_ACC(0, __builtin_readcyclecounter() - profT0);  // [0] cost copy
+        KW_T(tRoot);
         auto store_state = [&](int sid, const double (&v)[R], u32 forb, double gain, int activeCol) {
             unsigned char *st = stBase + (long long)sid * p.stateStride;
             double *su = reinterpret_cast<double *>(st), *sv = reinterpret_cast<double *>(st + offV);
@@ -372,6 +387,7 @@ __global__ void __launch_bounds__(WIDE_NW * 64, (R <= 2 ? 6 : 4)) kbest_wide_ker
             }
         }
         __syncthreads();
+        KW_ACC(1, __builtin_readcyclecounter() - tRoot);  // [1] root (incl. barrier)
         if (uni32(ctrl->stop) == 3) {  // infeasible: kBest2D returns 0 (cpp:588-593)
             if (tid == 0) { p.nf[b] = 0; if (p.pushed) p.pushed[b] = 0; }
             continue;
@@ -392,6 +408,8 @@ __global__ void __launch_bounds__(WIDE_NW * 64, (R <= 2 ? 6 : 4)) kbest_wide_ker
             double *dstG = poolG + (long long)(1 - cur) * p.poolStride;
             int *dstS = poolS + (long long)(1 - cur) * p.poolStride;
             // -- select + emission bookkeeping (wave 0)
+            KW_T(tSel);
+            KW_ACC(2, 1);  // [2] rounds
             if (wave == 0) {
                 int cnt = 0, firstU = -1;
                 for (int base = 0; base < n && cnt < spec; base += 64) {
@@ -455,6 +473,8 @@ __global__ void __launch_bounds__(WIDE_NW * 64, (R <= 2 ? 6 : 4)) kbest_wide_ker
                 }
             }
             __syncthreads();
+            KW_T(tOut);
+            KW_ACC(3, tOut - tSel);  // [3] select + emission bookkeeping (wave 0; the others wait)
             const int nsel = uni32(ctrl->nsel), nEmit = uni32(ctrl->nEmit), lastSel = uni32(ctrl->lastSel);
             // -- outputs of the hypotheses emitted in this round (cpp:618-630): from their saved states
             for (int idx = tid; idx < nEmit * (N + M); idx += NT) {
@@ -474,11 +494,17 @@ __global__ void __launch_bounds__(WIDE_NW * 64, (R <= 2 ? 6 : 4)) kbest_wide_ker
             const double cutG = ctrl->cutoffGain;
             if (useCut && !maximize && cutG < T) T = cutG;
             const double cmaxv = ctrl->cmax;
-            const int totalItems = uni32(ctrl->selOff[nsel]);
 
-            // -- children of the selected hypotheses (split, cpp:455-532), one wave each, dynamic queue over (node, column)
+            // -- children of the selected hypotheses (split, cpp:455-532), one wave each, dynamic queue over (node, column).
+            //    (A separate first-step pass over all children -- wave w tests the columns a + w, a + w + NW, ... of each node
+            //    with one ballot per child -- was measured and is slower: only 6 children in 10 end at their first step, the
+            //    others take 2-4, and the extra barrier costs more than the saved state loads: 10.4 -> 11.4 ms on 256 x 128x128.)
+            const int totalItems = uni32(ctrl->selOff[nsel]);
             int npush = 0;
+            KW_T(tCh);
+            KW_ACC(4, tCh - tOut);  // [4] outputs of the emitted hypotheses
             for (;;) {
+                KW_T(tA);
                 int t = 0;
                 if (lane == 0) t = atomicAdd(&ctrl->nextTicket, 1);
                 t = uni32(t);
@@ -520,11 +546,28 @@ __global__ void __launch_bounds__(WIDE_NW * 64, (R <= 2 ? 6 : 4)) kbest_wide_ker
                 u32 scanned;
                 double delta;
                 int sink = 0;
-                if (wide_dijkstra<R, true>(Cw, D, uW, c4rW, lane, v, cand, forbm, c, bound, spc, pred, scanned, delta, sink,
-                                           (p.flags & KBEST_FLAG_EXACT_ROOT) ? 0x7fffffff : M))
-                    continue;
+                KW_T(tB);
+                KW_ACC(5, tB - tA);  // [5] ticket + parent state load
+                KW_ACC(11, 1);       // [11] children started
+#ifdef KB_PROFILE
+                int nSteps = 0;
+                const int dj = wide_dijkstra<R, true>(Cw, D, uW, c4rW, lane, v, cand, forbm, c, bound, spc, pred, scanned, delta, sink,
+                                                      (p.flags & KBEST_FLAG_EXACT_ROOT) ? 0x7fffffff : M, &nSteps);
+                KW_ACC(13, nSteps);  // [13] Dijkstra steps
+#else
+                const int dj = wide_dijkstra<R, true>(Cw, D, uW, c4rW, lane, v, cand, forbm, c, bound, spc, pred, scanned, delta, sink,
+                                                      (p.flags & KBEST_FLAG_EXACT_ROOT) ? 0x7fffffff : M);
+#endif
+                KW_T(tC);
+                KW_ACC(6, tC - tB);  // [6] shortest augmenting path
+                if (dj) continue;
+                KW_ACC(12, 1);       // [12] children completed
                 wide_update<R>(uW, c4rW, r4cW, predW, lane, v, spc, pred, scanned, delta, sink, c, D);
+                KW_T(tD);
+                KW_ACC(7, tD - tC);  // [7] dual update + augmentation
                 const double g = wide_gain<R>(Cw, D, M, r4cW, lane);
+                KW_T(tE);
+                KW_ACC(8, tE - tD);  // [8] gain
                 if (useCut && (maximize ? (g < cutG) : (g > cutG))) continue;  // cutHyp, cpp:496/521
                 npush++;
                 int sid = -1;
@@ -546,9 +589,13 @@ __global__ void __launch_bounds__(WIDE_NW * 64, (R <= 2 ? 6 : 4)) kbest_wide_ker
                     childS[pos] = sid;
                     childC[pos] = (ps << 10) | c;  // (parent, column): the order of exact ties
                 }
+                KW_ACC(9, __builtin_readcyclecounter() - tE);  // [9] state store + push
             }
+            KW_T(tW);
             if ((p.flags & KBEST_FLAG_COUNT_PUSHED) && lane == 0 && npush) atomicAdd(&ctrl->pushed, npush);
             __syncthreads();
+            KW_T(tM);
+            KW_ACC(10, tM - tW);  // [10] wait at the barrier after the children
             if (uni32(ctrl->stop) != 0) break;
 
             // -- merge: the old entries that were not emitted and the children, sorted, first Rk kept; the entries selected
@@ -591,8 +638,14 @@ __global__ void __launch_bounds__(WIDE_NW * 64, (R <= 2 ? 6 : 4)) kbest_wide_ker
                 ctrl->nextTicket = 0;
             }
             __syncthreads();
+            KW_ACC(14, __builtin_readcyclecounter() - tM);  // [14] merge
         }
         __syncthreads();
+#ifdef KB_PROFILE
+        profAcc[15] = __builtin_readcyclecounter() - profT0;  // [15] whole problem (this wave)
+        if (p.prof && lane == 0)
+            for (int i = 0; i < 16; i++) atomicAdd(p.prof + (long long)b * 16 + i, profAcc[i]);
+#endif
         if (tid == 0) {
             p.nf[b] = (ctrl->stop == 2) ? -3 : ctrl->emitted;
             if (p.pushed) p.pushed[b] = ctrl->pushed;
@@ -600,15 +653,21 @@ __global__ void __launch_bounds__(WIDE_NW * 64, (R <= 2 ? 6 : 4)) kbest_wide_ker
     }
 }
 
+template <int R, bool TILE, int NWV>
+static hipError_t launch_wide_rtn(const WideParams &p, int grid, hipStream_t stream)
+{
+    const WideLds L = wide_lds_layout(p.maxRow, p.maxCol, TILE, NWV);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kbest_wide_kernel<R, TILE, NWV>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((kbest_wide_kernel<R, TILE, NWV>), dim3(grid), dim3(NWV * 64), L.total, stream, p);
+    return hipGetLastError();
+}
+
 template <int R, bool TILE>
 static hipError_t launch_wide_rt(const WideParams &p, int grid, hipStream_t stream)
 {
-    const WideLds L = wide_lds_layout(p.maxRow, p.maxCol, TILE);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kbest_wide_kernel<R, TILE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((kbest_wide_kernel<R, TILE>), dim3(grid), dim3(WIDE_NW * 64), L.total, stream, p);
-    return hipGetLastError();
+    return p.nw == 16 ? launch_wide_rtn<R, TILE, 16>(p, grid, stream) : launch_wide_rtn<R, TILE, 8>(p, grid, stream);
 }
 
 template <int R>
