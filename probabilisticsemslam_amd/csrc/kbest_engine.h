@@ -180,7 +180,7 @@ struct WideParams {
 // forbidden rows (u32 per lane), gain, activeCol; whole 128-byte lines
 __host__ __device__ inline long long wide_state_stride(int maxRow) { return (24LL * maxRow + 256 + 16 + 127) & ~127LL; }
 
-struct WideLds { int offWave, waveStride, offChildG, offChildS, offChildC, offRed, offCtrl, offTile, total; };
+struct WideLds { int offWave, waveStride, offNode, nodeStride, offChildG, offChildS, offChildC, offRed, offCtrl, offTile, total; };
 
 // tile: keep the shifted square cost copy in LDS instead of the HBM work space (when maxRow^2 * 8 bytes fit)
 // hypotheses split per round by the general-size kernel.  Measured (kernel ms at 1 / 2 / 4 / 8 per round).  Eight waves
@@ -195,15 +195,24 @@ __host__ __device__ inline int wide_spec(int maxCol, int nw = 8)
     return s >= 8 ? 8 : (s >= lo ? s : lo);
 }
 // capacity (LDS arrays, state slots): what KBEST_WIDE_SPEC may ask for
-__host__ __device__ inline int wide_spec_cap(int maxCol) { const int s = 1024 / (maxCol > 0 ? maxCol : 1); return s >= 8 ? 8 : (s >= 1 ? s : 1); }
+__host__ __device__ inline int wide_node_stride(int maxRow) { return (24 * maxRow + 256 + 16 + 15) & ~15; }  // LDS copy of a saved hypothesis
+__host__ __device__ inline int wide_spec_cap(int maxCol, int maxRow)
+{
+    int s = 1024 / (maxCol > 0 ? maxCol : 1);
+    const int fit = (32 * 1024) / wide_node_stride(maxRow);  // the split hypotheses' LDS copies: 32 KiB at most
+    s = s < fit ? s : fit;
+    return s >= 8 ? 8 : (s >= 1 ? s : 1);
+}
 
 __host__ __device__ inline WideLds wide_lds_layout(int maxRow, int maxCol, bool tile, int nw = WIDE_NW)
 {
     WideLds L;
-    const int nc = wide_spec_cap(maxCol) * maxCol; // children of one round at most
+    const int nc = wide_spec_cap(maxCol, maxRow) * maxCol; // children of one round at most
     int o = 0;
     L.waveStride = (20 * maxRow + 15) & ~15;       // per wave: u (fp64), col4row, row4col, pred (i32)
     L.offWave = o;       o += nw * L.waveStride;
+    L.nodeStride = wide_node_stride(maxRow);       // copy of a saved hypothesis (wide_state_stride's content)
+    L.offNode = o;       o += wide_spec_cap(maxCol, maxRow) * L.nodeStride;  // the hypotheses being split in this round
     L.offChildG = o;     o += nc * 8;               // surviving children of the round: gain, state slot, (parent, column)
     L.offChildS = o;     o += nc * 4;
     L.offChildC = o;     o += nc * 4;

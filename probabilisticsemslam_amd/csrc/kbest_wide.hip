@@ -65,73 +65,91 @@ template <int R, bool EARLY>
 __device__ __forceinline__ int wide_dijkstra(const double *Cw, int D, const double *uW, const int *c4rW, int lane,
                                              const double (&v)[R], u32 cand, u32 forb, int start, double bound,
                                              double (&spc)[R], int (&pred)[R], u32 &scannedOut, double &deltaOut,
-                                             int &sinkOut, int M = 0x7fffffff, int *stepsOut = nullptr)
+                                             int &sinkOut, int M = 0x7fffffff, int *stepsOut = nullptr, int freed = -1)
 {
+    // `freed`: the row the child took from its start column (cpp:277-278).  uW / c4rW may then be the PARENT's arrays,
+    // shared and read-only: the only entry of col4row that differs in the child is that row's (-1: it is the free row).
     // M < D (children of a rectangular problem): rows on the zero-padded columns M .. D-1 ("parked") all carry the same
     // dual, and so do those columns, in every dual-feasible solution -- once the search has settled ONE parked row at
     // distance d every other parked row is at distance d too and scanning their columns changes nothing (kbest_small.hip,
     // file header).  So when the first parked row is settled, all of them are: one step instead of one per parked row.
-    bool parkedOpen = true;
     const double INF = d_inf();
+    int rowOff[R];
 #pragma unroll
-    for (int i = 0; i < R; i++) { spc[i] = INF; pred[i] = 0; }
+    for (int i = 0; i < R; i++) {
+        spc[i] = INF;
+        pred[i] = 0;
+        const int r = lane + 64 * i;
+        rowOff[i] = r < D ? r : D - 1;  // rows beyond D are never candidates: any address inside the column will do
+    }
     u32 act = cand & ~forb, scanned = 0;
-    int cur = uni32(start);
+    int cur = uni32(start), parkThr = uni32(M), steps = 0;
     bound = __hiloint2double(uni32(__double2hiint(bound)), uni32(__double2loint(bound)));
     double delta = 0.0;
-    for (int step = 1;; step++) {
-        if (stepsOut) *stepsOut = step;
-        const double ucur = uW[cur];
-        const double *col = Cw + (long long)cur * D;
-        double best = INF;
-        int brow = 0x7fffffff;
-#pragma unroll
-        for (int i = 0; i < R; i++) {
-            if ((act >> i) & 1u) {
-                const double rc = ((delta + col[lane + 64 * i]) - ucur) - v[i];  // cpp:183 / cpp:313, left to right
-                if (rc < spc[i]) { spc[i] = rc; pred[i] = cur; }                  // strict '<': cpp:185, 314
-                if (spc[i] < best) { best = spc[i]; brow = lane + 64 * i; }       // lowest row first: cpp:191, 320
-            }
-        }
-        // wave arg-min.  Reduced costs are non-negative up to rounding, and for non-negative doubles the high word is
-        // an order-preserving key: one integer DPP chain finds it, and when a single lane holds it (four steps in
-        // five) that lane's row is the answer.  Otherwise -- a negative candidate, or several lanes on the same high
-        // word (mostly exact zeros on tight arcs) -- the full fp64 minimum and the lowest row among its holders.
-        const int bhi = __double2hiint(best);
-        const int mhi = wave_min_i32(bhi);
-        const u64 eq = __ballot(bhi == mhi);
-        double m;
-        int closest;
-        if (mhi >= 0 && (eq & (eq - 1)) == 0) {
-            const int ln = __builtin_ctzll(eq);
-            m = __hiloint2double(mhi, __builtin_amdgcn_readlane(__double2loint(best), ln));
-            closest = __builtin_amdgcn_readlane(brow, ln);
-        } else {
-            m = wave_min_f64(best);
-            closest = wave_min_i32(best == m ? brow : 0x7fffffff);
-        }
-        if (!(m < INF)) { scannedOut = scanned; return 1; }
-        if (EARLY && m > bound) { scannedOut = scanned; return 2; }
-        delta = m;
-        if (lane == (closest & 63)) { cand &= ~(1u << (closest >> 6)); scanned |= 1u << (closest >> 6); }
-        act = cand;
-        const int cc = uni32(c4rW[closest]);
-        if (cc < 0) { sinkOut = closest; break; }
-        if (cc >= M && parkedOpen) {
-            parkedOpen = false;
+    for (;;) {
+        // the plain steps: straight-line relaxation (selects, no divergent blocks), one exit test
+        int cc, closest;
+        do {
+            steps++;
+            const double ucur = uW[cur];
+            const double *col = Cw + (long long)cur * D;
+            double best = INF;
+            int brow = 0x7fffffff;
 #pragma unroll
             for (int i = 0; i < R; i++) {
-                if (((cand >> i) & 1u) && c4rW[lane + 64 * i] >= M) {
-                    spc[i] = delta;  // (what the relaxation through column cc gives them: equal duals, zero costs)
-                    pred[i] = cc;
-                    cand &= ~(1u << i);
-                    scanned |= 1u << i;
-                }
+                const bool on = ((act >> i) & 1u) != 0;
+                const double rc = ((delta + col[rowOff[i]]) - ucur) - v[i];  // cpp:183 / cpp:313, left to right
+                const bool better = on & (rc < spc[i]);                      // strict '<': cpp:185, 314
+                spc[i] = better ? rc : spc[i];
+                pred[i] = better ? cur : pred[i];
+                const bool low = on & (spc[i] < best);                       // lowest row first: cpp:191, 320
+                best = low ? spc[i] : best;
+                brow = low ? lane + 64 * i : brow;
             }
+            // wave arg-min.  Reduced costs are non-negative up to rounding, and for non-negative doubles the high word is
+            // an order-preserving key: one integer DPP chain finds it, and when a single lane holds it (four steps in
+            // five) that lane's row is the answer.  Otherwise -- a negative candidate, or several lanes on the same high
+            // word (mostly exact zeros on tight arcs) -- the full fp64 minimum and the lowest row among its holders.
+            const int bhi = __double2hiint(best);
+            const int mhi = wave_min_i32(bhi);
+            const u64 eq = __ballot(bhi == mhi);
+            double m;
+            if (mhi >= 0 && (eq & (eq - 1)) == 0) {
+                const int ln = __builtin_ctzll(eq);
+                m = __hiloint2double(mhi, __builtin_amdgcn_readlane(__double2loint(best), ln));
+                closest = __builtin_amdgcn_readlane(brow, ln);
+            } else {
+                m = wave_min_f64(best);
+                closest = wave_min_i32(best == m ? brow : 0x7fffffff);
+            }
+            if (!(m < INF) || (EARLY && m > bound)) {  // infeasible (cpp:197, 327) / beyond the bound
+                scannedOut = scanned;
+                if (stepsOut) *stepsOut = steps;
+                return (m < INF) ? 2 : 1;
+            }
+            delta = m;
+            const u32 bit = (lane == (closest & 63)) ? (1u << (closest >> 6)) : 0u;
+            cand &= ~bit;
+            scanned |= bit;
             act = cand;
+            cc = (closest == freed) ? -1 : uni32(c4rW[closest]);
+            cur = cc;
+        } while (cc >= 0 && cc < parkThr);
+        if (cc < 0) { sinkOut = closest; break; }
+        // the first parked row is settled: so are all the others (at the same distance, through column cc)
+        parkThr = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            if (((cand >> i) & 1u) && c4rW[rowOff[i]] >= M) {
+                spc[i] = delta;  // (what the relaxation through column cc gives them: equal duals, zero costs)
+                pred[i] = cc;
+                cand &= ~(1u << i);
+                scanned |= 1u << i;
+            }
         }
-        cur = cc;
+        act = cand;
     }
+    if (stepsOut) *stepsOut = steps;
     scannedOut = scanned;
     deltaOut = delta;
     return 0;
@@ -224,6 +242,7 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
     double *childG = reinterpret_cast<double *>(smem + L.offChildG);
     int *childS = reinterpret_cast<int *>(smem + L.offChildS);
     int *childC = reinterpret_cast<int *>(smem + L.offChildC);
+    unsigned char *nodeBase = smem + L.offNode;  // the hypotheses being split in this round: copies of their saved states
     double *red = reinterpret_cast<double *>(smem + L.offRed);
     WideCtrl *ctrl = reinterpret_cast<WideCtrl *>(smem + L.offCtrl);
 
@@ -488,6 +507,16 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
                 if (tid == 0 && ctrl->stop == 1) ctrl->emitted = emitted + nEmit;
                 break;
             }
+            // -- the hypotheses being split come into LDS once (coalesced): every child reads its parent from there
+            {
+                const int words = (int)(offTail + 16) >> 2;
+                for (int s2 = 0; s2 < nsel; s2++) {
+                    const int *src = reinterpret_cast<const int *>(stBase + (long long)uni32(ctrl->selSid[s2]) * p.stateStride);
+                    int *dst = reinterpret_cast<int *>(nodeBase + (size_t)s2 * L.nodeStride);
+                    for (int i = tid; i < words; i += NT) dst[i] = src[i];
+                }
+            }
+            __syncthreads();
             const int eNew = emitted + nEmit;
             const int nOld = n - nEmit, Rk = k - eNew;  // Rk: candidates that can still be output
             double T = (nOld >= Rk) ? srcG[nEmit + Rk - 1] : INF;
@@ -517,7 +546,7 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
                 if (round == 0 && p.rootColStride > 1 && (c % p.rootColStride) != p.rootColOffset) continue;  // the root's children
                 const double pgain = ctrl->selG[s2];
                 const double bound = (prune && T < INF) ? (T - pgain) + 1e-9 * (fabs(T) + cmaxv) : INF;
-                const unsigned char *P = stBase + (long long)ps * p.stateStride;
+                const unsigned char *P = nodeBase + (size_t)s2 * L.nodeStride;  // the parent, in LDS
                 const double *Pu = reinterpret_cast<const double *>(P), *Pv = reinterpret_cast<const double *>(P + offV);
                 const int *Pr4c = reinterpret_cast<const int *>(P + offR4C), *Pc4r = reinterpret_cast<const int *>(P + offC4R);
                 const u32 pforb = reinterpret_cast<const u32 *>(P + offForb)[lane];
@@ -529,39 +558,42 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
                     const int r = lane + 64 * i;
                     v[i] = 0.0;
                     if (r < D) {
-                        uW[r] = Pu[r];
                         v[i] = Pv[r];
-                        const int cr = Pc4r[r];
-                        c4rW[r] = cr;
-                        r4cW[r] = Pr4c[r];
-                        if (cr >= c) cand |= 1u << i;  // rows of columns >= c: cpp:480-488, 525-527
+                        if (Pc4r[r] >= c) cand |= 1u << i;  // rows of columns >= c: cpp:480-488, 525-527
                     }
                 }
                 const int fr = uni32(Pr4c[c]);  // row freed: cpp:277-278
                 const u32 frBit = (lane == (fr & 63)) ? (1u << (fr >> 6)) : 0u;
                 const u32 forbm = (c == a) ? pforb : frBit;  // cpp:490 / cpp:510-516
-                wave_fence();
-                if (lane == 0) { c4rW[fr] = -1; r4cW[c] = -1; }
-                wave_fence();
                 u32 scanned;
                 double delta;
                 int sink = 0;
                 KW_T(tB);
                 KW_ACC(5, tB - tA);  // [5] ticket + parent state load
                 KW_ACC(11, 1);       // [11] children started
+                // the search runs on the parent's u and col4row (shared, read-only); only a child that completes gets
+                // its own copy, to be updated and saved
 #ifdef KB_PROFILE
                 int nSteps = 0;
-                const int dj = wide_dijkstra<R, true>(Cw, D, uW, c4rW, lane, v, cand, forbm, c, bound, spc, pred, scanned, delta, sink,
-                                                      (p.flags & KBEST_FLAG_EXACT_ROOT) ? 0x7fffffff : M, &nSteps);
+                const int dj = wide_dijkstra<R, true>(Cw, D, Pu, Pc4r, lane, v, cand, forbm, c, bound, spc, pred, scanned, delta, sink,
+                                                      (p.flags & KBEST_FLAG_EXACT_ROOT) ? 0x7fffffff : M, &nSteps, fr);
                 KW_ACC(13, nSteps);  // [13] Dijkstra steps
 #else
-                const int dj = wide_dijkstra<R, true>(Cw, D, uW, c4rW, lane, v, cand, forbm, c, bound, spc, pred, scanned, delta, sink,
-                                                      (p.flags & KBEST_FLAG_EXACT_ROOT) ? 0x7fffffff : M);
+                const int dj = wide_dijkstra<R, true>(Cw, D, Pu, Pc4r, lane, v, cand, forbm, c, bound, spc, pred, scanned, delta, sink,
+                                                      (p.flags & KBEST_FLAG_EXACT_ROOT) ? 0x7fffffff : M, nullptr, fr);
 #endif
                 KW_T(tC);
                 KW_ACC(6, tC - tB);  // [6] shortest augmenting path
                 if (dj) continue;
                 KW_ACC(12, 1);       // [12] children completed
+#pragma unroll
+                for (int i = 0; i < R; i++) {
+                    const int r = lane + 64 * i;
+                    if (r < D) { uW[r] = Pu[r]; c4rW[r] = Pc4r[r]; r4cW[r] = Pr4c[r]; }
+                }
+                wave_fence();
+                if (lane == 0) { c4rW[fr] = -1; r4cW[c] = -1; }
+                wave_fence();
                 wide_update<R>(uW, c4rW, r4cW, predW, lane, v, spc, pred, scanned, delta, sink, c, D);
                 KW_T(tD);
                 KW_ACC(7, tD - tC);  // [7] dual update + augmentation
