@@ -260,7 +260,7 @@ int kbest_create(kbest_ctx **out, int device)
     ctx->exactRoot = getenv("KBEST_EXACT_ROOT") != nullptr;
     if (const char *e = getenv("KBEST_WIDE_NW")) { const int w = atoi(e); if (w == 8 || w == 16) ctx->wideNw = w; }
     if (const char *e = getenv("KBEST_WIDE_TILE")) ctx->wideTile = atoi(e) ? 1 : 0;
-    if (const char *e = getenv("KBEST_WIDE_SPEC")) { const int w = atoi(e); if (w >= 1 && w <= 8) ctx->wideSpec = w; }
+    if (const char *e = getenv("KBEST_WIDE_SPEC")) { const int w = atoi(e); if (w >= 1 && w <= kb::WIDE_MAX_SPEC) ctx->wideSpec = w; }
     if (const char *e = getenv("KBEST_SPEC")) {
         int w = atoi(e);
         if (w >= 1 && w <= 16) ctx->spec = w;
@@ -312,7 +312,7 @@ static WidePlan plan_wide(const kbest_ctx *ctx, int B, int maxRow, int maxCol, i
     auto up = [](size_t x) { return (x + 127) & ~(size_t)127; };
     WidePlan w;
     // pool + children of one round + slack (anyCols: kbest_reserve does not know numCol -- the largest round over numCol <= maxRow)
-    const int perRound = anyCols ? (maxRow > 1024 ? maxRow : (8 * maxRow < 1024 ? 8 * maxRow : 1024)) : kb::wide_spec_cap(maxCol, maxRow) * maxCol;
+    const int perRound = anyCols ? (maxRow > 1024 ? maxRow : (kb::WIDE_MAX_SPEC * maxRow < 1024 ? kb::WIDE_MAX_SPEC * maxRow : 1024)) : kb::wide_spec_cap(maxCol, maxRow) * maxCol;
     w.statesPerProblem = k + perRound + 2;
     w.poolStride = (long long)((k + 1 + 15) & ~15);
     w.freeStride = (long long)((w.statesPerProblem + 31) & ~31);
@@ -591,7 +591,7 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         p.tile = tile ? 1 : 0;
         p.nw = nw;
         // counting the reference's pushes needs the reference's exact order of splits: no speculation
-        p.spec = (opts->flags & KBEST_FLAG_COUNT_PUSHED) ? 1 : (ctx->wideSpec > 0 ? ctx->wideSpec : kb::wide_spec(maxCol, nw));
+        p.spec = (opts->flags & KBEST_FLAG_COUNT_PUSHED) ? 1 : (ctx->wideSpec > 0 ? ctx->wideSpec : kb::wide_spec(maxCol, nw, k));
         if (p.spec > kb::wide_spec_cap(maxCol, maxRow)) p.spec = kb::wide_spec_cap(maxCol, maxRow);
         p.k = k;
         p.maximize = opts->maximize;

@@ -140,6 +140,9 @@ struct BoxParams {
 // ---- general-size kernel (kbest_wide.hip): numRow up to 64 * 8, any k; hypotheses and pool in HBM work space ----
 constexpr int WIDE_NW = 8;         // waves per problem (16 in the one-workgroup-per-CU shapes: WideParams::nw)
 constexpr int WIDE_MAX_DIM = 512;  // rows per problem
+constexpr int WIDE_MAX_SPEC = 64;  // hypotheses split per round at most
+constexpr int WIDE_CTRL_BYTES = 1920;
+constexpr int WIDE_SAMPLES = 1024; // LDS index of the sorted pool: every 64th gain (k up to 65 535; beyond: binary search in HBM)
 
 struct WideParams {
     const double *cost;
@@ -150,7 +153,7 @@ struct WideParams {
     int ldRow, ldCol;         // leading dimensions of the outputs / of the default cost packing
     int minRows;              // problems with fewer rows are left to the LDS kernel (mixed batches); 0 = take all
     int tile;                 // 1: the square cost copy lives in LDS (it fits), Cw is not used
-    int spec;                 // hypotheses split per round (1 = the reference's order of operations exactly), <= 8
+    int spec;                 // hypotheses split per round (1 = the reference's order of operations exactly), <= WIDE_MAX_SPEC
     int nw;                   // waves per problem: 8 or 16
     int k;
     int maximize, useCutoff;
@@ -180,7 +183,7 @@ struct WideParams {
 // forbidden rows (u32 per lane), gain, activeCol; whole 128-byte lines
 __host__ __device__ inline long long wide_state_stride(int maxRow) { return (24LL * maxRow + 256 + 16 + 127) & ~127LL; }
 
-struct WideLds { int offWave, waveStride, offNode, nodeStride, offChildG, offChildS, offChildC, offRed, offCtrl, offTile, total; };
+struct WideLds { int offWave, waveStride, offNode, nodeStride, offChildG, offChildS, offChildC, offSample, offRed, offCtrl, offTile, total; };
 
 // tile: keep the shifted square cost copy in LDS instead of the HBM work space (when maxRow^2 * 8 bytes fit)
 // hypotheses split per round by the general-size kernel.  Measured (kernel ms at 1 / 2 / 4 / 8 per round).  Eight waves
@@ -189,9 +192,13 @@ struct WideLds { int offWave, waveStride, offNode, nodeStride, offChildG, offChi
 // 256 x 128x128 10.5 / 9.3 / 8.8 / 9.1, 256 x 256x256 44.6 / 42.4 / 43.1 / 43.1.  With few columns a round is a handful of
 // children and the rounds' latency dominates (speculation pays); with many columns one split already fills eight waves
 // and speculative splits are wasted work; sixteen waves want twice the children per round.
-__host__ __device__ inline int wide_spec(int maxCol, int nw = 8)
+// With k in the thousands (bruteForceProb, assignment.cpp:868) nearly every hypothesis near the pool's head is output
+// sooner or later, so speculation is almost never wasted and the number of rounds is what costs (each a chain of dependent
+// HBM round trips: 64 x 30x10, k = 20 000: 45 ms at 8 per round, 2 500 rounds): as many as the LDS copies allow.
+__host__ __device__ inline int wide_spec(int maxCol, int nw = 8, int k = 200)
 {
     const int s = (nw == 16 ? 512 : 256) / (maxCol > 0 ? maxCol : 1), lo = nw == 16 ? 2 : 1;
+    if (k >= 1024) return WIDE_MAX_SPEC;  // (clamped to wide_spec_cap by the caller)
     return s >= 8 ? 8 : (s >= lo ? s : lo);
 }
 // capacity (LDS arrays, state slots): what KBEST_WIDE_SPEC may ask for
@@ -199,9 +206,9 @@ __host__ __device__ inline int wide_node_stride(int maxRow) { return (24 * maxRo
 __host__ __device__ inline int wide_spec_cap(int maxCol, int maxRow)
 {
     int s = 1024 / (maxCol > 0 ? maxCol : 1);
-    const int fit = (32 * 1024) / wide_node_stride(maxRow);  // the split hypotheses' LDS copies: 32 KiB at most
+    const int fit = ((maxRow <= 64 ? 64 : 32) * 1024) / wide_node_stride(maxRow);  // the split hypotheses' LDS copies: 32 KiB at most (64 for small problems)
     s = s < fit ? s : fit;
-    return s >= 8 ? 8 : (s >= 1 ? s : 1);
+    return s >= WIDE_MAX_SPEC ? WIDE_MAX_SPEC : (s >= 1 ? s : 1);
 }
 
 __host__ __device__ inline WideLds wide_lds_layout(int maxRow, int maxCol, bool tile, int nw = WIDE_NW)
@@ -213,12 +220,15 @@ __host__ __device__ inline WideLds wide_lds_layout(int maxRow, int maxCol, bool 
     L.offWave = o;       o += nw * L.waveStride;
     L.nodeStride = wide_node_stride(maxRow);       // copy of a saved hypothesis (wide_state_stride's content)
     L.offNode = o;       o += wide_spec_cap(maxCol, maxRow) * L.nodeStride;  // the hypotheses being split in this round
-    L.offChildG = o;     o += nc * 8;               // surviving children of the round: gain, state slot, (parent, column)
+    int ncP = 1;
+    while (ncP <= nc) ncP <<= 1;                   // (the gains: padded to a power of two for the merge's searches)
+    L.offChildG = o;     o += ncP * 8;              // surviving children of the round: gain, state slot, (parent, column)
     L.offChildS = o;     o += nc * 4;
     L.offChildC = o;     o += nc * 4;
     o = (o + 7) & ~7;
+    L.offSample = o;     o += WIDE_SAMPLES * 8;
     L.offRed = o;        o += nw * 8;
-    L.offCtrl = o;       o += 320;                  // struct WideCtrl
+    L.offCtrl = o;       o += WIDE_CTRL_BYTES;      // struct WideCtrl
     o = (o + 15) & ~15;
     L.offTile = o;       if (tile) o += maxRow * maxRow * 8;
     L.total = (o + 15) & ~15;

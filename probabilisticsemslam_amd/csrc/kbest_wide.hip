@@ -50,10 +50,10 @@ struct WideCtrl {
     int nsel;        // hypotheses split in this round
     int nEmit;       // pool entries emitted in this round (the first nEmit)
     int lastSel;     // pool index of the last selected entry: every not yet split entry up to it is selected
-    int selIdx[8], selSid[8], selA[8], selOff[9];  // the selected entries: pool index, state slot, active column, first ticket
-    double selG[8];  //   and gain
+    int selIdx[WIDE_MAX_SPEC], selSid[WIDE_MAX_SPEC], selA[WIDE_MAX_SPEC], selOff[WIDE_MAX_SPEC + 1];  // the selected
+    double selG[WIDE_MAX_SPEC];  // entries: pool index, state slot, active column, first ticket, gain
 };
-static_assert(sizeof(WideCtrl) <= 320, "WideCtrl must fit the LDS slot reserved by wide_lds_layout");
+static_assert(sizeof(WideCtrl) <= WIDE_CTRL_BYTES, "WideCtrl must fit the LDS slot reserved by wide_lds_layout");
 constexpr int WIDE_SPLIT = 0x40000000;      // pool entry flag: children already generated
 constexpr int WIDE_SID_MASK = 0x3FFFFFFF;
 
@@ -242,6 +242,7 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
     double *childG = reinterpret_cast<double *>(smem + L.offChildG);
     int *childS = reinterpret_cast<int *>(smem + L.offChildS);
     int *childC = reinterpret_cast<int *>(smem + L.offChildC);
+    double *samp = reinterpret_cast<double *>(smem + L.offSample);  // every 64th gain of the current pool (merge)
     unsigned char *nodeBase = smem + L.offNode;  // the hypotheses being split in this round: copies of their saved states
     double *red = reinterpret_cast<double *>(smem + L.offRed);
     WideCtrl *ctrl = reinterpret_cast<WideCtrl *>(smem + L.offCtrl);
@@ -400,6 +401,7 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
                 if (lane == 0) {  // the pool starts with the root, not yet emitted, not yet split
                     poolG[0] = g;
                     poolS[0] = 0;
+                    samp[0] = g;
                     ctrl->n = 1;
                     ctrl->emitted = 0;
                 }
@@ -509,11 +511,19 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
             }
             // -- the hypotheses being split come into LDS once (coalesced): every child reads its parent from there
             {
-                const int words = (int)(offTail + 16) >> 2;
-                for (int s2 = 0; s2 < nsel; s2++) {
-                    const int *src = reinterpret_cast<const int *>(stBase + (long long)uni32(ctrl->selSid[s2]) * p.stateStride);
-                    int *dst = reinterpret_cast<int *>(nodeBase + (size_t)s2 * L.nodeStride);
-                    for (int i = tid; i < words; i += NT) dst[i] = src[i];
+                const int words = (int)(offTail + 16) >> 2, total = nsel * words;
+                for (int i0 = tid; i0 < total; i0 += 4 * NT) {  // four loads in flight per thread
+                    int val[4], s2v[4], wv[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int i = i0 + e * NT < total ? i0 + e * NT : i0;
+                        s2v[e] = i / words;
+                        wv[e] = i - s2v[e] * words;
+                        val[e] = reinterpret_cast<const int *>(stBase + (long long)ctrl->selSid[s2v[e]] * p.stateStride)[wv[e]];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (i0 + e * NT < total) reinterpret_cast<int *>(nodeBase + (size_t)s2v[e] * L.nodeStride)[wv[e]] = val[e];
                 }
             }
             __syncthreads();
@@ -539,7 +549,8 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
                 t = uni32(t);
                 if (t >= totalItems) break;
                 int s2 = 0;
-                while (s2 + 1 < nsel && t >= ctrl->selOff[s2 + 1]) s2++;
+                for (int h = WIDE_MAX_SPEC >> 1; h >= 1; h >>= 1)  // the node of ticket t: last s2 with selOff[s2] <= t
+                    if (s2 + h < nsel && t >= ctrl->selOff[s2 + h]) s2 += h;
                 s2 = uni32(s2);
                 const int a = uni32(ctrl->selA[s2]), ps = uni32(ctrl->selSid[s2]);
                 const int c = a + (t - uni32(ctrl->selOff[s2]));
@@ -634,30 +645,110 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
             //    in this round are split now; the states of the emitted ones (all of them split by now) are released
             const int nChild = uni32(ctrl->nChild);
             for (int j = tid; j < nEmit; j += NT) freeList[atomicAdd(&ctrl->nFree, 1)] = srcS[j] & WIDE_SID_MASK;
-            for (int i = tid; i < nOld; i += NT) {
-                const int j = nEmit + i;
-                const double g = srcG[j];
-                const int s2 = srcS[j] | ((j <= lastSel) ? WIDE_SPLIT : 0);
-                int pos = i;
-                for (int q = 0; q < nChild; q++) pos += (childG[q] < g) ? 1 : 0;
-                if (pos < Rk) { dstG[pos] = g; dstS[pos] = s2; }
-                else freeList[atomicAdd(&ctrl->nFree, 1)] = s2 & WIDE_SID_MASK;
+            // the children first sort themselves in LDS (rank among the children: gain, then (parent, column)); an old
+            // entry then finds how many children go before it by a binary search there -- with k in the thousands
+            // (bruteForceProb) the pool is what is long, and a linear pass over the children per entry was the round
+            {
+                double cg[2];
+                int cs[2], cr[2];
+#pragma unroll
+                for (int e = 0; e < 2; e++) {  // wide_lds_layout: at most 1024 children per round, NT >= 512
+                    const int j = tid + e * NT;
+                    cr[e] = -1;
+                    if (j < nChild) {
+                        const double g = childG[j];
+                        const int cj = childC[j];
+                        int r = 0;
+                        for (int j2 = 0; j2 < nChild; j2++) {
+                            const double g2 = childG[j2];
+                            r += (g2 < g || (g2 == g && childC[j2] < cj)) ? 1 : 0;
+                        }
+                        cg[e] = g; cs[e] = childS[j]; cr[e] = r;
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < 2; e++)
+                    if (cr[e] >= 0) { childG[cr[e]] = cg[e]; childS[cr[e]] = cs[e]; }
+                __syncthreads();
+            }
+            // (four entries per thread and pass: four loads in flight, four searches of the same fixed depth side by side;
+            //  the sorted children are padded with +inf to a power of two P > nChild)
+            int P = 1;
+            while (P <= nChild) P <<= 1;
+            for (int j = nChild + tid; j < P; j += NT) childG[j] = INF;
+            // where a child goes: the number of pool entries <= its gain.  samp[] holds every 64th gain of the pool (kept
+            // up to date by whoever writes the pool): a wave finds the 64-entry block in LDS, then ONE coalesced read of
+            // that block and a ballot -- instead of a binary search of ~15 dependent HBM reads per child
+            const bool useSamp = (long long)k + 1 <= 64LL * WIDE_SAMPLES;
+            if (useSamp) {
+                const int ns = (n + 63) >> 6;
+                for (int j = wave; j < nChild; j += NWV) {
+                    const double g = childG[j];
+                    int q = 0;
+                    for (int base = 0; base < ns; base += 64) {
+                        const u64 m = __ballot(base + lane < ns && samp[base + lane] <= g);
+                        q += __popcll(m);
+                        if (m != ~0ull) break;
+                    }
+                    int ub = 0;
+                    if (q > 0) {
+                        const int idx = (q - 1) * 64 + lane;
+                        ub = (q - 1) * 64 + __popcll(__ballot(idx < n && srcG[idx] <= g));
+                    }
+                    if (lane == 0) childC[j] = ub > nEmit ? ub - nEmit : 0;  // (every emitted entry is <= any new child)
+                }
+            } else {
+                for (int j = tid; j < nChild; j += NT) {
+                    const double g = childG[j];
+                    int lo = 0, hi = nOld;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (srcG[nEmit + mid] <= g) lo = mid + 1; else hi = mid;
+                    }
+                    childC[j] = lo;
+                }
+            }
+            __syncthreads();
+            for (int i0 = tid; i0 < nOld; i0 += 4 * NT) {
+                double g[4];
+                int sv[4], lo[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int i = i0 + e * NT, j = nEmit + (i < nOld ? i : i0);
+                    g[e] = srcG[j];
+                    sv[e] = srcS[j] | ((j <= lastSel) ? WIDE_SPLIT : 0);
+                    lo[e] = 0;
+                }
+                for (int h = P >> 1; h >= 1; h >>= 1) {  // children with a smaller gain (ties: pool entries before new children)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) lo[e] += (childG[lo[e] + h - 1] < g[e]) ? h : 0;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int i = i0 + e * NT;
+                    if (i < nOld) {
+                        const int pos = i + lo[e];
+                        if (pos < Rk) {
+                            dstG[pos] = g[e];
+                            dstS[pos] = sv[e];
+                            if (useSamp && (pos & 63) == 0) samp[pos >> 6] = g[e];
+                        } else {
+                            freeList[atomicAdd(&ctrl->nFree, 1)] = sv[e] & WIDE_SID_MASK;
+                        }
+                    }
+                }
             }
             for (int j = tid; j < nChild; j += NT) {
                 const double g = childG[j];
-                const int cj = childC[j];
-                int lo = 0, hi = nOld;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (srcG[nEmit + mid] <= g) lo = mid + 1; else hi = mid;
+                const int pos = childC[j] + j;
+                if (pos < Rk) {
+                    dstG[pos] = g;
+                    dstS[pos] = childS[j];
+                    if (useSamp && (pos & 63) == 0) samp[pos >> 6] = g;
+                } else {
+                    freeList[atomicAdd(&ctrl->nFree, 1)] = childS[j];
                 }
-                int pos = lo;
-                for (int j2 = 0; j2 < nChild; j2++) {
-                    const double g2 = childG[j2];
-                    pos += (g2 < g || (g2 == g && childC[j2] < cj)) ? 1 : 0;
-                }
-                if (pos < Rk) { dstG[pos] = g; dstS[pos] = childS[j]; }
-                else freeList[atomicAdd(&ctrl->nFree, 1)] = childS[j];
             }
             __syncthreads();
             if (tid == 0) {
