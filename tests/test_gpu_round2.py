@@ -220,3 +220,39 @@ def test_mid_size_frames_take_the_general_pipeline_without_a_host_round_trip(eng
         want[:, idx[: len(idx) - m]] = po[:, : len(idx) - m]
         want[:, l] = po[:, len(idx) - m]
         np.testing.assert_allclose(p, want, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("knobs", [{"KBEST_WIDE_NW": "8"}, {"KBEST_WIDE_NW": "16"}, {"KBEST_WIDE_TILE": "1", "KBEST_WIDE_NW": "8"},
+                                   {"KBEST_WIDE_TILE": "0"}, {"KBEST_WIDE_SPEC": "1"}, {"KBEST_WIDE_SPEC": "64"}])
+def test_general_size_kernel_launch_shapes(monkeypatch, knobs):
+    """Every launch shape of the general-size kernel (8 / 16 waves per problem, cost copy in LDS or in HBM, 1 ... 64
+    hypotheses split per round) returns the reference's enumeration: the knobs only move work around."""
+    for key, val in knobs.items():
+        monkeypatch.setenv(key, val)
+    monkeypatch.setenv("KBEST_FORCE_WIDE", "1")
+    e = pk.KBestEngine(0)
+    rng = np.random.default_rng(77)
+    for N, M, k, B in ((96, 96, 40, 2), (70, 33, 60, 3), (30, 10, 3000, 2), (64, 64, 100, 2), (20, 20, 300, 2), (140, 12, 50, 1)):
+        costs = rng.random((B, N * M)) * 12
+        nf, r4c, c4r, g = e.kbest(costs, N, M, k)[:4]
+        onf, or4c, oc4r, og, _ = ol.orc_kbest_batch(costs, N, M, k)
+        assert (nf == onf).all(), (knobs, N, M, k)
+        for b in range(B):
+            n = int(nf[b])
+            assert (r4c[b, :n] == or4c[b, :n]).all(), (knobs, N, M, k, b)
+            assert (g[b, :n].view(np.int64) == og[b, :n].view(np.int64)).all(), (knobs, N, M, k, b)
+    e.close()
+
+
+def test_k_beyond_the_sampled_pool_index(engine):
+    """k above 65 535: the merge's LDS index of the pool (every 64th gain) no longer covers it and the insertion points
+    come from a binary search over the pool in HBM; a 9 x 9 problem has 362 880 assignments to draw from."""
+    rng = np.random.default_rng(9)
+    N = M = 9
+    k = 70000
+    costs = rng.random((1, N * M)) * 4
+    nf, r4c, c4r, g = engine.kbest(costs, N, M, k)[:4]
+    onf, or4c, oc4r, og = ol.orc_kbest(costs[0], N, M, k)
+    assert nf[0] == onf == k
+    assert (g[0].view(np.int64) == og.view(np.int64)).all()
+    assert (r4c[0] == or4c).all()
