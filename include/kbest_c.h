@@ -75,6 +75,7 @@ enum {
 #define KBEST_FLAG_COUNT_PUSHED 2u /* fill `pushed` with the reference's push count */
 #define KBEST_FLAG_RECT_ROOT 4u    /* internal (kbest_assign_batch_f64): numCol augmentations on the rectangular problem */
 #define KBEST_FLAG_NO_SHIFT 8u     /* internal (kbest_assign_batch_f64): the cost matrix is already non-negative         */
+#define KBEST_FLAG_NO_T0 32u       /* do not use the a-priori threshold from combinations of the root's children (A/B tests) */
 #define KBEST_FLAG_EXACT_ROOT 16u  /* root LAP by the reference's own sequence of augmentations (no column reduction first)  */
 
 typedef struct kbest_opts {

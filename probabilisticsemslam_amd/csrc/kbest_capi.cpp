@@ -30,6 +30,7 @@ struct kbest_ctx {
     int ldsPerCU = 160 * 1024;
     int nCU = 256;
     int smallWaves = 0;  // waves per problem of the small-problem kernel; 0 = choose per launch (KBEST_SMALL_NW)
+    bool noT0 = false;        // KBEST_NO_T0: no a-priori threshold in the 64-row kernel (A/B tests)
     int wideNw = 0;           // KBEST_WIDE_NW: waves per problem of the general-size kernel (8 / 16; A/B tests)
     int wideTile = -1;        // KBEST_WIDE_TILE: 0 / 1 force the cost copy out of / into LDS (A/B tests)
     int wideSpec = 0;         // KBEST_WIDE_SPEC: hypotheses split per round by the general-size kernel (A/B tests)
@@ -258,6 +259,7 @@ int kbest_create(kbest_ctx **out, int device)
     ctx->forceSmall = getenv("KBEST_FORCE_SMALL") != nullptr;
     ctx->noPoll = getenv("KBEST_NO_POLL") != nullptr;
     ctx->exactRoot = getenv("KBEST_EXACT_ROOT") != nullptr;
+    if (const char *e = getenv("KBEST_NO_T0")) ctx->noT0 = atoi(e) != 0;
     if (const char *e = getenv("KBEST_WIDE_NW")) { const int w = atoi(e); if (w == 8 || w == 16) ctx->wideNw = w; }
     if (const char *e = getenv("KBEST_WIDE_TILE")) ctx->wideTile = atoi(e) ? 1 : 0;
     if (const char *e = getenv("KBEST_WIDE_SPEC")) { const int w = atoi(e); if (w >= 1 && w <= kb::WIDE_MAX_SPEC) ctx->wideSpec = w; }
@@ -541,7 +543,7 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         p.k = k;
         p.maximize = opts->maximize;
         p.useCutoff = opts->use_cutoff;
-        p.flags = opts->flags | (ctx->exactRoot ? KBEST_FLAG_EXACT_ROOT : 0u);
+        p.flags = opts->flags | (ctx->exactRoot ? KBEST_FLAG_EXACT_ROOT : 0u) | (ctx->noT0 ? KBEST_FLAG_NO_T0 : 0u);
         p.cutoff = opts->cutoff;
         p.rootColOffset = opts->root_col_offset;
         p.rootColStride = opts->root_col_stride;

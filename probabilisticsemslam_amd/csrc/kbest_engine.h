@@ -109,7 +109,7 @@ __host__ __device__ inline Lds lds_layout(int maxRow, int k, int spec, int nWave
     L.offSurv = o;       o += spec * 64 * 2;         // children that passed the filter: (last-arc bound / 7 bits, node, column)
     L.offFreshS = o;     o += spec * 64 * 2;         //   own state slot of the surviving children
     o = (o + 7) & ~7;
-    L.offCtrl = o;       o += 208;                   // struct Ctrl
+    L.offCtrl = o;       o += 216;                   // struct Ctrl
     o = (o + 15) & ~15;
     L.offGainW = o;      o += nWaves * 512;          // one line of gain terms per wave (calcGain)
     L.total = (o + 15) & ~15;

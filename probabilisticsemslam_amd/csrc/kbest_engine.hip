@@ -360,8 +360,97 @@ struct Ctrl {
     short selIdx[16];          // pool index of each node selected in the last A phase (they are split in the next B)
     unsigned short selSid[16]; // and its state slot
     int partsDone[16];         // waves that have finished their part of a node's first-step filter (the last one compacts)
+    double t0;                 // a-priori threshold on the k-th best gain (apriori_threshold), +inf when unknown
 };
-static_assert(sizeof(Ctrl) <= 208, "Ctrl must fit the LDS slot reserved by lds_layout");
+static_assert(sizeof(Ctrl) <= 216, "Ctrl must fit the LDS slot reserved by lds_layout");
+
+
+// A-priori threshold on the k-th best gain, computed once per problem when the root's children are solved (round 1).
+// Every child of the root differs from the optimum by ONE alternating path ("atom": extra cost d_i, rows moved m_i).
+// Atoms that move disjoint rows touch disjoint columns, so applying several of them at once is again an assignment, it
+// costs the sum, and different atom sets give different assignments (the symmetric difference with the optimum
+// decomposes uniquely into its paths).  Singles, pairs, triples of the 16 cheapest and quadruples of the 8 cheapest
+// atoms are a few thousand KNOWN assignments: the (k-1)-th smallest of their costs, plus the optimum, bounds the k-th
+// best gain from above -- 1.7-3.5x the true gap on 64x64, k = 200 -- while the pool has no threshold at all yet
+// (round 1 would otherwise complete every child of 8 hypotheses) and only a loose one for some rounds after.
+// The (k-1)-th smallest is bracketed by bisection on the value: every thread keeps its share of the combinations in
+// registers and counts those <= x; the upper end of the bracket is a valid bound whatever the precision.
+// A separate function on purpose: its registers must not count against the round loop's.
+constexpr int T0_SCRATCH = 160;  // u64 words of LDS scratch: sorted costs [64], masks [64], one counter per bisection step [32 x i32]
+template <int NW>
+__device__ __attribute__((noinline)) void apriori_threshold(u64 *scratch, const u64 *atoms, double *t0Out, int D, int k)
+{
+    constexpr int NT = NW * 64, SLOTS = (4096 + NT - 1) / NT;  // NW >= 8: at most 8 grid slots per thread and kind
+    const double INF = d_inf();
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *sd = reinterpret_cast<double *>(scratch);  // atoms sorted by cost
+    u64 *sm = scratch + 64;                            // their row masks
+    int *cnt = reinterpret_cast<int *>(scratch + 128);
+    if (wave == 0) {
+        const double dl = lane < D ? __longlong_as_double((long long)atoms[2 * lane]) : INF;
+        const u64 ml = lane < D ? atoms[2 * lane + 1] : 0ull;
+        int rank = 0;
+        for (int j = 0; j < 64; j++) {
+            const double dj = readlane_f64(dl, j);
+            rank += (dj < dl || (dj == dl && j < lane)) ? 1 : 0;
+        }
+        sd[rank] = dl;
+        sm[rank] = ml;
+    }
+    if (tid < 32) cnt[tid] = 0;
+    __syncthreads();
+    const int nA = __popcll(__ballot(sd[lane] < INF));
+    if (nA < 2) return;  // (uniform)
+    double val[3 * SLOTS + 1];
+    val[3 * SLOTS] = tid < 64 ? sd[tid] : INF;  // singles
+#pragma unroll
+    for (int e = 0; e < SLOTS; e++) {
+        const int idx = tid + e * NT;
+        {   // pairs of all atoms
+            const int i = idx >> 6, j = idx & 63;
+            double x = INF;
+            if (idx < 4096 && i < j && j < nA && (sm[i] & sm[j]) == 0ull) x = sd[i] + sd[j];
+            val[e] = x;
+        }
+        {   // triples of the 16 cheapest
+            const int i = idx >> 8, j = (idx >> 4) & 15, l = idx & 15;
+            double x = INF;
+            if (idx < 4096 && i < j && j < l && l < nA) {
+                const u64 mi = sm[i], mj = sm[j], ml = sm[l];
+                if (((mi & mj) | (mi & ml) | (mj & ml)) == 0ull) x = (sd[i] + sd[j]) + sd[l];
+            }
+            val[SLOTS + e] = x;
+        }
+        {   // quadruples of the 8 cheapest
+            const int i = idx >> 9, j = (idx >> 6) & 7, l = (idx >> 3) & 7, q = idx & 7;
+            double x = INF;
+            if (idx < 4096 && i < j && j < l && l < q && q < nA) {
+                const u64 mi = sm[i], mj = sm[j], ml = sm[l], mq = sm[q];
+                if (((mi & mj) | (mi & ml) | (mi & mq) | (mj & ml) | (mj & mq) | (ml & mq)) == 0ull)
+                    x = ((sd[i] + sd[j]) + sd[l]) + sd[q];
+            }
+            val[2 * SLOTS + e] = x;
+        }
+    }
+    auto total_le = [&](double x, int step) -> int {  // block-wide number of combinations <= x (one barrier)
+        int n = 0;
+#pragma unroll
+        for (int e = 0; e <= 3 * SLOTS; e++) n += (val[e] <= x) ? 1 : 0;
+        int w = 0;
+#pragma unroll
+        for (int bit = 0; bit < 5; bit++) w += __popcll(__ballot((n >> bit) & 1)) << bit;  // n <= 25
+        if (lane == 0 && w) atomicAdd(&cnt[step], w);
+        __syncthreads();
+        return __builtin_amdgcn_readfirstlane(cnt[step]);
+    };
+    double hi = 2.0 * sd[nA - 1], lo = 0.0;  // every single and every pair is <= hi
+    if (total_le(hi, 0) < k - 1) return;
+    for (int step = 1; step <= 16; step++) {
+        const double mid = 0.5 * (lo + hi);
+        if (total_le(mid, step) >= k - 1) hi = mid; else lo = mid;
+    }
+    if (tid == 0) *t0Out = __longlong_as_double((long long)atoms[2 * D]) + hi;
+}
 
 // pool entry: gain (fp64), meta (u32: column | parent state << 8 | flags), own state slot (u16)
 constexpr unsigned short SID_NONE = 0xFFFFu;  // no saved state: re-solve from the parent when selected
@@ -451,7 +540,9 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     const int parkFrom = (!rect && !(p.flags & KBEST_FLAG_EXACT_ROOT) && M < N) ? M : 64;
     const int rl = lane < D ? lane : D - 1;
     const u64 allRows = (D >= 64) ? ~0ull : ((1ull << D) - 1ull);
-    const int maxSid = p.statesPerProblem;
+    // the last state slot of the problem is not a hypothesis: it holds the root's gain and, per child of the root, its
+    // distance from the optimum and the rows it moves (the a-priori threshold of round 1, below)
+    const int nSlots = p.statesPerProblem, maxSid = nSlots > p.lazyStates ? nSlots - 1 : nSlots;
 #ifdef KB_PROFILE
     unsigned long long profAcc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long profT0 = __builtin_readcyclecounter();
@@ -509,13 +600,25 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             ctrl->nSurvBack = 0;
             ctrl->selIdx[0] = -1;
             ctrl->selSid[0] = 0;
+            ctrl->t0 = INF;
             for (int i = 0; i < 16; i++) ctrl->partsDone[i] = 0;
         }
         __syncthreads();
         for (int i = tid; i < spec * 64; i += NT) { lbKey[i] = ~0ull; lbIn[i] = ~0u; }  // (`red` is dead now)
     }
 
-    unsigned char *stBase = p.states + (long long)b * maxSid * p.stateStride;
+    unsigned char *stBase = p.states + (long long)b * nSlots * p.stateStride;
+    u64 *atoms = reinterpret_cast<u64 *>(stBase + (long long)maxSid * p.stateStride);  // [2c] delta bits, [2c+1] row mask; [2D] root gain
+    // A-priori threshold (used from round 1 on): k - 1 known assignments besides the optimum bound the k-th best gain
+    // from above.  Off where the enumeration is not the whole problem's (root-subtree sharding), where pushes are
+    // counted or pruning is disabled, and where its scratch (the fresh list's LDS) would not fit.
+#ifdef KB_T0_VARIANT_A
+    const bool t0On = false;
+#else
+    const bool t0On = prune && k >= 3 && p.rootColStride <= 1 && !(p.flags & (KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_T0)) &&
+                      !rect && NW >= 8 && spec >= 3 && 16 * D + 8 <= (int)p.stateStride && p.statesPerProblem > p.lazyStates;
+#endif
+    if (t0On && tid < D) atoms[2 * tid] = 0x7ff0000000000000ull;  // +inf: no such child (yet)
     // saved hypothesis (HBM): u[D'] v[D'] (fp64) | row4col[D'] col4row[D'] (u8) | forb, gain, activeCol
     const long long outBase = (long long)b * k;
     const int DS = p.maxRow;
@@ -634,6 +737,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             save_node(nd, 0, v, r4c, c4r, forb, g, 0);
             if (p.dualU && lane < M) p.dualU[(long long)b * p.ldCol + lane] = nd.u[lane];  // MurtyHyp::u, per column (hpp:53)
             if (p.dualV && lane < N) p.dualV[(long long)b * p.ldRow + lane] = v;           // MurtyHyp::v, per row (hpp:55)
+            if (t0On && lane == 0) atoms[2 * D] = (u64)__double_as_longlong(g);
             if (lane == 0) {
                 ctrl->cutoffGain = maximize ? (g - p.cutoff) : (g + p.cutoff);          // cpp:681/684
                 const double gu = maximize ? (-g + ctrl->cdelta) : (g + ctrl->cdelta);  // cpp:599-603
@@ -654,9 +758,16 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
 
     KB_ACC(0, __builtin_readcyclecounter() - profT0);  // [0] set-up + root solve
     // ---- phase 2: rounds ----------------------------------------------------------------------------
-    while (uni32(ctrl->stop) == 0) {
+    for (int roundNo = 0; uni32(ctrl->stop) == 0; roundNo++) {
         KB_T(tRound);
         KB_ACC(7, 1);  // [7] rounds
+        if (t0On && roundNo == 1) {
+#ifndef KB_T0_VARIANT_B
+            apriori_threshold<NW>(lbKey, atoms, &ctrl->t0, D, k);
+#endif
+            for (int i = tid; i < T0_SCRATCH; i += NT) lbKey[i] = ~0ull;  // re-arm the filter minima
+            __syncthreads();
+        }
         // control values come out of LDS in VGPRs: readfirstlane makes them provably wave-uniform, so every
         // loop below is scalar-controlled.  They are only rewritten in D, behind a barrier.
         const int nsel = uni32(ctrl->nsel);
@@ -681,6 +792,8 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         // threshold of the pool: once it holds R candidates only children below its largest can matter
         double T = (nOld >= R) ? PG[head + R - 1] : INF;
         if (useCut && !maximize && cutG < T) T = cutG;
+        const double T0 = ctrl->t0;  // a-priori threshold (+inf until round 1, or when it is off)
+        if (T0 < T) T = T0;
         const double cmaxv = ctrl->cmax;
         KB_T(tF0);
         KB_ACC(14, tF0 - tRound);  // [14] round prologue (control reads)
@@ -907,6 +1020,16 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 const double g = serial_gain(Cs, LDC, lane, r4c, M, gainW);
                 if (useCut && (maximize ? (g < cutG) : (g > cutG))) continue;  // cutHyp, cpp:496/521
                 npush++;
+                if (t0On && sid == 0) {
+                    // a child of the root: the optimum with ONE alternating path/cycle applied.  Rows it moves (rows on
+                    // zero-padded columns count as one place):
+                    const int cOld = c4rP >= M ? M : c4rP, cNew = c4rN >= M ? M : c4rN;
+                    const u64 moved = __ballot(lane < D && cOld != cNew);
+                    if (lane == 0) {
+                        atoms[2 * c] = (u64)__double_as_longlong(g - nd.gain[0]);
+                        atoms[2 * c + 1] = moved;
+                    }
+                }
                 int slot = -1;
                 if (lane == 0) {
                     const int sl = atomicAdd(&ctrl->nextEager, 1);

@@ -34,4 +34,7 @@ for mi in range(4):
     cut = (g[nf0 - 1] - g[0]) * (1 + 1e-9)
     t_cut = run(cut)
     nf1 = int(d_nf[0])
-    print(f"matrix {mi}: plain {t_plain:.3f} ms (nf {nf0}), perfect threshold from the start {t_cut:.3f} ms (nf {nf1}): {100*(1-t_cut/t_plain):.1f}% less")
+    print(f"matrix {mi}: plain {t_plain:.3f} ms (nf {nf0}), perfect threshold from the start {t_cut:.3f} ms (nf {nf1}): {100*(1-t_cut/t_plain):.1f}% less; gap {cut:.4f}")
+    for f in (1.5, 2, 3, 5, 10, 20):  # a looser a-priori bound (e.g. the k-th cheapest 2-swap of the optimum: 10-20x the gap)
+        t = run(cut * f)
+        print(f"    threshold {f:4.1f} x gap: {t:.3f} ms ({100*(1-t/t_plain):.1f}% less)")
