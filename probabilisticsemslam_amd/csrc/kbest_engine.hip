@@ -119,7 +119,8 @@ __device__ __forceinline__ int dijkstra(const double *Cs, int LDC, const double 
     //   * the loop goes on while (sink not reached) and (minimum key < bound key): sign bit of (mhi - bndHi) & ~cc;
     //   * the truly rare cases -- a negative candidate (-1e-17 from rounding), a high-word tie that needs the low
     //     words reduced -- leave the loop in mid-step (status 1) and are finished below in C++, which re-enters.
-    // Fixed registers: v[60:61] spc, v62 pred, v63 key, s[80:81] delta, s82 cur / col4row of the chosen row, s83
+    // Fixed registers (all caller-saved in the AMDGPU calling convention, v20-v39: the kernel makes one call,
+    // apriori_threshold, and values that live across it want the callee-saved ones): v[24:25] spc, v26 pred, v27 key, s[80:81] delta, s82 cur / col4row of the chosen row, s83
     // chosen row, s[84:85] rows still to scan, s[86:87] rows scanned against this column, s[88:89] rows at the minimum.
     // Wait states (gfx950): VALU write -> DPP read 2, VALU VGPR write -> readlane 1, VALU SGPR write -> VALU read 2.
     for (;;) {
@@ -127,46 +128,46 @@ __device__ __forceinline__ int dijkstra(const double *Cs, int LDC, const double 
             "L_step%=:\n\t"
             "s_mul_i32 s94, s82, s91\n\t"
             "s_lshl3_add_u32 s95, s82, s92\n\t"
-            "v_add_u32_e32 v72, s94, v56\n\t"
-            "v_mov_b32_e32 v75, s95\n\t"
-            "ds_read_b64 v[68:69], v72\n\t"
-            "ds_read_b64 v[70:71], v75\n\t"
-            "v_mov_b32_e32 v73, s82\n\t"
+            "v_add_u32_e32 v36, s94, v20\n\t"
+            "v_mov_b32_e32 v39, s95\n\t"
+            "ds_read_b64 v[32:33], v36\n\t"
+            "ds_read_b64 v[34:35], v39\n\t"
+            "v_mov_b32_e32 v37, s82\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
-            "v_add_f64 v[66:67], s[80:81], v[68:69]\n\t"
-            "v_add_f64 v[66:67], v[66:67], -v[70:71]\n\t"
-            "v_add_f64 v[66:67], v[66:67], -v[58:59]\n\t"
-            "v_cmp_lt_f64_e32 vcc, v[66:67], v[60:61]\n\t"
+            "v_add_f64 v[30:31], s[80:81], v[32:33]\n\t"
+            "v_add_f64 v[30:31], v[30:31], -v[34:35]\n\t"
+            "v_add_f64 v[30:31], v[30:31], -v[22:23]\n\t"
+            "v_cmp_lt_f64_e32 vcc, v[30:31], v[24:25]\n\t"
             "s_and_b64 vcc, vcc, s[86:87]\n\t"
-            "v_cndmask_b32_e32 v61, v61, v67, vcc\n\t"
-            "v_cndmask_b32_e64 v63, v74, v61, s[86:87]\n\t"
-            "v_cndmask_b32_e32 v60, v60, v66, vcc\n\t"
-            "v_cndmask_b32_e32 v62, v62, v73, vcc\n\t"
-            "v_min_i32_dpp v64, v63, v63 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_e32 v25, v25, v31, vcc\n\t"
+            "v_cndmask_b32_e64 v27, v38, v25, s[86:87]\n\t"
+            "v_cndmask_b32_e32 v24, v24, v30, vcc\n\t"
+            "v_cndmask_b32_e32 v26, v26, v37, vcc\n\t"
+            "v_min_i32_dpp v28, v27, v27 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
             "s_nop 1\n\t"
-            "v_min_i32_dpp v64, v64, v64 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_min_i32_dpp v28, v28, v28 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
             "s_nop 1\n\t"
-            "v_min_i32_dpp v64, v64, v64 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "v_min_i32_dpp v28, v28, v28 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
             "s_nop 1\n\t"
-            "v_min_i32_dpp v64, v64, v64 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "v_min_i32_dpp v28, v28, v28 row_mirror row_mask:0xf bank_mask:0xf\n\t"
             "s_nop 1\n\t"
-            "v_min_i32_dpp v64, v64, v64 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+            "v_min_i32_dpp v28, v28, v28 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
             "s_nop 1\n\t"
-            "v_min_i32_dpp v64, v64, v64 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+            "v_min_i32_dpp v28, v28, v28 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
             "s_nop 0\n\t"
-            "v_readlane_b32 s81, v64, 63\n\t"
+            "v_readlane_b32 s81, v28, 63\n\t"
             "s_nop 1\n\t"
-            "v_cmp_eq_u32_e64 s[88:89], s81, v63\n\t"
+            "v_cmp_eq_u32_e64 s[88:89], s81, v27\n\t"
             "s_cmp_lt_i32 s81, 0\n\t"
             "s_cbranch_scc1 L_slow%=\n\t"
             "s_ff1_i32_b64 s83, s[88:89]\n\t"
             "s_bcnt1_i32_b64 s94, s[88:89]\n\t"
-            "v_readlane_b32 s80, v60, s83\n\t"
+            "v_readlane_b32 s80, v24, s83\n\t"
             "s_cmp_gt_u32 s94, 1\n\t"
             "s_cbranch_scc1 L_tie%=\n\t"
             "L_tail%=:\n\t"
             "s_sub_i32 s94, s81, s93\n\t"
-            "v_readlane_b32 s82, v57, s83\n\t"
+            "v_readlane_b32 s82, v21, s83\n\t"
             "s_bitset0_b64 s[84:85], s83\n\t"
             "s_mov_b64 s[86:87], s[84:85]\n\t"
             "s_andn2_b32 s94, s94, s82\n\t"
@@ -178,18 +179,18 @@ __device__ __forceinline__ int dijkstra(const double *Cs, int LDC, const double 
             "s_branch L_done%=\n\t"
             "L_tie%=:\n\t"
             "s_nop 1\n\t"
-            "v_cmp_lt_u32_e64 s[76:77], v60, s80\n\t"
+            "v_cmp_lt_u32_e64 s[76:77], v24, s80\n\t"
             "s_and_b64 s[76:77], s[76:77], s[88:89]\n\t"
             "s_cmp_eq_u64 s[76:77], 0\n\t"
             "s_cbranch_scc1 L_tail%=\n\t"
             "L_slow%=:\n\t"
             "s_mov_b32 s95, 1\n\t"
             "L_done%=:\n\t"
-            : "+{s[80:81]}"(dbits), "+{s82}"(cur), "+{s[84:85]}"(cand), "+{s[86:87]}"(act), "+{v[60:61]}"(sp),
-              "+{v62}"(pred), "={v63}"(khi), "={s83}"(closest), "={s[88:89]}"(eq), "={s95}"(status)
-            : "{v56}"(rowAddr), "{v57}"(c4r), "{v[58:59]}"(v), "{v74}"(keyInf), "{s91}"(ldc8), "{s92}"(uBase),
+            : "+{s[80:81]}"(dbits), "+{s82}"(cur), "+{s[84:85]}"(cand), "+{s[86:87]}"(act), "+{v[24:25]}"(sp),
+              "+{v26}"(pred), "={v27}"(khi), "={s83}"(closest), "={s[88:89]}"(eq), "={s95}"(status)
+            : "{v20}"(rowAddr), "{v21}"(c4r), "{v[22:23]}"(v), "{v38}"(keyInf), "{s91}"(ldc8), "{s92}"(uBase),
               "{s93}"(bndHi), "{s96}"(parkThr)
-            : "v64", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v75", "s76", "s77", "s94", "s97", "vcc", "scc",
+            : "v28", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v39", "s76", "s77", "s94", "s97", "vcc", "scc",
               "memory");
         // (the compiler does not know that outputs bound to physical scalar registers are wave-uniform)
         dbits = uni64(dbits);
