@@ -440,7 +440,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="c4", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--config", default="c4", choices=["c2", "c3", "c4", "c5", "w128"])
     ap.add_argument("--batch", type=int, default=None, help="matrices per GPU (default: the config's B)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: the config's batch PER GPU; strong: the config's batch in all (BASELINE configs[3] literally)")

@@ -567,16 +567,24 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
     }
     if (runWide) {
         const WidePlan w = plan_wide(ctx, B, maxRow, maxCol, k);
-        if (kb::wide_lds_layout(maxRow, maxCol, false).total > ctx->ldsLimit)
+        if (kb::wide_lds_layout(maxRow, maxCol, false, 8, 1).total > ctx->ldsLimit)
             return fail(ctx, KBEST_ERR_UNSUPPORTED, "problem too large for the general-size kernel's LDS");
+        // hypotheses split per round: counting the reference's pushes needs the reference's exact order of splits (1)
+        auto spec_for = [&](int nwv) {
+            int sp = (opts->flags & KBEST_FLAG_COUNT_PUSHED) ? 1 : (ctx->wideSpec > 0 ? ctx->wideSpec : kb::wide_spec(maxCol, nwv, k));
+            const int cap = kb::wide_spec_cap(maxCol, maxRow);
+            return sp > cap ? cap : sp;
+        };
         // up to ~128 rows the square cost copy fits LDS next to the waves' working sets: a cost column then comes
-        // from LDS instead of L2 at every Dijkstra step.  It costs residency (one workgroup per CU instead of two), so
-        // only a batch that leaves CUs idle anyway takes it (256 x 128x128: 16 ms instead of 19; 512: 38 instead of 37).
-        const bool tileFits = maxRow <= 128 && kb::wide_lds_layout(maxRow, maxCol, true, 16).total <= ctx->ldsLimit;
-        const bool tile = tileFits && (ctx->wideTile >= 0 ? ctx->wideTile == 1 : B <= ctx->nCU);
-        int nw = (tile || B <= ctx->nCU) ? 16 : 8;
+        // from LDS instead of L2 at every Dijkstra step.  It costs residency (one workgroup per CU), so only a batch
+        // that leaves CUs idle anyway takes it; such a batch also gets 16 waves per problem instead of 8.
+        int nw = (B <= ctx->nCU) ? 16 : 8;
         if (ctx->wideNw) nw = ctx->wideNw;
-        if (kb::wide_lds_layout(maxRow, maxCol, tile, nw).total > ctx->ldsLimit) nw = 8;
+        int spec = spec_for(nw);
+        bool tile = maxRow <= 128 && (ctx->wideTile >= 0 ? ctx->wideTile == 1 : B <= ctx->nCU) &&
+                    kb::wide_lds_layout(maxRow, maxCol, true, nw, spec).total <= ctx->ldsLimit;
+        if (!tile && kb::wide_lds_layout(maxRow, maxCol, false, nw, spec).total > ctx->ldsLimit) { nw = 8; spec = spec_for(nw); }
+        while (spec > 1 && kb::wide_lds_layout(maxRow, maxCol, tile, nw, spec).total > ctx->ldsLimit) spec--;
         int rc = reserve_wide(ctx, w, grow);
         if (rc != KBEST_OK) return rc;
         kb::WideParams p;
@@ -592,9 +600,7 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         p.minRows = runFast ? KBEST_MAX_DIM + 1 : 0;
         p.tile = tile ? 1 : 0;
         p.nw = nw;
-        // counting the reference's pushes needs the reference's exact order of splits: no speculation
-        p.spec = (opts->flags & KBEST_FLAG_COUNT_PUSHED) ? 1 : (ctx->wideSpec > 0 ? ctx->wideSpec : kb::wide_spec(maxCol, nw, k));
-        if (p.spec > kb::wide_spec_cap(maxCol, maxRow)) p.spec = kb::wide_spec_cap(maxCol, maxRow);
+        p.spec = spec;
         p.k = k;
         p.maximize = opts->maximize;
         p.useCutoff = opts->use_cutoff;

@@ -211,15 +211,16 @@ __host__ __device__ inline int wide_spec_cap(int maxCol, int maxRow)
     return s >= WIDE_MAX_SPEC ? WIDE_MAX_SPEC : (s >= 1 ? s : 1);
 }
 
-__host__ __device__ inline WideLds wide_lds_layout(int maxRow, int maxCol, bool tile, int nw = WIDE_NW)
+// (sized for the `spec` hypotheses actually split per round -- LDS decides how many problems a CU holds)
+__host__ __device__ inline WideLds wide_lds_layout(int maxRow, int maxCol, bool tile, int nw, int spec)
 {
     WideLds L;
-    const int nc = wide_spec_cap(maxCol, maxRow) * maxCol; // children of one round at most
+    const int nc = spec * maxCol;                  // children of one round at most
     int o = 0;
     L.waveStride = (20 * maxRow + 15) & ~15;       // per wave: u (fp64), col4row, row4col, pred (i32)
     L.offWave = o;       o += nw * L.waveStride;
     L.nodeStride = wide_node_stride(maxRow);       // copy of a saved hypothesis (wide_state_stride's content)
-    L.offNode = o;       o += wide_spec_cap(maxCol, maxRow) * L.nodeStride;  // the hypotheses being split in this round
+    L.offNode = o;       o += spec * L.nodeStride;  // the hypotheses being split in this round
     int ncP = 1;
     while (ncP <= nc) ncP <<= 1;                   // (the gains: padded to a power of two for the merge's searches)
     L.offChildG = o;     o += ncP * 8;              // surviving children of the round: gain, state slot, (parent, column)

@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int DS = p.maxRow;
-    const WideLds L = wide_lds_layout(DS, p.maxCol, TILE, NWV);
+    const WideLds L = wide_lds_layout(DS, p.maxCol, TILE, NWV, p.spec);
     double *uW = reinterpret_cast<double *>(smem + L.offWave + (size_t)wave * L.waveStride);
     int *c4rW = reinterpret_cast<int *>(uW + DS);
     int *r4cW = c4rW + DS;
@@ -779,7 +779,7 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
 template <int R, bool TILE, int NWV>
 static hipError_t launch_wide_rtn(const WideParams &p, int grid, hipStream_t stream)
 {
-    const WideLds L = wide_lds_layout(p.maxRow, p.maxCol, TILE, NWV);
+    const WideLds L = wide_lds_layout(p.maxRow, p.maxCol, TILE, NWV, p.spec);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kbest_wide_kernel<R, TILE, NWV>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
     if (e != hipSuccess) return e;

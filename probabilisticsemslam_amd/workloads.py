@@ -23,6 +23,8 @@ DENSE_CONFIGS = {
     "c2": (1024, 16, 16, 50, 0x5EED0000 + 16050),
     "c3": (4096, 32, 32, 200, 0x5EED0000 + 32200),
     "c4": (1024, 64, 64, 200, 0x5EED0000 + 64200),
+    # not a BASELINE config: the general-size kernel's profile case, same seed rule
+    "w128": (512, 128, 128, 200, 0x5EED0000 + 128200),
 }
 
 

@@ -10,7 +10,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     rng = np.random.default_rng(0)
     N, M, k, B = (int(x) for x in sys.argv[2:6])
     eng = pk.KBestEngine(0)
-    costs = torch.from_numpy(rng.random((B, N * M)) * 50).to(dev)
+    scale = float(os.environ.get("SCALE", "50"))
+    if os.environ.get("SPLITMIX"):
+        from probabilisticsemslam_amd import workloads as wl
+        costs = torch.from_numpy(wl.dense_batch(B, N, M, 0x5EED0000 + 1000 * N + k)).to(dev)
+    else:
+        costs = torch.from_numpy(rng.random((B, N * M)) * scale).to(dev)
     r4c = torch.empty((B, k, M), dtype=torch.int32, device=dev); c4r = torch.empty((B, k, N), dtype=torch.int32, device=dev)
     g = torch.empty((B, k), dtype=torch.float64, device=dev); nf = torch.empty(B, dtype=torch.int32, device=dev)
     ts = torch.cuda.Stream(device=dev); torch.cuda.set_stream(ts); s = ts.cuda_stream

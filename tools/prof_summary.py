@@ -11,7 +11,7 @@ from collections import defaultdict
 out = sys.argv[1]
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 cfg = sys.argv[3] if len(sys.argv) > 3 else "c4"
-BATCH = {"c2": 1024, "c3": 4096, "c4": 1024, "c5": 1000}.get(cfg)
+BATCH = {"c2": 1024, "c3": 4096, "c4": 1024, "c5": 1000, "w128": 512}.get(cfg)
 
 
 def rows(pattern):
