@@ -444,11 +444,21 @@ __device__ __attribute__((noinline)) void apriori_threshold(u64 *scratch, const 
         __syncthreads();
         return __builtin_amdgcn_readfirstlane(cnt[step]);
     };
-    double hi = 2.0 * sd[nA - 1], lo = 0.0;  // every single and every pair is <= hi
-    if (total_le(hi, 0) < k - 1) return;
-    for (int step = 1; step <= 16; step++) {
+    // bracket: the answer is of the order of the cheapest atoms' sums -- start at twice the 16th cheapest atom and double
+    // until k - 1 combinations are below (every single and every pair is <= twice the dearest atom), then 8 bisections
+    const double top = 2.0 * sd[nA - 1];
+    double hi = 2.0 * sd[nA > 16 ? 15 : nA - 1], lo = 0.0;
+    int step = 0;
+    for (;;) {
+        if (hi > top) hi = top;
+        if (total_le(hi, step++) >= k - 1) break;
+        if (hi >= top || step >= 12) return;  // fewer than k - 1 known assignments: no threshold (uniform)
+        lo = hi;
+        hi = 2.0 * hi;
+    }
+    for (int it = 0; it < 8; it++) {
         const double mid = 0.5 * (lo + hi);
-        if (total_le(mid, step) >= k - 1) hi = mid; else lo = mid;
+        if (total_le(mid, step++) >= k - 1) hi = mid; else lo = mid;
     }
     if (tid == 0) *t0Out = __longlong_as_double((long long)atoms[2 * D]) + hi;
 }
