@@ -378,8 +378,20 @@ static_assert(sizeof(Ctrl) <= 216, "Ctrl must fit the LDS slot reserved by lds_l
 // registers and counts those <= x; the upper end of the bracket is a valid bound whatever the precision.
 // A separate function on purpose: its registers must not count against the round loop's.
 constexpr int T0_SCRATCH = 160;  // u64 words of LDS scratch: sorted costs [64], masks [64], one counter per bisection step [32 x i32]
+constexpr int T0_EXTRA = 160;    // atoms learnt in round 1 (HBM, behind the root's)
+// words of the atoms area in HBM: [2c] cost bits, [2c+1] rows moved, of the root's child on column c (c < D); [2D] the
+// root's gain; [2D+1] number of learnt atoms; then T0_EXTRA x (cost bits, rows moved)
+__host__ __device__ inline int t0_area_bytes(int D) { return 8 * (2 * D + 2 + 2 * T0_EXTRA); }
+// phase 0 (top of round 1): the atoms are the root's children.  phase 1 (top of round 2): the children completed in
+// round 1 that differ from the optimum by ONE path too (they mostly are the second-best way through a region that one of
+// the eight best atoms already covers -- the alternatives that the true k best are full of) join them; the 64 cheapest
+// of all are used.  They are distinct assignments (pool entries of one enumeration), each a single connected change of
+// the optimum, so the counting argument is the same: 1.2-1.8x the true gap instead of 1.7-3.5x.
+// `scratchWords`: u64 words of LDS available (the fresh list's gains); candidates beyond it are dropped (fewer known
+// assignments: a looser bound, still a bound).
 template <int NW>
-__device__ __attribute__((noinline)) void apriori_threshold(u64 *scratch, const u64 *atoms, double *t0Out, int D, int k)
+__device__ __attribute__((noinline)) void apriori_threshold(u64 *scratch, const u64 *atoms, double *t0Out, int D, int k,
+                                                            int phase, int scratchWords)
 {
     constexpr int NT = NW * 64, SLOTS = (4096 + NT - 1) / NT;  // NW >= 8: at most 8 grid slots per thread and kind
     const double INF = d_inf();
@@ -387,16 +399,51 @@ __device__ __attribute__((noinline)) void apriori_threshold(u64 *scratch, const 
     double *sd = reinterpret_cast<double *>(scratch);  // atoms sorted by cost
     u64 *sm = scratch + 64;                            // their row masks
     int *cnt = reinterpret_cast<int *>(scratch + 128);
-    if (wave == 0) {
-        const double dl = lane < D ? __longlong_as_double((long long)atoms[2 * lane]) : INF;
-        const u64 ml = lane < D ? atoms[2 * lane + 1] : 0ull;
-        int rank = 0;
-        for (int j = 0; j < 64; j++) {
-            const double dj = readlane_f64(dl, j);
-            rank += (dj < dl || (dj == dl && j < lane)) ? 1 : 0;
+    const double gRoot = __longlong_as_double((long long)atoms[2 * D]);
+    if (phase == 0) {
+        if (wave == 0) {
+            const double dl = lane < D ? __longlong_as_double((long long)atoms[2 * lane]) : INF;
+            const u64 ml = lane < D ? atoms[2 * lane + 1] : 0ull;
+            int rank = 0;
+            for (int j = 0; j < 64; j++) {
+                const double dj = readlane_f64(dl, j);
+                rank += (dj < dl || (dj == dl && j < lane)) ? 1 : 0;
+            }
+            sd[rank] = dl;
+            sm[rank] = ml;
         }
-        sd[rank] = dl;
-        sm[rank] = ml;
+    } else {
+        // candidates: every atom that can still matter (cost below the current threshold's gap), compacted into LDS
+        double *cd = reinterpret_cast<double *>(scratch + T0_SCRATCH);
+        const int candCap = (scratchWords - T0_SCRATCH) / 2;
+        u64 *cm = scratch + T0_SCRATCH + candCap;
+        int *ncand = reinterpret_cast<int *>(scratch + 144);
+        const double capGap = *t0Out - gRoot;  // (+inf when there is no threshold yet)
+        int nExtra = (int)(unsigned)atoms[2 * D + 1];
+        nExtra = nExtra > T0_EXTRA ? T0_EXTRA : nExtra;
+        if (tid < 64) { sd[tid] = INF; sm[tid] = 0ull; }
+        if (tid == 0) *ncand = 0;
+        __syncthreads();
+        for (int i = tid; i < D + nExtra; i += NT) {
+            const int w = i < D ? 2 * i : 2 * D + 2 + 2 * (i - D);
+            const double dl = __longlong_as_double((long long)atoms[w]);
+            if (dl < INF && dl <= capGap) {
+                const int pos = atomicAdd(ncand, 1);
+                if (pos < candCap) { cd[pos] = dl; cm[pos] = atoms[w + 1]; }
+            }
+        }
+        __syncthreads();
+        int nc = *ncand;
+        nc = nc > candCap ? candCap : nc;
+        for (int i = tid; i < nc; i += NT) {  // the 64 cheapest, sorted (ties by position)
+            const double dl = cd[i];
+            int rank = 0;
+            for (int j = 0; j < nc; j++) {
+                const double dj = cd[j];
+                rank += (dj < dl || (dj == dl && j < i)) ? 1 : 0;
+            }
+            if (rank < 64) { sd[rank] = dl; sm[rank] = cm[i]; }
+        }
     }
     if (tid < 32) cnt[tid] = 0;
     __syncthreads();
@@ -460,7 +507,7 @@ __device__ __attribute__((noinline)) void apriori_threshold(u64 *scratch, const 
         const double mid = 0.5 * (lo + hi);
         if (total_le(mid, step++) >= k - 1) hi = mid; else lo = mid;
     }
-    if (tid == 0) *t0Out = __longlong_as_double((long long)atoms[2 * D]) + hi;
+    if (tid == 0 && gRoot + hi < *t0Out) *t0Out = gRoot + hi;
 }
 
 // pool entry: gain (fp64), meta (u32: column | parent state << 8 | flags), own state slot (u16)
@@ -553,7 +600,9 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     const u64 allRows = (D >= 64) ? ~0ull : ((1ull << D) - 1ull);
     // the last state slot of the problem is not a hypothesis: it holds the root's gain and, per child of the root, its
     // distance from the optimum and the rows it moves (the a-priori threshold of round 1, below)
-    const int nSlots = p.statesPerProblem, maxSid = nSlots > p.lazyStates ? nSlots - 1 : nSlots;
+    const int nSlots = p.statesPerProblem;
+    const int atomSlots = (t0_area_bytes(D) + (int)p.stateStride - 1) / (int)p.stateStride;
+    const int maxSid = nSlots - atomSlots > p.lazyStates ? nSlots - atomSlots : nSlots;
 #ifdef KB_PROFILE
     unsigned long long profAcc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long profT0 = __builtin_readcyclecounter();
@@ -623,13 +672,14 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     // A-priori threshold (used from round 1 on): k - 1 known assignments besides the optimum bound the k-th best gain
     // from above.  Off where the enumeration is not the whole problem's (root-subtree sharding), where pushes are
     // counted or pruning is disabled, and where its scratch (the fresh list's LDS) would not fit.
-#ifdef KB_T0_VARIANT_A
-    const bool t0On = false;
-#else
     const bool t0On = prune && k >= 3 && p.rootColStride <= 1 && !(p.flags & (KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_T0)) &&
-                      !rect && NW >= 8 && spec >= 3 && 16 * D + 8 <= (int)p.stateStride && p.statesPerProblem > p.lazyStates;
-#endif
+                      !rect && NW >= 8 && spec >= 3 && maxSid < nSlots;
     if (t0On && tid < D) atoms[2 * tid] = 0x7ff0000000000000ull;  // +inf: no such child (yet)
+    if (t0On && tid == 0) atoms[2 * D + 1] = 0ull;                 // atoms learnt in round 1
+    // the second, sharper threshold (atoms learnt in round 1) needs the "one connected change" test: permutation cycles,
+    // i.e. square problems (on rectangular ones a change can be an open path through the unassigned rows)
+    const bool t1On = t0On && N == M && spec * 64 >= T0_SCRATCH + 64;
+    unsigned char *rootMap = smem + L.offRootMap;  // the optimum's col4row (lane = row)
     // saved hypothesis (HBM): u[D'] v[D'] (fp64) | row4col[D'] col4row[D'] (u8) | forb, gain, activeCol
     const long long outBase = (long long)b * k;
     const int DS = p.maxRow;
@@ -749,6 +799,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             if (p.dualU && lane < M) p.dualU[(long long)b * p.ldCol + lane] = nd.u[lane];  // MurtyHyp::u, per column (hpp:53)
             if (p.dualV && lane < N) p.dualV[(long long)b * p.ldRow + lane] = v;           // MurtyHyp::v, per row (hpp:55)
             if (t0On && lane == 0) atoms[2 * D] = (u64)__double_as_longlong(g);
+            if (t0On && lane < D) rootMap[lane] = (unsigned char)c4r;
             if (lane == 0) {
                 ctrl->cutoffGain = maximize ? (g - p.cutoff) : (g + p.cutoff);          // cpp:681/684
                 const double gu = maximize ? (-g + ctrl->cdelta) : (g + ctrl->cdelta);  // cpp:599-603
@@ -772,11 +823,14 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     for (int roundNo = 0; uni32(ctrl->stop) == 0; roundNo++) {
         KB_T(tRound);
         KB_ACC(7, 1);  // [7] rounds
-        if (t0On && roundNo == 1) {
-#ifndef KB_T0_VARIANT_B
-            apriori_threshold<NW>(lbKey, atoms, &ctrl->t0, D, k);
+        if ((t0On && roundNo == 1) || (t1On && roundNo == 2)) {
+            apriori_threshold<NW>(lbKey, atoms, &ctrl->t0, D, k, roundNo - 1, spec * 64);
+#ifdef KB_T0_DEBUG
+            __syncthreads();
+            if (tid == 0 && b < 4) printf("T0DBG b=%d round=%d t0gap=%.6f poolT=%.6f nOld=%d extra=%d\n", b, roundNo, ctrl->t0 - __longlong_as_double((long long)atoms[2 * D]),
+                                          (ctrl->nq - ctrl->head >= k - ctrl->emitted) ? PG[ctrl->head + k - ctrl->emitted - 1] - __longlong_as_double((long long)atoms[2 * D]) : -1.0, ctrl->nq - ctrl->head, (int)atoms[2 * D + 1]);
 #endif
-            for (int i = tid; i < T0_SCRATCH; i += NT) lbKey[i] = ~0ull;  // re-arm the filter minima
+            for (int i = tid; i < spec * 64; i += NT) lbKey[i] = ~0ull;  // re-arm the filter minima
             __syncthreads();
         }
         // control values come out of LDS in VGPRs: readfirstlane makes them provably wave-uniform, so every
@@ -804,6 +858,9 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         double T = (nOld >= R) ? PG[head + R - 1] : INF;
         if (useCut && !maximize && cutG < T) T = cutG;
         const double T0 = ctrl->t0;  // a-priori threshold (+inf until round 1, or when it is off)
+#ifdef KB_T0_DEBUG
+        if (tid == 0 && b < 2 && t0On) printf("T0DBG b=%d round=%02d poolgap=%.5f t0gap=%.5f emitted=%d nOld=%d\n", b, roundNo, T - __longlong_as_double((long long)atoms[2 * D]), T0 - __longlong_as_double((long long)atoms[2 * D]), emitted, nOld);
+#endif
         if (T0 < T) T = T0;
         const double cmaxv = ctrl->cmax;
         KB_T(tF0);
@@ -1031,6 +1088,31 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 const double g = serial_gain(Cs, LDC, lane, r4c, M, gainW);
                 if (useCut && (maximize ? (g < cutG) : (g > cutG))) continue;  // cutHyp, cpp:496/521
                 npush++;
+                if (t1On && roundNo == 1) {
+                    // a child of one of the root's best children: if it differs from the OPTIMUM by one cycle too (it mostly
+                    // is another way through the region its parent's path covers) it is one more atom for the second
+                    // threshold.  Rows moved against the optimum; one cycle <=> the orbit of a moved row under
+                    // "who holds my old column now" covers them all.
+                    const int rootC = (lane < D) ? (int)rootMap[lane] : -1;
+                    const u64 moved = __ballot(lane < D && c4rN != rootC);
+                    u64 seen = 0;
+                    if (moved) {
+                        const int r0 = __builtin_ctzll(moved);
+                        int r = r0, guard = 0;
+                        do {
+                            seen |= 1ull << r;
+                            const int col = __builtin_amdgcn_readlane(rootC, r);
+                            r = __builtin_amdgcn_readlane(r4c, col);
+                        } while (r != r0 && ++guard < 64);
+                    }
+                    if (moved != 0ull && seen == moved && lane == 0) {
+                        const unsigned pos = atomicAdd(reinterpret_cast<unsigned *>(&atoms[2 * D + 1]), 1u);
+                        if (pos < (unsigned)T0_EXTRA) {
+                            atoms[2 * D + 2 + 2 * pos] = (u64)__double_as_longlong(g - __longlong_as_double((long long)atoms[2 * D]));
+                            atoms[2 * D + 3 + 2 * pos] = moved;
+                        }
+                    }
+                }
                 if (t0On && sid == 0) {
                     // a child of the root: the optimum with ONE alternating path/cycle applied.  Rows it moves (rows on
                     // zero-padded columns count as one place):

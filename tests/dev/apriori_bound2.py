@@ -9,6 +9,8 @@ import oracle_lib as ol
 from probabilisticsemslam_amd import workloads as wl
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c4"
+OVERLAP = len(sys.argv) > 2
+DISJ = len(sys.argv) > 3
 _, N, M, k, seed = wl.DENSE_CONFIGS[cfg]
 batch = wl.dense_batch(6, N, M, seed)
 BIG = 1e6
@@ -31,7 +33,7 @@ def mask_of(a, b):
     return m
 
 def bound(d, ms):
-    order = np.argsort(d); d = np.array(d)[order]; ms = [ms[i] for i in order]; n = len(d)
+    order = np.argsort(d)[:64]; d = np.array(d)[order]; ms = [ms[i] for i in order]; n = len(d)
     vals = list(d) + [d[i] + d[j] for i in range(n) for j in range(i + 1, n) if ms[i] & ms[j] == 0]
     t16, t8 = min(n, 16), min(n, 8)
     vals += [d[i] + d[j] + d[l] for i, j, l in itertools.combinations(range(t16), 3) if ms[i] & ms[j] == 0 and ms[i] & ms[l] == 0 and ms[j] & ms[l] == 0]
@@ -60,7 +62,21 @@ for mi in range(6):
             v2, r2 = solve(C, range(c2), rowof, forb)
             if v2 is None: continue
             m2 = mask_of(r2, rowof)
-            if m2 & m: continue            # overlaps the parent's path
+            if m2 & m:                     # overlaps the parent's path: the grandchild against the ROOT, if that is ONE path
+                mr = mask_of(r2, root)
+                # connected? walk the permutation cycles of root^-1 o r2 over the moved columns
+                cols = [cc for cc in range(M) if r2[cc] != root[cc]]
+                colof_root = {int(root[cc]): cc for cc in range(M)}
+                seen = set(); ncyc = 0
+                for c0 in cols:
+                    if c0 in seen: continue
+                    ncyc += 1; cur = c0
+                    while cur not in seen:
+                        seen.add(cur); cur = colof_root[int(r2[cur])]
+                if ncyc == 1 and OVERLAP:
+                    masks.add(mr); extra.append((v2 - g[0], mr))
+                continue
+            if not DISJ: continue
             if m2 in masks: continue       # (maybe) a known atom
             masks.add(m2); extra.append((v2 - val, m2))
     b2 = bound([a[0] for a in atoms] + [e[0] for e in extra], [a[1] for a in atoms] + [e[1] for e in extra])
