@@ -84,7 +84,9 @@ int fail(kbest_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess)
 
 // Launch shape, tuned on MI355X (DESIGN.md sections 3, 8).  The 32 KiB cost tile of a 64-row problem limits a CU to three
 // resident matrices and 80 VGPRs limit it to 24 waves: {8 waves, 6 candidates, 3 matrices/CU} is the throughput shape,
-// {12 waves, 8 candidates, 2/CU} and {16 waves, 8 candidates, 1/CU} trade throughput for latency when the batch is small.
+// {12 waves, 12 candidates, 2/CU} and {16 waves, 16 candidates, 1/CU} trade throughput for latency when the batch is small.
+// (Since the a-priori thresholds bound the early rounds, speculative splits are cheap: 1 024 x 64x64 at 12 waves,
+//  8 / 10 / 12 candidates per round: 2.97 / 2.80 / 2.74 ms.)
 struct Shape { int nWaves, spec; };
 
 Shape choose_shape(const kbest_ctx *ctx, int B, int maxRow, int k)
@@ -93,14 +95,14 @@ Shape choose_shape(const kbest_ctx *ctx, int B, int maxRow, int k)
     // A batch that cannot fill the chip is a latency problem: the reference calls assignmentProb once per frame.
     // With at most one (two) matrices per CU the whole CU (half of it) goes to each: 16 (12) waves, 8 candidates per
     // round -- 64x64, k = 200 alone: 1.25 ms instead of 1.80; one 30x10 frame: 0.63 ms instead of 0.99.
-    if (B <= ctx->nCU) { s.nWaves = 16; s.spec = maxRow <= 32 ? 16 : 8; }  // small frames: 16 candidates (0.63 -> 0.57 ms), 64 rows: 8
-    else if (B <= 2 * ctx->nCU) { s.nWaves = 12; s.spec = 8; }
+    if (B <= ctx->nCU) { s.nWaves = 16; s.spec = 16; }  // 16 candidates per round (one 30x10 frame 0.63 -> 0.57 ms; 256 x 64x64 1.10 -> 1.03 ms)
+    else if (B <= 2 * ctx->nCU) { s.nWaves = 12; s.spec = 12; }
     else if (maxRow <= 32) { s.nWaves = 4; s.spec = 4; }
     else {
         // measured (64x64, k = 200, ms for 8 / 12 waves): B = 600: 2.28 / 2.48, 900: 3.35 / 3.05, 1024: 4.0 / 3.2,
         // 1100: 3.57 / 3.74, 1536: 4.27 / 4.60, 2048: 5.62 / 5.98, 8192: 19.4 / 21.9 -- three 8-wave matrices per CU win
         // except where they would leave a nearly empty second generation and two generations of 12-wave pairs fit
-        if (B > 3 * ctx->nCU && B <= 4 * ctx->nCU) { s.nWaves = 12; s.spec = 8; } else { s.nWaves = 8; s.spec = 6; }
+        if (B > 3 * ctx->nCU && B <= 4 * ctx->nCU) { s.nWaves = 12; s.spec = 12; } else { s.nWaves = 8; s.spec = 6; }
     }
     // the in-place pool merge holds at most 4 entries per thread: a long pool (bruteForceProb-style k in the
     // thousands, assignment.cpp:868) needs a bigger workgroup
@@ -108,7 +110,8 @@ Shape choose_shape(const kbest_ctx *ctx, int B, int maxRow, int k)
     if (ctx->nWaves > 0) s.nWaves = ctx->nWaves;
     if (ctx->spec > 0) s.spec = ctx->spec;
     if (s.spec > s.nWaves) s.spec = s.nWaves;
-    if (s.spec > 8 && s.nWaves < 16) s.spec = 8;  // only the 16-wave kernel carries 16 selection slots
+    if (s.spec > 8 && s.nWaves < 12) s.spec = 8;   // selection slots of the kernel: 8, 12 from 12 waves, 16 from 16 waves on
+    if (s.spec > 12 && s.nWaves < 16) s.spec = 12;
     while (s.spec > 1 && kb::lds_layout(maxRow, k, s.spec, s.nWaves).total > ctx->ldsLimit) s.spec /= 2;
     return s;
 }

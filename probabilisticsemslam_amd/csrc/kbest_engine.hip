@@ -1237,7 +1237,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         if (budget > spec) budget = spec;
         if (budget < 1) budget = 1;
         int mySel = -1, mySid = 0, nselNew = 0, nLazy = 0;
-        constexpr int MS = (NW >= 16) ? 16 : 8;  // candidates split per round at most (16 only in the 16-wave latency shape)
+        constexpr int MS = (NW >= 16) ? 16 : (NW >= 12 ? 12 : 8);  // candidates split per round at most
         int sIdx[MS], sSid[MS];
 #pragma unroll
         for (int w = 0; w < MS; w++) { sIdx[w] = -1; sSid[w] = 0; }
