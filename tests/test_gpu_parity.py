@@ -547,7 +547,7 @@ def test_brute_force_probs(eng):
         np.testing.assert_allclose(p, w, rtol=1e-12, atol=1e-15)
 
 
-@pytest.mark.parametrize("nw,spec", [(4, 4), (8, 6), (12, 8), (16, 8), (16, 16), (8, 1)])
+@pytest.mark.parametrize("nw,spec", [(4, 4), (8, 6), (12, 8), (12, 12), (16, 8), (16, 16), (8, 1), (8, 3)])
 def test_every_launch_shape(monkeypatch, nw, spec):
     """small batches now pick the latency shape (16 waves); every workgroup size / speculation depth the library can
     choose is pinned here against the oracle, whatever the batch size."""
