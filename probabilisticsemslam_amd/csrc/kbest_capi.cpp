@@ -318,7 +318,7 @@ static WidePlan plan_wide(const kbest_ctx *ctx, int B, int maxRow, int maxCol, i
     WidePlan w;
     // pool + children of one round + slack (anyCols: kbest_reserve does not know numCol -- the largest round over numCol <= maxRow)
     const int perRound = anyCols ? (maxRow > 1024 ? maxRow : (kb::WIDE_MAX_SPEC * maxRow < 1024 ? kb::WIDE_MAX_SPEC * maxRow : 1024)) : kb::wide_spec_cap(maxCol, maxRow) * maxCol;
-    w.statesPerProblem = k + perRound + 2;
+    w.statesPerProblem = k + perRound + 2 + kb::wide_atom_slots(maxRow, anyCols ? maxRow : maxCol);  // + the a-priori threshold's atoms
     w.poolStride = (long long)((k + 1 + 15) & ~15);
     w.freeStride = (long long)((w.statesPerProblem + 31) & ~31);
     w.cw = up((size_t)maxRow * maxRow * 8);

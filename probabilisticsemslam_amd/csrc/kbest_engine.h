@@ -184,6 +184,15 @@ struct WideParams {
 // forbidden rows (u32 per lane), gain, activeCol; whole 128-byte lines
 __host__ __device__ inline long long wide_state_stride(int maxRow) { return (24LL * maxRow + 256 + 16 + 127) & ~127LL; }
 
+// state slots at the end of a problem's work space that hold the atoms of the a-priori threshold: per column cost + rows
+// moved (rows per lane words), then the root's gain
+__host__ __device__ inline int wide_atom_slots(int maxRow, int maxCol)
+{
+    const int R = maxRow <= 64 ? 1 : (maxRow <= 128 ? 2 : (maxRow <= 256 ? 4 : 8));
+    const long long bytes = 8LL * ((long long)maxCol * (1 + R) + 1);
+    return (int)((bytes + wide_state_stride(maxRow) - 1) / wide_state_stride(maxRow));
+}
+
 struct WideLds { int offWave, waveStride, offNode, nodeStride, offChildG, offChildS, offChildC, offSample, offRed, offCtrl, offTile, total; };
 
 // tile: keep the shifted square cost copy in LDS instead of the HBM work space (when maxRow^2 * 8 bytes fit)
@@ -198,7 +207,10 @@ struct WideLds { int offWave, waveStride, offNode, nodeStride, offChildG, offChi
 // HBM round trips: 64 x 30x10, k = 20 000: 45 ms at 8 per round, 2 500 rounds): as many as the LDS copies allow.
 __host__ __device__ inline int wide_spec(int maxCol, int nw = 8, int k = 200)
 {
-    const int s = (nw == 16 ? 512 : 256) / (maxCol > 0 ? maxCol : 1), lo = nw == 16 ? 2 : 1;
+    // (re-scanned with the a-priori threshold in place, which makes the early rounds' speculative splits cheap: 16 waves,
+    //  256 x 128x128 at 2 / 4 / 8 per round 7.5 / 6.8 / 6.7 ms, 256 x 256x256 29.4 / 28.0 / 27.9, 256 x 64x64 3.0 / 2.5 / 2.3;
+    //  8 waves, 512 x 128x128 at 2 / 3 / 4 / 8: 13.2 / 13.0 / 13.0 / 19.6 -- the last one loses the second workgroup per CU)
+    const int s = (nw == 16 ? 1024 : 384) / (maxCol > 0 ? maxCol : 1), lo = nw == 16 ? 2 : 1;
     if (k >= 1024) return WIDE_MAX_SPEC;  // (clamped to wide_spec_cap by the caller)
     return s >= 8 ? 8 : (s >= lo ? s : lo);
 }

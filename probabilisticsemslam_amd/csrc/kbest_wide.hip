@@ -47,6 +47,7 @@ struct WideCtrl {
     int nFree;       // free state slots (stack in freeList)
     int nChild;      // children that survived this sweep
     int nextTicket;  // work queue over the children of the round
+    double t0;       // a-priori threshold (wide_apriori_threshold), +inf when unknown
     int nsel;        // hypotheses split in this round
     int nEmit;       // pool entries emitted in this round (the first nEmit)
     int lastSel;     // pool index of the last selected entry: every not yet split entry up to it is selected
@@ -215,6 +216,100 @@ __device__ __forceinline__ double wide_gain(const double *Cw, int D, int M, cons
 
 }  // namespace
 
+// A-priori threshold on the k-th best gain (the idea and the argument: apriori_threshold, kbest_engine.hip): every child of
+// the root differs from the optimum by one alternating path; children that move disjoint rows combine into further known
+// assignments (singles, pairs of the 64 cheapest, triples of the 16, quadruples of the 8 cheapest); the (k-1)-th smallest
+// of their costs bounds the k-th best gain while the pool has no threshold yet.  Row sets are W words here (row r = bit
+// r % 64 of word r / 64, W = rows per lane).  atoms: per column c (1 + W) words -- cost bits, rows moved --, then the root's gain.
+// sd / sm / cnt: LDS scratch (64 doubles, 64 x W words, 32 ints); cost: LDS, >= M doubles.
+template <int W, int NT>
+__device__ __attribute__((noinline)) void wide_apriori_threshold(double *sd, u64 *sm, int *cnt, double *cost, const u64 *atoms,
+                                                                  int M, int k, double *t0Out)
+{
+    constexpr int SLOTS = (4096 + NT - 1) / NT;
+    const double INF = d_inf();
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int c = tid; c < M; c += NT) cost[c] = __longlong_as_double((long long)atoms[(long long)c * (1 + W)]);
+    if (tid < 64) sd[tid] = INF;
+    if (tid < 32) cnt[tid] = 0;
+    __syncthreads();
+    for (int c = tid; c < M; c += NT) {  // the 64 cheapest atoms, sorted (ties by column)
+        const double dl = cost[c];
+        int rank = 0;
+        for (int j = 0; j < M; j++) {
+            const double dj = cost[j];
+            rank += (dj < dl || (dj == dl && j < c)) ? 1 : 0;
+        }
+        if (rank < 64 && dl < INF) {
+            sd[rank] = dl;
+#pragma unroll
+            for (int w = 0; w < W; w++) sm[rank * W + w] = atoms[(long long)c * (1 + W) + 1 + w];
+        }
+    }
+    __syncthreads();
+    const int nA = __popcll(__ballot(sd[lane] < INF));
+    if (nA < 2) return;  // (uniform)
+    auto disjoint = [&](int i, int j) {
+        u64 x = 0;
+#pragma unroll
+        for (int w = 0; w < W; w++) x |= sm[i * W + w] & sm[j * W + w];
+        return x == 0ull;
+    };
+    double val[3 * SLOTS + 1];
+    val[3 * SLOTS] = tid < 64 ? sd[tid] : INF;
+#pragma unroll
+    for (int e = 0; e < SLOTS; e++) {
+        const int idx = tid + e * NT;
+        {
+            const int i = idx >> 6, j = idx & 63;
+            double x = INF;
+            if (idx < 4096 && i < j && j < nA && disjoint(i, j)) x = sd[i] + sd[j];
+            val[e] = x;
+        }
+        {
+            const int i = idx >> 8, j = (idx >> 4) & 15, l = idx & 15;
+            double x = INF;
+            if (idx < 4096 && i < j && j < l && l < nA && disjoint(i, j) && disjoint(i, l) && disjoint(j, l)) x = (sd[i] + sd[j]) + sd[l];
+            val[SLOTS + e] = x;
+        }
+        {
+            const int i = idx >> 9, j = (idx >> 6) & 7, l = (idx >> 3) & 7, q = idx & 7;
+            double x = INF;
+            if (idx < 4096 && i < j && j < l && l < q && q < nA && disjoint(i, j) && disjoint(i, l) && disjoint(i, q) &&
+                disjoint(j, l) && disjoint(j, q) && disjoint(l, q))
+                x = ((sd[i] + sd[j]) + sd[l]) + sd[q];
+            val[2 * SLOTS + e] = x;
+        }
+    }
+    auto total_le = [&](double x, int step) -> int {
+        int n = 0;
+#pragma unroll
+        for (int e = 0; e <= 3 * SLOTS; e++) n += (val[e] <= x) ? 1 : 0;
+        int w = 0;
+#pragma unroll
+        for (int bit = 0; bit < 5; bit++) w += __popcll(__ballot((n >> bit) & 1)) << bit;
+        if (lane == 0 && w) atomicAdd(&cnt[step], w);
+        __syncthreads();
+        return __builtin_amdgcn_readfirstlane(cnt[step]);
+    };
+    const double top = 2.0 * sd[nA - 1];
+    double hi = 2.0 * sd[nA > 16 ? 15 : nA - 1], lo = 0.0;
+    int step = 0;
+    for (;;) {
+        if (hi > top) hi = top;
+        if (total_le(hi, step++) >= k - 1) break;
+        if (hi >= top || step >= 12) return;  // fewer than k - 1 known assignments: no threshold
+        lo = hi;
+        hi = 2.0 * hi;
+    }
+    for (int it = 0; it < 8; it++) {
+        const double mid = 0.5 * (lo + hi);
+        if (total_le(mid, step++) >= k - 1) hi = mid; else lo = mid;
+    }
+    if (tid == 0) *t0Out = __longlong_as_double((long long)atoms[(long long)M * (1 + W)]) + hi;
+}
+
+
 #ifdef KB_PROFILE
 #define KW_T(var) const unsigned long long var = __builtin_readcyclecounter()
 #define KW_ACC(slot, expr) do { profAcc[slot] += (unsigned long long)(expr); } while (0)
@@ -256,7 +351,8 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
     double *poolG = p.poolG + ws * 2 * p.poolStride;
     int *poolS = p.poolS + ws * 2 * p.poolStride;
     int *freeList = p.freeList + ws * p.freeStride;
-    const int S = p.statesPerProblem;
+    const int atomSlots = wide_atom_slots(p.maxRow, p.maxCol);
+    const int S = p.statesPerProblem - atomSlots;  // the last slots hold the atoms of the a-priori threshold
     const int k = p.k;
     const bool maximize = p.maximize != 0, useCut = p.useCutoff != 0;
     const bool prune = (p.flags & KBEST_FLAG_NO_PRUNE) == 0;
@@ -274,6 +370,13 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
         }
         const int D = N;
         const double *Cg = p.cost + (p.costOff ? p.costOff[b] : (long long)b * p.ldRow * p.ldCol);
+        // a-priori threshold (top of round 1): needs the whole problem's enumeration (no root-subtree sharding), pruning, and
+        // LDS scratch in the node area: 64 x (1 + R) words + 32 counters, and M doubles in the children's gain list
+        u64 *atoms = reinterpret_cast<u64 *>(p.states + (ws * (long long)p.statesPerProblem + S) * p.stateStride);
+        const bool t0On = prune && k >= 3 && p.rootColStride <= 1 && !(p.flags & (KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_T0)) &&
+                          p.spec * L.nodeStride >= 64 * (1 + R) * 8 + 128 && p.spec * p.maxCol >= M;
+        if (t0On)
+            for (int c = tid; c < M; c += NT) atoms[(long long)c * (1 + R)] = 0x7ff0000000000000ull;  // +inf: no such child
         const long long outBase = (long long)b * k;
 #ifdef KB_PROFILE
         unsigned long long profAcc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -322,6 +425,7 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
                 ctrl->nFree = S - 1;
                 ctrl->nChild = 0;
                 ctrl->nextTicket = 0;
+                ctrl->t0 = INF;
             }
             __syncthreads();
         }
@@ -398,6 +502,7 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
                 const int r0 = uni32(r4cW[0]);
                 const u32 forb = (lane == (r0 & 63)) ? (1u << (r0 >> 6)) : 0u;  // cpp:235
                 store_state(0, v, forb, g, 0);
+                if (t0On && lane == 0) atoms[(long long)M * (1 + R)] = (u64)__double_as_longlong(g);
                 if (lane == 0) {  // the pool starts with the root, not yet emitted, not yet split
                     poolG[0] = g;
                     poolS[0] = 0;
@@ -428,6 +533,13 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
             const int *srcS = poolS + (long long)cur * p.poolStride;
             double *dstG = poolG + (long long)(1 - cur) * p.poolStride;
             int *dstS = poolS + (long long)(1 - cur) * p.poolStride;
+            if (t0On && round == 1) {
+                double *sd = reinterpret_cast<double *>(nodeBase);
+                u64 *sm = reinterpret_cast<u64 *>(nodeBase) + 64;
+                int *cnt = reinterpret_cast<int *>(reinterpret_cast<u64 *>(nodeBase) + 64 + 64 * R);
+                wide_apriori_threshold<R, NT>(sd, sm, cnt, childG, atoms, M, k, &ctrl->t0);
+                __syncthreads();
+            }
             // -- select + emission bookkeeping (wave 0)
             KW_T(tSel);
             KW_ACC(2, 1);  // [2] rounds
@@ -532,6 +644,7 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
             double T = (nOld >= Rk) ? srcG[nEmit + Rk - 1] : INF;
             const double cutG = ctrl->cutoffGain;
             if (useCut && !maximize && cutG < T) T = cutG;
+            if (ctrl->t0 < T) T = ctrl->t0;  // (+inf until round 1, or when it is off)
             const double cmaxv = ctrl->cmax;
 
             // -- children of the selected hypotheses (split, cpp:455-532), one wave each, dynamic queue over (node, column).
@@ -613,6 +726,24 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
                 KW_ACC(8, tE - tD);  // [8] gain
                 if (useCut && (maximize ? (g < cutG) : (g > cutG))) continue;  // cutHyp, cpp:496/521
                 npush++;
+                if (t0On && ps == 0) {  // a child of the root: the optimum with one alternating path applied -- cost and rows moved
+                    u64 mw[R];
+#pragma unroll
+                    for (int i = 0; i < R; i++) {
+                        const int r = lane + 64 * i;
+                        bool moved = false;
+                        if (r < D) {
+                            const int cOld = Pc4r[r] >= M ? M : Pc4r[r], cNew = c4rW[r] >= M ? M : c4rW[r];  // (zero-padded columns: one place)
+                            moved = cOld != cNew;
+                        }
+                        mw[i] = __ballot(moved);
+                    }
+                    if (lane == 0) {
+                        atoms[(long long)c * (1 + R)] = (u64)__double_as_longlong(g - pgain);
+#pragma unroll
+                        for (int i = 0; i < R; i++) atoms[(long long)c * (1 + R) + 1 + i] = mw[i];
+                    }
+                }
                 int sid = -1;
                 if (lane == 0) {
                     const int idx = atomicSub(&ctrl->nFree, 1) - 1;

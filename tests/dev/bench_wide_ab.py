@@ -26,8 +26,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     e1.record(); torch.cuda.synchronize()
     print(f"{e0.elapsed_time(e1)/3:.2f} ms  gsum {float(g.sum()):.9e}")
     sys.exit(0)
-shapes = [(128, 128, 200, 256), (128, 128, 200, 512), (64, 64, 200, 256), (96, 96, 200, 512), (256, 256, 200, 256), (100, 20, 200, 1024)]
-variants = [{"KBEST_WIDE_SPEC": str(x)} for x in (1, 2, 3, 4, 6, 8)]
+shapes = [(128, 128, 200, 256), (128, 128, 200, 512), (64, 64, 200, 256), (256, 256, 200, 256)]
+variants = [{"KBEST_WIDE_SPEC": str(x)} for x in (2, 3, 4, 6, 8)]
 for sh in shapes:
     for v in variants:
         env = dict(os.environ); env.update(v)
