@@ -419,6 +419,9 @@ __device__ __attribute__((noinline)) void apriori_threshold(u64 *scratch, const 
         u64 *cm = scratch + T0_SCRATCH + candCap;
         int *ncand = reinterpret_cast<int *>(scratch + 144);
         const double capGap = *t0Out - gRoot;  // (+inf when there is no threshold yet)
+        // (the counter is bumped by L2 atomics; a plain load that hit a line cached before them could only read a SMALLER
+        //  count -- fewer atoms, a looser bound, still a bound; the atoms themselves are plain stores of this workgroup's
+        //  waves, coherent through the CU's vector L1)
         int nExtra = (int)(unsigned)atoms[2 * D + 1];
         nExtra = nExtra > T0_EXTRA ? T0_EXTRA : nExtra;
         if (tid < 64) { sd[tid] = INF; sm[tid] = 0ull; }
