@@ -1266,6 +1266,29 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 m &= m - 1;
             }
         }
+        // The saved state of this wave's node: the loads are issued here and land in registers while wave 0 does the
+        // emission bookkeeping below (it has a node of its own to bring in, and would otherwise be the last at the barrier
+        // every round by exactly that bookkeeping).
+        const bool haveNode = wave < nselNew;
+        const bool lazyNode = haveNode && uni32((int)PS[mySel]) == (int)SID_NONE;
+        double ldU = 0.0, ldV = 0.0, ldGain = 0.0;
+        int ldR = 0, ldC = 0, ldA = 0;
+        u64 ldForb = 0;
+        if (haveNode && !lazyNode) {
+            const unsigned char *st = stBase + (long long)mySid * p.stateStride;
+            const double *sd = reinterpret_cast<const double *>(st);
+            if (lane < D) {
+                ldU = sd[lane];
+                ldV = sd[DS + lane];
+                ldR = st[offR4C + lane];
+                ldC = st[offC4R + lane];
+            }
+            if (lane == 0) {
+                ldForb = *reinterpret_cast<const u64 *>(st + offTail);
+                ldGain = *reinterpret_cast<const double *>(st + offTail + 8);
+                ldA = *reinterpret_cast<const int *>(st + offTail + 16);
+            }
+        }
         if (wave == 0 && lane == 0) {
             // emission: the head goes out while it has been split; a head selected in THIS round (not split yet)
             // is emitted too but ends the run, because its children are not in the pool yet
@@ -1310,23 +1333,20 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             for (int w = 0; w < MS; w++) { ctrl->selIdx[w] = (short)sIdx[w]; ctrl->selSid[w] = (unsigned short)sSid[w]; }
             if (stop) ctrl->stop = 1;
         }
-        if (wave < nselNew) {
+        if (haveNode) {
             const NodeRef nd = node_ref(smem + L.offNodes + (size_t)wave * L.nodeStride, p.maxRow);
-            const bool lazy = uni32((int)PS[mySel]) == (int)SID_NONE;
-            if (!lazy) {
-                // the hypothesis was kept when it was found: bring it in
-                const unsigned char *st = stBase + (long long)mySid * p.stateStride;
-                const double *sd = reinterpret_cast<const double *>(st);
+            if (!lazyNode) {
+                // the hypothesis was kept when it was found: its state is in registers by now
                 if (lane < D) {
-                    nd.u[lane] = sd[lane];
-                    nd.v[lane] = sd[DS + lane];
-                    nd.r4c[lane] = st[offR4C + lane];
-                    nd.c4r[lane] = st[offC4R + lane];
+                    nd.u[lane] = ldU;
+                    nd.v[lane] = ldV;
+                    nd.r4c[lane] = (unsigned char)ldR;
+                    nd.c4r[lane] = (unsigned char)ldC;
                 }
                 if (lane == 0) {
-                    nd.forb[0] = *reinterpret_cast<const u64 *>(st + offTail);
-                    nd.gain[0] = *reinterpret_cast<const double *>(st + offTail + 8);
-                    nd.info[0] = *reinterpret_cast<const int *>(st + offTail + 16);
+                    nd.forb[0] = ldForb;
+                    nd.gain[0] = ldGain;
+                    nd.info[0] = ldA;
                     nd.info[1] = mySid;
                 }
             } else {
