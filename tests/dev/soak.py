@@ -14,8 +14,8 @@ eng = pk.KBestEngine(0)
 t0 = time.time(); ncase = nprob = 0
 kinds = ["uniform", "ints", "inf", "blocks", "near", "scaled", "neg"]
 while time.time() - t0 < budget:
-    big = rng.random() < 0.12
-    N = int(rng.integers(65, 200)) if big else int(rng.integers(1, 65))
+    big = rng.random() < float(os.environ.get("SOAK_BIG", "0.12"))
+    N = int(rng.integers(65, int(os.environ.get("SOAK_BIGMAX", "200")))) if big else int(rng.integers(1, 65))
     M = int(rng.integers(1, N + 1)) if rng.random() < 0.6 else N
     k = int(rng.choice([1, 2, 3, 7, 50, 200, 300])) if not big else int(rng.choice([3, 20, 60]))
     B = int(rng.choice([1, 2, 5, 9]))
