@@ -678,7 +678,10 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
     HIP_TRY(ctx, dC4R.alloc(ctx, nC4R * 4));
     HIP_TRY(ctx, dGain.alloc(ctx, nG * 8));
     HIP_TRY(ctx, dNf.alloc(ctx, (size_t)B * 4));
-    HIP_TRY(ctx, hipMemcpy(dCost.p, cost, nCost * 8, hipMemcpyHostToDevice));
+    // (uniform layout, large batch: the second half of the cost blocks goes up while the first half is being solved, below)
+    const size_t outBytesEarly = ((size_t)B * k * maxCol + (size_t)B * k * maxRow) * 4 + (size_t)B * k * 8;
+    const bool splitUpload = !nRow && !costOff && B >= 4 * ctx->nCU && outBytesEarly >= ((size_t)32 << 20);
+    HIP_TRY(ctx, hipMemcpy(dCost.p, cost, (splitUpload ? (size_t)(B / 2) * maxRow * maxCol : nCost) * 8, hipMemcpyHostToDevice));
     if (nRow) {
         HIP_TRY(ctx, dNR.alloc(ctx, (size_t)B * 4));
         HIP_TRY(ctx, dNC.alloc(ctx, (size_t)B * 4));
@@ -694,18 +697,48 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
     HIP_TRY(ctx, hipMemsetAsync(dR4C.p, 0xFF, nR4C * 4, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(dC4R.p, 0xFF, nC4R * 4, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(dGain.p, 0, nG * 8, ctx->stream));
-    int rc = batch_dev_impl(ctx, opts, B, maxRow, maxCol, nRow ? dNR.as<int32_t>() : nullptr,
-                            nRow ? dNC.as<int32_t>() : nullptr, dCost.as<double>(),
-                            costOff ? dOff.as<int64_t>() : nullptr, k, dR4C.as<int32_t>(), dC4R.as<int32_t>(),
-                            dGain.as<double>(), dNf.as<int32_t>(), pushed ? dPushed.as<int64_t>() : nullptr,
-                            ctx->stream, true);
-    if (rc != KBEST_OK) return rc;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(row4col, dR4C.p, nR4C * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(col4row, dC4R.p, nC4R * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(gain, dGain.p, nG * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(nf, dNf.p, (size_t)B * 4, hipMemcpyDeviceToHost));
-    if (pushed) HIP_TRY(ctx, hipMemcpy(pushed, dPushed.p, (size_t)B * 8, hipMemcpyDeviceToHost));
+    // A large batch goes in two halves: the second half's kernel runs while the first half's tables (the bulk of the
+    // traffic: k x (numRow + numCol) int32 per problem) cross PCIe.  1 024 x 64x64, k = 200: 107 MB out, 5.7 -> 4.9 ms per
+    // call; the halves still fill the chip (>= 2 problems per CU each).
+    const size_t outBytes = (nR4C + nC4R) * 4 + nG * 8;
+    const int nChunk = (B >= 4 * ctx->nCU && outBytes >= ((size_t)32 << 20)) ? 2 : 1;
+    hipEvent_t done[2] = {nullptr, nullptr};
+    int rc = KBEST_OK;
+    int b0s[3] = {0, nChunk == 2 ? B / 2 : B, B};
+    for (int c = 0; c < nChunk && rc == KBEST_OK; c++) {
+        const int b0 = b0s[c], nb = b0s[c + 1] - b0;
+        if (c == 1 && splitUpload) {
+            const size_t off = (size_t)b0 * maxRow * maxCol;
+            const hipError_t e = hipMemcpy(dCost.as<double>() + off, cost + off, (nCost - off) * 8, hipMemcpyHostToDevice);
+            if (e != hipSuccess) { rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: upload", e); break; }
+        }
+        rc = batch_dev_impl(ctx, opts, nb, maxRow, maxCol, nRow ? dNR.as<int32_t>() + b0 : nullptr,
+                            nRow ? dNC.as<int32_t>() + b0 : nullptr,
+                            costOff ? dCost.as<double>() : dCost.as<double>() + (size_t)b0 * maxRow * maxCol,
+                            costOff ? dOff.as<int64_t>() + b0 : nullptr, k, dR4C.as<int32_t>() + (size_t)b0 * k * maxCol,
+                            dC4R.as<int32_t>() + (size_t)b0 * k * maxRow, dGain.as<double>() + (size_t)b0 * k,
+                            dNf.as<int32_t>() + b0, pushed ? dPushed.as<int64_t>() + b0 : nullptr, ctx->stream, true);
+        if (rc == KBEST_OK && nChunk == 2) {
+            if (hipEventCreateWithFlags(&done[c], hipEventDisableTiming) != hipSuccess || hipEventRecord(done[c], ctx->stream) != hipSuccess)
+                rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: event", hipGetLastError());
+        }
+    }
+    for (int c = 0; c < nChunk && rc == KBEST_OK; c++) {
+        const int b0 = b0s[c], nb = b0s[c + 1] - b0;
+        hipError_t e = (nChunk == 2) ? hipEventSynchronize(done[c]) : hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = hipMemcpy(row4col + (size_t)b0 * k * maxCol, dR4C.as<int32_t>() + (size_t)b0 * k * maxCol, (size_t)nb * k * maxCol * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(col4row + (size_t)b0 * k * maxRow, dC4R.as<int32_t>() + (size_t)b0 * k * maxRow, (size_t)nb * k * maxRow * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(gain + (size_t)b0 * k, dGain.as<double>() + (size_t)b0 * k, (size_t)nb * k * 8, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(nf + b0, dNf.as<int32_t>() + b0, (size_t)nb * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && pushed) e = hipMemcpy(pushed + b0, dPushed.as<int64_t>() + b0, (size_t)nb * 8, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: copy back", e);
+    }
+    for (int c = 0; c < 2; c++)
+        if (done[c]) (void)hipEventDestroy(done[c]);
+    if (rc != KBEST_OK) {
+        (void)hipStreamSynchronize(ctx->stream);  // nothing of this call may still be running when its buffers go back to the cache
+        return rc;
+    }
     for (int b = 0; b < B; b++)  // shapes were validated above: a negative count can only be an engine failure
         if (nf[b] < 0) return fail(ctx, nf[b] == -1 ? KBEST_ERR_UNSUPPORTED : KBEST_ERR_INTERNAL, "kbest_batch_f64: a problem came back with nf < 0");
     return KBEST_OK;

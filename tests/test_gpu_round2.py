@@ -312,3 +312,24 @@ def test_a_priori_threshold_keeps_the_enumeration_exact(engine):
             assert len({x[1] for x in got}) == n, "duplicate assignment"
             lastg = float(og[n - 1])
             assert [x for x in got if x[0] < lastg] == [x for x in want if x[0] < lastg], (N, M, k, maximize, cutoff)
+
+
+def test_host_entry_in_two_halves_equals_the_device_entry(engine):
+    """kbest_batch_f64 sends a batch that is large in problems AND in output bytes through the GPU in two halves (the
+    second half's kernel overlaps the first half's copy back): every table must equal what one launch over the whole
+    batch writes (device entry), and the first problems must equal the oracle."""
+    import torch
+    costs, N, M, k = wl.dense_config("c4", B=1024)
+    nf, r4c, c4r, g = engine.kbest(costs, N, M, k)[:4]
+    dev = torch.device("cuda", 0)
+    d_cost = torch.from_numpy(costs).to(dev)
+    d_r4c = torch.empty((1024, k, M), dtype=torch.int32, device=dev); d_c4r = torch.empty((1024, k, N), dtype=torch.int32, device=dev)
+    d_g = torch.empty((1024, k), dtype=torch.float64, device=dev); d_nf = torch.empty(1024, dtype=torch.int32, device=dev)
+    engine.kbest_dev(d_cost, 1024, N, M, k, d_r4c, d_c4r, d_g, d_nf)
+    torch.cuda.synchronize()
+    assert (nf == d_nf.cpu().numpy()).all()
+    assert (r4c == d_r4c.cpu().numpy()).all() and (c4r == d_c4r.cpu().numpy()).all()
+    assert (bits(g) == bits(d_g.cpu().numpy())).all()
+    for b in (0, 511, 512, 1023):
+        onf, or4c, oc4r, og = ol.orc_kbest(costs[b], N, M, k)
+        assert nf[b] == onf and (r4c[b] == or4c).all() and (bits(g[b]) == bits(og)).all()
