@@ -38,6 +38,12 @@ struct kbest_ctx {
     bool noPoll = false;      // KBEST_NO_POLL: zero-copy calls wait for the stream instead of polling the completion counter
     bool forceSmall = false;  // KBEST_FORCE_SMALL: every batch of <= 32-row problems through the small-problem kernel
     bool noSmall = false;  // KBEST_NO_SMALL: problems of <= 32 rows through the 64-row kernel as well (A/B tests)
+    bool forceWide = false;   // KBEST_FORCE_WIDE: everything through the general-size kernel (test hook; read once at create)
+    bool noLane = false;      // KBEST_NO_LANE: no lane-per-child kernel (A/B tests)
+    bool forceLane = false;   // KBEST_FORCE_LANE: every plain batch of <= 32-row problems through the lane-per-child kernel
+    int laneNw = 0;           // KBEST_LANE_NW: waves per problem of the lane-per-child kernel (1 / 2 / 4); 0 = choose per launch
+    int laneSpec = 0;         // KBEST_LANE_SPEC: hypotheses split per round there (1 .. 16); 0 = choose per launch
+    int laneG = 0;            // KBEST_LANE_G: lanes per child there (2 / 4); 0 = choose per launch
     int extraStates = 64;  // lazy state slots beyond k per matrix (room for speculative re-solves)
     int eagerStates = 1024; // state slots per matrix for children that are kept in full when they are found
     unsigned long long *prof = nullptr;  // diagnostic builds only (kbest_set_profile_buffer)
@@ -87,7 +93,7 @@ int fail(kbest_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess)
 // {12 waves, 12 candidates, 2/CU} and {16 waves, 16 candidates, 1/CU} trade throughput for latency when the batch is small.
 // (Since the a-priori thresholds bound the early rounds, speculative splits are cheap: 1 024 x 64x64 at 12 waves,
 //  8 / 10 / 12 candidates per round: 2.97 / 2.80 / 2.74 ms.)
-struct Shape { int nWaves, spec; };
+struct Shape { int nWaves, spec; int lanes = 4; };
 
 Shape choose_shape(const kbest_ctx *ctx, int B, int maxRow, int k)
 {
@@ -259,6 +265,12 @@ int kbest_create(kbest_ctx **out, int device)
         if (w == 2 || w == 4 || w == 8 || w == 16) ctx->smallWaves = w;
     }
     ctx->noSmall = getenv("KBEST_NO_SMALL") != nullptr;
+    ctx->forceWide = getenv("KBEST_FORCE_WIDE") != nullptr;
+    ctx->noLane = getenv("KBEST_NO_LANE") != nullptr;
+    ctx->forceLane = getenv("KBEST_FORCE_LANE") != nullptr;
+    if (const char *e = getenv("KBEST_LANE_NW")) { const int w = atoi(e); if (w == 1 || w == 2 || w == 4) ctx->laneNw = w; }
+    if (const char *e = getenv("KBEST_LANE_G")) { const int w = atoi(e); if (w == 2 || w == 4) ctx->laneG = w; }
+    if (const char *e = getenv("KBEST_LANE_SPEC")) { const int w = atoi(e); if (w >= 1 && w <= kb::LANE_MAX_SPEC) ctx->laneSpec = w; }
     ctx->forceSmall = getenv("KBEST_FORCE_SMALL") != nullptr;
     ctx->noPoll = getenv("KBEST_NO_POLL") != nullptr;
     ctx->exactRoot = getenv("KBEST_EXACT_ROOT") != nullptr;
@@ -399,6 +411,41 @@ static size_t small_states_need(int B, int maxRow, int maxCol, int k, int nw)
     return (size_t)B * (size_t)kb::small_states_per_problem(k, nw, maxCol) * (size_t)kb::small_state_stride(maxRow, maxCol) + 256;
 }
 
+// Launch shape of the lane-per-child kernel (kbest_lane.hip): waves per problem and hypotheses split per round.  A lane is a
+// child, so a round wants about a wave's worth of children per wave: spec * (columns left per hypothesis, ~ half of them).
+static Shape lane_shape(const kbest_ctx *ctx, int B, int maxRow, int maxCol, int k)
+{
+    Shape s;
+    // measured (kernel ms, 1 / 2 / 4 waves per problem): 1 024 x 16x16, k = 50 at 8 hypotheses per round 0.32 / 0.233 / 0.228;
+    // 4 096 x 32x32, k = 200 at 6 per round 6.3 / 5.4 / 6.0
+    s.nWaves = 2;
+    s.spec = maxRow <= 16 ? 8 : 6;
+    if (ctx->laneNw > 0) s.nWaves = ctx->laneNw;
+    if (ctx->laneSpec > 0) s.spec = ctx->laneSpec;
+    s.lanes = ctx->laneG > 0 ? ctx->laneG : 4;
+    while (k > 4 * s.nWaves * 64 && s.nWaves < 4) s.nWaves *= 2;  // the in-place pool merge holds at most 4 entries per thread
+    while (s.spec > 1 && kb::lane_lds_layout(maxRow, maxCol, k, s.spec, s.nWaves, s.lanes).total > ctx->ldsLimit) s.spec--;
+    (void)B;
+    return s;
+}
+
+static bool lane_fits(const kbest_ctx *ctx, int B, int maxRow, int maxCol, int k, Shape *shapeOut)
+{
+    if (ctx->noLane || maxRow > kb::LANE_MAX_DIM || maxCol > maxRow) return false;
+    const Shape s = lane_shape(ctx, B, maxRow, maxCol, k);
+    if (shapeOut) *shapeOut = s;
+    return k <= 4 * s.nWaves * 64 && kb::lane_states_per_problem(k, s.spec, maxCol) <= 65534 &&
+           kb::lane_lds_layout(maxRow, maxCol, k, s.spec, s.nWaves, s.lanes).total <= ctx->ldsLimit;
+}
+
+// bytes of the lane kernel's workspace (saved hypotheses, then the slot -> state table) and where the table starts
+static size_t lane_states_need(int B, int maxRow, int maxCol, int k, int spec, size_t *slotOff)
+{
+    const size_t nStates = (size_t)B * (size_t)kb::lane_states_per_problem(k, spec, maxCol) * (size_t)kb::lane_state_stride(maxRow);
+    if (slotOff) *slotOff = (nStates + 127) & ~(size_t)127;
+    return ((nStates + 127) & ~(size_t)127) + (size_t)B * (size_t)kb::slot_table_stride(k) * 2 + 256;
+}
+
 static int ensure_states(kbest_ctx *ctx, size_t need, bool grow)
 {
     if (need <= ctx->statesBytes) return KBEST_OK;
@@ -419,16 +466,32 @@ int kbest_reserve(kbest_ctx *ctx, int B, int maxRow, int k)
     std::lock_guard<std::mutex> lock(ctx->mu);
     const int fastRow = maxRow < KBEST_MAX_DIM ? maxRow : KBEST_MAX_DIM;
     const bool kFits = k_fits_fast(ctx, B, fastRow, k, 0, nullptr) || k_fits_fast(ctx, B, fastRow, k, KBEST_FLAG_COUNT_PUSHED, nullptr);
-    int snw = 0;
-    if (small_fits(ctx, B, maxRow, maxRow, k, false, &snw)) {
-        int rc = ensure_states(ctx, small_states_need(B, maxRow, maxRow, k, snw), true);
+    // "launches of up to B problems" (kbest_c.h): a smaller batch may pick another kernel or launch shape than B itself --
+    // the small-problem kernel takes more waves (and state slots) per problem as the batch shrinks, and numCol < numRow may
+    // change its shape too -- so the reservation is the maximum over every tier reachable with B' <= B.
+    if (maxRow <= kb::SMALL_MAX_DIM && !ctx->noSmall && k <= kb::SMALL_MAX_K) {
+        size_t need = 0;
+        const int tiers[3] = {B, B < 2 * ctx->nCU ? B : 2 * ctx->nCU, B < ctx->nCU ? B : ctx->nCU};
+        for (int t = 0; t < 3; t++)
+            for (int nw = 2; nw <= 16; nw *= 2) {
+                const size_t n = small_states_need(tiers[t], maxRow, maxRow, k, nw);
+                if (kb::small_lds_layout(maxRow, maxRow, k, nw, false).total <= ctx->ldsLimit && n > need) need = n;
+            }
+        if (need) {
+            int rc = ensure_states(ctx, need, true);
+            if (rc != KBEST_OK) return rc;
+        }
+    }
+    Shape lsh;
+    if (lane_fits(ctx, B, maxRow, maxRow, k, &lsh)) {
+        int rc = ensure_states(ctx, lane_states_need(B, maxRow, maxRow, k, lsh.spec, nullptr), true);
         if (rc != KBEST_OK) return rc;
     }
     if (kFits) {
         int rc = reserve_states(ctx, B, fastRow, k, true);
         if (rc != KBEST_OK) return rc;
     }
-    if (!kFits || maxRow > KBEST_MAX_DIM || getenv("KBEST_FORCE_WIDE"))  // (numCol <= numRow bounds the general-size plan)
+    if (!kFits || maxRow > KBEST_MAX_DIM || ctx->forceWide)  // (numCol <= numRow bounds the general-size plan)
         return reserve_wide(ctx, plan_wide(ctx, B, maxRow, maxRow, k, true), true);
     return KBEST_OK;
 }
@@ -479,7 +542,7 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
     Shape shape;
     const bool kFits = k_fits_fast(ctx, B, fastRow, k, opts->flags, &shape);
     const int spec = shape.spec, nWaves = shape.nWaves;
-    const bool forceWide = getenv("KBEST_FORCE_WIDE") != nullptr && !extra;  // test hook: everything through the general-size kernel
+    const bool forceWide = ctx->forceWide && !extra;  // test hook: everything through the general-size kernel
     const bool runFast = !forceWide && kFits && (maxRow <= KBEST_MAX_DIM || d_nRow != nullptr);
     const bool runWide = forceWide || !kFits || maxRow > KBEST_MAX_DIM;
     if (extra && runWide) return fail(ctx, KBEST_ERR_UNSUPPORTED, "assign2D / shortestPathCPP entry: numRow > KBEST_MAX_DIM");
@@ -496,6 +559,51 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
     // Which of the two wins was measured: the small kernel on rectangular problems (implicit zero columns:
     // a third of the Dijkstra steps) and on batches that cannot fill the chip (latency: 32 workers per problem, two
     // barriers per round); the 64-row kernel with its hand-written step loop on large batches of square problems.
+    // Dense batches of <= 32-row problems that fill the chip: the lane-per-child kernel (kbest_lane.hip).  Plain enumeration
+    // only (no push counting, no unpruned mode, no duals): those stay on the 64-row kernel.
+    Shape lsh;
+    // (measured: 1 024 x 16x16, k = 50: 0.23 ms against 0.325 on the 64-row kernel; 4 096 x 32x32, k = 200: 5.4 against 4.9 --
+    //  above 16 rows the 64-row kernel keeps the batch)
+    const bool laneWins = ctx->forceLane || (maxCol == maxRow && maxRow <= 16 && B > 2 * ctx->nCU && !ctx->forceSmall);
+    if (!extra && !forceWide && laneWins && !(opts->flags & (KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_PRUNE | KBEST_FLAG_RECT_ROOT |
+                                                                 KBEST_FLAG_NO_SHIFT | KBEST_FLAG_EXACT_ROOT)) &&
+        lane_fits(ctx, B, maxRow, maxCol, k, &lsh)) {
+        size_t slotOff = 0;
+        int rc = ensure_states(ctx, lane_states_need(B, maxRow, maxCol, k, lsh.spec, &slotOff), grow);
+        if (rc != KBEST_OK) return rc;
+        kb::Params p;
+        memset(&p, 0, sizeof(p));
+        p.cost = d_cost;
+        p.costOff = reinterpret_cast<const long long *>(d_costOff);
+        p.nRow = d_nRow;
+        p.nCol = d_nCol;
+        p.maxRow = maxRow;
+        p.maxCol = maxCol;
+        p.ldRow = maxRow;
+        p.ldCol = maxCol;
+        p.k = k;
+        p.maximize = opts->maximize;
+        p.useCutoff = opts->use_cutoff;
+        p.flags = opts->flags;
+        p.cutoff = opts->cutoff;
+        p.rootColOffset = opts->root_col_offset;
+        p.rootColStride = opts->root_col_stride;
+        p.row4col = d_row4col;
+        p.col4row = d_col4row;
+        p.gain = d_gain;
+        p.nf = d_nf;
+        p.pushed = reinterpret_cast<long long *>(d_pushed);
+        p.states = ctx->states;
+        p.stateStride = kb::lane_state_stride(maxRow);
+        p.statesPerProblem = kb::lane_states_per_problem(k, lsh.spec, maxCol);
+        p.lazyStates = p.statesPerProblem;
+        p.spec = lsh.spec;
+        p.prof = ctx->prof;
+        p.slotSid = reinterpret_cast<unsigned short *>(ctx->states + slotOff);
+        hipError_t e = kb::launch_kbest_lane(p, B, lsh.nWaves, lsh.lanes, s);
+        if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "lane-per-child kbest kernel launch", e);
+        return KBEST_OK;
+    }
     int snw = 0;
     const bool smallWins = ctx->forceSmall || maxCol < maxRow || B <= 2 * ctx->nCU;
     if (!extra && !forceWide && smallWins && !(opts->flags & (KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_PRUNE)) &&

@@ -328,6 +328,61 @@ __host__ __device__ inline SmallLds small_lds_layout(int maxRow, int maxCol, int
     return L;
 }
 
+// ---- lane-per-child kernel (kbest_lane.hip): numRow <= 32, dense batches.  One LANE per child of Murty's partition: the
+//      rows of a child's Dijkstra are an unrolled loop over registers (spc[DR], pred[DR] per lane), 64 children advance one
+//      step per pass; uses kb::Params (lazyStates, slotSid as in the 64-row kernel; every completed child is kept in full,
+//      state slots come from an LDS free list) ----
+constexpr int LANE_MAX_DIM = 32;
+constexpr int LANE_MAX_SPEC = 16;
+
+__host__ __device__ inline int lane_rows(int maxRow) { return maxRow <= 16 ? 16 : 32; }  // rows unrolled per lane (template DR)
+// saved hypothesis of the lane kernel: the 64-row kernel's layout with DR rows -- u[DR] v[DR] (fp64), row4col[DR] col4row[DR]
+// (u8), forbidden mask (u64), gain, activeCol; whole 128-byte lines
+__host__ __device__ inline long long lane_state_stride(int maxRow) { return state_stride(lane_rows(maxRow)); }
+// emitted + pool (<= k together) + the children completed in one round (<= spec * maxCol) + the root
+__host__ __device__ inline int lane_states_per_problem(int k, int spec, int maxCol) { return k + spec * maxCol + 2; }
+
+struct LaneLds {
+    int offC, offNodes, nodeStride, offPoolG, offFreshG, offPoolM, offFreshM, offPoolS, offFreshS, offItems, offComp, offFree, offScr,
+        scrStride, offCtrl, offGainW, total;
+};
+// node block (a hypothesis being split), DR = lane_rows: u[DR] v[DR] (fp64) | row4col[DR] col4row[DR] (u8) | cand[DR] (u32:
+// rows of the columns >= c) | gain, bound (fp64) | forbidden mask, activeCol, state slot (i32)
+__host__ __device__ inline int lane_node_bytes(int DR) { return 22 * DR + 32; }
+
+__host__ __device__ inline LaneLds lane_lds_layout(int maxRow, int maxCol, int k, int spec, int nWaves, int lanesPerChild)
+{
+    LaneLds L;
+    const int DR = lane_rows(maxRow), ldc = maxRow | 1, nc = spec * maxCol;
+    int o = 0;
+    L.offC = o;        o += maxRow * ldc * 8;            // shifted, zero-padded cost tile (column stride odd: lanes on different columns hit different banks)
+    o = (o + 15) & ~15;
+    // lanes of one wave read v[r] of DIFFERENT nodes in one instruction: a stride of 8 (mod 128) bytes puts them on different banks
+    L.nodeStride = ((lane_node_bytes(DR) + 119) & ~127) + 8;
+    if (L.nodeStride < lane_node_bytes(DR)) L.nodeStride += 128;
+    L.offNodes = o;    o += spec * L.nodeStride;
+    o = (o + 15) & ~15;
+    L.offPoolG = o;    o += k * 8;                       // sorted candidate pool: gain
+    o = (o + 15) & ~15;
+    L.offFreshG = o;   o += (nc > 16 ? nc : 16) * 8;     // children completed in this round (16-byte aligned: read as double2; phase 0's scratch)
+    L.offPoolM = o;    o += k * 4;                       //   (parent state, column, flags)
+    L.offFreshM = o;   o += nc * 4;
+    L.offPoolS = o;    o += k * 2;                       //   own state slot
+    L.offFreshS = o;   o += nc * 2;
+    L.offItems = o;    o += nc * 2;                      // children of this round: (node, column)
+    L.offComp = o;     o += nc * 2;                      // state slots of the children that reached their sink this round
+    L.offFree = o;     o += lane_states_per_problem(k, spec, maxCol) * 2;  // stack of free state slots
+    o = (o + 3) & ~3;
+    L.scrStride = 4 * DR + 4;                            // per finishing child: row4col, col4row (u8 each), (pred, pred's row) pairs
+    L.offScr = o;      o += nWaves * (64 / lanesPerChild) * L.scrStride;  // completed children are finished 64 / lanesPerChild at a time per wave
+    o = (o + 15) & ~15;
+    L.offCtrl = o;     o += 160;
+    L.offGainW = o;    o += 512;                         // wave 0: the root's scratch line
+    L.total = (o + 15) & ~15;
+    return L;
+}
+
+hipError_t launch_kbest_lane(const Params &p, int B, int nWaves, int lanesPerChild, hipStream_t stream);
 hipError_t launch_kbest_small(const SmallParams &p, int B, int nWaves, hipStream_t stream);
 hipError_t launch_kbest(const Params &p, int B, int nWaves, hipStream_t stream);
 hipError_t launch_kbest_wide(const WideParams &p, int grid, hipStream_t stream);

@@ -68,6 +68,22 @@ if small:
     print(f"  rounds {rounds:.1f}; per wave kernel cycles {tot/nw:.0f} = {tot/nw/max(rounds,1):.0f} per round; dijkstra cycles per pass {m[6]/max(m[11],1):.0f}; rows scanned per pass {m[10]/max(m[11],1):.1f}")
     print("  nf:", d_nf.cpu().numpy()[:8])
     sys.exit(0)
+if os.environ.get("KBEST_FORCE_LANE"):  # lane-per-child kernel (kbest_lane.hip)
+    nw = int(os.environ.get("KBEST_LANE_NW", "1" if N <= 16 else "2"))
+    names = ["setup+root", "stepping busy", "merge(+barriers)", "select/emit/node loads", "children started", "lane-steps (active children x passes)",
+             "children completed", "rounds (x waves)", "-", "passes", "cyc finishing completed", "wait after stepping", "wait after A", "kernel cyc (sum over waves)",
+             "round prologue", "wait after finishing"]
+    tot = m[13]
+    print(f"{cfg} B={B} lane kernel NW={nw} SPEC={os.environ.get('KBEST_LANE_SPEC','-')} kernel {ms:.3f} ms (profiled build)")
+    for i, n in enumerate(names):
+        extra = f"  = {100*m[i]/tot:5.1f}% of wave-cycles, {m[i]/nw:9.0f} cyc/wave" if i in (0, 1, 2, 3, 10, 11, 12, 14, 15) else ""
+        print(f"  [{i:2d}] {n:40s} {m[i]:14.1f}{extra}")
+    rounds = m[7] / nw
+    stepc = m[1]
+    print(f"  rounds {rounds:.1f}; kernel cycles per wave {tot/nw:.0f} = {tot/nw/max(rounds,1):.0f} per round; passes per round per wave {m[9]/nw/max(rounds,1):.1f}; "
+          f"cycles per pass {stepc/max(m[9],1):.0f}; lanes active per pass {m[5]/max(m[9],1):.1f}; steps per child {m[5]/max(m[4],1):.2f}; completed/started {m[6]/max(m[4],1):.2f}")
+    print("  nf:", d_nf.cpu().numpy()[:8])
+    sys.exit(0)
 names = ["setup+root", "B busy", "C merge(+barrier)", "A/D busy", "children started", "child steps", "children completed",
          "rounds", "cyc in child dijkstra", "cyc child set-up", "cyc flip+gain", "wait after B", "wait after A", "kernel cyc (sum over waves)",
          "round prologue", "first-step filter busy"]
