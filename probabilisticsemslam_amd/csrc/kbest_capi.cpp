@@ -416,10 +416,12 @@ static size_t small_states_need(int B, int maxRow, int maxCol, int k, int nw)
 static Shape lane_shape(const kbest_ctx *ctx, int B, int maxRow, int maxCol, int k)
 {
     Shape s;
-    // measured (kernel ms, 1 / 2 / 4 waves per problem): 1 024 x 16x16, k = 50 at 8 hypotheses per round 0.32 / 0.233 / 0.228;
-    // 4 096 x 32x32, k = 200 at 6 per round 6.3 / 5.4 / 6.0
-    s.nWaves = 2;
-    s.spec = maxRow <= 16 ? 8 : 6;
+    // measured (kernel ms; tests/dev/lane_sweep.py): a batch of up to four problems per CU is latency -- 4 waves per problem,
+    // 8 hypotheses per round (1 024 x 16x16, k = 50: 0.212; 2 waves: 0.235; the 64-row kernel 0.29) --, beyond that throughput --
+    // 2 waves (16 384 x 16x16, k = 200: 5.9 ms against 8.8 with 4 waves and 10.2 on the 64-row kernel); 8 hypotheses per round
+    // except for short enumerations (k = 10: 4 are 6 % faster)
+    s.nWaves = B <= 4 * ctx->nCU ? 4 : 2;
+    s.spec = (k <= 16 && B > 4 * ctx->nCU) ? 4 : 8;
     if (ctx->laneNw > 0) s.nWaves = ctx->laneNw;
     if (ctx->laneSpec > 0) s.spec = ctx->laneSpec;
     s.lanes = ctx->laneG > 0 ? ctx->laneG : 4;
@@ -562,9 +564,13 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
     // Dense batches of <= 32-row problems that fill the chip: the lane-per-child kernel (kbest_lane.hip).  Plain enumeration
     // only (no push counting, no unpruned mode, no duals): those stay on the 64-row kernel.
     Shape lsh;
-    // (measured: 1 024 x 16x16, k = 50: 0.23 ms against 0.325 on the 64-row kernel; 4 096 x 32x32, k = 200: 5.4 against 4.9 --
-    //  above 16 rows the 64-row kernel keeps the batch)
-    const bool laneWins = ctx->forceLane || (maxCol == maxRow && maxRow <= 16 && B > 2 * ctx->nCU && !ctx->forceSmall);
+    // Measured against the 64-row kernel (tests/dev/lane_sweep.py): up to 16 rows 1.2 - 1.7 x faster from B = 600 to 16 384 and
+    // k = 10 to 200; 17 - 32 rows (twice the rows per lane) 10 % faster only where the batch is small enough for 4 waves per
+    // problem and the enumeration long, else up to 20 % slower (4 096 x 32x32, k = 200: 5.4 ms against 4.9).  Batches that
+    // cannot fill the chip (B <= 2 CUs) stay on the small-problem kernel (16 waves per problem: 0.33 against 0.40 ms at
+    // 256 x 16x16, k = 200), rectangular ones too (implicit zero columns).
+    const bool laneWins = ctx->forceLane || (maxCol == maxRow && B > 2 * ctx->nCU && !ctx->forceSmall &&
+                                             (maxRow <= 16 || (B <= 4 * ctx->nCU && k >= 100)));
     if (!extra && !forceWide && laneWins && !(opts->flags & (KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_PRUNE | KBEST_FLAG_RECT_ROOT |
                                                                  KBEST_FLAG_NO_SHIFT | KBEST_FLAG_EXACT_ROOT)) &&
         lane_fits(ctx, B, maxRow, maxCol, k, &lsh)) {

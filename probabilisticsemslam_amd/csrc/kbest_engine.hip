@@ -187,8 +187,12 @@ __device__ __attribute__((noinline)) void apriori_threshold(u64 *scratch, const 
     __syncthreads();
     const int nA = __popcll(__ballot(sd[lane] < INF));
     if (nA < 2) return;  // (uniform)
-    double val[3 * SLOTS + 1];
-    val[3 * SLOTS] = tid < 64 ? sd[tid] : INF;  // singles
+    // Every thread keeps its share of the combinations in registers as floats ROUNDED UP and counts them against x rounded
+    // DOWN: a combination is counted only if it really is <= x, so the count can only be too small and the x at which it
+    // reaches k - 1 is still an upper bound of the (k-1)-th smallest (half the registers of fp64 values: the function fits the
+    // caller-saved registers and needs no stack).
+    float val[3 * SLOTS + 1];
+    val[3 * SLOTS] = __double2float_ru(tid < 64 ? sd[tid] : INF);  // singles
 #pragma unroll
     for (int e = 0; e < SLOTS; e++) {
         const int idx = tid + e * NT;
@@ -196,7 +200,7 @@ __device__ __attribute__((noinline)) void apriori_threshold(u64 *scratch, const 
             const int i = idx >> 6, j = idx & 63;
             double x = INF;
             if (idx < 4096 && i < j && j < nA && (sm[i] & sm[j]) == 0ull) x = sd[i] + sd[j];
-            val[e] = x;
+            val[e] = __double2float_ru(x);
         }
         {   // triples of the 16 cheapest
             const int i = idx >> 8, j = (idx >> 4) & 15, l = idx & 15;
@@ -205,7 +209,7 @@ __device__ __attribute__((noinline)) void apriori_threshold(u64 *scratch, const 
                 const u64 mi = sm[i], mj = sm[j], ml = sm[l];
                 if (((mi & mj) | (mi & ml) | (mj & ml)) == 0ull) x = (sd[i] + sd[j]) + sd[l];
             }
-            val[SLOTS + e] = x;
+            val[SLOTS + e] = __double2float_ru(x);
         }
         {   // quadruples of the 8 cheapest
             const int i = idx >> 9, j = (idx >> 6) & 7, l = (idx >> 3) & 7, q = idx & 7;
@@ -215,13 +219,14 @@ __device__ __attribute__((noinline)) void apriori_threshold(u64 *scratch, const 
                 if (((mi & mj) | (mi & ml) | (mi & mq) | (mj & ml) | (mj & mq) | (ml & mq)) == 0ull)
                     x = ((sd[i] + sd[j]) + sd[l]) + sd[q];
             }
-            val[2 * SLOTS + e] = x;
+            val[2 * SLOTS + e] = __double2float_ru(x);
         }
     }
-    auto total_le = [&](double x, int step) -> int {  // block-wide number of combinations <= x (one barrier)
+    auto total_le = [&](double x, int step) -> int {  // block-wide number of combinations <= x (one barrier); never too large
+        const float xf = __double2float_rd(x);
         int n = 0;
 #pragma unroll
-        for (int e = 0; e <= 3 * SLOTS; e++) n += (val[e] <= x) ? 1 : 0;
+        for (int e = 0; e <= 3 * SLOTS; e++) n += (val[e] <= xf) ? 1 : 0;
         int w = 0;
 #pragma unroll
         for (int bit = 0; bit < 5; bit++) w += __popcll(__ballot((n >> bit) & 1)) << bit;  // n <= 25
@@ -285,8 +290,8 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = NW * 64;
     const double INF = d_inf();
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
+    int tid = threadIdx.x;   // (not const: see the top of the round loop)
+    int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
     const int N = p.nRow ? p.nRow[b] : p.maxRow;
@@ -559,6 +564,10 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     KB_ACC(0, __builtin_readcyclecounter() - profT0);  // [0] set-up + root solve
     // ---- phase 2: rounds ----------------------------------------------------------------------------
     for (int roundNo = 0; uni32(ctrl->stop) == 0; roundNo++) {
+        // The compiler hoists every cheap expression of the lane number out of this loop (addresses, lane masks: two dozen of
+        // them) and then has to spill them at 80 VGPRs: a scratch load per use instead of one or two vector instructions.
+        // Making the lane number opaque once per round keeps those expressions where they are used.
+        asm volatile("" : "+v"(lane), "+v"(tid));
         KB_T(tRound);
         KB_ACC(7, 1);  // [7] rounds
         if ((t0On && roundNo == 1) || (t1On && roundNo == 2)) {

@@ -27,10 +27,14 @@ def run(eng, B, N, k):
     return e0.elapsed_time(e1) / 5, g.sum().item(), int(nf.sum().item())
 
 old = engine(KBEST_NO_LANE=1)
-lanes = {f"nw{nw}s{sp}": engine(KBEST_FORCE_LANE=1, KBEST_LANE_NW=nw, KBEST_LANE_SPEC=sp) for nw in (2, 4) for sp in (4, 8)}
-for N in (6, 8, 12, 16, 20, 24, 32):
+small = len(sys.argv) > 1 and sys.argv[1] == "small"
+if small:
+    lanes = {f"nw{nw}s{sp}": engine(KBEST_FORCE_LANE=1, KBEST_LANE_NW=nw, KBEST_LANE_SPEC=sp) for nw in (4,) for sp in (4, 8, 12, 16)}
+else:
+    lanes = {f"nw{nw}s{sp}": engine(KBEST_FORCE_LANE=1, KBEST_LANE_NW=nw, KBEST_LANE_SPEC=sp) for nw in (2, 4) for sp in (4, 8)}
+for N in ((8, 16, 24, 32) if small else (6, 8, 12, 16, 20, 24, 32)):
     for k in (10, 50, 200):
-        for B in (600, 1024, 4096, 16384):
+        for B in ((1, 64, 256, 512) if small else (600, 1024, 4096, 16384)):
             t0, g0, n0 = run(old, B, N, k)
             line = f"{N:2d}x{N:<2d} k={k:<3d} B={B:<5d} old {t0:7.3f} ms |"
             for name, e in lanes.items():

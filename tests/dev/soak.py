@@ -1,55 +1,16 @@
-"""Randomised soak: GPU enumeration against the oracle on many random shapes, flags and cost structures.
-python tests/dev/soak.py [seconds] [seed].  Development aid (not part of the -m gpu suite: it runs for minutes)."""
-import os, sys, time
-import numpy as np
+"""Randomised soak: GPU enumeration against the oracle on many random shapes, flags and cost structures (tests/soak_lib.py).
+python tests/dev/soak.py [seconds] [seed].  The -m gpu suite runs a bounded fixed-seed slice of the same generator."""
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import probabilisticsemslam_amd as pk
-import oracle_lib as ol
+import soak_lib
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-rng = np.random.default_rng(seed)
 eng = pk.KBestEngine(0)
-t0 = time.time(); ncase = nprob = 0
-kinds = ["uniform", "ints", "inf", "blocks", "near", "scaled", "neg"]
-while time.time() - t0 < budget:
-    big = rng.random() < float(os.environ.get("SOAK_BIG", "0.12"))
-    N = int(rng.integers(65, int(os.environ.get("SOAK_BIGMAX", "200")))) if big else int(rng.integers(1, 65))
-    M = int(rng.integers(1, N + 1)) if rng.random() < 0.6 else N
-    k = int(rng.choice([1, 2, 3, 7, 50, 200, 300])) if not big else int(rng.choice([3, 20, 60]))
-    B = int(rng.choice([1, 2, 5, 9]))
-    maximize = bool(rng.random() < 0.2)
-    cutoff = float(rng.random() * 2) if rng.random() < 0.25 else None
-    kind = kinds[int(rng.integers(len(kinds)))]
-    C = rng.random((B, N * M))
-    if kind == "ints": C = rng.integers(0, 4, (B, N * M)).astype(np.float64)
-    elif kind == "inf": C[rng.random((B, N * M)) < rng.random() * 0.8] = np.inf
-    elif kind == "blocks":
-        C = C * 5 + 10
-        for b in range(B):
-            Cm = C[b].reshape(M, N)
-            for c in range(M): Cm[c, (c * 7) % N] = rng.random() * 0.05; Cm[c, (c * 7 + 1) % N] = rng.random() * 0.05
-    elif kind == "near": C = 1.0 + C * 1e-9
-    elif kind == "scaled": C = C * 1e6
-    elif kind == "neg": C = C - 0.5
-    if maximize and kind == "inf": C = np.where(np.isinf(C), -np.inf, C)
-    try:
-        nf, r4c, c4r, g = eng.kbest(C, N, M, k, maximize, cutoff)[:4]
-    except Exception as e:
-        print("GPU ERROR", N, M, k, B, maximize, cutoff, kind, e); sys.exit(1)
-    onf, or4c, oc4r, og, _ = ol.orc_kbest_batch(C, N, M, k, maximize, cutoff)
-    for b in range(B):
-        n = int(onf[b])
-        ok = nf[b] == n and (g[b, :n].view(np.int64) == og[b, :n].view(np.int64)).all()
-        if ok and not (r4c[b, :n] == or4c[b, :n]).all():
-            # equal gains may come out in another order: compare assignments as multisets below the last gain
-            got = sorted((float(g[b, i]), tuple(r4c[b, i].tolist())) for i in range(n))
-            want = sorted((float(og[b, i]), tuple(or4c[b, i].tolist())) for i in range(n))
-            last = float(og[b, n - 1]) if n else 0.0
-            ok = [x for x in got if x[0] != last] == [x for x in want if x[0] != last] and len({x[1] for x in got}) == n
-        if not ok:
-            print("MISMATCH", dict(N=N, M=M, k=k, B=B, b=b, maximize=maximize, cutoff=cutoff, kind=kind, seed=seed, nf=int(nf[b]), onf=n))
-            np.save("gpurun_out/soak_fail.npy", C[b]); sys.exit(1)
-    ncase += 1; nprob += B
-print(f"soak ok: {ncase} cases, {nprob} problems in {time.time() - t0:.0f} s (seed {seed})")
+ncase, nprob, bad = soak_lib.run(eng, seed, seconds=budget, big_frac=float(os.environ.get("SOAK_BIG", "0.12")),
+                                 big_max=int(os.environ.get("SOAK_BIGMAX", "200")))
+if bad:
+    print("MISMATCH", bad); sys.exit(1)
+print(f"soak ok: {ncase} cases, {nprob} problems (seed {seed})")

@@ -1,5 +1,8 @@
 """CPU: the checker's restatement of the cost-matrix producers."""
+import os
+
 import numpy as np
+import pytest
 
 import oracle_lib as ol
 
@@ -87,3 +90,63 @@ def test_cost_file_round_trip(tmp_path):
     assert (np.isinf(back) == np.isinf(f)).all()
     fin = np.isfinite(f)
     assert np.abs(back[fin] - f[fin]).max() <= 5e-7          # std::to_string keeps 6 decimals
+
+
+def _costfile_cases():
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "costfile_golden.npz"))
+    for name in z["names"]:
+        name = str(name)
+        nr, nc = (int(x) for x in z[name + "/shape"])
+        yield name, z[name + "/cost"], nr, nc, z[name + "/text"].tobytes(), z[name + "/rows"]
+
+
+def test_cost_file_matches_reference_golden(tmp_path):
+    """costfile.py against what the reference's own writer (assignment.cpp:821-831) puts on disk and what its own reader
+    (getCosts, comparison.cpp:32-57) returns for it: tests/golden/costfile_golden.npz, recorded from verbatim slices of the
+    reference (oracle/ref_costfile_shim.cpp).  The bytes written are identical and the values read are bit-identical."""
+    from probabilisticsemslam_amd import costfile
+    n = 0
+    for name, cost, nr, nc, text, rows in _costfile_cases():
+        p = str(tmp_path / f"{name}_frame0.dat")
+        costfile.write_cost_matrix(p, cost, nr, nc)
+        assert open(p, "rb").read() == text, name
+        open(p, "wb").write(text)
+        back, nL, nM = costfile.read_cost_matrix(p)
+        assert (nL, nM) == (nr - nc, nc), name
+        # comparison.cpp:151-156 unrolls getCosts' rows into the column-major vector the solver takes
+        want = np.ascontiguousarray(rows.T).reshape(-1)
+        assert back.view(np.int64).tolist() == want.view(np.int64).tolist(), name
+        n += 1
+    assert n >= 8
+
+
+def test_cost_file_matches_compiled_reference_live(tmp_path):
+    """Where oracle/_ref exists (the build container and the GPU box): random matrices through the compiled slices."""
+    import ctypes as C
+    lib_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libref_costfile.so")
+    if not os.path.exists(lib_path):
+        pytest.skip("oracle/_ref/libref_costfile.so not built")
+    from probabilisticsemslam_amd import costfile
+    lib = C.CDLL(lib_path)
+    lib.ref_get_costs.restype = C.c_int64
+    lib.ref_get_costs.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.ref_write_costs.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_char_p]
+    d = tmp_path / "generatedData" / "00" / "costMatrices"
+    d.mkdir(parents=True)
+    rng = np.random.default_rng(8)
+    for i in range(40):
+        nc = int(rng.integers(1, 9)); nr = nc + int(rng.integers(0, 25))
+        cost = rng.random(nr * nc) * 10.0 ** int(rng.integers(-4, 7))
+        cost[rng.random(nr * nc) < 0.2] = np.inf
+        ours, ref = str(d / f"ours_frame{i}.dat"), str(d / f"ref_frame{i}.dat")
+        costfile.write_cost_matrix(ours, cost, nr, nc)
+        c = np.ascontiguousarray(cost)
+        lib.ref_write_costs(c.ctypes.data, nr, nc, ref.encode())
+        assert open(ours, "rb").read() == open(ref, "rb").read()
+        out = np.empty(nr * nc, np.float64)
+        a, b = C.c_int64(0), C.c_int64(0)
+        n = lib.ref_get_costs(str(tmp_path).encode(), b"ours", i, out.ctypes.data, nr * nc, C.byref(a), C.byref(b))
+        assert n == nr * nc and (a.value, b.value) == (nr, nc)
+        back, nL, nM = costfile.read_cost_matrix(ours)
+        want = np.ascontiguousarray(out.reshape(nr, nc).T).reshape(-1)
+        assert back.view(np.int64).tolist() == want.view(np.int64).tolist()

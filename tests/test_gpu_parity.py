@@ -127,7 +127,7 @@ def test_ties_multiset(eng):
 @pytest.mark.parametrize("name", ["c2", "c3", "c4"])
 def test_full_size_properties(eng, name):
     """BASELINE.json full sizes: gains non-decreasing, assignments are distinct injections, each gain is the
-    serial column-order sum of the chosen entries (bit-exact), nf == k, first/last problems equal the oracle."""
+    serial column-order sum of the chosen entries (bit-exact), nf == k, and the whole batch equal to the oracle's."""
     costs, N, M, k = wl.dense_config(name)
     B = costs.shape[0]
     nf, r4c, c4r, g = eng.kbest(costs, N, M, k)
@@ -149,9 +149,10 @@ def test_full_size_properties(eng, name):
     # solutions of one problem are pairwise distinct
     for b in range(0, B, max(1, B // 64)):
         assert len({tuple(x) for x in r4c[b].tolist()}) == k
-    for b in (0, B - 1):
-        onf, or4c, oc4r, og = ol.orc_kbest(costs[b], N, M, k)
-        assert (r4c[b] == or4c).all() and (bits(g[b]) == bits(og)).all()
+    # against the checker: every matrix of c2 and c4 (the headline batch: ~20 s of host time), every 8th of c3
+    step = 8 if name == "c3" else 1
+    onf, or4c, oc4r, og, _ = ol.orc_kbest_batch(costs[::step], N, M, k)
+    assert (nf[::step] == onf).all() and (r4c[::step] == or4c).all() and (bits(g[::step]) == bits(og)).all()
 
 
 def test_weights_kitti_like(eng):

@@ -1,0 +1,182 @@
+"""GPU tests added in round 3: the lane-per-child kernel (kbest_lane.hip) in every launch shape, a bounded fixed-seed soak
+over all cost structures on every kernel, reservations that cover smaller batches, the chunked host entry on ragged
+batches."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import probabilisticsemslam_amd as pk
+import soak_lib
+from probabilisticsemslam_amd import workloads as wl
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.int64)
+
+
+def engine_with(monkeypatch, **env):
+    """A fresh context whose launch knobs come from the environment at creation (kbest_create reads them once)."""
+    for key, val in env.items():
+        monkeypatch.setenv(key, str(val))
+    eng = pk.KBestEngine(0)
+    for key in env:
+        monkeypatch.delenv(key)
+    return eng
+
+
+def canon(c4r, M):
+    c = c4r.copy()
+    c[c >= M] = -1  # rows on zero-padded columns: which padded column is a tie artefact
+    return c
+
+
+LANE_CASES = [(16, 16, 50, 40, {}), (32, 32, 200, 12, {}), (8, 8, 10, 30, {}), (20, 20, 64, 16, {}), (32, 32, 7, 20, {}),
+              (24, 10, 100, 20, {}), (16, 5, 30, 20, {}), (30, 30, 200, 8, {"maximize": True}), (12, 12, 300, 10, {}),
+              (32, 20, 150, 10, {"cutoff": 0.3}), (16, 16, 50, 16, {"cutoff": 0.05}), (5, 5, 200, 10, {}), (1, 1, 3, 4, {}),
+              (3, 2, 9, 6, {}), (17, 17, 40, 9, {}), (16, 16, 1, 5, {})]
+
+
+@pytest.mark.parametrize("nw,spec,lanes", [(1, 1, 4), (2, 3, 4), (4, 6, 4), (1, 8, 4), (2, 6, 2), (1, 3, 2), (4, 8, 2), (2, 16, 4)])
+def test_lane_kernel_every_launch_shape(monkeypatch, nw, spec, lanes):
+    """kbest_lane.hip forced for every plain batch of <= 32-row problems: waves per problem, hypotheses per round and lanes
+    per child swept; square, rectangular, maximise, cutoff, exhaustive (k beyond the number of assignments), exact ties
+    (multisets), k = 1.  nf, row4col and gains bit for bit against the oracle, col4row after mapping padded columns."""
+    eng = engine_with(monkeypatch, KBEST_FORCE_LANE=1, KBEST_LANE_NW=nw, KBEST_LANE_SPEC=spec, KBEST_LANE_G=lanes)
+    rng = np.random.default_rng(100 * nw + spec)
+    for (N, M, k, B, kw) in LANE_CASES:
+        costs = rng.random((B, N * M))
+        ties = N == 12
+        if ties:
+            costs = np.floor(costs * 4)
+        nf, r4c, c4r, g = eng.kbest(costs, N, M, k, **kw)
+        onf, or4c, oc4r, og, _ = ol.orc_kbest_batch(costs, N, M, k, **kw)
+        assert (nf == onf).all(), (N, M, k, kw)
+        for b in range(B):
+            n = int(nf[b])
+            if ties:
+                assert (np.sort(g[b, :n]) == np.sort(og[b, :n])).all()
+                continue
+            assert (r4c[b, :n] == or4c[b, :n]).all(), (N, M, k, kw, b)
+            assert (bits(g[b, :n]) == bits(og[b, :n])).all(), (N, M, k, kw, b)
+            assert (canon(c4r[b, :n], M) == canon(oc4r[b, :n], M)).all(), (N, M, k, kw, b)
+    eng.close()
+
+
+def test_lane_kernel_takes_the_dense_16_row_batches(monkeypatch):
+    """Default routing: a chip-filling batch of dense 16x16 problems runs on the lane-per-child kernel and equals both the
+    64-row kernel's result (KBEST_NO_LANE) and the oracle; ragged shapes inside one launch as well."""
+    costs, N, M, k = wl.dense_config("c2")
+    eng = pk.KBestEngine(0)
+    old = engine_with(monkeypatch, KBEST_NO_LANE=1)
+    a = eng.kbest(costs, N, M, k)
+    b = old.kbest(costs, N, M, k)
+    for x, y in zip(a, b):
+        assert (np.asarray(x) == np.asarray(y)).all()
+    onf, or4c, oc4r, og, _ = ol.orc_kbest_batch(costs, N, M, k)
+    assert (a[0] == onf).all() and (a[1] == or4c).all() and (bits(a[3]) == bits(og)).all()
+    # ragged: per-problem shapes up to 16 x 16, packed offsets
+    rng = np.random.default_rng(3)
+    B = 700
+    nRow = rng.integers(2, 17, B).astype(np.int32)
+    nCol = np.array([rng.integers(1, r + 1) for r in nRow], dtype=np.int32)
+    off = np.zeros(B, np.int64)
+    off[1:] = np.cumsum(nRow[:-1].astype(np.int64) * nCol[:-1])
+    flat = rng.random(int(off[-1] + nRow[-1] * nCol[-1]))
+    lane = engine_with(monkeypatch, KBEST_FORCE_LANE=1)
+    nf, r4c, c4r, g = lane.kbest(flat, 16, 16, 20, nRow=nRow, nCol=nCol, costOff=off)
+    for i in range(0, B, 7):
+        n, m = int(nRow[i]), int(nCol[i])
+        onf1, or4c1, _, og1 = ol.orc_kbest(flat[off[i]: off[i] + n * m], n, m, 20)
+        assert nf[i] == onf1 and (r4c[i, :onf1, :m] == or4c1[:onf1]).all() and (bits(g[i, :onf1]) == bits(og1[:onf1])).all()
+    for e in (eng, old, lane):
+        e.close()
+
+
+@pytest.mark.parametrize("knobs", [{}, {"KBEST_FORCE_LANE": 1}, {"KBEST_FORCE_SMALL": 1}, {"KBEST_NO_SMALL": 1, "KBEST_NO_LANE": 1},
+                                   {"KBEST_FORCE_WIDE": 1}])
+def test_fixed_seed_soak_on_every_kernel(monkeypatch, knobs):
+    """A bounded slice of the randomised soak (tests/soak_lib.py: seven cost structures incl. exact ties, +inf patterns,
+    near-ties at 1e-9; rectangular and square; maximise; cutoff; k = 1 ... 300), fixed seed, on the default routing and with
+    each kernel forced (the a-priori thresholds are on wherever the launch shape has them)."""
+    eng = engine_with(monkeypatch, **knobs)
+    ncase, nprob, bad = soak_lib.run(eng, seed=20261003, n_cases=110 if not knobs else 60, big_frac=0.05 if not knobs else 0.0,
+                                     big_max=130)
+    eng.close()
+    assert bad is None, bad
+    assert ncase >= 60
+
+
+def test_soak_large_batches_with_thresholds_on(engine):
+    """The a-priori thresholds (T0 / T1) only run in the 8+ wave launch shapes, i.e. for batches that fill the chip: the
+    same cost structures in batches of 300 ... 1200 problems of 33 ... 64 rows."""
+    rng = np.random.default_rng(77)
+    for _ in range(6):
+        case = soak_lib.draw_case(rng, max_rows=64, batches=(300, 700, 1200))
+        while case["N"] < 33 or case["k"] < 3:
+            case = soak_lib.draw_case(rng, max_rows=64, batches=(300, 700, 1200))
+        bad = soak_lib.check_case(engine, case)
+        assert bad is None, bad
+
+
+def test_reservation_covers_smaller_batches():
+    """kbest_c.h: after kbest_reserve(B, ...) 'launches of up to B problems' never allocate.  A smaller batch may pick
+    another kernel or launch shape (more waves, more state slots per problem): every tier has to be covered."""
+    import torch
+    dev = torch.device("cuda", 0)
+    eng = pk.KBestEngine(0)
+    for (N, k, Bres) in ((32, 200, 1100), (16, 50, 2000), (28, 64, 600)):
+        eng.reserve(Bres, N, k)
+        for B in (Bres, 1025, 600, 513, 512, 300, 257, 256, 100, 3, 1):
+            if B > Bres:
+                continue
+            for M in (N, max(1, N // 3)):
+                costs = wl.dense_batch(B, N, M, 5 + B + M)
+                d_cost = torch.from_numpy(costs).to(dev)
+                r4c = torch.empty((B, k, M), dtype=torch.int32, device=dev)
+                c4r = torch.empty((B, k, N), dtype=torch.int32, device=dev)
+                g = torch.empty((B, k), dtype=torch.float64, device=dev)
+                nf = torch.empty(B, dtype=torch.int32, device=dev)
+                eng.kbest_dev(d_cost, B, N, M, k, r4c, c4r, g, nf)  # raises KBestError(NOT_RESERVED) if the reservation is short
+                torch.cuda.synchronize()
+                b = B // 2
+                onf, or4c, _, og = ol.orc_kbest(costs[b], N, M, k)
+                assert int(nf[b]) == onf and (r4c[b, :onf].cpu().numpy() == or4c[:onf]).all()
+                assert (bits(g[b, :onf].cpu().numpy()) == bits(og[:onf])).all()
+    eng.close()
+
+
+def test_chunked_host_entry_odd_ragged_and_pushed(engine):
+    """kbest_batch_f64 sends a large batch through the GPU in chunks (upload / kernel / copy back overlap): odd batch sizes,
+    per-problem shapes with packed offsets, and the push counter go through the same path."""
+    rng = np.random.default_rng(9)
+    # uniform, odd B, large enough outputs to be chunked
+    B, N, M, k = 1027, 64, 64, 200
+    costs = wl.dense_batch(B, N, M, 0xABCD)
+    nf, r4c, c4r, g = engine.kbest(costs, N, M, k)
+    for b in (0, 1, 513, 514, 1026):
+        onf, or4c, oc4r, og = ol.orc_kbest(costs[b], N, M, k)
+        assert nf[b] == onf and (r4c[b] == or4c).all() and (bits(g[b]) == bits(og)).all()
+        assert (canon(c4r[b], M) == canon(oc4r, M)).all()
+    # ragged + offsets
+    B, N, M, k = 1501, 40, 30, 120
+    nRow = rng.integers(5, N + 1, B).astype(np.int32)
+    nCol = np.minimum(rng.integers(1, M + 1, B), nRow).astype(np.int32)
+    off = np.zeros(B, np.int64)
+    off[1:] = np.cumsum(nRow[:-1].astype(np.int64) * nCol[:-1])
+    flat = rng.random(int(off[-1] + nRow[-1] * nCol[-1]))
+    nf, r4c, c4r, g = engine.kbest(flat, N, M, k, nRow=nRow, nCol=nCol, costOff=off)
+    for b in list(range(0, B, 97)) + [B - 1]:
+        n, m = int(nRow[b]), int(nCol[b])
+        onf, or4c, _, og = ol.orc_kbest(flat[off[b]: off[b] + n * m], n, m, k)
+        assert nf[b] == onf and (r4c[b, :onf, :m] == or4c[:onf]).all() and (bits(g[b, :onf]) == bits(og[:onf])).all()
+    # push counting (the reference's order of splits, no pruning) on a chunked batch
+    B, N, M, k = 1100, 48, 48, 200
+    costs = wl.dense_batch(B, N, M, 0xBEEF)
+    nf, r4c, c4r, g, pushed = engine.kbest(costs, N, M, k, count_pushed=True, prune=False)
+    for b in (0, 549, 550, 1099):
+        onf, or4c, _, og, op = ol.orc_kbest_batch(costs[b:b + 1], N, M, k)
+        assert nf[b] == onf[0] and (r4c[b] == or4c[0]).all() and pushed[b] == op[0]

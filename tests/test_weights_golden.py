@@ -4,9 +4,9 @@ assignment.cpp compiled with -O2): conditionCosts (:439-525), toProbs (:527-542)
 bruteForceProb (:835-964).
 
 CPU part: the oracle restatement must reproduce them bit for bit (same libm exp, same summation order).
-GPU part: the engine through the C ABI -- conditionCosts bit-exact, probabilities within 1e-12 absolute (the device
-exp differs from libm by <= 1 ulp; north-star tolerance 1e-6 relative), including the fused one-launch
-association path of kbest_assoc_probs_batch_f64 on the RAW blocks.
+GPU part: the engine through the C ABI -- conditionCosts bit-exact, probabilities within 1e-9 RELATIVE (the device
+exp differs from libm by <= 1 ulp, measured agreement ~1e-15; north-star tolerance 1e-6 relative), including the fused
+one-launch association path of kbest_assoc_probs_batch_f64 on the RAW blocks.
 """
 import os
 
@@ -14,6 +14,8 @@ import numpy as np
 import pytest
 
 import oracle_lib as ol
+
+RTOL, ATOL = 1e-9, 1e-300  # relative, as the north star states its tolerance (an absolute one says nothing about 1e-15 weights)
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "weights_golden.npz")
 
@@ -106,10 +108,10 @@ def test_gpu_assignment_prob_matches_reference_golden(engine):
         condL = c["good"] - c["nM"]
         out, nf = engine.weights([c["cond"]], [condL], [c["nM"]], c["k"])
         want = c["probs"][:, : condL + 1]  # nM == 1: the reference's row is 1 x size(cost), zeros beyond nL+1
-        np.testing.assert_allclose(out[0], want, rtol=0, atol=1e-12, err_msg=c["name"])
+        np.testing.assert_allclose(out[0], want, rtol=RTOL, atol=ATOL, err_msg=c["name"])
         if c["brute"] is not None:
             outb, _ = engine.weights([c["cond"]], [condL], [c["nM"]], 20000, brute_force=True)
-            np.testing.assert_allclose(outb[0], c["brute"][:, : condL + 1], rtol=0, atol=1e-12, err_msg=c["name"])
+            np.testing.assert_allclose(outb[0], c["brute"][:, : condL + 1], rtol=RTOL, atol=ATOL, err_msg=c["name"])
 
 
 @pytest.mark.gpu
@@ -120,8 +122,8 @@ def test_gpu_assoc_probs_on_raw_blocks_matches_reference_golden(engine):
         out, nf = engine.weights([c["raw"] for c in sel], [c["nL"] for c in sel], [c["nM"] for c in sel], k,
                                  condition=True)
         for c, p in zip(sel, out):
-            np.testing.assert_allclose(p, _scatter_back(c), rtol=0, atol=1e-12, err_msg=c["name"])
+            np.testing.assert_allclose(p, _scatter_back(c), rtol=RTOL, atol=ATOL, err_msg=c["name"])
     # and one frame per call, the reference's own call pattern (system.cpp:268)
     for c in CASES[:8]:
         out, nf = engine.weights([c["raw"]], [c["nL"]], [c["nM"]], c["k"], condition=True)
-        np.testing.assert_allclose(out[0], _scatter_back(c), rtol=0, atol=1e-12, err_msg=c["name"])
+        np.testing.assert_allclose(out[0], _scatter_back(c), rtol=RTOL, atol=ATOL, err_msg=c["name"])
