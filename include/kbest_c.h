@@ -245,11 +245,26 @@ int kbest_bb_match_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int
                              const double *boxR, double gate, int32_t *assign);
 
 /*
+ * The "global k-best heap" of the subtree-sharded enumeration (reference partition: split,
+ * shortestPathCPP.cpp:455-532): shard s of nShard enumerated the root's children on columns c % nShard == s
+ * (kbest_opts.root_col_offset / root_col_stride) and holds its own k best -- slot 0 is the root on every shard.  This
+ * k-way merge on the device gives the global table: the root, then the k - 1 best of the union of the shards' slots 1..
+ * in increasing cost (decreasing profit when `maximize`); exact ties are ordered by the assignment (lexicographic
+ * row4col), so the result does not depend on the number of shards.  d_gain / d_row4col / d_nf point at shard 0's
+ * [B][k] fp64 / [B][k][maxCol] i32 / [B] i32 tables, shard s's tables start s * shardStrideBytes behind them (the
+ * packed per-rank slices of the all-gather, or plain [nShard][B][...] arrays).  Asynchronous on `stream`
+ * (NULL = the context's stream); device pointers.
+ */
+int kbest_merge_topk_f64_dev(kbest_ctx *ctx, int B, int nShard, int k, int maxCol, int maximize, const void *d_gain,
+                             const void *d_row4col, const void *d_nf, int64_t shardStrideBytes, double *d_outGain,
+                             int32_t *d_outRow4col, int32_t *d_outNf, void *stream);
+
+/*
  * Multi-device entries (BASELINE.json config 4): one engine context + one stream per GPU and an
  * RCCL communicator over them (ncclCommInitAll; xGMI inside a node).  kbest_batch_f64_multi shards the batch in
  * contiguous blocks (device g solves matrices [g*ceil(B/G), ...)), each device solving its block with the kernels of
- * the single-device entries straight into its slice of a global table; ONE in-place all-gather of the packed
- * (gain[k], row4col[k*M], nf) per matrix then leaves EVERY device with the same global k-best table (there is no
+ * the single-device entries straight into its packed slice (gain | row4col | nf) of a global table; ONE in-place
+ * ncclAllGather of those slices then leaves EVERY device with the same global k-best table (there is no
  * other collective: the matrices are independent).  The host outputs are read back from device 0; col4row is not part
  * of the exchange and comes from the device that solved the block.  Same argument meaning as kbest_batch_f64
  * (uniform packing b*maxRow*maxCol; nRow/nCol optional).  RCCL is bound at run time (dlopen): without it
@@ -263,7 +278,22 @@ const char *kbest_multi_last_error(const kbest_multi *m);
 int kbest_batch_f64_multi(kbest_multi *m, const kbest_opts *opts, int B, int maxRow, int maxCol, const int32_t *nRow,
                           const int32_t *nCol, const double *cost, int k, int32_t *row4col, int32_t *col4row, double *gain,
                           int32_t *nf);
-/* 1 when every device holds the same global table after the last kbest_batch_f64_multi call, 0 when not (test aid). */
+/*
+ * The same with the sharding mode explicit.  KBEST_MULTI_BATCH: as above.  KBEST_MULTI_SUBTREE (few large matrices; the
+ * north star's "per-rank top-k into a global k-best heap"): every device receives ALL B matrices; shard s of nShard
+ * (0 = one per device; more than devices: dealt round robin, a device runs its shards one after the other) expands only
+ * the root's children on columns c % nShard == s (reference partition: split, shortestPathCPP.cpp:455-532) and enumerates
+ * its own k best; ONE all-gather of the packed per-shard lists, then every device merges them into the global k best
+ * (kbest_merge_topk_f64_dev).  Results are those of the batch mode for tie-free costs (exact ties: ordered by the
+ * assignment); col4row, which is not part of the exchange, is returned as the inverse of row4col with -1 for rows
+ * without a real column.  opts->root_col_offset / stride must be unset.
+ */
+#define KBEST_MULTI_BATCH 0
+#define KBEST_MULTI_SUBTREE 1
+int kbest_batch_f64_multi_ex(kbest_multi *m, const kbest_opts *opts, int mode, int nShard, int B, int maxRow, int maxCol,
+                             const int32_t *nRow, const int32_t *nCol, const double *cost, int k, int32_t *row4col,
+                             int32_t *col4row, double *gain, int32_t *nf);
+/* 1 when every device holds the same global table after the last kbest_batch_f64_multi[_ex] call, 0 when not (test aid). */
 int kbest_multi_tables_agree(kbest_multi *m);
 
 #ifdef __cplusplus

@@ -858,6 +858,34 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
     return KBEST_OK;
 }
 
+int kbest_merge_topk_f64_dev(kbest_ctx *ctx, int B, int nShard, int k, int maxCol, int maximize, const void *d_gain,
+                             const void *d_row4col, const void *d_nf, int64_t shardStrideBytes, double *d_outGain,
+                             int32_t *d_outRow4col, int32_t *d_outNf, void *stream)
+{
+    if (!ctx) return KBEST_ERR_BAD_ARG;
+    if (B < 0 || nShard < 1 || k < 1 || maxCol < 1 || !d_gain || !d_row4col || !d_nf || !d_outGain || !d_outRow4col || !d_outNf ||
+        (nShard > 1 && shardStrideBytes <= 0))
+        return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_merge_topk_f64_dev: bad argument");
+    if (B == 0) return KBEST_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    kb::MergeParams p;
+    p.gain = static_cast<const unsigned char *>(d_gain);
+    p.row4col = static_cast<const unsigned char *>(d_row4col);
+    p.nf = static_cast<const unsigned char *>(d_nf);
+    p.shardStride = shardStrideBytes;
+    p.nShard = nShard;
+    p.k = k;
+    p.maxCol = maxCol;
+    p.ldCol = maxCol;
+    p.maximize = maximize;
+    p.outGain = d_outGain;
+    p.outRow4col = d_outRow4col;
+    p.outNf = d_outNf;
+    hipError_t e = kb::launch_merge_topk(p, B, stream ? static_cast<hipStream_t>(stream) : ctx->stream);
+    if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "merge kernel launch", e);
+    return KBEST_OK;
+}
+
 int kbest_assign_batch_f64(kbest_ctx *ctx, int B, int maxRow, int maxCol, const int32_t *nRow, const int32_t *nCol,
                            const double *cost, const int64_t *costOff, int maximize, int shift, int gainCols,
                            int32_t *row4col, int32_t *col4row, double *gain, double *u, double *v, int32_t *feasible)

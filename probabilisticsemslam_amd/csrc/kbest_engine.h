@@ -382,6 +382,19 @@ __host__ __device__ inline LaneLds lane_lds_layout(int maxRow, int maxCol, int k
     return L;
 }
 
+// k-way merge of per-shard k-best lists into the global k best (kbest_merge.hip).  The lists of shard s start
+// s * shardStride BYTES behind those of shard 0 (the packed per-rank slices of the all-gather, or plain [S][B][...] arrays).
+struct MergeParams {
+    const unsigned char *gain;     // shard 0: [B][k] fp64
+    const unsigned char *row4col;  // shard 0: [B][k][ldCol] i32
+    const unsigned char *nf;       // shard 0: [B] i32
+    long long shardStride;
+    int nShard, k, maxCol, ldCol, maximize;
+    double *outGain;               // [B][k]
+    int *outRow4col;               // [B][k][ldCol]
+    int *outNf;                    // [B]
+};
+hipError_t launch_merge_topk(const MergeParams &p, int B, hipStream_t stream);
 hipError_t launch_kbest_lane(const Params &p, int B, int nWaves, int lanesPerChild, hipStream_t stream);
 hipError_t launch_kbest_small(const SmallParams &p, int B, int nWaves, hipStream_t stream);
 hipError_t launch_kbest(const Params &p, int B, int nWaves, hipStream_t stream);

@@ -1,0 +1,92 @@
+// kbest_merge.hip -- the "global k-best heap" of the subtree-sharded enumeration (north star: "RCCL allgather of
+// per-rank top-k costs into a global k-best heap"), on the device.
+//
+// Murty's partition of the root is disjoint (split, shortestPathCPP.cpp:455-532): shard s of S enumerates only the root's
+// children on columns c with c % S == s and produces its own k best -- slot 0 is the root itself on every shard, slots 1..
+// are that shard's subtrees in increasing cost (decreasing profit when maximising).  The global k best are the root
+// followed by the k - 1 best of the union of the shards' slots 1..: a k-way merge of S sorted lists.  One workgroup per
+// problem; every candidate finds its own output position by counting the candidates that precede it -- per shard a binary
+// search on the gain, then a walk over the run of equal gains, which are ordered by the assignment itself (lexicographic
+// row4col) so that the merged table does not depend on the number of shards or on which shard a hypothesis came from
+// (exact ties: SURVEY 8(a) quirk 7; the reference's own order there is a heap artefact).
+#include <hip/hip_runtime.h>
+
+#include "kbest_engine.h"
+
+namespace kb {
+
+namespace {
+
+// (gain, assignment) of candidate A strictly before candidate B in the merged order?
+__device__ __forceinline__ bool before(double ga, const int *ra, double gb, const int *rb, int M, bool maximize)
+{
+    if (ga != gb) return maximize ? (ga > gb) : (ga < gb);
+    for (int c = 0; c < M; c++)
+        if (ra[c] != rb[c]) return ra[c] < rb[c];
+    return false;
+}
+
+}  // namespace
+
+__global__ void __launch_bounds__(256) merge_topk_kernel(MergeParams p)
+{
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int S = p.nShard, k = p.k, M = p.maxCol;
+    const bool maximize = p.maximize != 0;
+    auto gainOf = [&](int s) { return reinterpret_cast<const double *>(p.gain + (long long)s * p.shardStride) + (long long)b * k; };
+    auto rowsOf = [&](int s) { return reinterpret_cast<const int *>(p.row4col + (long long)s * p.shardStride) + (long long)b * k * p.ldCol; };
+    auto nfOf = [&](int s) { return reinterpret_cast<const int *>(p.nf + (long long)s * p.shardStride)[b]; };
+    double *og = p.outGain + (long long)b * k;
+    int *orow = p.outRow4col + (long long)b * k * p.ldCol;
+    const int nf0 = nfOf(0);
+    if (nf0 <= 0) {  // infeasible (every shard solves the same root): kBest2D returns 0 (cpp:588-593); errors pass through
+        if (tid == 0) p.outNf[b] = nf0;
+        return;
+    }
+    __shared__ int total;
+    if (tid == 0) total = 0;
+    __syncthreads();
+    // the root: slot 0 of shard 0
+    if (tid == 0) og[0] = gainOf(0)[0];
+    for (int c = tid; c < M; c += 256) orow[c] = rowsOf(0)[c];
+    int mine = 0;
+    for (int idx = tid; idx < S * k; idx += 256) {
+        const int s = idx / k, i = idx - s * k;
+        const int n = nfOf(s);
+        if (i < 1 || i >= n) continue;  // the root, or beyond what the shard found
+        mine++;
+        const double g = gainOf(s)[i];
+        const int *r = rowsOf(s) + (long long)i * p.ldCol;
+        int pos = 0;
+        for (int t = 0; t < S; t++) {
+            const double *gt = gainOf(t);
+            const int nt = nfOf(t);
+            // entries 1 .. nt-1 of shard t are sorted by gain: the first one that is not strictly better than g
+            int lo = 1, hi = nt > 1 ? nt : 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const bool better = maximize ? (gt[mid] > g) : (gt[mid] < g);
+                if (better) lo = mid + 1; else hi = mid;
+            }
+            pos += lo - 1;
+            const int *rt = rowsOf(t);
+            for (int j = lo; j < nt && gt[j] == g; j++)  // the run of equal gains: ordered by the assignment
+                pos += before(gt[j], rt + (long long)j * p.ldCol, g, r, M, maximize) ? 1 : 0;
+        }
+        if (1 + pos < k) {
+            og[1 + pos] = g;
+            for (int c = 0; c < M; c++) orow[(long long)(1 + pos) * p.ldCol + c] = r[c];
+        }
+    }
+    if (mine) atomicAdd(&total, mine);
+    __syncthreads();
+    if (tid == 0) p.outNf[b] = (1 + total < k) ? 1 + total : k;
+}
+
+hipError_t launch_merge_topk(const MergeParams &p, int B, hipStream_t stream)
+{
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(B), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace kb

@@ -4,9 +4,13 @@
 // This is the C++ side of BASELINE.json's config 4 ("sharded across 8 MI355X via RCCL top-k allgather"): a host
 // program written like the reference (one process, plain C++) shards without a Python launcher.
 //
-// The matrices are independent, so there is NO data-path collective: each device solves its block with the same
-// kernels as the single-device entries, writing straight into its slice of the global table; the all-gather is
-// in place (send buffer = own slice of the receive buffer) and is the only exchange.
+// Batch mode: the matrices are independent, so there is NO data-path collective: each device solves its block with the
+// same kernels as the single-device entries, writing straight into its packed slice (gain | row4col | nf) of the global
+// table; ONE in-place ncclAllGather of the packed slices (send buffer = own slice of the receive buffer) is the only
+// exchange.  Subtree mode (few large matrices): every device enumerates its share of the root's subtrees of EVERY matrix,
+// the packed per-shard lists are all-gathered the same way and every device merges them into the global k best
+// (kbest_merge.hip): the "global k-best heap" of the north star.  On any failure every device stream that was given work
+// is drained and an open RCCL group is closed before the entry returns.
 //
 // RCCL is bound at run time (dlopen of librccl.so.1): the library stays loadable -- and every single-device entry
 // usable -- on a host without RCCL, and a process that already carries another copy of RCCL (PyTorch bundles one) does
@@ -58,14 +62,15 @@ struct Dev {
     kbest_ctx *ctx = nullptr;
     hipStream_t stream = nullptr;
     ncclComm_t comm = nullptr;
+    bool issued = false;        // work of the current call has been put on `stream`
     // device buffers, grown on demand
     double *cost = nullptr;
-    int32_t *shape = nullptr;   // nRow | nCol of this device's block
+    int32_t *shape = nullptr;   // nRow | nCol of this device's problems
     int32_t *c4r = nullptr;     // col4row of this device's block (not gathered: SURVEY 8(e) exchanges gain, row4col, nf)
-    int32_t *gR4C = nullptr;    // global tables, identical on every device after the gather
-    double *gGain = nullptr;
-    int32_t *gNf = nullptr;
-    size_t costB = 0, shapeB = 0, c4rB = 0, gR4CB = 0, gGainB = 0, gNfB = 0;
+    unsigned char *packed = nullptr;  // the global table: one packed slice (gain | row4col | nf) per device, identical everywhere after the gather
+    double *mGain = nullptr;    // subtree mode: the merged global k best (identical on every device)
+    int32_t *mR4C = nullptr, *mNf = nullptr;
+    size_t costB = 0, shapeB = 0, c4rB = 0, packedB = 0, mGainB = 0, mR4CB = 0, mNfB = 0;
 };
 
 }  // namespace
@@ -75,7 +80,8 @@ struct kbest_multi {
     Rccl rccl;
     std::string err;
     // shape of the last call (for kbest_multi_tables_agree)
-    int lastB = 0, lastPad = 0, lastK = 0, lastCol = 0;
+    int lastB = 0, lastK = 0, lastCol = 0, lastMode = 0;
+    size_t lastBytes = 0;  // bytes of the packed global table
 };
 
 namespace {
@@ -86,26 +92,74 @@ int mfail(kbest_multi *m, int code, const std::string &what)
     return code;
 }
 
-#define M_HIP(m, call)                                                                                   \
-    do {                                                                                                 \
-        hipError_t e_ = (call);                                                                          \
-        if (e_ != hipSuccess) return mfail(m, KBEST_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
-    } while (0)
-#define M_NCCL(m, call)                                                                                   \
-    do {                                                                                                  \
-        ncclResult_t r_ = (call);                                                                         \
-        if (r_ != ncclSuccess) return mfail(m, KBEST_ERR_HIP, std::string(#call) + ": " + m->rccl.GetErrorString(r_)); \
-    } while (0)
+size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
 
-template <class T> int grow(kbest_multi *m, T *&p, size_t &have, size_t need)
+// One packed slice: gain[n][k] fp64 | row4col[n][k][maxCol] i32 | nf[n] i32 (each part 16-byte aligned)
+struct Slice {
+    size_t offGain, offR4C, offNf, bytes;
+    Slice(size_t n, int k, int maxCol)
+    {
+        offGain = 0;
+        offR4C = up16(n * (size_t)k * 8);
+        offNf = offR4C + up16(n * (size_t)k * maxCol * 4);
+        bytes = offNf + up16(n * 4);
+    }
+};
+
+// Every device stream that has been given work in this call is drained: nothing of a failed call may still read the
+// caller's buffers or write device memory when the entry returns.
+void drain(kbest_multi *m)
+{
+    for (auto &d : m->dev)
+        if (d.issued) {
+            (void)hipSetDevice(d.id);
+            (void)hipStreamSynchronize(d.stream);
+            d.issued = false;
+        }
+}
+
+template <class T> int grow(kbest_multi *m, Dev &d, T *&p, size_t &have, size_t need)
 {
     if (need <= have) return KBEST_OK;
-    if (p) (void)hipFree(p);
+    if (p) {  // an earlier (asynchronous) call may still use the old buffer
+        (void)hipStreamSynchronize(d.stream);
+        (void)hipFree(p);
+    }
     p = nullptr;
     have = 0;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), need);
     if (e != hipSuccess) return mfail(m, KBEST_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
     have = need;
+    return KBEST_OK;
+}
+
+#define M_TRY(m, expr)                                  \
+    do {                                                \
+        const int rc_ = (expr);                         \
+        if (rc_ != KBEST_OK) { drain(m); return rc_; }  \
+    } while (0)
+#define M_HIP(m, call)                                                                                              \
+    do {                                                                                                            \
+        hipError_t e_ = (call);                                                                                     \
+        if (e_ != hipSuccess) { drain(m); return mfail(m, KBEST_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } \
+    } while (0)
+
+// ONE all-gather of the packed per-device slices (in place: the send buffer is the device's own slice of the receive
+// buffer), stream-ordered behind each device's kernels.  The RCCL group is always closed, whatever fails inside it.
+int gather_packed(kbest_multi *m, size_t perDev)
+{
+    const int G = (int)m->dev.size();
+    ncclResult_t first = ncclSuccess;
+    ncclResult_t r = m->rccl.GroupStart();
+    if (r != ncclSuccess) { drain(m); return mfail(m, KBEST_ERR_HIP, std::string("ncclGroupStart: ") + m->rccl.GetErrorString(r)); }
+    for (int g = 0; g < G && first == ncclSuccess; g++) {
+        Dev &d = m->dev[g];
+        first = m->rccl.AllGather(d.packed + (size_t)g * perDev, d.packed, perDev, ncclChar, d.comm, d.stream);
+        d.issued = true;
+    }
+    r = m->rccl.GroupEnd();
+    if (first == ncclSuccess) first = r;
+    if (first != ncclSuccess) { drain(m); return mfail(m, KBEST_ERR_HIP, std::string("ncclAllGather: ") + m->rccl.GetErrorString(first)); }
     return KBEST_OK;
 }
 
@@ -144,8 +198,9 @@ int kbest_destroy_multi(kbest_multi *m)
     if (!m) return KBEST_OK;
     for (auto &d : m->dev) {
         (void)hipSetDevice(d.id);
+        if (d.stream) (void)hipStreamSynchronize(d.stream);
         if (d.comm && m->rccl.CommDestroy) (void)m->rccl.CommDestroy(d.comm);
-        for (void *p : {(void *)d.cost, (void *)d.shape, (void *)d.c4r, (void *)d.gR4C, (void *)d.gGain, (void *)d.gNf})
+        for (void *p : {(void *)d.cost, (void *)d.shape, (void *)d.c4r, (void *)d.packed, (void *)d.mGain, (void *)d.mR4C, (void *)d.mNf})
             if (p) (void)hipFree(p);
         if (d.stream) (void)hipStreamDestroy(d.stream);
         if (d.ctx) kbest_destroy(d.ctx);
@@ -158,97 +213,200 @@ int kbest_multi_size(const kbest_multi *m) { return m ? (int)m->dev.size() : 0; 
 
 const char *kbest_multi_last_error(const kbest_multi *m) { return m ? m->err.c_str() : "null context"; }
 
-int kbest_batch_f64_multi(kbest_multi *m, const kbest_opts *opts, int B, int maxRow, int maxCol, const int32_t *nRow,
-                          const int32_t *nCol, const double *cost, int k, int32_t *row4col, int32_t *col4row, double *gain,
-                          int32_t *nf)
+int kbest_batch_f64_multi_ex(kbest_multi *m, const kbest_opts *opts, int mode, int nShard, int B, int maxRow, int maxCol,
+                             const int32_t *nRow, const int32_t *nCol, const double *cost, int k, int32_t *row4col,
+                             int32_t *col4row, double *gain, int32_t *nf)
 {
     if (!m) return KBEST_ERR_BAD_ARG;
     if (!opts || B < 0 || k < 1 || maxCol < 1 || maxRow < maxCol || !cost || !row4col || !gain || !nf ||
-        (nRow == nullptr) != (nCol == nullptr))
+        (nRow == nullptr) != (nCol == nullptr) || (mode != KBEST_MULTI_BATCH && mode != KBEST_MULTI_SUBTREE) || nShard < 0)
         return mfail(m, KBEST_ERR_BAD_ARG, "kbest_batch_f64_multi: bad argument");
+    if (nRow)  // the same validation as kbest_batch_f64: a bad shape is an argument error, not a kernel's nf = -1
+        for (int b = 0; b < B; b++)
+            if (nCol[b] < 1 || nRow[b] < nCol[b] || nRow[b] > maxRow || nCol[b] > maxCol)
+                return mfail(m, KBEST_ERR_BAD_ARG, "kbest_batch_f64_multi: shape out of range (need 1 <= numCol <= numRow <= maxRow)");
     if (B == 0) return KBEST_OK;
     const int G = (int)m->dev.size();
-    const int pad = (B + G - 1) / G;  // matrices per device (the last devices may hold fewer): equal all-gather counts
     const size_t per = (size_t)maxRow * maxCol;
-    m->lastB = B; m->lastPad = pad; m->lastK = k; m->lastCol = maxCol;
-    // 1. every device: its block of cost matrices in, its slice of the global table solved in place
-    for (int g = 0; g < G; g++) {
-        Dev &d = m->dev[g];
-        const int b0 = g * pad, nb = (b0 >= B) ? 0 : ((B - b0 < pad) ? B - b0 : pad);
-        M_HIP(m, hipSetDevice(d.id));
-        int rc = grow(m, d.gR4C, d.gR4CB, (size_t)G * pad * k * maxCol * 4);
-        if (rc == KBEST_OK) rc = grow(m, d.gGain, d.gGainB, (size_t)G * pad * k * 8);
-        if (rc == KBEST_OK) rc = grow(m, d.gNf, d.gNfB, (size_t)G * pad * 4);
-        if (rc == KBEST_OK) rc = grow(m, d.cost, d.costB, (size_t)pad * per * 8);
-        if (rc == KBEST_OK && col4row) rc = grow(m, d.c4r, d.c4rB, (size_t)pad * k * maxRow * 4);
-        if (rc == KBEST_OK && nRow) rc = grow(m, d.shape, d.shapeB, (size_t)2 * pad * 4);
-        if (rc != KBEST_OK) return rc;
-        // slots the kernels do not write (beyond nf, padding problems) get defined values
-        M_HIP(m, hipMemsetAsync(d.gR4C + (size_t)b0 * k * maxCol, 0xFF, (size_t)pad * k * maxCol * 4, d.stream));
-        M_HIP(m, hipMemsetAsync(d.gGain + (size_t)b0 * k, 0, (size_t)pad * k * 8, d.stream));
-        M_HIP(m, hipMemsetAsync(d.gNf + b0, 0, (size_t)pad * 4, d.stream));
-        if (nb == 0) continue;
-        if (col4row) M_HIP(m, hipMemsetAsync(d.c4r, 0xFF, (size_t)pad * k * maxRow * 4, d.stream));
-        M_HIP(m, hipMemcpyAsync(d.cost, cost + (size_t)b0 * per, (size_t)nb * per * 8, hipMemcpyHostToDevice, d.stream));
-        if (nRow) {
-            M_HIP(m, hipMemcpyAsync(d.shape, nRow + b0, (size_t)nb * 4, hipMemcpyHostToDevice, d.stream));
-            M_HIP(m, hipMemcpyAsync(d.shape + pad, nCol + b0, (size_t)nb * 4, hipMemcpyHostToDevice, d.stream));
-        }
-        rc = kbest_reserve(d.ctx, nb, maxRow, k);
-        if (rc != KBEST_OK) return mfail(m, rc, std::string("device ") + std::to_string(d.id) + ": " + kbest_last_error(d.ctx));
-        rc = kbest_batch_f64_dev(d.ctx, opts, nb, maxRow, maxCol, nRow ? d.shape : nullptr, nRow ? d.shape + pad : nullptr, d.cost,
-                                 nullptr, k, d.gR4C + (size_t)b0 * k * maxCol, col4row ? d.c4r : nullptr,
-                                 d.gGain + (size_t)b0 * k, d.gNf + b0, nullptr, d.stream);
-        if (rc != KBEST_OK) return mfail(m, rc, std::string("device ") + std::to_string(d.id) + ": " + kbest_last_error(d.ctx));
-    }
-    // 2. the one exchange: in-place all-gather of (gain[k], row4col[k*M], nf) per matrix, stream-ordered behind each
-    //    device's kernel
-    M_NCCL(m, m->rccl.GroupStart());
-    for (int g = 0; g < G; g++) {
-        Dev &d = m->dev[g];
-        const size_t b0 = (size_t)g * pad;
-        M_NCCL(m, m->rccl.AllGather(d.gGain + b0 * k, d.gGain, (size_t)pad * k, ncclDouble, d.comm, d.stream));
-        M_NCCL(m, m->rccl.AllGather(d.gR4C + b0 * k * maxCol, d.gR4C, (size_t)pad * k * maxCol, ncclInt32, d.comm, d.stream));
-        M_NCCL(m, m->rccl.AllGather(d.gNf + b0, d.gNf, (size_t)pad, ncclInt32, d.comm, d.stream));
-    }
-    M_NCCL(m, m->rccl.GroupEnd());
-    // 3. results: the global table from device 0 (any device holds it), col4row from the device that solved the block
-    for (int g = 0; g < G; g++) {
-        Dev &d = m->dev[g];
-        M_HIP(m, hipSetDevice(d.id));
-        M_HIP(m, hipStreamSynchronize(d.stream));
-    }
-    Dev &d0 = m->dev[0];
-    M_HIP(m, hipSetDevice(d0.id));
-    M_HIP(m, hipMemcpy(row4col, d0.gR4C, (size_t)B * k * maxCol * 4, hipMemcpyDeviceToHost));
-    M_HIP(m, hipMemcpy(gain, d0.gGain, (size_t)B * k * 8, hipMemcpyDeviceToHost));
-    M_HIP(m, hipMemcpy(nf, d0.gNf, (size_t)B * 4, hipMemcpyDeviceToHost));
-    if (col4row) {
+    for (auto &d : m->dev) d.issued = false;
+
+    if (mode == KBEST_MULTI_BATCH) {
+        const int pad = (B + G - 1) / G;  // matrices per device (the last devices may hold fewer): equal all-gather counts
+        const Slice sl((size_t)pad, k, maxCol);
+        m->lastB = B; m->lastK = k; m->lastCol = maxCol; m->lastMode = mode; m->lastBytes = (size_t)G * sl.bytes;
+        // 1. every device: its block of cost matrices in, its slice of the global table solved in place
         for (int g = 0; g < G; g++) {
             Dev &d = m->dev[g];
             const int b0 = g * pad, nb = (b0 >= B) ? 0 : ((B - b0 < pad) ? B - b0 : pad);
-            if (nb == 0) continue;
             M_HIP(m, hipSetDevice(d.id));
-            M_HIP(m, hipMemcpy(col4row + (size_t)b0 * k * maxRow, d.c4r, (size_t)nb * k * maxRow * 4, hipMemcpyDeviceToHost));
+            M_TRY(m, grow(m, d, d.packed, d.packedB, (size_t)G * sl.bytes));
+            M_TRY(m, grow(m, d, d.cost, d.costB, (size_t)pad * per * 8));
+            if (col4row) M_TRY(m, grow(m, d, d.c4r, d.c4rB, (size_t)pad * k * maxRow * 4));
+            if (nRow) M_TRY(m, grow(m, d, d.shape, d.shapeB, (size_t)2 * pad * 4));
+            unsigned char *mine = d.packed + (size_t)g * sl.bytes;
+            // slots the kernels do not write (beyond nf, padding problems) get defined values: gain 0, row4col -1, nf 0
+            d.issued = true;
+            M_HIP(m, hipMemsetAsync(mine, 0, sl.bytes, d.stream));
+            M_HIP(m, hipMemsetAsync(mine + sl.offR4C, 0xFF, (size_t)pad * k * maxCol * 4, d.stream));
+            if (nb == 0) continue;
+            if (col4row) M_HIP(m, hipMemsetAsync(d.c4r, 0xFF, (size_t)pad * k * maxRow * 4, d.stream));
+            M_HIP(m, hipMemcpyAsync(d.cost, cost + (size_t)b0 * per, (size_t)nb * per * 8, hipMemcpyHostToDevice, d.stream));
+            if (nRow) {
+                M_HIP(m, hipMemcpyAsync(d.shape, nRow + b0, (size_t)nb * 4, hipMemcpyHostToDevice, d.stream));
+                M_HIP(m, hipMemcpyAsync(d.shape + pad, nCol + b0, (size_t)nb * 4, hipMemcpyHostToDevice, d.stream));
+            }
+            int rc = kbest_reserve(d.ctx, nb, maxRow, k);
+            if (rc == KBEST_OK)
+                rc = kbest_batch_f64_dev(d.ctx, opts, nb, maxRow, maxCol, nRow ? d.shape : nullptr, nRow ? d.shape + pad : nullptr,
+                                         d.cost, nullptr, k, reinterpret_cast<int32_t *>(mine + sl.offR4C), col4row ? d.c4r : nullptr,
+                                         reinterpret_cast<double *>(mine + sl.offGain), reinterpret_cast<int32_t *>(mine + sl.offNf),
+                                         nullptr, d.stream);
+            if (rc != KBEST_OK) {
+                drain(m);
+                return mfail(m, rc, std::string("device ") + std::to_string(d.id) + ": " + kbest_last_error(d.ctx));
+            }
         }
+        // 2. the one exchange: ONE all-gather of the packed (gain[k], row4col[k*M], nf) slices
+        M_TRY(m, gather_packed(m, sl.bytes));
+        // 3. results: the global table from device 0 (any device holds it), col4row from the device that solved the block
+        drain(m);
+        Dev &d0 = m->dev[0];
+        std::vector<unsigned char> host((size_t)G * sl.bytes);
+        M_HIP(m, hipSetDevice(d0.id));
+        M_HIP(m, hipMemcpy(host.data(), d0.packed, host.size(), hipMemcpyDeviceToHost));
+        for (int g = 0; g < G; g++) {
+            const int b0 = g * pad, nb = (b0 >= B) ? 0 : ((B - b0 < pad) ? B - b0 : pad);
+            if (nb == 0) continue;
+            const unsigned char *s = host.data() + (size_t)g * sl.bytes;
+            memcpy(gain + (size_t)b0 * k, s + sl.offGain, (size_t)nb * k * 8);
+            memcpy(row4col + (size_t)b0 * k * maxCol, s + sl.offR4C, (size_t)nb * k * maxCol * 4);
+            memcpy(nf + b0, s + sl.offNf, (size_t)nb * 4);
+            if (col4row) {
+                Dev &d = m->dev[g];
+                M_HIP(m, hipSetDevice(d.id));
+                M_HIP(m, hipMemcpy(col4row + (size_t)b0 * k * maxRow, d.c4r, (size_t)nb * k * maxRow * 4, hipMemcpyDeviceToHost));
+            }
+        }
+    } else {
+        // Subtree mode (few large matrices; SURVEY 8(e), north star): every device holds ALL B matrices; shard s of S expands
+        // only the root's children on columns c % S == s and enumerates its own k best (slot 0: the root); the packed lists
+        // are all-gathered and every device merges them into the global k best (kbest_merge_topk_f64_dev).  Shards are dealt
+        // to the devices round robin: with S > G a device runs several shards one after the other (and one device can
+        // stand in for several: the one-GPU test of this path).
+        const int S = nShard > 0 ? nShard : G;
+        const int spd = (S + G - 1) / G;  // shard slots per device
+        const Slice sl((size_t)B, k, maxCol);
+        const size_t perDev = (size_t)spd * sl.bytes;
+        m->lastB = B; m->lastK = k; m->lastCol = maxCol; m->lastMode = mode;
+        m->lastBytes = 0;
+        if (opts->root_col_stride > 1) return mfail(m, KBEST_ERR_BAD_ARG, "kbest_batch_f64_multi: subtree mode sets root_col_offset / stride itself");
+        for (int g = 0; g < G; g++) {
+            Dev &d = m->dev[g];
+            M_HIP(m, hipSetDevice(d.id));
+            M_TRY(m, grow(m, d, d.packed, d.packedB, (size_t)G * perDev));
+            M_TRY(m, grow(m, d, d.cost, d.costB, (size_t)B * per * 8));
+            M_TRY(m, grow(m, d, d.mGain, d.mGainB, (size_t)B * k * 8));
+            M_TRY(m, grow(m, d, d.mR4C, d.mR4CB, (size_t)B * k * maxCol * 4));
+            M_TRY(m, grow(m, d, d.mNf, d.mNfB, (size_t)B * 4));
+            if (nRow) M_TRY(m, grow(m, d, d.shape, d.shapeB, (size_t)2 * B * 4));
+            unsigned char *mine = d.packed + (size_t)g * perDev;
+            d.issued = true;
+            M_HIP(m, hipMemsetAsync(mine, 0, perDev, d.stream));  // (an unused shard slot: nf = 0, no candidates)
+            M_HIP(m, hipMemsetAsync(d.mR4C, 0xFF, (size_t)B * k * maxCol * 4, d.stream));
+            M_HIP(m, hipMemsetAsync(d.mGain, 0, (size_t)B * k * 8, d.stream));
+            M_HIP(m, hipMemcpyAsync(d.cost, cost, (size_t)B * per * 8, hipMemcpyHostToDevice, d.stream));
+            if (nRow) {
+                M_HIP(m, hipMemcpyAsync(d.shape, nRow, (size_t)B * 4, hipMemcpyHostToDevice, d.stream));
+                M_HIP(m, hipMemcpyAsync(d.shape + B, nCol, (size_t)B * 4, hipMemcpyHostToDevice, d.stream));
+            }
+            int rc = kbest_reserve(d.ctx, B, maxRow, k);
+            for (int j = 0; j < spd && rc == KBEST_OK; j++) {
+                const int s = j * G + g;  // round robin
+                if (s >= S) break;
+                unsigned char *slot = mine + (size_t)j * sl.bytes;
+                M_HIP(m, hipMemsetAsync(slot + sl.offR4C, 0xFF, (size_t)B * k * maxCol * 4, d.stream));
+                kbest_opts o = *opts;
+                o.root_col_offset = s;
+                o.root_col_stride = S;
+                rc = kbest_batch_f64_dev(d.ctx, &o, B, maxRow, maxCol, nRow ? d.shape : nullptr, nRow ? d.shape + B : nullptr, d.cost,
+                                         nullptr, k, reinterpret_cast<int32_t *>(slot + sl.offR4C), nullptr,
+                                         reinterpret_cast<double *>(slot + sl.offGain), reinterpret_cast<int32_t *>(slot + sl.offNf),
+                                         nullptr, d.stream);
+            }
+            if (rc != KBEST_OK) {
+                drain(m);
+                return mfail(m, rc, std::string("device ") + std::to_string(d.id) + ": " + kbest_last_error(d.ctx));
+            }
+        }
+        M_TRY(m, gather_packed(m, perDev));
+        // the global k-best heap, on every device.  In the gathered buffer shard s = j * G + g sits at (g * spd + j) slices:
+        // the merge takes "shard i" at i * sl.bytes, which enumerates the slots device by device -- any order of the
+        // shards gives the same table (ties are ordered by the assignment), but the ROOT is taken from the first slot,
+        // which is shard 0 (device 0, j = 0).
+        for (int g = 0; g < G; g++) {
+            Dev &d = m->dev[g];
+            M_HIP(m, hipSetDevice(d.id));
+            const int rc = kbest_merge_topk_f64_dev(d.ctx, B, G * spd, k, maxCol, opts->maximize, d.packed + sl.offGain,
+                                                    d.packed + sl.offR4C, d.packed + sl.offNf, (int64_t)sl.bytes, d.mGain, d.mR4C,
+                                                    d.mNf, d.stream);
+            if (rc != KBEST_OK) {
+                drain(m);
+                return mfail(m, rc, std::string("device ") + std::to_string(d.id) + ": " + kbest_last_error(d.ctx));
+            }
+        }
+        drain(m);
+        Dev &d0 = m->dev[0];
+        M_HIP(m, hipSetDevice(d0.id));
+        M_HIP(m, hipMemcpy(gain, d0.mGain, (size_t)B * k * 8, hipMemcpyDeviceToHost));
+        M_HIP(m, hipMemcpy(row4col, d0.mR4C, (size_t)B * k * maxCol * 4, hipMemcpyDeviceToHost));
+        M_HIP(m, hipMemcpy(nf, d0.mNf, (size_t)B * 4, hipMemcpyDeviceToHost));
+        if (col4row)  // not part of the exchange: the inverse of row4col, rows without a real column -1
+            for (int b = 0; b < B; b++)
+                for (int s = 0; s < k; s++) {
+                    int32_t *c = col4row + ((size_t)b * k + s) * maxRow;
+                    for (int r = 0; r < maxRow; r++) c[r] = -1;
+                    if (s >= nf[b]) continue;
+                    const int M = nCol ? nCol[b] : maxCol;
+                    const int32_t *r4 = row4col + ((size_t)b * k + s) * maxCol;
+                    for (int j = 0; j < M; j++)
+                        if (r4[j] >= 0 && r4[j] < maxRow) c[r4[j]] = j;
+                }
     }
     for (int b = 0; b < B; b++)
         if (nf[b] < 0) return mfail(m, nf[b] == -1 ? KBEST_ERR_UNSUPPORTED : KBEST_ERR_INTERNAL, "kbest_batch_f64_multi: a problem came back with nf < 0");
     return KBEST_OK;
 }
 
+int kbest_batch_f64_multi(kbest_multi *m, const kbest_opts *opts, int B, int maxRow, int maxCol, const int32_t *nRow,
+                          const int32_t *nCol, const double *cost, int k, int32_t *row4col, int32_t *col4row, double *gain,
+                          int32_t *nf)
+{
+    return kbest_batch_f64_multi_ex(m, opts, KBEST_MULTI_BATCH, 0, B, maxRow, maxCol, nRow, nCol, cost, k, row4col, col4row, gain, nf);
+}
+
 int kbest_multi_tables_agree(kbest_multi *m)
 {
     if (!m || m->lastB == 0) return KBEST_ERR_BAD_ARG;
+    for (auto &d : m->dev) d.issued = false;
+    if (m->lastMode == KBEST_MULTI_BATCH) {
+        std::vector<unsigned char> a(m->lastBytes), b(m->lastBytes);
+        for (size_t g = 0; g < m->dev.size(); g++) {
+            Dev &d = m->dev[g];
+            M_HIP(m, hipSetDevice(d.id));
+            M_HIP(m, hipMemcpy(g ? b.data() : a.data(), d.packed, m->lastBytes, hipMemcpyDeviceToHost));
+            if (g && memcmp(a.data(), b.data(), m->lastBytes)) return 0;
+        }
+        return 1;
+    }
     const size_t nG = (size_t)m->lastB * m->lastK, nR = nG * m->lastCol;
     std::vector<double> g0(nG), g1(nG);
     std::vector<int32_t> r0(nR), r1(nR), n0(m->lastB), n1(m->lastB);
     for (size_t g = 0; g < m->dev.size(); g++) {
         Dev &d = m->dev[g];
         M_HIP(m, hipSetDevice(d.id));
-        M_HIP(m, hipMemcpy(g ? g1.data() : g0.data(), d.gGain, nG * 8, hipMemcpyDeviceToHost));
-        M_HIP(m, hipMemcpy(g ? r1.data() : r0.data(), d.gR4C, nR * 4, hipMemcpyDeviceToHost));
-        M_HIP(m, hipMemcpy(g ? n1.data() : n0.data(), d.gNf, (size_t)m->lastB * 4, hipMemcpyDeviceToHost));
+        M_HIP(m, hipMemcpy(g ? g1.data() : g0.data(), d.mGain, nG * 8, hipMemcpyDeviceToHost));
+        M_HIP(m, hipMemcpy(g ? r1.data() : r0.data(), d.mR4C, nR * 4, hipMemcpyDeviceToHost));
+        M_HIP(m, hipMemcpy(g ? n1.data() : n0.data(), d.mNf, (size_t)m->lastB * 4, hipMemcpyDeviceToHost));
         if (g && (memcmp(g0.data(), g1.data(), nG * 8) || memcmp(r0.data(), r1.data(), nR * 4) ||
                   memcmp(n0.data(), n1.data(), (size_t)m->lastB * 4)))
             return 0;

@@ -57,11 +57,17 @@ def merge_subtree_topk(gain: torch.Tensor, row4col: torch.Tensor, nf: torch.Tens
     """Subtree mode.  gain[B,k], row4col[B,k,M], nf[B] are this rank's k best of ITS root subtrees; slot 0 is
     the root itself on every rank.  Returns the global (gain[B,k], row4col[B,k,M], nf[B]), identical on all
     ranks: root first, then the k-1 best of the union of the ranks' slots 1.. in increasing cost
-    (decreasing profit when maximize)."""
+    (decreasing profit when maximize).  (On the GPU node the merge itself runs on the device:
+    kbest_merge_topk_f64_dev / kbest_batch_f64_multi_ex; this torch form is the same rule, used with gloo.)"""
     world = dist.get_world_size()
     G = _all_gather(gain, world)        # [W, B, k]
     R = _all_gather(row4col, world)     # [W, B, k, M]
     Nf = _all_gather(nf, world)         # [W, B]
+    return merge_lists(G, R, Nf, k, maximize)
+
+
+def merge_lists(G: torch.Tensor, R: torch.Tensor, Nf: torch.Tensor, k: int, maximize: bool = False):
+    """The k-way merge of W shards' lists G[W,B,k], R[W,B,k,M], Nf[W,B] (no communication)."""
     W, B, kk = G.shape
     bad = float("-inf") if maximize else float("inf")
     slot = torch.arange(kk, device=G.device).view(1, 1, kk)
@@ -69,12 +75,13 @@ def merge_subtree_topk(gain: torch.Tensor, row4col: torch.Tensor, nf: torch.Tens
     cand = torch.where(valid, G, torch.full_like(G, bad)).permute(1, 0, 2).reshape(B, W * kk)
     rows = R.permute(1, 0, 2, 3).reshape(B, W * kk, -1)
     # Exact ties in gain (integer-like costs; the reference's own order is a heap artefact) are
-    # ordered by the assignment itself, so the merged table does not depend on which rank a hypothesis came from or on
-    # the number of ranks: first a stable sort by a mixing key of row4col, then the stable sort by gain.
-    mix = torch.zeros((B, W * kk), dtype=torch.int64, device=G.device)
-    for c in range(rows.shape[-1]):
-        mix = mix * 1000003 + rows[..., c].to(torch.int64) + 1
-    o1 = torch.argsort(mix, dim=1, stable=True)
+    # ordered by the assignment itself -- lexicographic row4col, the rule of the device merge (kbest_merge.hip) -- so the
+    # merged table does not depend on which rank a hypothesis came from or on the number of ranks: stable sorts by the
+    # columns from the last to the first (a lexicographic sort), then the stable sort by gain.
+    o1 = torch.arange(W * kk, device=G.device).unsqueeze(0).expand(B, -1).contiguous()
+    for c in range(rows.shape[-1] - 1, -1, -1):
+        key = torch.gather(rows[..., c].to(torch.int64), 1, o1)
+        o1 = torch.gather(o1, 1, torch.argsort(key, dim=1, stable=True))
     o2 = torch.argsort(torch.gather(cand, 1, o1), dim=1, descending=maximize, stable=True)
     order = torch.gather(o1, 1, o2)[:, : k - 1]
     cg = torch.gather(cand, 1, order)
@@ -83,5 +90,5 @@ def merge_subtree_topk(gain: torch.Tensor, row4col: torch.Tensor, nf: torch.Tens
     out_r = torch.cat([R[0, :, :1], cr], 1)
     n_other = valid.sum(dim=(0, 2))
     feasible = Nf[0] > 0
-    out_nf = torch.where(feasible, torch.clamp(1 + n_other, max=k), torch.zeros_like(n_other)).to(nf.dtype)
-    return out_g, out_r, out_nf
+    out_nf = torch.where(feasible, torch.clamp(1 + n_other, max=k), torch.zeros_like(n_other))
+    return out_g, out_r, out_nf.to(Nf.dtype)

@@ -24,8 +24,9 @@ C_ABI_SYMBOLS = (
     "kbest_bruteforce_probs_batch_f64", "kbest_assign_batch_f64", "kbest_to_probs_f64",
     "kbest_assoc_probs_batch_f64_dev", "kbest_reserve_assoc",
     "kbest_create_multi", "kbest_destroy_multi", "kbest_multi_size", "kbest_multi_last_error", "kbest_batch_f64_multi",
-    "kbest_multi_tables_agree",
+    "kbest_multi_tables_agree", "kbest_batch_f64_multi_ex", "kbest_merge_topk_f64_dev",
 )
+KBEST_MULTI_BATCH, KBEST_MULTI_SUBTREE = 0, 1
 
 
 class KBestError(RuntimeError):
@@ -93,6 +94,10 @@ def load_library():
     lib.kbest_batch_f64_multi.argtypes = [vp, C.POINTER(KBestOpts), C.c_int, C.c_int, C.c_int, i32p, i32p, dp, C.c_int, i32p,
                                           i32p, dp, i32p]
     lib.kbest_multi_tables_agree.argtypes = [vp]
+    lib.kbest_batch_f64_multi_ex.argtypes = [vp, C.POINTER(KBestOpts), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p, i32p, dp,
+                                             C.c_int, i32p, i32p, dp, i32p]
+    lib.kbest_merge_topk_f64_dev.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int64, dp, i32p,
+                                             i32p, vp]
     _lib = lib
     return lib
 
@@ -289,6 +294,15 @@ class KBestEngine:
                                                  dp(d_pushed), C.c_void_p(stream) if stream else None))
 
 
+    def merge_topk_dev(self, B, n_shard, k, M, d_gain, d_row4col, d_nf, shard_stride_bytes, d_out_gain, d_out_row4col, d_out_nf,
+                       maximize=False, stream=None):
+        """kbest_merge_topk_f64_dev: k-way merge of per-shard k-best lists (torch tensors / device pointers)."""
+        def dp(t):
+            return None if t is None else C.c_void_p(t.data_ptr() if hasattr(t, "data_ptr") else int(t))
+        self._check(self.lib.kbest_merge_topk_f64_dev(self.ctx, B, n_shard, k, M, int(bool(maximize)), dp(d_gain), dp(d_row4col),
+                                                      dp(d_nf), int(shard_stride_bytes), dp(d_out_gain), dp(d_out_row4col),
+                                                      dp(d_out_nf), C.c_void_p(stream) if stream else None))
+
     def reserve_assoc(self, B, maxRawRow, maxCol, k):
         self._check(self.lib.kbest_reserve_assoc(self.ctx, B, maxRawRow, maxCol, k))
 
@@ -325,7 +339,10 @@ class KBestMulti:
         except Exception:
             pass
 
-    def kbest(self, costs, N, M, k, maximize=False, cutoff=None, nRow=None, nCol=None):
+    def kbest(self, costs, N, M, k, maximize=False, cutoff=None, nRow=None, nCol=None, subtree=False, n_shard=0):
+        """Batch mode (default): contiguous blocks of the batch per device.  subtree=True: every device enumerates its share
+        of the root's subtrees of every matrix (n_shard shards, 0 = one per device), one all-gather of the packed lists,
+        k-way merge on the device (kbest_merge.hip)."""
         costs = np.ascontiguousarray(costs, dtype=np.float64).reshape(-1, N * M)
         B = costs.shape[0]
         r4c = np.empty((B, k, M), np.int32); c4r = np.empty((B, k, N), np.int32)
@@ -335,8 +352,12 @@ class KBestMulti:
         o.maximize = int(bool(maximize)); o.use_cutoff = int(cutoff is not None); o.cutoff = float(cutoff or 0.0)
         if nRow is not None:
             nRow = np.ascontiguousarray(nRow, dtype=np.int32); nCol = np.ascontiguousarray(nCol, dtype=np.int32)
-        rc = self.lib.kbest_batch_f64_multi(self.m, C.byref(o), B, N, M, _ptr(nRow), _ptr(nCol), _ptr(costs), k, _ptr(r4c),
-                                            _ptr(c4r), _ptr(gain), _ptr(nf))
+        if subtree:
+            rc = self.lib.kbest_batch_f64_multi_ex(self.m, C.byref(o), KBEST_MULTI_SUBTREE, int(n_shard), B, N, M, _ptr(nRow),
+                                                   _ptr(nCol), _ptr(costs), k, _ptr(r4c), _ptr(c4r), _ptr(gain), _ptr(nf))
+        else:
+            rc = self.lib.kbest_batch_f64_multi(self.m, C.byref(o), B, N, M, _ptr(nRow), _ptr(nCol), _ptr(costs), k, _ptr(r4c),
+                                                _ptr(c4r), _ptr(gain), _ptr(nf))
         if rc != 0:
             raise KBestError(f"{self.lib.kbest_strerror(rc).decode()}: {self.lib.kbest_multi_last_error(self.m).decode()}")
         return nf, r4c, c4r, gain

@@ -103,7 +103,7 @@ def test_fixed_seed_soak_on_every_kernel(monkeypatch, knobs):
     near-ties at 1e-9; rectangular and square; maximise; cutoff; k = 1 ... 300), fixed seed, on the default routing and with
     each kernel forced (the a-priori thresholds are on wherever the launch shape has them)."""
     eng = engine_with(monkeypatch, **knobs)
-    ncase, nprob, bad = soak_lib.run(eng, seed=20261003, n_cases=110 if not knobs else 60, big_frac=0.05 if not knobs else 0.0,
+    ncase, nprob, bad = soak_lib.run(eng, seed=20261003, n_cases=600 if not knobs else 300, big_frac=0.05 if not knobs else 0.0,
                                      big_max=130)
     eng.close()
     assert bad is None, bad
@@ -180,3 +180,105 @@ def test_chunked_host_entry_odd_ragged_and_pushed(engine):
     for b in (0, 549, 550, 1099):
         onf, or4c, _, og, op = ol.orc_kbest_batch(costs[b:b + 1], N, M, k)
         assert nf[b] == onf[0] and (r4c[b] == or4c[0]).all() and pushed[b] == op[0]
+
+
+def _shard_lists(eng, costs, N, M, k, S, **kw):
+    """The k best of every shard's root subtrees (engine, root_shard = (s, S)), stacked [S, B, ...]."""
+    out = [eng.kbest(costs, N, M, k, root_shard=(s, S), **kw) for s in range(S)]
+    return (np.stack([o[3] for o in out]), np.stack([o[1] for o in out]), np.stack([o[0] for o in out]))
+
+
+@pytest.mark.parametrize("S", [1, 2, 3, 8])
+def test_device_merge_is_the_global_kbest(engine, S):
+    """kbest_merge_topk_f64_dev (the global k-best heap of the subtree-sharded enumeration, on the device): S shards'
+    lists -> the single-enumeration result = the oracle; equal to the torch merge of distributed.py (same tie rule); with
+    exact ties (integer costs) the gains agree as multisets and the table does not depend on the number of shards."""
+    import torch
+    from probabilisticsemslam_amd import distributed as kd
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(40 + S)
+    for (N, M, k, B, ties, maximize) in ((16, 16, 50, 6, False, False), (40, 12, 120, 3, False, False), (10, 10, 64, 5, True, False),
+                                          (24, 24, 30, 4, False, True), (5, 5, 200, 3, False, False)):
+        costs = rng.random((B, N * M))
+        if ties:
+            costs = np.floor(costs * 3)
+        G, R, Nf = _shard_lists(engine, costs, N, M, k, S, maximize=maximize)
+        tg, tr, tn = (torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (G, R, Nf))
+        og = torch.zeros((B, k), dtype=torch.float64, device=dev)
+        orr = torch.full((B, k, M), -1, dtype=torch.int32, device=dev)
+        on = torch.zeros(B, dtype=torch.int32, device=dev)
+        # plain [S][B][...] arrays: the three tables have different shard strides, so merge shard by shard layout = packed slices
+        up16 = lambda x: (x + 15) & ~15  # noqa: E731
+        off_r, off_n = up16(B * k * 8), up16(B * k * 8) + up16(B * k * M * 4)
+        sl = off_n + up16(B * 4)
+        pack = torch.zeros(S * sl, dtype=torch.uint8, device=dev)
+        for s in range(S):
+            base = s * sl
+            pack[base: base + B * k * 8] = tg[s].contiguous().view(torch.uint8).reshape(-1)
+            pack[base + off_r: base + off_r + B * k * M * 4] = tr[s].contiguous().view(torch.uint8).reshape(-1)
+            pack[base + off_n: base + off_n + B * 4] = tn[s].contiguous().view(torch.uint8).reshape(-1)
+        p0 = pack.data_ptr()
+        engine.merge_topk_dev(B, S, k, M, p0, p0 + off_r, p0 + off_n, sl, og, orr, on, maximize=maximize)
+        torch.cuda.synchronize()
+        mg, mr, mn = og.cpu().numpy(), orr.cpu().numpy(), on.cpu().numpy()
+        # the torch merge (gloo path) gives the same table, ties included
+        cg, cr, cn = kd.merge_lists(tg.cpu(), tr.cpu(), tn.cpu(), k, maximize)
+        for b in range(B):
+            n = int(mn[b])
+            assert n == int(cn[b])
+            assert (bits(mg[b, :n]) == bits(cg[b, :n].numpy())).all() and (mr[b, :n] == cr[b, :n].numpy()).all()
+        onf, or4c, _, ogain, _ = ol.orc_kbest_batch(costs, N, M, k, maximize=maximize)
+        for b in range(B):
+            n = int(onf[b])
+            assert mn[b] == n
+            if ties:
+                assert (np.sort(mg[b, :n]) == np.sort(ogain[b, :n])).all()
+                assert len({tuple(x) for x in mr[b, :n].tolist()}) == n
+            else:
+                assert (bits(mg[b, :n]) == bits(ogain[b, :n])).all() and (mr[b, :n] == or4c[b, :n]).all()
+
+
+def test_multi_entry_subtree_mode_on_one_device(engine):
+    """kbest_batch_f64_multi_ex(KBEST_MULTI_SUBTREE) with nDev = 1 standing in for 1, 2, 4 and 8 shards: enumeration per
+    shard, ONE packed all-gather on the RCCL communicator, merge on the device = the batch mode = the oracle."""
+    m = pk.KBestMulti([0])
+    rng = np.random.default_rng(12)
+    for (N, M, k, B) in ((64, 64, 200, 3), (30, 10, 100, 4), (16, 16, 50, 7)):
+        costs = rng.random((B, N * M)) * 3
+        onf, or4c, oc4r, og, _ = ol.orc_kbest_batch(costs, N, M, k)
+        for S in (1, 2, 4, 8):
+            nf, r4c, c4r, g = m.kbest(costs, N, M, k, subtree=True, n_shard=S)
+            assert (nf == onf).all() and (r4c == or4c).all() and (bits(g) == bits(og)).all(), (N, M, k, S)
+            assert m.tables_agree()
+            # col4row is the inverse of row4col, -1 for rows without a real column
+            for b in range(B):
+                for s in range(0, int(nf[b]), 17):
+                    want = np.full(N, -1)
+                    want[r4c[b, s]] = np.arange(M)
+                    assert (c4r[b, s] == want).all()
+    # bad shapes are argument errors, not kernel errors
+    with pytest.raises(pk.KBestError):
+        m.kbest(np.zeros((2, 12)), 4, 3, 5, nRow=[4, 2], nCol=[3, 3])
+    m.close()
+
+
+def test_multi_entry_two_devices():
+    """The multi-device entries on two (or more) GPUs of the box: batch mode with B not divisible by the devices and with
+    B smaller than the number of devices, subtree mode.  Skipped on a one-GPU box (the driver's multi-GPU node runs it)."""
+    lib = pk.load_library()
+    n = lib.kbest_device_count()
+    if n < 2:
+        pytest.skip("needs at least two GPUs")
+    devs = list(range(min(n, 8)))
+    m = pk.KBestMulti(devs)
+    rng = np.random.default_rng(2)
+    for (N, M, k, B) in ((32, 32, 100, 2 * len(devs) + 1), (16, 16, 50, 1), (64, 64, 200, len(devs) - 1)):
+        costs = rng.random((B, N * M))
+        onf, or4c, oc4r, og, _ = ol.orc_kbest_batch(costs, N, M, k)
+        nf, r4c, c4r, g = m.kbest(costs, N, M, k)
+        assert (nf == onf).all() and (r4c == or4c).all() and (bits(g) == bits(og)).all()
+        assert m.tables_agree()
+        nf, r4c, c4r, g = m.kbest(costs, N, M, k, subtree=True)
+        assert (nf == onf).all() and (r4c == or4c).all() and (bits(g) == bits(og)).all()
+        assert m.tables_agree()
+    m.close()
