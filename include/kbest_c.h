@@ -47,6 +47,7 @@
 #ifndef KBEST_C_H
 #define KBEST_C_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -125,7 +126,14 @@ int kbest_batch_f64_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRo
                         const int64_t *d_costOff, int k, int32_t *d_row4col, int32_t *d_col4row,
                         double *d_gain, int32_t *d_nf, int64_t *d_pushed, void *stream);
 
-/* Same with host buffers (copies in, runs, copies out, synchronises). */
+/*
+ * Same with host buffers (copies in, runs, copies out, synchronises; col4row may be NULL = not wanted).  A caller that runs
+ * batch after batch with the same
+ * buffers should register them once (kbest_register_host_buffer): result tables that lie in registered memory are written
+ * there by the kernels themselves, spread over the whole run, and nothing is left to copy when the last problem ends;
+ * cost blocks in registered memory come up with an asynchronous copy.  (1 024 x 64x64, k = 200, 107 MB of tables: the
+ * copying path takes ~4.4 ms per call, the registered one ~3 ms, the kernel alone 2.7.)
+ */
 int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, int maxCol,
                     const int32_t *nRow, const int32_t *nCol, const double *cost,
                     const int64_t *costOff, int k, int32_t *row4col, int32_t *col4row, double *gain,
@@ -243,6 +251,14 @@ int kbest_quadric_assoc_probs_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL
  */
 int kbest_bb_match_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nR, const double *boxL,
                              const double *boxR, double gate, int32_t *assign);
+
+/*
+ * Pin [ptr, ptr + bytes) of caller-owned host memory and map it into the device's address space (hipHostRegister), for the
+ * host-buffer entries above.  The range must stay allocated until kbest_unregister_host_buffer (or kbest_destroy).  Any number
+ * of ranges; a buffer argument is taken as registered when it lies completely inside one of them.
+ */
+int kbest_register_host_buffer(kbest_ctx *ctx, void *ptr, size_t bytes);
+int kbest_unregister_host_buffer(kbest_ctx *ctx, void *ptr);
 
 /*
  * The "global k-best heap" of the subtree-sharded enumeration (reference partition: split,

@@ -20,6 +20,7 @@ struct DevBufRaw { void *p = nullptr; size_t bytes = 0; };
 struct kbest_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr};  // the other pieces of a large host-entry batch (kbest_batch_f64)
     unsigned char *states = nullptr;  // hypothesis-state workspace (+ the slot -> state table behind it)
     size_t statesBytes = 0;
         unsigned char *wide = nullptr;    // work space of the general-size kernel (kbest_wide.hip)
@@ -64,6 +65,11 @@ struct kbest_ctx {
     DevBufRaw stageIn, stageOut;
     // Device buffers of the host-pointer entry points are recycled: the reference calls assignmentProb once per
     // frame, and a dozen hipMalloc/hipFree pairs per call cost more than the kernels of a 30 x 10 problem.
+    // Host memory the caller has registered (kbest_register_host_buffer): pinned and mapped into the device's address space,
+    // so that result tables go there straight from the kernel and cost blocks come up with asynchronous copies.
+    struct HostReg { char *host; char *dev; size_t bytes; };
+    std::vector<HostReg> regs;
+    std::mutex regMu;
     struct Block { void *p; size_t n; bool used; };
     std::vector<Block> cache;
     size_t cacheBytes = 0;  // all blocks, idle or in use
@@ -296,6 +302,7 @@ int kbest_destroy(kbest_ctx *ctx)
 {
     if (!ctx) return KBEST_OK;
     (void)hipSetDevice(ctx->device);
+    for (auto &r : ctx->regs) (void)hipHostUnregister(r.host);
     if (ctx->states) (void)hipFree(ctx->states);
     if (ctx->wide) (void)hipFree(ctx->wide);
     for (auto &b : ctx->cache) (void)hipFree(b.p);
@@ -304,6 +311,8 @@ int kbest_destroy(kbest_ctx *ctx)
     if (ctx->stageIn.p) (void)hipFree(ctx->stageIn.p);
     if (ctx->stageOut.p) (void)hipFree(ctx->stageOut.p);
     if (ctx->lastEvent) (void)hipEventDestroy(ctx->lastEvent);
+    for (auto &a : ctx->aux)
+        if (a) (void)hipStreamDestroy(a);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return KBEST_OK;
@@ -503,6 +512,12 @@ struct DevExtra {  // optional outputs / modes of kbest_assign_batch_f64 (root s
     int gainCols = 0;
 };
 
+// A launch that is one piece of a larger batch (the host entry sends a big batch through in pieces whose uploads, kernels
+// and result traffic overlap): kernel choice, launch shape and workspace are those of the WHOLE batch (`logicalB`), the
+// piece uses the workspace slice of its problems (`blockBase` = index of its first problem) and may run concurrently with
+// the other pieces on another stream (it is not ordered behind the context's previous launch).
+struct SubBatch { int logicalB = 0, blockBase = 0; };
+
 // Order this launch (on stream s) behind the previous launch of the context when that ran on another stream: both
 // use the context's one hypothesis workspace.  Called with ctx->mu held.
 static int order_behind_last(kbest_ctx *ctx, hipStream_t s)
@@ -526,7 +541,7 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
                           const int32_t *d_nRow, const int32_t *d_nCol, const double *d_cost,
                           const int64_t *d_costOff, int k, int32_t *d_row4col, int32_t *d_col4row,
                           double *d_gain, int32_t *d_nf, int64_t *d_pushed, void *stream, bool grow,
-                          const DevExtra *extra = nullptr)
+                          const DevExtra *extra = nullptr, const SubBatch *sub = nullptr)
 {
     if (!ctx) return KBEST_ERR_BAD_ARG;
     if (!opts || B < 0 || k < 1 || maxCol < 1 || maxRow < maxCol || !d_cost || !d_row4col || !d_gain || !d_nf)
@@ -541,8 +556,10 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
     // problems), a uniform batch of larger problems, or any shape when k is beyond the LDS pool.
     const int fastRow = maxRow < KBEST_MAX_DIM ? maxRow : KBEST_MAX_DIM;
     const int fastCol = maxCol < fastRow ? maxCol : fastRow;
+    const int LB = sub ? sub->logicalB : B;          // the batch that decides kernel, shape and workspace
+    const size_t base = sub ? (size_t)sub->blockBase : 0;  // first problem of this piece in that batch
     Shape shape;
-    const bool kFits = k_fits_fast(ctx, B, fastRow, k, opts->flags, &shape);
+    const bool kFits = k_fits_fast(ctx, LB, fastRow, k, opts->flags, &shape);
     const int spec = shape.spec, nWaves = shape.nWaves;
     const bool forceWide = ctx->forceWide && !extra;  // test hook: everything through the general-size kernel
     const bool runFast = !forceWide && kFits && (maxRow <= KBEST_MAX_DIM || d_nRow != nullptr);
@@ -551,7 +568,7 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
     std::lock_guard<std::mutex> lock(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
-    {
+    if (!sub) {
         int rc = order_behind_last(ctx, s);
         if (rc != KBEST_OK) return rc;
     }
@@ -569,13 +586,13 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
     // problem and the enumeration long, else up to 20 % slower (4 096 x 32x32, k = 200: 5.4 ms against 4.9).  Batches that
     // cannot fill the chip (B <= 2 CUs) stay on the small-problem kernel (16 waves per problem: 0.33 against 0.40 ms at
     // 256 x 16x16, k = 200), rectangular ones too (implicit zero columns).
-    const bool laneWins = ctx->forceLane || (maxCol == maxRow && B > 2 * ctx->nCU && !ctx->forceSmall &&
-                                             (maxRow <= 16 || (B <= 4 * ctx->nCU && k >= 100)));
+    const bool laneWins = ctx->forceLane || (maxCol == maxRow && LB > 2 * ctx->nCU && !ctx->forceSmall &&
+                                             (maxRow <= 16 || (LB <= 4 * ctx->nCU && k >= 100)));
     if (!extra && !forceWide && laneWins && !(opts->flags & (KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_PRUNE | KBEST_FLAG_RECT_ROOT |
                                                                  KBEST_FLAG_NO_SHIFT | KBEST_FLAG_EXACT_ROOT)) &&
-        lane_fits(ctx, B, maxRow, maxCol, k, &lsh)) {
+        lane_fits(ctx, LB, maxRow, maxCol, k, &lsh)) {
         size_t slotOff = 0;
-        int rc = ensure_states(ctx, lane_states_need(B, maxRow, maxCol, k, lsh.spec, &slotOff), grow);
+        int rc = ensure_states(ctx, lane_states_need(LB, maxRow, maxCol, k, lsh.spec, &slotOff), grow);
         if (rc != KBEST_OK) return rc;
         kb::Params p;
         memset(&p, 0, sizeof(p));
@@ -599,22 +616,22 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         p.gain = d_gain;
         p.nf = d_nf;
         p.pushed = reinterpret_cast<long long *>(d_pushed);
-        p.states = ctx->states;
         p.stateStride = kb::lane_state_stride(maxRow);
         p.statesPerProblem = kb::lane_states_per_problem(k, lsh.spec, maxCol);
+        p.states = ctx->states + base * (size_t)p.statesPerProblem * (size_t)p.stateStride;
         p.lazyStates = p.statesPerProblem;
         p.spec = lsh.spec;
         p.prof = ctx->prof;
-        p.slotSid = reinterpret_cast<unsigned short *>(ctx->states + slotOff);
+        p.slotSid = reinterpret_cast<unsigned short *>(ctx->states + slotOff) + base * (size_t)kb::slot_table_stride(k);
         hipError_t e = kb::launch_kbest_lane(p, B, lsh.nWaves, lsh.lanes, s);
         if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "lane-per-child kbest kernel launch", e);
         return KBEST_OK;
     }
     int snw = 0;
-    const bool smallWins = ctx->forceSmall || maxCol < maxRow || B <= 2 * ctx->nCU;
+    const bool smallWins = ctx->forceSmall || maxCol < maxRow || LB <= 2 * ctx->nCU;
     if (!extra && !forceWide && smallWins && !(opts->flags & (KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_PRUNE)) &&
-        opts->root_col_stride <= 1 && small_fits(ctx, B, maxRow, maxCol, k, false, &snw)) {
-        int rc = ensure_states(ctx, small_states_need(B, maxRow, maxCol, k, snw), grow);
+        opts->root_col_stride <= 1 && small_fits(ctx, LB, maxRow, maxCol, k, false, &snw)) {
+        int rc = ensure_states(ctx, small_states_need(LB, maxRow, maxCol, k, snw), grow);
         if (rc != KBEST_OK) return rc;
         kb::SmallParams sp;
         memset(&sp, 0, sizeof(sp));
@@ -634,20 +651,21 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         sp.col4row = d_col4row;
         sp.gain = d_gain;
         sp.nf = d_nf;
-        sp.states = ctx->states;
         sp.stateStride = kb::small_state_stride(maxRow, maxCol);
         sp.statesPerProblem = kb::small_states_per_problem(k, snw, maxCol);
+        sp.states = ctx->states + base * (size_t)sp.statesPerProblem * (size_t)sp.stateStride;
         sp.prof = ctx->prof;
         hipError_t e = kb::launch_kbest_small(sp, B, snw, s);
         if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "small-problem kbest kernel launch", e);
         return KBEST_OK;
     }
 
+    if (sub && runWide) return fail(ctx, KBEST_ERR_INTERNAL, "a piece of a batch on the general-size kernel");
     if (runFast) {
-        int rc = reserve_states(ctx, B, fastRow, k, grow);
+        int rc = reserve_states(ctx, LB, fastRow, k, grow);
         if (rc != KBEST_OK) return rc;
         size_t slotOff = 0;
-        (void)states_need(ctx, B, fastRow, k, &slotOff);
+        (void)states_need(ctx, LB, fastRow, k, &slotOff);
         kb::Params p;
         p.cost = d_cost;
         p.costOff = reinterpret_cast<const long long *>(d_costOff);
@@ -669,13 +687,13 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         p.gain = d_gain;
         p.nf = d_nf;
         p.pushed = reinterpret_cast<long long *>(d_pushed);
-        p.states = ctx->states;
         p.stateStride = kb::state_stride(fastRow);
-        p.statesPerProblem = k + ctx->extraStates + eager_states(ctx, B, fastRow, k);
+        p.statesPerProblem = k + ctx->extraStates + eager_states(ctx, LB, fastRow, k);
+        p.states = ctx->states + base * (size_t)p.statesPerProblem * (size_t)p.stateStride;
         p.lazyStates = k + ctx->extraStates;
         p.spec = spec;
         p.prof = ctx->prof;
-        p.slotSid = reinterpret_cast<unsigned short *>(ctx->states + slotOff);
+        p.slotSid = reinterpret_cast<unsigned short *>(ctx->states + slotOff) + base * (size_t)kb::slot_table_stride(k);
         p.dualU = extra ? extra->dualU : nullptr;
         p.dualV = extra ? extra->dualV : nullptr;
         p.gainCols = extra ? extra->gainCols : 0;
@@ -760,13 +778,54 @@ int kbest_batch_f64_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRo
                           d_gain, d_nf, d_pushed, stream, false);
 }
 
+// device address of [p, p + n) when the whole range lies inside a registered host buffer, else nullptr
+static void *mapped(kbest_ctx *ctx, const void *p, size_t n)
+{
+    std::lock_guard<std::mutex> lock(ctx->regMu);
+    const char *q = static_cast<const char *>(p);
+    for (const auto &r : ctx->regs)
+        if (q >= r.host && q + n <= r.host + r.bytes) return r.dev + (q - r.host);
+    return nullptr;
+}
+
+int kbest_register_host_buffer(kbest_ctx *ctx, void *ptr, size_t bytes)
+{
+    if (!ctx || !ptr || bytes == 0) return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_register_host_buffer: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+    if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "hipHostRegister", e);
+    void *dev = nullptr;
+    e = hipHostGetDevicePointer(&dev, ptr, 0);
+    if (e != hipSuccess) { (void)hipHostUnregister(ptr); return fail(ctx, KBEST_ERR_HIP, "hipHostGetDevicePointer", e); }
+    std::lock_guard<std::mutex> lock(ctx->regMu);
+    ctx->regs.push_back({static_cast<char *>(ptr), static_cast<char *>(dev), bytes});
+    return KBEST_OK;
+}
+
+int kbest_unregister_host_buffer(kbest_ctx *ctx, void *ptr)
+{
+    if (!ctx || !ptr) return KBEST_ERR_BAD_ARG;
+    {
+        std::lock_guard<std::mutex> lock(ctx->regMu);
+        auto it = ctx->regs.begin();
+        for (; it != ctx->regs.end(); ++it)
+            if (it->host == ptr) break;
+        if (it == ctx->regs.end()) return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_unregister_host_buffer: not registered");
+        ctx->regs.erase(it);
+    }
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);  // nothing may still be writing there
+    HIP_TRY(ctx, hipHostUnregister(ptr));
+    return KBEST_OK;
+}
+
 int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, int maxCol,
                     const int32_t *nRow, const int32_t *nCol, const double *cost,
                     const int64_t *costOff, int k, int32_t *row4col, int32_t *col4row, double *gain,
                     int32_t *nf, int64_t *pushed)
 {
     if (!ctx) return KBEST_ERR_BAD_ARG;
-    if (!opts || B < 0 || k < 1 || maxCol < 1 || maxRow < maxCol || !cost || !row4col || !col4row || !gain || !nf)
+    if (!opts || B < 0 || k < 1 || maxCol < 1 || maxRow < maxCol || !cost || !row4col || !gain || !nf)  // (col4row NULL: not wanted)
         return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_batch_f64: bad argument");
     if (opts->flags & (KBEST_FLAG_RECT_ROOT | KBEST_FLAG_NO_SHIFT)) return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_batch_f64: internal flag");
     if ((nRow == nullptr) != (nCol == nullptr))
@@ -785,17 +844,40 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
         nCost = (size_t)B * maxRow * maxCol;
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    DevBuf dCost, dOff, dNR, dNC, dR4C, dC4R, dGain, dNf, dPushed;
     const size_t nR4C = (size_t)B * k * maxCol, nC4R = (size_t)B * k * maxRow, nG = (size_t)B * k;
+    // Result tables in registered (pinned, device-mapped) host memory (kbest_register_host_buffer) are written THERE by the
+    // kernels, spread over the whole run (the 64-row kernel emits a slot's tables as soon as the slot is final), so that
+    // nothing is left to copy when the last matrix ends; otherwise they are staged in device buffers and copied back.
+    int32_t *mR4C = static_cast<int32_t *>(mapped(ctx, row4col, nR4C * 4));
+    int32_t *mC4R = col4row ? static_cast<int32_t *>(mapped(ctx, col4row, nC4R * 4)) : nullptr;
+    double *mGain = static_cast<double *>(mapped(ctx, gain, nG * 8));
+    int32_t *mNf = static_cast<int32_t *>(mapped(ctx, nf, (size_t)B * 4));
+    const bool direct = mR4C && (mC4R || !col4row) && mGain && mNf && !pushed;
+    const bool pinnedCost = mapped(ctx, cost, nCost * 8) != nullptr;
+    DevBuf dCost, dOff, dNR, dNC, dR4C, dC4R, dGain, dNf, dPushed;
     HIP_TRY(ctx, dCost.alloc(ctx, nCost * 8));
-    HIP_TRY(ctx, dR4C.alloc(ctx, nR4C * 4));
-    HIP_TRY(ctx, dC4R.alloc(ctx, nC4R * 4));
-    HIP_TRY(ctx, dGain.alloc(ctx, nG * 8));
-    HIP_TRY(ctx, dNf.alloc(ctx, (size_t)B * 4));
-    // (uniform layout, large batch: the second half of the cost blocks goes up while the first half is being solved, below)
-    const size_t outBytesEarly = ((size_t)B * k * maxCol + (size_t)B * k * maxRow) * 4 + (size_t)B * k * 8;
-    const bool splitUpload = !nRow && !costOff && B >= 4 * ctx->nCU && outBytesEarly >= ((size_t)32 << 20);
-    HIP_TRY(ctx, hipMemcpy(dCost.p, cost, (splitUpload ? (size_t)(B / 2) * maxRow * maxCol : nCost) * 8, hipMemcpyHostToDevice));
+    if (!direct) {
+        HIP_TRY(ctx, dR4C.alloc(ctx, nR4C * 4));
+        if (col4row) HIP_TRY(ctx, dC4R.alloc(ctx, nC4R * 4));
+        HIP_TRY(ctx, dGain.alloc(ctx, nG * 8));
+        HIP_TRY(ctx, dNf.alloc(ctx, (size_t)B * 4));
+        if (pushed) HIP_TRY(ctx, dPushed.alloc(ctx, (size_t)B * 8));
+    }
+    int32_t *oR4C = direct ? mR4C : dR4C.as<int32_t>(), *oC4R = !col4row ? nullptr : (direct ? mC4R : dC4R.as<int32_t>()), *oNf = direct ? mNf : dNf.as<int32_t>();
+    double *oGain = direct ? mGain : dGain.as<double>();
+    // A batch that is large in problems and in output bytes goes through the GPU in PIECES on separate streams: the launch
+    // shape and the workspace are those of the whole batch (SubBatch), so the pieces' workgroups fill the chip exactly as one
+    // launch of the whole batch would -- but a piece starts as soon as ITS cost blocks are up, and its tables cross PCIe
+    // while later pieces still run.  1 024 x 64x64, k = 200 (33 MB in, 107 MB out): pageable buffers 5.7 ms in one piece,
+    // 4.4 in two half-size launches (round 2), now four pieces; registered buffers 3.7 ms in one piece.
+    const size_t outBytes = (nR4C + (col4row ? nC4R : 0)) * 4 + nG * 8;
+    const int fastRow = maxRow < KBEST_MAX_DIM ? maxRow : KBEST_MAX_DIM;
+    const bool canPiece = !costOff && maxRow <= KBEST_MAX_DIM && !ctx->forceWide && B >= 4 * ctx->nCU && outBytes >= ((size_t)32 << 20) &&
+                          k_fits_fast(ctx, B, fastRow, k, opts->flags, nullptr);
+    const int nPiece = canPiece ? 4 : 1;
+    if (nPiece > 1)
+        for (int i = 0; i < 3; i++)
+            if (!ctx->aux[i]) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking));
     if (nRow) {
         HIP_TRY(ctx, dNR.alloc(ctx, (size_t)B * 4));
         HIP_TRY(ctx, dNC.alloc(ctx, (size_t)B * 4));
@@ -806,53 +888,62 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
         HIP_TRY(ctx, dOff.alloc(ctx, (size_t)B * 8));
         HIP_TRY(ctx, hipMemcpy(dOff.p, costOff, (size_t)B * 8, hipMemcpyHostToDevice));
     }
-    if (pushed) HIP_TRY(ctx, dPushed.alloc(ctx, (size_t)B * 8));
-    // slots beyond nf are never written by the kernel: give them a defined value
-    HIP_TRY(ctx, hipMemsetAsync(dR4C.p, 0xFF, nR4C * 4, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(dC4R.p, 0xFF, nC4R * 4, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(dGain.p, 0, nG * 8, ctx->stream));
-    // A large batch goes in two halves: the second half's kernel runs while the first half's tables (the bulk of the
-    // traffic: k x (numRow + numCol) int32 per problem) cross PCIe.  1 024 x 64x64, k = 200: 107 MB out, 5.7 -> 4.9 ms per
-    // call; the halves still fill the chip (>= 2 problems per CU each).
-    const size_t outBytes = (nR4C + nC4R) * 4 + nG * 8;
-    const int nChunk = (B >= 4 * ctx->nCU && outBytes >= ((size_t)32 << 20)) ? 2 : 1;
-    hipEvent_t done[2] = {nullptr, nullptr};
     int rc = KBEST_OK;
-    int b0s[3] = {0, nChunk == 2 ? B / 2 : B, B};
-    for (int c = 0; c < nChunk && rc == KBEST_OK; c++) {
-        const int b0 = b0s[c], nb = b0s[c + 1] - b0;
-        if (c == 1 && splitUpload) {
-            const size_t off = (size_t)b0 * maxRow * maxCol;
-            const hipError_t e = hipMemcpy(dCost.as<double>() + off, cost + off, (nCost - off) * 8, hipMemcpyHostToDevice);
-            if (e != hipSuccess) { rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: upload", e); break; }
-        }
-        rc = batch_dev_impl(ctx, opts, nb, maxRow, maxCol, nRow ? dNR.as<int32_t>() + b0 : nullptr,
-                            nRow ? dNC.as<int32_t>() + b0 : nullptr,
-                            costOff ? dCost.as<double>() : dCost.as<double>() + (size_t)b0 * maxRow * maxCol,
-                            costOff ? dOff.as<int64_t>() + b0 : nullptr, k, dR4C.as<int32_t>() + (size_t)b0 * k * maxCol,
-                            dC4R.as<int32_t>() + (size_t)b0 * k * maxRow, dGain.as<double>() + (size_t)b0 * k,
-                            dNf.as<int32_t>() + b0, pushed ? dPushed.as<int64_t>() + b0 : nullptr, ctx->stream, true);
-        if (rc == KBEST_OK && nChunk == 2) {
-            if (hipEventCreateWithFlags(&done[c], hipEventDisableTiming) != hipSuccess || hipEventRecord(done[c], ctx->stream) != hipSuccess)
-                rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: event", hipGetLastError());
+    hipEvent_t done[4] = {nullptr, nullptr, nullptr, nullptr}, start = nullptr;
+    hipStream_t st[4] = {ctx->stream, ctx->aux[0], ctx->aux[1], ctx->aux[2]};
+    if (nPiece > 1) {
+        // the pieces run on other streams than the context's previous (possibly still running) launch: order them behind it
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        rc = order_behind_last(ctx, ctx->stream);
+        if (rc == KBEST_OK && (hipEventCreateWithFlags(&start, hipEventDisableTiming) != hipSuccess || hipEventRecord(start, ctx->stream) != hipSuccess))
+            rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: event", hipGetLastError());
+        for (int c = 1; c < nPiece && rc == KBEST_OK; c++)
+            if (hipStreamWaitEvent(st[c], start, 0) != hipSuccess) rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: wait", hipGetLastError());
+    }
+    const size_t per = (size_t)maxRow * maxCol;
+    for (int c = 0; c < nPiece && rc == KBEST_OK; c++) {
+        const int b0 = (int)((long long)B * c / nPiece), nb = (int)((long long)B * (c + 1) / nPiece) - b0;
+        const size_t cOff = costOff ? 0 : (size_t)b0 * per, cLen = (nPiece == 1) ? nCost : (size_t)nb * per;
+        hipError_t e;
+        if (pinnedCost) e = hipMemcpyAsync(dCost.as<double>() + cOff, cost + cOff, cLen * 8, hipMemcpyHostToDevice, st[c]);
+        else e = hipMemcpy(dCost.as<double>() + cOff, cost + cOff, cLen * 8, hipMemcpyHostToDevice);  // (complete on return; earlier pieces run meanwhile)
+        if (e != hipSuccess) { rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: upload", e); break; }
+        const SubBatch sub{B, b0};
+        rc = batch_dev_impl(ctx, opts, nb, maxRow, maxCol, nRow ? dNR.as<int32_t>() + b0 : nullptr, nRow ? dNC.as<int32_t>() + b0 : nullptr,
+                            costOff ? dCost.as<double>() : dCost.as<double>() + (size_t)b0 * per, costOff ? dOff.as<int64_t>() + b0 : nullptr,
+                            k, oR4C + (size_t)b0 * k * maxCol, oC4R ? oC4R + (size_t)b0 * k * maxRow : nullptr, oGain + (size_t)b0 * k, oNf + b0,
+                            pushed ? dPushed.as<int64_t>() + b0 : nullptr, st[c], true, nullptr, nPiece > 1 ? &sub : nullptr);
+        if (rc != KBEST_OK) break;
+        // slots beyond nf are never written by the kernels: give them defined values (row4col / col4row -1, gain 0)
+        e = kb::launch_fill_unused(oNf + b0, nb, k, maxCol, maxRow, oR4C + (size_t)b0 * k * maxCol, oC4R ? oC4R + (size_t)b0 * k * maxRow : nullptr,
+                                   oGain + (size_t)b0 * k, st[c]);
+        if (e != hipSuccess) { rc = fail(ctx, KBEST_ERR_HIP, "fill kernel launch", e); break; }
+        if (!direct && nPiece > 1 &&
+            (hipEventCreateWithFlags(&done[c], hipEventDisableTiming) != hipSuccess || hipEventRecord(done[c], st[c]) != hipSuccess))
+            rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: event", hipGetLastError());
+    }
+    if (rc == KBEST_OK && !direct) {
+        for (int c = 0; c < nPiece && rc == KBEST_OK; c++) {
+            const int b0 = (int)((long long)B * c / nPiece), nb = (int)((long long)B * (c + 1) / nPiece) - b0;
+            hipError_t e = (nPiece > 1) ? hipEventSynchronize(done[c]) : hipStreamSynchronize(ctx->stream);
+            if (e == hipSuccess) e = hipMemcpy(row4col + (size_t)b0 * k * maxCol, dR4C.as<int32_t>() + (size_t)b0 * k * maxCol, (size_t)nb * k * maxCol * 4, hipMemcpyDeviceToHost);
+            if (e == hipSuccess && col4row) e = hipMemcpy(col4row + (size_t)b0 * k * maxRow, dC4R.as<int32_t>() + (size_t)b0 * k * maxRow, (size_t)nb * k * maxRow * 4, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(gain + (size_t)b0 * k, dGain.as<double>() + (size_t)b0 * k, (size_t)nb * k * 8, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(nf + b0, dNf.as<int32_t>() + b0, (size_t)nb * 4, hipMemcpyDeviceToHost);
+            if (e == hipSuccess && pushed) e = hipMemcpy(pushed + b0, dPushed.as<int64_t>() + b0, (size_t)nb * 8, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: copy back", e);
         }
     }
-    for (int c = 0; c < nChunk && rc == KBEST_OK; c++) {
-        const int b0 = b0s[c], nb = b0s[c + 1] - b0;
-        hipError_t e = (nChunk == 2) ? hipEventSynchronize(done[c]) : hipStreamSynchronize(ctx->stream);
-        if (e == hipSuccess) e = hipMemcpy(row4col + (size_t)b0 * k * maxCol, dR4C.as<int32_t>() + (size_t)b0 * k * maxCol, (size_t)nb * k * maxCol * 4, hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(col4row + (size_t)b0 * k * maxRow, dC4R.as<int32_t>() + (size_t)b0 * k * maxRow, (size_t)nb * k * maxRow * 4, hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(gain + (size_t)b0 * k, dGain.as<double>() + (size_t)b0 * k, (size_t)nb * k * 8, hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(nf + b0, dNf.as<int32_t>() + b0, (size_t)nb * 4, hipMemcpyDeviceToHost);
-        if (e == hipSuccess && pushed) e = hipMemcpy(pushed + b0, dPushed.as<int64_t>() + b0, (size_t)nb * 8, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: copy back", e);
+    // nothing of this call may still be running when its buffers go back to the cache (and, on the direct path, the tables
+    // are complete in the caller's memory only now)
+    for (int c = 0; c < nPiece; c++) {
+        const hipError_t e = hipStreamSynchronize(st[c]);
+        if (e != hipSuccess && rc == KBEST_OK) rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: synchronize", e);
     }
-    for (int c = 0; c < 2; c++)
+    for (int c = 0; c < 4; c++)
         if (done[c]) (void)hipEventDestroy(done[c]);
-    if (rc != KBEST_OK) {
-        (void)hipStreamSynchronize(ctx->stream);  // nothing of this call may still be running when its buffers go back to the cache
-        return rc;
-    }
+    if (start) (void)hipEventDestroy(start);
+    if (rc != KBEST_OK) return rc;
     for (int b = 0; b < B; b++)  // shapes were validated above: a negative count can only be an engine failure
         if (nf[b] < 0) return fail(ctx, nf[b] == -1 ? KBEST_ERR_UNSUPPORTED : KBEST_ERR_INTERNAL, "kbest_batch_f64: a problem came back with nf < 0");
     return KBEST_OK;

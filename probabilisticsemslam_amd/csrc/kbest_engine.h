@@ -110,7 +110,7 @@ __host__ __device__ inline Lds lds_layout(int maxRow, int k, int spec, int nWave
     L.offFreshS = o;     o += spec * 64 * 2;         //   own state slot of the surviving children
     L.offRootMap = o;    o += maxRow;                // the optimum's col4row (u8): atoms of the a-priori threshold
     o = (o + 7) & ~7;
-    L.offCtrl = o;       o += 216;                   // struct Ctrl
+    L.offCtrl = o;       o += 224;                   // struct Ctrl
     o = (o + 15) & ~15;
     L.offGainW = o;      o += nWaves * 512;          // one line of gain terms per wave (calcGain)
     L.total = (o + 15) & ~15;
@@ -395,6 +395,7 @@ struct MergeParams {
     int *outNf;                    // [B]
 };
 hipError_t launch_merge_topk(const MergeParams &p, int B, hipStream_t stream);
+hipError_t launch_fill_unused(const int *nf, int B, int k, int ldCol, int ldRow, int *row4col, int *col4row, double *gain, hipStream_t stream);
 hipError_t launch_kbest_lane(const Params &p, int B, int nWaves, int lanesPerChild, hipStream_t stream);
 hipError_t launch_kbest_small(const SmallParams &p, int B, int nWaves, hipStream_t stream);
 hipError_t launch_kbest(const Params &p, int B, int nWaves, hipStream_t stream);

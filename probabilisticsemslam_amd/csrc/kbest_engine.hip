@@ -97,8 +97,10 @@ struct Ctrl {
     unsigned short selSid[16]; // and its state slot
     int partsDone[16];         // waves that have finished their part of a node's first-step filter (the last one compacts)
     double t0;                 // a-priori threshold on the k-th best gain (apriori_threshold), +inf when unknown
+    int outDone;               // output slots whose row4col / col4row tables have been written
+    int outTicket;             // work queue of the output writes of this round
 };
-static_assert(sizeof(Ctrl) <= 216, "Ctrl must fit the LDS slot reserved by lds_layout");
+static_assert(sizeof(Ctrl) <= 224, "Ctrl must fit the LDS slot reserved by lds_layout");
 
 
 // A-priori threshold on the k-th best gain, computed once per problem when the root's children are solved (round 1).
@@ -404,6 +406,8 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             ctrl->selIdx[0] = -1;
             ctrl->selSid[0] = 0;
             ctrl->t0 = INF;
+            ctrl->outDone = 0;
+            ctrl->outTicket = 0;
             for (int i = 0; i < 16; i++) ctrl->partsDone[i] = 0;
         }
         __syncthreads();
@@ -762,6 +766,27 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             else if (keep) surv[spec * 64 - 1 - (baseL + __popcll(kl & below))] = entry;
         }
         __syncthreads();
+        // -- outputs, as they become final: the slots emitted up to the last round (their states are saved, their slot ->
+        //    state entries written behind a barrier) are widened into row4col / col4row NOW, one slot per wave.  The result tables then leave the kernel spread over its
+        //    whole run instead of in one burst at the end of every matrix -- which is what a host that takes them over PCIe
+        //    (result tables in pinned host memory, kbest_batch_f64) would otherwise wait for after the last matrix.  At the
+        //    START of the children phase: the stores (microseconds each when they cross PCIe) drain while the children are
+        //    solved, not in front of a barrier.
+        {
+            const int outDone = uni32(ctrl->outDone);
+            for (;;) {
+                int t = 0;
+                if (lane == 0) t = atomicAdd(&ctrl->outTicket, 1);
+                const int sOut = outDone + uni32(t);
+                if (sOut >= emitted) break;
+                const unsigned char *st = stBase + (long long)slotSid[sOut] * p.stateStride;
+                if (lane < M) p.row4col[(outBase + sOut) * p.ldCol + lane] = st[offR4C + lane];
+                if (p.col4row && lane < N) {
+                    const int cv = st[offC4R + lane];
+                    p.col4row[(outBase + sOut) * p.ldRow + lane] = (rect && cv == 255) ? -1 : cv;  // unassigned row (cpp:134)
+                }
+            }
+        }
         // -- B2: surviving children (shortestPathUpdateCPP, gain only), dynamic queue over the survivor list.  The
         //    per-node data a wave needs is cached in registers across consecutive items of the same node, and the
         //    next queue ticket is drawn before the current child is solved so that its LDS round trip is hidden.
@@ -1071,6 +1096,8 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             ctrl->nFresh = 0;
             ctrl->nSurv = 0;
             ctrl->nSurvBack = 0;
+            ctrl->outDone = emitted;  // (the slots emitted before this round: written above, before the barrier after B)
+            ctrl->outTicket = 0;
             ctrl->nq = nq;
             ctrl->head = h;
 #pragma unroll
@@ -1133,8 +1160,10 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     }
     const int stopCode = uni32(ctrl->stop);
     const int nf = (stopCode == 2) ? -3 : uni32(ctrl->emitted);
-    // ---- phase 3: outputs.  Slot s holds hypothesis slotSid[s]: widen its saved row4col / col4row --------
-    for (int idx = tid; idx < nf * (N + M); idx += NT) {
+    // ---- phase 3: outputs.  Slot s holds hypothesis slotSid[s]: widen its saved row4col / col4row (the slots that were not
+    //      written during the rounds: those emitted in the last one) --------
+    const int outDoneEnd = uni32(ctrl->outDone);
+    for (int idx = tid + outDoneEnd * (N + M); idx < nf * (N + M); idx += NT) {
         const int s = idx / (N + M), j = idx - s * (N + M);
         const unsigned char *st = stBase + (long long)slotSid[s] * p.stateStride;
         if (j < M) p.row4col[(outBase + s) * p.ldCol + j] = st[offR4C + j];

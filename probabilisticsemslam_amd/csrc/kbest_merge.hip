@@ -83,6 +83,27 @@ __global__ void __launch_bounds__(256) merge_topk_kernel(MergeParams p)
     if (tid == 0) p.outNf[b] = (1 + total < k) ? 1 + total : k;
 }
 
+// Output slots beyond the number found are never written by the enumeration kernels: give them the values the host
+// entries promise (row4col / col4row -1, gain 0) -- one workgroup per problem, nothing to do when nf == k.
+__global__ void __launch_bounds__(256) fill_unused_kernel(const int *nf, int k, int ldCol, int ldRow, int *row4col, int *col4row, double *gain)
+{
+    const int b = blockIdx.x;
+    int n = nf[b];
+    n = n < 0 ? 0 : n;
+    if (n >= k) return;
+    const long long base = (long long)b * k;
+    for (int i = threadIdx.x + n * ldCol; i < k * ldCol; i += 256) row4col[base * ldCol + i] = -1;
+    if (col4row)
+        for (int i = threadIdx.x + n * ldRow; i < k * ldRow; i += 256) col4row[base * ldRow + i] = -1;
+    for (int i = threadIdx.x + n; i < k; i += 256) gain[base + i] = 0.0;
+}
+
+hipError_t launch_fill_unused(const int *nf, int B, int k, int ldCol, int ldRow, int *row4col, int *col4row, double *gain, hipStream_t stream)
+{
+    hipLaunchKernelGGL(fill_unused_kernel, dim3(B), dim3(256), 0, stream, nf, k, ldCol, ldRow, row4col, col4row, gain);
+    return hipGetLastError();
+}
+
 hipError_t launch_merge_topk(const MergeParams &p, int B, hipStream_t stream)
 {
     hipLaunchKernelGGL(merge_topk_kernel, dim3(B), dim3(256), 0, stream, p);

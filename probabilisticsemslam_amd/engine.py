@@ -24,7 +24,8 @@ C_ABI_SYMBOLS = (
     "kbest_bruteforce_probs_batch_f64", "kbest_assign_batch_f64", "kbest_to_probs_f64",
     "kbest_assoc_probs_batch_f64_dev", "kbest_reserve_assoc",
     "kbest_create_multi", "kbest_destroy_multi", "kbest_multi_size", "kbest_multi_last_error", "kbest_batch_f64_multi",
-    "kbest_multi_tables_agree", "kbest_batch_f64_multi_ex", "kbest_merge_topk_f64_dev",
+    "kbest_multi_tables_agree", "kbest_batch_f64_multi_ex", "kbest_merge_topk_f64_dev", "kbest_register_host_buffer",
+    "kbest_unregister_host_buffer",
 )
 KBEST_MULTI_BATCH, KBEST_MULTI_SUBTREE = 0, 1
 
@@ -98,6 +99,8 @@ def load_library():
                                              C.c_int, i32p, i32p, dp, i32p]
     lib.kbest_merge_topk_f64_dev.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int64, dp, i32p,
                                              i32p, vp]
+    lib.kbest_register_host_buffer.argtypes = [vp, vp, C.c_size_t]
+    lib.kbest_unregister_host_buffer.argtypes = [vp, vp]
     _lib = lib
     return lib
 
@@ -274,6 +277,16 @@ class KBestEngine:
         return [asg[off[b]: off[b + 1]] for b in range(len(boxesL))]
 
     # ---- device buffers (torch tensors already resident in HBM) -------------------------
+    def register_host(self, *arrays):
+        """kbest_register_host_buffer on numpy arrays the caller keeps using (cost blocks, result tables): pinned and mapped,
+        so that kbest_batch_f64 moves them without staging copies.  The arrays must stay alive until unregister_host."""
+        for a in arrays:
+            self._check(self.lib.kbest_register_host_buffer(self.ctx, a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def unregister_host(self, *arrays):
+        for a in arrays:
+            self._check(self.lib.kbest_unregister_host_buffer(self.ctx, a.ctypes.data_as(C.c_void_p)))
+
     def reserve(self, B, N, k):
         self._check(self.lib.kbest_reserve(self.ctx, B, N, k))
 

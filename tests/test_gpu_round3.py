@@ -282,3 +282,29 @@ def test_multi_entry_two_devices():
         assert (nf == onf).all() and (r4c == or4c).all() and (bits(g) == bits(og)).all()
         assert m.tables_agree()
     m.close()
+
+
+def test_registered_host_buffers_take_the_direct_path(engine):
+    """kbest_register_host_buffer: result tables in registered host memory are written by the kernels themselves (no staging,
+    no copy back), cost blocks come up asynchronously; results identical to the copying path, slots beyond nf get the same
+    defined values, partly registered argument sets fall back to the copying path."""
+    import ctypes as C
+    rng = np.random.default_rng(21)
+    for (N, M, k, B, kw) in ((64, 64, 200, 300, {}), (16, 16, 50, 700, {}), (30, 10, 100, 40, {"cutoff": 1.0}), (5, 5, 200, 9, {}),
+                             (100, 20, 30, 12, {})):
+        costs = np.ascontiguousarray(rng.random((B, N * M)) * 4)
+        want = engine.kbest(costs, N, M, k, **kw)
+        r4c = np.full((B, k, M), 7, np.int32); c4r = np.full((B, k, N), 7, np.int32)
+        gain = np.full((B, k), 7.0); nf = np.full(B, 7, np.int32)
+        o = engine._opts(False, kw.get("cutoff"))
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        engine.register_host(costs, r4c, c4r, gain, nf)
+        rc = engine.lib.kbest_batch_f64(engine.ctx, C.byref(o), B, N, M, None, None, p(costs), None, k, p(r4c), p(c4r), p(gain), p(nf), None)
+        engine.unregister_host(costs, r4c, c4r, gain, nf)
+        assert rc == 0
+        assert (nf == want[0]).all() and (r4c == want[1]).all() and (c4r == want[2]).all() and (bits(gain) == bits(want[3])).all()
+    # only some of the buffers registered: the copying path, same results
+    engine.register_host(r4c)
+    got = engine.kbest(costs, N, M, k)
+    engine.unregister_host(r4c)
+    assert all((np.asarray(a) == np.asarray(b)).all() for a, b in zip(got, want))
