@@ -427,6 +427,37 @@ def run_c5(eng, torch, steps, warmup, dev, tstream, no_cpu, F=1000, k=200, nL=20
             lat[i] = time.perf_counter() - t1
             if i < 8:
                 assert np.array_equal(op.reshape(nM, nL + 1), probs[i])
+    # -- the reference's REAL frame sizes ("3-5 measurements per frame", README.md:11): one frame per call, next to the
+    #    reference's own conditionCosts + assignmentProb on one host core.  A GPU call cannot be shorter than its launch and
+    #    completion (~0.06 ms); at these sizes one host core is faster per call and the GPU wins from a few frames per call on
+    #    (table: profiles/r03_crossover.json).
+    small = []
+    for (snL, snM) in ((6, 3), (6, 5)):
+        sf = wl.kitti_like_frames(64, nL=snL, nM=snM, seed=0xC0FFEE + snL * 100 + snM)
+        s_l, s_m = np.array([snL], np.int32), np.array([snM], np.int32)
+        sp_, snf = np.zeros(snM * (snL + 1)), np.zeros(1, np.int32)
+        slat = np.empty(200)
+        for i in range(-100, 200):
+            f = sf[i % 64]
+            t1 = time.perf_counter()
+            lib.kbest_assoc_probs_batch_f64(ctx, 1, p(s_l), p(s_m), p(f), p(zero), k, p(sp_), p(zero), p(snf))
+            if i >= 0:
+                slat[i] = time.perf_counter() - t1
+        ent = {"nL": snL, "nM": snM, "us_mean": 1e6 * float(slat.mean()), "us_median": 1e6 * float(np.median(slat)), "calls": 200}
+        if not no_cpu:
+            kindS = "reference" if os.path.exists(ol.REF_ASSIGN_OFAST_SO) else "port"
+            t1 = time.perf_counter()
+            for f in sf:
+                if kindS == "reference":
+                    c, ridx = ol.ref_condition_costs(f, snL + snM, snM)
+                    ol.ref_assignment_prob(c, len(ridx) - snM, snM, k, ofast=True)
+                else:
+                    c, ridx = ol.condition_costs(f, snL + snM, snM)
+                    ol.assignment_prob(c, len(ridx) - snM, snM, k)
+            ent["cpu_us_per_frame"] = 1e6 * (time.perf_counter() - t1) / len(sf)
+            ent["cpu_kind"] = kindS
+            ent["speedup_vs_cpu_per_frame"] = ent["cpu_us_per_frame"] / ent["us_mean"]
+        small.append(ent)
     # -- algorithmic bytes: raw block in, probabilities out, hypothesis states (P counted by the engine on the
     #    conditioned blocks in its no-prune mode, D = rows conditionCosts keeps)
     conds, idxs = eng.condition_costs(frames, [nR] * F, [nM] * F)
@@ -448,6 +479,7 @@ def run_c5(eng, torch, steps, warmup, dev, tstream, no_cpu, F=1000, k=200, nL=20
                                   "calls_over_1ms": int((lat > 1e-3).sum()), "slowest_calls": [int(i) for i in np.argsort(-lat)[:3]], "calls": ncall,
                                   "what": "kbest_assoc_probs_batch_f64(B=1) per frame, host buffers in and out (the reference's "
                                           "call pattern, system.cpp:268): zero-copy pinned staging, one launch, one stream sync"},
+           "one_frame_per_call_small": small,
            "mean_rows_kept": float(D.mean()), "mean_pushed_per_frame": float(pushed.mean()),
            "roofline": roofline_block("c5", F, balg, kern_ms)}
     iss = issue_block("c5")
