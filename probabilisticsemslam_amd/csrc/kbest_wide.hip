@@ -325,8 +325,8 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = NWV * 64;
     const double INF = d_inf();
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
+    int tid = threadIdx.x;   // (not const: made opaque once per round, see the round loop)
+    int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int DS = p.maxRow;
     const WideLds L = wide_lds_layout(DS, p.maxCol, TILE, NWV, p.spec);
@@ -528,6 +528,9 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
         // split in this round: it is emitted too, but ends the run (its children are not in the pool yet).
         const int spec = p.spec;
         for (int round = 0;; round++) {
+            // (cheap expressions of the lane number are recomputed where they are used instead of being hoisted out of the
+            //  round loop and spilled: kbest_engine.hip, the same remark)
+            asm volatile("" : "+v"(lane), "+v"(tid));
             const int cur = uni32(ctrl->cur), n = uni32(ctrl->n), emitted = uni32(ctrl->emitted);
             const double *srcG = poolG + (long long)cur * p.poolStride;
             const int *srcS = poolS + (long long)cur * p.poolStride;

@@ -1,5 +1,5 @@
 """A/B of in-tree builds in ONE process, interleaved rounds (cdna_hip_programming.md rule 24): kernel time of a dense config.
-usage: python tests/dev/ab_libs.py c4|c3|c2 [B] libA.so libB.so ...      (library names relative to probabilisticsemslam_amd/)"""
+usage: python tests/dev/ab_libs.py c4|c3|c2|NxM:k:B [B] libA.so libB.so ...      (library names relative to probabilisticsemslam_amd/)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +13,11 @@ args = sys.argv[1:]
 cfg = args.pop(0)
 B = int(args.pop(0)) if args and args[0].isdigit() else None
 libs = args
-Bc, N, M, k, seed = wl.DENSE_CONFIGS[cfg]
+if "x" in cfg:  # custom shape "NxM:k:B"
+    shp, k, Bc = cfg.split(":")
+    N, M = (int(x) for x in shp.split("x")); k = int(k); Bc = int(Bc); seed = 0x5EED0000 + 1000 * N + k
+else:
+    Bc, N, M, k, seed = wl.DENSE_CONFIGS[cfg]
 B = B or Bc
 costs = torch.from_numpy(wl.dense_batch(B, N, M, seed)).to(dev)
 r4c = torch.empty((B, k, M), dtype=torch.int32, device=dev); c4r = torch.empty((B, k, N), dtype=torch.int32, device=dev)
