@@ -20,6 +20,13 @@
 // its flags are set the way kBest2DCutoff sets them (cpp:650-651), its buffers
 // are not used.
 //
+// col4rowBest on zero-padded columns: for numRow > numCol the reference pads to a square, and WHICH padded column a
+// left-over row lands on is an artefact of tie resolution among identical zero columns.  The
+// engine's root starts from a column reduction and places left-over rows on the padded columns in ascending row order:
+// values >= numCol in col4rowBest can differ from the reference's; values < numCol, row4colBest, gainBest and the return
+// value are identical (the reference's own callers read only row4colBest, assignment.cpp:629).  KBEST_EXACT_ROOT=1 (or
+// KBEST_FLAG_EXACT_ROOT) makes the root run the reference's own sequence of augmentations instead.
+//
 // Error behaviour follows the reference: no exceptions from the solver, the
 // return value is the number of solutions found and 0 means infeasible.  An
 // engine failure (no GPU, unsupported size) cannot be expressed in that
