@@ -61,9 +61,9 @@ def algorithmic_bytes(N, M, k, nf, pushed):
 
 
 def profile_summary(cfg):
-    """profiles/r02_<cfg>_summary.json (tools/prof.sh + tools/prof_summary.py on the GPU box): HBM traffic and the
-    instruction-issue counters of the dominant kernel for this configuration, or None."""
-    for rnd in ("r02",):
+    """profiles/r03_<cfg>_summary.json (tools/prof.sh + tools/prof_summary.py on the GPU box; an older round's if this
+    round has none): HBM traffic and the instruction-issue counters of the dominant kernel for this configuration, or None."""
+    for rnd in ("r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{cfg}_summary.json")
         if os.path.exists(path):
             try:

@@ -521,21 +521,28 @@ struct DevExtra {  // optional outputs / modes of kbest_assign_batch_f64 (root s
 struct SubBatch { int logicalB = 0, blockBase = 0; };
 
 // Order this launch (on stream s) behind the previous launch of the context when that ran on another stream: both
-// use the context's one hypothesis workspace.  Called with ctx->mu held.
+// use the context's one hypothesis workspace.  Called with ctx->mu held.  A caller-owned stream may be destroyed by its
+// owner at any time after our launch, so it is never touched again: the event that marks the end of a launch on such a
+// stream is recorded right behind the launch (Launched, below), while the stream is certainly alive; only the context's
+// own stream -- which lives as long as the context -- gets its event recorded lazily, here, when a switch happens.
 static int order_behind_last(kbest_ctx *ctx, hipStream_t s)
 {
     if (ctx->haveLast && ctx->lastStream != s) {
-        if (hipEventRecord(ctx->lastEvent, ctx->lastStream) == hipSuccess) {
-            HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->lastEvent, 0));
-        } else {  // the previous stream is gone (destroyed by its owner): wait for everything
-            (void)hipGetLastError();
-            HIP_TRY(ctx, hipDeviceSynchronize());
-        }
+        if (ctx->lastStream == ctx->stream) HIP_TRY(ctx, hipEventRecord(ctx->lastEvent, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->lastEvent, 0));
     }
     ctx->lastStream = s;
     ctx->haveLast = true;
     return KBEST_OK;
 }
+
+// Scope guard of an asynchronous entry: whatever was enqueued on a caller-owned stream `s` is marked by the context's
+// event when the entry returns (see order_behind_last).
+struct Launched {
+    kbest_ctx *ctx;
+    hipStream_t s;
+    ~Launched() { if (s != ctx->stream) (void)hipEventRecord(ctx->lastEvent, s); }
+};
 
 // grow: the host-pointer entries (which synchronise anyway) let the workspace grow on demand; the asynchronous
 // device-pointer entry never allocates or synchronises -- it needs kbest_reserve up front.
@@ -574,6 +581,7 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         int rc = order_behind_last(ctx, s);
         if (rc != KBEST_OK) return rc;
     }
+    const Launched mark{ctx, sub ? ctx->stream : s};
     // Problems of up to 32 rows: the small-problem kernel (half-wave workers, implicit zero columns).  The modes that
     // need the reference's exact order of splits (push counting), no pruning, subtree sharding or the duals of the
     // padded formulation stay on the 64-row kernel.
@@ -1248,6 +1256,7 @@ extern "C" int kbest_assoc_probs_batch_f64_dev(kbest_ctx *ctx, int B, int maxRaw
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
     int rc = order_behind_last(ctx, s);
     if (rc != KBEST_OK) return rc;
+    const Launched mark{ctx, s};
     rc = ensure_states(ctx, small_states_need(B, capRow, maxCol, k, nw), false);  // asynchronous entry: never allocates
     if (rc != KBEST_OK) return rc;
     kb::SmallParams sp;
