@@ -526,6 +526,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the `configs` block (c2, c3, c5 in the same run)")
+    ap.add_argument("--no-host", action="store_true", help="skip value_host_inclusive (under the profiler: only the timed launches)")
     ap.add_argument("--kernel-only", action="store_true", help="c5 under the profiler: only the timed launches of the fused kernel")
     args = ap.parse_args()
 
@@ -611,7 +612,7 @@ def main():
             iss = issue_block(args.config)
             if iss:
                 out["issue"] = iss
-            if world == 1:
+            if world == 1 and not args.no_host:
                 out["value_host_inclusive"] = host_inclusive_dense(eng, m["costs"], N, M, k)
             if world == 1 and not args.no_cpu:
                 sample = args.cpu_sample or cpu_samples[args.config]

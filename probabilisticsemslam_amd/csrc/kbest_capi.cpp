@@ -40,6 +40,9 @@ struct kbest_ctx {
     bool forceSmall = false;  // KBEST_FORCE_SMALL: every batch of <= 32-row problems through the small-problem kernel
     bool noSmall = false;  // KBEST_NO_SMALL: problems of <= 32 rows through the 64-row kernel as well (A/B tests)
     bool forceWide = false;   // KBEST_FORCE_WIDE: everything through the general-size kernel (test hook; read once at create)
+    bool noSplit = false;     // KBEST_NO_SPLIT: never split one matrix over several workgroups (A/B tests)
+    int splitForce = 0;       // KBEST_SPLIT: workgroups per matrix (2 / 4) whenever the split is possible (A/B tests)
+    DevBufRaw splitBuf;       // per-share result tables + shared thresholds of the split
     int pieces = 0;           // KBEST_PIECES: pieces of a large host-entry batch (1 / 2 / 4; A/B tests); 0 = choose
     bool noLane = false;      // KBEST_NO_LANE: no lane-per-child kernel (A/B tests)
     bool forceLane = false;   // KBEST_FORCE_LANE: every plain batch of <= 32-row problems through the lane-per-child kernel
@@ -274,6 +277,8 @@ int kbest_create(kbest_ctx **out, int device)
     ctx->noSmall = getenv("KBEST_NO_SMALL") != nullptr;
     ctx->forceWide = getenv("KBEST_FORCE_WIDE") != nullptr;
     ctx->noLane = getenv("KBEST_NO_LANE") != nullptr;
+    ctx->noSplit = getenv("KBEST_NO_SPLIT") != nullptr;
+    if (const char *e = getenv("KBEST_SPLIT")) { const int w = atoi(e); if (w == 2 || w == 4) ctx->splitForce = w; }
     if (const char *e = getenv("KBEST_PIECES")) { const int w = atoi(e); if (w == 1 || w == 2 || w == 4) ctx->pieces = w; }
     ctx->forceLane = getenv("KBEST_FORCE_LANE") != nullptr;
     if (const char *e = getenv("KBEST_LANE_NW")) { const int w = atoi(e); if (w == 1 || w == 2 || w == 4) ctx->laneNw = w; }
@@ -312,6 +317,7 @@ int kbest_destroy(kbest_ctx *ctx)
     if (ctx->pinOut.host) (void)hipHostFree(ctx->pinOut.host);
     if (ctx->stageIn.p) (void)hipFree(ctx->stageIn.p);
     if (ctx->stageOut.p) (void)hipFree(ctx->stageOut.p);
+    if (ctx->splitBuf.p) (void)hipFree(ctx->splitBuf.p);
     if (ctx->lastEvent) (void)hipEventDestroy(ctx->lastEvent);
     for (auto &a : ctx->aux)
         if (a) (void)hipStreamDestroy(a);
@@ -390,6 +396,21 @@ static bool k_fits_fast(const kbest_ctx *ctx, int B, int fastRow, int k, unsigne
 }
 
 static int ensure_states(kbest_ctx *ctx, size_t need, bool grow);
+static int raw_reserve(kbest_ctx *ctx, DevBufRaw &d, size_t need);
+
+// per-share result tables [S][B][...] + one shared threshold per matrix of a split launch (split_factor)
+struct SplitLayout {
+    size_t offGain, offR4C, offNf, offT, bytes;
+    SplitLayout(int B, int S, int k, int maxCol)
+    {
+        auto up = [](size_t x) { return (x + 127) & ~(size_t)127; };
+        offGain = 0;
+        offR4C = up((size_t)S * B * k * 8);
+        offNf = offR4C + up((size_t)S * B * k * maxCol * 4);
+        offT = offNf + up((size_t)S * B * 4);
+        bytes = offT + up((size_t)B * 8);
+    }
+};
 
 static int reserve_states(kbest_ctx *ctx, int B, int maxRow, int k, bool grow)
 {
@@ -501,7 +522,14 @@ int kbest_reserve(kbest_ctx *ctx, int B, int maxRow, int k)
         if (rc != KBEST_OK) return rc;
     }
     if (kFits) {
+        // (a small batch of 33 ... 64-row problems may run split: up to four workgroups, i.e. four work spaces, per matrix)
+        const int Bs = (ctx->splitForce && !ctx->noSplit && maxRow > 32 && maxRow <= KBEST_MAX_DIM) ? ((4 * B <= ctx->nCU) ? 4 * B : ((2 * B <= ctx->nCU) ? 2 * B : B)) : B;
         int rc = reserve_states(ctx, B, fastRow, k, true);
+        if (rc == KBEST_OK && Bs > B) rc = reserve_states(ctx, Bs, fastRow, k, true);
+        if (rc == KBEST_OK && Bs > B) {
+            const SplitLayout sl(B, Bs / B, k, maxRow);
+            if (sl.bytes > ctx->splitBuf.bytes) rc = raw_reserve(ctx, ctx->splitBuf, sl.bytes);
+        }
         if (rc != KBEST_OK) return rc;
     }
     if (!kFits || maxRow > KBEST_MAX_DIM || ctx->forceWide)  // (numCol <= numRow bounds the general-size plan)
@@ -544,6 +572,23 @@ struct Launched {
     ~Launched() { if (s != ctx->stream) (void)hipEventRecord(ctx->lastEvent, s); }
 };
 
+// One matrix over several workgroups (64-row kernel).  When a batch leaves CUs idle -- at most half as many 33 ... 64-row
+// square problems as CUs -- every matrix is alone on a CU and bound by the latency of its own rounds (128 x 64x64, k = 200:
+// 1.04 ms where 1 024 take 2.7).  S workgroups can take the root's subtrees in turn (columns c % S == share), share their
+// thresholds through HBM and have a k-way merge assemble the k best (kbest_merge.hip).  Built, bit-exact -- and SLOWER in
+// every case measured (tests/dev/split_check.py: 128 x 64x64 1.05 -> 1.27 ms with two workgroups per matrix, one matrix alone
+// 0.68 -> 0.83 / 0.96 with two / four; 48x48, k = 100 the same picture): a share needs as many rounds as the whole matrix (its
+// front advances through the same gains), its a-priori thresholds come from half the atoms, and the shared threshold lags by
+// a round.  Off unless KBEST_SPLIT = 2 / 4 asks for it (the parity test and the measurements use that).
+static int split_factor(const kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, int maxCol, int k, bool uniform, bool plain)
+{
+    if (!ctx->splitForce || ctx->noSplit || !uniform || !plain || maxRow != maxCol || maxRow <= 32 || maxRow > KBEST_MAX_DIM || k < 50 ||
+        opts->root_col_stride > 1 || (opts->flags & (KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_PRUNE | KBEST_FLAG_RECT_ROOT |
+                                                     KBEST_FLAG_NO_SHIFT | KBEST_FLAG_EXACT_ROOT)))
+        return 1;
+    return ctx->splitForce * B <= ctx->nCU ? ctx->splitForce : ((2 * B <= ctx->nCU) ? 2 : 1);
+}
+
 // grow: the host-pointer entries (which synchronise anyway) let the workspace grow on demand; the asynchronous
 // device-pointer entry never allocates or synchronises -- it needs kbest_reserve up front.
 static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, int maxCol,
@@ -569,7 +614,6 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
     const size_t base = sub ? (size_t)sub->blockBase : 0;  // first problem of this piece in that batch
     Shape shape;
     const bool kFits = k_fits_fast(ctx, LB, fastRow, k, opts->flags, &shape);
-    const int spec = shape.spec, nWaves = shape.nWaves;
     const bool forceWide = ctx->forceWide && !extra;  // test hook: everything through the general-size kernel
     const bool runFast = !forceWide && kFits && (maxRow <= KBEST_MAX_DIM || d_nRow != nullptr);
     const bool runWide = forceWide || !kFits || maxRow > KBEST_MAX_DIM;
@@ -672,11 +716,26 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
 
     if (sub && runWide) return fail(ctx, KBEST_ERR_INTERNAL, "a piece of a batch on the general-size kernel");
     if (runFast) {
-        int rc = reserve_states(ctx, LB, fastRow, k, grow);
+        const int S = sub ? 1 : split_factor(ctx, opts, B, maxRow, maxCol, k, d_nRow == nullptr && d_costOff == nullptr, extra == nullptr);
+        const int PB = LB * S;  // workgroups = problems of the launch as the kernel sees them
+        Shape shp = shape;
+        if (S > 1 && !k_fits_fast(ctx, PB, fastRow, k, opts->flags, &shp)) return fail(ctx, KBEST_ERR_INTERNAL, "split launch shape");
+        int rc = reserve_states(ctx, PB, fastRow, k, grow);
         if (rc != KBEST_OK) return rc;
         size_t slotOff = 0;
-        (void)states_need(ctx, LB, fastRow, k, &slotOff);
+        (void)states_need(ctx, PB, fastRow, k, &slotOff);
+        const SplitLayout sl(B, S, k, maxCol);
+        if (S > 1) {
+            if (sl.bytes > ctx->splitBuf.bytes) {
+                if (!grow) return fail(ctx, KBEST_ERR_NOT_RESERVED, "split work space too small: call kbest_reserve first");
+                rc = raw_reserve(ctx, ctx->splitBuf, sl.bytes);
+                if (rc != KBEST_OK) return rc;
+            }
+            HIP_TRY(ctx, hipMemsetAsync(static_cast<char *>(ctx->splitBuf.p) + sl.offT, 0xFF, (size_t)B * 8, s));  // no threshold yet
+        }
+        char *sb = static_cast<char *>(ctx->splitBuf.p);
         kb::Params p;
+        memset(&p, 0, sizeof(p));
         p.cost = d_cost;
         p.costOff = reinterpret_cast<const long long *>(d_costOff);
         p.nRow = d_nRow;
@@ -692,23 +751,48 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         p.cutoff = opts->cutoff;
         p.rootColOffset = opts->root_col_offset;
         p.rootColStride = opts->root_col_stride;
-        p.row4col = d_row4col;
-        p.col4row = d_col4row;
-        p.gain = d_gain;
-        p.nf = d_nf;
+        p.row4col = S > 1 ? reinterpret_cast<int32_t *>(sb + sl.offR4C) : d_row4col;
+        p.col4row = S > 1 ? nullptr : d_col4row;
+        p.gain = S > 1 ? reinterpret_cast<double *>(sb + sl.offGain) : d_gain;
+        p.nf = S > 1 ? reinterpret_cast<int32_t *>(sb + sl.offNf) : d_nf;
         p.pushed = reinterpret_cast<long long *>(d_pushed);
         p.stateStride = kb::state_stride(fastRow);
-        p.statesPerProblem = k + ctx->extraStates + eager_states(ctx, LB, fastRow, k);
+        p.statesPerProblem = k + ctx->extraStates + eager_states(ctx, PB, fastRow, k);
         p.states = ctx->states + base * (size_t)p.statesPerProblem * (size_t)p.stateStride;
         p.lazyStates = k + ctx->extraStates;
-        p.spec = spec;
+        p.spec = shp.spec;
         p.prof = ctx->prof;
         p.slotSid = reinterpret_cast<unsigned short *>(ctx->states + slotOff) + base * (size_t)kb::slot_table_stride(k);
         p.dualU = extra ? extra->dualU : nullptr;
         p.dualV = extra ? extra->dualV : nullptr;
         p.gainCols = extra ? extra->gainCols : 0;
-        hipError_t e = kb::launch_kbest(p, B, nWaves, s);
+        p.split = S;
+        p.splitB = B;
+        p.sharedT = S > 1 ? reinterpret_cast<unsigned long long *>(sb + sl.offT) : nullptr;
+        hipError_t e = kb::launch_kbest(p, B * S, shp.nWaves, s);
         if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "kbest kernel launch", e);
+        if (S > 1) {  // the global k best of every matrix from its shares' lists
+            kb::MergeParams mp;
+            memset(&mp, 0, sizeof(mp));
+            mp.gain = reinterpret_cast<const unsigned char *>(sb + sl.offGain);
+            mp.row4col = reinterpret_cast<const unsigned char *>(sb + sl.offR4C);
+            mp.nf = reinterpret_cast<const unsigned char *>(sb + sl.offNf);
+            mp.shardStride = (long long)B * k * 8;
+            mp.strideR4C = (long long)B * k * maxCol * 4;
+            mp.strideNf = (long long)B * 4;
+            mp.nShard = S;
+            mp.k = k;
+            mp.maxCol = maxCol;
+            mp.ldCol = maxCol;
+            mp.maximize = opts->maximize;
+            mp.outGain = d_gain;
+            mp.outRow4col = d_row4col;
+            mp.outNf = d_nf;
+            mp.outCol4row = d_col4row;
+            mp.ldRow = maxRow;
+            e = kb::launch_merge_topk(mp, B, s);
+            if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "merge kernel launch", e);
+        }
     }
     if (runWide) {
         const WidePlan w = plan_wide(ctx, B, maxRow, maxCol, k);
@@ -985,6 +1069,10 @@ int kbest_merge_topk_f64_dev(kbest_ctx *ctx, int B, int nShard, int k, int maxCo
     p.outGain = d_outGain;
     p.outRow4col = d_outRow4col;
     p.outNf = d_outNf;
+    p.outCol4row = nullptr;
+    p.ldRow = 0;
+    p.strideR4C = 0;
+    p.strideNf = 0;
     hipError_t e = kb::launch_merge_topk(p, B, stream ? static_cast<hipStream_t>(stream) : ctx->stream);
     if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "merge kernel launch", e);
     return KBEST_OK;
@@ -1105,7 +1193,7 @@ static int raw_reserve(kbest_ctx *ctx, DevBufRaw &d, size_t need)
     if (need <= d.bytes) return KBEST_OK;
     size_t cap = 1 << 16;
     while (cap < need) cap <<= 1;
-    if (d.p) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(d.p); d.p = nullptr; d.bytes = 0; }
+    if (d.p) { HIP_TRY(ctx, hipDeviceSynchronize()); (void)hipFree(d.p); d.p = nullptr; d.bytes = 0; }  // (rare: only when it grows)
     hipError_t e = hipMalloc(&d.p, cap);
     if (e != hipSuccess) return fail(ctx, KBEST_ERR_NOMEM, "hipMalloc(staging)", e);
     d.bytes = cap;

@@ -43,6 +43,8 @@ struct Params {
     double *dualU;            // [B][ldCol] duals of the root solution per column (MurtyHyp::u), or nullptr
     double *dualV;            // [B][ldRow] ... per row (MurtyHyp::v), or nullptr
     int gainCols;             // numCol4Gain of shortestPathCPP (cpp:232); 0 = numCol
+    int split, splitB;        // split > 1 (64-row kernel): `split` workgroups per matrix, splitB matrices; tables / work space per workgroup
+    unsigned long long *sharedT;  // [splitB] smallest threshold any share of a matrix has published (ordered key; ~0 = none)
 };
 
 struct CondParams {
@@ -110,7 +112,7 @@ __host__ __device__ inline Lds lds_layout(int maxRow, int k, int spec, int nWave
     L.offFreshS = o;     o += spec * 64 * 2;         //   own state slot of the surviving children
     L.offRootMap = o;    o += maxRow;                // the optimum's col4row (u8): atoms of the a-priori threshold
     o = (o + 7) & ~7;
-    L.offCtrl = o;       o += 224;                   // struct Ctrl
+    L.offCtrl = o;       o += 232;                   // struct Ctrl
     o = (o + 15) & ~15;
     L.offGainW = o;      o += nWaves * 512;          // one line of gain terms per wave (calcGain)
     L.total = (o + 15) & ~15;
@@ -388,11 +390,14 @@ struct MergeParams {
     const unsigned char *gain;     // shard 0: [B][k] fp64
     const unsigned char *row4col;  // shard 0: [B][k][ldCol] i32
     const unsigned char *nf;       // shard 0: [B] i32
-    long long shardStride;
+    long long shardStride;         // bytes between consecutive shards' gain tables (and, unless the next two are set, of all three)
+    long long strideR4C, strideNf; // 0 = shardStride (packed slices); else the tables' own strides (plain [S][B][...] arrays)
     int nShard, k, maxCol, ldCol, maximize;
     double *outGain;               // [B][k]
     int *outRow4col;               // [B][k][ldCol]
     int *outNf;                    // [B]
+    int *outCol4row;               // [B][k][ldRow] or nullptr: the inverse of the merged row4col, -1 for rows without a column
+    int ldRow;
 };
 hipError_t launch_merge_topk(const MergeParams &p, int B, hipStream_t stream);
 hipError_t launch_fill_unused(const int *nf, int B, int k, int ldCol, int ldRow, int *row4col, int *col4row, double *gain, hipStream_t stream);

@@ -99,8 +99,9 @@ struct Ctrl {
     double t0;                 // a-priori threshold on the k-th best gain (apriori_threshold), +inf when unknown
     int outDone;               // output slots whose row4col / col4row tables have been written
     int outTicket;             // work queue of the output writes of this round
+    double tShared;            // split launches: the smallest threshold any share of this matrix has published (+inf: none)
 };
-static_assert(sizeof(Ctrl) <= 224, "Ctrl must fit the LDS slot reserved by lds_layout");
+static_assert(sizeof(Ctrl) <= 232, "Ctrl must fit the LDS slot reserved by lds_layout");
 
 
 // A-priori threshold on the k-th best gain, computed once per problem when the root's children are solved (round 1).
@@ -295,12 +296,19 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     int tid = threadIdx.x;   // (not const: see the top of the round loop)
     int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x;
+    // split > 1: ONE matrix is enumerated by `split` workgroups, each taking the root's children on columns c % split == share
+    // (Murty's partition of the root is disjoint, cpp:455-532) into its own tables [share][matrix]; a k-way merge follows
+    // (kbest_merge.hip).  They share an upper bound of the k-th best gain through sharedT (see the top of the round loop).
+    const int blk = blockIdx.x;  // index of this workgroup's work space and output tables
+    const int S = p.split > 1 ? p.split : 1;
+    const int share = S > 1 ? blk / p.splitB : 0;
+    const int b = S > 1 ? blk - share * p.splitB : blk;  // the matrix (inputs)
+    const int rcStride = S > 1 ? S : p.rootColStride, rcOffset = S > 1 ? share : p.rootColOffset;
     const int N = p.nRow ? p.nRow[b] : p.maxRow;
     const int M = p.nCol ? p.nCol[b] : p.maxCol;
     const int k = p.k;
     if (N < 1 || M < 1 || N < M || N > p.maxRow || M > p.maxCol) {  // undefined in the reference
-        if (tid == 0) p.nf[b] = (M == 0 || N == 0) ? 0 : -1;            // (an empty frame: nothing to assign, nothing found)
+        if (tid == 0) p.nf[blk] = (M == 0 || N == 0) ? 0 : -1;          // (an empty frame: nothing to assign, nothing found)
         return;
     }
     // odd column stride of the LDS cost tile: row-wise (lane = row) and column-wise (lane = column) walks are
@@ -408,18 +416,21 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             ctrl->t0 = INF;
             ctrl->outDone = 0;
             ctrl->outTicket = 0;
+            ctrl->tShared = INF;
             for (int i = 0; i < 16; i++) ctrl->partsDone[i] = 0;
         }
         __syncthreads();
         for (int i = tid; i < spec * 64; i += NT) { lbKey[i] = ~0ull; lbIn[i] = ~0u; }  // (`red` is dead now)
     }
 
-    unsigned char *stBase = p.states + (long long)b * nSlots * p.stateStride;
+    unsigned char *stBase = p.states + (long long)blk * nSlots * p.stateStride;
     u64 *atoms = reinterpret_cast<u64 *>(stBase + (long long)maxSid * p.stateStride);  // [2c] delta bits, [2c+1] row mask; [2D] root gain
     // A-priori threshold (used from round 1 on): k - 1 known assignments besides the optimum bound the k-th best gain
     // from above.  Off where the enumeration is not the whole problem's (root-subtree sharding), where pushes are
     // counted or pruning is disabled, and where its scratch (the fresh list's LDS) would not fit.
-    const bool t0On = prune && k >= 3 && p.rootColStride <= 1 && !(p.flags & (KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_T0)) &&
+    // (a caller's own root sharding wants the shard's OWN k best: no global bound there; the internal split merges, so a bound on
+    //  the global k-th best from this share's atoms is exactly what it may prune with)
+    const bool t0On = prune && k >= 3 && (p.rootColStride <= 1 || S > 1) && !(p.flags & (KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_T0)) &&
                       !rect && NW >= 8 && spec >= 3 && maxSid < nSlots;
     if (t0On && tid < D) atoms[2 * tid] = 0x7ff0000000000000ull;  // +inf: no such child (yet)
     if (t0On && tid == 0) atoms[2 * D + 1] = 0ull;                 // atoms learnt in round 1
@@ -428,7 +439,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     const bool t1On = t0On && N == M && spec * 64 >= T0_SCRATCH + 64;
     unsigned char *rootMap = smem + L.offRootMap;  // the optimum's col4row (lane = row)
     // saved hypothesis (HBM): u[D'] v[D'] (fp64) | row4col[D'] col4row[D'] (u8) | forb, gain, activeCol
-    const long long outBase = (long long)b * k;
+    const long long outBase = (long long)blk * k;
     const int DS = p.maxRow;
     const int offR4C = 16 * DS, offC4R = 17 * DS, offTail = (18 * DS + 7) & ~7;
 
@@ -561,7 +572,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     }
     __syncthreads();
     if (uni32(ctrl->stop) == 3) {  // infeasible: kBest2D returns 0 (cpp:588-593)
-        if (tid == 0) { p.nf[b] = 0; if (p.pushed) p.pushed[b] = 0; }
+        if (tid == 0) { p.nf[blk] = 0; if (p.pushed) p.pushed[blk] = 0; }
         return;
     }
 
@@ -613,6 +624,26 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         if (tid == 0 && b < 2 && t0On) printf("T0DBG b=%d round=%02d poolgap=%.5f t0gap=%.5f emitted=%d nOld=%d\n", b, roundNo, T - __longlong_as_double((long long)atoms[2 * D]), T0 - __longlong_as_double((long long)atoms[2 * D]), emitted, nOld);
 #endif
         if (T0 < T) T = T0;
+        if (S > 1) {
+            // The shares of one matrix exchange their thresholds: a share that holds k candidates at or below T has shown that the
+            // GLOBAL k-th best gain is at most T, so every share may prune with the smallest T any of them has published
+            // (atomicMin on the order-preserving key; a stale read only prunes later, never wrongly).
+            u64 *sh = p.sharedT + b;
+            if (wave == 0 && lane == 0 && T < INF) {
+                int khi;
+                u32 klo;
+                to_key(T, khi, klo);
+                atomicMin(sh, ((u64)((u32)khi ^ 0x80000000u) << 32) | klo);
+            }
+            const u64 kk = uni64(__hip_atomic_load(sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (kk != ~0ull) {
+                const double Tsh = from_key((int)((u32)(kk >> 32) ^ 0x80000000u), (u32)kk);
+                if (Tsh < T) T = Tsh;
+                // (read again in A / D, behind two barriers: candidates beyond it are neither split nor emitted -- they cannot be
+                //  among the global k best, and without this a share would go on to emit k hypotheses of its own)
+                if (wave == 0 && lane == 0) ctrl->tShared = Tsh;
+            }
+        }
         const double cmaxv = ctrl->cmax;
         KB_T(tF0);
         KB_ACC(14, tF0 - tRound);  // [14] round prologue (control reads)
@@ -737,7 +768,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             const double pgain = nd.gain[0];
             const double bound = (prune && T < INF) ? (T - pgain) + 1e-9 * (fabs(T) + cmaxv) : INF;
             const int c = a + lane;
-            const bool live = c < M && !(sid == 0 && p.rootColStride > 1 && (c % p.rootColStride) != p.rootColOffset);
+            const bool live = c < M && !(sid == 0 && rcStride > 1 && (c % rcStride) != rcOffset);
             const u64 key = lbKey[myNode * 64 + lane];
             const double m = from_key((int)((u32)(key >> 32) ^ 0x80000000u), (u32)key);
             const u32 inH = lbIn[myNode * 64 + lane];
@@ -1005,6 +1036,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         //    w-th of them into node block w -- by loading its saved state, or, if it has none, by re-solving it
         //    from its parent's state.  Lane 0 of wave 0 also does the emission bookkeeping, which depends only on
         //    the pool order and flags.  Lazy state slots: keep one in hand for every output still to come.
+        const double tShared = (S > 1) ? ctrl->tShared : INF;
         int budget = (p.lazyStates - k) + 1 - (sidBase - emitted);
         if (budget > spec) budget = spec;
         if (budget < 1) budget = 1;
@@ -1017,7 +1049,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         const int walk = (wave == 0 || budget <= wave) ? budget : wave + 1;
         for (int base = 0; base < nq && nselNew < walk; base += 64) {
             const int i = base + lane;
-            const bool open = i < nq && !(PM[i] & META_SPLIT);
+            const bool open = i < nq && !(PM[i] & META_SPLIT) && !(S > 1 && PG[i] > tShared);
             const unsigned short ps = (i < nq) ? PS[i] : SID_NONE;
             u64 m = __ballot(open);
             const u64 lazyM = __ballot(open && ps == SID_NONE);
@@ -1065,6 +1097,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             while (h < nq && e < k) {
                 int sid;
                 bool fresh = false;
+                if (S > 1 && PG[h] > tShared) { stop = 1; break; }  // beyond the global k-th best: this share is done
                 if (!(PM[h] & META_SPLIT)) {
                     if (selSeen >= nselNew) break;  // not split and not selected this round: wait
                     sid = sSid[0];
@@ -1173,13 +1206,13 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         }
     }
     if (tid == 0) {
-        p.nf[b] = nf;
-        if (p.pushed) p.pushed[b] = ctrl->pushed;
+        p.nf[blk] = nf;
+        if (p.pushed) p.pushed[blk] = ctrl->pushed;
     }
 #ifdef KB_PROFILE
     profAcc[13] = __builtin_readcyclecounter() - profT0;  // [13] whole kernel (this wave)
     if (p.prof && lane == 0)
-        for (int i = 0; i < 16; i++) atomicAdd(p.prof + (long long)b * 16 + i, profAcc[i]);
+        for (int i = 0; i < 16; i++) atomicAdd(p.prof + (long long)blk * 16 + i, profAcc[i]);
 #endif
 }
 

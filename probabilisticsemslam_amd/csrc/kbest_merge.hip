@@ -34,8 +34,9 @@ __global__ void __launch_bounds__(256) merge_topk_kernel(MergeParams p)
     const int S = p.nShard, k = p.k, M = p.maxCol;
     const bool maximize = p.maximize != 0;
     auto gainOf = [&](int s) { return reinterpret_cast<const double *>(p.gain + (long long)s * p.shardStride) + (long long)b * k; };
-    auto rowsOf = [&](int s) { return reinterpret_cast<const int *>(p.row4col + (long long)s * p.shardStride) + (long long)b * k * p.ldCol; };
-    auto nfOf = [&](int s) { return reinterpret_cast<const int *>(p.nf + (long long)s * p.shardStride)[b]; };
+    const long long sR = p.strideR4C ? p.strideR4C : p.shardStride, sN = p.strideNf ? p.strideNf : p.shardStride;
+    auto rowsOf = [&](int s) { return reinterpret_cast<const int *>(p.row4col + (long long)s * sR) + (long long)b * k * p.ldCol; };
+    auto nfOf = [&](int s) { return reinterpret_cast<const int *>(p.nf + (long long)s * sN)[b]; };
     double *og = p.outGain + (long long)b * k;
     int *orow = p.outRow4col + (long long)b * k * p.ldCol;
     const int nf0 = nfOf(0);
@@ -80,7 +81,18 @@ __global__ void __launch_bounds__(256) merge_topk_kernel(MergeParams p)
     }
     if (mine) atomicAdd(&total, mine);
     __syncthreads();
-    if (tid == 0) p.outNf[b] = (1 + total < k) ? 1 + total : k;
+    const int nOut = (1 + total < k) ? 1 + total : k;
+    if (tid == 0) p.outNf[b] = nOut;
+    if (p.outCol4row) {  // the inverse of the merged row4col (the writes above are this workgroup's own: visible after the barrier)
+        int *oc = p.outCol4row + (long long)b * k * p.ldRow;
+        for (int i = tid; i < nOut * p.ldRow; i += 256) oc[i] = -1;
+        __syncthreads();
+        for (int i = tid; i < nOut * M; i += 256) {
+            const int s = i / M, c = i - s * M;
+            const int r = orow[(long long)s * p.ldCol + c];
+            if (r >= 0 && r < p.ldRow) oc[(long long)s * p.ldRow + r] = c;
+        }
+    }
 }
 
 // Output slots beyond the number found are never written by the enumeration kernels: give them the values the host

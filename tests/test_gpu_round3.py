@@ -308,3 +308,30 @@ def test_registered_host_buffers_take_the_direct_path(engine):
     got = engine.kbest(costs, N, M, k)
     engine.unregister_host(r4c)
     assert all((np.asarray(a) == np.asarray(b)).all() for a, b in zip(got, want))
+
+
+def test_one_matrix_over_several_workgroups(monkeypatch):
+    """(KBEST_SPLIT: measured slower than the unsplit launch and therefore off by default -- kbest_capi.cpp, split_factor --, but
+    kept exact.)  A batch of 33 ... 64-row square problems that leaves CUs idle is enumerated by 2 or 4 workgroups per matrix (the root's
+    subtrees in turn, thresholds shared through HBM) and merged on the device: results are the unsplit launch's and the
+    oracle's bit for bit, col4row is the inverse of row4col; maximise and cutoff go through the same path."""
+    import torch
+    dev = torch.device("cuda", 0)
+    plain = engine_with(monkeypatch, KBEST_NO_SPLIT=1)
+    engs = {"four": engine_with(monkeypatch, KBEST_SPLIT=4), "two": engine_with(monkeypatch, KBEST_SPLIT=2)}
+    rng = np.random.default_rng(61)
+    for (N, k, B, kw) in ((64, 200, 5, {}), (64, 200, 100, {}), (48, 100, 33, {}), (33, 50, 7, {"maximize": True}),
+                          (64, 120, 3, {"cutoff": 0.08}), (40, 64, 1, {})):
+        costs = rng.random((B, N * N))
+        want = plain.kbest(costs, N, N, k, **kw)
+        onf, or4c, oc4r, og, _ = ol.orc_kbest_batch(costs[:4], N, N, k, **kw)
+        assert (want[0][:4] == onf).all() and (want[1][:4] == or4c).all() and (bits(want[3][:4]) == bits(og)).all()
+        for name, e in engs.items():
+            got = e.kbest(costs, N, N, k, **kw)
+            assert (got[0] == want[0]).all(), (name, N, k, B)
+            for b in range(B):
+                n = int(got[0][b])
+                assert (got[1][b, :n] == want[1][b, :n]).all() and (bits(got[3][b, :n]) == bits(want[3][b, :n])).all(), (name, N, k, B, b)
+                assert (got[2][b, :n] == want[2][b, :n]).all(), (name, N, k, B, b)  # square: every row has a real column
+    for e in list(engs.values()) + [plain]:
+        e.close()
