@@ -281,6 +281,7 @@ def host_inclusive_dense(eng, costs, N, M, k):
     caller-owned buffers that are allocated (and touched) once, as a caller that runs frame after frame would.
     Twice: with plain (pageable) numpy buffers, and with the same buffers registered once with the engine
     (kbest_register_host_buffer: pinned + device-mapped, the result tables are written there by the kernel itself)."""
+    from probabilisticsemslam_amd import engine as pk_engine
     B = costs.shape[0]
     costs = np.ascontiguousarray(costs)
     r4c = np.zeros((B, k, M), np.int32)
@@ -311,8 +312,21 @@ def host_inclusive_dense(eng, costs, N, M, k):
         registered = timed()
         same = all(np.array_equal(x, y) for x, y in zip(ref, (r4c, c4r, gain, nf)))
         no_c4r = timed(with_c4r=False)
-        eng.unregister_host(costs, r4c, c4r, gain, nf)
+        eng.unregister_host(r4c, c4r)
+        # the same tables as int8 (KBEST_FLAG_TABLES_I8): every index of a 64-row problem fits a byte
+        r8, c8 = np.zeros((B, k, M), np.int8), np.zeros((B, k, N), np.int8)
+        eng.register_host(r8, c8)
+        o.flags |= pk_engine.KBEST_FLAG_TABLES_I8
+        r4c_keep, c4r_keep = r4c, c4r
+        r4c, c4r = r8, c8
+        i8 = timed()
+        same8 = np.array_equal(r8, ref[0]) and np.array_equal(c8, ref[1]) and np.array_equal(gain, ref[2])
+        i8_no_c4r = timed(with_c4r=False)
+        r4c, c4r = r4c_keep, c4r_keep
+        o.flags &= ~pk_engine.KBEST_FLAG_TABLES_I8
+        eng.unregister_host(costs, r8, c8, gain, nf)
         assert same, "registered-buffer path differs from the copying path"
+        assert same8, "int8 tables differ from the int32 tables"
     except Exception as ex:  # (keep the pageable number if registration is not possible on this host)
         registered = None
         err = repr(ex)
@@ -329,6 +343,10 @@ def host_inclusive_dense(eng, costs, N, M, k):
         out["ms_without_col4row"] = 1e3 * no_c4r
         out["without_col4row_what"] = ("col4row = NULL (legal: it is the inverse of row4col, and assignmentProb, the reference's caller, "
                                        "never reads it -- assignment.cpp:629): half the table bytes, the PCIe link no longer slows the kernel")
+        out["ms_int8_tables"] = 1e3 * i8
+        out["ms_int8_tables_without_col4row"] = 1e3 * i8_no_c4r
+        out["int8_tables_what"] = ("KBEST_FLAG_TABLES_I8: row4col / col4row as int8 tables (same values; indices of <= 127-row problems fit a "
+                                   "byte): a quarter of the table bytes cross PCIe; checked equal to the int32 tables")
         out["note"] = (f"{(r4c.nbytes + c4r.nbytes + gain.nbytes) / 1e6:.0f} MB of int32 tables leave the kernel over PCIe while it runs: "
                        "~35 GB/s is the link's rate for these stores, so the run cannot end before ~3.0 ms; see DESIGN.md section 6")
     return out

@@ -43,6 +43,7 @@ struct kbest_ctx {
     bool noSplit = false;     // KBEST_NO_SPLIT: never split one matrix over several workgroups (A/B tests)
     int splitForce = 0;       // KBEST_SPLIT: workgroups per matrix (2 / 4) whenever the split is possible (A/B tests)
     DevBufRaw splitBuf;       // per-share result tables + shared thresholds of the split
+    int zcCost = 1;           // KBEST_ZC_COST=0: cost blocks in registered memory are copied up first instead of read in place (A/B tests)
     int pieces = 0;           // KBEST_PIECES: pieces of a large host-entry batch (1 / 2 / 4; A/B tests); 0 = choose
     bool noLane = false;      // KBEST_NO_LANE: no lane-per-child kernel (A/B tests)
     bool forceLane = false;   // KBEST_FORCE_LANE: every plain batch of <= 32-row problems through the lane-per-child kernel
@@ -279,6 +280,7 @@ int kbest_create(kbest_ctx **out, int device)
     ctx->noLane = getenv("KBEST_NO_LANE") != nullptr;
     ctx->noSplit = getenv("KBEST_NO_SPLIT") != nullptr;
     if (const char *e = getenv("KBEST_SPLIT")) { const int w = atoi(e); if (w == 2 || w == 4) ctx->splitForce = w; }
+    if (const char *e = getenv("KBEST_ZC_COST")) ctx->zcCost = atoi(e);
     if (const char *e = getenv("KBEST_PIECES")) { const int w = atoi(e); if (w == 1 || w == 2 || w == 4) ctx->pieces = w; }
     ctx->forceLane = getenv("KBEST_FORCE_LANE") != nullptr;
     if (const char *e = getenv("KBEST_LANE_NW")) { const int w = atoi(e); if (w == 1 || w == 2 || w == 4) ctx->laneNw = w; }
@@ -584,7 +586,7 @@ static int split_factor(const kbest_ctx *ctx, const kbest_opts *opts, int B, int
 {
     if (!ctx->splitForce || ctx->noSplit || !uniform || !plain || maxRow != maxCol || maxRow <= 32 || maxRow > KBEST_MAX_DIM || k < 50 ||
         opts->root_col_stride > 1 || (opts->flags & (KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_PRUNE | KBEST_FLAG_RECT_ROOT |
-                                                     KBEST_FLAG_NO_SHIFT | KBEST_FLAG_EXACT_ROOT)))
+                                                     KBEST_FLAG_NO_SHIFT | KBEST_FLAG_EXACT_ROOT | KBEST_FLAG_TABLES_I8)))
         return 1;
     return ctx->splitForce * B <= ctx->nCU ? ctx->splitForce : ((2 * B <= ctx->nCU) ? 2 : 1);
 }
@@ -603,6 +605,9 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
     if ((d_nRow == nullptr) != (d_nCol == nullptr))
         return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_batch_f64_dev: give both nRow and nCol or neither");
     if (maxRow > KBEST_MAX_DIM_WIDE) return fail(ctx, KBEST_ERR_UNSUPPORTED, "numRow > KBEST_MAX_DIM_WIDE");
+    const bool tabI8 = (opts->flags & KBEST_FLAG_TABLES_I8) != 0;
+    if (tabI8 && extra) return fail(ctx, KBEST_ERR_BAD_ARG, "KBEST_FLAG_TABLES_I8: k-best entries only");
+    if (tabI8 && maxRow > 127) return fail(ctx, KBEST_ERR_UNSUPPORTED, "KBEST_FLAG_TABLES_I8: numRow > 127 does not fit int8 tables");
     if (B == 0) return KBEST_OK;
     // Two kernels share the work.  The LDS kernel (kbest_engine.hip) takes every problem of up to KBEST_MAX_DIM
     // rows as long as the candidate pool for k fits its LDS; the general-size kernel (kbest_wide.hip) takes the
@@ -703,6 +708,7 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         sp.cutoff = opts->cutoff;
         sp.row4col = d_row4col;
         sp.col4row = d_col4row;
+        sp.tabI8 = tabI8 ? 1 : 0;
         sp.gain = d_gain;
         sp.nf = d_nf;
         sp.stateStride = kb::small_state_stride(maxRow, maxCol);
@@ -939,36 +945,50 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t nR4C = (size_t)B * k * maxCol, nC4R = (size_t)B * k * maxRow, nG = (size_t)B * k;
+    const bool tabI8 = (opts->flags & KBEST_FLAG_TABLES_I8) != 0;  // row4col / col4row are int8 tables behind the int32_t pointers
+    const size_t esz = tabI8 ? 1 : 4;
+    if (tabI8 && maxRow > 127) return fail(ctx, KBEST_ERR_UNSUPPORTED, "KBEST_FLAG_TABLES_I8: numRow > 127 does not fit int8 tables");
     // Result tables in registered (pinned, device-mapped) host memory (kbest_register_host_buffer) are written THERE by the
     // kernels, spread over the whole run (the 64-row kernel emits a slot's tables as soon as the slot is final), so that
     // nothing is left to copy when the last matrix ends; otherwise they are staged in device buffers and copied back.
-    int32_t *mR4C = static_cast<int32_t *>(mapped(ctx, row4col, nR4C * 4));
-    int32_t *mC4R = col4row ? static_cast<int32_t *>(mapped(ctx, col4row, nC4R * 4)) : nullptr;
+    char *mR4C = static_cast<char *>(mapped(ctx, row4col, nR4C * esz));
+    char *mC4R = col4row ? static_cast<char *>(mapped(ctx, col4row, nC4R * esz)) : nullptr;
     double *mGain = static_cast<double *>(mapped(ctx, gain, nG * 8));
     int32_t *mNf = static_cast<int32_t *>(mapped(ctx, nf, (size_t)B * 4));
     const bool direct = mR4C && (mC4R || !col4row) && mGain && mNf && !pushed;
-    const bool pinnedCost = mapped(ctx, cost, nCost * 8) != nullptr;
+    double *mCost = static_cast<double *>(mapped(ctx, cost, nCost * 8));
+    const bool pinnedCost = mCost != nullptr;
+    // Registered cost blocks with registered result tables: the LDS kernels read every cost block exactly once, into their
+    // tile, so they take it from the caller's memory over the link themselves -- no upload in front of the first workgroup,
+    // later generations' reads hide behind the running ones (1 024 x 64x64, k = 200: 3.74 -> 3.33 ms per call; 3.00 with
+    // int8 tables).  Not for the general-size kernel (it re-reads costs from memory at every step), and not together with
+    // copies back of pageable tables (measured slower: they share the link).
+    const bool zcCost = pinnedCost && direct && ctx->zcCost && maxRow <= KBEST_MAX_DIM && !ctx->forceWide &&
+                        k_fits_fast(ctx, B, maxRow < KBEST_MAX_DIM ? maxRow : KBEST_MAX_DIM, k, opts->flags, nullptr);
     DevBuf dCost, dOff, dNR, dNC, dR4C, dC4R, dGain, dNf, dPushed;
-    HIP_TRY(ctx, dCost.alloc(ctx, nCost * 8));
+    if (!zcCost) HIP_TRY(ctx, dCost.alloc(ctx, nCost * 8));
+    const double *devCost = zcCost ? mCost : dCost.as<double>();
     if (!direct) {
-        HIP_TRY(ctx, dR4C.alloc(ctx, nR4C * 4));
-        if (col4row) HIP_TRY(ctx, dC4R.alloc(ctx, nC4R * 4));
+        HIP_TRY(ctx, dR4C.alloc(ctx, nR4C * esz));
+        if (col4row) HIP_TRY(ctx, dC4R.alloc(ctx, nC4R * esz));
         HIP_TRY(ctx, dGain.alloc(ctx, nG * 8));
         HIP_TRY(ctx, dNf.alloc(ctx, (size_t)B * 4));
         if (pushed) HIP_TRY(ctx, dPushed.alloc(ctx, (size_t)B * 8));
     }
-    int32_t *oR4C = direct ? mR4C : dR4C.as<int32_t>(), *oC4R = !col4row ? nullptr : (direct ? mC4R : dC4R.as<int32_t>()), *oNf = direct ? mNf : dNf.as<int32_t>();
+    // (tables addressed in bytes: esz per entry)
+    char *oR4C = direct ? mR4C : dR4C.as<char>(), *oC4R = !col4row ? nullptr : (direct ? mC4R : dC4R.as<char>());
+    int32_t *oNf = direct ? mNf : dNf.as<int32_t>();
     double *oGain = direct ? mGain : dGain.as<double>();
     // A batch that is large in problems and in output bytes goes through the GPU in PIECES on separate streams: the launch
     // shape and the workspace are those of the whole batch (SubBatch), so the pieces' workgroups fill the chip exactly as one
     // launch of the whole batch would -- but a piece starts as soon as ITS cost blocks are up, and its tables cross PCIe
     // while later pieces still run.  1 024 x 64x64, k = 200 (33 MB in, 107 MB out): pageable buffers 5.7 ms in one piece,
     // 4.4 in two half-size launches (round 2), now four pieces; registered buffers 3.7 ms in one piece.
-    const size_t outBytes = (nR4C + (col4row ? nC4R : 0)) * 4 + nG * 8;
+    const size_t outBytes = (nR4C + (col4row ? nC4R : 0)) * esz + nG * 8;
     const int fastRow = maxRow < KBEST_MAX_DIM ? maxRow : KBEST_MAX_DIM;
     const bool canPiece = !costOff && maxRow <= KBEST_MAX_DIM && !ctx->forceWide && B >= 4 * ctx->nCU && outBytes >= ((size_t)32 << 20) &&
                           k_fits_fast(ctx, B, fastRow, k, opts->flags, nullptr);
-    const int nPiece = canPiece ? (ctx->pieces > 0 ? ctx->pieces : 4) : 1;
+    const int nPiece = canPiece ? (ctx->pieces > 0 ? ctx->pieces : ((zcCost && direct) ? 1 : 4)) : 1;
     if (nPiece > 1)
         for (int i = 0; i < 3; i++)
             if (!ctx->aux[i]) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking));
@@ -1002,18 +1022,21 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
         // (registered cost blocks: asynchronous copies, all pieces' at once -- they share the link, so the first piece's kernel
         //  starts ~0.3 ms into the call; chaining the copies with events, or blocking copies piece by piece, measured slower:
         //  3.9 - 4.1 ms per call against 3.7)
-        if (pinnedCost) e = hipMemcpyAsync(dCost.as<double>() + cOff, cost + cOff, cLen * 8, hipMemcpyHostToDevice, st[c]);
+        if (zcCost) e = hipSuccess;
+        else if (pinnedCost) e = hipMemcpyAsync(dCost.as<double>() + cOff, cost + cOff, cLen * 8, hipMemcpyHostToDevice, st[c]);
         else e = hipMemcpy(dCost.as<double>() + cOff, cost + cOff, cLen * 8, hipMemcpyHostToDevice);  // (complete on return; earlier pieces run meanwhile)
         if (e != hipSuccess) { rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: upload", e); break; }
         const SubBatch sub{B, b0};
         rc = batch_dev_impl(ctx, opts, nb, maxRow, maxCol, nRow ? dNR.as<int32_t>() + b0 : nullptr, nRow ? dNC.as<int32_t>() + b0 : nullptr,
-                            costOff ? dCost.as<double>() : dCost.as<double>() + (size_t)b0 * per, costOff ? dOff.as<int64_t>() + b0 : nullptr,
-                            k, oR4C + (size_t)b0 * k * maxCol, oC4R ? oC4R + (size_t)b0 * k * maxRow : nullptr, oGain + (size_t)b0 * k, oNf + b0,
+                            costOff ? devCost : devCost + (size_t)b0 * per, costOff ? dOff.as<int64_t>() + b0 : nullptr,
+                            k, reinterpret_cast<int32_t *>(oR4C + (size_t)b0 * k * maxCol * esz),
+                            oC4R ? reinterpret_cast<int32_t *>(oC4R + (size_t)b0 * k * maxRow * esz) : nullptr, oGain + (size_t)b0 * k, oNf + b0,
                             pushed ? dPushed.as<int64_t>() + b0 : nullptr, st[c], true, nullptr, nPiece > 1 ? &sub : nullptr);
         if (rc != KBEST_OK) break;
         // slots beyond nf are never written by the kernels: give them defined values (row4col / col4row -1, gain 0)
-        e = kb::launch_fill_unused(oNf + b0, nb, k, maxCol, maxRow, oR4C + (size_t)b0 * k * maxCol, oC4R ? oC4R + (size_t)b0 * k * maxRow : nullptr,
-                                   oGain + (size_t)b0 * k, st[c]);
+        e = kb::launch_fill_unused(oNf + b0, nb, k, maxCol, maxRow, reinterpret_cast<int32_t *>(oR4C + (size_t)b0 * k * maxCol * esz),
+                                   oC4R ? reinterpret_cast<int32_t *>(oC4R + (size_t)b0 * k * maxRow * esz) : nullptr, oGain + (size_t)b0 * k, tabI8,
+                                   st[c]);
         if (e != hipSuccess) { rc = fail(ctx, KBEST_ERR_HIP, "fill kernel launch", e); break; }
         if (!direct && nPiece > 1 &&
             (hipEventCreateWithFlags(&done[c], hipEventDisableTiming) != hipSuccess || hipEventRecord(done[c], st[c]) != hipSuccess))
@@ -1023,8 +1046,9 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
         for (int c = 0; c < nPiece && rc == KBEST_OK; c++) {
             const int b0 = (int)((long long)B * c / nPiece), nb = (int)((long long)B * (c + 1) / nPiece) - b0;
             hipError_t e = (nPiece > 1) ? hipEventSynchronize(done[c]) : hipStreamSynchronize(ctx->stream);
-            if (e == hipSuccess) e = hipMemcpy(row4col + (size_t)b0 * k * maxCol, dR4C.as<int32_t>() + (size_t)b0 * k * maxCol, (size_t)nb * k * maxCol * 4, hipMemcpyDeviceToHost);
-            if (e == hipSuccess && col4row) e = hipMemcpy(col4row + (size_t)b0 * k * maxRow, dC4R.as<int32_t>() + (size_t)b0 * k * maxRow, (size_t)nb * k * maxRow * 4, hipMemcpyDeviceToHost);
+            const size_t rOff = (size_t)b0 * k * maxCol * esz, cOff = (size_t)b0 * k * maxRow * esz;
+            if (e == hipSuccess) e = hipMemcpy(reinterpret_cast<char *>(row4col) + rOff, dR4C.as<char>() + rOff, (size_t)nb * k * maxCol * esz, hipMemcpyDeviceToHost);
+            if (e == hipSuccess && col4row) e = hipMemcpy(reinterpret_cast<char *>(col4row) + cOff, dC4R.as<char>() + cOff, (size_t)nb * k * maxRow * esz, hipMemcpyDeviceToHost);
             if (e == hipSuccess) e = hipMemcpy(gain + (size_t)b0 * k, dGain.as<double>() + (size_t)b0 * k, (size_t)nb * k * 8, hipMemcpyDeviceToHost);
             if (e == hipSuccess) e = hipMemcpy(nf + b0, dNf.as<int32_t>() + b0, (size_t)nb * 4, hipMemcpyDeviceToHost);
             if (e == hipSuccess && pushed) e = hipMemcpy(pushed + b0, dPushed.as<int64_t>() + b0, (size_t)nb * 8, hipMemcpyDeviceToHost);

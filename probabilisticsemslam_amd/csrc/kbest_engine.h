@@ -284,6 +284,7 @@ struct SmallParams {
     const long long *probOff;
     unsigned long long *prof; // diagnostic builds only
     int imm, immRow, immCol, immL;  // imm = 1 (B = 1): the shape of the one problem travels in the kernel arguments
+    int tabI8;                // 1: row4col / col4row are int8 tables (KBEST_FLAG_TABLES_I8)
     int *done;                // host-mapped completion counter (zero-copy calls) or nullptr
 };
 
@@ -400,7 +401,8 @@ struct MergeParams {
     int ldRow;
 };
 hipError_t launch_merge_topk(const MergeParams &p, int B, hipStream_t stream);
-hipError_t launch_fill_unused(const int *nf, int B, int k, int ldCol, int ldRow, int *row4col, int *col4row, double *gain, hipStream_t stream);
+hipError_t launch_fill_unused(const int *nf, int B, int k, int ldCol, int ldRow, int *row4col, int *col4row, double *gain, bool tablesI8,
+                              hipStream_t stream);
 hipError_t launch_kbest_lane(const Params &p, int B, int nWaves, int lanesPerChild, hipStream_t stream);
 hipError_t launch_kbest_small(const SmallParams &p, int B, int nWaves, hipStream_t stream);
 hipError_t launch_kbest(const Params &p, int B, int nWaves, hipStream_t stream);

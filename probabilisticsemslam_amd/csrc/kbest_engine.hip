@@ -345,6 +345,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     // unassigned rows stay -1, no zero-padded columns; NO_SHIFT: the matrix is already "safe" (shortestPathCPP is
     // called on workMem.C as it is)
     const bool rect = (p.flags & KBEST_FLAG_RECT_ROOT) != 0;
+    const bool tabI8 = (p.flags & KBEST_FLAG_TABLES_I8) != 0;
     const bool noShift = (p.flags & KBEST_FLAG_NO_SHIFT) != 0;
     const int gainCols = (p.gainCols > 0 && p.gainCols < M) ? p.gainCols : M;  // numCol4Gain (cpp:232)
     // rows on the zero-padded columns M .. D-1 are settled together in a child's search (dijkstra<>); 64 = never
@@ -811,10 +812,10 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 const int sOut = outDone + uni32(t);
                 if (sOut >= emitted) break;
                 const unsigned char *st = stBase + (long long)slotSid[sOut] * p.stateStride;
-                if (lane < M) p.row4col[(outBase + sOut) * p.ldCol + lane] = st[offR4C + lane];
+                if (lane < M) put_index(p.row4col, (outBase + sOut) * p.ldCol + lane, st[offR4C + lane], tabI8);
                 if (p.col4row && lane < N) {
                     const int cv = st[offC4R + lane];
-                    p.col4row[(outBase + sOut) * p.ldRow + lane] = (rect && cv == 255) ? -1 : cv;  // unassigned row (cpp:134)
+                    put_index(p.col4row, (outBase + sOut) * p.ldRow + lane, (rect && cv == 255) ? -1 : cv, tabI8);  // unassigned row (cpp:134)
                 }
             }
         }
@@ -1199,10 +1200,10 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     for (int idx = tid + outDoneEnd * (N + M); idx < nf * (N + M); idx += NT) {
         const int s = idx / (N + M), j = idx - s * (N + M);
         const unsigned char *st = stBase + (long long)slotSid[s] * p.stateStride;
-        if (j < M) p.row4col[(outBase + s) * p.ldCol + j] = st[offR4C + j];
+        if (j < M) put_index(p.row4col, (outBase + s) * p.ldCol + j, st[offR4C + j], tabI8);
         else if (p.col4row) {
             const int cv = st[offC4R + (j - M)];
-            p.col4row[(outBase + s) * p.ldRow + (j - M)] = (rect && cv == 255) ? -1 : cv;  // unassigned row (cpp:134)
+            put_index(p.col4row, (outBase + s) * p.ldRow + (j - M), (rect && cv == 255) ? -1 : cv, tabI8);  // unassigned row (cpp:134)
         }
     }
     if (tid == 0) {

@@ -46,7 +46,6 @@ namespace kb {
 namespace {
 
 constexpr u32 LN_SPLIT = 0x80000000u;  // pool meta: children already generated and merged
-constexpr u32 LN_META_MASK = 0x00FFFFFFu;
 
 struct LaneCtrl {
     double cdelta;      // CDelta * numCol (cpp:583)
@@ -159,6 +158,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
     const double *Cg = p.cost + (p.costOff ? p.costOff[b] : (long long)b * p.ldRow * p.ldCol);
     const bool maximize = p.maximize != 0, useCut = p.useCutoff != 0;
     const bool prune = (p.flags & KBEST_FLAG_NO_PRUNE) == 0;
+    const bool tabI8 = (p.flags & KBEST_FLAG_TABLES_I8) != 0;
     const int rl = lane < D ? lane : D - 1;
     const u64 allRows = (D >= 64) ? ~0ull : ((1ull << D) - 1ull);
     const int nSlots = p.statesPerProblem;
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
     unsigned short *compList = reinterpret_cast<unsigned short *>(smem + L.offComp);
     const int ldc8 = LDC * 8;
     // ---- phase 2: rounds ----------------------------------------------------------------------------
-    for (int roundNo = 0; uni32(ctrl->stop) == 0; roundNo++) {
+    while (uni32(ctrl->stop) == 0) {
         KB_T(tRound);
         KB_ACC(7, 1);  // [7] rounds
         const int nsel = uni32(ctrl->nsel);
@@ -837,8 +837,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
     for (int idx = tid; idx < nf * (N + M); idx += NT) {
         const int s = idx / (N + M), j = idx - s * (N + M);
         const unsigned char *st = stBase + (long long)slotSid[s] * p.stateStride;
-        if (j < M) p.row4col[(outBase + s) * p.ldCol + j] = st[S_R4C + j];
-        else if (p.col4row) p.col4row[(outBase + s) * p.ldRow + (j - M)] = st[S_C4R + (j - M)];
+        if (j < M) put_index(p.row4col, (outBase + s) * p.ldCol + j, st[S_R4C + j], tabI8);
+        else if (p.col4row) put_index(p.col4row, (outBase + s) * p.ldRow + (j - M), st[S_C4R + (j - M)], tabI8);
     }
     if (tid == 0) {
         p.nf[b] = nf;

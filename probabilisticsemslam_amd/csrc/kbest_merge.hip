@@ -97,7 +97,8 @@ __global__ void __launch_bounds__(256) merge_topk_kernel(MergeParams p)
 
 // Output slots beyond the number found are never written by the enumeration kernels: give them the values the host
 // entries promise (row4col / col4row -1, gain 0) -- one workgroup per problem, nothing to do when nf == k.
-__global__ void __launch_bounds__(256) fill_unused_kernel(const int *nf, int k, int ldCol, int ldRow, int *row4col, int *col4row, double *gain)
+template <typename T>
+__global__ void __launch_bounds__(256) fill_unused_kernel(const int *nf, int k, int ldCol, int ldRow, T *row4col, T *col4row, double *gain)
 {
     const int b = blockIdx.x;
     int n = nf[b];
@@ -110,9 +111,14 @@ __global__ void __launch_bounds__(256) fill_unused_kernel(const int *nf, int k, 
     for (int i = threadIdx.x + n; i < k; i += 256) gain[base + i] = 0.0;
 }
 
-hipError_t launch_fill_unused(const int *nf, int B, int k, int ldCol, int ldRow, int *row4col, int *col4row, double *gain, hipStream_t stream)
+hipError_t launch_fill_unused(const int *nf, int B, int k, int ldCol, int ldRow, int *row4col, int *col4row, double *gain, bool tablesI8,
+                              hipStream_t stream)
 {
-    hipLaunchKernelGGL(fill_unused_kernel, dim3(B), dim3(256), 0, stream, nf, k, ldCol, ldRow, row4col, col4row, gain);
+    if (tablesI8)  // KBEST_FLAG_TABLES_I8: the same tables, one byte per entry
+        hipLaunchKernelGGL(fill_unused_kernel<signed char>, dim3(B), dim3(256), 0, stream, nf, k, ldCol, ldRow,
+                           reinterpret_cast<signed char *>(row4col), reinterpret_cast<signed char *>(col4row), gain);
+    else
+        hipLaunchKernelGGL(fill_unused_kernel<int>, dim3(B), dim3(256), 0, stream, nf, k, ldCol, ldRow, row4col, col4row, gain);
     return hipGetLastError();
 }
 

@@ -221,6 +221,8 @@ int kbest_batch_f64_multi_ex(kbest_multi *m, const kbest_opts *opts, int mode, i
     if (!opts || B < 0 || k < 1 || maxCol < 1 || maxRow < maxCol || !cost || !row4col || !gain || !nf ||
         (nRow == nullptr) != (nCol == nullptr) || (mode != KBEST_MULTI_BATCH && mode != KBEST_MULTI_SUBTREE) || nShard < 0)
         return mfail(m, KBEST_ERR_BAD_ARG, "kbest_batch_f64_multi: bad argument");
+    if (opts->flags & KBEST_FLAG_TABLES_I8)
+        return mfail(m, KBEST_ERR_UNSUPPORTED, "kbest_batch_f64_multi: int8 tables (the gather and the merge work on int32 tables)");
     if (nRow)  // the same validation as kbest_batch_f64: a bad shape is an argument error, not a kernel's nf = -1
         for (int b = 0; b < B; b++)
             if (nCol[b] < 1 || nRow[b] < nCol[b] || nRow[b] > maxRow || nCol[b] > maxCol)

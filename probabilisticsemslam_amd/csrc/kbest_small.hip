@@ -58,12 +58,6 @@ constexpr u64 SM_LO = 0x00000000FFFFFFFFull, SM_HI = 0xFFFFFFFF00000000ull;
 constexpr u32 SM_SPLIT = 0x80000000u;  // pool meta: children already generated
 constexpr double SM_GATE = 42.0;       // assignment.cpp:9
 
-__device__ __forceinline__ double sel_f64(u64 mask, double ifset, double ifclear)
-{
-    return __hiloint2double(sel32(mask, __double2hiint(ifset), __double2hiint(ifclear)),
-                            sel32(mask, __double2loint(ifset), __double2loint(ifclear)));
-}
-
 // value for the lower half-wave, value for the upper one -> one lane value
 __device__ __forceinline__ int pick(int forLow, int forHigh) { return sel32(SM_HI, forHigh, forLow); }
 
@@ -1153,12 +1147,12 @@ __global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
     if (p.row4col || p.col4row || p.gain) {
         for (int s = worker; s < nf; s += W) {  // one half-wave per solution
             const unsigned char *st = stBase + (long long)ES[s] * p.stateStride;
-            if (p.row4col && l < M) p.row4col[(outBase + s) * p.ldCol + l] = st[offR4C + l];
+            if (p.row4col && l < M) put_index(p.row4col, (outBase + s) * p.ldCol + l, st[offR4C + l], p.tabI8 != 0);
             if (p.col4row) {
                 const int c = (l < N) ? (int)st[offC4R + l] : 0;
                 const u64 pk = __ballot(l < N && c == SM_PARKED) & myHalf;
                 const int rank = __popcll(pk & ((1ull << lane) - 1ull));
-                if (l < N) p.col4row[(outBase + s) * p.ldRow + l] = (c == SM_PARKED) ? M + rank : c;
+                if (l < N) put_index(p.col4row, (outBase + s) * p.ldRow + l, (c == SM_PARKED) ? M + rank : c, p.tabI8 != 0);
             }
         }
         if (p.gain)

@@ -115,5 +115,13 @@ __device__ __forceinline__ void wave_fence()
 
 __device__ __forceinline__ u64 bit64(int i) { return 1ull << (i & 63); }
 
+// One entry of a result table (row4col / col4row): int32, the interface's type, or int8 with KBEST_FLAG_TABLES_I8 (the
+// same values; every index of a problem of up to 127 rows fits, -1 stays -1).  `i8` is uniform over the launch.
+__device__ __forceinline__ void put_index(int *table, long long i, int value, bool i8)
+{
+    if (i8) reinterpret_cast<signed char *>(table)[i] = (signed char)value;
+    else table[i] = value;
+}
+
 }  // namespace kb
 #endif

@@ -356,6 +356,7 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
     const int k = p.k;
     const bool maximize = p.maximize != 0, useCut = p.useCutoff != 0;
     const bool prune = (p.flags & KBEST_FLAG_NO_PRUNE) == 0;
+    const bool tabI8 = (p.flags & KBEST_FLAG_TABLES_I8) != 0;
     // saved hypothesis: u[DS] v[DS] (fp64) | row4col[DS] col4row[DS] (i32) | forbidden rows (u32 per lane) | gain, activeCol
     const long long offV = 8LL * DS, offR4C = 16LL * DS, offC4R = 20LL * DS, offForb = 24LL * DS, offTail = 24LL * DS + 256;
 
@@ -616,8 +617,8 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
             for (int idx = tid; idx < nEmit * (N + M); idx += NT) {
                 const int j = idx / (N + M), q = idx - j * (N + M);
                 const unsigned char *E = stBase + (long long)(srcS[j] & WIDE_SID_MASK) * p.stateStride;
-                if (q < M) p.row4col[(outBase + emitted + j) * p.ldCol + q] = reinterpret_cast<const int *>(E + offR4C)[q];
-                else if (p.col4row) p.col4row[(outBase + emitted + j) * p.ldRow + (q - M)] = reinterpret_cast<const int *>(E + offC4R)[q - M];
+                if (q < M) put_index(p.row4col, (outBase + emitted + j) * p.ldCol + q, reinterpret_cast<const int *>(E + offR4C)[q], tabI8);
+                else if (p.col4row) put_index(p.col4row, (outBase + emitted + j) * p.ldRow + (q - M), reinterpret_cast<const int *>(E + offC4R)[q - M], tabI8);
             }
             if (uni32(ctrl->stop) != 0) {
                 __syncthreads();

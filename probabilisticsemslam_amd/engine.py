@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 KBEST_FLAG_NO_PRUNE = 1
 KBEST_FLAG_COUNT_PUSHED = 2
+KBEST_FLAG_TABLES_I8 = 64
 KBEST_MAX_DIM = 64        # rows handled by the LDS-resident kernel
 KBEST_MAX_DIM_WIDE = 512  # rows handled at all (general-size kernel beyond KBEST_MAX_DIM)
 
@@ -147,10 +148,11 @@ class KBestEngine:
 
     # ---- host buffers -----------------------------------------------------------------
     def kbest(self, costs, N, M, k, maximize=False, cutoff=None, nRow=None, nCol=None, costOff=None,
-              count_pushed=False, prune=True, root_shard=None):
+              count_pushed=False, prune=True, root_shard=None, tables_i8=False):
         """Batched kBest2D / kBest2DCutoff.  costs: (B, N*M) for uniform shapes, or a flat packed
         array with per-problem nRow/nCol/costOff (N, M are then the maxima).
-        Returns (nf[B], row4col[B,k,M], col4row[B,k,N], gain[B,k]) (+ pushed[B] if count_pushed)."""
+        Returns (nf[B], row4col[B,k,M], col4row[B,k,N], gain[B,k]) (+ pushed[B] if count_pushed).
+        tables_i8: the two tables come back as int8 (KBEST_FLAG_TABLES_I8; N <= 127)."""
         costs = np.ascontiguousarray(costs, dtype=np.float64)
         if nRow is None:
             costs = costs.reshape(-1, N * M)
@@ -160,12 +162,14 @@ class KBestEngine:
             nCol = np.ascontiguousarray(nCol, dtype=np.int32)
             costOff = np.ascontiguousarray(costOff, dtype=np.int64)
             B = len(nRow)
-        r4c = np.empty((B, k, M), np.int32)
-        c4r = np.empty((B, k, N), np.int32)
+        tdt = np.int8 if tables_i8 else np.int32
+        r4c = np.empty((B, k, M), tdt)
+        c4r = np.empty((B, k, N), tdt)
         gain = np.empty((B, k), np.float64)
         nf = np.empty(B, np.int32)
         pushed = np.zeros(B, np.int64) if count_pushed else None
-        flags = (KBEST_FLAG_COUNT_PUSHED if count_pushed else 0) | (0 if prune else KBEST_FLAG_NO_PRUNE)
+        flags = ((KBEST_FLAG_COUNT_PUSHED if count_pushed else 0) | (0 if prune else KBEST_FLAG_NO_PRUNE) |
+                 (KBEST_FLAG_TABLES_I8 if tables_i8 else 0))
         o = self._opts(maximize, cutoff, flags, root_shard)
         self._check(self.lib.kbest_batch_f64(self.ctx, C.byref(o), B, N, M, _ptr(nRow), _ptr(nCol), _ptr(costs),
                                              _ptr(costOff), k, _ptr(r4c), _ptr(c4r), _ptr(gain), _ptr(nf),
@@ -291,10 +295,12 @@ class KBestEngine:
         self._check(self.lib.kbest_reserve(self.ctx, B, N, k))
 
     def kbest_dev(self, d_cost, B, N, M, k, d_row4col, d_col4row, d_gain, d_nf, maximize=False, cutoff=None,
-                  d_pushed=None, prune=True, stream=None, root_shard=None, d_nRow=None, d_nCol=None, d_costOff=None):
+                  d_pushed=None, prune=True, stream=None, root_shard=None, d_nRow=None, d_nCol=None, d_costOff=None,
+                  tables_i8=False):
         """Asynchronous launch on `stream` (a raw hipStream_t integer, e.g.
-        torch.cuda.current_stream().cuda_stream).  All d_* are torch CUDA tensors."""
-        flags = (KBEST_FLAG_COUNT_PUSHED if d_pushed is not None else 0) | (0 if prune else KBEST_FLAG_NO_PRUNE)
+        torch.cuda.current_stream().cuda_stream).  All d_* are torch CUDA tensors (tables_i8: d_row4col / d_col4row int8)."""
+        flags = ((KBEST_FLAG_COUNT_PUSHED if d_pushed is not None else 0) | (0 if prune else KBEST_FLAG_NO_PRUNE) |
+                 (KBEST_FLAG_TABLES_I8 if tables_i8 else 0))
         o = self._opts(maximize, cutoff, flags, root_shard)
         # the C entry never allocates (kbest_c.h): size the workspace here (a no-op once it is large enough)
         self.reserve(B, N, k)

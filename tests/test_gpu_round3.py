@@ -335,3 +335,44 @@ def test_one_matrix_over_several_workgroups(monkeypatch):
                 assert (got[2][b, :n] == want[2][b, :n]).all(), (name, N, k, B, b)  # square: every row has a real column
     for e in list(engs.values()) + [plain]:
         e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(64, 64, 50, 40), (16, 16, 30, 700), (12, 12, 20, 64), (28, 10, 60, 33), (100, 100, 12, 6), (70, 20, 15, 5)])
+def test_int8_tables_equal_the_int32_tables(shape):
+    """KBEST_FLAG_TABLES_I8: the same row4col / col4row, one byte per entry, from every kernel (64-row, lane-per-child,
+    small-problem, general-size), with unused slots filled with -1 -- plain and registered host buffers."""
+    N, M, k, B = shape
+    rng = np.random.default_rng(N * 1000 + M)
+    costs = rng.uniform(0.0, 1.0, (B, N * M))
+    if N >= 64:
+        costs[0, :] = np.inf  # an infeasible problem: nf = 0, every slot is "unused"
+        costs[0, : N * M : 7] = 1.0
+    eng = pk.KBestEngine(0)
+    nf, r4c, c4r, gain = eng.kbest(costs, N, M, k)
+    nf8, r8, c8, gain8 = eng.kbest(costs, N, M, k, tables_i8=True)
+    assert r8.dtype == np.int8 and c8.dtype == np.int8
+    assert np.array_equal(nf, nf8) and np.array_equal(gain.view(np.int64), gain8.view(np.int64))
+    assert np.array_equal(r4c, r8) and np.array_equal(c4r, c8)
+    # registered buffers: the kernels write the byte tables straight into host memory
+    import ctypes as C
+    from probabilisticsemslam_amd import engine as E
+    rr, cc = np.full((B, k, M), 99, np.int8), np.full((B, k, N), 99, np.int8)
+    g2, n2 = np.zeros((B, k)), np.zeros(B, np.int32)
+    eng.register_host(rr, cc, g2, n2)
+    try:
+        o = eng._opts(False, None, E.KBEST_FLAG_TABLES_I8)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        cst = np.ascontiguousarray(costs)
+        eng._check(eng.lib.kbest_batch_f64(eng.ctx, C.byref(o), B, N, M, None, None, p(cst), None, k, p(rr), p(cc), p(g2), p(n2), None))
+    finally:
+        eng.unregister_host(rr, cc, g2, n2)
+    assert np.array_equal(rr, r4c) and np.array_equal(cc, c4r) and np.array_equal(n2, nf)
+
+
+@pytest.mark.gpu
+def test_int8_tables_refused_beyond_127_rows():
+    eng = pk.KBestEngine(0)
+    costs = np.random.default_rng(3).uniform(0, 1, (2, 130 * 130))
+    with pytest.raises(pk.KBestError, match="int8"):
+        eng.kbest(costs, 130, 130, 4, tables_i8=True)
