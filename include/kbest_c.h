@@ -135,8 +135,9 @@ int kbest_batch_f64_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRo
  * batch after batch with the same
  * buffers should register them once (kbest_register_host_buffer): result tables that lie in registered memory are written
  * there by the kernels themselves, spread over the whole run, and nothing is left to copy when the last problem ends;
- * cost blocks in registered memory come up with an asynchronous copy.  (1 024 x 64x64, k = 200, 107 MB of tables: the
- * copying path takes ~4.4 ms per call, the registered one ~3 ms, the kernel alone 2.7.)
+ * cost blocks in registered memory are read in place by the kernels (each block once, into its LDS tile) when the result
+ * tables are registered too.  (1 024 x 64x64, k = 200, 107 MB of tables: the copying path takes ~4.3 ms per call, the
+ * registered one 3.35, with KBEST_FLAG_TABLES_I8 3.04, the kernel alone 2.7.)
  */
 int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, int maxCol,
                     const int32_t *nRow, const int32_t *nCol, const double *cost,
@@ -259,7 +260,8 @@ int kbest_bb_match_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int
 /*
  * Pin [ptr, ptr + bytes) of caller-owned host memory and map it into the device's address space (hipHostRegister), for the
  * host-buffer entries above.  The range must stay allocated until kbest_unregister_host_buffer (or kbest_destroy).  Any number
- * of ranges; a buffer argument is taken as registered when it lies completely inside one of them.
+ * of ranges; a buffer argument is taken as registered when it lies completely inside one of them.  Honoured by
+ * kbest_batch_f64 (cost, row4col, col4row, gain, nf) and by the association entries (cost, probs).
  */
 int kbest_register_host_buffer(kbest_ctx *ctx, void *ptr, size_t bytes);
 int kbest_unregister_host_buffer(kbest_ctx *ctx, void *ptr);

@@ -376,3 +376,36 @@ def test_int8_tables_refused_beyond_127_rows():
     costs = np.random.default_rng(3).uniform(0, 1, (2, 130 * 130))
     with pytest.raises(pk.KBestError, match="int8"):
         eng.kbest(costs, 130, 130, 4, tables_i8=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F", [1, 9, 40, 700])
+def test_association_entry_on_registered_buffers(F):
+    """kbest_assoc_probs_batch_f64 with the cost blocks and the probabilities in registered caller memory (read / written
+    in place by the fused kernel) returns the same bits as with plain buffers -- which the other tests hold against the
+    reference's goldens and the checker."""
+    import ctypes as C
+    k, nL, nM = 200, 20, 10
+    frames = wl.kitti_like_frames(F, nL=nL, nM=nM, seed=0xBEEF + F)
+    nR = nL + nM
+    raw = np.ascontiguousarray(np.concatenate(frames))
+    h_nL, h_nM = np.full(F, nL, np.int32), np.full(F, nM, np.int32)
+    h_coff = np.arange(F, dtype=np.int64) * nR * nM
+    h_poff = np.arange(F, dtype=np.int64) * nM * (nL + 1)
+    eng = pk.KBestEngine(0)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+
+    def call(hp, hnf):
+        eng._check(eng.lib.kbest_assoc_probs_batch_f64(eng.ctx, F, p(h_nL), p(h_nM), p(raw), p(h_coff), k, p(hp), p(h_poff), p(hnf)))
+
+    ref_p, ref_nf = np.zeros(F * nM * (nL + 1)), np.zeros(F, np.int32)
+    call(ref_p, ref_nf)
+    assert (ref_nf > 0).all() and np.allclose(ref_p.reshape(F, nM, nL + 1).sum(axis=2), 1.0, rtol=0, atol=1e-12)
+    hp, hnf = np.full_like(ref_p, -7.0), np.zeros(F, np.int32)
+    eng.register_host(raw, hp)
+    try:
+        call(hp, hnf)
+        call(hp, hnf)
+    finally:
+        eng.unregister_host(raw, hp)
+    assert np.array_equal(hp.view(np.int64), ref_p.view(np.int64)) and np.array_equal(hnf, ref_nf)
