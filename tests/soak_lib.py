@@ -47,7 +47,9 @@ def check_case(eng, case):
     """None if the engine's result equals the oracle's (nf, gains bit for bit, assignments; equal gains as multisets),
     else a description of the first mismatch."""
     N, M, k, C = case["N"], case["M"], case["k"], case["C"]
-    nf, r4c, c4r, g = eng.kbest(C, N, M, k, case["maximize"], case["cutoff"])[:4]
+    # every third case takes its tables as int8 (KBEST_FLAG_TABLES_I8): the same values from every kernel's output phase
+    i8 = N <= 127 and (N + M + k + case["B"]) % 3 == 0
+    nf, r4c, c4r, g = eng.kbest(C, N, M, k, case["maximize"], case["cutoff"], tables_i8=i8)[:4]
     onf, or4c, oc4r, og, _ = ol.orc_kbest_batch(C, N, M, k, case["maximize"], case["cutoff"])
     for b in range(case["B"]):
         n = int(onf[b])
