@@ -1091,52 +1091,68 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 ldA = *reinterpret_cast<const int *>(st + offTail + 16);
             }
         }
-        if (wave == 0 && lane == 0) {
-            // emission: the head goes out while it has been split; a head selected in THIS round (not split yet)
-            // is emitted too but ends the run, because its children are not in the pool yet
-            int e = emitted, h = 0, stop = 0, selSeen = 0;
-            while (h < nq && e < k) {
-                int sid;
-                bool fresh = false;
-                if (S > 1 && PG[h] > tShared) { stop = 1; break; }  // beyond the global k-th best: this share is done
-                if (!(PM[h] & META_SPLIT)) {
-                    if (selSeen >= nselNew) break;  // not split and not selected this round: wait
-                    sid = sSid[0];
-#pragma unroll
-                    for (int w = 1; w < MS; w++) sid = (selSeen == w) ? sSid[w] : sid;  // selection is in pool order
-                    selSeen++;
-                    fresh = true;
-                } else {
-                    sid = (int)PS[h];
+        if (wave == 0) {
+            // emission (kBest2D cpp:607-634), all lanes of wave 0, 64 pool entries per pass: the head goes out while it has
+            // been split; the first entry that has NOT been split is the first one selected in this round (selection is in
+            // pool order): it is emitted too but ends the run, because its children are not in the pool yet.  (One lane walking
+            // the entries one by one -- five dependent LDS reads each -- kept the other eleven waves at the barrier below for
+            // ~10 000 cycles per round.)
+            int e = emitted, h = 0, stop = 0;
+            const double cdel = ctrl->cdelta, g0u = ctrl->gain0u;
+            bool more = true;
+            for (int base = 0; more && base < nq && e < k; base += 64) {
+                const int i = base + lane;
+                const bool valid = i < nq;
+                const double g = valid ? PG[i] : 0.0;
+                const u32 meta = valid ? PM[i] : 0u;
+                const int psid = valid ? (int)PS[i] : 0;
+                const double gu = maximize ? (-g + cdel) : (g + cdel);  // cpp:626-630
+                const bool cutB = useCut && valid && (maximize ? (gu < g0u - p.cutoff) : (gu > g0u + p.cutoff));
+                const bool shB = S > 1 && valid && g > tShared;  // beyond the global k-th best: this share is done
+                const u64 plainM = __ballot(valid && (meta & META_SPLIT) && !cutB && !shB);
+                int run = (~plainM == 0ull) ? 64 : __builtin_ctzll(~plainM);  // leading entries that simply go out
+                if (run > k - e) run = k - e;
+                if (lane < run) {
+                    p.gain[outBase + e + lane] = gu;
+                    slotSid[e + lane] = (unsigned short)psid;
                 }
-                const double g = PG[h];
-                const double gu = maximize ? (-g + ctrl->cdelta) : (g + ctrl->cdelta);  // cpp:626-630
-                p.gain[outBase + e] = gu;
-                slotSid[e] = (unsigned short)sid;
-                if (useCut && (maximize ? (gu < ctrl->gain0u - p.cutoff) : (gu > ctrl->gain0u + p.cutoff))) {
-                    stop = 1;  // cpp:709-719: slot written, not counted
-                    break;
+                e += run;
+                h += run;
+                if (run == 64) continue;     // the whole pass went out: next 64 entries
+                more = false;
+                if (e >= k || base + run >= nq) break;
+                // the entry that ended the run
+                const bool tSh = (__ballot(shB) >> run) & 1ull, tSplit = (__ballot((meta & META_SPLIT) != 0) >> run) & 1ull;
+                const bool tCut = (__ballot(cutB) >> run) & 1ull;
+                if (tSh) { stop = 1; break; }
+                if (!tSplit && nselNew == 0) break;  // not split and not selected this round: wait
+                if (lane == run) {
+                    p.gain[outBase + e] = gu;
+                    slotSid[e] = (unsigned short)(tSplit ? psid : sSid[0]);
                 }
+                if (tCut) { stop = 1; break; }  // cpp:709-719: slot written, not counted
                 e++;
                 h++;
-                if (fresh) break;
+                // (a split entry beyond the cutoff cannot get here; a fresh one ends the run)
             }
             if (e >= k) stop = 1;
             if (h >= nq && nselNew == 0) stop = 1;  // queue empty, nothing left to split: cpp:631-633
-            ctrl->emitted = e;
-            ctrl->nsel = nselNew;
-            ctrl->nextSid = sidBase + nLazy;
-            ctrl->nextItem = 0;
-            ctrl->nFresh = 0;
-            ctrl->nSurv = 0;
-            ctrl->nSurvBack = 0;
-            ctrl->outDone = emitted;  // (the slots emitted before this round: written above, before the barrier after B)
-            ctrl->outTicket = 0;
-            ctrl->nq = nq;
-            ctrl->head = h;
+            if (lane == 0) {
+                ctrl->emitted = e;
+                ctrl->nsel = nselNew;
+                ctrl->nextSid = sidBase + nLazy;
+                ctrl->nextItem = 0;
+                ctrl->nFresh = 0;
+                ctrl->nSurv = 0;
+                ctrl->nSurvBack = 0;
+                ctrl->outDone = emitted;  // (the slots emitted before this round: written above, before the barrier after B)
+                ctrl->outTicket = 0;
+                ctrl->nq = nq;
+                ctrl->head = h;
 #pragma unroll
-            for (int w = 0; w < MS; w++) { ctrl->selIdx[w] = (short)sIdx[w]; ctrl->selSid[w] = (unsigned short)sSid[w]; }
-            if (stop) ctrl->stop = 1;
+                for (int w = 0; w < MS; w++) { ctrl->selIdx[w] = (short)sIdx[w]; ctrl->selSid[w] = (unsigned short)sSid[w]; }
+                if (stop) ctrl->stop = 1;
+            }
         }
         if (haveNode) {
             const NodeRef nd = node_ref(smem + L.offNodes + (size_t)wave * L.nodeStride, p.maxRow);

@@ -761,43 +761,57 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
             }
         }
         wave_fence();
-        if (wave == 0 && lane == 0) {
-            // emission: the head goes out while it has been split; a head selected in THIS round (not split yet)
-            // is emitted too but ends the run, because its children are not in the pool yet
-            int e = emitted, h = 0, stop = 0, selSeen = 0;
-            while (h < nq && e < k) {
-                int sid;
-                bool fresh = false;
-                if (!(PM[h] & LN_SPLIT)) {
-                    if (selSeen >= nselNew) break;  // not split and not selected this round: wait
-                    sid = (int)ctrl->selSid[selSeen];  // selection is in pool order
-                    selSeen++;
-                    fresh = true;
-                } else {
-                    sid = (int)PS[h];
+        if (wave == 0) {
+            // emission (kBest2D cpp:607-634), all lanes of wave 0, 64 pool entries per pass: the head goes out while it has
+            // been split; the first entry that has NOT been split is the first one selected in this round (selection is in
+            // pool order): it is emitted too but ends the run, because its children are not in the pool yet.
+            int e = emitted, h = 0, stop = 0;
+            const double cdel = ctrl->cdelta, g0u = ctrl->gain0u;
+            const int sid0 = (int)ctrl->selSid[0];
+            bool more = true;
+            for (int base = 0; more && base < nq && e < k; base += 64) {
+                const int i = base + lane;
+                const bool valid = i < nq;
+                const double g = valid ? PG[i] : 0.0;
+                const u32 meta = valid ? PM[i] : 0u;
+                const int psid = valid ? (int)PS[i] : 0;
+                const double gu = maximize ? (-g + cdel) : (g + cdel);  // cpp:626-630
+                const bool cutB = useCut && valid && (maximize ? (gu < g0u - p.cutoff) : (gu > g0u + p.cutoff));
+                const u64 plainM = __ballot(valid && (meta & LN_SPLIT) && !cutB);
+                int run = (~plainM == 0ull) ? 64 : __builtin_ctzll(~plainM);  // leading entries that simply go out
+                if (run > k - e) run = k - e;
+                if (lane < run) {
+                    p.gain[outBase + e + lane] = gu;
+                    slotSid[e + lane] = (unsigned short)psid;
                 }
-                const double g = PG[h];
-                const double gu = maximize ? (-g + ctrl->cdelta) : (g + ctrl->cdelta);  // cpp:626-630
-                p.gain[outBase + e] = gu;
-                slotSid[e] = (unsigned short)sid;
-                if (useCut && (maximize ? (gu < ctrl->gain0u - p.cutoff) : (gu > ctrl->gain0u + p.cutoff))) {
-                    stop = 1;  // cpp:709-719: slot written, not counted
-                    break;
+                e += run;
+                h += run;
+                if (run == 64) continue;  // the whole pass went out: next 64 entries
+                more = false;
+                if (e >= k || base + run >= nq) break;
+                // the entry that ended the run
+                const bool tSplit = (__ballot((meta & LN_SPLIT) != 0) >> run) & 1ull, tCut = (__ballot(cutB) >> run) & 1ull;
+                if (!tSplit && nselNew == 0) break;  // not split and not selected this round: wait
+                if (lane == run) {
+                    p.gain[outBase + e] = gu;
+                    slotSid[e] = (unsigned short)(tSplit ? psid : sid0);
                 }
+                if (tCut) { stop = 1; break; }  // cpp:709-719: slot written, not counted
                 e++;
                 h++;
-                if (fresh) break;
             }
             if (e >= k) stop = 1;
             if (h >= nq && nselNew == 0) stop = 1;  // queue empty, nothing left to split: cpp:631-633
-            ctrl->emitted = e;
-            ctrl->nsel = nselNew;
-            ctrl->nextItem = 0;
-            ctrl->nFresh = 0;
-            ctrl->nComp = 0;
-            ctrl->nq = nq;
-            ctrl->head = h;
-            if (stop && ctrl->stop == 0) ctrl->stop = 1;
+            if (lane == 0) {
+                ctrl->emitted = e;
+                ctrl->nsel = nselNew;
+                ctrl->nextItem = 0;
+                ctrl->nFresh = 0;
+                ctrl->nComp = 0;
+                ctrl->nq = nq;
+                ctrl->head = h;
+                if (stop && ctrl->stop == 0) ctrl->stop = 1;
+            }
         }
         for (int j0 = wave; j0 < nselNew; j0 += 4 * NW) {  // four saved states in flight per wave
             double ldU[4], ldV[4], ldGain[4];
