@@ -377,16 +377,21 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
         // Per node: the early-termination bound on the Dijkstra distance (child gain = parent gain + delta up to rounding, so
         // delta > (T - parent gain) + margin can never enter the k best), and the round's list of children (node, column).
         // Every wave writes both itself -- identical values -- and reads only what it has written: no barrier.
+        // (lane w < nsel fetches node w's active column and gain at once; the loop over the nodes then runs on register reads,
+        //  not on a chain of dependent LDS reads)
         int totalItems = 0;
-        for (int w = 0; w < nsel; w++) {
-            const int nb = L.offNodes + w * L.nodeStride;
-            const int a = uni32(*reinterpret_cast<const int *>(smem + nb + N_A));
-            if (lane == 0) {
-                const double pgain = *reinterpret_cast<const double *>(smem + nb + N_GAIN);
-                *reinterpret_cast<double *>(smem + nb + N_BOUND) = (prune && T < INF) ? (T - pgain) + 1e-9 * (fabs(T) + cmaxv) : INF;
+        {
+            const int nbL = L.offNodes + (lane < nsel ? lane : 0) * L.nodeStride;
+            const int aL = *reinterpret_cast<const int *>(smem + nbL + N_A);
+            if (lane < nsel) {
+                const double pgain = *reinterpret_cast<const double *>(smem + nbL + N_GAIN);
+                *reinterpret_cast<double *>(smem + nbL + N_BOUND) = (prune && T < INF) ? (T - pgain) + 1e-9 * (fabs(T) + cmaxv) : INF;
             }
-            if (a + lane < M) items[totalItems + lane] = (unsigned short)((w << 6) | (a + lane));
-            totalItems += (M - a) > 0 ? (M - a) : 0;
+            for (int w = 0; w < nsel; w++) {
+                const int a = __builtin_amdgcn_readlane(aL, w);
+                if (a + lane < M) items[totalItems + lane] = (unsigned short)((w << 6) | (a + lane));
+                totalItems += (M - a) > 0 ? (M - a) : 0;
+            }
         }
         wave_fence();
         KB_T(tB0);
@@ -751,15 +756,13 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
             const int i = base + lane;
             const bool open = i < nq && !(PM[i] & LN_SPLIT);
             const int ps = (i < nq) ? (int)PS[i] : 0;
-            u64 m = __ballot(open);
-            while (m && nselNew < spec) {
-                const int bitpos = __builtin_ctzll(m);
-                // (every wave writes the same values and reads back only what it has written itself)
-                if (lane == bitpos) { ctrl->selIdx[nselNew] = (short)i; ctrl->selSid[nselNew] = (unsigned short)ps; }
-                nselNew++;
-                m &= m - 1;
-            }
+            const u64 m = __ballot(open);
+            // (every wave writes the same values and reads back only what it has written itself)
+            const int rank = nselNew + __popcll(m & ((1ull << lane) - 1ull));
+            if (open && rank < spec) { ctrl->selIdx[rank] = (short)i; ctrl->selSid[rank] = (unsigned short)ps; }
+            nselNew += __popcll(m);
         }
+        nselNew = nselNew < spec ? nselNew : spec;
         wave_fence();
         if (wave == 0) {
             // emission (kBest2D cpp:607-634), all lanes of wave 0, 64 pool entries per pass: the head goes out while it has
