@@ -470,7 +470,77 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
             // 100 landmarks x 20 measurements).  Which padded column a free row sits on is immaterial (SURVEY 8(a)
             // quirk 6); the duals are another optimal pair than the reference's, which no output depends on.
             const int nAug = (p.flags & KBEST_FLAG_EXACT_ROOT) ? D : M;
+            if (!(p.flags & KBEST_FLAG_EXACT_ROOT) && M == D) {
+                // Square problems start from a column reduction and a row reduction (as the LDS kernels, kbest_engine.hip):
+                // u[c] = min of column c, the row of that minimum goes to the lowest such column; then a row without a
+                // column takes v[r] = min over c of (C[r,c] - u[c]) and that column if it is still free (the lowest row wins).
+                // Reduced costs stay >= 0, assigned arcs are tight; the augmentations below run from the columns left over
+                // -- a quarter of them -- with half the Dijkstra steps (128x128: 518 instead of 1 049).
+                for (int c = 0; c < D; c++) {
+                    const double *col = Cw + (long long)c * D;
+                    double m = INF;
+                    int am = 0x7fffffff;
+#pragma unroll
+                    for (int i = 0; i < R; i++) {
+                        const int r = lane + 64 * i;
+                        const double x = r < D ? col[r] : INF;
+                        const bool better = x < m;  // (rows of one lane ascend: strict '<' keeps the lowest)
+                        m = better ? x : m;
+                        am = better ? r : am;
+                    }
+                    const double mm = wave_min_f64(m);
+                    if (!(mm < INF)) continue;  // (uniform) a column without a finite entry: the search below reports it
+                    const int row = wave_min_i32(m == mm ? am : 0x7fffffff);  // the lowest row among equal minima
+                    if (lane == 0) {
+                        uW[c] = mm;
+                        if (c4rW[row] < 0) { c4rW[row] = c; r4cW[c] = row; }
+                    }
+                    wave_fence();
+                }
+                double m2[R];
+                int a2[R];
+#pragma unroll
+                for (int i = 0; i < R; i++) { m2[i] = INF; a2[i] = 0; }
+                for (int c = 0; c < D; c++) {
+                    const double uc = uW[c];
+                    const double *col = Cw + (long long)c * D;
+#pragma unroll
+                    for (int i = 0; i < R; i++) {
+                        const int r = lane + 64 * i;
+                        const double d = (r < D ? col[r] : INF) - uc;
+                        const bool better = d < m2[i];  // strict '<': the lowest column among equal minima
+                        m2[i] = better ? d : m2[i];
+                        a2[i] = better ? c : a2[i];
+                    }
+                }
+                int *owner = predW;  // (free until the first augmentation)
+#pragma unroll
+                for (int i = 0; i < R; i++) {
+                    const int r = lane + 64 * i;
+                    if (r < D) owner[r] = 0x7fffffff;
+                }
+                wave_fence();
+                bool want[R];
+#pragma unroll
+                for (int i = 0; i < R; i++) {
+                    const int r = lane + 64 * i;
+                    want[i] = r < D && c4rW[r] < 0 && m2[i] < INF;
+                    if (want[i]) {
+                        v[i] = m2[i];
+                        if (r4cW[a2[i]] < 0) atomicMin(&owner[a2[i]], r);
+                        else want[i] = false;
+                    }
+                }
+                wave_fence();
+#pragma unroll
+                for (int i = 0; i < R; i++) {
+                    const int r = lane + 64 * i;
+                    if (want[i] && owner[a2[i]] == r) { c4rW[r] = a2[i]; r4cW[a2[i]] = r; }
+                }
+                wave_fence();
+            }
             for (int c = 0; c < nAug; c++) {
+                if (uni32(r4cW[c]) >= 0) continue;  // assigned by the reductions above
                 u32 scanned;
                 double delta;
                 int sink = 0;
