@@ -78,6 +78,7 @@ enum {
 #define KBEST_FLAG_NO_SHIFT 8u     /* internal (kbest_assign_batch_f64): the cost matrix is already non-negative         */
 #define KBEST_FLAG_NO_T0 32u       /* do not use the a-priori threshold from combinations of the root's children (A/B tests) */
 #define KBEST_FLAG_EXACT_ROOT 16u  /* root LAP by the reference's own sequence of augmentations (no column reduction first)  */
+#define KBEST_FLAG_NO_REORDER 128u /* 64-row kernel: enumerate in the reference's column order (A/B tests; same results)          */
 #define KBEST_FLAG_TABLES_I8 64u   /* kbest_batch_f64 / kbest_batch_f64_dev: row4col / col4row are tables of int8_t (same shapes, */
                                    /* same values, -1 = unassigned / unused) instead of int32_t: every index of a problem of up   */
                                    /* to 127 rows fits a byte, and a quarter of the bytes cross PCIe.  numRow > 127:              */

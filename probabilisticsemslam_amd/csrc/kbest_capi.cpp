@@ -44,6 +44,7 @@ struct kbest_ctx {
     bool noSplit = false;     // KBEST_NO_SPLIT: never split one matrix over several workgroups (A/B tests)
     int splitForce = 0;       // KBEST_SPLIT: workgroups per matrix (2 / 4) whenever the split is possible (A/B tests)
     DevBufRaw splitBuf;       // per-share result tables + shared thresholds of the split
+    bool noReorder = false;   // KBEST_NO_REORDER: the 64-row kernel enumerates in the reference's column order (A/B tests)
     int zcCost = 1;           // KBEST_ZC_COST=0: cost blocks in registered memory are copied up first instead of read in place (A/B tests)
     int pieces = 0;           // KBEST_PIECES: pieces of a large host-entry batch (1 / 2 / 4; A/B tests); 0 = choose
     bool noLane = false;      // KBEST_NO_LANE: no lane-per-child kernel (A/B tests)
@@ -282,6 +283,7 @@ int kbest_create(kbest_ctx **out, int device)
     ctx->noSplit = getenv("KBEST_NO_SPLIT") != nullptr;
     if (const char *e = getenv("KBEST_SPLIT")) { const int w = atoi(e); if (w == 2 || w == 4) ctx->splitForce = w; }
     if (const char *e = getenv("KBEST_ZC_COST")) ctx->zcCost = atoi(e);
+    ctx->noReorder = getenv("KBEST_NO_REORDER") != nullptr;
     if (const char *e = getenv("KBEST_PIECES")) { const int w = atoi(e); if (w == 1 || w == 2 || w == 4) ctx->pieces = w; }
     ctx->forceLane = getenv("KBEST_FORCE_LANE") != nullptr;
     if (const char *e = getenv("KBEST_LANE_NW")) { const int w = atoi(e); if (w == 1 || w == 2 || w == 4) ctx->laneNw = w; }
@@ -755,7 +757,8 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         p.k = k;
         p.maximize = opts->maximize;
         p.useCutoff = opts->use_cutoff;
-        p.flags = opts->flags | (ctx->exactRoot ? KBEST_FLAG_EXACT_ROOT : 0u) | (ctx->noT0 ? KBEST_FLAG_NO_T0 : 0u);
+        p.flags = opts->flags | (ctx->exactRoot ? KBEST_FLAG_EXACT_ROOT : 0u) | (ctx->noT0 ? KBEST_FLAG_NO_T0 : 0u) |
+                  (ctx->noReorder ? KBEST_FLAG_NO_REORDER : 0u);
         p.cutoff = opts->cutoff;
         p.rootColOffset = opts->root_col_offset;
         p.rootColStride = opts->root_col_stride;

@@ -91,7 +91,7 @@ __host__ __device__ inline long long slot_table_stride(int k) { return (((long l
 
 // LDS carve-up of one workgroup (= one cost matrix).
 struct Lds {
-    int offC, offNodes, nodeStride, offFreshG, offFreshM, offPoolG, offPoolM, offPoolS, offSurv, offFreshS, offRootMap, offCtrl, offGainW, total;
+    int offC, offNodes, nodeStride, offFreshG, offFreshM, offPoolG, offPoolM, offPoolS, offSurv, offFreshS, offRootMap, offPerm, offCtrl, offGainW, total;
 };
 
 __host__ __device__ inline Lds lds_layout(int maxRow, int k, int spec, int nWaves)
@@ -111,6 +111,8 @@ __host__ __device__ inline Lds lds_layout(int maxRow, int k, int spec, int nWave
     L.offSurv = o;       o += spec * 64 * 2;         // children that passed the filter: (last-arc bound / 7 bits, node, column)
     L.offFreshS = o;     o += spec * 64 * 2;         //   own state slot of the surviving children
     L.offRootMap = o;    o += maxRow;                // the optimum's col4row (u8): atoms of the a-priori threshold
+    o = (o + 3) & ~3;
+    L.offPerm = o;       o += 128;                   // column order of the enumeration: original column of a position, and back
     o = (o + 7) & ~7;
     L.offCtrl = o;       o += 232;                   // struct Ctrl
     o = (o + 15) & ~15;

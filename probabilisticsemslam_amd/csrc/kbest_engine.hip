@@ -336,6 +336,8 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     u64 *lbKey = reinterpret_cast<u64 *>(smem + L.offFreshG);
     unsigned short *freshS = reinterpret_cast<unsigned short *>(smem + L.offFreshS);
     Ctrl *ctrl = reinterpret_cast<Ctrl *>(smem + L.offCtrl);
+    // column order of the enumeration (phase 1b): colOf[position] = the reference's column, posOf = its inverse
+    unsigned char *colOf = smem + L.offPerm, *posOf = colOf + 64;
     double *gainW = reinterpret_cast<double *>(smem + L.offGainW) + wave * 64;  // this wave's line of gain terms
 
     const double *Cg = p.cost + (p.costOff ? p.costOff[b] : (long long)b * p.ldRow * p.ldCol);
@@ -363,7 +365,9 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
 #endif
 
     // ---- phase 0: makeCostMatrixSafe + zero padding (cpp:534-569, 582-585) --
+    double cdelTile = 0.0;  // the shift of the tile (kept for phase 1b, which loads the columns again in another order)
     {
+        if (tid < 64) { colOf[tid] = (unsigned char)tid; posOf[tid] = (unsigned char)tid; }
         double mn = INF;  // min of C, or min of -C when maximising (max C = -min(-C), exact)
         for (int c = wave; c < M; c += NW)
             for (int r = lane; r < N; r += 64) {
@@ -377,6 +381,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         mn = red[0];
         for (int w = 1; w < NW; w++) mn = min_keep(mn, red[w]);
         const double cdel = noShift ? 0.0 : (maximize ? -mn : mn);
+        cdelTile = cdel;
         __syncthreads();
         double cm = 0.0;
         for (int c = wave; c < D; c += NW)
@@ -615,6 +620,80 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         return;
     }
 
+    // ---- phase 1b: the column order of the enumeration -------------------------------------------------------------
+    // Murty's partition (split, cpp:455-532) lets the child on column c keep the parent's rows on the columns BEFORE c.  The
+    // k best assignments are the optimum with a few cheap changes; where those columns stand in the order decides how much
+    // of a child is already fixed when it is searched.  With the columns that are DEAR to change first and the cheap ones
+    // last, the children that carry the k best have nearly everything fixed (short searches, few candidate rows), and the
+    // children on the dear columns die at the bound.  The order changes the tree, not the set of the k best nor their gains
+    // -- those are sums over the reference's column order (serial_gain's `orig`), and the tables go out in that order too.
+    // The key of column c: the exact cost of taking its row away from it with nothing else fixed (one search from the
+    // root's duals, the waves share the columns).  Measured on the host first (tests/dev/colorder_probe.py, columns permuted
+    // before the call): 1 024 x 64x64, k = 200 2.50 ms as given, 2.09 by a two-arc lower bound, 1.70 by this key; 4 096 x
+    // 32x32 4.87 / 4.29 / 3.63.  Not where the reference's own order is part of the answer (push counts, unpruned mode, the
+    // exact-root mode, the assign2D entries) and not in split launches.
+    const bool reorder = !rect && prune && S == 1 && M >= 3 && k >= 3 &&
+                         !(p.flags & (KBEST_FLAG_EXACT_ROOT | KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_REORDER));
+    if (reorder) {
+        double *key = reinterpret_cast<double *>(lbKey);  // (the filter's minima are re-armed below)
+        const NodeRef nd0 = node_ref(smem + L.offNodes, p.maxRow);
+        {
+            const double v0 = (lane < D) ? nd0.v[lane] : 0.0;
+            const int c4r0 = (lane < D) ? (int)nd0.c4r[lane] : -1;
+            const int r4c0 = (lane < D) ? (int)nd0.r4c[lane] : -1;
+#pragma unroll 1
+            for (int c = wave; c < M; c += NW) {
+                const int fr = __builtin_amdgcn_readlane(r4c0, c);
+                const int c4r = (lane == fr) ? -1 : c4r0;
+                double spc, delta;
+                int pred, sink = 0;
+                u64 scanned;
+                const int st = dijkstra<false>(Cs, LDC, nd0.u, rl, lane, v0, c4r, allRows, bit64(fr), c, INF, spc, pred, scanned,
+                                               delta, sink, 0.0, 0, parkFrom);
+                if (lane == 0) key[c] = (st == 0) ? delta : INF;
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // positions by descending key, equal keys by column (deterministic)
+            const double kl = key[lane < M ? lane : 0];
+            int rank = 0;
+            for (int j = 0; j < M; j++) {
+                const double kj = readlane_f64(kl, j);
+                rank += (kj > kl || (kj == kl && j < lane)) ? 1 : 0;
+            }
+            if (lane < M) { posOf[lane] = (unsigned char)rank; colOf[rank] = (unsigned char)lane; }
+            wave_fence();
+            // the root in that order: u and row4col by position, col4row's values are positions, v as it is
+            const int oc = (lane < M) ? (int)colOf[lane] : lane;
+            const double uN = (lane < D) ? nd0.u[oc] : 0.0;
+            const int r4cN = (lane < D) ? (int)nd0.r4c[oc] : -1;
+            const int cOld = (lane < D) ? (int)nd0.c4r[lane] : -1;
+            const int c4rN = (cOld >= 0 && cOld < M) ? (int)posOf[cOld] : cOld;
+            const double vN = (lane < D) ? nd0.v[lane] : 0.0;
+            const double g = nd0.gain[0];
+            wave_fence();
+            if (lane < D) nd0.u[lane] = uN;
+            wave_fence();
+            const u64 forb = bit64(__builtin_amdgcn_readlane(r4cN, 0));  // cpp:235: the row of the FIRST column of the order
+            save_node(nd0, 0, vN, r4cN, c4rN, forb, g, 0);
+            if (t0On && lane < D) rootMap[lane] = (unsigned char)c4rN;
+        }
+        __syncthreads();
+        // the tile's real columns again, in the new order (the block is L2-resident)
+        for (int c = wave; c < M; c += NW) {
+            const int oc = colOf[c];
+            for (int r = lane; r < N; r += 64) {
+                const double x = Cg[r + (long long)oc * N];
+                double val = noShift ? x : (maximize ? (-x + cdelTile) : (x - cdelTile));  // cpp:558 / cpp:564
+                if (val != val) val = INF;
+                Cs[r + c * LDC] = val;
+            }
+        }
+        for (int i = tid; i < spec * 64; i += NT) lbKey[i] = ~0ull;  // re-arm the filter minima (the keys lay there)
+        __syncthreads();
+    }
+
     KB_ACC(0, __builtin_readcyclecounter() - profT0);  // [0] set-up + root solve
     // ---- phase 2: rounds ----------------------------------------------------------------------------
     for (int roundNo = 0; uni32(ctrl->stop) == 0; roundNo++) {
@@ -850,10 +929,11 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 const int sOut = outDone + uni32(t);
                 if (sOut >= emitted) break;
                 const unsigned char *st = stBase + (long long)slotSid[sOut] * p.stateStride;
-                if (lane < M) put_index(p.row4col, (outBase + sOut) * p.ldCol + lane, st[offR4C + lane], tabI8);
+                // (the states are in the enumeration's column order: the tables in the reference's)
+                if (lane < M) put_index(p.row4col, (outBase + sOut) * p.ldCol + colOf[lane], st[offR4C + lane], tabI8);
                 if (p.col4row && lane < N) {
                     const int cv = st[offC4R + lane];
-                    put_index(p.col4row, (outBase + sOut) * p.ldRow + lane, (rect && cv == 255) ? -1 : cv, tabI8);  // unassigned row (cpp:134)
+                    put_index(p.col4row, (outBase + sOut) * p.ldRow + lane, (rect && cv == 255) ? -1 : (cv < M ? (int)colOf[cv] : cv), tabI8);  // unassigned row (cpp:134)
                 }
             }
         }
@@ -927,7 +1007,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                         r = nxt;
                     } while (cc != c && ++guard < 64);
                 }
-                const double g = serial_gain(Cs, LDC, lane, r4c, M, gainW);
+                const double g = serial_gain(Cs, LDC, lane, r4c, M, gainW, colOf);
                 if (useCut && (maximize ? (g < cutG) : (g > cutG))) continue;  // cutHyp, cpp:496/521
                 npush++;
                 if (t1On && roundNo == 1) {
@@ -1235,7 +1315,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 const int rc = dijkstra<false>(Cs, LDC, nd.u, rl, lane, v, c4r, cand, forbm, col, INF, spc, pred, scanned,
                                                delta, sink, 0.0, 0, parkFrom);
                 if (rc == 0) dual_update_flip(nd.u, lane, v, c4r, r4c, spc, pred, scanned, delta, sink, col);
-                const double g = serial_gain(Cs, LDC, lane, r4c, M, gainW);
+                const double g = serial_gain(Cs, LDC, lane, r4c, M, gainW, colOf);
                 const u64 forbN = forbm | bit64(__builtin_amdgcn_readlane(r4c, col));  // cpp:362
                 save_node(nd, mySid, v, r4c, c4r, forbN, g, col);
                 if (lane == 0 && rc != 0) ctrl->stop = 2;  // cannot happen: the candidate was solved before
@@ -1254,10 +1334,10 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     for (int idx = tid + outDoneEnd * (N + M); idx < nf * (N + M); idx += NT) {
         const int s = idx / (N + M), j = idx - s * (N + M);
         const unsigned char *st = stBase + (long long)slotSid[s] * p.stateStride;
-        if (j < M) put_index(p.row4col, (outBase + s) * p.ldCol + j, st[offR4C + j], tabI8);
+        if (j < M) put_index(p.row4col, (outBase + s) * p.ldCol + colOf[j], st[offR4C + j], tabI8);
         else if (p.col4row) {
             const int cv = st[offC4R + (j - M)];
-            put_index(p.col4row, (outBase + s) * p.ldRow + (j - M), (rect && cv == 255) ? -1 : cv, tabI8);  // unassigned row (cpp:134)
+            put_index(p.col4row, (outBase + s) * p.ldRow + (j - M), (rect && cv == 255) ? -1 : (cv < M ? (int)colOf[cv] : cv), tabI8);  // unassigned row (cpp:134)
         }
     }
     if (tid == 0) {

@@ -242,11 +242,15 @@ __device__ __forceinline__ void dual_update_flip(double *u, int lane, double &v,
 // column's term and parks it in the wave's LDS scratch line; the chain of adds then reads the terms back as
 // broadcast 16-byte reads (two terms per LDS instruction, no lane reads on the vector unit), in the reference's
 // order.  Lanes >= M contribute +0.0, and x + 0.0 == x exactly for the non-negative partial sums here.
-__device__ __forceinline__ double serial_gain(const double *Cs, int LDC, int lane, int r4c, int M, double *scratch)
+// `orig` (64-row kernel with a column order of its own, kbest_engine.hip): lane is a POSITION in that order and
+// orig[lane] the reference's column index -- the terms are parked at their reference index, so the chain adds them in the
+// reference's order whatever order the enumeration works in.
+__device__ __forceinline__ double serial_gain(const double *Cs, int LDC, int lane, int r4c, int M, double *scratch,
+                                              const unsigned char *orig = nullptr)
 {
     double t = 0.0;
     if (lane < M) t = Cs[r4c + lane * LDC];
-    scratch[lane] = t;
+    scratch[orig ? (int)orig[lane] : lane] = t;
     wave_fence();
     double acc = 0.0;
     const double2 *terms = reinterpret_cast<const double2 *>(scratch);

@@ -13,6 +13,7 @@ cfg = sys.argv[1]
 B, N, M, k, seed = wl.DENSE_CONFIGS[cfg]
 costs = wl.dense_batch(B, N, M, seed)            # (B, N*M) column-major blocks: C[r + c*N]
 eng = pk.KBestEngine(0)
+ts = torch.cuda.Stream(device=dev); torch.cuda.set_stream(ts); S = ts.cuda_stream
 ok, r4c, c4r, g, u, v = eng.assign(costs, N, M, shift=False)
 C = costs.reshape(B, M, N)                        # [b, c, r]
 rc = C - u[:, :, None] - v[:, None, :]            # reduced costs [b, c, r]
@@ -20,24 +21,48 @@ own = np.zeros_like(rc, dtype=bool)
 bi, ci = np.meshgrid(np.arange(B), np.arange(M), indexing="ij")
 own[bi, ci, r4c] = True
 m = np.where(own, np.inf, rc).min(axis=2)         # [b, c]: cheapest other row of column c
+fr = r4c                                           # [b, c] row of column c
+rin = np.take_along_axis(rc, fr[:, None, :].repeat(M, axis=1), axis=2) if False else None
+# last arc into the freed row fr = r4c[c] from any other column j: rc[b, j, fr[b, c]]
+rcT = np.transpose(rc, (0, 2, 1))                 # [b, r, j]
+into = np.take_along_axis(rcT, fr[:, :, None].repeat(M, axis=2), axis=1)  # [b, c, j] = rc[b, j, fr[b,c]]
+into[bi, ci, ci] = np.inf
+min_in = np.clip(into.min(axis=2), 0, None)       # [b, c]
+exact = None
+if os.environ.get("PROBE_EXACT"):
+    from scipy.optimize import linear_sum_assignment
+    nb = min(B, int(os.environ.get("PROBE_EXACT")))
+    exact = m + min_in
+    exact = exact.copy()
+    for b in range(nb):
+        Cb = C[b].T.copy()   # [r, c]
+        base = Cb[r4c[b], np.arange(M)].sum()
+        for c in range(M):
+            r = r4c[b, c]; old = Cb[r, c]; Cb[r, c] = 1e9
+            ri, cj = linear_sum_assignment(Cb)
+            exact[b, c] = Cb[ri, cj].sum() - base
+            Cb[r, c] = old
 def run(perm_kind):
     if perm_kind == "none": P = np.tile(np.arange(M), (B, 1))
     elif perm_kind == "dear_first": P = np.argsort(-m, axis=1, kind="stable")
     elif perm_kind == "cheap_first": P = np.argsort(m, axis=1, kind="stable")
+    elif perm_kind == "exact_first": P = np.argsort(-exact, axis=1, kind="stable")
+    elif perm_kind == "dear2_first": P = np.argsort(-(m + min_in), axis=1, kind="stable")
+    elif perm_kind == "dearmax_first": P = np.argsort(-np.maximum(m, min_in), axis=1, kind="stable")
     Cp = np.take_along_axis(C, P[:, :, None], axis=1)
     d_cost = torch.from_numpy(np.ascontiguousarray(Cp.reshape(B, N * M))).to(dev)
     o = (torch.empty((B, k, M), dtype=torch.int32, device=dev), torch.empty((B, k, N), dtype=torch.int32, device=dev),
          torch.empty((B, k), dtype=torch.float64, device=dev), torch.empty(B, dtype=torch.int32, device=dev))
     eng.reserve(B, N, k)
-    eng.kbest_dev(d_cost, B, N, M, k, *o); torch.cuda.synchronize()
+    eng.kbest_dev(d_cost, B, N, M, k, *o, stream=S); torch.cuda.synchronize()
     best = 1e9
     for _ in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(5): eng.kbest_dev(d_cost, B, N, M, k, *o)
+        for _ in range(5): eng.kbest_dev(d_cost, B, N, M, k, *o, stream=S)
         e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / 5)
     return best, o[2].sum().item()
-for kind in ("none", "dear_first", "cheap_first", "none"):
+for kind in (("none", "dear2_first", "exact_first", "none") if exact is not None else ("none", "dear_first", "dear2_first", "dearmax_first", "none")):
     t, gs = run(kind)
     print(f"{cfg} columns {kind:12s}: {t:.3f} ms   (sum of gains {gs:.6f})", flush=True)
