@@ -670,7 +670,7 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         p.k = k;
         p.maximize = opts->maximize;
         p.useCutoff = opts->use_cutoff;
-        p.flags = opts->flags;
+        p.flags = opts->flags | (ctx->noReorder ? KBEST_FLAG_NO_REORDER : 0u);
         p.cutoff = opts->cutoff;
         p.rootColOffset = opts->root_col_offset;
         p.rootColStride = opts->root_col_stride;

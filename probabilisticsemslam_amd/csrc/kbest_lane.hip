@@ -170,6 +170,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
 #endif
 
     // ---- phase 0: makeCostMatrixSafe + zero padding (cpp:534-569, 582-585) --
+    double cdelTile = 0.0;  // the tile's shift (phase 1b loads the columns again in another order)
     {
         double mn = INF;  // min of C, or min of -C when maximising (max C = -min(-C), exact)
         for (int c = wave; c < M; c += NW)
@@ -184,6 +185,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
         mn = red[0];
         for (int w = 1; w < NW; w++) mn = min_keep(mn, red[w]);
         const double cdel = maximize ? -mn : mn;
+        cdelTile = cdel;
         __syncthreads();
         double cm = 0.0;
         for (int c = wave; c < D; c += NW)
@@ -379,6 +381,69 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
     if (uni32(ctrl->stop) == 3) {  // infeasible: kBest2D returns 0 (cpp:588-593)
         if (tid == 0) { p.nf[b] = 0; if (p.pushed) p.pushed[b] = 0; }
         return;
+    }
+    // ---- phase 1b: the column order of the enumeration (as in the 64-row kernel, kbest_engine.hip) --------------------
+    // The columns that are dear to change go first, the cheap ones last: the children that carry the k best then have nearly
+    // everything fixed.  Key of column c: the exact cost of taking its row away with nothing else fixed -- one search from the
+    // root's duals per column, the waves share them.  Gains are still summed in the reference's column order and the tables
+    // written in it.  colOf[position] = the reference's column, posOf = its inverse (in the root's scratch line, free now).
+    unsigned char *colOf = reinterpret_cast<unsigned char *>(gainW), *posOf = colOf + 64;
+    if (tid < 64) { colOf[tid] = (unsigned char)tid; posOf[tid] = (unsigned char)tid; }
+    __syncthreads();
+    const bool reorder = prune && M >= 3 && k >= 3 && !(p.flags & (KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_REORDER));
+    if (reorder) {
+        double *key = freshG;
+        const int nb0 = L.offNodes;
+        double *u0 = reinterpret_cast<double *>(smem + nb0);
+        {
+            const double v0 = (lane < D) ? *reinterpret_cast<const double *>(smem + nb0 + N_V + 8 * lane) : 0.0;
+            const int c4r0 = (lane < D) ? (int)smem[nb0 + N_C4R + lane] : -1;
+            const int r4c0 = (lane < D) ? (int)smem[nb0 + N_R4C + lane] : -1;
+#pragma unroll 1
+            for (int c = wave; c < M; c += NW) {
+                const int fr = __builtin_amdgcn_readlane(r4c0, c);
+                const int c4r = (lane == fr) ? -1 : c4r0;
+                double spc, delta;
+                int pred, sink = 0;
+                u64 scanned;
+                const int st = dijkstra<false>(Cs, LDC, u0, rl, lane, v0, c4r, allRows, 1ull << fr, c, INF, spc, pred, scanned, delta, sink);
+                if (lane == 0) key[c] = (st == 0) ? delta : INF;
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const double kl = key[lane < M ? lane : 0];
+            int rank = 0;
+            for (int j = 0; j < M; j++) {  // positions by descending key, equal keys by column
+                const double kj = readlane_f64(kl, j);
+                rank += (kj > kl || (kj == kl && j < lane)) ? 1 : 0;
+            }
+            if (lane < M) { posOf[lane] = (unsigned char)rank; colOf[rank] = (unsigned char)lane; }
+            wave_fence();
+            // the root in that order: u and row4col by position, col4row's values are positions, v as it is
+            const int oc = (lane < M) ? (int)colOf[lane] : lane;
+            const double uN = (lane < D) ? u0[oc] : 0.0;
+            const int r4cN = (lane < D) ? (int)smem[nb0 + N_R4C + oc] : 0;
+            const int cOld = (lane < D) ? (int)smem[nb0 + N_C4R + lane] : 0;
+            const int c4rN = (cOld < M) ? (int)posOf[cOld] : cOld;
+            const double vN = (lane < D) ? *reinterpret_cast<const double *>(smem + nb0 + N_V + 8 * lane) : 0.0;
+            const double g = *reinterpret_cast<const double *>(smem + nb0 + N_GAIN);
+            wave_fence();
+            const u32 forb = 1u << (__builtin_amdgcn_readlane(r4cN, 0) & 31);  // cpp:235: the row of the FIRST column of the order
+            store_state(0, uN, vN, r4cN, c4rN, (u64)forb, g, 0);
+            fill_node(nb0, uN, vN, r4cN, c4rN, forb, g, 0, 0);
+        }
+        __syncthreads();
+        for (int c = wave; c < M; c += NW) {  // the tile's real columns again, in the new order
+            const int oc = colOf[c];
+            for (int r = lane; r < N; r += 64) {
+                const double x = Cg[r + (long long)oc * N];
+                double val = maximize ? (-x + cdelTile) : (x - cdelTile);  // cpp:558 / cpp:564
+                if (val != val) val = INF;
+                Cs[r + c * LDC] = val;
+            }
+        }
+        __syncthreads();
     }
     KB_ACC(0, __builtin_readcyclecounter() - profT0);  // [0] set-up + root solve
 
@@ -644,10 +709,13 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
                     if (j0 < M) {
                         int rows[8];
                         double term[8];
+                        int posj[8];  // position of the reference's column j0 + i in the enumeration's order
 #pragma unroll
-                        for (int i = 0; i < 8; i++) rows[i] = (mine && j0 + i < M) ? (int)smem[sb + j0 + i] : 0;
+                        for (int i = 0; i < 8; i++) posj[i] = (j0 + i < M) ? (int)posOf[j0 + i] : 0;
 #pragma unroll
-                        for (int i = 0; i < 8; i++) term[i] = *reinterpret_cast<const double *>(smem + L.offC + (rows[i] + (j0 + i < M ? j0 + i : 0) * LDC) * 8);
+                        for (int i = 0; i < 8; i++) rows[i] = (mine && j0 + i < M) ? (int)smem[sb + posj[i]] : 0;
+#pragma unroll
+                        for (int i = 0; i < 8; i++) term[i] = *reinterpret_cast<const double *>(smem + L.offC + (rows[i] + posj[i] * LDC) * 8);
 #pragma unroll
                         for (int i = 0; i < 8; i++) g = (j0 + i < M) ? g + term[i] : g;
                     }
@@ -889,8 +957,12 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
     for (int idx = tid; idx < nf * (N + M); idx += NT) {
         const int s = idx / (N + M), j = idx - s * (N + M);
         const unsigned char *st = stBase + (long long)slotSid[s] * p.stateStride;
-        if (j < M) put_index(p.row4col, (outBase + s) * p.ldCol + j, st[S_R4C + j], tabI8);
-        else if (p.col4row) put_index(p.col4row, (outBase + s) * p.ldRow + (j - M), st[S_C4R + (j - M)], tabI8);
+        // (the states are in the enumeration's column order: the tables in the reference's)
+        if (j < M) put_index(p.row4col, (outBase + s) * p.ldCol + colOf[j], st[S_R4C + j], tabI8);
+        else if (p.col4row) {
+            const int cv = st[S_C4R + (j - M)];
+            put_index(p.col4row, (outBase + s) * p.ldRow + (j - M), cv < M ? (int)colOf[cv] : cv, tabI8);
+        }
     }
     if (tid == 0) {
         p.nf[b] = nf;
