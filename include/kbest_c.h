@@ -138,7 +138,7 @@ int kbest_batch_f64_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRo
  * there by the kernels themselves, spread over the whole run, and nothing is left to copy when the last problem ends;
  * cost blocks in registered memory are read in place by the kernels (each block once, into its LDS tile) when the result
  * tables are registered too.  (1 024 x 64x64, k = 200, 107 MB of tables: the copying path takes ~4.3 ms per call, the
- * registered one 3.14, with KBEST_FLAG_TABLES_I8 2.82, the kernel alone 2.5.)
+ * registered one 3.14, with KBEST_FLAG_TABLES_I8 2.27, the kernel alone 1.8.)
  */
 int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, int maxCol,
                     const int32_t *nRow, const int32_t *nCol, const double *cost,
