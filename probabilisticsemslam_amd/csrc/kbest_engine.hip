@@ -635,9 +635,47 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     const bool reorder = !rect && prune && S == 1 && M >= 3 && k >= 3 &&
                          !(p.flags & (KBEST_FLAG_EXACT_ROOT | KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_REORDER));
     if (reorder) {
-        double *key = reinterpret_cast<double *>(lbKey);  // (the filter's minima are re-armed below)
+        double *key = reinterpret_cast<double *>(smem + L.offGainW);  // (wave 0's line of gain terms: free between the root and round 0)
         const NodeRef nd0 = node_ref(smem + L.offNodes, p.maxRow);
-        {
+        // All the keys at once: in the graph whose nodes are the columns and whose arc j -> j' costs what column j pays for the
+        // row that j' holds (its reduced cost, >= 0), the key of column c is the shortest cycle through c -- the diagonal of the
+        // all-pairs closure with an empty diagonal to start from.  Floyd-Warshall in fp32 (the keys only ORDER the columns; any
+        // order gives the same results), the matrix in the LDS of the node blocks and lists that round 0 has not touched yet:
+        // D barriers and D^3 / threads min-plus steps instead of D searches of ~30 Dijkstra steps (64x64: 38 000 cycles
+        // against 175 000).  Shapes whose matrix does not fit there run the searches.
+        constexpr int FW_EPT = 8;
+        const int fwBytes = L.offRootMap - (L.offNodes + L.nodeStride);
+        const bool fw = D * D * 4 <= fwBytes && D * D <= FW_EPT * NT;
+        if (fw) {
+            float *dm = reinterpret_cast<float *>(smem + L.offNodes + L.nodeStride);
+            int ei[FW_EPT], ej[FW_EPT];
+            float dv[FW_EPT];
+#pragma unroll
+            for (int q = 0; q < FW_EPT; q++) {
+                const int e = tid + q * NT;
+                const bool ok = e < D * D;
+                const int i = ok ? e / D : 0, j = ok ? e - (e / D) * D : 0;
+                ei[q] = ok ? i : -1;
+                ej[q] = j;
+                const int row = nd0.r4c[j];
+                double w = (Cs[row + i * LDC] - nd0.u[i]) - nd0.v[row];
+                w = w < 0.0 ? 0.0 : w;
+                dv[q] = (i == j) ? __int_as_float(0x7f800000) : (float)w;
+                if (ok) dm[e] = dv[q];
+            }
+            for (int kk = 0; kk < D; kk++) {
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < FW_EPT; q++)
+                    if (ei[q] >= 0) {
+                        const float t = dm[ei[q] * D + kk] + dm[kk * D + ej[q]];
+                        if (t < dv[q]) { dv[q] = t; dm[ei[q] * D + ej[q]] = t; }
+                    }
+            }
+#pragma unroll
+            for (int q = 0; q < FW_EPT; q++)
+                if (ei[q] >= 0 && ei[q] == ej[q] && ei[q] < M) key[ei[q]] = (double)dv[q];
+        } else {
             const double v0 = (lane < D) ? nd0.v[lane] : 0.0;
             const int c4r0 = (lane < D) ? (int)nd0.c4r[lane] : -1;
             const int r4c0 = (lane < D) ? (int)nd0.r4c[lane] : -1;
@@ -690,7 +728,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 Cs[r + c * LDC] = val;
             }
         }
-        for (int i = tid; i < spec * 64; i += NT) lbKey[i] = ~0ull;  // re-arm the filter minima (the keys lay there)
+        for (int i = tid; i < spec * 64; i += NT) { lbKey[i] = ~0ull; lbIn[i] = ~0u; }  // re-arm the filter minima (the key matrix lay there)
         __syncthreads();
     }
 

@@ -47,6 +47,11 @@ def run(perm_kind):
     elif perm_kind == "dear_first": P = np.argsort(-m, axis=1, kind="stable")
     elif perm_kind == "cheap_first": P = np.argsort(m, axis=1, kind="stable")
     elif perm_kind == "exact_first": P = np.argsort(-exact, axis=1, kind="stable")
+    elif perm_kind.startswith("clip"):   # exact keys only up to the sum of the m cheapest: beyond it, order by the two-arc bound
+        mm = int(perm_kind[4:])
+        bnd = np.sort(exact, axis=1)[:, :mm].sum(axis=1, keepdims=True)
+        keyc = np.where(exact <= bnd, exact, bnd + (m + min_in))
+        P = np.argsort(-keyc, axis=1, kind="stable")
     elif perm_kind == "dear2_first": P = np.argsort(-(m + min_in), axis=1, kind="stable")
     elif perm_kind == "dearmax_first": P = np.argsort(-np.maximum(m, min_in), axis=1, kind="stable")
     Cp = np.take_along_axis(C, P[:, :, None], axis=1)
@@ -63,6 +68,6 @@ def run(perm_kind):
         e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / 5)
     return best, o[2].sum().item()
-for kind in (("none", "dear2_first", "exact_first", "none") if exact is not None else ("none", "dear_first", "dear2_first", "dearmax_first", "none")):
+for kind in (("exact_first", "clip4", "clip6", "clip8", "clip12", "exact_first") if exact is not None else ("none", "dear_first", "dear2_first", "dearmax_first", "none")):
     t, gs = run(kind)
     print(f"{cfg} columns {kind:12s}: {t:.3f} ms   (sum of gains {gs:.6f})", flush=True)
