@@ -197,7 +197,7 @@ __host__ __device__ inline int wide_atom_slots(int maxRow, int maxCol)
     return (int)((bytes + wide_state_stride(maxRow) - 1) / wide_state_stride(maxRow));
 }
 
-struct WideLds { int offWave, waveStride, offNode, nodeStride, offChildG, offChildS, offChildC, offSample, offRed, offCtrl, offTile, total; };
+struct WideLds { int offWave, waveStride, offNode, nodeStride, offChildG, offChildS, offChildC, offSample, offRed, offCtrl, offPerm, offTile, total; };
 
 // tile: keep the shifted square cost copy in LDS instead of the HBM work space (when maxRow^2 * 8 bytes fit)
 // hypotheses split per round by the general-size kernel.  Measured (kernel ms at 1 / 2 / 4 / 8 per round).  Eight waves
@@ -247,6 +247,7 @@ __host__ __device__ inline WideLds wide_lds_layout(int maxRow, int maxCol, bool 
     L.offSample = o;     o += WIDE_SAMPLES * 8;
     L.offRed = o;        o += nw * 8;
     L.offCtrl = o;       o += WIDE_CTRL_BYTES;      // struct WideCtrl
+    L.offPerm = o;       o += 4 * maxRow;           // column order of the enumeration: original column of a position, and back (u16)
     o = (o + 15) & ~15;
     L.offTile = o;       if (tile) o += maxRow * maxRow * 8;
     L.total = (o + 15) & ~15;

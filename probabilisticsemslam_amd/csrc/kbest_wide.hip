@@ -191,7 +191,11 @@ __device__ __forceinline__ void wide_update(double *uW, int *c4rW, int *r4cW, in
 
 // calcGain (cpp:59-80): serial left-to-right sum over the M real columns, from 0.0
 template <int R>
-__device__ __forceinline__ double wide_gain(const double *Cw, int D, int M, const int *r4cW, int lane)
+// `posOf` (the enumeration runs in a column order of its own, phase 1b): the maps and the cost copy are indexed by POSITION,
+// posOf[c] is the position of the reference's column c -- the terms are fetched per reference column, so the chain adds them
+// in the reference's order.
+__device__ __forceinline__ double wide_gain(const double *Cw, int D, int M, const int *r4cW, int lane,
+                                            const unsigned short *posOf = nullptr)
 {
     double acc = 0.0;
 #pragma unroll
@@ -199,7 +203,10 @@ __device__ __forceinline__ double wide_gain(const double *Cw, int D, int M, cons
         if (64 * i < M) {
             const int c = lane + 64 * i;
             double t = 0.0;  // columns >= M add +0.0: exact for the non-negative partial sums
-            if (c < M) t = Cw[r4cW[c] + (long long)c * D];
+            if (c < M) {
+                const int pc = posOf ? (int)posOf[c] : c;
+                t = Cw[r4cW[pc] + (long long)pc * D];
+            }
             const int tlo = __double2loint(t), thi = __double2hiint(t);
             for (int j0 = 0; j0 < 64 && 64 * i + j0 < M; j0 += 8) {
                 double term[8];
@@ -385,6 +392,9 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
 #endif
 
         // ---- phase 0: makeCostMatrixSafe + zero padding (cpp:534-569, 582-585) ----
+        double cdelW = 0.0;  // the shift of the cost copy (phase 1b writes its columns again in another order)
+        unsigned short *colOf = reinterpret_cast<unsigned short *>(smem + L.offPerm), *posOf = colOf + p.maxRow;
+        for (int i = tid; i < D; i += NT) { colOf[i] = (unsigned short)i; posOf[i] = (unsigned short)i; }
         {
             double mn = INF;
             for (int i = tid; i < N * M; i += NT) {
@@ -398,6 +408,7 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
             mn = red[0];
             for (int w = 1; w < NWV; w++) mn = min_keep(mn, red[w]);
             const double cdel = maximize ? -mn : mn;
+            cdelW = cdel;
             __syncthreads();
             double cm = 0.0;
             for (int i = tid; i < D * D; i += NT) {
@@ -569,7 +580,7 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
             if (bad) {
                 if (lane == 0) ctrl->stop = 3;
             } else {
-                const double g = wide_gain<R>(Cw, D, M, r4cW, lane);
+                const double g = wide_gain<R>(Cw, D, M, r4cW, lane);  // (the root: before phase 1b, the reference's order)
                 const int r0 = uni32(r4cW[0]);
                 const u32 forb = (lane == (r0 & 63)) ? (1u << (r0 >> 6)) : 0u;  // cpp:235
                 store_state(0, v, forb, g, 0);
@@ -588,6 +599,84 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
         if (uni32(ctrl->stop) == 3) {  // infeasible: kBest2D returns 0 (cpp:588-593)
             if (tid == 0) { p.nf[b] = 0; if (p.pushed) p.pushed[b] = 0; }
             continue;
+        }
+
+        // ---- phase 1b: the column order of the enumeration (point 8; as in kbest_engine.hip) ----------
+        // Columns that are dear to change first, cheap ones last; key = the exact cost of taking a column's row away with nothing
+        // else fixed (one search per column from the root's duals; every wave brings the root into its own working set).  The
+        // gains are still summed and the tables written in the reference's column order (posOf / colOf).
+        if (prune && M >= 3 && k >= 3 && !(p.flags & (KBEST_FLAG_EXACT_ROOT | KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_REORDER))) {
+            double v[R];
+            u32 all = 0;
+            {
+                const unsigned char *st0 = stBase;
+                const double *su = reinterpret_cast<const double *>(st0), *sv = reinterpret_cast<const double *>(st0 + offV);
+                const int *sr = reinterpret_cast<const int *>(st0 + offR4C), *sc = reinterpret_cast<const int *>(st0 + offC4R);
+#pragma unroll
+                for (int i = 0; i < R; i++) {
+                    const int r = lane + 64 * i;
+                    v[i] = 0.0;
+                    if (r < D) { uW[r] = su[r]; v[i] = sv[r]; r4cW[r] = sr[r]; c4rW[r] = sc[r]; all |= 1u << i; }
+                }
+            }
+            wave_fence();
+            double *key = childG;  // (M doubles: the children's gain list, empty before round 0)
+#pragma unroll 1
+            for (int c = wave; c < M; c += NWV) {
+                const int fr = uni32(r4cW[c]);
+                const u32 frBit = (lane == (fr & 63)) ? (1u << (fr >> 6)) : 0u;
+                double spc[R], delta;
+                int pred[R], sink = 0;
+                u32 scanned;
+                const int dj = wide_dijkstra<R, false>(Cw, D, uW, c4rW, lane, v, all, frBit, c, INF, spc, pred, scanned, delta, sink, M, nullptr, fr);
+                if (lane == 0) key[c] = dj ? INF : delta;
+            }
+            __syncthreads();
+            for (int c = tid; c < M; c += NT) {  // positions by descending key, equal keys by column
+                const double kc = key[c];
+                int rank = 0;
+                for (int j = 0; j < M; j++) {
+                    const double kj = key[j];
+                    rank += (kj > kc || (kj == kc && j < c)) ? 1 : 0;
+                }
+                posOf[c] = (unsigned short)rank;
+                colOf[rank] = (unsigned short)c;
+            }
+            __syncthreads();
+            if (wave == 0) {  // the root in that order: u and row4col by position, col4row's values are positions, v as it is
+                double uN[R];
+                int rN[R], cN[R];
+#pragma unroll
+                for (int i = 0; i < R; i++) {
+                    const int r = lane + 64 * i;
+                    uN[i] = 0.0; rN[i] = -1; cN[i] = -1;
+                    if (r < D) {
+                        const int oc = r < M ? (int)colOf[r] : r;
+                        uN[i] = uW[oc];
+                        rN[i] = r4cW[oc];
+                        const int cOld = c4rW[r];
+                        cN[i] = (cOld >= 0 && cOld < M) ? (int)posOf[cOld] : cOld;
+                    }
+                }
+                wave_fence();
+#pragma unroll
+                for (int i = 0; i < R; i++) {
+                    const int r = lane + 64 * i;
+                    if (r < D) { uW[r] = uN[i]; r4cW[r] = rN[i]; c4rW[r] = cN[i]; }
+                }
+                wave_fence();
+                const int r0 = uni32(r4cW[0]);
+                const u32 forb = (lane == (r0 & 63)) ? (1u << (r0 >> 6)) : 0u;  // cpp:235: the row of the FIRST column of the order
+                store_state(0, v, forb, poolG[0], 0);
+            }
+            for (int i = tid; i < N * M; i += NT) {  // the cost copy's real columns again, in the new order (D == N)
+                const int c = i / N, r = i - c * N;
+                const double x = Cg[r + (long long)colOf[c] * N];
+                double val = maximize ? (-x + cdelW) : (x - cdelW);  // cpp:558 / cpp:564
+                if (val != val) val = INF;
+                Cw[i] = val;
+            }
+            __syncthreads();
         }
 
         // ---- phase 2: rounds (kBest2D cpp:607-634 + split cpp:455-532 as a batched frontier) ----
@@ -687,8 +776,12 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
             for (int idx = tid; idx < nEmit * (N + M); idx += NT) {
                 const int j = idx / (N + M), q = idx - j * (N + M);
                 const unsigned char *E = stBase + (long long)(srcS[j] & WIDE_SID_MASK) * p.stateStride;
-                if (q < M) put_index(p.row4col, (outBase + emitted + j) * p.ldCol + q, reinterpret_cast<const int *>(E + offR4C)[q], tabI8);
-                else if (p.col4row) put_index(p.col4row, (outBase + emitted + j) * p.ldRow + (q - M), reinterpret_cast<const int *>(E + offC4R)[q - M], tabI8);
+                // (the states are in the enumeration's column order: the tables in the reference's)
+                if (q < M) put_index(p.row4col, (outBase + emitted + j) * p.ldCol + colOf[q], reinterpret_cast<const int *>(E + offR4C)[q], tabI8);
+                else if (p.col4row) {
+                    const int cv = reinterpret_cast<const int *>(E + offC4R)[q - M];
+                    put_index(p.col4row, (outBase + emitted + j) * p.ldRow + (q - M), (cv >= 0 && cv < M) ? (int)colOf[cv] : cv, tabI8);
+                }
             }
             if (uni32(ctrl->stop) != 0) {
                 __syncthreads();
@@ -795,7 +888,7 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
                 wide_update<R>(uW, c4rW, r4cW, predW, lane, v, spc, pred, scanned, delta, sink, c, D);
                 KW_T(tD);
                 KW_ACC(7, tD - tC);  // [7] dual update + augmentation
-                const double g = wide_gain<R>(Cw, D, M, r4cW, lane);
+                const double g = wide_gain<R>(Cw, D, M, r4cW, lane, posOf);
                 KW_T(tE);
                 KW_ACC(8, tE - tD);  // [8] gain
                 if (useCut && (maximize ? (g < cutG) : (g > cutG))) continue;  // cutHyp, cpp:496/521
