@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 KBEST_FLAG_NO_PRUNE = 1
 KBEST_FLAG_COUNT_PUSHED = 2
 KBEST_FLAG_TABLES_I8 = 64
+KBEST_FLAG_NO_REORDER = 128
 KBEST_MAX_DIM = 64        # rows handled by the LDS-resident kernel
 KBEST_MAX_DIM_WIDE = 512  # rows handled at all (general-size kernel beyond KBEST_MAX_DIM)
 
@@ -148,7 +149,7 @@ class KBestEngine:
 
     # ---- host buffers -----------------------------------------------------------------
     def kbest(self, costs, N, M, k, maximize=False, cutoff=None, nRow=None, nCol=None, costOff=None,
-              count_pushed=False, prune=True, root_shard=None, tables_i8=False):
+              count_pushed=False, prune=True, root_shard=None, tables_i8=False, reorder=True):
         """Batched kBest2D / kBest2DCutoff.  costs: (B, N*M) for uniform shapes, or a flat packed
         array with per-problem nRow/nCol/costOff (N, M are then the maxima).
         Returns (nf[B], row4col[B,k,M], col4row[B,k,N], gain[B,k]) (+ pushed[B] if count_pushed).
@@ -169,7 +170,7 @@ class KBestEngine:
         nf = np.empty(B, np.int32)
         pushed = np.zeros(B, np.int64) if count_pushed else None
         flags = ((KBEST_FLAG_COUNT_PUSHED if count_pushed else 0) | (0 if prune else KBEST_FLAG_NO_PRUNE) |
-                 (KBEST_FLAG_TABLES_I8 if tables_i8 else 0))
+                 (KBEST_FLAG_TABLES_I8 if tables_i8 else 0) | (0 if reorder else KBEST_FLAG_NO_REORDER))
         o = self._opts(maximize, cutoff, flags, root_shard)
         self._check(self.lib.kbest_batch_f64(self.ctx, C.byref(o), B, N, M, _ptr(nRow), _ptr(nCol), _ptr(costs),
                                              _ptr(costOff), k, _ptr(r4c), _ptr(c4r), _ptr(gain), _ptr(nf),

@@ -409,3 +409,29 @@ def test_association_entry_on_registered_buffers(F):
     finally:
         eng.unregister_host(raw, hp)
     assert np.array_equal(hp.view(np.int64), ref_p.view(np.int64)) and np.array_equal(hnf, ref_nf)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(64, 64, 120, 300), (32, 32, 200, 700), (16, 16, 50, 900), (12, 12, 30, 40), (40, 17, 60, 20),
+                                   (100, 100, 25, 6), (90, 30, 40, 5)])
+def test_column_order_of_the_enumeration_does_not_change_the_result(shape):
+    """DESIGN section 2 point 8: the kernels enumerate in a column order of their own (dear columns first).  With
+    KBEST_FLAG_NO_REORDER they walk the columns as the reference does.  Tie-free costs: both give the same tables, bit for bit
+    (and the default is what every other test holds against the oracle)."""
+    N, M, k, B = shape
+    rng = np.random.default_rng(7 * N + M)
+    costs = rng.uniform(0.0, 1.0, (B, N * M))
+    eng = pk.KBestEngine(0)
+    a = eng.kbest(costs, N, M, k)
+    b = eng.kbest(costs, N, M, k, reorder=False)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[3].view(np.int64), b[3].view(np.int64))
+    assert np.array_equal(a[1], b[1])
+    real = b[2] < M  # col4row: rows on zero-padded columns may sit on another padded column (INTEGRATION.md)
+    assert np.array_equal(a[2] < M, real) and np.array_equal(a[2][real], b[2][real])
+    # maximise + cutoff through the same switch
+    a = eng.kbest(costs, N, M, k, maximize=True, cutoff=0.5)
+    b = eng.kbest(costs, N, M, k, maximize=True, cutoff=0.5, reorder=False)
+    n = a[0]
+    assert np.array_equal(n, b[0])
+    for i in range(B):
+        assert np.array_equal(a[3][i, : n[i]].view(np.int64), b[3][i, : n[i]].view(np.int64)) and np.array_equal(a[1][i, : n[i]], b[1][i, : n[i]])
