@@ -522,10 +522,15 @@ int kbest_reserve(kbest_ctx *ctx, int B, int maxRow, int k)
             if (rc != KBEST_OK) return rc;
         }
     }
-    Shape lsh;
-    if (lane_fits(ctx, B, maxRow, maxRow, k, &lsh)) {
-        int rc = ensure_states(ctx, lane_states_need(B, maxRow, maxRow, k, lsh.spec, nullptr), true);
-        if (rc != KBEST_OK) return rc;
+    {   // the lane-per-child kernel: its launch shape (hypotheses split per round -> state slots per problem) follows the batch size
+        const int tiers[2] = {B, B < 4 * ctx->nCU ? B : 4 * ctx->nCU};
+        for (int t = 0; t < 2; t++) {
+            Shape lsh;
+            if (lane_fits(ctx, tiers[t], maxRow, maxRow, k, &lsh)) {
+                int rc = ensure_states(ctx, lane_states_need(tiers[t], maxRow, maxRow, k, lsh.spec, nullptr), true);
+                if (rc != KBEST_OK) return rc;
+            }
+        }
     }
     if (kFits) {
         // (a small batch of 33 ... 64-row problems may run split: up to four workgroups, i.e. four work spaces, per matrix)
@@ -649,8 +654,14 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
     // problem and the enumeration long, else up to 20 % slower (4 096 x 32x32, k = 200: 5.4 ms against 4.9).  Batches that
     // cannot fill the chip (B <= 2 CUs) stay on the small-problem kernel (16 waves per problem: 0.33 against 0.40 ms at
     // 256 x 16x16, k = 200), rectangular ones too (implicit zero columns).
-    const bool laneWins = ctx->forceLane || (maxCol == maxRow && LB > 2 * ctx->nCU && !ctx->forceSmall &&
-                                             (maxRow <= 16 || (LB <= 4 * ctx->nCU && k >= 100)));
+    // Since the kernels enumerate in a column order of their own (DESIGN.md section 2 point 8; the small-problem kernel does
+    // not: nothing to gain with its free rows), uniform SQUARE batches no longer go to the small-problem kernel at any size:
+    // 16x16, k = 50: 0.124 - 0.172 ms on the lane kernel against 0.125 - 0.228 from 1 to 512 problems; 32x32, k = 200:
+    // 0.36 - 0.67 ms on the 64-row kernel against 0.50 - 1.02.
+    const bool squareU = maxCol == maxRow && d_nRow == nullptr;
+    const bool laneWins = ctx->forceLane || (maxCol == maxRow && !ctx->forceSmall &&
+                                             ((maxRow <= 16 && (squareU || LB > 2 * ctx->nCU)) ||
+                                              (LB > 2 * ctx->nCU && LB <= 4 * ctx->nCU && k >= 100)));
     if (!extra && !forceWide && laneWins && !(opts->flags & (KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_PRUNE | KBEST_FLAG_RECT_ROOT |
                                                                  KBEST_FLAG_NO_SHIFT | KBEST_FLAG_EXACT_ROOT)) &&
         lane_fits(ctx, LB, maxRow, maxCol, k, &lsh)) {
@@ -691,7 +702,7 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         return KBEST_OK;
     }
     int snw = 0;
-    const bool smallWins = ctx->forceSmall || maxCol < maxRow || LB <= 2 * ctx->nCU;
+    const bool smallWins = ctx->forceSmall || maxCol < maxRow || (LB <= 2 * ctx->nCU && !squareU);
     if (!extra && !forceWide && smallWins && !(opts->flags & (KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_PRUNE)) &&
         opts->root_col_stride <= 1 && small_fits(ctx, LB, maxRow, maxCol, k, false, &snw)) {
         int rc = ensure_states(ctx, small_states_need(LB, maxRow, maxCol, k, snw), grow);
