@@ -42,11 +42,20 @@ if os.environ.get("PROBE_EXACT"):
             ri, cj = linear_sum_assignment(Cb)
             exact[b, c] = Cb[ri, cj].sum() - base
             Cb[r, c] = old
+freq = None
+if os.environ.get("PROBE_FREQ"):
+    # the ideal static order, from the answer itself: how often each column differs from the optimum in the k best
+    nf0, r0, c0, g0 = eng.kbest(costs, N, M, k)
+    freq = (r0 != r0[:, :1, :]).sum(axis=1).astype(np.float64)   # [b, c]
 def run(perm_kind):
     if perm_kind == "none": P = np.tile(np.arange(M), (B, 1))
     elif perm_kind == "dear_first": P = np.argsort(-m, axis=1, kind="stable")
     elif perm_kind == "cheap_first": P = np.argsort(m, axis=1, kind="stable")
     elif perm_kind == "exact_first": P = np.argsort(-exact, axis=1, kind="stable")
+    elif perm_kind == "freq_last": P = np.argsort(freq, axis=1, kind="stable")            # rarely changed first, often changed last
+    elif perm_kind == "freq_then_exact":                                                   # never-changed columns by dearness, the rest by frequency
+        keyf = np.where(freq == 0, -1e9 - (exact if exact is not None else m), freq)
+        P = np.argsort(keyf, axis=1, kind="stable")
     elif perm_kind.startswith("clip"):   # exact keys only up to the sum of the m cheapest: beyond it, order by the two-arc bound
         mm = int(perm_kind[4:])
         bnd = np.sort(exact, axis=1)[:, :mm].sum(axis=1, keepdims=True)
@@ -68,6 +77,6 @@ def run(perm_kind):
         e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / 5)
     return best, o[2].sum().item()
-for kind in (("exact_first", "clip4", "clip6", "clip8", "clip12", "exact_first") if exact is not None else ("none", "dear_first", "dear2_first", "dearmax_first", "none")):
+for kind in (("exact_first", "freq_last", "freq_then_exact", "exact_first") if (exact is not None and freq is not None) else ("exact_first", "clip4", "clip6", "clip8", "clip12", "exact_first") if exact is not None else ("none", "dear_first", "dear2_first", "dearmax_first", "none")):
     t, gs = run(kind)
     print(f"{cfg} columns {kind:12s}: {t:.3f} ms   (sum of gains {gs:.6f})", flush=True)
