@@ -121,7 +121,11 @@ Shape choose_shape(const kbest_ctx *ctx, int B, int maxRow, int k)
         // measured (64x64, k = 200, ms for 8 / 12 waves): B = 600: 2.28 / 2.48, 900: 3.35 / 3.05, 1024: 4.0 / 3.2,
         // 1100: 3.57 / 3.74, 1536: 4.27 / 4.60, 2048: 5.62 / 5.98, 8192: 19.4 / 21.9 -- three 8-wave matrices per CU win
         // except where they would leave a nearly empty second generation and two generations of 12-wave pairs fit
-        if (B > 3 * ctx->nCU && B <= 4 * ctx->nCU) { s.nWaves = 12; s.spec = 12; } else { s.nWaves = 8; s.spec = 6; }
+        // (re-scanned after the enumeration got its own column order, DESIGN.md section 2 point 8 -- fewer, shorter children: the
+        //  12-wave pairs now win at every batch size, ms for 8 / 12 waves: B = 600: 1.85 / 1.61, 768: 2.02 / 1.78, 1 100: 2.71 /
+        //  2.44, 1 536: 3.36 / 2.98, 2 048: 4.27 / 3.84, 4 096: 7.95 / 7.26)
+        s.nWaves = 12;
+        s.spec = 12;
     }
     // the in-place pool merge holds at most 4 entries per thread: a long pool (bruteForceProb-style k in the
     // thousands, assignment.cpp:868) needs a bigger workgroup
