@@ -116,7 +116,11 @@ Shape choose_shape(const kbest_ctx *ctx, int B, int maxRow, int k)
     // round -- 64x64, k = 200 alone: 1.25 ms instead of 1.80; one 30x10 frame: 0.63 ms instead of 0.99.
     if (B <= ctx->nCU) { s.nWaves = 16; s.spec = 16; }  // 16 candidates per round (one 30x10 frame 0.63 -> 0.57 ms; 256 x 64x64 1.10 -> 1.03 ms)
     else if (B <= 2 * ctx->nCU) { s.nWaves = 12; s.spec = 12; }
-    else if (maxRow <= 32) { s.nWaves = 4; s.spec = 4; }
+    else if (maxRow <= 32) {
+        // (32x32, k = 200, ms for 4 / 8 / 12 waves with as many hypotheses per round: B = 2 048: 2.28 / 2.12 / 2.29, 4 096: 3.74 /
+        //  3.86 / 4.33, 8 192: 6.81 / 7.30 / 8.39)
+        if (B <= 12 * ctx->nCU) { s.nWaves = 8; s.spec = 8; } else { s.nWaves = 4; s.spec = 4; }
+    }
     else {
         // measured (64x64, k = 200, ms for 8 / 12 waves): B = 600: 2.28 / 2.48, 900: 3.35 / 3.05, 1024: 4.0 / 3.2,
         // 1100: 3.57 / 3.74, 1536: 4.27 / 4.60, 2048: 5.62 / 5.98, 8192: 19.4 / 21.9 -- three 8-wave matrices per CU win
