@@ -694,7 +694,8 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         __syncthreads();
         if (wave == 0) {
             // positions by descending key, equal keys by column (deterministic)
-            const double kl = key[lane < M ? lane : 0];
+            double kl = key[lane < M ? lane : 0];
+            kl = (kl == kl) ? kl : INF;  // (a NaN key would break the ranks' uniqueness: any order is valid, a non-permutation is not)
             int rank = 0;
             for (int j = 0; j < M; j++) {
                 const double kj = readlane_f64(kl, j);

@@ -412,7 +412,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
         }
         __syncthreads();
         if (wave == 0) {
-            const double kl = key[lane < M ? lane : 0];
+            double kl = key[lane < M ? lane : 0];
+            kl = (kl == kl) ? kl : INF;  // (a NaN key would break the ranks' uniqueness: any order is valid, a non-permutation is not)
             int rank = 0;
             for (int j = 0; j < M; j++) {  // positions by descending key, equal keys by column
                 const double kj = readlane_f64(kl, j);

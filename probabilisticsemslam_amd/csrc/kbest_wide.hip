@@ -629,7 +629,7 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
                 int pred[R], sink = 0;
                 u32 scanned;
                 const int dj = wide_dijkstra<R, false>(Cw, D, uW, c4rW, lane, v, all, frBit, c, INF, spc, pred, scanned, delta, sink, M, nullptr, fr);
-                if (lane == 0) key[c] = dj ? INF : delta;
+                if (lane == 0) key[c] = (dj || delta != delta) ? INF : delta;  // (never a NaN: the ranks below must be a permutation)
             }
             __syncthreads();
             for (int c = tid; c < M; c += NT) {  // positions by descending key, equal keys by column
