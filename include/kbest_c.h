@@ -32,8 +32,8 @@
  *
  * Order of exact ties.  Hypotheses with EXACTLY equal gain have no defined relative order in the reference (it is
  * an artefact of std::priority_queue's binary heap, cpp:574).  The engine orders them deterministically -- old pool
- * entries before fresh ones, fresh ones by (parent hypothesis, column) -- which is in general NOT the reference's
- * order.  For continuous costs ties have probability zero and every output is bit-identical; for integer-like costs
+ * entries before fresh ones, fresh ones by (parent hypothesis, column in the enumeration's own column order, DESIGN.md
+ * section 2 point 8) -- which is in general NOT the reference's order.  For continuous costs ties have probability zero and every output is bit-identical; for integer-like costs
  * (conditionCosts produces exact zeros) the multiset of gains and the validity of every assignment are the
  * reference's, but when a tie group straddles slot k (or the best + cutoff gate) the emitted SET, and with it
  * assignmentProb's weights, may differ from the reference's by more than rounding.
