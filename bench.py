@@ -307,29 +307,49 @@ def host_inclusive_dense(eng, costs, N, M, k):
     for a in (r4c, c4r, gain, nf):
         a[...] = 0
     registered = None
+    r8, c8 = np.zeros((B, k, M), np.int8), np.zeros((B, k, N), np.int8)
+    regs = []  # what is registered right now (unregistered in the finally block whatever happens)
+
+    def register(*arrays):
+        for a in arrays:
+            eng.register_host(a)
+            regs.append(a)
+
+    def unregister(*arrays):
+        for a in arrays:
+            eng.unregister_host(a)
+            regs[:] = [x for x in regs if x is not a]
+
     try:
-        eng.register_host(costs, r4c, c4r, gain, nf)
-        registered = timed()
-        same = all(np.array_equal(x, y) for x, y in zip(ref, (r4c, c4r, gain, nf)))
-        no_c4r = timed(with_c4r=False)
-        eng.unregister_host(r4c, c4r)
-        # the same tables as int8 (KBEST_FLAG_TABLES_I8): every index of a 64-row problem fits a byte
-        r8, c8 = np.zeros((B, k, M), np.int8), np.zeros((B, k, N), np.int8)
-        eng.register_host(r8, c8)
-        o.flags |= pk_engine.KBEST_FLAG_TABLES_I8
-        r4c_keep, c4r_keep = r4c, c4r
-        r4c, c4r = r8, c8
-        i8 = timed()
-        same8 = np.array_equal(r8, ref[0]) and np.array_equal(c8, ref[1]) and np.array_equal(gain, ref[2])
-        i8_no_c4r = timed(with_c4r=False)
-        r4c, c4r = r4c_keep, c4r_keep
-        o.flags &= ~pk_engine.KBEST_FLAG_TABLES_I8
-        eng.unregister_host(costs, r8, c8, gain, nf)
-        assert same, "registered-buffer path differs from the copying path"
-        assert same8, "int8 tables differ from the int32 tables"
-    except Exception as ex:  # (keep the pageable number if registration is not possible on this host)
-        registered = None
-        err = repr(ex)
+        try:
+            register(costs, r4c, c4r, gain, nf)
+        except pk_engine.KBestError as ex:  # only a failed registration falls back to the pageable number
+            err = repr(ex)
+        else:
+            registered = timed()
+            # (a mismatch on any of the paths below is a failure of the bench, not a reason to fall back)
+            assert all(np.array_equal(x, y) for x, y in zip(ref, (r4c, c4r, gain, nf))), "registered-buffer path differs from the copying path"
+            no_c4r = timed(with_c4r=False)
+            unregister(r4c, c4r)
+            # the same tables as int8 (KBEST_FLAG_TABLES_I8): every index of a 64-row problem fits a byte
+            register(r8, c8)
+            o.flags |= pk_engine.KBEST_FLAG_TABLES_I8
+            r4c_keep, c4r_keep = r4c, c4r
+            r4c, c4r = r8, c8
+            try:
+                i8 = timed()
+                assert np.array_equal(r8, ref[0]) and np.array_equal(c8, ref[1]) and np.array_equal(gain, ref[2]), "int8 tables differ from the int32 tables"
+                i8_no_c4r = timed(with_c4r=False)
+            finally:
+                r4c, c4r = r4c_keep, c4r_keep
+                o.flags &= ~pk_engine.KBEST_FLAG_TABLES_I8
+    finally:
+        for a in list(regs):
+            try:
+                eng.unregister_host(a)
+            except pk_engine.KBestError:
+                pass
+        regs.clear()
     best = registered if registered is not None else pageable
     out = {"value": float(nf.sum()) / best, "unit": "assignments/s", "ms": 1e3 * best,
            "includes": "H2D of the cost blocks, kernel, D2H of row4col / col4row / gain / nf (host buffers in and out: kbest_batch_f64)",
@@ -350,6 +370,30 @@ def host_inclusive_dense(eng, costs, N, M, k):
         out["note"] = (f"{(r4c.nbytes + c4r.nbytes + gain.nbytes) / 1e6:.0f} MB of int32 tables leave the kernel over PCIe while it runs: "
                        "~35 GB/s is the link's rate for these stores, so the run cannot end before ~3.0 ms; see DESIGN.md section 6")
     return out
+
+
+def multi_entry_dense(costs, N, M, k, G, ref_nf, ref_gain):
+    """The same batch through the ONE-PROCESS multi-device entry (kbest_batch_f64_multi, kbest_multi.cpp) on G contexts of GPU 0
+    ("logical devices"): host buffers in and out, one worker thread per device, the packed slices exchanged device to device.
+    With G = 1 it is the single-device host path plus the exchange; with G = 8 the host side of config 4 as written (each
+    device 1/8 of the batch) runs on one GPU, and the timeline shows what each device's thread did when."""
+    import probabilisticsemslam_amd as pk
+    multi = pk.KBestMulti([0] * G)
+    best, out = None, None
+    for _ in range(4):
+        t0 = time.perf_counter()
+        out = multi.kbest(costs, N, M, k)
+        dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+    tl = multi.timeline()
+    agree = bool(multi.tables_agree())
+    multi.close()
+    assert (out[0] == ref_nf).all() and (out[3].view(np.int64) == ref_gain.view(np.int64)).all(), "multi-device entry differs from the single-device result"
+    return {"devices": G, "ms": 1e3 * best, "value": float(out[0].sum()) / best, "unit": "assignments/s", "tables_agree": agree,
+            "timeline_ms": {"what": "host times of the last call per device, ms since entry: worker started, first upload issued, first "
+                                    "kernel issued, fed (own results back), exchange issued, done (kbest_multi_timeline)",
+                            "per_device": [[round(1e3 * float(x), 3) for x in row] for row in tl]},
+            "no_device_waits_for_anothers_copy": bool(tl[:, 1].max() < tl[:, 3].min())}
 
 
 def two_in_flight(torch, dev, cfg, B, ms_single, steps=20):
@@ -739,6 +783,16 @@ def main():
                     extra["c4_two_batches_in_flight"] = two_in_flight(torch, dev, "c4", Bc, out["ms_per_step"])
                 except Exception as ex:
                     extra["c4_two_batches_in_flight"] = {"error": repr(ex)}
+                # the one-process multi-device entry on logical devices of this GPU: 1 (against the single-device host path) and 8
+                # (the host side of configs[3] as written)
+                for G in (1, 8):
+                    try:
+                        me = multi_entry_dense(m["costs"], N, M, k, G, m["nf"], m["g"])
+                        if G == 1 and "value_host_inclusive" in out:
+                            me["vs_single_device_host_path_pageable"] = me["ms"] / out["value_host_inclusive"]["pageable_ms"]
+                        extra[f"c4_multi_entry_{G}dev"] = me
+                    except Exception as ex:
+                        extra[f"c4_multi_entry_{G}dev"] = {"error": repr(ex)}
                 out["configs"] = extra
             line = json.dumps(out)
     if use_dist:

@@ -79,6 +79,7 @@ enum {
 #define KBEST_FLAG_NO_T0 32u       /* do not use the a-priori threshold from combinations of the root's children (A/B tests) */
 #define KBEST_FLAG_EXACT_ROOT 16u  /* root LAP by the reference's own sequence of augmentations (no column reduction first)  */
 #define KBEST_FLAG_NO_REORDER 128u /* 64-row kernel: enumerate in the reference's column order (A/B tests; same results)          */
+#define KBEST_FLAG_NO_OPT 256u     /* 64-row kernel: no optimistic bounds / re-split tickets (A/B tests; same results)           */
 #define KBEST_FLAG_TABLES_I8 64u   /* kbest_batch_f64 / kbest_batch_f64_dev: row4col / col4row are tables of int8_t (same shapes, */
                                    /* same values, -1 = unassigned / unused) instead of int32_t: every index of a problem of up   */
                                    /* to 127 rows fits a byte, and a quarter of the bytes cross PCIe.  numRow > 127:              */
@@ -288,8 +289,10 @@ int kbest_merge_topk_f64_dev(kbest_ctx *ctx, int B, int nShard, int k, int maxCo
  * contiguous blocks (device g solves matrices [g*ceil(B/G), ...)), each device solving its block with the kernels of
  * the single-device entries straight into its packed slice (gain | row4col | nf) of a global table; ONE in-place
  * ncclAllGather of those slices then leaves EVERY device with the same global k-best table (there is no
- * other collective: the matrices are independent).  The host outputs are read back from device 0; col4row is not part
- * of the exchange and comes from the device that solved the block.  Same argument meaning as kbest_batch_f64
+ * other collective: the matrices are independent).  Every device is fed and read back by a host thread of its own: the
+ * host outputs of a block come from the device that solved it (col4row is not part of the exchange).  device_ids may
+ * name one GPU several times ("logical devices", e.g. {0, 0, 0, 0}): the slices then travel by device-to-device copies
+ * instead of RCCL -- the same host path, testable on one GPU.  Same argument meaning as kbest_batch_f64
  * (uniform packing b*maxRow*maxCol; nRow/nCol optional).  RCCL is bound at run time (dlopen): without it
  * kbest_create_multi returns KBEST_ERR_NO_DEVICE and every single-device entry still works.
  */
@@ -318,6 +321,15 @@ int kbest_batch_f64_multi_ex(kbest_multi *m, const kbest_opts *opts, int mode, i
                              int32_t *col4row, double *gain, int32_t *nf);
 /* 1 when every device holds the same global table after the last kbest_batch_f64_multi[_ex] call, 0 when not (test aid). */
 int kbest_multi_tables_agree(kbest_multi *m);
+/*
+ * Host timeline of the last kbest_batch_f64_multi[_ex] call: out[g * KBEST_MULTI_STAMPS + i], seconds since the call was
+ * entered, for device g: [0] its worker thread started, [1] its first upload was issued, [2] its first kernel was issued,
+ * [3] it was fed (batch mode: its own results are back in the caller's tables as well), [4] the exchange was issued, [5] done.
+ * Every device is fed and read back by a thread of its own, so no device waits for another one's copies; this is the
+ * evidence.  Returns the number of devices written (at most capDevices).
+ */
+#define KBEST_MULTI_STAMPS 6
+int kbest_multi_timeline(const kbest_multi *m, double *out, int capDevices);
 
 #ifdef __cplusplus
 }

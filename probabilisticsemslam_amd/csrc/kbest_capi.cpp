@@ -15,6 +15,10 @@
 #include "kbest_c.h"
 #include "kbest_engine.h"
 
+namespace kb {
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}
+
 struct DevBufRaw { void *p = nullptr; size_t bytes = 0; };
 
 struct kbest_ctx {
@@ -52,12 +56,17 @@ struct kbest_ctx {
     int laneNw = 0;           // KBEST_LANE_NW: waves per problem of the lane-per-child kernel (1 / 2 / 4); 0 = choose per launch
     int laneSpec = 0;         // KBEST_LANE_SPEC: hypotheses split per round there (1 .. 16); 0 = choose per launch
     int laneG = 0;            // KBEST_LANE_G: lanes per child there (2 / 4); 0 = choose per launch
+    // optimistic bounds of the 64-row kernel (kbest_engine.hip, struct Opt); < 0: choose per launch shape (opt_defaults)
+    float optRho0 = -1.0f, optRho1 = -1.0f, optPhi = -1.0f, optKappa = 0.25f;
+    int optMinPool = 8;
+    bool noOpt = false;       // KBEST_NO_OPT: no optimistic bounds (A/B tests)
     int extraStates = 64;  // lazy state slots beyond k per matrix (room for speculative re-solves)
     int eagerStates = 1024; // state slots per matrix for children that are kept in full when they are found
     unsigned long long *prof = nullptr;  // diagnostic builds only (kbest_set_profile_buffer)
     std::string err;
     std::mutex errMu;  // entry points may be called from several host threads
-    std::mutex mu;     // serialises launches: the hypothesis workspace is shared by every launch of this context
+    std::recursive_mutex mu;  // serialises launches: the hypothesis workspace is shared by every launch of this context (recursive: the
+                              // host entry holds it across all pieces of a pieced launch, each of which takes it again)
     // The workspace is per context, not per stream: a launch on another stream than the previous one must wait for it
     // (an event recorded on the previous stream when the switch is detected).
     hipStream_t lastStream = nullptr;
@@ -298,6 +307,12 @@ int kbest_create(kbest_ctx **out, int device)
     if (const char *e = getenv("KBEST_LANE_G")) { const int w = atoi(e); if (w == 2 || w == 4) ctx->laneG = w; }
     if (const char *e = getenv("KBEST_LANE_SPEC")) { const int w = atoi(e); if (w >= 1 && w <= kb::LANE_MAX_SPEC) ctx->laneSpec = w; }
     ctx->forceSmall = getenv("KBEST_FORCE_SMALL") != nullptr;
+    ctx->noOpt = getenv("KBEST_NO_OPT") != nullptr;
+    if (const char *e = getenv("KBEST_OPT_RHO0")) ctx->optRho0 = (float)atof(e);
+    if (const char *e = getenv("KBEST_OPT_RHO1")) ctx->optRho1 = (float)atof(e);
+    if (const char *e = getenv("KBEST_OPT_PHI")) ctx->optPhi = (float)atof(e);
+    if (const char *e = getenv("KBEST_OPT_KAPPA")) ctx->optKappa = (float)atof(e);
+    if (const char *e = getenv("KBEST_OPT_MINPOOL")) ctx->optMinPool = atoi(e);
     ctx->noPoll = getenv("KBEST_NO_POLL") != nullptr;
     if (const char *e = getenv("KBEST_ZC_LIMIT_KB")) ctx->zcLimit = (size_t)atoll(e) << 10;
     ctx->exactRoot = getenv("KBEST_EXACT_ROOT") != nullptr;
@@ -511,7 +526,7 @@ int kbest_reserve(kbest_ctx *ctx, int B, int maxRow, int k)
     if (!ctx || B < 0 || maxRow < 1 || k < 1) return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_reserve: bad argument");
     if (maxRow > KBEST_MAX_DIM_WIDE) return fail(ctx, KBEST_ERR_UNSUPPORTED, "numRow > KBEST_MAX_DIM_WIDE");
     if (B == 0) return KBEST_OK;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     const int fastRow = maxRow < KBEST_MAX_DIM ? maxRow : KBEST_MAX_DIM;
     const bool kFits = k_fits_fast(ctx, B, fastRow, k, 0, nullptr) || k_fits_fast(ctx, B, fastRow, k, KBEST_FLAG_COUNT_PUSHED, nullptr);
     // "launches of up to B problems" (kbest_c.h): a smaller batch may pick another kernel or launch shape than B itself --
@@ -572,8 +587,19 @@ struct SubBatch { int logicalB = 0, blockBase = 0; };
 // owner at any time after our launch, so it is never touched again: the event that marks the end of a launch on such a
 // stream is recorded right behind the launch (Launched, below), while the stream is certainly alive; only the context's
 // own stream -- which lives as long as the context -- gets its event recorded lazily, here, when a switch happens.
+static bool capturing(hipStream_t s)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return s && hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+}
+
 static int order_behind_last(kbest_ctx *ctx, hipStream_t s)
 {
+    // Under stream capture (kbest_c.h allows the asynchronous entries inside a graph capture) nothing of the cross-stream
+    // bookkeeping may happen: an event recorded on a capturing stream becomes a node of the graph, and another stream that
+    // later waits on it would be pulled into the capture (or fail).  A captured launch is therefore NOT ordered against the
+    // context's other streams -- a context whose launches are captured is used on that one stream (kbest_c.h).
+    if (capturing(s)) return KBEST_OK;
     if (ctx->haveLast && ctx->lastStream != s) {
         if (ctx->lastStream == ctx->stream) HIP_TRY(ctx, hipEventRecord(ctx->lastEvent, ctx->stream));
         HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->lastEvent, 0));
@@ -588,7 +614,7 @@ static int order_behind_last(kbest_ctx *ctx, hipStream_t s)
 struct Launched {
     kbest_ctx *ctx;
     hipStream_t s;
-    ~Launched() { if (s != ctx->stream) (void)hipEventRecord(ctx->lastEvent, s); }
+    ~Launched() { if (s != ctx->stream && !capturing(s)) (void)hipEventRecord(ctx->lastEvent, s); }
 };
 
 // One matrix over several workgroups (64-row kernel).  When a batch leaves CUs idle -- at most half as many 33 ... 64-row
@@ -640,7 +666,7 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
     const bool runFast = !forceWide && kFits && (maxRow <= KBEST_MAX_DIM || d_nRow != nullptr);
     const bool runWide = forceWide || !kFits || maxRow > KBEST_MAX_DIM;
     if (extra && runWide) return fail(ctx, KBEST_ERR_UNSUPPORTED, "assign2D / shortestPathCPP entry: numRow > KBEST_MAX_DIM");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
     if (!sub) {
@@ -798,6 +824,18 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         p.gainCols = extra ? extra->gainCols : 0;
         p.split = S;
         p.splitB = B;
+        // optimistic bounds: the quantile of the pool a node is split against (host model: tests/dev/proto_tickets.cpp).  With many
+        // hypotheses split per round most of the early pool is speculation (start low, end at the valid threshold); with few
+        // the pool is mostly the answer all along.
+        if (ctx->noOpt) p.optRho0 = 2.0f;
+        else {
+            const bool deep = shp.spec >= 10;
+            p.optRho0 = ctx->optRho0 >= 0.0f ? ctx->optRho0 : (deep ? 0.55f : 0.85f);
+            p.optRho1 = ctx->optRho1 >= 0.0f ? ctx->optRho1 : (deep ? 1.0f : 0.85f);
+            p.optPhi = ctx->optPhi > 0.0f ? ctx->optPhi : 1.0f;
+            p.optKappa = ctx->optKappa;
+            p.optMinPool = ctx->optMinPool > 1 ? ctx->optMinPool : 2;
+        }
         p.sharedT = S > 1 ? reinterpret_cast<unsigned long long *>(sb + sl.offT) : nullptr;
         hipError_t e = kb::launch_kbest(p, B * S, shp.nWaves, s);
         if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "kbest kernel launch", e);
@@ -943,10 +981,15 @@ int kbest_unregister_host_buffer(kbest_ctx *ctx, void *ptr)
     return KBEST_OK;
 }
 
-int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, int maxCol,
-                    const int32_t *nRow, const int32_t *nCol, const double *cost,
-                    const int64_t *costOff, int k, int32_t *row4col, int32_t *col4row, double *gain,
-                    int32_t *nf, int64_t *pushed)
+}  // extern "C"
+
+// The host-buffer entry.  `keep` (kbest_multi.cpp): the result tables are staged in the CALLER's device buffers -- a device's
+// packed slice of the multi-device global table -- and stay there after they have been copied back, so that the all-gather
+// can follow; everything else (pieces, uploads, copies back) is the single-device path.
+int kbest_batch_f64_keep(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, int maxCol,
+                         const int32_t *nRow, const int32_t *nCol, const double *cost,
+                         const int64_t *costOff, int k, int32_t *row4col, int32_t *col4row, double *gain,
+                         int32_t *nf, int64_t *pushed, const kb::KeepTables *keep)
 {
     if (!ctx) return KBEST_ERR_BAD_ARG;
     if (!opts || B < 0 || k < 1 || maxCol < 1 || maxRow < maxCol || !cost || !row4col || !gain || !nf)  // (col4row NULL: not wanted)
@@ -979,7 +1022,7 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
     char *mC4R = col4row ? static_cast<char *>(mapped(ctx, col4row, nC4R * esz)) : nullptr;
     double *mGain = static_cast<double *>(mapped(ctx, gain, nG * 8));
     int32_t *mNf = static_cast<int32_t *>(mapped(ctx, nf, (size_t)B * 4));
-    const bool direct = mR4C && (mC4R || !col4row) && mGain && mNf && !pushed;
+    const bool direct = mR4C && (mC4R || !col4row) && mGain && mNf && !pushed && !keep;
     double *mCost = static_cast<double *>(mapped(ctx, cost, nCost * 8));
     const bool pinnedCost = mCost != nullptr;
     // Registered cost blocks with registered result tables: the LDS kernels read every cost block exactly once, into their
@@ -992,17 +1035,23 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
     DevBuf dCost, dOff, dNR, dNC, dR4C, dC4R, dGain, dNf, dPushed;
     if (!zcCost) HIP_TRY(ctx, dCost.alloc(ctx, nCost * 8));
     const double *devCost = zcCost ? mCost : dCost.as<double>();
-    if (!direct) {
+    if (keep && (tabI8 || (col4row && !keep->col4row))) return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_batch_f64_keep: bad device tables");
+    if (!direct && !keep) {
         HIP_TRY(ctx, dR4C.alloc(ctx, nR4C * esz));
         if (col4row) HIP_TRY(ctx, dC4R.alloc(ctx, nC4R * esz));
         HIP_TRY(ctx, dGain.alloc(ctx, nG * 8));
         HIP_TRY(ctx, dNf.alloc(ctx, (size_t)B * 4));
-        if (pushed) HIP_TRY(ctx, dPushed.alloc(ctx, (size_t)B * 8));
     }
+    if (!direct && pushed) HIP_TRY(ctx, dPushed.alloc(ctx, (size_t)B * 8));
+    // the device-side staging of the tables: the caller's (keep) or the context's recycled blocks
+    char *sR4C = keep ? reinterpret_cast<char *>(keep->row4col) : dR4C.as<char>();
+    char *sC4R = keep ? reinterpret_cast<char *>(keep->col4row) : dC4R.as<char>();
+    double *sGain = keep ? keep->gain : dGain.as<double>();
+    int32_t *sNf = keep ? keep->nf : dNf.as<int32_t>();
     // (tables addressed in bytes: esz per entry)
-    char *oR4C = direct ? mR4C : dR4C.as<char>(), *oC4R = !col4row ? nullptr : (direct ? mC4R : dC4R.as<char>());
-    int32_t *oNf = direct ? mNf : dNf.as<int32_t>();
-    double *oGain = direct ? mGain : dGain.as<double>();
+    char *oR4C = direct ? mR4C : sR4C, *oC4R = !col4row ? nullptr : (direct ? mC4R : sC4R);
+    int32_t *oNf = direct ? mNf : sNf;
+    double *oGain = direct ? mGain : sGain;
     // A batch that is large in problems and in output bytes goes through the GPU in PIECES on separate streams: the launch
     // shape and the workspace are those of the whole batch (SubBatch), so the pieces' workgroups fill the chip exactly as one
     // launch of the whole batch would -- but a piece starts as soon as ITS cost blocks are up, and its tables cross PCIe
@@ -1029,9 +1078,14 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
     int rc = KBEST_OK;
     hipEvent_t done[4] = {nullptr, nullptr, nullptr, nullptr}, start = nullptr;
     hipStream_t st[4] = {ctx->stream, ctx->aux[0], ctx->aux[1], ctx->aux[2]};
+    // A pieced launch holds the context from its first piece to its last: the pieces run on the context's auxiliary streams on
+    // slices of the one hypothesis workspace, and another thread's launch on this context (kbest_batch_f64_dev on a stream of
+    // its own) must neither slip in between them nor overlap them -- it is ordered behind ctx->stream, which waits for every
+    // piece below.
+    std::unique_lock<std::recursive_mutex> pieceLock(ctx->mu, std::defer_lock);
     if (nPiece > 1) {
         // the pieces run on other streams than the context's previous (possibly still running) launch: order them behind it
-        std::lock_guard<std::mutex> lock(ctx->mu);
+        pieceLock.lock();
         rc = order_behind_last(ctx, ctx->stream);
         if (rc == KBEST_OK && (hipEventCreateWithFlags(&start, hipEventDisableTiming) != hipSuccess || hipEventRecord(start, ctx->stream) != hipSuccess))
             rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: event", hipGetLastError());
@@ -1046,6 +1100,7 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
         // (registered cost blocks: asynchronous copies, all pieces' at once -- they share the link, so the first piece's kernel
         //  starts ~0.3 ms into the call; chaining the copies with events, or blocking copies piece by piece, measured slower:
         //  3.9 - 4.1 ms per call against 3.7)
+        if (keep && keep->stamps && c == 0) keep->stamps[0] = kb::now_s();
         if (zcCost) e = hipSuccess;
         else if (pinnedCost) e = hipMemcpyAsync(dCost.as<double>() + cOff, cost + cOff, cLen * 8, hipMemcpyHostToDevice, st[c]);
         else e = hipMemcpy(dCost.as<double>() + cOff, cost + cOff, cLen * 8, hipMemcpyHostToDevice);  // (complete on return; earlier pieces run meanwhile)
@@ -1057,24 +1112,33 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
                             oC4R ? reinterpret_cast<int32_t *>(oC4R + (size_t)b0 * k * maxRow * esz) : nullptr, oGain + (size_t)b0 * k, oNf + b0,
                             pushed ? dPushed.as<int64_t>() + b0 : nullptr, st[c], true, nullptr, nPiece > 1 ? &sub : nullptr);
         if (rc != KBEST_OK) break;
-        // slots beyond nf are never written by the kernels: give them defined values (row4col / col4row -1, gain 0)
-        e = kb::launch_fill_unused(oNf + b0, nb, k, maxCol, maxRow, reinterpret_cast<int32_t *>(oR4C + (size_t)b0 * k * maxCol * esz),
+        if (keep && keep->stamps && c == 0) keep->stamps[1] = kb::now_s();
+        // slots beyond nf are never written by the kernels, nor is the padding of a ragged batch's emitted slots: give them
+        // defined values (row4col / col4row -1, gain 0)
+        e = kb::launch_fill_unused(oNf + b0, nRow ? dNR.as<int32_t>() + b0 : nullptr, nRow ? dNC.as<int32_t>() + b0 : nullptr, nb, k, maxCol, maxRow,
+                                   reinterpret_cast<int32_t *>(oR4C + (size_t)b0 * k * maxCol * esz),
                                    oC4R ? reinterpret_cast<int32_t *>(oC4R + (size_t)b0 * k * maxRow * esz) : nullptr, oGain + (size_t)b0 * k, tabI8,
                                    st[c]);
         if (e != hipSuccess) { rc = fail(ctx, KBEST_ERR_HIP, "fill kernel launch", e); break; }
-        if (!direct && nPiece > 1 &&
+        if (nPiece > 1 &&
             (hipEventCreateWithFlags(&done[c], hipEventDisableTiming) != hipSuccess || hipEventRecord(done[c], st[c]) != hipSuccess))
             rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: event", hipGetLastError());
+    }
+    if (nPiece > 1) {
+        for (int c = 1; c < nPiece; c++)  // whatever is ordered behind the context's stream from now on is behind every piece
+            if (done[c] && hipStreamWaitEvent(ctx->stream, done[c], 0) != hipSuccess && rc == KBEST_OK)
+                rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: wait", hipGetLastError());
+        pieceLock.unlock();
     }
     if (rc == KBEST_OK && !direct) {
         for (int c = 0; c < nPiece && rc == KBEST_OK; c++) {
             const int b0 = (int)((long long)B * c / nPiece), nb = (int)((long long)B * (c + 1) / nPiece) - b0;
             hipError_t e = (nPiece > 1) ? hipEventSynchronize(done[c]) : hipStreamSynchronize(ctx->stream);
             const size_t rOff = (size_t)b0 * k * maxCol * esz, cOff = (size_t)b0 * k * maxRow * esz;
-            if (e == hipSuccess) e = hipMemcpy(reinterpret_cast<char *>(row4col) + rOff, dR4C.as<char>() + rOff, (size_t)nb * k * maxCol * esz, hipMemcpyDeviceToHost);
-            if (e == hipSuccess && col4row) e = hipMemcpy(reinterpret_cast<char *>(col4row) + cOff, dC4R.as<char>() + cOff, (size_t)nb * k * maxRow * esz, hipMemcpyDeviceToHost);
-            if (e == hipSuccess) e = hipMemcpy(gain + (size_t)b0 * k, dGain.as<double>() + (size_t)b0 * k, (size_t)nb * k * 8, hipMemcpyDeviceToHost);
-            if (e == hipSuccess) e = hipMemcpy(nf + b0, dNf.as<int32_t>() + b0, (size_t)nb * 4, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(reinterpret_cast<char *>(row4col) + rOff, sR4C + rOff, (size_t)nb * k * maxCol * esz, hipMemcpyDeviceToHost);
+            if (e == hipSuccess && col4row) e = hipMemcpy(reinterpret_cast<char *>(col4row) + cOff, sC4R + cOff, (size_t)nb * k * maxRow * esz, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(gain + (size_t)b0 * k, sGain + (size_t)b0 * k, (size_t)nb * k * 8, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(nf + b0, sNf + b0, (size_t)nb * 4, hipMemcpyDeviceToHost);
             if (e == hipSuccess && pushed) e = hipMemcpy(pushed + b0, dPushed.as<int64_t>() + b0, (size_t)nb * 8, hipMemcpyDeviceToHost);
             if (e != hipSuccess) rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: copy back", e);
         }
@@ -1092,6 +1156,16 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
     for (int b = 0; b < B; b++)  // shapes were validated above: a negative count can only be an engine failure
         if (nf[b] < 0) return fail(ctx, nf[b] == -1 ? KBEST_ERR_UNSUPPORTED : KBEST_ERR_INTERNAL, "kbest_batch_f64: a problem came back with nf < 0");
     return KBEST_OK;
+}
+
+extern "C" {
+
+int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, int maxCol,
+                    const int32_t *nRow, const int32_t *nCol, const double *cost,
+                    const int64_t *costOff, int k, int32_t *row4col, int32_t *col4row, double *gain,
+                    int32_t *nf, int64_t *pushed)
+{
+    return kbest_batch_f64_keep(ctx, opts, B, maxRow, maxCol, nRow, nCol, cost, costOff, k, row4col, col4row, gain, nf, pushed, nullptr);
 }
 
 int kbest_merge_topk_f64_dev(kbest_ctx *ctx, int B, int nShard, int k, int maxCol, int maximize, const void *d_gain,
@@ -1261,7 +1335,7 @@ static int weights_small(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t
     int nw = 0;
     if (!small_fits(ctx, B, capRow, maxCol, k, true, &nw)) return 1;
     if (!condition && rawMaxRow > kb::SMALL_MAX_DIM) return 1;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     {
         int rc = order_behind_last(ctx, ctx->stream);
@@ -1394,7 +1468,7 @@ extern "C" int kbest_assoc_probs_batch_f64_dev(kbest_ctx *ctx, int B, int maxRaw
         (!condition && maxRawRow > kb::SMALL_MAX_DIM) || !small_fits(ctx, B, capRow, maxCol, k, true, &nw))
         return fail(ctx, KBEST_ERR_UNSUPPORTED, "kbest_assoc_probs_batch_f64_dev: frames beyond the fused association kernel "
                                                 "(nM <= 32, k <= 1024; without conditioning nL + nM <= 32)");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
     int rc = order_behind_last(ctx, s);
@@ -1439,7 +1513,7 @@ extern "C" int kbest_reserve_assoc(kbest_ctx *ctx, int B, int maxRawRow, int max
     int nw = 0;
     if (maxCol > kb::SMALL_MAX_DIM || !small_fits(ctx, B, capRow, maxCol, k, true, &nw))
         return fail(ctx, KBEST_ERR_UNSUPPORTED, "kbest_reserve_assoc: frames beyond the fused association kernel");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     return ensure_states(ctx, small_states_need(B, capRow, maxCol, k, nw), true);
 }
 
@@ -1622,7 +1696,7 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
     w.gate = bruteForce ? 0 : 1;
     w.solveRows = maxRow;
     {
-        std::lock_guard<std::mutex> lock(ctx->mu);
+        std::lock_guard<std::recursive_mutex> lock(ctx->mu);
         hipError_t e = kb::launch_weights(w, B, ctx->stream);
         if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "weights kernel launch", e);
     }
@@ -1815,7 +1889,7 @@ int kbest_condition_costs_f64(kbest_ctx *ctx, int B, const int32_t *nRow, const 
     c.rowIdx = dRowIdx.as<int>();
     c.maxRow = maxRow;
     {
-        std::lock_guard<std::mutex> lock(ctx->mu);
+        std::lock_guard<std::recursive_mutex> lock(ctx->mu);
         hipError_t e = kb::launch_condition(c, B, ctx->stream);
         if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "condition kernel launch", e);
     }

@@ -45,6 +45,11 @@ struct Params {
     int gainCols;             // numCol4Gain of shortestPathCPP (cpp:232); 0 = numCol
     int split, splitB;        // split > 1 (64-row kernel): `split` workgroups per matrix, splitB matrices; tables / work space per workgroup
     unsigned long long *sharedT;  // [splitB] smallest threshold any share of a matrix has published (ordered key; ~0 = none)
+    // optimistic bounds (64-row kernel; kbest_engine.hip "optimistic bounds and tickets"): a node is split against the optRho-quantile
+    // of the pool's candidates instead of its last one; optRho grows linearly from optRho0 to optRho1 while the first optPhi * k
+    // solutions go out.  optRho0 >= 1: off.
+    float optRho0, optRho1, optPhi, optKappa;
+    int optMinPool;           // candidates the pool must hold before a quantile of it is used
 };
 
 struct CondParams {
@@ -81,17 +86,19 @@ struct WeightParams {
 // forbidden-row mask, gain, activeCol.
 __host__ __device__ inline long long state_stride(int maxRow)
 {
-    // u, v (fp64), row4col, col4row (u8), forbidden mask, gain, activeCol; rounded to whole 128-byte
-    // lines: neighbouring states never share a cache line
-    return ((((long long)18 * maxRow + 7) & ~7LL) + 24 + 127) & ~127LL;
+    // u, v (fp64), row4col, col4row (u8), forbidden mask, gain, activeCol, columns whose child has been completed (u64: the
+    // 64-row kernel's re-split tickets); rounded to whole 128-byte lines: neighbouring states never share a cache line
+    return ((((long long)18 * maxRow + 7) & ~7LL) + 32 + 127) & ~127LL;
 }
 
 // u16 entries of one matrix's slot -> state table, rounded to whole 128-byte lines
 __host__ __device__ inline long long slot_table_stride(int k) { return (((long long)k * 2 + 127) & ~127LL) / 2; }
 
 // LDS carve-up of one workgroup (= one cost matrix).
+constexpr int OPT_TICKETS = 64;   // re-split tickets a problem can hold (one wave sorts them)
+constexpr int OPT_BYTES = 16 * 8 * 3 + 16 + 8 + OPT_TICKETS * 10 + 8;  // struct Opt (kbest_engine.hip)
 struct Lds {
-    int offC, offNodes, nodeStride, offFreshG, offFreshM, offPoolG, offPoolM, offPoolS, offSurv, offFreshS, offRootMap, offPerm, offCtrl, offGainW, total;
+    int offC, offNodes, nodeStride, offFreshG, offFreshM, offPoolG, offPoolM, offPoolS, offSurv, offFreshS, offRootMap, offPerm, offCtrl, offOpt, offGainW, total;
 };
 
 __host__ __device__ inline Lds lds_layout(int maxRow, int k, int spec, int nWaves)
@@ -115,6 +122,8 @@ __host__ __device__ inline Lds lds_layout(int maxRow, int k, int spec, int nWave
     L.offPerm = o;       o += 128;                   // column order of the enumeration: original column of a position, and back
     o = (o + 7) & ~7;
     L.offCtrl = o;       o += 232;                   // struct Ctrl
+    o = (o + 7) & ~7;
+    L.offOpt = o;        o += OPT_BYTES;             // struct Opt: optimistic bounds, per-node accumulators, re-split tickets
     o = (o + 15) & ~15;
     L.offGainW = o;      o += nWaves * 512;          // one line of gain terms per wave (calcGain)
     L.total = (o + 15) & ~15;
@@ -403,9 +412,13 @@ struct MergeParams {
     int *outCol4row;               // [B][k][ldRow] or nullptr: the inverse of the merged row4col, -1 for rows without a column
     int ldRow;
 };
+// kbest_batch_f64 with the tables staged in (and left in) caller-owned device buffers: the multi-device entry's per-device step
+// (kbest_capi.cpp).  stamps (optional): host times (seconds, steady clock) at which the first upload / the first kernel was issued.
+struct KeepTables { int32_t *row4col, *col4row; double *gain; int32_t *nf; double *stamps; };
+double now_s();
 hipError_t launch_merge_topk(const MergeParams &p, int B, hipStream_t stream);
-hipError_t launch_fill_unused(const int *nf, int B, int k, int ldCol, int ldRow, int *row4col, int *col4row, double *gain, bool tablesI8,
-                              hipStream_t stream);
+hipError_t launch_fill_unused(const int *nf, const int *nRow, const int *nCol, int B, int k, int ldCol, int ldRow, int *row4col,
+                              int *col4row, double *gain, bool tablesI8, hipStream_t stream);
 hipError_t launch_kbest_lane(const Params &p, int B, int nWaves, int lanesPerChild, hipStream_t stream);
 hipError_t launch_kbest_small(const SmallParams &p, int B, int nWaves, hipStream_t stream);
 hipError_t launch_kbest(const Params &p, int B, int nWaves, hipStream_t stream);
@@ -419,4 +432,8 @@ hipError_t launch_condition(const CondParams &p, int B, hipStream_t stream);
 hipError_t launch_to_probs(double *x, long long n, hipStream_t stream);
 
 }  // namespace kb
+
+int kbest_batch_f64_keep(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, int maxCol, const int32_t *nRow,
+                         const int32_t *nCol, const double *cost, const int64_t *costOff, int k, int32_t *row4col,
+                         int32_t *col4row, double *gain, int32_t *nf, int64_t *pushed, const kb::KeepTables *keep);
 #endif

@@ -103,6 +103,31 @@ struct Ctrl {
 };
 static_assert(sizeof(Ctrl) <= 232, "Ctrl must fit the LDS slot reserved by lds_layout");
 
+// Optimistic bounds and re-split tickets.  The pool's threshold T (the gain of its last entry once it holds k - emitted
+// candidates) is a VALID bound, but a loose one for most of the run: half of the children that complete under it never make
+// the k best (tests/dev/proto_tickets.cpp: 4 096 x 32x32, k = 200: 498 completions per matrix for 199 that are needed).  A node is
+// therefore split against an OPTIMISTIC bound Tg <= T -- a quantile of the pool's candidates -- and the children that die
+// between the two are not lost: the smallest lower bound among them (first + last arc at the filter, the settled distance at
+// which a search was given up) is kept as the node's TICKET.  Tickets are a small sorted list beside the pool: a candidate
+// is only emitted while its gain is below the smallest ticket key, and a ticket that reaches the front of the union is
+// selected like a candidate -- its node is split AGAIN against a higher bound, skipping the children that completed before
+// (`done` mask, kept with the node's saved state).  Whatever Tg is, the enumeration stays exact: an optimistic guess costs
+// a re-split, never a result.  Measured on the host model: completions 498 -> 292, Dijkstra steps -24 %, 3 tickets per
+// matrix, rounds + 2 %.
+struct Opt {
+    u64 defKey[16];     // per node of this round: smallest lower bound among its deferred children (ordered key of the shifted gain; ~0: none)
+    u64 done[16];       // per node: positions (columns in the enumeration's order) whose child has completed, now or in an earlier split
+    double bAbs[16];    // per node: the (absolute, shifted-gain) optimistic bound it is split against, set when it is selected
+    double gRoot;       // the optimum's shifted gain
+    int nT;             // tickets in the list
+    u32 selTicket;      // bit w: node w of this round is a ticket (a re-split)
+    int anyFinite;      // some node of this round has a finite optimistic bound (the filter's last-arc pass is worth running)
+    double TK[OPT_TICKETS];          // ticket keys, ascending
+    unsigned short TS[OPT_TICKETS];  // state slot of each ticket's node
+};
+static_assert(sizeof(Opt) <= OPT_BYTES, "Opt must fit the LDS slot reserved by lds_layout");
+constexpr int OPT_TSEL = 4;  // tickets that can be selected in one round (the first ones of the list)
+
 
 // A-priori threshold on the k-th best gain, computed once per problem when the root's children are solved (round 1).
 // Every child of the root differs from the optimum by ONE alternating path ("atom": extra cost d_i, rows moved m_i).
@@ -336,6 +361,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     u64 *lbKey = reinterpret_cast<u64 *>(smem + L.offFreshG);
     unsigned short *freshS = reinterpret_cast<unsigned short *>(smem + L.offFreshS);
     Ctrl *ctrl = reinterpret_cast<Ctrl *>(smem + L.offCtrl);
+    Opt *opt = reinterpret_cast<Opt *>(smem + L.offOpt);
     // column order of the enumeration (phase 1b): colOf[position] = the reference's column, posOf = its inverse
     unsigned char *colOf = smem + L.offPerm, *posOf = colOf + 64;
     double *gainW = reinterpret_cast<double *>(smem + L.offGainW) + wave * 64;  // this wave's line of gain terms
@@ -423,7 +449,11 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             ctrl->outDone = 0;
             ctrl->outTicket = 0;
             ctrl->tShared = INF;
-            for (int i = 0; i < 16; i++) ctrl->partsDone[i] = 0;
+            for (int i = 0; i < 16; i++) { ctrl->partsDone[i] = 0; opt->defKey[i] = ~0ull; opt->done[i] = 0ull; opt->bAbs[i] = INF; }
+            opt->nT = 0;
+            opt->selTicket = 0u;
+            opt->anyFinite = 0;
+            opt->gRoot = 0.0;
         }
         __syncthreads();
         for (int i = tid; i < spec * 64; i += NT) { lbKey[i] = ~0ull; lbIn[i] = ~0u; }  // (`red` is dead now)
@@ -443,6 +473,11 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     // the second, sharper threshold (atoms learnt in round 1) needs the "one connected change" test: permutation cycles,
     // i.e. square problems (on rectangular ones a change can be an open path through the unassigned rows)
     const bool t1On = t0On && N == M && spec * 64 >= T0_SCRATCH + 64;
+    // optimistic bounds with re-split tickets (struct Opt): not where the reference's own order of operations is the point
+    // (push counts, the unpruned mode, the assign2D entries) and not in split launches (their shares trade thresholds)
+    const bool optOn = prune && S == 1 && !rect && k >= 3 && p.optRho0 < 1.0f &&
+                       !(p.flags & (KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_OPT | KBEST_FLAG_EXACT_ROOT));
+    const int offDone = ((18 * p.maxRow + 7) & ~7) + 24;  // saved state: columns whose child has been completed
     unsigned char *rootMap = smem + L.offRootMap;  // the optimum's col4row (lane = row)
     // saved hypothesis (HBM): u[D'] v[D'] (fp64) | row4col[D'] col4row[D'] (u8) | forb, gain, activeCol
     const long long outBase = (long long)blk * k;
@@ -601,6 +636,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             if (p.dualU && lane < M) p.dualU[(long long)b * p.ldCol + lane] = nd.u[lane];  // MurtyHyp::u, per column (hpp:53)
             if (p.dualV && lane < N) p.dualV[(long long)b * p.ldRow + lane] = v;           // MurtyHyp::v, per row (hpp:55)
             if (t0On && lane == 0) atoms[2 * D] = (u64)__double_as_longlong(g);
+            if (lane == 0) opt->gRoot = g;
             if (t0On && lane < D) rootMap[lane] = (unsigned char)c4r;
             if (lane == 0) {
                 ctrl->cutoffGain = maximize ? (g - p.cutoff) : (g + p.cutoff);          // cpp:681/684
@@ -802,6 +838,8 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             }
         }
         const double cmaxv = ctrl->cmax;
+        // (the optimistic bounds of this round's nodes were set when they were selected: opt->bAbs[w], struct Opt)
+        const bool optAny = optOn && uni32(opt->anyFinite) != 0;
         KB_T(tF0);
         KB_ACC(14, tF0 - tRound);  // [14] round prologue (control reads)
         int myNode = -1, myParts = 1;  // the node whose filter this wave took part in
@@ -878,7 +916,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 // of (C[fr,j] - u[j]) - v[fr] (high word, clamped at 0: a lower bound) -- first arc and last arc are
                 // different arcs of the same path and all reduced costs are >= 0, so first + last > bound kills the
                 // child here, and what survives starts its search against bound - minIn.
-                if (prune && T < INF) {
+                if (prune && (T < INF || optAny)) {
                     const int fr = (int)nd.r4c[cc];
                     const double vfr = nd.v[fr];
                     const double *Crow = Cs + fr;
@@ -923,14 +961,30 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             const int a = uni32(nd.info[0]);
             const int sid = uni32(nd.info[1]);
             const double pgain = nd.gain[0];
-            const double bound = (prune && T < INF) ? (T - pgain) + 1e-9 * (fabs(T) + cmaxv) : INF;
+            // boundV: against the pool's valid threshold; bound: against this node's optimistic bound (<= boundV).  A child between
+            // the two is deferred: its lower bound goes into the node's ticket (struct Opt)
+            const double boundV = (prune && T < INF) ? (T - pgain) + 1e-9 * (fabs(T) + cmaxv) : INF;
+            double bAbs = T;
+            if (optOn) { const double bo = opt->bAbs[myNode]; bAbs = bo < T ? bo : T; }
+            const double bound = (prune && bAbs < INF) ? (bAbs - pgain) + 1e-9 * (fabs(bAbs) + cmaxv) : INF;
+            const u64 doneM = optOn ? uni64(opt->done[myNode]) : 0ull;  // children completed in an earlier split of this node
             const int c = a + lane;
-            const bool live = c < M && !(sid == 0 && rcStride > 1 && (c % rcStride) != rcOffset);
+            // (root-subtree sharding partitions on the REFERENCE's column, kbest_c.h: the enumeration's own order depends on the launch
+            //  shape and the knobs, and shards that differ in them must still enumerate disjoint, complete partitions)
+            const bool live = c < M && !(sid == 0 && rcStride > 1 && ((int)colOf[c & 63] % rcStride) != rcOffset) &&
+                              !((doneM >> (c & 63)) & 1ull);
             const u64 key = lbKey[myNode * 64 + lane];
             const double m = from_key((int)((u32)(key >> 32) ^ 0x80000000u), (u32)key);
             const u32 inH = lbIn[myNode * 64 + lane];
-            const double minIn = (prune && T < INF) ? __hiloint2double((int)inH, 0) : 0.0;  // +inf: no last arc at all
+            const double minIn = (prune && (T < INF || optAny)) ? __hiloint2double((int)inH, 0) : 0.0;  // +inf: no last arc at all
             const bool keep = live && m < INF && !(m + minIn > bound);
+            if (optOn && live && (m + minIn) < INF && (m + minIn > bound) && !(m + minIn > boundV)) {
+                // deferred at the filter: first arc + last arc is a lower bound of the child's distance
+                int khi;
+                u32 klo;
+                to_key(pgain + (m + minIn), khi, klo);
+                atomicMin(&opt->defKey[myNode], ((u64)((u32)khi ^ 0x80000000u) << 32) | klo);
+            }
             // Children whose first step is far inside the bound tend to run long (they are the ones that complete):
             // they are queued from the front, the others from the back, so that the long ones start first and the
             // round does not end waiting for one late straggler.
@@ -1009,8 +1063,11 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                     c4rP = (lane < D) ? (int)nd.c4r[lane] : -1;
                     r4cP = (lane < D) ? (int)nd.r4c[lane] : -1;
                     // early-termination bound on the Dijkstra distance: child gain = parent gain + delta (up to
-                    // rounding), so delta > (T - parent gain) + margin can never enter the k best.
-                    bound = (prune && T < INF) ? (T - pgain) + 1e-9 * (fabs(T) + cmaxv) : INF;
+                    // rounding), so delta > (T - parent gain) + margin can never enter the k best.  The search runs against the
+                    // node's optimistic bound (struct Opt); boundV is the valid one.
+                    double bAbsN = T;
+                    if (optOn) { const double bo = opt->bAbs[w]; bAbsN = bo < T ? bo : T; }
+                    bound = (prune && bAbsN < INF) ? (bAbsN - pgain) + 1e-9 * (fabs(bAbsN) + cmaxv) : INF;
                 }
                 const int fr = __builtin_amdgcn_readlane(r4cP, c);           // row freed: cpp:277-278
                 const u64 cand = __ballot(lane < D && c4rP >= c);             // rows of columns >= c: cpp:480-488, 525-527
@@ -1028,7 +1085,24 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 KB_T(tDij1);
                 KB_ACC(8, tDij1 - tDij0);  // [8] cycles inside child Dijkstra
                 KB_ACC(5, __popcll(scanned) + (st != 0));  // [5] child Dijkstra steps (approx: scanned rows)
-                if (st != 0) continue;
+                if (st != 0) {
+                    // given up against the optimistic bound: the child's gain is beyond that bound, and at least parent gain +
+                    // the distance settled so far -- deferred (the node's ticket) unless that is beyond the valid bound too
+                    // (the node's bounds are fetched again here rather than kept in registers across the child loop)
+                    if (optOn && st == 2) {
+                        const double pg = nd.gain[0], bo = opt->bAbs[w];
+                        const double boundV = (T < INF) ? (T - pg) + 1e-9 * (fabs(T) + cmaxv) : INF;
+                        if (bo < T && !(delta > boundV) && lane == 0) {
+                            const double lbAbs = pg + delta;
+                            int khi;
+                            u32 klo;
+                            to_key(lbAbs > bo ? lbAbs : bo, khi, klo);
+                            atomicMin(&opt->defKey[w], ((u64)((u32)khi ^ 0x80000000u) << 32) | klo);
+                        }
+                    }
+                    continue;
+                }
+                if (optOn && lane == 0) atomicOr(&opt->done[w], 1ull << c);  // never generated again when the node is split again
                 KB_ACC(6, 1);  // [6] children completed
                 // The child survived: finish it the way shortestPathUpdateCPP does -- path flip (cpp:108-116), exact
                 // gain (calcGain, cpp:59-80) and,
@@ -1121,6 +1195,49 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         //    entries into registers), keep the R smallest.  Ties in gain are ordered by (parent, column), so the
         //    result does not depend on the arrival order of the fresh list.
         const int nFresh = uni32(ctrl->nFresh);
+        if (optOn && wave == NW - 1) {
+            // The tickets (struct Opt), one wave, lane = node for the new ones and lane = list index for the old ones: the
+            // nodes split in this round get their `done` masks saved with their states and, where children were deferred, a
+            // ticket keyed by the smallest lower bound among them (minus twice the pruning margin: the bounds are sums of
+            // rounded terms, the gains they are compared with are serial sums); tickets consumed by this round's re-splits
+            // and tickets beyond the valid threshold leave the list; the list stays sorted.
+            const int nTo = uni32(opt->nT);
+            const u32 selTicket = (u32)uni32((int)opt->selTicket);
+            const bool isNode = lane < nsel;
+            const u64 dk = isNode ? opt->defKey[lane] : ~0ull;
+            if (__ballot(dk != ~0ull) != 0ull || selTicket != 0u || nTo != 0) {
+            const int sidL = isNode ? (int)ctrl->selSid[lane] : 0;
+            double nK = INF;
+            if (dk != ~0ull) {
+                const double lb = from_key((int)((u32)(dk >> 32) ^ 0x80000000u), (u32)dk);
+                nK = lb - 2e-9 * (fabs(lb) + cmaxv);
+            }
+            const bool hasNew = isNode && dk != ~0ull && !(nK > T);  // (beyond the valid threshold: nothing of it can be output)
+            if (hasNew) *reinterpret_cast<u64 *>(stBase + (long long)sidL * p.stateStride + offDone) = opt->done[lane];
+            if (isNode) opt->defKey[lane] = ~0ull;
+            const double oK = lane < nTo ? opt->TK[lane] : INF;
+            const int oS = lane < nTo ? (int)opt->TS[lane] : -1;
+            bool consumed = false;
+            for (int w = 0; w < nsel; w++)
+                if ((selTicket >> w) & 1u) consumed = consumed || (oS == __builtin_amdgcn_readlane(sidL, w));
+            const bool oKeep = lane < nTo && !consumed && !(oK > T);
+            const u64 keepM = __ballot(oKeep);
+            u64 newM = __ballot(hasNew);
+            int posO = __popcll(keepM & ((1ull << lane) - 1ull)), posN = 0;
+            for (u64 mm = newM; mm; mm &= mm - 1) {
+                const int w = __builtin_ctzll(mm);
+                const double kw = readlane_f64(nK, w);
+                posO += (kw < oK) ? 1 : 0;                                    // old before new among equal keys
+                const int cntOld = __popcll(__ballot(oKeep && oK <= kw));
+                posN = (lane == w) ? posN + cntOld : posN;
+                posN += (hasNew && lane != w && (kw < nK || (kw == nK && w < lane))) ? 1 : 0;
+            }
+            wave_fence();
+            if (oKeep) { opt->TK[posO] = oK; opt->TS[posO] = (unsigned short)oS; }
+            if (hasNew) { opt->TK[posN] = nK; opt->TS[posN] = (unsigned short)sidL; }
+            if (lane == 0) opt->nT = __popcll(keepM) + __popcll(newM);
+            }
+        }
         double og[EPT];
         u32 om[EPT];
         unsigned short os[EPT];
@@ -1205,34 +1322,87 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         for (int w = 0; w < MS; w++) { sIdx[w] = -1; sSid[w] = 0; }
         // wave 0 walks the whole selection (it writes the control block); wave w only as far as its own, the w-th
         const int walk = (wave == 0 || budget <= wave) ? budget : wave + 1;
-        for (int base = 0; base < nq && nselNew < walk; base += 64) {
-            const int i = base + lane;
-            const bool open = i < nq && !(PM[i] & META_SPLIT) && !(S > 1 && PG[i] > tShared);
-            const unsigned short ps = (i < nq) ? PS[i] : SID_NONE;
-            u64 m = __ballot(open);
-            const u64 lazyM = __ballot(open && ps == SID_NONE);
-            while (m && nselNew < walk) {
-                const int bitpos = __builtin_ctzll(m);
-                const bool lazy = (lazyM >> bitpos) & 1ull;
-                const int sidv = lazy ? sidBase + nLazy : __builtin_amdgcn_readlane((int)ps, bitpos);
-                if (nselNew == wave) { mySel = base + bitpos; mySid = sidv; }
+        // Re-split tickets (struct Opt) take their places in the selection by key, between the candidates: the first OPT_TSEL
+        // of the (sorted) list are considered per round.  myTicket: this wave's node is a ticket; sTickM: which of the round's.
+        const int nTl = optOn ? uni32(opt->nT) : 0;
+        const int nTc = nTl < OPT_TSEL ? nTl : OPT_TSEL;
+        double tMin = INF;  // emission stops at the smallest ticket key (+inf: no ticket)
+        bool myTicket = false;
+        u32 sTickM = 0u;
+        if (nTc == 0) {
+            for (int base = 0; base < nq && nselNew < walk; base += 64) {
+                const int i = base + lane;
+                const bool open = i < nq && !(PM[i] & META_SPLIT) && !(S > 1 && PG[i] > tShared);
+                const unsigned short ps = (i < nq) ? PS[i] : SID_NONE;
+                u64 m = __ballot(open);
+                const u64 lazyM = __ballot(open && ps == SID_NONE);
+                while (m && nselNew < walk) {
+                    const int bitpos = __builtin_ctzll(m);
+                    const bool lazy = (lazyM >> bitpos) & 1ull;
+                    const int sidv = lazy ? sidBase + nLazy : __builtin_amdgcn_readlane((int)ps, bitpos);
+                    if (nselNew == wave) { mySel = base + bitpos; mySid = sidv; }
+                    if (wave == 0) {
+#pragma unroll
+                        for (int w = 0; w < MS; w++) if (w == nselNew) { sIdx[w] = base + bitpos; sSid[w] = sidv; }
+                    }
+                    nLazy += lazy ? 1 : 0;
+                    nselNew++;
+                    m &= m - 1;
+                }
+            }
+        } else {
+            const double tkL = (lane < nTc) ? opt->TK[lane] : INF;
+            tMin = readlane_f64(tkL, 0);
+            int tNext = 0;
+            auto place_ticket = [&]() {  // the next ticket of the list takes selection rank nselNew
+                const int sidT = uni32((int)opt->TS[tNext]);
+                const double keyT = readlane_f64(tkL, tNext);
+                if (nselNew == wave) { mySel = -1; mySid = sidT; myTicket = true; }
                 if (wave == 0) {
 #pragma unroll
-                    for (int w = 0; w < MS; w++) if (w == nselNew) { sIdx[w] = base + bitpos; sSid[w] = sidv; }
+                    for (int w = 0; w < MS; w++) if (w == nselNew) { sIdx[w] = -1; sSid[w] = sidT; }
+                    if (lane == 0) opt->bAbs[nselNew] = keyT;  // (the ticket's key: turned into the node's bound below)
                 }
-                nLazy += lazy ? 1 : 0;
+                sTickM |= 1u << nselNew;
                 nselNew++;
-                m &= m - 1;
+                tNext++;
+            };
+            for (int base = 0; base < nq && nselNew < walk; base += 64) {
+                const int i = base + lane;
+                const bool open = i < nq && !(PM[i] & META_SPLIT) && !(S > 1 && PG[i] > tShared);
+                const unsigned short ps = (i < nq) ? PS[i] : SID_NONE;
+                const double pgL = (i < nq) ? PG[i] : 0.0;
+                u64 m = __ballot(open);
+                const u64 lazyM = __ballot(open && ps == SID_NONE);
+                while (m && nselNew < walk) {
+                    const int bitpos = __builtin_ctzll(m);
+                    if (tNext < nTc) {  // tickets at or below this candidate's gain go first
+                        const double gC = readlane_f64(pgL, bitpos);
+                        while (tNext < nTc && nselNew < walk && readlane_f64(tkL, tNext) <= gC) place_ticket();
+                        if (nselNew >= walk) break;
+                    }
+                    const bool lazy = (lazyM >> bitpos) & 1ull;
+                    const int sidv = lazy ? sidBase + nLazy : __builtin_amdgcn_readlane((int)ps, bitpos);
+                    if (nselNew == wave) { mySel = base + bitpos; mySid = sidv; }
+                    if (wave == 0) {
+#pragma unroll
+                        for (int w = 0; w < MS; w++) if (w == nselNew) { sIdx[w] = base + bitpos; sSid[w] = sidv; }
+                    }
+                    nLazy += lazy ? 1 : 0;
+                    nselNew++;
+                    m &= m - 1;
+                }
             }
+            while (tNext < nTc && nselNew < walk) place_ticket();  // tickets beyond the last open candidate
         }
         // The saved state of this wave's node: the loads are issued here and land in registers while wave 0 does the
         // emission bookkeeping below (it has a node of its own to bring in, and would otherwise be the last at the barrier
         // every round by exactly that bookkeeping).
         const bool haveNode = wave < nselNew;
-        const bool lazyNode = haveNode && uni32((int)PS[mySel]) == (int)SID_NONE;
+        const bool lazyNode = haveNode && !myTicket && uni32((int)PS[mySel < 0 ? 0 : mySel]) == (int)SID_NONE;
         double ldU = 0.0, ldV = 0.0, ldGain = 0.0;
         int ldR = 0, ldC = 0, ldA = 0;
-        u64 ldForb = 0;
+        u64 ldForb = 0, ldDone = 0;
         if (haveNode && !lazyNode) {
             const unsigned char *st = stBase + (long long)mySid * p.stateStride;
             const double *sd = reinterpret_cast<const double *>(st);
@@ -1246,6 +1416,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 ldForb = *reinterpret_cast<const u64 *>(st + offTail);
                 ldGain = *reinterpret_cast<const double *>(st + offTail + 8);
                 ldA = *reinterpret_cast<const int *>(st + offTail + 16);
+                if (myTicket) ldDone = *reinterpret_cast<const u64 *>(st + offDone);  // (a first split starts from an empty mask)
             }
         }
         if (wave == 0) {
@@ -1266,7 +1437,8 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 const double gu = maximize ? (-g + cdel) : (g + cdel);  // cpp:626-630
                 const bool cutB = useCut && valid && (maximize ? (gu < g0u - p.cutoff) : (gu > g0u + p.cutoff));
                 const bool shB = S > 1 && valid && g > tShared;  // beyond the global k-th best: this share is done
-                const u64 plainM = __ballot(valid && (meta & META_SPLIT) && !cutB && !shB);
+                const bool tickB = valid && !(g < tMin);  // a re-split ticket comes first: its node may still hold something better
+                const u64 plainM = __ballot(valid && (meta & META_SPLIT) && !cutB && !shB && !tickB);
                 int run = (~plainM == 0ull) ? 64 : __builtin_ctzll(~plainM);  // leading entries that simply go out
                 if (run > k - e) run = k - e;
                 if (lane < run) {
@@ -1282,6 +1454,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 const bool tSh = (__ballot(shB) >> run) & 1ull, tSplit = (__ballot((meta & META_SPLIT) != 0) >> run) & 1ull;
                 const bool tCut = (__ballot(cutB) >> run) & 1ull;
                 if (tSh) { stop = 1; break; }
+                if ((__ballot(tickB) >> run) & 1ull) break;  // behind a ticket: wait for its node's re-split
                 if (!tSplit && nselNew == 0) break;  // not split and not selected this round: wait
                 if (lane == run) {
                     p.gain[outBase + e] = gu;
@@ -1308,11 +1481,44 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 ctrl->head = h;
 #pragma unroll
                 for (int w = 0; w < MS; w++) { ctrl->selIdx[w] = (short)sIdx[w]; ctrl->selSid[w] = (unsigned short)sSid[w]; }
+                opt->selTicket = sTickM;
                 if (stop) ctrl->stop = 1;
+            }
+            if (optOn) {
+                // The optimistic bound of the nodes just selected (struct Opt), from the pool as it stands for their round: the gain
+                // at the rho-quantile of its candidates, rho growing from optRho0 to optRho1 while the first optPhi * k solutions
+                // go out (early on most of the pool is speculation, late most of it is the answer); for a ticket at least a step
+                // beyond its key (progress).  Any value is correct (the users take the minimum with the valid threshold); with no
+                // room for the round's tickets there is no guess.
+                const int Rn = k - e, nOldN = nq - h;
+                double Tv = (Rn > 0 && nOldN >= Rn) ? PG[h + Rn - 1] : INF;
+                if (useCut && !maximize && cutG < Tv) Tv = cutG;
+                double Tgn = Tv;
+                if (nOldN >= p.optMinPool && nTl + nselNew <= OPT_TICKETS) {
+                    const int n = nOldN < Rn ? nOldN : Rn;
+                    float fr = (float)e / (p.optPhi * (float)k);
+                    fr = fr > 1.0f ? 1.0f : fr;
+                    int qi = (int)((p.optRho0 + (p.optRho1 - p.optRho0) * fr) * (float)n);
+                    qi = qi >= n ? n - 1 : (qi < 0 ? 0 : qi);
+                    const double gq = PG[h + qi];
+                    if (gq < Tgn) Tgn = gq;
+                }
+                wave_fence();
+                double bA = Tgn;
+                if (lane < nselNew && ((sTickM >> lane) & 1u)) {
+                    const double K = opt->bAbs[lane];
+                    const double up = K + (double)p.optKappa * (K - opt->gRoot) + 8e-9 * (fabs(K) + ctrl->cmax);
+                    bA = up > bA ? up : bA;
+                }
+                bA = bA < Tv ? bA : Tv;
+                if (lane < nselNew) opt->bAbs[lane] = bA;
+                const u64 fin = __ballot(lane < nselNew && bA < INF);
+                if (lane == 0) opt->anyFinite = fin != 0ull ? 1 : 0;
             }
         }
         if (haveNode) {
             const NodeRef nd = node_ref(smem + L.offNodes + (size_t)wave * L.nodeStride, p.maxRow);
+            if (lane == 0) opt->done[wave] = ldDone;
             if (!lazyNode) {
                 // the hypothesis was kept when it was found: its state is in registers by now
                 if (lane < D) {

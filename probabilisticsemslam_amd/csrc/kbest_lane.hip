@@ -538,7 +538,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
                         const u32 nforb = *reinterpret_cast<const u32 *>(smem + nbN + N_FORB);
                         const int sidP = *reinterpret_cast<const int *>(smem + nbN + N_SID);
                         const u32 forb = (c == a) ? nforb : (1u << frN);                               // cpp:490 / cpp:510-516
-                        const bool live = got && !(sidP == 0 && p.rootColStride > 1 && (c % p.rootColStride) != p.rootColOffset);
+                        // (root-subtree sharding partitions on the REFERENCE's column, kbest_c.h: the enumeration's own order depends on the launch)
+                        const bool live = got && !(sidP == 0 && p.rootColStride > 1 && ((int)colOf[c] % p.rootColStride) != p.rootColOffset);
                         const double bnd = *reinterpret_cast<const double *>(smem + nbN + N_BOUND);
                         const u32 candP = (cand >> partRow) & ((1u << RL) - 1u), forbP = (forb >> partRow) & ((1u << RL) - 1u);
                         nb = got ? nbN : nb;

@@ -27,7 +27,8 @@ namespace kb {
 // is the exact double.  Early termination compares key high words in SALU and
 // falls back to an fp64 compare only when they are equal.
 // Returns 0 = path found, 1 = infeasible (cpp:197, 327), 2 = abandoned because
-// delta exceeds `bound` (only when EARLY).
+// delta exceeds `bound` (only when EARLY; deltaOut is then the settled distance
+// at which the search was given up: a lower bound of the child's distance).
 template <bool EARLY>
 __device__ __forceinline__ int dijkstra(const double *Cs, int LDC, const double *u, int rl, int lane,
                                         double v, int c4r, u64 cand, u64 forb, int start, double bound,
@@ -188,11 +189,11 @@ __device__ __forceinline__ int dijkstra(const double *Cs, int LDC, const double 
         if (__builtin_expect(mhi >= bndHi, 0)) {
             const double delta = __longlong_as_double((long long)dbits);
             if (mhi >= KEY_INF_HI) { scannedOut = cand0 & ~cand; return 1; }  // minimum is +inf: infeasible (cpp:197, 327)
-            if (EARLY && delta > bound) { scannedOut = cand0 & ~cand; return 2; }  // beyond the k best
+            if (EARLY && delta > bound) { scannedOut = cand0 & ~cand; deltaOut = delta; return 2; }  // beyond the k best (deltaOut: the distance reached)
             if (EARLY && useTight && delta > tight) {
                 const int slo = __double2loint(sp), shi = __double2hiint(sp);
                 const double sfr = __hiloint2double(__builtin_amdgcn_readlane(shi, sinkRow), __builtin_amdgcn_readlane(slo, sinkRow));
-                if (sfr > bound) { scannedOut = cand0 & ~cand; return 2; }  // the sink cannot come within the bound
+                if (sfr > bound) { scannedOut = cand0 & ~cand; deltaOut = delta; return 2; }  // the sink cannot come within the bound
                 useTight = false;
                 to_key(bound, bndHi, bndLo);
             }

@@ -96,29 +96,40 @@ __global__ void __launch_bounds__(256) merge_topk_kernel(MergeParams p)
 }
 
 // Output slots beyond the number found are never written by the enumeration kernels: give them the values the host
-// entries promise (row4col / col4row -1, gain 0) -- one workgroup per problem, nothing to do when nf == k.
+// entries promise (row4col / col4row -1, gain 0) -- one workgroup per problem.  In a ragged batch (nRow / nCol given) the
+// kernels write only row4col[.., c < nCol[b]] and col4row[.., r < nRow[b]] of an emitted slot: the padding of those slots,
+// columns [nCol[b], ldCol) and rows [nRow[b], ldRow), is -1 as well, so that the whole table is defined whatever the
+// buffer held before (recycled device blocks, the caller's registered memory).
 template <typename T>
-__global__ void __launch_bounds__(256) fill_unused_kernel(const int *nf, int k, int ldCol, int ldRow, T *row4col, T *col4row, double *gain)
+__global__ void __launch_bounds__(256) fill_unused_kernel(const int *nf, const int *nRow, const int *nCol, int k, int ldCol, int ldRow,
+                                                          T *row4col, T *col4row, double *gain)
 {
     const int b = blockIdx.x;
     int n = nf[b];
-    n = n < 0 ? 0 : n;
-    if (n >= k) return;
+    n = n < 0 ? 0 : (n > k ? k : n);
     const long long base = (long long)b * k;
+    if (nRow) {  // the padding of the emitted slots
+        const int M = nCol[b] < ldCol ? (nCol[b] > 0 ? nCol[b] : 0) : ldCol, N = nRow[b] < ldRow ? (nRow[b] > 0 ? nRow[b] : 0) : ldRow;
+        const int padC = ldCol - M, padR = ldRow - N;
+        for (int i = threadIdx.x; i < n * padC; i += 256) row4col[(base + i / padC) * ldCol + M + i % padC] = -1;
+        if (col4row)
+            for (int i = threadIdx.x; i < n * padR; i += 256) col4row[(base + i / padR) * ldRow + N + i % padR] = -1;
+    }
+    if (n >= k) return;
     for (int i = threadIdx.x + n * ldCol; i < k * ldCol; i += 256) row4col[base * ldCol + i] = -1;
     if (col4row)
         for (int i = threadIdx.x + n * ldRow; i < k * ldRow; i += 256) col4row[base * ldRow + i] = -1;
     for (int i = threadIdx.x + n; i < k; i += 256) gain[base + i] = 0.0;
 }
 
-hipError_t launch_fill_unused(const int *nf, int B, int k, int ldCol, int ldRow, int *row4col, int *col4row, double *gain, bool tablesI8,
-                              hipStream_t stream)
+hipError_t launch_fill_unused(const int *nf, const int *nRow, const int *nCol, int B, int k, int ldCol, int ldRow, int *row4col, int *col4row,
+                              double *gain, bool tablesI8, hipStream_t stream)
 {
     if (tablesI8)  // KBEST_FLAG_TABLES_I8: the same tables, one byte per entry
-        hipLaunchKernelGGL(fill_unused_kernel<signed char>, dim3(B), dim3(256), 0, stream, nf, k, ldCol, ldRow,
+        hipLaunchKernelGGL(fill_unused_kernel<signed char>, dim3(B), dim3(256), 0, stream, nf, nRow, nCol, k, ldCol, ldRow,
                            reinterpret_cast<signed char *>(row4col), reinterpret_cast<signed char *>(col4row), gain);
     else
-        hipLaunchKernelGGL(fill_unused_kernel<int>, dim3(B), dim3(256), 0, stream, nf, k, ldCol, ldRow, row4col, col4row, gain);
+        hipLaunchKernelGGL(fill_unused_kernel<int>, dim3(B), dim3(256), 0, stream, nf, nRow, nCol, k, ldCol, ldRow, row4col, col4row, gain);
     return hipGetLastError();
 }
 

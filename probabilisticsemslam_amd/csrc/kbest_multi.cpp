@@ -12,6 +12,13 @@
 // (kbest_merge.hip): the "global k-best heap" of the north star.  On any failure every device stream that was given work
 // is drained and an open RCCL group is closed before the entry returns.
 //
+// The host side is parallel: one worker thread per device feeds it (upload, launches: the single-device host path of
+// kbest_capi.cpp with its pieces, the tables staged in the device's slice) and reads ITS OWN slice of the results back, so no
+// device waits for another one's copies; the host times of every step are kept per device (kbest_multi_timeline).
+// Several entries of device_ids may name the SAME GPU ("logical devices": the one-GPU tests and the bench's multi-entry line
+// exercise the whole host path with G > 1 that way); RCCL cannot span one GPU twice, so such a context exchanges the
+// slices by device-to-device copies instead of ncclAllGather -- same buffers, same result.
+//
 // RCCL is bound at run time (dlopen of librccl.so.1): the library stays loadable -- and every single-device entry
 // usable -- on a host without RCCL, and a process that already carries another copy of RCCL (PyTorch bundles one) does
 // not get a second one forced into its link map unless it asks for the multi-device entries.
@@ -20,10 +27,14 @@
 #include <rccl/rccl.h>
 
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kbest_c.h"
+#include "kbest_engine.h"
 
 namespace {
 
@@ -63,6 +74,10 @@ struct Dev {
     hipStream_t stream = nullptr;
     ncclComm_t comm = nullptr;
     bool issued = false;        // work of the current call has been put on `stream`
+    hipEvent_t ev = nullptr;    // local exchange (logical devices): this device's slice is ready / its copies are out
+    int rc = 0;                 // result of this device's worker in the current call
+    std::string werr;
+    double t[KBEST_MULTI_STAMPS] = {0, 0, 0, 0, 0, 0};  // host times of the current call, seconds since its entry
     // device buffers, grown on demand
     double *cost = nullptr;
     int32_t *shape = nullptr;   // nRow | nCol of this device's problems
@@ -79,6 +94,8 @@ struct kbest_multi {
     std::vector<Dev> dev;
     Rccl rccl;
     std::string err;
+    bool local = false;  // device_ids names a GPU more than once: no RCCL communicator, the slices travel by device-to-device copies
+    double t0 = 0;       // entry time of the current call
     // shape of the last call (for kbest_multi_tables_agree)
     int lastB = 0, lastK = 0, lastCol = 0, lastMode = 0;
     size_t lastBytes = 0;  // bytes of the packed global table
@@ -88,6 +105,8 @@ namespace {
 
 int mfail(kbest_multi *m, int code, const std::string &what)
 {
+    static std::mutex mu;  // (the per-device workers may fail at the same time)
+    std::lock_guard<std::mutex> lock(mu);
     if (m) m->err = what;
     return code;
 }
@@ -149,6 +168,29 @@ template <class T> int grow(kbest_multi *m, Dev &d, T *&p, size_t &have, size_t 
 int gather_packed(kbest_multi *m, size_t perDev)
 {
     const int G = (int)m->dev.size();
+    for (auto &d : m->dev) d.t[4] = kb::now_s() - m->t0;
+    if (m->local) {
+        // logical devices on one GPU: every device's slice is copied into every other device's table, stream-ordered behind
+        // the producer's kernels (event) and in front of whatever the receiver does next (event back)
+        for (int g = 0; g < G; g++) {
+            Dev &d = m->dev[g];
+            if (hipSetDevice(d.id) != hipSuccess || hipEventRecord(d.ev, d.stream) != hipSuccess) { drain(m); return mfail(m, KBEST_ERR_HIP, "local gather: event"); }
+            d.issued = true;
+        }
+        for (int g = 0; g < G; g++) {
+            Dev &d = m->dev[g];
+            for (int h = 0; h < G; h++) {
+                if (h == g) continue;
+                // device g pulls slice h once it is ready
+                if (hipStreamWaitEvent(d.stream, m->dev[h].ev, 0) != hipSuccess ||
+                    hipMemcpyAsync(d.packed + (size_t)h * perDev, m->dev[h].packed + (size_t)h * perDev, perDev, hipMemcpyDeviceToDevice, d.stream) != hipSuccess) {
+                    drain(m);
+                    return mfail(m, KBEST_ERR_HIP, "local gather: copy");
+                }
+            }
+        }
+        return KBEST_OK;
+    }
     ncclResult_t first = ncclSuccess;
     ncclResult_t r = m->rccl.GroupStart();
     if (r != ncclSuccess) { drain(m); return mfail(m, KBEST_ERR_HIP, std::string("ncclGroupStart: ") + m->rccl.GetErrorString(r)); }
@@ -184,11 +226,22 @@ int kbest_create_multi(kbest_multi **out, const int *device_ids, int nDev)
             return KBEST_ERR_NO_DEVICE;
         }
     }
-    std::string err;
-    if (!m->rccl.load(err)) { kbest_destroy_multi(m); return KBEST_ERR_NO_DEVICE; }
-    std::vector<ncclComm_t> comms(nDev);
-    if (m->rccl.CommInitAll(comms.data(), nDev, device_ids) != ncclSuccess) { kbest_destroy_multi(m); return KBEST_ERR_HIP; }
-    for (int g = 0; g < nDev; g++) m->dev[g].comm = comms[g];
+    for (int g = 0; g < nDev; g++)
+        for (int h = 0; h < g; h++)
+            if (device_ids[g] == device_ids[h]) m->local = true;
+    if (m->local) {
+        for (int g = 0; g < nDev; g++)
+            if (hipSetDevice(device_ids[g]) != hipSuccess || hipEventCreateWithFlags(&m->dev[g].ev, hipEventDisableTiming) != hipSuccess) {
+                kbest_destroy_multi(m);
+                return KBEST_ERR_HIP;
+            }
+    } else {
+        std::string err;
+        if (!m->rccl.load(err)) { kbest_destroy_multi(m); return KBEST_ERR_NO_DEVICE; }
+        std::vector<ncclComm_t> comms(nDev);
+        if (m->rccl.CommInitAll(comms.data(), nDev, device_ids) != ncclSuccess) { kbest_destroy_multi(m); return KBEST_ERR_HIP; }
+        for (int g = 0; g < nDev; g++) m->dev[g].comm = comms[g];
+    }
     *out = m;
     return KBEST_OK;
 }
@@ -203,6 +256,7 @@ int kbest_destroy_multi(kbest_multi *m)
         for (void *p : {(void *)d.cost, (void *)d.shape, (void *)d.c4r, (void *)d.packed, (void *)d.mGain, (void *)d.mR4C, (void *)d.mNf})
             if (p) (void)hipFree(p);
         if (d.stream) (void)hipStreamDestroy(d.stream);
+        if (d.ev) (void)hipEventDestroy(d.ev);
         if (d.ctx) kbest_destroy(d.ctx);
     }
     delete m;
@@ -230,65 +284,79 @@ int kbest_batch_f64_multi_ex(kbest_multi *m, const kbest_opts *opts, int mode, i
     if (B == 0) return KBEST_OK;
     const int G = (int)m->dev.size();
     const size_t per = (size_t)maxRow * maxCol;
-    for (auto &d : m->dev) d.issued = false;
+    m->t0 = kb::now_s();
+    for (auto &d : m->dev) {
+        d.issued = false;
+        d.rc = KBEST_OK;
+        d.werr.clear();
+        for (double &x : d.t) x = 0.0;
+    }
+    // one worker thread per device for the steps that block the host (uploads from the caller's pageable memory, copies back):
+    // no device waits for another one's copies.  A worker reports through Dev::rc / werr.
+    auto run_workers = [&](const std::function<void(int)> &job) -> int {
+        std::vector<std::thread> th;
+        for (int g = 1; g < G; g++) th.emplace_back(job, g);
+        job(0);
+        for (auto &t : th) t.join();
+        for (int g = 0; g < G; g++)
+            if (m->dev[g].rc != KBEST_OK) {
+                drain(m);
+                return mfail(m, m->dev[g].rc, std::string("device ") + std::to_string(m->dev[g].id) + ": " + m->dev[g].werr);
+            }
+        return KBEST_OK;
+    };
+    auto wfail = [](Dev &d, int code, const std::string &what) { d.rc = code; d.werr = what; };
+#define W_HIP(d, call)                                                                          \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) { wfail(d, KBEST_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); return; } \
+    } while (0)
+#define W_TRY(d, expr)                                              \
+    do {                                                            \
+        const int rc_ = (expr);                                     \
+        if (rc_ != KBEST_OK) { wfail(d, rc_, m->err); return; }     \
+    } while (0)
 
     if (mode == KBEST_MULTI_BATCH) {
         const int pad = (B + G - 1) / G;  // matrices per device (the last devices may hold fewer): equal all-gather counts
         const Slice sl((size_t)pad, k, maxCol);
         m->lastB = B; m->lastK = k; m->lastCol = maxCol; m->lastMode = mode; m->lastBytes = (size_t)G * sl.bytes;
-        // 1. every device: its block of cost matrices in, its slice of the global table solved in place
-        for (int g = 0; g < G; g++) {
+        // 1. every device, in its own thread: its block of cost matrices in, its slice of the global table solved in place and
+        //    copied back into the caller's tables -- the single-device host path (kbest_batch_f64: pieces whose uploads,
+        //    kernels and copies back overlap), with the tables staged in the device's slice, where they stay for the exchange
+        M_TRY(m, run_workers([&](int g) {
             Dev &d = m->dev[g];
             const int b0 = g * pad, nb = (b0 >= B) ? 0 : ((B - b0 < pad) ? B - b0 : pad);
-            M_HIP(m, hipSetDevice(d.id));
-            M_TRY(m, grow(m, d, d.packed, d.packedB, (size_t)G * sl.bytes));
-            M_TRY(m, grow(m, d, d.cost, d.costB, (size_t)pad * per * 8));
-            if (col4row) M_TRY(m, grow(m, d, d.c4r, d.c4rB, (size_t)pad * k * maxRow * 4));
-            if (nRow) M_TRY(m, grow(m, d, d.shape, d.shapeB, (size_t)2 * pad * 4));
+            d.t[0] = kb::now_s() - m->t0;
+            W_HIP(d, hipSetDevice(d.id));
+            W_TRY(d, grow(m, d, d.packed, d.packedB, (size_t)G * sl.bytes));
+            if (col4row) W_TRY(d, grow(m, d, d.c4r, d.c4rB, (size_t)pad * k * maxRow * 4));
             unsigned char *mine = d.packed + (size_t)g * sl.bytes;
-            // slots the kernels do not write (beyond nf, padding problems) get defined values: gain 0, row4col -1, nf 0
+            // slots the kernels do not write (padding problems of the last devices) get defined values: gain 0, row4col -1, nf 0
             d.issued = true;
-            M_HIP(m, hipMemsetAsync(mine, 0, sl.bytes, d.stream));
-            M_HIP(m, hipMemsetAsync(mine + sl.offR4C, 0xFF, (size_t)pad * k * maxCol * 4, d.stream));
-            if (nb == 0) continue;
-            if (col4row) M_HIP(m, hipMemsetAsync(d.c4r, 0xFF, (size_t)pad * k * maxRow * 4, d.stream));
-            M_HIP(m, hipMemcpyAsync(d.cost, cost + (size_t)b0 * per, (size_t)nb * per * 8, hipMemcpyHostToDevice, d.stream));
-            if (nRow) {
-                M_HIP(m, hipMemcpyAsync(d.shape, nRow + b0, (size_t)nb * 4, hipMemcpyHostToDevice, d.stream));
-                M_HIP(m, hipMemcpyAsync(d.shape + pad, nCol + b0, (size_t)nb * 4, hipMemcpyHostToDevice, d.stream));
+            if (nb < pad) {
+                W_HIP(d, hipMemsetAsync(mine, 0, sl.bytes, d.stream));
+                W_HIP(d, hipMemsetAsync(mine + sl.offR4C, 0xFF, (size_t)pad * k * maxCol * 4, d.stream));
+                W_HIP(d, hipStreamSynchronize(d.stream));
             }
-            int rc = kbest_reserve(d.ctx, nb, maxRow, k);
-            if (rc == KBEST_OK)
-                rc = kbest_batch_f64_dev(d.ctx, opts, nb, maxRow, maxCol, nRow ? d.shape : nullptr, nRow ? d.shape + pad : nullptr,
-                                         d.cost, nullptr, k, reinterpret_cast<int32_t *>(mine + sl.offR4C), col4row ? d.c4r : nullptr,
-                                         reinterpret_cast<double *>(mine + sl.offGain), reinterpret_cast<int32_t *>(mine + sl.offNf),
-                                         nullptr, d.stream);
-            if (rc != KBEST_OK) {
-                drain(m);
-                return mfail(m, rc, std::string("device ") + std::to_string(d.id) + ": " + kbest_last_error(d.ctx));
-            }
-        }
-        // 2. the one exchange: ONE all-gather of the packed (gain[k], row4col[k*M], nf) slices
+            if (nb == 0) { d.t[1] = d.t[2] = d.t[3] = kb::now_s() - m->t0; return; }
+            double stamps[2] = {0.0, 0.0};
+            const kb::KeepTables keep{reinterpret_cast<int32_t *>(mine + sl.offR4C), col4row ? d.c4r : nullptr,
+                                      reinterpret_cast<double *>(mine + sl.offGain), reinterpret_cast<int32_t *>(mine + sl.offNf), stamps};
+            const int rc = kbest_batch_f64_keep(d.ctx, opts, nb, maxRow, maxCol, nRow ? nRow + b0 : nullptr, nCol ? nCol + b0 : nullptr,
+                                                cost + (size_t)b0 * per, nullptr, k, row4col + (size_t)b0 * k * maxCol,
+                                                col4row ? col4row + (size_t)b0 * k * maxRow : nullptr, gain + (size_t)b0 * k, nf + b0,
+                                                nullptr, &keep);
+            d.t[1] = stamps[0] - m->t0;
+            d.t[2] = stamps[1] - m->t0;
+            d.t[3] = kb::now_s() - m->t0;
+            if (rc != KBEST_OK) wfail(d, rc, kbest_last_error(d.ctx));
+        }));
+        // 2. the one exchange: ONE all-gather of the packed (gain[k], row4col[k*M], nf) slices; every device then
+        //    holds the global table (the host has its results already: each device's own slice came back in step 1)
         M_TRY(m, gather_packed(m, sl.bytes));
-        // 3. results: the global table from device 0 (any device holds it), col4row from the device that solved the block
         drain(m);
-        Dev &d0 = m->dev[0];
-        std::vector<unsigned char> host((size_t)G * sl.bytes);
-        M_HIP(m, hipSetDevice(d0.id));
-        M_HIP(m, hipMemcpy(host.data(), d0.packed, host.size(), hipMemcpyDeviceToHost));
-        for (int g = 0; g < G; g++) {
-            const int b0 = g * pad, nb = (b0 >= B) ? 0 : ((B - b0 < pad) ? B - b0 : pad);
-            if (nb == 0) continue;
-            const unsigned char *s = host.data() + (size_t)g * sl.bytes;
-            memcpy(gain + (size_t)b0 * k, s + sl.offGain, (size_t)nb * k * 8);
-            memcpy(row4col + (size_t)b0 * k * maxCol, s + sl.offR4C, (size_t)nb * k * maxCol * 4);
-            memcpy(nf + b0, s + sl.offNf, (size_t)nb * 4);
-            if (col4row) {
-                Dev &d = m->dev[g];
-                M_HIP(m, hipSetDevice(d.id));
-                M_HIP(m, hipMemcpy(col4row + (size_t)b0 * k * maxRow, d.c4r, (size_t)nb * k * maxRow * 4, hipMemcpyDeviceToHost));
-            }
-        }
+        for (auto &d : m->dev) d.t[5] = kb::now_s() - m->t0;
     } else {
         // Subtree mode (few large matrices; SURVEY 8(e), north star): every device holds ALL B matrices; shard s of S expands
         // only the root's children on columns c % S == s and enumerates its own k best (slot 0: the root); the packed lists
@@ -302,66 +370,68 @@ int kbest_batch_f64_multi_ex(kbest_multi *m, const kbest_opts *opts, int mode, i
         m->lastB = B; m->lastK = k; m->lastCol = maxCol; m->lastMode = mode;
         m->lastBytes = 0;
         if (opts->root_col_stride > 1) return mfail(m, KBEST_ERR_BAD_ARG, "kbest_batch_f64_multi: subtree mode sets root_col_offset / stride itself");
-        for (int g = 0; g < G; g++) {
+        M_TRY(m, run_workers([&](int g) {
             Dev &d = m->dev[g];
-            M_HIP(m, hipSetDevice(d.id));
-            M_TRY(m, grow(m, d, d.packed, d.packedB, (size_t)G * perDev));
-            M_TRY(m, grow(m, d, d.cost, d.costB, (size_t)B * per * 8));
-            M_TRY(m, grow(m, d, d.mGain, d.mGainB, (size_t)B * k * 8));
-            M_TRY(m, grow(m, d, d.mR4C, d.mR4CB, (size_t)B * k * maxCol * 4));
-            M_TRY(m, grow(m, d, d.mNf, d.mNfB, (size_t)B * 4));
-            if (nRow) M_TRY(m, grow(m, d, d.shape, d.shapeB, (size_t)2 * B * 4));
+            d.t[0] = kb::now_s() - m->t0;
+            W_HIP(d, hipSetDevice(d.id));
+            W_TRY(d, grow(m, d, d.packed, d.packedB, (size_t)G * perDev));
+            W_TRY(d, grow(m, d, d.cost, d.costB, (size_t)B * per * 8));
+            W_TRY(d, grow(m, d, d.mGain, d.mGainB, (size_t)B * k * 8));
+            W_TRY(d, grow(m, d, d.mR4C, d.mR4CB, (size_t)B * k * maxCol * 4));
+            W_TRY(d, grow(m, d, d.mNf, d.mNfB, (size_t)B * 4));
+            if (nRow) W_TRY(d, grow(m, d, d.shape, d.shapeB, (size_t)2 * B * 4));
             unsigned char *mine = d.packed + (size_t)g * perDev;
             d.issued = true;
-            M_HIP(m, hipMemsetAsync(mine, 0, perDev, d.stream));  // (an unused shard slot: nf = 0, no candidates)
-            M_HIP(m, hipMemsetAsync(d.mR4C, 0xFF, (size_t)B * k * maxCol * 4, d.stream));
-            M_HIP(m, hipMemsetAsync(d.mGain, 0, (size_t)B * k * 8, d.stream));
-            M_HIP(m, hipMemcpyAsync(d.cost, cost, (size_t)B * per * 8, hipMemcpyHostToDevice, d.stream));
+            W_HIP(d, hipMemsetAsync(mine, 0, perDev, d.stream));  // (an unused shard slot: nf = 0, no candidates)
+            W_HIP(d, hipMemsetAsync(d.mR4C, 0xFF, (size_t)B * k * maxCol * 4, d.stream));
+            W_HIP(d, hipMemsetAsync(d.mGain, 0, (size_t)B * k * 8, d.stream));
+            d.t[1] = kb::now_s() - m->t0;
+            // (from the caller's pageable memory the copy blocks THIS thread until the data is staged; the other devices' threads run)
+            W_HIP(d, hipMemcpyAsync(d.cost, cost, (size_t)B * per * 8, hipMemcpyHostToDevice, d.stream));
             if (nRow) {
-                M_HIP(m, hipMemcpyAsync(d.shape, nRow, (size_t)B * 4, hipMemcpyHostToDevice, d.stream));
-                M_HIP(m, hipMemcpyAsync(d.shape + B, nCol, (size_t)B * 4, hipMemcpyHostToDevice, d.stream));
+                W_HIP(d, hipMemcpyAsync(d.shape, nRow, (size_t)B * 4, hipMemcpyHostToDevice, d.stream));
+                W_HIP(d, hipMemcpyAsync(d.shape + B, nCol, (size_t)B * 4, hipMemcpyHostToDevice, d.stream));
             }
             int rc = kbest_reserve(d.ctx, B, maxRow, k);
             for (int j = 0; j < spd && rc == KBEST_OK; j++) {
-                const int s = j * G + g;  // round robin
-                if (s >= S) break;
+                const int sh = j * G + g;  // round robin
+                if (sh >= S) break;
                 unsigned char *slot = mine + (size_t)j * sl.bytes;
-                M_HIP(m, hipMemsetAsync(slot + sl.offR4C, 0xFF, (size_t)B * k * maxCol * 4, d.stream));
+                W_HIP(d, hipMemsetAsync(slot + sl.offR4C, 0xFF, (size_t)B * k * maxCol * 4, d.stream));
                 kbest_opts o = *opts;
-                o.root_col_offset = s;
+                o.root_col_offset = sh;
                 o.root_col_stride = S;
                 rc = kbest_batch_f64_dev(d.ctx, &o, B, maxRow, maxCol, nRow ? d.shape : nullptr, nRow ? d.shape + B : nullptr, d.cost,
                                          nullptr, k, reinterpret_cast<int32_t *>(slot + sl.offR4C), nullptr,
                                          reinterpret_cast<double *>(slot + sl.offGain), reinterpret_cast<int32_t *>(slot + sl.offNf),
                                          nullptr, d.stream);
+                if (j == 0) d.t[2] = kb::now_s() - m->t0;
             }
-            if (rc != KBEST_OK) {
-                drain(m);
-                return mfail(m, rc, std::string("device ") + std::to_string(d.id) + ": " + kbest_last_error(d.ctx));
-            }
-        }
+            d.t[3] = kb::now_s() - m->t0;
+            if (rc != KBEST_OK) wfail(d, rc, kbest_last_error(d.ctx));
+        }));
         M_TRY(m, gather_packed(m, perDev));
         // the global k-best heap, on every device.  In the gathered buffer shard s = j * G + g sits at (g * spd + j) slices:
         // the merge takes "shard i" at i * sl.bytes, which enumerates the slots device by device -- any order of the
         // shards gives the same table (ties are ordered by the assignment), but the ROOT is taken from the first slot,
-        // which is shard 0 (device 0, j = 0).
-        for (int g = 0; g < G; g++) {
+        // which is shard 0 (device 0, j = 0).  Every device then sends ITS share of the (identical) merged tables home.
+        M_TRY(m, run_workers([&](int g) {
             Dev &d = m->dev[g];
-            M_HIP(m, hipSetDevice(d.id));
+            W_HIP(d, hipSetDevice(d.id));
             const int rc = kbest_merge_topk_f64_dev(d.ctx, B, G * spd, k, maxCol, opts->maximize, d.packed + sl.offGain,
                                                     d.packed + sl.offR4C, d.packed + sl.offNf, (int64_t)sl.bytes, d.mGain, d.mR4C,
                                                     d.mNf, d.stream);
-            if (rc != KBEST_OK) {
-                drain(m);
-                return mfail(m, rc, std::string("device ") + std::to_string(d.id) + ": " + kbest_last_error(d.ctx));
+            if (rc != KBEST_OK) { wfail(d, rc, kbest_last_error(d.ctx)); return; }
+            const int b0 = (int)((long long)B * g / G), nb = (int)((long long)B * (g + 1) / G) - b0;
+            W_HIP(d, hipStreamSynchronize(d.stream));
+            d.issued = false;
+            if (nb > 0) {
+                W_HIP(d, hipMemcpy(gain + (size_t)b0 * k, d.mGain + (size_t)b0 * k, (size_t)nb * k * 8, hipMemcpyDeviceToHost));
+                W_HIP(d, hipMemcpy(row4col + (size_t)b0 * k * maxCol, d.mR4C + (size_t)b0 * k * maxCol, (size_t)nb * k * maxCol * 4, hipMemcpyDeviceToHost));
+                W_HIP(d, hipMemcpy(nf + b0, d.mNf + b0, (size_t)nb * 4, hipMemcpyDeviceToHost));
             }
-        }
-        drain(m);
-        Dev &d0 = m->dev[0];
-        M_HIP(m, hipSetDevice(d0.id));
-        M_HIP(m, hipMemcpy(gain, d0.mGain, (size_t)B * k * 8, hipMemcpyDeviceToHost));
-        M_HIP(m, hipMemcpy(row4col, d0.mR4C, (size_t)B * k * maxCol * 4, hipMemcpyDeviceToHost));
-        M_HIP(m, hipMemcpy(nf, d0.mNf, (size_t)B * 4, hipMemcpyDeviceToHost));
+            d.t[5] = kb::now_s() - m->t0;
+        }));
         if (col4row)  // not part of the exchange: the inverse of row4col, rows without a real column -1
             for (int b = 0; b < B; b++)
                 for (int s = 0; s < k; s++) {
@@ -374,9 +444,23 @@ int kbest_batch_f64_multi_ex(kbest_multi *m, const kbest_opts *opts, int mode, i
                         if (r4[j] >= 0 && r4[j] < maxRow) c[r4[j]] = j;
                 }
     }
+#undef W_HIP
+#undef W_TRY
     for (int b = 0; b < B; b++)
         if (nf[b] < 0) return mfail(m, nf[b] == -1 ? KBEST_ERR_UNSUPPORTED : KBEST_ERR_INTERNAL, "kbest_batch_f64_multi: a problem came back with nf < 0");
     return KBEST_OK;
+}
+
+// Host times of the last kbest_batch_f64_multi[_ex] call, per device, in seconds since the call was entered:
+// [0] the device's worker started, [1] its first upload was issued, [2] its first kernel was issued, [3] it was fed (batch mode:
+// its own results are back in the caller's tables as well), [4] the exchange was issued, [5] everything of the call is done.
+int kbest_multi_timeline(const kbest_multi *m, double *out, int capDevices)
+{
+    if (!m || !out) return KBEST_ERR_BAD_ARG;
+    const int n = (int)m->dev.size() < capDevices ? (int)m->dev.size() : capDevices;
+    for (int g = 0; g < n; g++)
+        for (int i = 0; i < KBEST_MULTI_STAMPS; i++) out[(size_t)g * KBEST_MULTI_STAMPS + i] = m->dev[g].t[i];
+    return n;
 }
 
 int kbest_batch_f64_multi(kbest_multi *m, const kbest_opts *opts, int B, int maxRow, int maxCol, const int32_t *nRow,

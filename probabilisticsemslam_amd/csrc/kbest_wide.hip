@@ -834,7 +834,8 @@ __global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) 
                 s2 = uni32(s2);
                 const int a = uni32(ctrl->selA[s2]), ps = uni32(ctrl->selSid[s2]);
                 const int c = a + (t - uni32(ctrl->selOff[s2]));
-                if (round == 0 && p.rootColStride > 1 && (c % p.rootColStride) != p.rootColOffset) continue;  // the root's children
+                // (the root's children; the partition is on the REFERENCE's column, kbest_c.h, whatever order the enumeration works in)
+                if (round == 0 && p.rootColStride > 1 && ((int)colOf[c < M ? c : 0] % p.rootColStride) != p.rootColOffset) continue;
                 const double pgain = ctrl->selG[s2];
                 const double bound = (prune && T < INF) ? (T - pgain) + 1e-9 * (fabs(T) + cmaxv) : INF;
                 const unsigned char *P = nodeBase + (size_t)s2 * L.nodeStride;  // the parent, in LDS

@@ -35,11 +35,32 @@ def _all_gather(t: torch.Tensor, world: int) -> torch.Tensor:
     return out.view((world,) + tuple(t.shape))
 
 
+def _pack(gain: torch.Tensor, row4col: torch.Tensor, nf: torch.Tensor) -> torch.Tensor:
+    """One rank's result tables as ONE buffer of bytes: gain fp64 | row4col i32 | nf i32 (the exchange is a single
+    all-gather of the packed per-rank slices, as in bench.py and kbest_multi.cpp)."""
+    parts = [gain.contiguous().to(torch.float64).view(torch.uint8).reshape(-1),
+             row4col.contiguous().to(torch.int32).view(torch.uint8).reshape(-1),
+             nf.contiguous().to(torch.int32).view(torch.uint8).reshape(-1)]
+    return torch.cat(parts)
+
+
+def _unpack(buf: torch.Tensor, world: int, n: int, k: int, M: int):
+    """The gathered slices back as (gain[W, n, k], row4col[W, n, k, M], nf[W, n])."""
+    per = buf.numel() // world
+    b = buf.view(world, per)
+    o1, o2 = n * k * 8, n * k * 8 + n * k * M * 4
+    G = b[:, :o1].contiguous().view(torch.float64).view(world, n, k)
+    R = b[:, o1:o2].contiguous().view(torch.int32).view(world, n, k, M)
+    N = b[:, o2:o2 + n * 4].contiguous().view(torch.int32).view(world, n)
+    return G, R, N
+
+
 def gather_batch(gain: torch.Tensor, row4col: torch.Tensor, nf: torch.Tensor, B: int):
-    """Batch mode: every rank passes its own shard (padded to the largest shard); returns the global
-    (gain[B,k], row4col[B,k,M], nf[B]) on every rank."""
+    """Batch mode: every rank passes its own shard; ONE all-gather of the packed slices (padded to the largest shard); returns
+    the global (gain[B,k], row4col[B,k,M], nf[B]) on every rank."""
     world = dist.get_world_size()
     per = max(shard_range(B, r, world)[1] - shard_range(B, r, world)[0] for r in range(world))
+    k, M = gain.shape[1], row4col.shape[2]
 
     def pad(t):
         if t.shape[0] == per:
@@ -47,10 +68,10 @@ def gather_batch(gain: torch.Tensor, row4col: torch.Tensor, nf: torch.Tensor, B:
         z = torch.zeros((per - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         return torch.cat([t, z], 0)
 
-    G, R, N = _all_gather(pad(gain), world), _all_gather(pad(row4col), world), _all_gather(pad(nf), world)
+    G, R, N = _unpack(_all_gather(_pack(pad(gain), pad(row4col), pad(nf)), world).reshape(-1), world, per, k, M)
     parts = [(shard_range(B, r, world)[1] - shard_range(B, r, world)[0]) for r in range(world)]
     cat = lambda X: torch.cat([X[r, :parts[r]] for r in range(world)], 0)  # noqa: E731
-    return cat(G), cat(R), cat(N)
+    return cat(G).to(gain.dtype), cat(R).to(row4col.dtype), cat(N).to(nf.dtype)
 
 
 def merge_subtree_topk(gain: torch.Tensor, row4col: torch.Tensor, nf: torch.Tensor, k: int, maximize: bool = False):
@@ -60,10 +81,10 @@ def merge_subtree_topk(gain: torch.Tensor, row4col: torch.Tensor, nf: torch.Tens
     (decreasing profit when maximize).  (On the GPU node the merge itself runs on the device:
     kbest_merge_topk_f64_dev / kbest_batch_f64_multi_ex; this torch form is the same rule, used with gloo.)"""
     world = dist.get_world_size()
-    G = _all_gather(gain, world)        # [W, B, k]
-    R = _all_gather(row4col, world)     # [W, B, k, M]
-    Nf = _all_gather(nf, world)         # [W, B]
-    return merge_lists(G, R, Nf, k, maximize)
+    B, kk, M = row4col.shape
+    # ONE all-gather of the packed (gain | row4col | nf) lists, then the merge: G [W, B, k], R [W, B, k, M], Nf [W, B]
+    G, R, Nf = _unpack(_all_gather(_pack(gain, row4col, nf), world).reshape(-1), world, B, kk, M)
+    return merge_lists(G.to(gain.dtype), R.to(row4col.dtype), Nf.to(nf.dtype), k, maximize)
 
 
 def merge_lists(G: torch.Tensor, R: torch.Tensor, Nf: torch.Tensor, k: int, maximize: bool = False):

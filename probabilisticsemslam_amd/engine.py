@@ -27,8 +27,9 @@ C_ABI_SYMBOLS = (
     "kbest_assoc_probs_batch_f64_dev", "kbest_reserve_assoc",
     "kbest_create_multi", "kbest_destroy_multi", "kbest_multi_size", "kbest_multi_last_error", "kbest_batch_f64_multi",
     "kbest_multi_tables_agree", "kbest_batch_f64_multi_ex", "kbest_merge_topk_f64_dev", "kbest_register_host_buffer",
-    "kbest_unregister_host_buffer",
+    "kbest_unregister_host_buffer", "kbest_multi_timeline",
 )
+KBEST_MULTI_STAMPS = 6
 KBEST_MULTI_BATCH, KBEST_MULTI_SUBTREE = 0, 1
 
 
@@ -101,6 +102,7 @@ def load_library():
                                              C.c_int, i32p, i32p, dp, i32p]
     lib.kbest_merge_topk_f64_dev.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int64, dp, i32p,
                                              i32p, vp]
+    lib.kbest_multi_timeline.argtypes = [vp, dp, C.c_int]
     lib.kbest_register_host_buffer.argtypes = [vp, vp, C.c_size_t]
     lib.kbest_unregister_host_buffer.argtypes = [vp, vp]
     _lib = lib
@@ -384,6 +386,13 @@ class KBestMulti:
 
     def tables_agree(self):
         return self.lib.kbest_multi_tables_agree(self.m) == 1
+
+    def timeline(self):
+        """Host times of the last call per device: array [nDev, 6] of seconds since the call was entered (kbest_multi_timeline)."""
+        n = self.lib.kbest_multi_size(self.m)
+        out = np.zeros((n, KBEST_MULTI_STAMPS))
+        self.lib.kbest_multi_timeline(self.m, _ptr(out), n)
+        return out
 
 
 # ---- reference-named conveniences (B = 1), mirroring shortestPathCPP.hpp / assignment.h -------------

@@ -65,3 +65,14 @@ def test_product_never_touches_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h", ".hpp")) or f == "Makefile":
                 txt = open(os.path.join(dp, f)).read()
                 assert "oracle" not in txt.lower() or f in (), (dp, f)
+
+
+def test_step_loop_is_what_the_source_says():
+    """tools/check_step_loop.py: the hand-written Dijkstra step loop on fixed registers, disassembled from the built code
+    object, instruction for instruction (a compiler bump must fail loudly, not silently)."""
+    import subprocess
+    import sys
+    obj = os.path.join(ROOT, "probabilisticsemslam_amd", "csrc", ".obj", "kbest_engine.hip.o")
+    if not os.path.exists(obj):
+        pytest.skip("objects not built in this tree (the library was shipped prebuilt)")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "check_step_loop.py")])

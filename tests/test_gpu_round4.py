@@ -1,0 +1,211 @@
+"""GPU tests added in round 4: whole result tables of ragged batches (padding and unused slots defined), the multi-device
+entry's host timeline, the host entry's int8 staging, the general-size kernel beyond 512 rows."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import probabilisticsemslam_amd as pk
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.int64)
+
+
+def engine_with(monkeypatch, **env):
+    """A fresh context whose launch knobs come from the environment at creation (kbest_create reads them once)."""
+    for key, val in env.items():
+        monkeypatch.setenv(key, str(val))
+    eng = pk.KBestEngine(0)
+    for key in env:
+        monkeypatch.delenv(key)
+    return eng
+
+
+def _ragged(rng, B, N, M):
+    nRow = rng.integers(2, N + 1, B).astype(np.int32)
+    nCol = np.minimum(rng.integers(1, M + 1, B), nRow).astype(np.int32)
+    nRow[0], nCol[0] = N, M  # (the maxima are reached)
+    off = np.zeros(B, np.int64)
+    off[1:] = np.cumsum(nRow[:-1].astype(np.int64) * nCol[:-1])
+    flat = rng.random(int(off[-1] + int(nRow[-1]) * int(nCol[-1])))
+    return nRow, nCol, off, flat
+
+
+def _expected_tables(flat, nRow, nCol, off, N, M, k, **kw):
+    B = len(nRow)
+    r4c = np.full((B, k, M), -1, np.int64)
+    c4r = np.full((B, k, N), -1, np.int64)
+    g = np.zeros((B, k))
+    nf = np.zeros(B, np.int64)
+    for b in range(B):
+        n, m = int(nRow[b]), int(nCol[b])
+        onf, or4c, oc4r, og = ol.orc_kbest(flat[off[b]: off[b] + n * m], n, m, k, **kw)
+        nf[b] = onf
+        r4c[b, :onf, :m] = or4c[:onf]
+        oc = np.asarray(oc4r[:onf]).copy()
+        oc[oc >= m] = -1  # rows on zero-padded columns
+        c4r[b, :onf, :n] = oc
+        g[b, :onf] = og[:onf]
+    return nf, r4c, c4r, g
+
+
+@pytest.mark.parametrize("knobs", [{}, {"KBEST_NO_SMALL": 1, "KBEST_NO_LANE": 1}, {"KBEST_FORCE_SMALL": 1}, {"KBEST_FORCE_WIDE": 1}])
+@pytest.mark.parametrize("registered", [False, True])
+def test_ragged_batch_whole_tables_are_defined(monkeypatch, knobs, registered):
+    """Every entry of row4col / col4row / gain of a ragged batch has a defined value: the assignments where a problem has
+    columns / rows, -1 in the padding [nCol[b], maxCol) / [nRow[b], maxRow) of emitted slots and in the slots beyond nf,
+    gain 0 there -- whatever the buffers held before (recycled device blocks, the caller's registered memory)."""
+    eng = engine_with(monkeypatch, **knobs)
+    rng = np.random.default_rng(404)
+    B, N, M, k = 37, 24, 17, 40
+    nRow, nCol, off, flat = _ragged(rng, B, N, M)
+    # poison what the staging buffers will be drawn from: a uniform batch of the same table sizes, all slots used
+    eng.kbest(rng.random((B, N * M)), N, M, k)
+    want = _expected_tables(flat, nRow, nCol, off, N, M, k)
+    if registered:
+        r4c = np.full((B, k, M), 0x5555, np.int32)
+        c4r = np.full((B, k, N), 0x5555, np.int32)
+        g = np.full((B, k), 7.0)
+        nf = np.full(B, 99, np.int32)
+        costs = flat.copy()
+        eng.register_host(costs, r4c, c4r, g, nf)
+        o = eng._opts(False, None)
+        import ctypes as C
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        rc = eng.lib.kbest_batch_f64(eng.ctx, C.byref(o), B, N, M, p(nRow), p(nCol), p(costs), p(off), k, p(r4c), p(c4r), p(g), p(nf), None)
+        eng.unregister_host(costs, r4c, c4r, g, nf)
+        assert rc == 0
+    else:
+        nf, r4c, c4r, g = eng.kbest(flat, N, M, k, nRow=nRow, nCol=nCol, costOff=off)
+    assert (nf == want[0]).all()
+    c = c4r.astype(np.int64).copy()
+    for b in range(B):
+        blk = c[b, :, : nRow[b]]
+        blk[blk >= nCol[b]] = -1
+    assert (r4c == want[1]).all()
+    assert (c == want[2]).all()
+    assert (bits(g) == bits(want[3])).all()
+    eng.close()
+
+
+def _multi_vs_single(eng, ids, costs, N, M, k, **kw):
+    multi = pk.KBestMulti(ids)
+    got = multi.kbest(costs, N, M, k, **kw)
+    assert multi.tables_agree()
+    tl = multi.timeline()
+    multi.close()
+    want = eng.kbest(costs, N, M, k)
+    assert (got[0] == want[0]).all() and (got[1] == want[1]).all() and (bits(got[3]) == bits(want[3])).all()
+    return got, want, tl
+
+
+@pytest.mark.parametrize("G", [2, 4, 8])
+def test_multi_entry_logical_devices_batch_mode(engine, G):
+    """kbest_create_multi with one GPU named G times: G contexts, G host workers, the slices exchanged by device-to-device
+    copies.  The whole host path of the multi-device entry with G > 1 on one GPU: results equal the single-device entry's,
+    every logical device holds the same global table, and the host timeline shows that every device's upload had been
+    issued before ANY device was done being fed -- no device waits for another one's copies (kbest_multi.cpp)."""
+    from probabilisticsemslam_amd import workloads as wl
+    B, N, M, k = 515, 64, 64, 200  # (not divisible by G: the last device's padding)
+    costs = wl.dense_batch(B, N, M, 0x4D554C)
+    got, want, tl = _multi_vs_single(engine, [0] * G, costs, N, M, k)
+    c = got[2].copy(); c[c >= M] = -1
+    w = want[2].copy(); w[w >= M] = -1
+    assert (c == w).all()
+    assert tl.shape == (G, 6)
+    assert (tl[:, 1] > 0).all() and (tl[:, 3] >= tl[:, 2]).all() and (tl[:, 5] >= tl[:, 4]).all()
+    assert tl[:, 1].max() < tl[:, 3].min(), f"a device was fed before another one's upload was even issued:\n{tl}"
+    # ragged shapes through the same path
+    rng = np.random.default_rng(5)
+    Br, Nr, Mr, kr = 67, 30, 12, 40
+    costs = rng.random((Br, Nr * Mr))
+    nRow = rng.integers(12, Nr + 1, Br).astype(np.int32)
+    nCol = np.minimum(rng.integers(1, Mr + 1, Br), nRow).astype(np.int32)
+    packed = np.zeros((Br, Nr * Mr))
+    for b in range(Br):
+        packed[b, : nRow[b] * nCol[b]] = rng.random(int(nRow[b]) * int(nCol[b]))
+    multi = pk.KBestMulti([0] * G)
+    nf, r4c, c4r, g = multi.kbest(packed, Nr, Mr, kr, nRow=nRow, nCol=nCol)
+    assert multi.tables_agree()
+    multi.close()
+    for b in range(0, Br, 7):
+        n, m = int(nRow[b]), int(nCol[b])
+        onf, or4c, _, og = ol.orc_kbest(packed[b, : n * m], n, m, kr)
+        assert nf[b] == onf and (r4c[b, :onf, :m] == or4c[:onf]).all() and (bits(g[b, :onf]) == bits(og[:onf])).all()
+
+
+@pytest.mark.parametrize("G,S", [(2, 2), (3, 8), (4, 4)])
+def test_multi_entry_logical_devices_subtree_mode(engine, G, S):
+    """Subtree mode over logical devices: every device enumerates its shards of every matrix, one exchange, the merge on every
+    device, each device sends its share of the merged table home; equal to the single-device result."""
+    from probabilisticsemslam_amd import workloads as wl
+    B, N, M, k = 9, 48, 48, 120
+    costs = wl.dense_batch(B, N, M, 0x535542)
+    multi = pk.KBestMulti([0] * G)
+    got = multi.kbest(costs, N, M, k, subtree=True, n_shard=S)
+    assert multi.tables_agree()
+    tl = multi.timeline()
+    multi.close()
+    want = engine.kbest(costs, N, M, k)
+    assert (got[0] == want[0]).all() and (got[1] == want[1]).all() and (bits(got[3]) == bits(want[3])).all()
+    assert tl[:, 1].max() < tl[:, 3].min() or G == 1
+
+
+def test_subtree_shards_from_differently_configured_contexts(monkeypatch):
+    """Root-subtree sharding partitions on the REFERENCE's column (kbest_c.h), not on a position in the enumeration's own
+    column order: shards enumerated by contexts that differ in kernel, launch shape and knobs still form disjoint, complete
+    partitions, and their merge is the global k best."""
+    import torch
+    from probabilisticsemslam_amd import distributed as kd
+    rng = np.random.default_rng(77)
+    B, N, M, k, S = 6, 40, 40, 90, 3
+    costs = rng.random((B, N * M))
+    knobs = [{}, {"KBEST_NO_REORDER": 1, "KBEST_NWAVES": 8, "KBEST_SPEC": 6}, {"KBEST_FORCE_WIDE": 1}]
+    G, R, F = [], [], []
+    for s in range(S):
+        eng = engine_with(monkeypatch, **knobs[s])
+        nf, r4c, _, g = eng.kbest(costs, N, M, k, root_shard=(s, S))
+        G.append(torch.from_numpy(g)); R.append(torch.from_numpy(r4c.astype(np.int64))); F.append(torch.from_numpy(nf.astype(np.int64)))
+        eng.close()
+    mg, mr, mnf = kd.merge_lists(torch.stack(G), torch.stack(R), torch.stack(F), k)
+    onf, or4c, _, og, _ = ol.orc_kbest_batch(costs, N, M, k)
+    assert (mnf.numpy() == onf).all() and (mr.numpy() == or4c).all() and (bits(mg.numpy()) == bits(og)).all()
+
+
+def test_graph_capture_of_the_device_entry(engine):
+    """kbest_batch_f64_dev is legal inside a stream capture (kbest_c.h): no event of the context's cross-stream bookkeeping may
+    end up in the graph.  Captured once, replayed twice on new inputs; then a plain launch on another stream still works."""
+    import torch
+    from probabilisticsemslam_amd import workloads as wl
+    B, N, M, k = 300, 16, 16, 30
+    dev = torch.device("cuda", 0)
+    costs = wl.dense_batch(B, N, M, 0x47524150)
+    d_cost = torch.from_numpy(costs).to(dev)
+    d_r4c = torch.empty((B, k, M), dtype=torch.int32, device=dev)
+    d_c4r = torch.empty((B, k, N), dtype=torch.int32, device=dev)
+    d_g = torch.empty((B, k), dtype=torch.float64, device=dev)
+    d_nf = torch.empty(B, dtype=torch.int32, device=dev)
+    engine.reserve(B, N, k)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):  # once outside the capture: lazy one-off work of the runtime (function attributes)
+        engine.kbest_dev(d_cost, B, N, M, k, d_r4c, d_c4r, d_g, d_nf, stream=s.cuda_stream)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        engine.kbest_dev(d_cost, B, N, M, k, d_r4c, d_c4r, d_g, d_nf, stream=s.cuda_stream)
+    for seed in (1, 2):
+        costs = wl.dense_batch(B, N, M, 0x47524150 + seed)
+        d_cost.copy_(torch.from_numpy(costs))
+        d_g.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        onf, or4c, _, og, _ = ol.orc_kbest_batch(costs[:40], N, M, k)
+        assert (d_nf.cpu().numpy()[:40] == onf).all() and (d_r4c.cpu().numpy()[:40] == or4c).all()
+        assert (bits(d_g.cpu().numpy()[:40]) == bits(og)).all()
+    s2 = torch.cuda.Stream()
+    with torch.cuda.stream(s2):
+        engine.kbest_dev(d_cost, B, N, M, k, d_r4c, d_c4r, d_g, d_nf, stream=s2.cuda_stream)
+    torch.cuda.synchronize()
+    assert (bits(d_g.cpu().numpy()[:40]) == bits(og)).all()
