@@ -672,7 +672,7 @@ def main():
     tstream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(tstream)
     assert tstream.cuda_stream != 0
-    cpu_samples = {"c4": 512, "c3": 1024, "c2": 1024}
+    cpu_samples = {"c4": 512, "c3": 4096, "c2": 1024}  # (c3, c2: the whole batch -- the GPU result of every matrix is compared with the reference's)
 
     line = None
     if args.config == "c5":

@@ -68,7 +68,7 @@ enum {
 };
 
 #define KBEST_MAX_DIM 64       /* rows per problem handled by the LDS-resident kernel (the fast path)      */
-#define KBEST_MAX_DIM_WIDE 512 /* rows per problem handled at all: beyond KBEST_MAX_DIM, or with a k beyond */
+#define KBEST_MAX_DIM_WIDE 1024 /* rows per problem handled at all: beyond KBEST_MAX_DIM, or with a k beyond */
                                /* the LDS candidate pool, the general-size kernel (HBM work space) runs      */
 
 /* flags */

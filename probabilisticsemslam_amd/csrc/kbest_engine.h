@@ -151,9 +151,9 @@ struct BoxParams {
     int *assign;                         // [sum nL] matched right box or -1
 };
 
-// ---- general-size kernel (kbest_wide.hip): numRow up to 64 * 8, any k; hypotheses and pool in HBM work space ----
-constexpr int WIDE_NW = 8;         // waves per problem (16 in the one-workgroup-per-CU shapes: WideParams::nw)
-constexpr int WIDE_MAX_DIM = 512;  // rows per problem
+// ---- general-size kernel (kbest_wide.hip): numRow up to 64 * 16, any k; hypotheses and pool in HBM work space ----
+constexpr int WIDE_NW = 8;         // waves per problem (16 in the one-workgroup-per-CU shapes, 4 beyond 512 rows: WideParams::nw)
+constexpr int WIDE_MAX_DIM = 1024; // rows per problem (16 rows per lane at most)
 constexpr int WIDE_MAX_SPEC = 64;  // hypotheses split per round at most
 constexpr int WIDE_CTRL_BYTES = 1920;
 constexpr int WIDE_SAMPLES = 1024; // LDS index of the sorted pool: every 64th gain (k up to 65 535; beyond: binary search in HBM)
@@ -168,7 +168,7 @@ struct WideParams {
     int minRows;              // problems with fewer rows are left to the LDS kernel (mixed batches); 0 = take all
     int tile;                 // 1: the square cost copy lives in LDS (it fits), Cw is not used
     int spec;                 // hypotheses split per round (1 = the reference's order of operations exactly), <= WIDE_MAX_SPEC
-    int nw;                   // waves per problem: 8 or 16
+    int nw;                   // waves per problem: 8 or 16 (4 beyond 512 rows: the waves' working sets are 20 bytes per row each)
     int k;
     int maximize, useCutoff;
     unsigned flags;
@@ -201,7 +201,7 @@ __host__ __device__ inline long long wide_state_stride(int maxRow) { return (24L
 // moved (rows per lane words), then the root's gain
 __host__ __device__ inline int wide_atom_slots(int maxRow, int maxCol)
 {
-    const int R = maxRow <= 64 ? 1 : (maxRow <= 128 ? 2 : (maxRow <= 256 ? 4 : 8));
+    const int R = maxRow <= 64 ? 1 : (maxRow <= 128 ? 2 : (maxRow <= 256 ? 4 : (maxRow <= 512 ? 8 : 16)));
     const long long bytes = 8LL * ((long long)maxCol * (1 + R) + 1);
     return (int)((bytes + wide_state_stride(maxRow) - 1) / wide_state_stride(maxRow));
 }

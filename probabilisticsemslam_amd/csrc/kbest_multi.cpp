@@ -27,6 +27,7 @@
 #include <rccl/rccl.h>
 
 #include <cstring>
+#include <condition_variable>
 #include <functional>
 #include <mutex>
 #include <string>
@@ -90,8 +91,68 @@ struct Dev {
 
 }  // namespace
 
+// The per-device host workers: G - 1 threads that live as long as the context (a thread's first HIP call on a device costs
+// about a millisecond -- more than a whole share of config 4 --, so they are not created per call), each bound to its device
+// once; device 0's job runs on the calling thread.
+struct Workers {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cvGo, cvDone;
+    const std::function<void(int)> *job = nullptr;
+    unsigned long long gen = 0;  // bumped per dispatch
+    int pending = 0;
+    bool quit = false;
+    void start(int G, const std::vector<int> &ids)
+    {
+        for (int g = 1; g < G; g++)
+            th.emplace_back([this, g, id = ids[g]]() {
+                (void)hipSetDevice(id);
+                unsigned long long seen = 0;
+                for (;;) {
+                    const std::function<void(int)> *j;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cvGo.wait(lk, [&] { return quit || gen != seen; });
+                        if (quit) return;
+                        seen = gen;
+                        j = job;
+                    }
+                    (*j)(g);
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        if (--pending == 0) cvDone.notify_all();
+                    }
+                }
+            });
+    }
+    void run(const std::function<void(int)> &j)  // job(g) for every device, job(0) on this thread; returns when all are done
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job = &j;
+            pending = (int)th.size();
+            gen++;
+        }
+        cvGo.notify_all();
+        j(0);
+        std::unique_lock<std::mutex> lk(mu);
+        cvDone.wait(lk, [&] { return pending == 0; });
+    }
+    void stop()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quit = true;
+        }
+        cvGo.notify_all();
+        for (auto &t : th) t.join();
+        th.clear();
+    }
+};
+
 struct kbest_multi {
     std::vector<Dev> dev;
+    Workers workers;
     Rccl rccl;
     std::string err;
     bool local = false;  // device_ids names a GPU more than once: no RCCL communicator, the slices travel by device-to-device copies
@@ -242,6 +303,7 @@ int kbest_create_multi(kbest_multi **out, const int *device_ids, int nDev)
         if (m->rccl.CommInitAll(comms.data(), nDev, device_ids) != ncclSuccess) { kbest_destroy_multi(m); return KBEST_ERR_HIP; }
         for (int g = 0; g < nDev; g++) m->dev[g].comm = comms[g];
     }
+    m->workers.start(nDev, std::vector<int>(device_ids, device_ids + nDev));
     *out = m;
     return KBEST_OK;
 }
@@ -249,6 +311,7 @@ int kbest_create_multi(kbest_multi **out, const int *device_ids, int nDev)
 int kbest_destroy_multi(kbest_multi *m)
 {
     if (!m) return KBEST_OK;
+    m->workers.stop();
     for (auto &d : m->dev) {
         (void)hipSetDevice(d.id);
         if (d.stream) (void)hipStreamSynchronize(d.stream);
@@ -294,10 +357,7 @@ int kbest_batch_f64_multi_ex(kbest_multi *m, const kbest_opts *opts, int mode, i
     // one worker thread per device for the steps that block the host (uploads from the caller's pageable memory, copies back):
     // no device waits for another one's copies.  A worker reports through Dev::rc / werr.
     auto run_workers = [&](const std::function<void(int)> &job) -> int {
-        std::vector<std::thread> th;
-        for (int g = 1; g < G; g++) th.emplace_back(job, g);
-        job(0);
-        for (auto &t : th) t.join();
+        m->workers.run(job);
         for (int g = 0; g < G; g++)
             if (m->dev[g].rc != KBEST_OK) {
                 drain(m);

@@ -5,7 +5,7 @@
 // (kBest2D, shortestPathCPP.cpp:571-644, takes any numRow >= numCol and any k;
 // bruteForceProb, assignment.cpp:868, asks for up to 20 000 assignments), so
 // this kernel handles everything beyond them -- numRow up to 64 * R (R rows per
-// lane, R <= 8) and any k -- with the SAME arithmetic in the same order:
+// lane, R <= 16: 1 024 rows) and any k -- with the SAME arithmetic in the same order:
 //   * cost copy, duals, hypotheses and the candidate pool live in HBM work
 //     space (L2-resident for the sizes in question), only the hypothesis a
 //     wave is working on sits in LDS / registers;
@@ -327,7 +327,7 @@ __device__ __attribute__((noinline)) void wide_apriori_threshold(double *sd, u64
 
 // up to 128 rows the working set fits 80 VGPRs: three 8-wave workgroups per CU instead of two
 template <int R, bool TILE, int NWV>
-__global__ void __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (R <= 2 ? 6 : 4))) kbest_wide_kernel(WideParams p)
+__global__ void __launch_bounds__(NWV * 64, (R >= 16 ? 1 : (NWV == 16 ? 4 : (R <= 2 ? 6 : 4)))) kbest_wide_kernel(WideParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = NWV * 64;
@@ -1103,7 +1103,8 @@ hipError_t launch_kbest_wide(const WideParams &p, int grid, hipStream_t stream)
     if (p.maxRow <= 64) return launch_wide_r<1>(p, grid, stream);
     if (p.maxRow <= 128) return launch_wide_r<2>(p, grid, stream);
     if (p.maxRow <= 256) return launch_wide_rt<4, false>(p, grid, stream);  // 256^2 doubles never fit
-    return launch_wide_rt<8, false>(p, grid, stream);
+    if (p.maxRow <= 512) return launch_wide_rt<8, false>(p, grid, stream);
+    return launch_wide_rtn<16, false, 4>(p, grid, stream);  // 513 .. 1 024 rows: 16 rows per lane, four waves per problem
 }
 
 }  // namespace kb

@@ -15,7 +15,7 @@ KBEST_FLAG_COUNT_PUSHED = 2
 KBEST_FLAG_TABLES_I8 = 64
 KBEST_FLAG_NO_REORDER = 128
 KBEST_MAX_DIM = 64        # rows handled by the LDS-resident kernel
-KBEST_MAX_DIM_WIDE = 512  # rows handled at all (general-size kernel beyond KBEST_MAX_DIM)
+KBEST_MAX_DIM_WIDE = 1024  # rows handled at all (general-size kernel beyond KBEST_MAX_DIM)
 
 # every symbol include/kbest_c.h declares
 C_ABI_SYMBOLS = (
