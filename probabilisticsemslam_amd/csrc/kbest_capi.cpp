@@ -386,7 +386,7 @@ static WidePlan plan_wide(const kbest_ctx *ctx, int B, int maxRow, int maxCol, i
     w.perSlot = w.cw + w.states + w.pool + up((size_t)2 * w.poolStride * 4) + w.freeL;
     const size_t budget = (size_t)8 << 30;  // the grid strides over the batch: more slots than this buys nothing
     long long g = (long long)(budget / w.perSlot);
-    const long long perCU = maxRow <= 128 ? 3 : 2;  // resident workgroups per CU (80 VGPRs up to 128 rows, 128 beyond)
+    const long long perCU = maxRow <= 128 ? 3 : (maxRow <= 512 ? 2 : 1);  // resident workgroups per CU (80 VGPRs up to 128 rows, 128 beyond; LDS beyond 512)
     if (g > perCU * ctx->nCU) g = perCU * ctx->nCU;
     if (g > B) g = B;
     if (g < 1) g = 1;
@@ -824,19 +824,24 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         p.gainCols = extra ? extra->gainCols : 0;
         p.split = S;
         p.splitB = B;
-        // optimistic bounds: the quantile of the pool a node is split against (host model: tests/dev/proto_tickets.cpp).  With many
-        // hypotheses split per round most of the early pool is speculation (start low, end at the valid threshold); with few
-        // the pool is mostly the answer all along.
-        if (ctx->noOpt) p.optRho0 = 2.0f;
-        else {
-            const bool deep = shp.spec >= 10;
-            p.optRho0 = ctx->optRho0 >= 0.0f ? ctx->optRho0 : (deep ? 0.55f : 0.85f);
-            p.optRho1 = ctx->optRho1 >= 0.0f ? ctx->optRho1 : (deep ? 1.0f : 0.85f);
-            p.optPhi = ctx->optPhi > 0.0f ? ctx->optPhi : 1.0f;
-            p.optKappa = ctx->optKappa;
-            p.optMinPool = ctx->optMinPool > 1 ? ctx->optMinPool : 2;
+        // optimistic bounds: the quantile of the pool a node is split against (host model: tests/dev/proto_tickets.cpp; kernel:
+        // struct Opt).  Measured (kernel ms, off -> on, one box, interleaved): 4 096 x 32x32, k = 200 (4 waves, 4 hypotheses per
+        // round, no a-priori thresholds there) 3.87 -> 3.67 at 0.85 (0.8: 3.81, 0.9: 3.76, 0.75: 4.12); 1 024 x 64x64 (12 x 12, where
+        // the a-priori thresholds already bound the early rounds) 1.865 -> 1.856 at 0.8, 1.90 at 0.7, 2.16 at 0.55: nothing to
+        // gain there, and the extra rounds of re-splits cost -- off in the shapes that run the a-priori thresholds.
+        {
+            const bool t0Shape = shp.nWaves >= 8 && shp.spec >= 3;  // (kbest_engine.hip: t0On)
+            const float rho0 = ctx->optRho0 >= 0.0f ? ctx->optRho0 : (t0Shape ? 2.0f : 0.85f);
+            if (ctx->noOpt || rho0 >= 1.0f) p.optRho0 = 2.0f;
+            else {
+                p.optRho0 = rho0;
+                p.optRho1 = ctx->optRho1 >= 0.0f ? ctx->optRho1 : rho0;
+                const float phi = ctx->optPhi > 0.0f ? ctx->optPhi : 1.0f;
+                p.optSlope = (p.optRho1 - p.optRho0) / (phi * (float)k);
+                p.optKappa = (double)ctx->optKappa;
+                p.optMinPool = ctx->optMinPool > 1 ? ctx->optMinPool : 2;
+            }
         }
-        p.sharedT = S > 1 ? reinterpret_cast<unsigned long long *>(sb + sl.offT) : nullptr;
         hipError_t e = kb::launch_kbest(p, B * S, shp.nWaves, s);
         if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "kbest kernel launch", e);
         if (S > 1) {  // the global k best of every matrix from its shares' lists
@@ -864,7 +869,8 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
     }
     if (runWide) {
         const WidePlan w = plan_wide(ctx, B, maxRow, maxCol, k);
-        if (kb::wide_lds_layout(maxRow, maxCol, false, 8, 1).total > ctx->ldsLimit)
+        const int nwMin = maxRow > 512 ? 4 : 8;  // (beyond 512 rows: 16 rows per lane, four waves per problem -- the waves' LDS working sets)
+        if (kb::wide_lds_layout(maxRow, maxCol, false, nwMin, 1).total > ctx->ldsLimit)
             return fail(ctx, KBEST_ERR_UNSUPPORTED, "problem too large for the general-size kernel's LDS");
         // hypotheses split per round: counting the reference's pushes needs the reference's exact order of splits (1)
         auto spec_for = [&](int nwv) {
@@ -877,10 +883,11 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         // that leaves CUs idle anyway takes it; such a batch also gets 16 waves per problem instead of 8.
         int nw = (B <= ctx->nCU) ? 16 : 8;
         if (ctx->wideNw) nw = ctx->wideNw;
+        if (maxRow > 512) nw = 4;
         int spec = spec_for(nw);
         bool tile = maxRow <= 128 && (ctx->wideTile >= 0 ? ctx->wideTile == 1 : B <= ctx->nCU) &&
                     kb::wide_lds_layout(maxRow, maxCol, true, nw, spec).total <= ctx->ldsLimit;
-        if (!tile && kb::wide_lds_layout(maxRow, maxCol, false, nw, spec).total > ctx->ldsLimit) { nw = 8; spec = spec_for(nw); }
+        if (!tile && nw > 8 && kb::wide_lds_layout(maxRow, maxCol, false, nw, spec).total > ctx->ldsLimit) { nw = 8; spec = spec_for(nw); }
         while (spec > 1 && kb::wide_lds_layout(maxRow, maxCol, tile, nw, spec).total > ctx->ldsLimit) spec--;
         int rc = reserve_wide(ctx, w, grow);
         if (rc != KBEST_OK) return rc;

@@ -48,7 +48,8 @@ struct Params {
     // optimistic bounds (64-row kernel; kbest_engine.hip "optimistic bounds and tickets"): a node is split against the optRho-quantile
     // of the pool's candidates instead of its last one; optRho grows linearly from optRho0 to optRho1 while the first optPhi * k
     // solutions go out.  optRho0 >= 1: off.
-    float optRho0, optRho1, optPhi, optKappa;
+    float optRho0, optRho1, optSlope;  // optSlope = (optRho1 - optRho0) / (optPhi * k), by the host: no loop-invariant float arithmetic in the kernel
+    double optKappa;          // a ticket's re-split goes at least optKappa * (key - optimum) beyond its key
     int optMinPool;           // candidates the pool must hold before a quantile of it is used
 };
 

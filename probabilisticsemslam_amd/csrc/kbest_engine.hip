@@ -120,7 +120,7 @@ struct Opt {
     double bAbs[16];    // per node: the (absolute, shifted-gain) optimistic bound it is split against, set when it is selected
     double gRoot;       // the optimum's shifted gain
     int nT;             // tickets in the list
-    u32 selTicket;      // bit w: node w of this round is a ticket (a re-split)
+    u32 selTicket;      // nodes 0 .. selTicket - 1 of this round are tickets (re-splits): the first selTicket entries of the list
     int anyFinite;      // some node of this round has a finite optimistic bound (the filter's last-arc pass is worth running)
     double TK[OPT_TICKETS];          // ticket keys, ascending
     unsigned short TS[OPT_TICKETS];  // state slot of each ticket's node
@@ -668,7 +668,10 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     // before the call): 1 024 x 64x64, k = 200 2.50 ms as given, 2.09 by a two-arc lower bound, 1.70 by this key; 4 096 x
     // 32x32 4.87 / 4.29 / 3.63.  Not where the reference's own order is part of the answer (push counts, unpruned mode, the
     // exact-root mode, the assign2D entries) and not in split launches.
-    const bool reorder = !rect && prune && S == 1 && M >= 3 && k >= 3 &&
+    // (and not under root-subtree sharding: WHICH assignments the child on a column holds depends on the order of the columns --
+    //  the columns before it are fixed --, so shards enumerated in different orders would not partition the problem; the shards
+    //  of kbest_c.h are those of the reference's order, whatever kernel, launch shape or key arithmetic a rank uses)
+    const bool reorder = !rect && prune && S == 1 && p.rootColStride <= 1 && M >= 3 && k >= 3 &&
                          !(p.flags & (KBEST_FLAG_EXACT_ROOT | KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_REORDER));
     if (reorder) {
         double *key = reinterpret_cast<double *>(smem + L.offGainW);  // (wave 0's line of gain terms: free between the root and round 0)
@@ -971,8 +974,14 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             const int c = a + lane;
             // (root-subtree sharding partitions on the REFERENCE's column, kbest_c.h: the enumeration's own order depends on the launch
             //  shape and the knobs, and shards that differ in them must still enumerate disjoint, complete partitions)
-            const bool live = c < M && !(sid == 0 && rcStride > 1 && ((int)colOf[c & 63] % rcStride) != rcOffset) &&
-                              !((doneM >> (c & 63)) & 1ull);
+            bool live = c < M && !((doneM >> (c & 63)) & 1ull);
+            if (__builtin_expect(sid == 0 && rcStride > 1, 0)) {
+                // (the stride is made opaque here: the compiler would otherwise keep the reciprocal of this division in a register
+                //  across the whole round loop -- and spill it -- for a test that only the root of a sharded run ever makes)
+                int st = rcStride;
+                asm volatile("" : "+s"(st));
+                live = live && ((int)colOf[c & 63] % st) == rcOffset;
+            }
             const u64 key = lbKey[myNode * 64 + lane];
             const double m = from_key((int)((u32)(key >> 32) ^ 0x80000000u), (u32)key);
             const u32 inH = lbIn[myNode * 64 + lane];
@@ -1090,8 +1099,8 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                     // the distance settled so far -- deferred (the node's ticket) unless that is beyond the valid bound too
                     // (the node's bounds are fetched again here rather than kept in registers across the child loop)
                     if (optOn && st == 2) {
-                        const double pg = nd.gain[0], bo = opt->bAbs[w];
-                        const double boundV = (T < INF) ? (T - pg) + 1e-9 * (fabs(T) + cmaxv) : INF;
+                        const double pg = nd.gain[0], bo = opt->bAbs[w];  // (two independent LDS reads)
+                        const double boundV = (T - pg) + 1e-9 * (fabs(T) + cmaxv);  // (+inf with T)
                         if (bo < T && !(delta > boundV) && lane == 0) {
                             const double lbAbs = pg + delta;
                             int khi;
@@ -1217,9 +1226,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             if (isNode) opt->defKey[lane] = ~0ull;
             const double oK = lane < nTo ? opt->TK[lane] : INF;
             const int oS = lane < nTo ? (int)opt->TS[lane] : -1;
-            bool consumed = false;
-            for (int w = 0; w < nsel; w++)
-                if ((selTicket >> w) & 1u) consumed = consumed || (oS == __builtin_amdgcn_readlane(sidL, w));
+            const bool consumed = lane < (int)selTicket;  // (selected in list order, and the list has not changed since)
             const bool oKeep = lane < nTo && !consumed && !(oK > T);
             const u64 keepM = __ballot(oKeep);
             u64 newM = __ballot(hasNew);
@@ -1322,20 +1329,18 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         for (int w = 0; w < MS; w++) { sIdx[w] = -1; sSid[w] = 0; }
         // wave 0 walks the whole selection (it writes the control block); wave w only as far as its own, the w-th
         const int walk = (wave == 0 || budget <= wave) ? budget : wave + 1;
-        // Re-split tickets (struct Opt) take their places in the selection by key, between the candidates: the first OPT_TSEL
-        // of the (sorted) list are considered per round.  myTicket: this wave's node is a ticket; sTickM: which of the round's.
-        const int nTl = optOn ? uni32(opt->nT) : 0;
-        const int nTc = nTl < OPT_TSEL ? nTl : OPT_TSEL;
-        double tMin = INF;  // emission stops at the smallest ticket key (+inf: no ticket)
-        bool myTicket = false;
-        u32 sTickM = 0u;
-        if (nTc == 0) {
+        int firstOpen = -1;  // pool index of the first candidate that has not been split
+        // the candidates: selection ranks rank0, rank0 + 1, ... go to the first open entries of the pool, in pool order
+        auto walk_candidates = [&](int rank0) {
+            nselNew = rank0;
+            nLazy = 0;
             for (int base = 0; base < nq && nselNew < walk; base += 64) {
                 const int i = base + lane;
                 const bool open = i < nq && !(PM[i] & META_SPLIT) && !(S > 1 && PG[i] > tShared);
                 const unsigned short ps = (i < nq) ? PS[i] : SID_NONE;
                 u64 m = __ballot(open);
                 const u64 lazyM = __ballot(open && ps == SID_NONE);
+                if (m && firstOpen < 0) firstOpen = base + __builtin_ctzll(m);
                 while (m && nselNew < walk) {
                     const int bitpos = __builtin_ctzll(m);
                     const bool lazy = (lazyM >> bitpos) & 1ull;
@@ -1350,50 +1355,56 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                     m &= m - 1;
                 }
             }
-        } else {
-            const double tkL = (lane < nTc) ? opt->TK[lane] : INF;
-            tMin = readlane_f64(tkL, 0);
-            int tNext = 0;
-            auto place_ticket = [&]() {  // the next ticket of the list takes selection rank nselNew
-                const int sidT = uni32((int)opt->TS[tNext]);
-                const double keyT = readlane_f64(tkL, tNext);
-                if (nselNew == wave) { mySel = -1; mySid = sidT; myTicket = true; }
+        };
+        walk_candidates(0);
+        // Re-split tickets (struct Opt): a ticket is DUE when its key is at or below the gain of the first open candidate (it
+        // would block the emission of everything from there on); the due tickets -- the first tSel of the sorted list -- take the
+        // first selection ranks of the round and the candidates move up.  Rare (a few per matrix): a second walk then.
+        const int nTl = optOn ? uni32(opt->nT) : 0;
+        int tSel = 0;
+        if (nTl > 0) {
+            const double g1 = firstOpen >= 0 ? PG[firstOpen] : INF;
+            const double tk = lane < nTl ? opt->TK[lane] : INF;
+            tSel = __popcll(__ballot(lane < nTl && tk <= g1));
+            tSel = tSel > OPT_TSEL ? OPT_TSEL : tSel;
+            tSel = tSel > budget ? budget : tSel;
+            if (tSel > 0) {
+                mySel = -1;
+#pragma unroll
+                for (int w = 0; w < MS; w++) { sIdx[w] = -1; sSid[w] = 0; }
+                walk_candidates(tSel);
+                if (wave < tSel) { mySel = -1; mySid = uni32((int)opt->TS[wave]); }
                 if (wave == 0) {
 #pragma unroll
-                    for (int w = 0; w < MS; w++) if (w == nselNew) { sIdx[w] = -1; sSid[w] = sidT; }
-                    if (lane == 0) opt->bAbs[nselNew] = keyT;  // (the ticket's key: turned into the node's bound below)
-                }
-                sTickM |= 1u << nselNew;
-                nselNew++;
-                tNext++;
-            };
-            for (int base = 0; base < nq && nselNew < walk; base += 64) {
-                const int i = base + lane;
-                const bool open = i < nq && !(PM[i] & META_SPLIT) && !(S > 1 && PG[i] > tShared);
-                const unsigned short ps = (i < nq) ? PS[i] : SID_NONE;
-                const double pgL = (i < nq) ? PG[i] : 0.0;
-                u64 m = __ballot(open);
-                const u64 lazyM = __ballot(open && ps == SID_NONE);
-                while (m && nselNew < walk) {
-                    const int bitpos = __builtin_ctzll(m);
-                    if (tNext < nTc) {  // tickets at or below this candidate's gain go first
-                        const double gC = readlane_f64(pgL, bitpos);
-                        while (tNext < nTc && nselNew < walk && readlane_f64(tkL, tNext) <= gC) place_ticket();
-                        if (nselNew >= walk) break;
-                    }
-                    const bool lazy = (lazyM >> bitpos) & 1ull;
-                    const int sidv = lazy ? sidBase + nLazy : __builtin_amdgcn_readlane((int)ps, bitpos);
-                    if (nselNew == wave) { mySel = base + bitpos; mySid = sidv; }
-                    if (wave == 0) {
-#pragma unroll
-                        for (int w = 0; w < MS; w++) if (w == nselNew) { sIdx[w] = base + bitpos; sSid[w] = sidv; }
-                    }
-                    nLazy += lazy ? 1 : 0;
-                    nselNew++;
-                    m &= m - 1;
+                    for (int w = 0; w < MS; w++) if (w < tSel) { sIdx[w] = -1; sSid[w] = uni32((int)opt->TS[w]); }
                 }
             }
-            while (tNext < nTc && nselNew < walk) place_ticket();  // tickets beyond the last open candidate
+        }
+        const bool myTicket = wave < tSel;
+        if (optOn && wave == NW - 1) {
+            // The optimistic bound of the nodes just selected (struct Opt), by the LAST wave -- it has walked the whole selection, and
+            // wave 0, whose emission bookkeeping is the critical path of this phase, is left alone --: the gain at the rho-quantile of
+            // the pool's candidates, rho growing from optRho0 to optRho1 while the first optPhi * k solutions go out (early on most
+            // of the pool is speculation, late most of it is the answer); for a ticket at least a step beyond its key (progress).
+            // ANY value is correct -- the users take the minimum with the round's valid threshold --, so the pool is taken as it
+            // stands before this round's emission; with no room for the round's tickets there is no guess.
+            double bA = INF;
+            if (nq >= p.optMinPool && nTl + nselNew <= OPT_TICKETS) {
+                const int n = nq < R ? nq : R;
+                float rho = p.optRho0 + p.optSlope * (float)emitted;  // (optSlope: kbest_engine.h)
+                rho = (p.optSlope >= 0.0f) == (rho > p.optRho1) ? p.optRho1 : rho;
+                int qi = (int)(rho * (float)n);
+                qi = qi >= n ? n - 1 : (qi < 0 ? 0 : qi);
+                bA = PG[qi];
+            }
+            if (lane < tSel) {  // (selection rank = place in the list)
+                const double K = opt->TK[lane];
+                const double up = K + p.optKappa * (K - opt->gRoot) + 8e-9 * (fabs(K) + cmaxv);
+                bA = up > bA ? up : bA;
+            }
+            if (lane < nselNew) opt->bAbs[lane] = bA;
+            const u64 fin = __ballot(lane < nselNew && bA < INF);
+            if (lane == 0) { opt->anyFinite = fin != 0ull ? 1 : 0; opt->selTicket = (u32)tSel; }
         }
         // The saved state of this wave's node: the loads are issued here and land in registers while wave 0 does the
         // emission bookkeeping below (it has a node of its own to bring in, and would otherwise be the last at the barrier
@@ -1402,7 +1413,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         const bool lazyNode = haveNode && !myTicket && uni32((int)PS[mySel < 0 ? 0 : mySel]) == (int)SID_NONE;
         double ldU = 0.0, ldV = 0.0, ldGain = 0.0;
         int ldR = 0, ldC = 0, ldA = 0;
-        u64 ldForb = 0, ldDone = 0;
+        u64 ldForb = 0;
         if (haveNode && !lazyNode) {
             const unsigned char *st = stBase + (long long)mySid * p.stateStride;
             const double *sd = reinterpret_cast<const double *>(st);
@@ -1416,7 +1427,6 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 ldForb = *reinterpret_cast<const u64 *>(st + offTail);
                 ldGain = *reinterpret_cast<const double *>(st + offTail + 8);
                 ldA = *reinterpret_cast<const int *>(st + offTail + 16);
-                if (myTicket) ldDone = *reinterpret_cast<const u64 *>(st + offDone);  // (a first split starts from an empty mask)
             }
         }
         if (wave == 0) {
@@ -1427,6 +1437,10 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             // ~10 000 cycles per round.)
             int e = emitted, h = 0, stop = 0;
             const double cdel = ctrl->cdelta, g0u = ctrl->gain0u;
+            const double tMin = nTl > 0 ? opt->TK[0] : INF;  // emission stops at the smallest ticket key (struct Opt)
+            int sidFirst = sSid[0];                          // state slot of the first selected CANDIDATE (rank tSel)
+#pragma unroll
+            for (int w = 1; w < MS; w++) sidFirst = (w == tSel) ? sSid[w] : sidFirst;
             bool more = true;
             for (int base = 0; more && base < nq && e < k; base += 64) {
                 const int i = base + lane;
@@ -1455,10 +1469,10 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 const bool tCut = (__ballot(cutB) >> run) & 1ull;
                 if (tSh) { stop = 1; break; }
                 if ((__ballot(tickB) >> run) & 1ull) break;  // behind a ticket: wait for its node's re-split
-                if (!tSplit && nselNew == 0) break;  // not split and not selected this round: wait
+                if (!tSplit && nselNew <= tSel) break;  // not split and not selected this round: wait
                 if (lane == run) {
                     p.gain[outBase + e] = gu;
-                    slotSid[e] = (unsigned short)(tSplit ? psid : sSid[0]);
+                    slotSid[e] = (unsigned short)(tSplit ? psid : sidFirst);
                 }
                 if (tCut) { stop = 1; break; }  // cpp:709-719: slot written, not counted
                 e++;
@@ -1481,44 +1495,13 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 ctrl->head = h;
 #pragma unroll
                 for (int w = 0; w < MS; w++) { ctrl->selIdx[w] = (short)sIdx[w]; ctrl->selSid[w] = (unsigned short)sSid[w]; }
-                opt->selTicket = sTickM;
                 if (stop) ctrl->stop = 1;
-            }
-            if (optOn) {
-                // The optimistic bound of the nodes just selected (struct Opt), from the pool as it stands for their round: the gain
-                // at the rho-quantile of its candidates, rho growing from optRho0 to optRho1 while the first optPhi * k solutions
-                // go out (early on most of the pool is speculation, late most of it is the answer); for a ticket at least a step
-                // beyond its key (progress).  Any value is correct (the users take the minimum with the valid threshold); with no
-                // room for the round's tickets there is no guess.
-                const int Rn = k - e, nOldN = nq - h;
-                double Tv = (Rn > 0 && nOldN >= Rn) ? PG[h + Rn - 1] : INF;
-                if (useCut && !maximize && cutG < Tv) Tv = cutG;
-                double Tgn = Tv;
-                if (nOldN >= p.optMinPool && nTl + nselNew <= OPT_TICKETS) {
-                    const int n = nOldN < Rn ? nOldN : Rn;
-                    float fr = (float)e / (p.optPhi * (float)k);
-                    fr = fr > 1.0f ? 1.0f : fr;
-                    int qi = (int)((p.optRho0 + (p.optRho1 - p.optRho0) * fr) * (float)n);
-                    qi = qi >= n ? n - 1 : (qi < 0 ? 0 : qi);
-                    const double gq = PG[h + qi];
-                    if (gq < Tgn) Tgn = gq;
-                }
-                wave_fence();
-                double bA = Tgn;
-                if (lane < nselNew && ((sTickM >> lane) & 1u)) {
-                    const double K = opt->bAbs[lane];
-                    const double up = K + (double)p.optKappa * (K - opt->gRoot) + 8e-9 * (fabs(K) + ctrl->cmax);
-                    bA = up > bA ? up : bA;
-                }
-                bA = bA < Tv ? bA : Tv;
-                if (lane < nselNew) opt->bAbs[lane] = bA;
-                const u64 fin = __ballot(lane < nselNew && bA < INF);
-                if (lane == 0) opt->anyFinite = fin != 0ull ? 1 : 0;
             }
         }
         if (haveNode) {
             const NodeRef nd = node_ref(smem + L.offNodes + (size_t)wave * L.nodeStride, p.maxRow);
-            if (lane == 0) opt->done[wave] = ldDone;
+            // children completed in an earlier split of this node: a first split starts from an empty mask, a ticket's from the saved one
+            if (optOn && lane == 0) opt->done[wave] = myTicket ? *reinterpret_cast<const u64 *>(stBase + (long long)mySid * p.stateStride + offDone) : 0ull;
             if (!lazyNode) {
                 // the hypothesis was kept when it was found: its state is in registers by now
                 if (lane < D) {

@@ -390,7 +390,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
     unsigned char *colOf = reinterpret_cast<unsigned char *>(gainW), *posOf = colOf + 64;
     if (tid < 64) { colOf[tid] = (unsigned char)tid; posOf[tid] = (unsigned char)tid; }
     __syncthreads();
-    const bool reorder = prune && M >= 3 && k >= 3 && !(p.flags & (KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_REORDER));
+    // (not under root-subtree sharding: the shards of kbest_c.h are those of the reference's column order, kbest_engine.hip)
+    const bool reorder = prune && p.rootColStride <= 1 && M >= 3 && k >= 3 && !(p.flags & (KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_REORDER));
     if (reorder) {
         double *key = freshG;
         const int nb0 = L.offNodes;
@@ -539,7 +540,12 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
                         const int sidP = *reinterpret_cast<const int *>(smem + nbN + N_SID);
                         const u32 forb = (c == a) ? nforb : (1u << frN);                               // cpp:490 / cpp:510-516
                         // (root-subtree sharding partitions on the REFERENCE's column, kbest_c.h: the enumeration's own order depends on the launch)
-                        const bool live = got && !(sidP == 0 && p.rootColStride > 1 && ((int)colOf[c] % p.rootColStride) != p.rootColOffset);
+                        bool live = got;
+                        if (__builtin_expect(p.rootColStride > 1, 0)) {  // (the stride opaque: its reciprocal must not be kept across the rounds)
+                            int st = p.rootColStride;
+                            asm volatile("" : "+s"(st));
+                            live = got && !(sidP == 0 && ((int)colOf[c] % st) != p.rootColOffset);
+                        }
                         const double bnd = *reinterpret_cast<const double *>(smem + nbN + N_BOUND);
                         const u32 candP = (cand >> partRow) & ((1u << RL) - 1u), forbP = (forb >> partRow) & ((1u << RL) - 1u);
                         nb = got ? nbN : nb;

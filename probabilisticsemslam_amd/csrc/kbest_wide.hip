@@ -605,7 +605,8 @@ __global__ void __launch_bounds__(NWV * 64, (R >= 16 ? 1 : (NWV == 16 ? 4 : (R <
         // Columns that are dear to change first, cheap ones last; key = the exact cost of taking a column's row away with nothing
         // else fixed (one search per column from the root's duals; every wave brings the root into its own working set).  The
         // gains are still summed and the tables written in the reference's column order (posOf / colOf).
-        if (prune && M >= 3 && k >= 3 && !(p.flags & (KBEST_FLAG_EXACT_ROOT | KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_REORDER))) {
+        // (not under root-subtree sharding: the shards of kbest_c.h are those of the reference's column order, kbest_engine.hip)
+        if (prune && p.rootColStride <= 1 && M >= 3 && k >= 3 && !(p.flags & (KBEST_FLAG_EXACT_ROOT | KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_REORDER))) {
             double v[R];
             u32 all = 0;
             {
