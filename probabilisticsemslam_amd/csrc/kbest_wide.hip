@@ -949,10 +949,11 @@ __global__ void __launch_bounds__(NWV * 64, (R >= 16 ? 1 : (NWV == 16 ? 4 : (R <
             // entry then finds how many children go before it by a binary search there -- with k in the thousands
             // (bruteForceProb) the pool is what is long, and a linear pass over the children per entry was the round
             {
-                double cg[2];
-                int cs[2], cr[2];
+                constexpr int EPC = (1024 + NT - 1) / NT < 2 ? 2 : (1024 + NT - 1) / NT;  // wide_lds_layout: at most 1024 children per round
+                double cg[EPC];
+                int cs[EPC], cr[EPC];
 #pragma unroll
-                for (int e = 0; e < 2; e++) {  // wide_lds_layout: at most 1024 children per round, NT >= 512
+                for (int e = 0; e < EPC; e++) {
                     const int j = tid + e * NT;
                     cr[e] = -1;
                     if (j < nChild) {
@@ -968,7 +969,7 @@ __global__ void __launch_bounds__(NWV * 64, (R >= 16 ? 1 : (NWV == 16 ? 4 : (R <
                 }
                 __syncthreads();
 #pragma unroll
-                for (int e = 0; e < 2; e++)
+                for (int e = 0; e < EPC; e++)
                     if (cr[e] >= 0) { childG[cr[e]] = cg[e]; childS[cr[e]] = cs[e]; }
                 __syncthreads();
             }
