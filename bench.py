@@ -351,12 +351,38 @@ def host_inclusive_dense(eng, costs, N, M, k):
                 pass
         regs.clear()
     best = registered if registered is not None else pageable
+    # the same call with the int32 tables crossing the link as they are (round 3's path, KBEST_NO_NARROW: a second context)
+    wide_ms = None
+    try:
+        import probabilisticsemslam_amd as pk
+        os.environ["KBEST_NO_NARROW"] = "1"
+        eng_w = pk.KBestEngine(0)
+        del os.environ["KBEST_NO_NARROW"]
+        eng_main, eng = eng, eng_w
+        try:
+            eng_w.register_host(costs, r4c, c4r, gain, nf)
+            wide_ms = 1e3 * timed()
+            assert all(np.array_equal(x, y) for x, y in zip(ref, (r4c, c4r, gain, nf))), "narrow staging differs from the int32 tables written by the kernel"
+        finally:
+            for a in (costs, r4c, c4r, gain, nf):
+                try:
+                    eng_w.unregister_host(a)
+                except pk_engine.KBestError:
+                    pass
+            eng = eng_main
+            eng_w.close()
+    except pk_engine.KBestError:
+        os.environ.pop("KBEST_NO_NARROW", None)
     out = {"value": float(nf.sum()) / best, "unit": "assignments/s", "ms": 1e3 * best,
-           "includes": "H2D of the cost blocks, kernel, D2H of row4col / col4row / gain / nf (host buffers in and out: kbest_batch_f64)",
-           "buffers": "caller-owned numpy arrays, reused across calls and registered once with kbest_register_host_buffer (pinned, "
-                      "device-mapped): the kernel writes the tables there as the slots become final" if registered is not None else "pageable",
+           "includes": "H2D of the cost blocks, kernel, D2H of row4col / col4row / gain / nf (host buffers in and out: kbest_batch_f64), into the "
+                       "caller's int32 tables: the kernels write row4col as bytes into pinned staging, in four pieces; host threads of the "
+                       "context widen a piece into row4col and its inverse col4row while the GPU works on the next one",
+           "buffers": "caller-owned numpy arrays, reused across calls; cost blocks registered once with kbest_register_host_buffer (read in "
+                      "place by the kernel)" if registered is not None else "pageable",
            "pageable_ms": 1e3 * pageable,
-           "pageable_what": "the same call with unregistered (pageable) buffers: staging copies, two halves overlapped"}
+           "pageable_what": "the same call with unregistered (pageable) buffers: the cost blocks are uploaded piece by piece",
+           "ms_int32_tables_over_the_link": wide_ms,
+           "int32_over_the_link_what": "round 3's path (KBEST_NO_NARROW): the kernel writes the 107 MB of int32 tables into registered caller memory itself"}
     if registered is None:
         out["register_error"] = err
     else:

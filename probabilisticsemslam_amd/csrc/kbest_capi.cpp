@@ -8,8 +8,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kbest_c.h"
@@ -20,6 +23,69 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 }
 
 struct DevBufRaw { void *p = nullptr; size_t bytes = 0; };
+
+// A few host threads of the context for the host-side half of the host-buffer entry (widening byte tables into the caller's
+// int32 tables while the GPU works on the next piece): created at first use, parked on a condition variable between calls.
+struct HostPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cvGo, cvDone;
+    const std::function<void(int)> *job = nullptr;
+    std::atomic<int> next{0};
+    int nTasks = 0, busy = 0;
+    unsigned long long gen = 0;
+    bool quit = false;
+    void worker()
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            const std::function<void(int)> *j;
+            int n;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cvGo.wait(lk, [&] { return quit || gen != seen; });
+                if (quit) return;
+                seen = gen;
+                j = job;
+                n = nTasks;
+            }
+            for (int t; (t = next.fetch_add(1, std::memory_order_relaxed)) < n;) (*j)(t);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--busy == 0) cvDone.notify_all();
+            }
+        }
+    }
+    void start(int n)
+    {
+        for (int i = 0; i < n; i++) th.emplace_back([this] { worker(); });
+    }
+    // fn(0 .. n-1), spread over the pool and the calling thread; returns when all are done
+    void run(int n, const std::function<void(int)> &fn)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job = &fn;
+            nTasks = n;
+            next.store(0, std::memory_order_relaxed);
+            busy = (int)th.size();
+            gen++;
+        }
+        cvGo.notify_all();
+        for (int t; (t = next.fetch_add(1, std::memory_order_relaxed)) < n;) fn(t);
+        std::unique_lock<std::mutex> lk(mu);
+        cvDone.wait(lk, [&] { return busy == 0; });
+    }
+    ~HostPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quit = true;
+        }
+        cvGo.notify_all();
+        for (auto &t : th) t.join();
+    }
+};
 
 struct kbest_ctx {
     int device = 0;
@@ -78,6 +144,11 @@ struct kbest_ctx {
     // through one asynchronous copy each way.
     struct Arena { void *host = nullptr; void *dev = nullptr; size_t bytes = 0; };
     Arena pinIn, pinOut;
+    Arena pinTab;             // byte tables + gains + counts of the host-buffer entry's narrow staging (kbest_batch_f64)
+    HostPool *pool = nullptr; // host threads that widen them (created at first use)
+    std::mutex narrowMu;      // one narrow-staged call at a time per context (the staging memory and the pool are the context's)
+    int hostThreads = 0;      // KBEST_HOST_THREADS: size of that pool (0 = choose: up to 31 + the caller)
+    bool noNarrow = false;    // KBEST_NO_NARROW: int32 tables cross PCIe as they are (A/B tests)
     DevBufRaw stageIn, stageOut;
     // Device buffers of the host-pointer entry points are recycled: the reference calls assignmentProb once per
     // frame, and a dozen hipMalloc/hipFree pairs per call cost more than the kernels of a 30 x 10 problem.
@@ -308,6 +379,8 @@ int kbest_create(kbest_ctx **out, int device)
     if (const char *e = getenv("KBEST_LANE_SPEC")) { const int w = atoi(e); if (w >= 1 && w <= kb::LANE_MAX_SPEC) ctx->laneSpec = w; }
     ctx->forceSmall = getenv("KBEST_FORCE_SMALL") != nullptr;
     ctx->noOpt = getenv("KBEST_NO_OPT") != nullptr;
+    ctx->noNarrow = getenv("KBEST_NO_NARROW") != nullptr;
+    if (const char *e = getenv("KBEST_HOST_THREADS")) ctx->hostThreads = atoi(e);
     if (const char *e = getenv("KBEST_OPT_RHO0")) ctx->optRho0 = (float)atof(e);
     if (const char *e = getenv("KBEST_OPT_RHO1")) ctx->optRho1 = (float)atof(e);
     if (const char *e = getenv("KBEST_OPT_PHI")) ctx->optPhi = (float)atof(e);
@@ -344,6 +417,8 @@ int kbest_destroy(kbest_ctx *ctx)
     for (auto &b : ctx->cache) (void)hipFree(b.p);
     if (ctx->pinIn.host) (void)hipHostFree(ctx->pinIn.host);
     if (ctx->pinOut.host) (void)hipHostFree(ctx->pinOut.host);
+    if (ctx->pinTab.host) (void)hipHostFree(ctx->pinTab.host);
+    delete ctx->pool;
     if (ctx->stageIn.p) (void)hipFree(ctx->stageIn.p);
     if (ctx->stageOut.p) (void)hipFree(ctx->stageOut.p);
     if (ctx->splitBuf.p) (void)hipFree(ctx->splitBuf.p);
@@ -426,6 +501,7 @@ static bool k_fits_fast(const kbest_ctx *ctx, int B, int fastRow, int k, unsigne
 
 static int ensure_states(kbest_ctx *ctx, size_t need, bool grow);
 static int raw_reserve(kbest_ctx *ctx, DevBufRaw &d, size_t need);
+static int arena_reserve(kbest_ctx *ctx, kbest_ctx::Arena &a, size_t need);
 
 // per-share result tables [S][B][...] + one shared threshold per matrix of a split launch (split_factor)
 struct SplitLayout {
@@ -990,6 +1066,10 @@ int kbest_unregister_host_buffer(kbest_ctx *ctx, void *ptr)
 
 }  // extern "C"
 
+static inline size_t outBytesHint(int B, int k, int maxRow, int maxCol) { return (size_t)B * k * ((size_t)maxRow + maxCol) * 4; }
+// registered cost blocks are read by the LDS kernels in place (one trip over the link, no upload in front of the first workgroup)
+static inline bool zcCostOK(bool pinnedCost, const kbest_ctx *ctx) { return pinnedCost && ctx->zcCost != 0; }
+
 // The host-buffer entry.  `keep` (kbest_multi.cpp): the result tables are staged in the CALLER's device buffers -- a device's
 // packed slice of the multi-device global table -- and stay there after they have been copied back, so that the all-gather
 // can follow; everything else (pieces, uploads, copies back) is the single-device path.
@@ -1039,6 +1119,120 @@ int kbest_batch_f64_keep(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxR
     // copies back of pageable tables (measured slower: they share the link).
     const bool zcCost = pinnedCost && direct && ctx->zcCost && maxRow <= KBEST_MAX_DIM && !ctx->forceWide &&
                         k_fits_fast(ctx, B, maxRow < KBEST_MAX_DIM ? maxRow : KBEST_MAX_DIM, k, opts->flags, nullptr);
+    // Narrow staging: the reference's int32 tables are 107 MB for 1 024 x 64x64, k = 200, and the link, not the kernel, set the time
+    // of this entry (3.1 ms against 1.8).  Every index fits a byte and col4row is the inverse of row4col on a square problem, so
+    // the kernels write row4col as BYTES into pinned staging memory (13 MB, as the slots become final), in pieces, and host
+    // threads widen a piece into the caller's row4col / col4row while the GPU works on the next one.  Uniform square batches of
+    // up to 64 rows (every row has a column: the inverse is complete); everything else takes the path below.
+    const bool narrow = !keep && !tabI8 && !pushed && !nRow && !costOff && maxRow == maxCol && maxRow <= KBEST_MAX_DIM && !ctx->forceWide &&
+                        !ctx->noNarrow && outBytesHint(B, k, maxRow, maxCol) >= ((size_t)8 << 20) &&
+                        k_fits_fast(ctx, B, maxRow, k, opts->flags, nullptr);
+    if (narrow) {
+        std::lock_guard<std::mutex> narrowLock(ctx->narrowMu);
+        const size_t offG = (nR4C + 63) & ~(size_t)63, offN = offG + nG * 8, tabBytes = offN + (size_t)B * 4;
+        {
+            std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+            int rc0 = arena_reserve(ctx, ctx->pinTab, tabBytes);
+            if (rc0 != KBEST_OK) return rc0;
+            if (!ctx->pool) {
+                int nth = ctx->hostThreads > 0 ? ctx->hostThreads - 1 : (int)std::thread::hardware_concurrency() - 1;
+                nth = nth > 31 ? 31 : (nth < 0 ? 0 : nth);
+                ctx->pool = new HostPool;
+                ctx->pool->start(nth);
+            }
+        }
+        signed char *h8 = static_cast<signed char *>(ctx->pinTab.host);
+        char *d8 = static_cast<char *>(ctx->pinTab.dev);
+        const double *hG = reinterpret_cast<const double *>(h8 + offG);
+        const int32_t *hN = reinterpret_cast<const int32_t *>(h8 + offN);
+        DevBuf dCostN;
+        if (!zcCostOK(pinnedCost, ctx)) HIP_TRY(ctx, dCostN.alloc(ctx, nCost * 8));
+        const bool zc = zcCostOK(pinnedCost, ctx);
+        const double *devC = zc ? mCost : dCostN.as<double>();
+        const int nP = (B >= 4 * ctx->nCU) ? 4 : 1;
+        for (int i = 0; i < 3 && nP > 1; i++)
+            if (!ctx->aux[i]) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking));
+        kbest_opts o8 = *opts;
+        o8.flags |= KBEST_FLAG_TABLES_I8;
+        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}, start = nullptr;
+        hipStream_t st[4] = {ctx->stream, ctx->aux[0], ctx->aux[1], ctx->aux[2]};
+        int rc = KBEST_OK;
+        std::unique_lock<std::recursive_mutex> pieceLock(ctx->mu);  // the context is held from the first piece to the last
+        rc = order_behind_last(ctx, ctx->stream);
+        if (rc == KBEST_OK && nP > 1) {
+            if (hipEventCreateWithFlags(&start, hipEventDisableTiming) != hipSuccess || hipEventRecord(start, ctx->stream) != hipSuccess)
+                rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: event", hipGetLastError());
+            for (int c = 1; c < nP && rc == KBEST_OK; c++)
+                if (hipStreamWaitEvent(st[c], start, 0) != hipSuccess) rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: wait", hipGetLastError());
+        }
+        const size_t per = (size_t)maxRow * maxCol;
+        // the host half of a piece: row4col widened, col4row = its inverse, gains and counts copied -- by the context's host threads
+        auto widen_piece = [&](int c) {
+            const int b0 = (int)((long long)B * c / nP), nb = (int)((long long)B * (c + 1) / nP) - b0;
+            if (hipEventSynchronize(ev[c]) != hipSuccess) { rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: synchronize", hipGetLastError()); return; }
+            const int chunk = 2, nTask = (nb + chunk - 1) / chunk;
+            const std::function<void(int)> widen = [&](int t) {
+                const int lo = b0 + t * chunk, hi = lo + chunk < b0 + nb ? lo + chunk : b0 + nb;
+                for (int b = lo; b < hi; b++) {
+                    const signed char *src = h8 + (size_t)b * k * maxCol;
+                    int32_t *r4 = row4col + (size_t)b * k * maxCol;
+                    int32_t *c4 = col4row ? col4row + (size_t)b * k * maxRow : nullptr;
+                    for (int sl = 0; sl < k; sl++) {
+                        const signed char *s8 = src + (size_t)sl * maxCol;
+                        int32_t *r = r4 + (size_t)sl * maxCol;
+                        for (int j = 0; j < maxCol; j++) r[j] = (int32_t)s8[j];
+                        if (c4) {
+                            int32_t *cc = c4 + (size_t)sl * maxRow;
+                            for (int j = 0; j < maxRow; j++) cc[j] = -1;
+                            for (int j = 0; j < maxCol; j++)
+                                if (s8[j] >= 0) cc[s8[j]] = j;
+                        }
+                    }
+                    memcpy(gain + (size_t)b * k, hG + (size_t)b * k, (size_t)k * 8);
+                    nf[b] = hN[b];
+                }
+            };
+            ctx->pool->run(nTask, widen);
+        };
+        for (int c = 0; c < nP && rc == KBEST_OK; c++) {
+            const int b0 = (int)((long long)B * c / nP), nb = (int)((long long)B * (c + 1) / nP) - b0;
+            hipError_t e = hipSuccess;
+            if (!zc) {
+                if (pinnedCost) e = hipMemcpyAsync(dCostN.as<double>() + (size_t)b0 * per, cost + (size_t)b0 * per, (size_t)nb * per * 8, hipMemcpyHostToDevice, st[c]);
+                else e = hipMemcpy(dCostN.as<double>() + (size_t)b0 * per, cost + (size_t)b0 * per, (size_t)nb * per * 8, hipMemcpyHostToDevice);
+            }
+            if (e != hipSuccess) { rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: upload", e); break; }
+            const SubBatch sub{B, b0};
+            int32_t *pR = reinterpret_cast<int32_t *>(d8 + (size_t)b0 * k * maxCol);
+            double *pG = reinterpret_cast<double *>(d8 + offG) + (size_t)b0 * k;
+            int32_t *pN = reinterpret_cast<int32_t *>(d8 + offN) + b0;
+            rc = batch_dev_impl(ctx, &o8, nb, maxRow, maxCol, nullptr, nullptr, devC + (size_t)b0 * per, nullptr, k, pR, nullptr, pG, pN, nullptr,
+                                st[c], true, nullptr, nP > 1 ? &sub : nullptr);
+            if (rc != KBEST_OK) break;
+            e = kb::launch_fill_unused(pN, nullptr, nullptr, nb, k, maxCol, maxRow, pR, nullptr, pG, true, st[c]);
+            if (e != hipSuccess) { rc = fail(ctx, KBEST_ERR_HIP, "fill kernel launch", e); break; }
+            if (hipEventCreateWithFlags(&ev[c], hipEventDisableTiming) != hipSuccess || hipEventRecord(ev[c], st[c]) != hipSuccess) {
+                rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: event", hipGetLastError());
+                break;
+            }
+            if (c > 0 && hipStreamWaitEvent(ctx->stream, ev[c], 0) != hipSuccess) { rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: wait", hipGetLastError()); break; }
+        }
+        pieceLock.unlock();
+        // (all pieces are in flight first: doing the host half of piece c - 1 before piece c + 1 is uploaded and launched was measured
+        //  slower, 2.47 -> 2.97 ms -- the host then waits for a piece that shares the GPU with its successor)
+        for (int c = 0; c < nP && rc == KBEST_OK; c++) widen_piece(c);
+        for (int c = 0; c < nP; c++) {
+            const hipError_t e = hipStreamSynchronize(st[c]);
+            if (e != hipSuccess && rc == KBEST_OK) rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: synchronize", e);
+        }
+        for (int c = 0; c < 4; c++)
+            if (ev[c]) (void)hipEventDestroy(ev[c]);
+        if (start) (void)hipEventDestroy(start);
+        if (rc != KBEST_OK) return rc;
+        for (int b = 0; b < B; b++)
+            if (nf[b] < 0) return fail(ctx, nf[b] == -1 ? KBEST_ERR_UNSUPPORTED : KBEST_ERR_INTERNAL, "kbest_batch_f64: a problem came back with nf < 0");
+        return KBEST_OK;
+    }
     DevBuf dCost, dOff, dNR, dNC, dR4C, dC4R, dGain, dNf, dPushed;
     if (!zcCost) HIP_TRY(ctx, dCost.alloc(ctx, nCost * 8));
     const double *devCost = zcCost ? mCost : dCost.as<double>();

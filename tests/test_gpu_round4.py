@@ -225,3 +225,43 @@ def test_general_size_kernel_beyond_512_rows(engine, shape):
         c = c4r[b, :onf].copy(); c[c >= M] = -1
         w = np.asarray(oc4r[:onf]).copy(); w[w >= M] = -1
         assert (c == w).all()
+
+
+@pytest.mark.parametrize("shape", [(1027, 64, 200), (300, 32, 200), (3000, 5, 200), (2100, 16, 150)])
+def test_narrow_staging_of_the_host_entry_equals_the_wide_tables(monkeypatch, shape):
+    """kbest_batch_f64 on uniform square batches: the kernels write row4col as bytes into pinned staging and host threads widen
+    it into the caller's int32 row4col and its inverse col4row, piece by piece.  Every table equals what the same entry gives
+    with the int32 tables written by the kernel itself (KBEST_NO_NARROW) -- also with fewer than k solutions (5x5: 120
+    assignments), with forbidden arcs, and from six host threads at once on one context."""
+    import threading
+    B, N, k = shape
+    rng = np.random.default_rng(B + N)
+    costs = rng.random((B, N * N))
+    if N == 16:
+        costs[rng.random(costs.shape) < 0.3] = np.inf
+    eng = pk.KBestEngine(0)
+    wide = engine_with(monkeypatch, KBEST_NO_NARROW=1)
+    a = eng.kbest(costs, N, N, k)
+    b = wide.kbest(costs, N, N, k)
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all() and (bits(a[3]) == bits(b[3])).all()
+    if N == 5:
+        assert (a[0] == 120).all() and (a[1][:, 120:] == -1).all() and (a[2][:, 120:] == -1).all() and (a[3][:, 120:] == 0).all()
+    for bb in range(0, B, max(1, B // 5)):
+        onf, or4c, oc4r, og = ol.orc_kbest(costs[bb], N, N, k)
+        assert a[0][bb] == onf and (a[1][bb, :onf] == or4c[:onf]).all() and (a[2][bb, :onf] == oc4r[:onf]).all()
+    if N == 32:
+        out, errs = [None] * 6, []
+
+        def work(i):
+            try:
+                out[i] = eng.kbest(costs, N, N, k)
+            except Exception as ex:  # noqa: BLE001
+                errs.append(ex)
+        th = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errs
+        for o in out:
+            assert (o[0] == a[0]).all() and (o[1] == a[1]).all() and (o[2] == a[2]).all() and (bits(o[3]) == bits(a[3])).all()
+    eng.close()
+    wide.close()
