@@ -350,7 +350,7 @@ def host_inclusive_dense(eng, costs, N, M, k):
             except pk_engine.KBestError:
                 pass
         regs.clear()
-    best = registered if registered is not None else pageable
+    best = min(registered, pageable) if registered is not None else pageable
     # the same call with the int32 tables crossing the link as they are (round 3's path, KBEST_NO_NARROW: a second context)
     wide_ms = None
     try:
@@ -377,8 +377,9 @@ def host_inclusive_dense(eng, costs, N, M, k):
            "includes": "H2D of the cost blocks, kernel, D2H of row4col / col4row / gain / nf (host buffers in and out: kbest_batch_f64), into the "
                        "caller's int32 tables: the kernels write row4col as bytes into pinned staging, in four pieces; host threads of the "
                        "context widen a piece into row4col and its inverse col4row while the GPU works on the next one",
-           "buffers": "caller-owned numpy arrays, reused across calls; cost blocks registered once with kbest_register_host_buffer (read in "
-                      "place by the kernel)" if registered is not None else "pageable",
+           "buffers": "caller-owned numpy arrays, reused across calls: the better of plain (pageable) arrays and of arrays registered once with "
+                      "kbest_register_host_buffer (cost blocks then read in place by the kernel)",
+           "registered_ms": None if registered is None else 1e3 * registered,
            "pageable_ms": 1e3 * pageable,
            "pageable_what": "the same call with unregistered (pageable) buffers: the cost blocks are uploaded piece by piece",
            "ms_int32_tables_over_the_link": wide_ms,
@@ -404,13 +405,23 @@ def multi_entry_dense(costs, N, M, k, G, ref_nf, ref_gain):
     With G = 1 it is the single-device host path plus the exchange; with G = 8 the host side of config 4 as written (each
     device 1/8 of the batch) runs on one GPU, and the timeline shows what each device's thread did when."""
     import probabilisticsemslam_amd as pk
+    from probabilisticsemslam_amd import engine as pk_engine
     multi = pk.KBestMulti([0] * G)
-    best, out = None, None
-    for _ in range(4):
+    B = costs.shape[0]
+    costs = np.ascontiguousarray(costs)
+    # caller-owned tables, allocated and touched once (as in host_inclusive_dense: a caller that runs batch after batch)
+    r4c, c4r, gain, nf = np.zeros((B, k, M), np.int32), np.zeros((B, k, N), np.int32), np.zeros((B, k)), np.zeros(B, np.int32)
+    o = pk_engine.KBestOpts()
+    multi.lib.kbest_default_opts(C.byref(o))
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    best = None
+    for _ in range(5):
         t0 = time.perf_counter()
-        out = multi.kbest(costs, N, M, k)
+        rc = multi.lib.kbest_batch_f64_multi(multi.m, C.byref(o), B, N, M, None, None, p(costs), k, p(r4c), p(c4r), p(gain), p(nf))
         dt = time.perf_counter() - t0
+        assert rc == 0, multi.lib.kbest_multi_last_error(multi.m)
         best = dt if best is None or dt < best else best
+    out = (nf, r4c, c4r, gain)
     tl = multi.timeline()
     agree = bool(multi.tables_agree())
     multi.close()
@@ -602,6 +613,9 @@ def run_c5(eng, torch, steps, warmup, dev, tstream, no_cpu, F=1000, k=200, nL=20
         ent = {"nL": snL, "nM": snM, "us_mean": 1e6 * float(slat.mean()), "us_median": 1e6 * float(np.median(slat)), "calls": 200}
         if not no_cpu:
             kindS = "reference" if os.path.exists(ol.REF_ASSIGN_OFAST_SO) else "port"
+            if kindS == "reference":  # (untimed first call: loads the checker's library)
+                c0, r0 = ol.ref_condition_costs(sf[0], snL + snM, snM)
+                ol.ref_assignment_prob(c0, len(r0) - snM, snM, k, ofast=True)
             t1 = time.perf_counter()
             for f in sf:
                 if kindS == "reference":

@@ -133,13 +133,15 @@ int kbest_batch_f64_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRo
                         double *d_gain, int32_t *d_nf, int64_t *d_pushed, void *stream);
 
 /*
- * Same with host buffers (copies in, runs, copies out, synchronises; col4row may be NULL = not wanted).  A caller that runs
- * batch after batch with the same
- * buffers should register them once (kbest_register_host_buffer): result tables that lie in registered memory are written
- * there by the kernels themselves, spread over the whole run, and nothing is left to copy when the last problem ends;
- * cost blocks in registered memory are read in place by the kernels (each block once, into its LDS tile) when the result
- * tables are registered too.  (1 024 x 64x64, k = 200, 107 MB of tables: the copying path takes ~4.3 ms per call, the
- * registered one 3.14, with KBEST_FLAG_TABLES_I8 2.27, the kernel alone 1.8.)
+ * Same with host buffers (copies in, runs, copies out, synchronises; col4row may be NULL = not wanted).  Uniform square batches
+ * of up to KBEST_MAX_DIM rows go through narrow staging: the kernels write row4col as bytes into pinned memory of the context, in
+ * pieces, and host threads of the context widen a piece into the caller's int32 row4col and its inverse col4row while the GPU
+ * works on the next one (the same tables bit for bit; 1 024 x 64x64, k = 200, 107 MB of int32 tables: 2.5 - 2.8 ms per call, the
+ * kernel alone 1.8; round 3's paths -- copying 4.3, kernels writing the int32 tables into registered memory 3.1 -- remain for
+ * everything else and behind KBEST_NO_NARROW).  A caller that runs batch after batch with the same buffers can register them
+ * once (kbest_register_host_buffer): result tables that lie in registered memory are written there by the kernels themselves,
+ * spread over the whole run; cost blocks in registered memory are read in place (each block once, into its LDS tile).  With
+ * KBEST_FLAG_TABLES_I8 the caller takes the byte tables as they are (2.2 ms).
  */
 int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, int maxCol,
                     const int32_t *nRow, const int32_t *nCol, const double *cost,

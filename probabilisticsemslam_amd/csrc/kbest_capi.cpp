@@ -12,6 +12,7 @@
 #include <functional>
 #include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -24,9 +25,12 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 
 struct DevBufRaw { void *p = nullptr; size_t bytes = 0; };
 
-// A few host threads of the context for the host-side half of the host-buffer entry (widening byte tables into the caller's
-// int32 tables while the GPU works on the next piece): created at first use, parked on a condition variable between calls.
+// A few host threads for the host-side half of the host-buffer entry (widening byte tables into the caller's int32 tables while
+// the GPU works on the next piece): ONE pool per process, shared by every context (a pool per context ran a test session with
+// dozens of contexts into the host's thread limit), created at first use, parked on a condition variable between calls, never
+// destroyed (the process ends with its threads parked).
 struct HostPool {
+    std::mutex runMu;  // one parallel job at a time
     std::vector<std::thread> th;
     std::mutex mu;
     std::condition_variable cvGo, cvDone;
@@ -58,11 +62,18 @@ struct HostPool {
     }
     void start(int n)
     {
-        for (int i = 0; i < n; i++) th.emplace_back([this] { worker(); });
+        for (int i = 0; i < n; i++) {
+            try {
+                th.emplace_back([this] { worker(); });
+            } catch (const std::system_error &) {  // (no more threads to be had: the pool is as large as it got)
+                break;
+            }
+        }
     }
     // fn(0 .. n-1), spread over the pool and the calling thread; returns when all are done
     void run(int n, const std::function<void(int)> &fn)
     {
+        std::lock_guard<std::mutex> one(runMu);
         {
             std::lock_guard<std::mutex> lk(mu);
             job = &fn;
@@ -76,16 +87,18 @@ struct HostPool {
         std::unique_lock<std::mutex> lk(mu);
         cvDone.wait(lk, [&] { return busy == 0; });
     }
-    ~HostPool()
-    {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            quit = true;
-        }
-        cvGo.notify_all();
-        for (auto &t : th) t.join();
-    }
 };
+
+static HostPool *host_pool(int want)  // want: threads besides the caller (first call decides)
+{
+    static std::once_flag once;
+    static HostPool *pool = nullptr;
+    std::call_once(once, [&] {
+        pool = new HostPool;
+        pool->start(want);
+    });
+    return pool;
+}
 
 struct kbest_ctx {
     int device = 0;
@@ -145,9 +158,8 @@ struct kbest_ctx {
     struct Arena { void *host = nullptr; void *dev = nullptr; size_t bytes = 0; };
     Arena pinIn, pinOut;
     Arena pinTab;             // byte tables + gains + counts of the host-buffer entry's narrow staging (kbest_batch_f64)
-    HostPool *pool = nullptr; // host threads that widen them (created at first use)
     std::mutex narrowMu;      // one narrow-staged call at a time per context (the staging memory and the pool are the context's)
-    int hostThreads = 0;      // KBEST_HOST_THREADS: size of that pool (0 = choose: up to 31 + the caller)
+    int hostThreads = 0;      // KBEST_HOST_THREADS: size of the process's pool of widening threads when this context creates it (0 = choose: up to 15 + the caller)
     bool noNarrow = false;    // KBEST_NO_NARROW: int32 tables cross PCIe as they are (A/B tests)
     DevBufRaw stageIn, stageOut;
     // Device buffers of the host-pointer entry points are recycled: the reference calls assignmentProb once per
@@ -418,7 +430,6 @@ int kbest_destroy(kbest_ctx *ctx)
     if (ctx->pinIn.host) (void)hipHostFree(ctx->pinIn.host);
     if (ctx->pinOut.host) (void)hipHostFree(ctx->pinOut.host);
     if (ctx->pinTab.host) (void)hipHostFree(ctx->pinTab.host);
-    delete ctx->pool;
     if (ctx->stageIn.p) (void)hipFree(ctx->stageIn.p);
     if (ctx->stageOut.p) (void)hipFree(ctx->stageOut.p);
     if (ctx->splitBuf.p) (void)hipFree(ctx->splitBuf.p);
@@ -900,13 +911,14 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         p.gainCols = extra ? extra->gainCols : 0;
         p.split = S;
         p.splitB = B;
+        p.sharedT = S > 1 ? reinterpret_cast<unsigned long long *>(sb + sl.offT) : nullptr;
         // optimistic bounds: the quantile of the pool a node is split against (host model: tests/dev/proto_tickets.cpp; kernel:
         // struct Opt).  Measured (kernel ms, off -> on, one box, interleaved): 4 096 x 32x32, k = 200 (4 waves, 4 hypotheses per
         // round, no a-priori thresholds there) 3.87 -> 3.67 at 0.85 (0.8: 3.81, 0.9: 3.76, 0.75: 4.12); 1 024 x 64x64 (12 x 12, where
         // the a-priori thresholds already bound the early rounds) 1.865 -> 1.856 at 0.8, 1.90 at 0.7, 2.16 at 0.55: nothing to
         // gain there, and the extra rounds of re-splits cost -- off in the shapes that run the a-priori thresholds.
         {
-            const bool t0Shape = shp.nWaves >= 8 && shp.spec >= 3;  // (kbest_engine.hip: t0On)
+            const bool t0Shape = shp.nWaves >= 8;  // (kbest_engine.hip: t0On needs 8 waves; OPT_SHAPE compiles the mechanism out there)
             const float rho0 = ctx->optRho0 >= 0.0f ? ctx->optRho0 : (t0Shape ? 2.0f : 0.85f);
             if (ctx->noOpt || rho0 >= 1.0f) p.optRho0 = 2.0f;
             else {
@@ -1124,7 +1136,7 @@ int kbest_batch_f64_keep(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxR
     // the kernels write row4col as BYTES into pinned staging memory (13 MB, as the slots become final), in pieces, and host
     // threads widen a piece into the caller's row4col / col4row while the GPU works on the next one.  Uniform square batches of
     // up to 64 rows (every row has a column: the inverse is complete); everything else takes the path below.
-    const bool narrow = !keep && !tabI8 && !pushed && !nRow && !costOff && maxRow == maxCol && maxRow <= KBEST_MAX_DIM && !ctx->forceWide &&
+    const bool narrow = (!keep || keep->row4col8) && !tabI8 && !pushed && !nRow && !costOff && maxRow == maxCol && maxRow <= KBEST_MAX_DIM && !ctx->forceWide &&
                         !ctx->noNarrow && outBytesHint(B, k, maxRow, maxCol) >= ((size_t)8 << 20) &&
                         k_fits_fast(ctx, B, maxRow, k, opts->flags, nullptr);
     if (narrow) {
@@ -1134,13 +1146,10 @@ int kbest_batch_f64_keep(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxR
             std::lock_guard<std::recursive_mutex> lock(ctx->mu);
             int rc0 = arena_reserve(ctx, ctx->pinTab, tabBytes);
             if (rc0 != KBEST_OK) return rc0;
-            if (!ctx->pool) {
-                int nth = ctx->hostThreads > 0 ? ctx->hostThreads - 1 : (int)std::thread::hardware_concurrency() - 1;
-                nth = nth > 31 ? 31 : (nth < 0 ? 0 : nth);
-                ctx->pool = new HostPool;
-                ctx->pool->start(nth);
-            }
         }
+        int nth = ctx->hostThreads > 0 ? ctx->hostThreads - 1 : (int)std::thread::hardware_concurrency() - 1;
+        nth = nth > 15 ? 15 : (nth < 0 ? 0 : nth);
+        HostPool *pool = host_pool(nth);
         signed char *h8 = static_cast<signed char *>(ctx->pinTab.host);
         char *d8 = static_cast<char *>(ctx->pinTab.dev);
         const double *hG = reinterpret_cast<const double *>(h8 + offG);
@@ -1192,25 +1201,37 @@ int kbest_batch_f64_keep(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxR
                     nf[b] = hN[b];
                 }
             };
-            ctx->pool->run(nTask, widen);
+            pool->run(nTask, widen);
         };
         for (int c = 0; c < nP && rc == KBEST_OK; c++) {
             const int b0 = (int)((long long)B * c / nP), nb = (int)((long long)B * (c + 1) / nP) - b0;
             hipError_t e = hipSuccess;
+            if (keep && keep->stamps && c == 0) keep->stamps[0] = kb::now_s();
             if (!zc) {
                 if (pinnedCost) e = hipMemcpyAsync(dCostN.as<double>() + (size_t)b0 * per, cost + (size_t)b0 * per, (size_t)nb * per * 8, hipMemcpyHostToDevice, st[c]);
                 else e = hipMemcpy(dCostN.as<double>() + (size_t)b0 * per, cost + (size_t)b0 * per, (size_t)nb * per * 8, hipMemcpyHostToDevice);
             }
             if (e != hipSuccess) { rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: upload", e); break; }
             const SubBatch sub{B, b0};
-            int32_t *pR = reinterpret_cast<int32_t *>(d8 + (size_t)b0 * k * maxCol);
-            double *pG = reinterpret_cast<double *>(d8 + offG) + (size_t)b0 * k;
-            int32_t *pN = reinterpret_cast<int32_t *>(d8 + offN) + b0;
+            // the piece's tables: pinned staging (the kernel writes over the link), or -- keep -- the caller's device buffers
+            int32_t *pR = keep ? reinterpret_cast<int32_t *>(keep->row4col8 + (size_t)b0 * k * maxCol) : reinterpret_cast<int32_t *>(d8 + (size_t)b0 * k * maxCol);
+            double *pG = keep ? keep->gain + (size_t)b0 * k : reinterpret_cast<double *>(d8 + offG) + (size_t)b0 * k;
+            int32_t *pN = keep ? keep->nf + b0 : reinterpret_cast<int32_t *>(d8 + offN) + b0;
             rc = batch_dev_impl(ctx, &o8, nb, maxRow, maxCol, nullptr, nullptr, devC + (size_t)b0 * per, nullptr, k, pR, nullptr, pG, pN, nullptr,
                                 st[c], true, nullptr, nP > 1 ? &sub : nullptr);
             if (rc != KBEST_OK) break;
             e = kb::launch_fill_unused(pN, nullptr, nullptr, nb, k, maxCol, maxRow, pR, nullptr, pG, true, st[c]);
             if (e != hipSuccess) { rc = fail(ctx, KBEST_ERR_HIP, "fill kernel launch", e); break; }
+            if (keep) {
+                // the device keeps int32 row4col (its slice of the global table); the bytes, the gains and the counts go home
+                const size_t nEnt = (size_t)nb * k * maxCol;
+                e = kb::launch_widen_i8(reinterpret_cast<const signed char *>(pR), keep->row4col + (size_t)b0 * k * maxCol, (long long)nEnt, st[c]);
+                if (e == hipSuccess) e = hipMemcpyAsync(h8 + (size_t)b0 * k * maxCol, pR, nEnt, hipMemcpyDeviceToHost, st[c]);
+                if (e == hipSuccess) e = hipMemcpyAsync(const_cast<double *>(hG) + (size_t)b0 * k, pG, (size_t)nb * k * 8, hipMemcpyDeviceToHost, st[c]);
+                if (e == hipSuccess) e = hipMemcpyAsync(const_cast<int32_t *>(hN) + b0, pN, (size_t)nb * 4, hipMemcpyDeviceToHost, st[c]);
+                if (e != hipSuccess) { rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: copy back", e); break; }
+            }
+            if (keep && keep->stamps && c == 0) keep->stamps[1] = kb::now_s();
             if (hipEventCreateWithFlags(&ev[c], hipEventDisableTiming) != hipSuccess || hipEventRecord(ev[c], st[c]) != hipSuccess) {
                 rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: event", hipGetLastError());
                 break;

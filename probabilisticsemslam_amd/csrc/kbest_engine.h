@@ -415,7 +415,10 @@ struct MergeParams {
 };
 // kbest_batch_f64 with the tables staged in (and left in) caller-owned device buffers: the multi-device entry's per-device step
 // (kbest_capi.cpp).  stamps (optional): host times (seconds, steady clock) at which the first upload / the first kernel was issued.
-struct KeepTables { int32_t *row4col, *col4row; double *gain; int32_t *nf; double *stamps; };
+// row4col8 (optional): device scratch for the block's row4col as bytes -- the narrow staging of uniform square batches then
+// runs with it (bytes cross PCIe, row4col is widened into `row4col` on the device, col4row is rebuilt on the host and not kept).
+struct KeepTables { int32_t *row4col, *col4row; double *gain; int32_t *nf; double *stamps; signed char *row4col8; };
+hipError_t launch_widen_i8(const signed char *src, int *dst, long long n, hipStream_t stream);
 double now_s();
 hipError_t launch_merge_topk(const MergeParams &p, int B, hipStream_t stream);
 hipError_t launch_fill_unused(const int *nf, const int *nRow, const int *nCol, int B, int k, int ldCol, int ldRow, int *row4col,

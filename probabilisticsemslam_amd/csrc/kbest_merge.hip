@@ -133,6 +133,26 @@ hipError_t launch_fill_unused(const int *nf, const int *nRow, const int *nCol, i
     return hipGetLastError();
 }
 
+// int8 table -> int32 table (the multi-device entry's narrow staging: the kernels write a block's row4col as bytes -- that is what
+// crosses PCIe --, the device's slice of the global table holds int32 as the exchange promises)
+__global__ void __launch_bounds__(256) widen_i8_kernel(const signed char *src, int *dst, long long n)
+{
+    const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 + 4 <= n) {
+        const char4 v = *reinterpret_cast<const char4 *>(src + i0);
+        *reinterpret_cast<int4 *>(dst + i0) = make_int4((int)v.x, (int)v.y, (int)v.z, (int)v.w);
+    } else {
+        for (long long i = i0; i < n; i++) dst[i] = (int)src[i];
+    }
+}
+
+hipError_t launch_widen_i8(const signed char *src, int *dst, long long n, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(widen_i8_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, stream, src, dst, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_merge_topk(const MergeParams &p, int B, hipStream_t stream)
 {
     hipLaunchKernelGGL(merge_topk_kernel, dim3(B), dim3(256), 0, stream, p);

@@ -83,6 +83,8 @@ struct Dev {
     double *cost = nullptr;
     int32_t *shape = nullptr;   // nRow | nCol of this device's problems
     int32_t *c4r = nullptr;     // col4row of this device's block (not gathered: SURVEY 8(e) exchanges gain, row4col, nf)
+    signed char *r8 = nullptr;  // row4col of this device's block as bytes (narrow staging of the host path: what crosses PCIe)
+    size_t r8B = 0;
     unsigned char *packed = nullptr;  // the global table: one packed slice (gain | row4col | nf) per device, identical everywhere after the gather
     double *mGain = nullptr;    // subtree mode: the merged global k best (identical on every device)
     int32_t *mR4C = nullptr, *mNf = nullptr;
@@ -316,7 +318,7 @@ int kbest_destroy_multi(kbest_multi *m)
         (void)hipSetDevice(d.id);
         if (d.stream) (void)hipStreamSynchronize(d.stream);
         if (d.comm && m->rccl.CommDestroy) (void)m->rccl.CommDestroy(d.comm);
-        for (void *p : {(void *)d.cost, (void *)d.shape, (void *)d.c4r, (void *)d.packed, (void *)d.mGain, (void *)d.mR4C, (void *)d.mNf})
+        for (void *p : {(void *)d.cost, (void *)d.shape, (void *)d.c4r, (void *)d.packed, (void *)d.mGain, (void *)d.mR4C, (void *)d.mNf, (void *)d.r8})
             if (p) (void)hipFree(p);
         if (d.stream) (void)hipStreamDestroy(d.stream);
         if (d.ev) (void)hipEventDestroy(d.ev);
@@ -391,6 +393,7 @@ int kbest_batch_f64_multi_ex(kbest_multi *m, const kbest_opts *opts, int mode, i
             W_HIP(d, hipSetDevice(d.id));
             W_TRY(d, grow(m, d, d.packed, d.packedB, (size_t)G * sl.bytes));
             if (col4row) W_TRY(d, grow(m, d, d.c4r, d.c4rB, (size_t)pad * k * maxRow * 4));
+            W_TRY(d, grow(m, d, d.r8, d.r8B, (size_t)pad * k * maxCol));
             unsigned char *mine = d.packed + (size_t)g * sl.bytes;
             // slots the kernels do not write (padding problems of the last devices) get defined values: gain 0, row4col -1, nf 0
             d.issued = true;
@@ -402,7 +405,7 @@ int kbest_batch_f64_multi_ex(kbest_multi *m, const kbest_opts *opts, int mode, i
             if (nb == 0) { d.t[1] = d.t[2] = d.t[3] = kb::now_s() - m->t0; return; }
             double stamps[2] = {0.0, 0.0};
             const kb::KeepTables keep{reinterpret_cast<int32_t *>(mine + sl.offR4C), col4row ? d.c4r : nullptr,
-                                      reinterpret_cast<double *>(mine + sl.offGain), reinterpret_cast<int32_t *>(mine + sl.offNf), stamps};
+                                      reinterpret_cast<double *>(mine + sl.offGain), reinterpret_cast<int32_t *>(mine + sl.offNf), stamps, d.r8};
             const int rc = kbest_batch_f64_keep(d.ctx, opts, nb, maxRow, maxCol, nRow ? nRow + b0 : nullptr, nCol ? nCol + b0 : nullptr,
                                                 cost + (size_t)b0 * per, nullptr, k, row4col + (size_t)b0 * k * maxCol,
                                                 col4row ? col4row + (size_t)b0 * k * maxRow : nullptr, gain + (size_t)b0 * k, nf + b0,

@@ -102,7 +102,8 @@ def load_library():
                                              C.c_int, i32p, i32p, dp, i32p]
     lib.kbest_merge_topk_f64_dev.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int64, dp, i32p,
                                              i32p, vp]
-    lib.kbest_multi_timeline.argtypes = [vp, dp, C.c_int]
+    if hasattr(lib, "kbest_multi_timeline"):  # (absent from older in-tree builds selected with KBEST_LIB for A/B runs)
+        lib.kbest_multi_timeline.argtypes = [vp, dp, C.c_int]
     lib.kbest_register_host_buffer.argtypes = [vp, vp, C.c_size_t]
     lib.kbest_unregister_host_buffer.argtypes = [vp, vp]
     _lib = lib
