@@ -685,76 +685,13 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         // order gives the same results), the matrix in the LDS of the node blocks and lists that round 0 has not touched yet:
         // D barriers and D^3 / threads min-plus steps instead of D searches of ~30 Dijkstra steps (64x64: 38 000 cycles
         // against 175 000).  Shapes whose matrix does not fit there run the searches.
-        // BLOCKED (round 4): 16 x 16 blocks; per block round r the diagonal block (one wave, 16 steps in lock step, no workgroup
-        // barrier), then the blocks of its row and column (a wave each, the same 16 steps against the finished diagonal block),
-        // then all other blocks (every thread, 16 independent min-plus terms per entry): three barriers per block round -- 12 for 64
-        // columns where the plain form had 64, each followed by eight entries' worth of work per thread.  The same recurrence in
-        // another order of independent updates; and any order of the columns gives the same results anyway.
+        // (round 4: the closure is blocked, 12 barriers instead of 64 -- column_keys_closure, kbest_lap.h)
         const int fwOff = (L.offNodes + L.nodeStride + 15) & ~15;  // (16-byte aligned: the blocks are read four entries at a time)
         const int fwBytes = L.offRootMap - fwOff;
-        const int Dp = (D + 15) & ~15, nbk = Dp >> 4;
+        const int Dp = (D + 15) & ~15;
         const bool fw = Dp * Dp * 4 <= fwBytes;
         if (fw) {
-            float *dm = reinterpret_cast<float *>(smem + fwOff);
-            const float FINF = __int_as_float(0x7f800000);
-            for (int e = tid; e < Dp * Dp; e += NT) {
-                const int i = e / Dp, j = e - i * Dp;
-                float wf = FINF;  // (the diagonal and the padding of the last block)
-                if (i < D && j < D && i != j) {
-                    const int row = nd0.r4c[j];
-                    double w = (Cs[row + i * LDC] - nd0.u[i]) - nd0.v[row];
-                    w = w < 0.0 ? 0.0 : w;
-                    wf = (float)w;
-                }
-                dm[e] = wf;
-            }
-            __syncthreads();
-            // one 16 x 16 block by one wave: entry (il, jl .. jl + 3) per lane; 16 steps, the wave in lock step.  A = the target's
-            // rows in the columns of block r, B = block r's rows in the target's columns; whichever of them lies in the target
-            // itself changes from step to step (the write back + fence), the other is final.
-            const int il = lane >> 2, jl = (lane & 3) * 4;
-            auto fw_block = [&](int ti, int tj, int o) {
-                float *trow = dm + (ti + il) * Dp + tj + jl;
-                float4 d4 = *reinterpret_cast<const float4 *>(trow);
-#pragma unroll 4
-                for (int kk = 0; kk < 16; kk++) {
-                    const float av = dm[(ti + il) * Dp + o + kk];
-                    const float4 b4 = *reinterpret_cast<const float4 *>(dm + (o + kk) * Dp + tj + jl);
-                    d4.x = fminf(d4.x, av + b4.x);
-                    d4.y = fminf(d4.y, av + b4.y);
-                    d4.z = fminf(d4.z, av + b4.z);
-                    d4.w = fminf(d4.w, av + b4.w);
-                    wave_fence();
-                    *reinterpret_cast<float4 *>(trow) = d4;
-                    wave_fence();
-                }
-            };
-            for (int r = 0; r < nbk; r++) {
-                const int o = r * 16;
-                if (wave == 0) fw_block(o, o, o);
-                __syncthreads();
-                for (int bi = wave; bi < 2 * (nbk - 1); bi += NW) {
-                    const bool rowBlk = bi < nbk - 1;
-                    int c = rowBlk ? bi : bi - (nbk - 1);
-                    c += (c >= r) ? 1 : 0;
-                    fw_block(rowBlk ? o : c * 16, rowBlk ? c * 16 : o, o);
-                }
-                __syncthreads();
-                const int cnt = (nbk - 1) * (nbk - 1) * 256;
-                for (int e = tid; e < cnt; e += NT) {
-                    const int blk = e >> 8;
-                    int ba = blk / (nbk - 1), bb = blk - ba * (nbk - 1);
-                    ba += (ba >= r) ? 1 : 0;
-                    bb += (bb >= r) ? 1 : 0;
-                    const int i = ba * 16 + ((e >> 4) & 15), j = bb * 16 + (e & 15);
-                    float acc = dm[i * Dp + j];
-#pragma unroll 4
-                    for (int kk = 0; kk < 16; kk++) acc = fminf(acc, dm[i * Dp + o + kk] + dm[(o + kk) * Dp + j]);
-                    dm[i * Dp + j] = acc;
-                }
-                __syncthreads();
-            }
-            for (int c = tid; c < M; c += NT) key[c] = (double)dm[c * Dp + c];
+            column_keys_closure<NW>(reinterpret_cast<float *>(smem + fwOff), key, Cs, LDC, nd0.u, nd0.v, nd0.r4c, D, M);
         } else {
             const double v0 = (lane < D) ? nd0.v[lane] : 0.0;
             const int c4r0 = (lane < D) ? (int)nd0.c4r[lane] : -1;

@@ -393,10 +393,18 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
     // (not under root-subtree sharding: the shards of kbest_c.h are those of the reference's column order, kbest_engine.hip)
     const bool reorder = prune && p.rootColStride <= 1 && M >= 3 && k >= 3 && !(p.flags & (KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_REORDER));
     if (reorder) {
-        double *key = freshG;
+        // (the keys: wave 0's scratch line behind the two index tables; the closure's matrix: the lists of the rounds, all unused
+        //  before round 0)
+        double *key = gainW + 16;
         const int nb0 = L.offNodes;
         double *u0 = reinterpret_cast<double *>(smem + nb0);
-        {
+        const int Dp = (D + 15) & ~15;
+        if (Dp * Dp * 4 <= L.offFree - L.offFreshG) {
+            // all keys from ONE blocked all-pairs closure of the column graph (column_keys_closure, kbest_lap.h): for 16 columns a
+            // single 16 x 16 block on one wave -- 16 lock-step passes instead of 16 searches shared by the waves
+            column_keys_closure<NW>(reinterpret_cast<float *>(smem + L.offFreshG), key, Cs, LDC, u0,
+                                    reinterpret_cast<const double *>(smem + nb0 + N_V), smem + nb0 + N_R4C, D, M);
+        } else {
             const double v0 = (lane < D) ? *reinterpret_cast<const double *>(smem + nb0 + N_V + 8 * lane) : 0.0;
             const int c4r0 = (lane < D) ? (int)smem[nb0 + N_C4R + lane] : -1;
             const int r4c0 = (lane < D) ? (int)smem[nb0 + N_R4C + lane] : -1;
