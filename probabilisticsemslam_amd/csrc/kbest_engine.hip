@@ -310,6 +310,8 @@ __device__ __forceinline__ NodeRef node_ref(unsigned char *base, int maxRow)
 
 // Register budget: 6 waves per SIMD (80 VGPRs) lets three 8-wave (or six 4-wave) workgroups share a CU; without the
 // bound the compiler settles at ~90-100 VGPRs and residency silently drops to two matrices per CU.
+// (seven 4-wave workgroups per CU at 72 VGPRs -- the LDS would hold them -- were measured in round 4: 4 096 x 32x32 3.65 -> 3.72 ms,
+//  six spills and more waves on an issue-bound kernel)
 constexpr int min_waves_per_simd(int nw) { return nw <= 12 ? 6 : 4; }
 
 template <int NW, int EPT>  // EPT: pool entries per thread held in registers across the in-place merge (k <= EPT * NW * 64)
