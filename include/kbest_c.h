@@ -92,7 +92,11 @@ typedef struct kbest_opts {
     uint32_t flags;        /* KBEST_FLAG_*                                        */
     int32_t  root_col_offset; /* subtree sharding (multi-GPU latency mode):       */
     int32_t  root_col_stride; /* only root children on columns c with             */
-                              /* c % stride == offset are expanded; 0/1 = all     */
+                              /* c % stride == offset are expanded; 0/1 = all.    */
+                              /* c is the REFERENCE's column and the partition is the reference's (split, cpp:455-532: the    */
+                              /* child on column c keeps the root's rows on columns 0 .. c-1): a sharded run enumerates in    */
+                              /* the reference's column order whatever kernel or launch shape runs it, so shards computed by  */
+                              /* differently configured ranks still partition the problem.                                     */
 } kbest_opts;
 
 void kbest_default_opts(kbest_opts *o);

@@ -1226,9 +1226,11 @@ int kbest_batch_f64_keep(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxR
                 // the device keeps int32 row4col (its slice of the global table); the bytes, the gains and the counts go home
                 const size_t nEnt = (size_t)nb * k * maxCol;
                 e = kb::launch_widen_i8(reinterpret_cast<const signed char *>(pR), keep->row4col + (size_t)b0 * k * maxCol, (long long)nEnt, st[c]);
-                if (e == hipSuccess) e = hipMemcpyAsync(h8 + (size_t)b0 * k * maxCol, pR, nEnt, hipMemcpyDeviceToHost, st[c]);
-                if (e == hipSuccess) e = hipMemcpyAsync(const_cast<double *>(hG) + (size_t)b0 * k, pG, (size_t)nb * k * 8, hipMemcpyDeviceToHost, st[c]);
-                if (e == hipSuccess) e = hipMemcpyAsync(const_cast<int32_t *>(hN) + b0, pN, (size_t)nb * 4, hipMemcpyDeviceToHost, st[c]);
+                // (by copy kernels on the piece's stream into the host-mapped staging: kbest_merge.hip, launch_copy_words)
+                if (e == hipSuccess && nEnt % 4 == 0) e = kb::launch_copy_words(pR, d8 + (size_t)b0 * k * maxCol, (long long)nEnt, st[c]);
+                else if (e == hipSuccess) e = hipMemcpyAsync(h8 + (size_t)b0 * k * maxCol, pR, nEnt, hipMemcpyDeviceToHost, st[c]);
+                if (e == hipSuccess) e = kb::launch_copy_words(pG, d8 + offG + (size_t)b0 * k * 8, (long long)nb * k * 8, st[c]);
+                if (e == hipSuccess) e = kb::launch_copy_words(pN, d8 + offN + (size_t)b0 * 4, (long long)nb * 4, st[c]);
                 if (e != hipSuccess) { rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: copy back", e); break; }
             }
             if (keep && keep->stamps && c == 0) keep->stamps[1] = kb::now_s();

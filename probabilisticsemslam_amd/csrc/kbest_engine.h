@@ -419,6 +419,7 @@ struct MergeParams {
 // runs with it (bytes cross PCIe, row4col is widened into `row4col` on the device, col4row is rebuilt on the host and not kept).
 struct KeepTables { int32_t *row4col, *col4row; double *gain; int32_t *nf; double *stamps; signed char *row4col8; };
 hipError_t launch_widen_i8(const signed char *src, int *dst, long long n, hipStream_t stream);
+hipError_t launch_copy_words(const void *src, void *dst, long long bytes, hipStream_t stream);  // bytes: a multiple of 4
 double now_s();
 hipError_t launch_merge_topk(const MergeParams &p, int B, hipStream_t stream);
 hipError_t launch_fill_unused(const int *nf, const int *nRow, const int *nCol, int B, int k, int ldCol, int ldRow, int *row4col,
