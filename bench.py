@@ -61,10 +61,10 @@ def algorithmic_bytes(N, M, k, nf, pushed):
 
 
 def profile_summary(cfg):
-    """profiles/r03_<cfg>_summary.json (tools/prof.sh + tools/prof_summary.py on the GPU box; an older round's if this
-    round has none): HBM traffic and the instruction-issue counters of the dominant kernel for this configuration, or None."""
-    for rnd in ("r03", "r02"):
-        path = os.path.join(ROOT, "profiles", f"{rnd}_{cfg}_summary.json")
+    """profiles/rNN_<cfg>_summary.json of the newest round that has one (tools/prof.sh + tools/prof_summary.py on the GPU box):
+    HBM traffic and the instruction-issue counters of the dominant kernel for this configuration, or None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{cfg}_summary.json")), reverse=True):
         if os.path.exists(path):
             try:
                 j = json.load(open(path))
@@ -93,7 +93,7 @@ def issue_block(cfg):
         out["lds_insts"] = pm["SQ_INSTS_LDS"]
     if "SQ_WAIT_ANY" in pm and "SQ_WAVE_CYCLES" in pm and pm["SQ_WAVE_CYCLES"]:
         out["wave_wait_frac"] = pm["SQ_WAIT_ANY"] / pm["SQ_WAVE_CYCLES"]
-    out["bound"] = "instruction issue / latency (not HBM): see DESIGN.md section 8"
+    out["bound"] = "instruction issue / latency (not HBM): see DESIGN.md section 4 and NOTES.md section 8"
     return out
 
 
