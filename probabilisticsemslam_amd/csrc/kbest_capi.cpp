@@ -919,7 +919,13 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         // gain there, and the extra rounds of re-splits cost -- off in the shapes that run the a-priori thresholds.
         {
             const bool t0Shape = shp.nWaves >= 8;  // (kbest_engine.hip: t0On needs 8 waves; OPT_SHAPE compiles the mechanism out there)
-            const float rho0 = ctx->optRho0 >= 0.0f ? ctx->optRho0 : (t0Shape ? 2.0f : 0.85f);
+            // Where it pays was measured on dense square batches (tests/dev/opt_ab.py, 4 waves x 4, off -> on): 4 096 x 32x32, k = 200
+            // -5 %, k = 400 -1.6 %, 28x28, k = 100 -2.4 %; but 24x24, k = 200 +2.2 %, 17x17, k = 200 +12 % (the early pool of a small
+            // problem is a poor sample of where its k-th best will lie: 27 re-splits per matrix in the host model against 4 at 32 rows),
+            // 32x32, k = 50 +1.5 %, k = 20 +5.9 % (short enumerations: nothing to save, the bookkeeping remains).  Hence on from 28
+            // rows and k = 100 only; KBEST_OPT_RHO0 forces it anywhere.
+            const bool optShape = !t0Shape && fastRow >= 28 && k >= 100;
+            const float rho0 = ctx->optRho0 >= 0.0f ? ctx->optRho0 : (optShape ? 0.85f : 2.0f);
             if (ctx->noOpt || rho0 >= 1.0f) p.optRho0 = 2.0f;
             else {
                 p.optRho0 = rho0;

@@ -38,7 +38,7 @@ struct Solver {
     int mode;
     std::vector<int> order;  // static order (modes 0, 1): position -> column
     double lastDelta = 0, lastLB = 0;
-    double rho = 1.0, kappa = 0.25, rho1 = 1.0, phi = 1e9;
+    double rho = 1.0, kappa = 0.25, rho1 = 1.0, phi = 1e9, rhoNow = 1.0, adaptA = 0.0, adaptB = 0.0, rhoMin = 0.0;
     int minPool = 8;
     double Tcap = INF;       // an upper bound of the k-th best gain known from the start (the cutoff variant fed the answer)
     double lastGain = 0;     // gain of the last hypothesis emitted
@@ -204,6 +204,7 @@ struct Solver {
         while (emitted < k && !sel.empty()) {
             ct.rounds++;
             const int R = k - emitted;
+            if (ct.rounds == 1) rhoNow = rho;
             std::vector<double> cg;
             for (auto &e : pool) if (!e.ticket) cg.push_back(e.key);
             double T = ((int)cg.size() >= R) ? cg[R - 1] : INF;
@@ -212,12 +213,13 @@ struct Solver {
             if (rho < 1.0 && (int)cg.size() >= minPool) {
                 const int n = std::min((int)cg.size(), R);
                 const double fr = std::min(1.0, (double)emitted / (phi * k));
-                const double rhoE = rho + (rho1 - rho) * fr;  // the quantile grows with the share of the answer that is out
+                const double rhoE = adaptA > 0 ? rhoNow : rho + (rho1 - rho) * fr;  // the quantile grows with the share of the answer that is out
                 int qi = (int)(rhoE * n);
                 if (qi >= n) qi = n - 1;
                 if (cg[qi] < Tg) Tg = cg[qi];
             }
             std::vector<PE> fresh;
+            int newTickets = 0;
             for (const Sel &s : sel) {
                 const Node P = nodes[s.id].n;
                 double bAbs = Tg;
@@ -263,6 +265,11 @@ struct Solver {
                     fixedSoFar |= 1ull << c;
                 }
                 if (lbP < INF) fresh.push_back({lbP, s.id, false, true});
+                if (s.ticket) newTickets++;  // (the feedback counts the re-splits, not the tickets written: most of those are never due)
+            }
+            if (adaptA > 0) {  // feedback: every ticket pushes the quantile towards the valid threshold, quiet rounds let it sink back
+                rhoNow = std::min(1.0, rhoNow + adaptA * newTickets);
+                if (!newTickets) rhoNow = std::max(rhoMin, rhoNow - adaptB);
             }
             for (auto &e : fresh) pool.push_back(e);
             std::stable_sort(pool.begin(), pool.end(), [](const PE &a, const PE &b) { return a.key < b.key || (a.key == b.key && a.ticket && !b.ticket); });
@@ -331,6 +338,9 @@ int main(int argc, char **argv)
             S.rho = rho; S.kappa = kappa; S.minPool = minPool;
             if (getenv("RHO1")) S.rho1 = atof(getenv("RHO1")); else S.rho1 = rho;
             if (getenv("PHI")) S.phi = atof(getenv("PHI"));
+            if (getenv("ADAPT_A")) S.adaptA = atof(getenv("ADAPT_A"));
+            if (getenv("ADAPT_B")) S.adaptB = atof(getenv("ADAPT_B"));
+            S.rhoMin = getenv("RHO_MIN") ? atof(getenv("RHO_MIN")) : rho;
             if (t0slack > 0) { Solver S0; S0.mode = 1; S0.run(k, spec, N, C.data()); S.Tcap = S0.rootGain + t0slack * (S0.lastGain - S0.rootGain); }
             S.run(k, spec, N, C.data());
             chk += S.lastGain;

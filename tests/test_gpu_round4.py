@@ -265,3 +265,26 @@ def test_narrow_staging_of_the_host_entry_equals_the_wide_tables(monkeypatch, sh
             assert (o[0] == a[0]).all() and (o[1] == a[1]).all() and (o[2] == a[2]).all() and (bits(o[3]) == bits(a[3])).all()
     eng.close()
     wide.close()
+
+
+@pytest.mark.parametrize("knobs", [{"KBEST_OPT_RHO0": 0.85}, {"KBEST_OPT_RHO0": 0.4, "KBEST_OPT_KAPPA": 0.05}, {"KBEST_OPT_RHO0": 0.6, "KBEST_SPEC": 2},
+                                   {"KBEST_OPT_RHO0": 0.3, "KBEST_OPT_MINPOOL": 2}])
+def test_optimistic_bounds_keep_the_enumeration_exact(monkeypatch, knobs):
+    """Optimistic bounds with re-split tickets (kbest_engine.hip, struct Opt), forced on everywhere they compile in (4-wave 64-row
+    kernel) at quantiles from the tuned one down to absurdly tight ones -- many tickets, nodes split three and four times, tiny
+    steps between re-splits --: a bounded slice of the randomised soak (seven cost structures incl. exact ties and near-ties at
+    1e-9, +inf patterns, rectangular, maximise, cutoff, k = 1 ... 300) and the dense 32x32, k = 200 case the default routing
+    uses them for.  Whatever the guess, results are the checker's bit for bit."""
+    import soak_lib
+    from probabilisticsemslam_amd import workloads as wl
+    env = {"KBEST_NO_SMALL": 1, "KBEST_NO_LANE": 1, "KBEST_NWAVES": 4, "KBEST_SPEC": 4}
+    env.update(knobs)
+    eng = engine_with(monkeypatch, **env)
+    ncase, nprob, bad = soak_lib.run(eng, seed=20261004, n_cases=250, big_frac=0.0, big_max=64)
+    assert bad is None, bad
+    assert ncase >= 60
+    costs, N, M, k = wl.dense_config("c3", B=96)
+    nf, r4c, c4r, g = eng.kbest(costs, N, M, k)
+    onf, or4c, oc4r, og, _ = ol.orc_kbest_batch(costs, N, M, k)
+    assert (nf == onf).all() and (r4c == or4c).all() and (c4r == oc4r).all() and (bits(g) == bits(og)).all()
+    eng.close()
