@@ -375,7 +375,7 @@ int kbest_create(kbest_ctx **out, int device)
     }
     if (const char *e = getenv("KBEST_SMALL_NW")) {
         int w = atoi(e);
-        if (w == 2 || w == 4 || w == 8 || w == 16) ctx->smallWaves = w;
+        if ((w >= 2 && w <= 6) || w == 8 || w == 10 || w == 12 || w == 16) ctx->smallWaves = w;
     }
     ctx->noSmall = getenv("KBEST_NO_SMALL") != nullptr;
     ctx->forceWide = getenv("KBEST_FORCE_WIDE") != nullptr;

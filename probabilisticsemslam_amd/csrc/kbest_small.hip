@@ -151,54 +151,54 @@ __device__ __forceinline__ void dijkstra2(const double *Cs, double *uW, int hubC
             // first row does not win, a half that is finished -- leaves it: status 0 = the step's choice is made (rows
             // c0 / c1, their keys, low words and columns are in the out registers), nothing committed; status 1 = the
             // choice itself needs the exact path.  A finished half (liveMask) takes part inertly.
-            // Fixed registers: v54 +inf key, v55 u base, v56 row address, v57 c4r, v[58:59] v, v[60:61] spc, v62 pred;
+            // Fixed registers: v26 +inf key, v27 u base, v28 row address, v29 c4r, v[30:31] v, v[32:33] spc, v34 pred;
             // s[70:71] live lanes, s[80:83] delta A / B, s84/s85 column A / B, s[86:87] rows to scan, s[88:89] rows to relax,
             // s[90:91] upper-half mask, s92 column stride in bytes, s93/s94 bound high words.
             int dAlo = dLoA, dAhi = dHiA, dBlo = dLoB, dBhi = dHiB;
             asm volatile(
                 "L_pstep%=:\n\t"
-                "v_mov_b32_e32 v72, s84\n\t"
-                "v_mov_b32_e32 v73, s85\n\t"
-                "v_cndmask_b32_e64 v72, v72, v73, s[90:91]\n\t"
-                "v_mad_u32_u24 v74, v72, s92, v56\n\t"
-                "v_lshl_add_u32 v75, v72, 3, v55\n\t"
-                "ds_read_b64 v[68:69], v74\n\t"
-                "ds_read_b64 v[70:71], v75\n\t"
-                "v_mov_b32_e32 v76, s80\n\t"
-                "v_mov_b32_e32 v73, s82\n\t"
-                "v_cndmask_b32_e64 v76, v76, v73, s[90:91]\n\t"
-                "v_mov_b32_e32 v77, s81\n\t"
-                "v_mov_b32_e32 v73, s83\n\t"
-                "v_cndmask_b32_e64 v77, v77, v73, s[90:91]\n\t"
+                "v_mov_b32_e32 v44, s84\n\t"
+                "v_mov_b32_e32 v45, s85\n\t"
+                "v_cndmask_b32_e64 v44, v44, v45, s[90:91]\n\t"
+                "v_mad_u32_u24 v46, v44, s92, v28\n\t"
+                "v_lshl_add_u32 v47, v44, 3, v27\n\t"
+                "ds_read_b64 v[40:41], v46\n\t"
+                "ds_read_b64 v[42:43], v47\n\t"
+                "v_mov_b32_e32 v48, s80\n\t"
+                "v_mov_b32_e32 v45, s82\n\t"
+                "v_cndmask_b32_e64 v48, v48, v45, s[90:91]\n\t"
+                "v_mov_b32_e32 v49, s81\n\t"
+                "v_mov_b32_e32 v45, s83\n\t"
+                "v_cndmask_b32_e64 v49, v49, v45, s[90:91]\n\t"
                 "s_waitcnt lgkmcnt(0)\n\t"
-                "v_add_f64 v[66:67], v[76:77], v[68:69]\n\t"
-                "v_add_f64 v[66:67], v[66:67], -v[70:71]\n\t"
-                "v_add_f64 v[66:67], v[66:67], -v[58:59]\n\t"
-                "v_cmp_lt_f64_e32 vcc, v[66:67], v[60:61]\n\t"
+                "v_add_f64 v[38:39], v[48:49], v[40:41]\n\t"
+                "v_add_f64 v[38:39], v[38:39], -v[42:43]\n\t"
+                "v_add_f64 v[38:39], v[38:39], -v[30:31]\n\t"
+                "v_cmp_lt_f64_e32 vcc, v[38:39], v[32:33]\n\t"
                 "s_and_b64 vcc, vcc, s[88:89]\n\t"
-                "v_cndmask_b32_e32 v61, v61, v67, vcc\n\t"
-                "v_cndmask_b32_e32 v60, v60, v66, vcc\n\t"
-                "v_cndmask_b32_e32 v62, v62, v72, vcc\n\t"
+                "v_cndmask_b32_e32 v33, v33, v39, vcc\n\t"
+                "v_cndmask_b32_e32 v32, v32, v38, vcc\n\t"
+                "v_cndmask_b32_e32 v34, v34, v44, vcc\n\t"
                 "s_and_b64 s[76:77], s[86:87], s[70:71]\n\t"
-                "v_cndmask_b32_e64 v63, v54, v61, s[76:77]\n\t"
+                "v_cndmask_b32_e64 v35, v26, v33, s[76:77]\n\t"
                 "s_nop 1\n\t"
-                "v_min_i32_dpp v64, v63, v63 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                "v_min_i32_dpp v36, v35, v35 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
                 "s_nop 1\n\t"
-                "v_min_i32_dpp v64, v64, v64 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                "v_min_i32_dpp v36, v36, v36 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
                 "s_nop 1\n\t"
-                "v_min_i32_dpp v64, v64, v64 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                "v_min_i32_dpp v36, v36, v36 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
                 "s_nop 1\n\t"
-                "v_min_i32_dpp v64, v64, v64 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                "v_min_i32_dpp v36, v36, v36 row_mirror row_mask:0xf bank_mask:0xf\n\t"
                 "s_nop 1\n\t"
-                "v_min_i32_dpp v64, v64, v64 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                "v_min_i32_dpp v36, v36, v36 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
                 "s_nop 1\n\t"
-                "v_readlane_b32 s72, v64, 31\n\t"
-                "v_readlane_b32 s73, v64, 63\n\t"
+                "v_readlane_b32 s72, v36, 31\n\t"
+                "v_readlane_b32 s73, v36, 63\n\t"
                 "s_nop 0\n\t"
-                "v_mov_b32_e32 v65, s72\n\t"
-                "v_mov_b32_e32 v73, s73\n\t"
-                "v_cndmask_b32_e64 v65, v65, v73, s[90:91]\n\t"
-                "v_cmp_eq_u32_e64 s[98:99], v65, v63\n\t"
+                "v_mov_b32_e32 v37, s72\n\t"
+                "v_mov_b32_e32 v45, s73\n\t"
+                "v_cndmask_b32_e64 v37, v37, v45, s[90:91]\n\t"
+                "v_cmp_eq_u32_e64 s[98:99], v37, v35\n\t"
                 "s_and_b64 s[98:99], s[98:99], s[76:77]\n\t"
                 "s_or_b32 s76, s72, s73\n\t"
                 "s_cmp_lt_i32 s76, 0\n\t"
@@ -216,16 +216,16 @@ __device__ __forceinline__ void dijkstra2(const double *Cs, double *uW, int hubC
                 "s_add_u32 s97, s97, 32\n\t"
                 "s_cmp_lg_u32 s76, 0\n\t"
                 "s_cbranch_scc1 L_pslow%=\n\t"
-                "v_readlane_b32 s74, v60, s96\n\t"
-                "v_readlane_b32 s75, v60, s97\n\t"
+                "v_readlane_b32 s74, v32, s96\n\t"
+                "v_readlane_b32 s75, v32, s97\n\t"
                 "s_bcnt1_i32_b32 s76, s98\n\t"
                 "s_bcnt1_i32_b32 s77, s99\n\t"
                 "s_max_u32 s76, s76, s77\n\t"
                 "s_cmp_gt_u32 s76, 1\n\t"
                 "s_cbranch_scc1 L_ptie%=\n\t"
                 "L_pchoice%=:\n\t"
-                "v_readlane_b32 s78, v57, s96\n\t"
-                "v_readlane_b32 s79, v57, s97\n\t"
+                "v_readlane_b32 s78, v29, s96\n\t"
+                "v_readlane_b32 s79, v29, s97\n\t"
                 // the chosen row of a live half is PARKED (on a zero column) and its key is below the bound: enter the zero
                 // columns here -- all parked rows of the half are settled at this distance, the hub's dual slot becomes
                 // -v[row], the next column is the hub column
@@ -235,21 +235,21 @@ __device__ __forceinline__ void dijkstra2(const double *Cs, double *uW, int hubC
                 "s_cbranch_scc1 L_pnoparkA%=\n\t"
                 "s_cmp_ge_i32 s72, s93\n\t"
                 "s_cbranch_scc1 L_pnoparkA%=\n\t"
-                "v_readlane_b32 s76, v58, s96\n\t"
-                "v_readlane_b32 s77, v59, s96\n\t"
+                "v_readlane_b32 s76, v30, s96\n\t"
+                "v_readlane_b32 s77, v31, s96\n\t"
                 "s_xor_b32 s77, s77, 0x80000000\n\t"
                 "s_mov_b64 vcc, exec\n\t"
                 "s_mov_b64 exec, 1\n\t"
-                "v_mov_b32_e32 v74, s76\n\t"
-                "v_mov_b32_e32 v75, s77\n\t"
-                "ds_write_b64 v53, v[74:75]\n\t"
+                "v_mov_b32_e32 v46, s76\n\t"
+                "v_mov_b32_e32 v47, s77\n\t"
+                "ds_write_b64 v25, v[46:47]\n\t"
                 "s_mov_b64 exec, vcc\n\t"
                 "s_and_b32 s76, s68, s86\n\t"
                 "s_mov_b32 s77, 0\n\t"
-                "v_mov_b32_e32 v73, s72\n\t"
-                "v_cndmask_b32_e64 v61, v61, v73, s[76:77]\n\t"
-                "v_mov_b32_e32 v73, s74\n\t"
-                "v_cndmask_b32_e64 v60, v60, v73, s[76:77]\n\t"
+                "v_mov_b32_e32 v45, s72\n\t"
+                "v_cndmask_b32_e64 v33, v33, v45, s[76:77]\n\t"
+                "v_mov_b32_e32 v45, s74\n\t"
+                "v_cndmask_b32_e64 v32, v32, v45, s[76:77]\n\t"
                 "s_andn2_b32 s86, s86, s76\n\t"
                 "s_mov_b32 s66, s96\n\t"
                 "s_mov_b32 s78, s67\n\t"
@@ -260,22 +260,22 @@ __device__ __forceinline__ void dijkstra2(const double *Cs, double *uW, int hubC
                 "s_cbranch_scc1 L_pnoparkB%=\n\t"
                 "s_cmp_ge_i32 s73, s94\n\t"
                 "s_cbranch_scc1 L_pnoparkB%=\n\t"
-                "v_readlane_b32 s76, v58, s97\n\t"
-                "v_readlane_b32 s77, v59, s97\n\t"
+                "v_readlane_b32 s76, v30, s97\n\t"
+                "v_readlane_b32 s77, v31, s97\n\t"
                 "s_xor_b32 s77, s77, 0x80000000\n\t"
                 "s_mov_b64 vcc, exec\n\t"
                 "s_mov_b32 exec_lo, 0\n\t"
                 "s_mov_b32 exec_hi, 1\n\t"
-                "v_mov_b32_e32 v74, s76\n\t"
-                "v_mov_b32_e32 v75, s77\n\t"
-                "ds_write_b64 v53, v[74:75]\n\t"
+                "v_mov_b32_e32 v46, s76\n\t"
+                "v_mov_b32_e32 v47, s77\n\t"
+                "ds_write_b64 v25, v[46:47]\n\t"
                 "s_mov_b64 exec, vcc\n\t"
                 "s_mov_b32 s76, 0\n\t"
                 "s_and_b32 s77, s69, s87\n\t"
-                "v_mov_b32_e32 v73, s73\n\t"
-                "v_cndmask_b32_e64 v61, v61, v73, s[76:77]\n\t"
-                "v_mov_b32_e32 v73, s75\n\t"
-                "v_cndmask_b32_e64 v60, v60, v73, s[76:77]\n\t"
+                "v_mov_b32_e32 v45, s73\n\t"
+                "v_cndmask_b32_e64 v33, v33, v45, s[76:77]\n\t"
+                "v_mov_b32_e32 v45, s75\n\t"
+                "v_cndmask_b32_e64 v32, v32, v45, s[76:77]\n\t"
                 "s_andn2_b32 s87, s87, s77\n\t"
                 "s_sub_u32 s65, s97, 32\n\t"
                 "s_mov_b32 s79, s67\n\t"
@@ -308,10 +308,10 @@ __device__ __forceinline__ void dijkstra2(const double *Cs, double *uW, int hubC
                 "s_and_b64 s[88:89], s[86:87], s[70:71]\n\t"
                 "s_branch L_pstep%=\n\t"
                 "L_ptie%=:\n\t"
-                "v_mov_b32_e32 v73, s74\n\t"
-                "v_mov_b32_e32 v74, s75\n\t"
-                "v_cndmask_b32_e64 v73, v73, v74, s[90:91]\n\t"
-                "v_cmp_lt_u32_e64 s[76:77], v60, v73\n\t"
+                "v_mov_b32_e32 v45, s74\n\t"
+                "v_mov_b32_e32 v46, s75\n\t"
+                "v_cndmask_b32_e64 v45, v45, v46, s[90:91]\n\t"
+                "v_cmp_lt_u32_e64 s[76:77], v32, v45\n\t"
                 "s_and_b64 s[76:77], s[76:77], s[98:99]\n\t"
                 "s_cmp_eq_u64 s[76:77], 0\n\t"
                 "s_cbranch_scc1 L_pchoice%=\n\t"
@@ -322,13 +322,13 @@ __device__ __forceinline__ void dijkstra2(const double *Cs, double *uW, int hubC
                 "s_mov_b32 s95, 0\n\t"
                 "L_pdone%=:\n\t"
                 : "+{s80}"(dAlo), "+{s81}"(dAhi), "+{s82}"(dBlo), "+{s83}"(dBhi), "+{s84}"(curA), "+{s85}"(curB),
-                  "+{s[86:87]}"(cand), "+{s[88:89]}"(act), "+{v60}"(spLo), "+{v61}"(spHi), "+{v62}"(pred), "={s95}"(status),
+                  "+{s[86:87]}"(cand), "+{s[88:89]}"(act), "+{v32}"(spLo), "+{v33}"(spHi), "+{v34}"(pred), "={s95}"(status),
                   "={s96}"(c0), "={s97}"(c1), "={s72}"(m0), "={s73}"(m1), "={s74}"(dlo0), "={s75}"(dlo1), "={s78}"(cnA),
                   "={s79}"(cnB), "={s[98:99]}"(eq), "+{s66}"(hubRowA), "+{s65}"(hubRowB)
-                : "{v53}"(hubAddr), "{v54}"(keyInf), "{v55}"(uBase), "{v56}"(rowAddr), "{v57}"(c4r), "{v[58:59]}"(v),
+                : "{v25}"(hubAddr), "{v26}"(keyInf), "{v27}"(uBase), "{v28}"(rowAddr), "{v29}"(c4r), "{v[30:31]}"(v),
                   "{s67}"(hubCol), "{s[68:69]}"(parked), "{s[70:71]}"(liveMask), "{s[90:91]}"(SM_HI), "{s92}"(LDC * 8),
                   "{s93}"(bHiA), "{s94}"(bHiB)
-                : "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77",
+                : "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49",
                   "s76", "s77", "vcc", "scc", "memory");
             // (outputs bound to physical scalar registers: the values ARE wave-uniform; KS_UNI decides whether the compiler is
             //  told so by a readfirstlane round trip)
@@ -480,8 +480,12 @@ struct SCtrl {
 };
 static_assert(sizeof(SCtrl) <= 96, "SCtrl must fit the LDS slot reserved by small_lds_layout");
 
+#ifndef KS_WAVES_PER_EU
+#define KS_WAVES_PER_EU 5
+#endif
 template <int NW>
-__global__ void __launch_bounds__(NW * 64) kbest_small_kernel(SmallParams p)
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(KS_WAVES_PER_EU, KS_WAVES_PER_EU)))
+kbest_small_kernel(SmallParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = NW * 64, W = 2 * NW;
@@ -1236,8 +1240,13 @@ hipError_t launch_kbest_small(const SmallParams &p, int B, int nWaves, hipStream
 {
     switch (nWaves) {
     case 2: return launch_small_nw<2>(p, B, stream);
+    case 3: return launch_small_nw<3>(p, B, stream);
     case 4: return launch_small_nw<4>(p, B, stream);
+    case 5: return launch_small_nw<5>(p, B, stream);
+    case 6: return launch_small_nw<6>(p, B, stream);
     case 8: return launch_small_nw<8>(p, B, stream);
+    case 10: return launch_small_nw<10>(p, B, stream);
+    case 12: return launch_small_nw<12>(p, B, stream);
     default: return launch_small_nw<16>(p, B, stream);
     }
 }
