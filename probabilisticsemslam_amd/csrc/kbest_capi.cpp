@@ -375,7 +375,7 @@ int kbest_create(kbest_ctx **out, int device)
     }
     if (const char *e = getenv("KBEST_SMALL_NW")) {
         int w = atoi(e);
-        if ((w >= 2 && w <= 6) || w == 8 || w == 10 || w == 12 || w == 16) ctx->smallWaves = w;
+        if (w == 2 || w == 4 || w == 8 || w == 16) ctx->smallWaves = w;
     }
     ctx->noSmall = getenv("KBEST_NO_SMALL") != nullptr;
     ctx->forceWide = getenv("KBEST_FORCE_WIDE") != nullptr;
@@ -539,8 +539,10 @@ static int reserve_states(kbest_ctx *ctx, int B, int maxRow, int k, bool grow)
 static int small_waves(const kbest_ctx *ctx, int B)
 {
     if (ctx->smallWaves > 0) return ctx->smallWaves;
+    // (the kernel runs six waves per SIMD: three 8-wave problems per CU at once.  Measured on 200 ... 8 000 KITTI-like frames,
+    //  tests/dev/c5_sweep.py: 16 waves win up to one problem per CU, 8 up to ~3 000 frames -- 1 000: 0.54 against 0.60 ms --, 4 beyond)
     if (B <= ctx->nCU) return 16;
-    if (B <= 2 * ctx->nCU) return 8;
+    if (B <= 12 * ctx->nCU) return 8;
     return 4;
 }
 
@@ -548,7 +550,8 @@ static bool small_fits(const kbest_ctx *ctx, int B, int maxRow, int maxCol, int 
 {
     if (ctx->noSmall || maxRow > kb::SMALL_MAX_DIM || maxCol > kb::SMALL_MAX_DIM || k > kb::SMALL_MAX_K) return false;
     int nw = small_waves(ctx, B);
-    while (nw > 2 && kb::small_lds_layout(maxRow, maxCol, k, nw, weights).total > ctx->ldsLimit) nw /= 2;
+    while (nw > 2 && kb::small_lds_layout(maxRow, maxCol, k, nw, weights).total > ctx->ldsLimit)
+        nw /= 2;
     if (kb::small_lds_layout(maxRow, maxCol, k, nw, weights).total > ctx->ldsLimit) return false;
     if (nwOut) *nwOut = nw;
     return true;
@@ -557,6 +560,21 @@ static bool small_fits(const kbest_ctx *ctx, int B, int maxRow, int maxCol, int 
 static size_t small_states_need(int B, int maxRow, int maxCol, int k, int nw)
 {
     return (size_t)B * (size_t)kb::small_states_per_problem(k, nw, maxCol) * (size_t)kb::small_state_stride(maxRow, maxCol) + 256;
+}
+
+// "Launches of up to B problems": a smaller batch takes more waves -- and state slots -- per problem (small_waves), so a
+// reservation is the maximum over every tier reachable with B' <= B.
+static size_t small_states_need_upto(const kbest_ctx *ctx, int B, int maxRow, int maxCol, int k, bool weights)
+{
+    size_t need = 0;
+    const int tiers[3] = {B, B < 12 * ctx->nCU ? B : 12 * ctx->nCU, B < ctx->nCU ? B : ctx->nCU};
+    const int shapes[4] = {2, 4, 8, 16};
+    for (int t = 0; t < 3; t++)
+        for (int i = 0; i < 4; i++) {
+            const size_t n = small_states_need(tiers[t], maxRow, maxCol, k, shapes[i]);
+            if (kb::small_lds_layout(maxRow, maxCol, k, shapes[i], weights).total <= ctx->ldsLimit && n > need) need = n;
+        }
+    return need;
 }
 
 // Launch shape of the lane-per-child kernel (kbest_lane.hip): waves per problem and hypotheses split per round.  A lane is a
@@ -620,13 +638,7 @@ int kbest_reserve(kbest_ctx *ctx, int B, int maxRow, int k)
     // the small-problem kernel takes more waves (and state slots) per problem as the batch shrinks, and numCol < numRow may
     // change its shape too -- so the reservation is the maximum over every tier reachable with B' <= B.
     if (maxRow <= kb::SMALL_MAX_DIM && !ctx->noSmall && k <= kb::SMALL_MAX_K) {
-        size_t need = 0;
-        const int tiers[3] = {B, B < 2 * ctx->nCU ? B : 2 * ctx->nCU, B < ctx->nCU ? B : ctx->nCU};
-        for (int t = 0; t < 3; t++)
-            for (int nw = 2; nw <= 16; nw *= 2) {
-                const size_t n = small_states_need(tiers[t], maxRow, maxRow, k, nw);
-                if (kb::small_lds_layout(maxRow, maxRow, k, nw, false).total <= ctx->ldsLimit && n > need) need = n;
-            }
+        const size_t need = small_states_need_upto(ctx, B, maxRow, maxRow, k, false);
         if (need) {
             int rc = ensure_states(ctx, need, true);
             if (rc != KBEST_OK) return rc;
@@ -1744,7 +1756,7 @@ extern "C" int kbest_reserve_assoc(kbest_ctx *ctx, int B, int maxRawRow, int max
     if (maxCol > kb::SMALL_MAX_DIM || !small_fits(ctx, B, capRow, maxCol, k, true, &nw))
         return fail(ctx, KBEST_ERR_UNSUPPORTED, "kbest_reserve_assoc: frames beyond the fused association kernel");
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
-    return ensure_states(ctx, small_states_need(B, capRow, maxCol, k, nw), true);
+    return ensure_states(ctx, small_states_need_upto(ctx, B, capRow, maxCol, k, true), true);
 }
 
 static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM, const double *cost,

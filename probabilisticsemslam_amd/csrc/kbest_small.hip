@@ -480,11 +480,17 @@ struct SCtrl {
 };
 static_assert(sizeof(SCtrl) <= 96, "SCtrl must fit the LDS slot reserved by small_lds_layout");
 
+// Six waves per SIMD (80 VGPRs; three values spilled outside the loops) instead of five: 24 wave slots per CU hold three
+// 8-wave problems at once, and 8 waves per problem then beat 4 up to ~3 000 frames per launch (1 000 KITTI-like frames: 0.60 ->
+// 0.54 ms; at five per SIMD only 2.5 such workgroups fit and the second generation starts late).  Workgroups with an odd number
+// of waves (5, 6 per problem) only pack when there are spare slots: 4 x 5 waves on 20 slots are not placed together (measured).
 #ifndef KS_WAVES_PER_EU
-#define KS_WAVES_PER_EU 5
+#define KS_WAVES_PER_EU 6
 #endif
 template <int NW>
-__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(KS_WAVES_PER_EU, KS_WAVES_PER_EU)))
+// (16 waves: a lone problem on its CU, four waves per SIMD -- no reason to give up registers there)
+__global__ void __launch_bounds__(NW * 64)
+__attribute__((amdgpu_waves_per_eu(NW == 16 ? 4 : KS_WAVES_PER_EU, NW == 16 ? 4 : KS_WAVES_PER_EU)))
 kbest_small_kernel(SmallParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1240,13 +1246,8 @@ hipError_t launch_kbest_small(const SmallParams &p, int B, int nWaves, hipStream
 {
     switch (nWaves) {
     case 2: return launch_small_nw<2>(p, B, stream);
-    case 3: return launch_small_nw<3>(p, B, stream);
     case 4: return launch_small_nw<4>(p, B, stream);
-    case 5: return launch_small_nw<5>(p, B, stream);
-    case 6: return launch_small_nw<6>(p, B, stream);
     case 8: return launch_small_nw<8>(p, B, stream);
-    case 10: return launch_small_nw<10>(p, B, stream);
-    case 12: return launch_small_nw<12>(p, B, stream);
     default: return launch_small_nw<16>(p, B, stream);
     }
 }
