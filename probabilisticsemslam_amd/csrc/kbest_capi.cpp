@@ -114,6 +114,7 @@ struct kbest_ctx {
     int ldsPerCU = 160 * 1024;
     int nCU = 256;
     int smallWaves = 0;  // waves per problem of the small-problem kernel; 0 = choose per launch (KBEST_SMALL_NW)
+    bool noTiny = false; // KBEST_NO_TINY: frames with a handful of measurements through the enumeration kernels too (A/B, tests)
     bool noT0 = false;        // KBEST_NO_T0: no a-priori threshold in the 64-row kernel (A/B tests)
     int wideNw = 0;           // KBEST_WIDE_NW: waves per problem of the general-size kernel (8 / 16; A/B tests)
     int wideTile = -1;        // KBEST_WIDE_TILE: 0 / 1 force the cost copy out of / into LDS (A/B tests)
@@ -382,6 +383,7 @@ int kbest_create(kbest_ctx **out, int device)
     ctx->noLane = getenv("KBEST_NO_LANE") != nullptr;
     ctx->noSplit = getenv("KBEST_NO_SPLIT") != nullptr;
     if (const char *e = getenv("KBEST_SPLIT")) { const int w = atoi(e); if (w == 2 || w == 4) ctx->splitForce = w; }
+    ctx->noTiny = getenv("KBEST_NO_TINY") != nullptr;
     if (const char *e = getenv("KBEST_ZC_COST")) ctx->zcCost = atoi(e);
     ctx->noReorder = getenv("KBEST_NO_REORDER") != nullptr;
     if (const char *e = getenv("KBEST_PIECES")) { const int w = atoi(e); if (w == 1 || w == 2 || w == 4) ctx->pieces = w; }
@@ -1564,6 +1566,24 @@ static int raw_reserve(kbest_ctx *ctx, DevBufRaw &d, size_t need)
     return KBEST_OK;
 }
 
+// Frames with a handful of measurements -- the reference's real ones (README.md:11: 3-5 per frame) -- have so few assignments in
+// all, (nL + nM)! / nL! before conditioning, that looking at every one of them beats enumerating the k best (kbest_tiny.hip).  The
+// whole batch must qualify (one launch); the production mode only (conditionCosts, cutoff 42, gate).
+static bool tiny_takes(const kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM, int k, bool condition, bool bruteForce)
+{
+    if (ctx->noTiny || !condition || bruteForce || k > kb::SMALL_MAX_K) return false;
+    if (kb::tiny_lds_bytes(k) > ctx->ldsLimit) return false;
+    for (int b = 0; b < B; b++) {
+        const int m = nM[b], l = nL[b];
+        if (m == 0) continue;  // (an empty frame: answered by either kernel at its shape test)
+        if (m < 2 || m > kb::TINY_MAX_COL || l < 0 || l + m > kb::TINY_MAX_ROW) return false;
+        long long cnt = 1;
+        for (int c = 0; c < m; c++) cnt *= (l + m - c);
+        if (cnt > kb::TINY_MAX_COUNT) return false;
+    }
+    return true;
+}
+
 // The association path on the small-problem kernel (kbest_small.hip): conditionCosts -> kBest2DCutoff(42) -> weights
 // -> scatter back, ONE launch, only [nM][nL+1] doubles per frame come back.  Returns 1 when some frame does not fit
 // that kernel (more than 32 kept rows, ...): the caller then runs the general pipeline.
@@ -1662,7 +1682,8 @@ static int weights_small(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t
         *hdone = 0;
         sp.done = reinterpret_cast<int *>(dout + outBytes);
     }
-    hipError_t e = kb::launch_kbest_small(sp, B, nw, ctx->stream);
+    hipError_t e = tiny_takes(ctx, B, nL, nM, k, condition, bruteForce) ? kb::launch_kbest_tiny(sp, B, B > 2 * ctx->nCU, ctx->stream)
+                                                                          : kb::launch_kbest_small(sp, B, nw, ctx->stream);
     if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "association kernel launch", e);
     if (!zeroCopy) HIP_TRY(ctx, hipMemcpyAsync(hout, dout, outBytes, hipMemcpyDeviceToHost, ctx->stream));
     if (sp.done) {

@@ -269,6 +269,10 @@ __host__ __device__ inline WideLds wide_lds_layout(int maxRow, int maxCol, bool 
 //      conditionCosts prologue and assignmentProb epilogue (cost block in -> probabilities out, one launch) ----
 constexpr int SMALL_MAX_DIM = 32;
 constexpr int SMALL_MAX_K = 1024;
+constexpr int TINY_MAX_COL = 8;        // kbest_tiny.hip: measurements per frame,
+constexpr int TINY_MAX_ROW = 64;       //   rows of the raw block (landmarks + measurements),
+constexpr int TINY_MAX_COUNT = 1 << 20; //   assignments of the frame in all: (nL + nM)! / nL!,
+constexpr int TINY_CAP = 1024;         //   candidates kept for the final sort
 constexpr int SMALL_MAX_RAW_ROWS = 2048;  // rows of the unconditioned block (assoc mode)
 
 struct SmallParams {
@@ -426,6 +430,10 @@ hipError_t launch_fill_unused(const int *nf, const int *nRow, const int *nCol, i
                               int *col4row, double *gain, bool tablesI8, hipStream_t stream);
 hipError_t launch_kbest_lane(const Params &p, int B, int nWaves, int lanesPerChild, hipStream_t stream);
 hipError_t launch_kbest_small(const SmallParams &p, int B, int nWaves, hipStream_t stream);
+// kbest_tiny.hip: the fused association path by exhaustive enumeration, for frames whose assignments are few (condition + gate +
+// cutoff mode of SmallParams only); nf = -2: the frame is for the enumeration kernels after all
+hipError_t launch_kbest_tiny(const SmallParams &p, int B, bool many, hipStream_t stream);
+int tiny_lds_bytes(int k);
 hipError_t launch_kbest(const Params &p, int B, int nWaves, hipStream_t stream);
 hipError_t launch_kbest_wide(const WideParams &p, int grid, hipStream_t stream);
 hipError_t launch_quadric_costs(const QuadricParams &p, int B, hipStream_t stream);

@@ -288,3 +288,84 @@ def test_optimistic_bounds_keep_the_enumeration_exact(monkeypatch, knobs):
     onf, or4c, oc4r, og, _ = ol.orc_kbest_batch(costs, N, M, k)
     assert (nf == onf).all() and (r4c == or4c).all() and (c4r == oc4r).all() and (bits(g) == bits(og)).all()
     eng.close()
+
+
+def _assoc_expected(frame, nL, nM, k):
+    """getAssignmentProbs on one raw block by the checker: conditionCosts -> assignmentProb -> scatter back (assignment.cpp:38-74)."""
+    cond, idx = ol.condition_costs(frame, nL + nM, nM)
+    cl = len(idx) - nM
+    po, nf = ol.assignment_prob(cond, cl, nM, k)
+    want = np.zeros((nM, nL + 1))
+    want[:, idx[:cl]] = po[:, :cl]
+    want[:, nL] = po[:, cl]
+    return want, nf
+
+
+TINY_SHAPES = [(6, 3), (6, 5), (4, 2), (9, 4), (0, 3), (12, 3), (3, 6), (0, 8), (5, 5), (40, 2), (62, 2), (1, 2)]
+
+
+@pytest.mark.parametrize("k", [200, 7])
+def test_frames_with_a_handful_of_measurements_by_exhaustive_enumeration(monkeypatch, k):
+    """kbest_tiny.hip: frames whose assignments are few in all ((nL + nM)! / nL! <= 65 536: the reference's real frame sizes,
+    README.md:11) are answered by looking at every assignment instead of enumerating the k best.  Same probabilities as the
+    checker's getAssignmentProbs chain, and bit for bit those of the enumeration kernel on the same frames (same gains, same
+    order of additions) -- frame by frame (one frame per call: the reference's call pattern), as one mixed batch, and as a batch
+    that fills the chip (smaller workgroups)."""
+    from probabilisticsemslam_amd import workloads as wl
+    tiny = pk.KBestEngine(0)
+    plain = engine_with(monkeypatch, KBEST_NO_TINY=1)
+    frames, nLs, nMs = [], [], []
+    for i, (nL, nM) in enumerate(TINY_SHAPES):
+        for f in wl.kitti_like_frames(3, nL=nL, nM=nM, seed=0x7151 + 97 * i) if nL > 0 else [None] * 2:
+            if f is None:  # no landmarks: every measurement is new (assignment.cpp:52-54)
+                f = np.full(nM * nM, np.inf)
+                for c in range(nM):
+                    f[c * nM + c] = 10.0
+            frames.append(f)
+            nLs.append(nL)
+            nMs.append(nM)
+    # one frame per call
+    for f, nL, nM in zip(frames, nLs, nMs):
+        out, nf = tiny.weights([f], [nL], [nM], k, condition=True)
+        ref, nfr = plain.weights([f], [nL], [nM], k, condition=True)
+        want, nfw = _assoc_expected(f, nL, nM, k)
+        assert nf[0] == nfr[0] == nfw, (nL, nM, nf, nfr, nfw)
+        assert np.array_equal(out[0], ref[0]), (nL, nM)
+        np.testing.assert_allclose(out[0], want, rtol=0, atol=1e-12)
+    # one mixed batch, and a batch of 600 frames (256-thread workgroups)
+    out, nf = tiny.weights(frames, nLs, nMs, k, condition=True)
+    ref, nfr = plain.weights(frames, nLs, nMs, k, condition=True)
+    assert (nf == nfr).all()
+    for a, b in zip(out, ref):
+        assert np.array_equal(a, b)
+    many = wl.kitti_like_frames(600, nL=6, nM=4, seed=0xBEEF)
+    out, nf = tiny.weights(many, [6] * 600, [4] * 600, k, condition=True)
+    ref, nfr = plain.weights(many, [6] * 600, [4] * 600, k, condition=True)
+    assert (nf == nfr).all() and all(np.array_equal(a, b) for a, b in zip(out, ref))
+    tiny.close()
+    plain.close()
+
+
+def test_exhaustive_enumeration_with_ties_and_with_too_many_of_them(monkeypatch):
+    """Integer costs: masses of exact ties.  With k beyond the number of assignments the order of equal gains cannot matter and
+    the probabilities are the checker's.  A frame whose k-th gain sits in a group of thousands of equal ones overflows the
+    candidate list: it comes back through the enumeration kernels (nf = -2 inside), with valid probabilities."""
+    eng = pk.KBestEngine(0)
+    nL, nM = 4, 3  # 7 x 3: 210 assignments
+    nR = nL + nM
+    C = np.full(nR * nM, np.inf)
+    for c in range(nM):
+        for r in range(nL):
+            C[c * nR + r] = float((r + c) % 3)
+        C[c * nR + nL + c] = 2.0
+    out, nf = eng.weights([C], [nL], [nM], 1024, condition=True)
+    want, nfw = _assoc_expected(C, nL, nM, 1024)
+    assert nfw < 1024 and nf[0] == nfw  # everything within the gate is enumerated
+    np.testing.assert_allclose(out[0], want, rtol=0, atol=1e-12)
+    # 12 x 4, all costs equal: 11 880 assignments with the same gain
+    Z = np.zeros(12 * 4)
+    out, nf = eng.weights([Z], [8], [4], 200, condition=True)
+    assert nf[0] == 200
+    np.testing.assert_allclose(out[0].sum(axis=1), np.ones(4), rtol=0, atol=1e-12)
+    assert (out[0] >= 0).all()
+    eng.close()
