@@ -596,8 +596,8 @@ def run_c5(eng, torch, steps, warmup, dev, tstream, no_cpu, F=1000, k=200, nL=20
         floor_us = {"error": repr(ex)}
     # -- the reference's REAL frame sizes ("3-5 measurements per frame", README.md:11): one frame per call, next to the
     #    reference's own conditionCosts + assignmentProb on one host core.  A GPU call cannot be shorter than its launch and
-    #    completion (~0.06 ms); at these sizes one host core is faster per call and the GPU wins from a few frames per call on
-    #    (table: profiles/r03_crossover.json).
+    #    completion (one_frame_per_call_floor); frames with this few assignments in all go through the exhaustive kernel
+    #    (kbest_tiny.hip) instead of the enumeration (table: profiles/r04_crossover.json).
     small = []
     for (snL, snM) in ((6, 3), (6, 5)):
         sf = wl.kitti_like_frames(64, nL=snL, nM=snM, seed=0xC0FFEE + snL * 100 + snM)

@@ -12,6 +12,7 @@ echo "64-row kernel only, 12 waves x 12, 120 s, seed 45: $(KBEST_NO_SMALL=1 KBES
 echo "lane-per-child kernel forced, 120 s, seed 46: $(KBEST_FORCE_LANE=1 timeout 300 python3 tests/dev/soak.py 120 46 2>&1 | tail -1)"
 echo "general-size kernel forced, 120 s, seed 47: $(KBEST_FORCE_WIDE=1 timeout 300 python3 tests/dev/soak.py 120 47 2>&1 | tail -1)"
 echo "rows up to 1 024 (SOAK_BIG=0.5 SOAK_BIGMAX=1024), 240 s, seed 48: $(SOAK_BIG=0.5 SOAK_BIGMAX=1024 timeout 500 python3 tests/dev/soak.py 240 48 2>&1 | tail -1)"
+echo "exhaustive kernel against the enumeration kernels (frames of 2-8 measurements through kbest_assoc_probs_batch_f64), 120 s, seed 50: $(timeout 300 python3 tests/dev/soak_tiny.py 120 50 2>&1 | tail -1)"
 echo "association path, 120 s, seed 49: $(timeout 300 python3 tests/dev/soak_assoc.py 120 49 2>&1 | tail -1)"
 } > $out/soak.log 2>&1
 cat $out/soak.log
