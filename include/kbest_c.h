@@ -224,7 +224,9 @@ int kbest_condition_costs_f64(kbest_ctx *ctx, int B, const int32_t *nRow, const 
  * instead of enumerating the k best: same gains bit for bit (calcGain's sum), same solutions, same probabilities; only
  * when two DIFFERENT assignments with exactly equal gains sit on both sides of slot k can the emitted sets differ (the
  * order of exact ties is the reference heap's artefact and unspecified there too).  KBEST_NO_TINY=1 at kbest_create
- * switches it off.
+ * switches it off.  kbest_weights_batch_f64 on blocks that are conditioned already (all entries >= 0, an exact zero
+ * somewhere: what conditionCosts returns and assignment.cpp:58-62 passes on) takes the same kernel; any other block
+ * is answered by the enumeration kernels.
  */
 int kbest_assoc_probs_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM,
                                 const double *cost, const int64_t *costOff, int k, double *probs,

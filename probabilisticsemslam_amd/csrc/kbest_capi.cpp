@@ -1568,10 +1568,12 @@ static int raw_reserve(kbest_ctx *ctx, DevBufRaw &d, size_t need)
 
 // Frames with a handful of measurements -- the reference's real ones (README.md:11: 3-5 per frame) -- have so few assignments in
 // all, (nL + nM)! / nL! before conditioning, that looking at every one of them beats enumerating the k best (kbest_tiny.hip).  The
-// whole batch must qualify (one launch); the production mode only (conditionCosts, cutoff 42, gate).
+// whole batch must qualify (one launch); assignmentProb's mode only (cutoff 42, gate), on raw blocks (conditionCosts first) or on
+// conditioned ones.
 static bool tiny_takes(const kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM, int k, bool condition, bool bruteForce)
 {
-    if (ctx->noTiny || !condition || bruteForce || k > kb::SMALL_MAX_K) return false;
+    (void)condition;  // (without conditioning: assignmentProb on a block that IS conditioned -- the kernel checks, -2 otherwise)
+    if (ctx->noTiny || bruteForce || k > kb::SMALL_MAX_K) return false;
     if (kb::tiny_lds_bytes(k) > ctx->ldsLimit) return false;
     for (int b = 0; b < B; b++) {
         const int m = nM[b], l = nL[b];
@@ -1677,36 +1679,46 @@ static int weights_small(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t
     }
     unsigned char *hout = static_cast<unsigned char *>(ctx->pinOut.host);
     volatile int *hdone = reinterpret_cast<volatile int *>(hout + outBytes);
-    // (a few frames only: with hundreds of workgroups the counter's system-scope atomics cost more than the wake-up saves)
-    if (zeroCopy && !ctx->noPoll && B <= 8) {
-        *hdone = 0;
-        sp.done = reinterpret_cast<int *>(dout + outBytes);
-    }
-    hipError_t e = tiny_takes(ctx, B, nL, nM, k, condition, bruteForce) ? kb::launch_kbest_tiny(sp, B, B > 2 * ctx->nCU, ctx->stream)
-                                                                          : kb::launch_kbest_small(sp, B, nw, ctx->stream);
-    if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "association kernel launch", e);
-    if (!zeroCopy) HIP_TRY(ctx, hipMemcpyAsync(hout, dout, outBytes, hipMemcpyDeviceToHost, ctx->stream));
-    if (sp.done) {
-        // The results land in this host memory; every workgroup bumps the counter (system-scope release) when its last
-        // byte is written.  Polling it skips the runtime's completion path (interrupt / wake-up), which is a tenth of a
-        // one-frame call.  After ~2 ms without completion the ordinary wait takes over (it also reports device errors).
-        const auto t0 = std::chrono::steady_clock::now();
-        int spins = 0;
-        while (*hdone != B) {
-            if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
-        }
-        std::atomic_thread_fence(std::memory_order_acquire);
-        if (*hdone != B) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    } else {
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    }
     const int32_t *hnf = reinterpret_cast<const int32_t *>(hout + probBytes);
     bool anyUnfit = false;
-    for (int b = 0; b < B; b++)
-        if (hnf[b] == -2) {  // a frame that keeps more rows than this kernel takes: general pipeline
-            anyUnfit = true;
-            if (unfit) unfit->push_back(b);
+    // First the exhaustive kernel where the whole batch qualifies (tiny_takes); a frame it hands back (-2: thousands of equal
+    // gains at slot k, or -- without conditioning -- a block that is not a conditioned one) sends the batch through the fused
+    // enumeration kernel after all, whose own -2 (more rows kept than it takes) goes to the general pipeline.
+    bool useTiny = tiny_takes(ctx, B, nL, nM, k, condition, bruteForce);
+    for (;;) {
+        // (a few frames only: with hundreds of workgroups the counter's system-scope atomics cost more than the wake-up saves)
+        if (zeroCopy && !ctx->noPoll && B <= 8) {
+            *hdone = 0;
+            sp.done = reinterpret_cast<int *>(dout + outBytes);
         }
+        hipError_t e = useTiny ? kb::launch_kbest_tiny(sp, B, B > 2 * ctx->nCU, ctx->stream) : kb::launch_kbest_small(sp, B, nw, ctx->stream);
+        if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "association kernel launch", e);
+        if (!zeroCopy) HIP_TRY(ctx, hipMemcpyAsync(hout, dout, outBytes, hipMemcpyDeviceToHost, ctx->stream));
+        if (sp.done) {
+            // The results land in this host memory; every workgroup bumps the counter (system-scope release) when its last
+            // byte is written.  Polling it skips the runtime's completion path (interrupt / wake-up), which is a tenth of a
+            // one-frame call.  After ~2 ms without completion the ordinary wait takes over (it also reports device errors).
+            const auto t0 = std::chrono::steady_clock::now();
+            int spins = 0;
+            while (*hdone != B) {
+                if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            if (*hdone != B) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        } else {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        anyUnfit = false;
+        for (int b = 0; b < B; b++) anyUnfit = anyUnfit || hnf[b] == -2;
+        if (useTiny && anyUnfit) {
+            useTiny = false;
+            continue;
+        }
+        break;
+    }
+    if (anyUnfit && unfit)
+        for (int b = 0; b < B; b++)
+            if (hnf[b] == -2) unfit->push_back(b);  // a frame that keeps more rows than the fused kernel takes: general pipeline
     if (anyUnfit && !unfit) return 1;
     if (!mProbs) memcpy(probs, hout, nProb * 8);
     if (nf) memcpy(nf, hnf, (size_t)B * 4);

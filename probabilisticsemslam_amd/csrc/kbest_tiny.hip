@@ -191,35 +191,67 @@ __global__ void __launch_bounds__(NT) kbest_tiny_kernel(SmallParams p)
         ctl->total = 0;
     }
     __syncthreads();
-    for (int c = wave; c < M; c += NWV) {  // column minima (:450-458)
-        double m = INF;
-        for (int r = lane; r < NR; r += 64) m = min_keep(m, stage[c * NR + r]);
-        m = wave_min_f64(m);
-        if (lane == 0) colMin[c] = m;
-    }
-    __syncthreads();
-    if (wave == 0) {  // a row is kept iff some entry is within 42 of its column's minimum (:462-474)
-        bool good = false;
-        if (lane < NR)
-            for (int c = 0; c < M; c++) good = good | (stage[c * NR + lane] <= colMin[c] + TN_GATE);
-        const u64 m = __ballot(good);
-        if (lane == 0) *keepW = m;
-    }
-    __syncthreads();
-    const u64 keep = *keepW;
-    const int N = __popcll(keep);
-    if (N < M) {  // undefined in the reference (size_t underflow at assignment.cpp:60); the enumeration kernels answer -2 as well
-        if (tid == 0) p.nf[b] = -2;
-        signal_done();
-        return;
-    }
-    if (tid < NR && ((keep >> tid) & 1ull)) {  // kept rows compacted in order; entries cost - colMin, +inf beyond the gate (:476-496)
-        const int nr = __popcll(keep & ((1ull << tid) - 1ull));
-        rowIdx[nr] = (unsigned short)tid;
-        for (int c = 0; c < M; c++) {
-            const double x = stage[c * NR + tid];
-            Cs[nr + c * TN_LDT] = (x <= colMin[c] + TN_GATE) ? (x - colMin[c]) : INF;
+    int N;
+    if (p.condition) {
+        for (int c = wave; c < M; c += NWV) {  // column minima (:450-458)
+            double m = INF;
+            for (int r = lane; r < NR; r += 64) m = min_keep(m, stage[c * NR + r]);
+            m = wave_min_f64(m);
+            if (lane == 0) colMin[c] = m;
         }
+        __syncthreads();
+        if (wave == 0) {  // a row is kept iff some entry is within 42 of its column's minimum (:462-474)
+            bool good = false;
+            if (lane < NR)
+                for (int c = 0; c < M; c++) good = good | (stage[c * NR + lane] <= colMin[c] + TN_GATE);
+            const u64 m = __ballot(good);
+            if (lane == 0) *keepW = m;
+        }
+        __syncthreads();
+        const u64 keep = *keepW;
+        N = __popcll(keep);
+        if (N < M) {  // undefined in the reference (size_t underflow at assignment.cpp:60); the enumeration kernels answer -2 as well
+            if (tid == 0) p.nf[b] = -2;
+            signal_done();
+            return;
+        }
+        if (tid < NR && ((keep >> tid) & 1ull)) {  // kept rows compacted in order; entries cost - colMin, +inf beyond the gate (:476-496)
+            const int nr = __popcll(keep & ((1ull << tid) - 1ull));
+            rowIdx[nr] = (unsigned short)tid;
+            for (int c = 0; c < M; c++) {
+                const double x = stage[c * NR + tid];
+                Cs[nr + c * TN_LDT] = (x <= colMin[c] + TN_GATE) ? (x - colMin[c]) : INF;
+            }
+        }
+    } else {
+        // assignmentProb on a block that is conditioned already (the reference's own call, assignment.cpp:58-62).  kBest2DCutoff
+        // shifts the matrix by its smallest entry (makeCostMatrixSafe, cpp:534-569) and adds CDelta * numCol back to every gain
+        // (cpp:583, 626-630): on a conditioned block that entry is an exact 0.0 -- every column holds one -- the shift is the
+        // identity and the gains are calcGain's sums as they stand.  Any other block (a negative entry, no zero) is not this
+        // kernel's: -2.
+        N = NR;
+        double mn = INF;
+        for (int i = tid; i < NR * M; i += NT) {
+            const double x = stage[i];
+            mn = min_keep(mn, x);
+            const int c = i / NR, r = i - c * NR;
+            Cs[r + c * TN_LDT] = (x == x) ? x : INF;  // NaN: every comparison the reference makes with it is false, like +inf
+        }
+        mn = wave_min_f64(mn);
+        if (lane == 0) {  // (bit patterns of non-negative doubles order like the values; a negative entry is flagged apart)
+            if (mn < 0.0) atomicAdd(&ctl->total, 1);
+            else atomicMin(&ctl->minBits, (unsigned long long)__double_as_longlong(mn));
+        }
+        if (tid < NR) rowIdx[tid] = (unsigned short)tid;
+        __syncthreads();
+        const bool notMine = ctl->minBits != 0ull || ctl->total != 0;
+        __syncthreads();
+        if (notMine) {
+            if (tid == 0) p.nf[b] = -2;
+            signal_done();
+            return;
+        }
+        if (tid == 0) ctl->minBits = 0x7ff0000000000000ull;
     }
     __syncthreads();
     const int nLc = N - M;  // condL (assignment.cpp:60)

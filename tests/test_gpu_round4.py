@@ -338,6 +338,28 @@ def test_frames_with_a_handful_of_measurements_by_exhaustive_enumeration(monkeyp
     assert (nf == nfr).all()
     for a, b in zip(out, ref):
         assert np.array_equal(a, b)
+    # assignmentProb alone, on blocks that are conditioned already (the reference's own call, assignment.cpp:58-62; the shim's
+    # path): the exhaustive kernel takes them too; a block that is NOT a conditioned one (negative entries, no exact zero) is
+    # handed back and answered by the enumeration kernel
+    conds, cls, cms = [], [], []
+    for f, nL, nM in zip(frames, nLs, nMs):
+        if nL == 0:
+            continue
+        c, idx = ol.condition_costs(f, nL + nM, nM)
+        conds.append(c)
+        cls.append(len(idx) - nM)
+        cms.append(nM)
+    out, nf = tiny.weights(conds, cls, cms, k)
+    ref, nfr = plain.weights(conds, cls, cms, k)
+    assert (nf == nfr).all() and all(np.array_equal(a, b) for a, b in zip(out, ref))
+    for c, cl, cm, o in zip(conds[:6], cls, cms, out):
+        po, _ = ol.assignment_prob(c, cl, cm, k)
+        np.testing.assert_allclose(o, po, rtol=0, atol=1e-12)
+    rng = np.random.default_rng(11)
+    odd = [rng.normal(size=(7 + 3) * 3) * 5.0 for _ in range(4)]
+    out, nf = tiny.weights(odd, [7] * 4, [3] * 4, k)
+    ref, nfr = plain.weights(odd, [7] * 4, [3] * 4, k)
+    assert (nf == nfr).all() and all(np.array_equal(a, b) for a, b in zip(out, ref))
     many = wl.kitti_like_frames(600, nL=6, nM=4, seed=0xBEEF)
     out, nf = tiny.weights(many, [6] * 600, [4] * 600, k, condition=True)
     ref, nfr = plain.weights(many, [6] * 600, [4] * 600, k, condition=True)
