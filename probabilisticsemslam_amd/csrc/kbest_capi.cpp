@@ -542,9 +542,12 @@ static int small_waves(const kbest_ctx *ctx, int B)
 {
     if (ctx->smallWaves > 0) return ctx->smallWaves;
     // (the kernel runs six waves per SIMD: three 8-wave problems per CU at once.  Measured on 200 ... 8 000 KITTI-like frames,
-    //  tests/dev/c5_sweep.py: 16 waves win up to one problem per CU, 8 up to ~3 000 frames -- 1 000: 0.54 against 0.60 ms --, 4 beyond)
+    //  tests/dev/c5_sweep.py: 16 waves win up to one problem per CU, 8 up to ~3 000 frames -- 1 000: 0.54 against 0.60 ms --, 4
+    //  beyond; on other rectangular batches, tests/dev/small_shapes.py, ms for 4 / 8 waves: 600 x 32x24, k = 200: 1.09 / 0.86,
+    //  800 x 24x12, k = 400: 1.15 / 0.94, but 2 048 x 20x8, k = 50: 0.28 / 0.33, 3 000 x 16x4, k = 20: 0.18 / 0.25 -- short
+    //  problems in several generations want the small shape: 8 waves up to two generations of them)
     if (B <= ctx->nCU) return 16;
-    if (B <= 12 * ctx->nCU) return 8;
+    if (B <= 6 * ctx->nCU) return 8;
     return 4;
 }
 
@@ -569,7 +572,7 @@ static size_t small_states_need(int B, int maxRow, int maxCol, int k, int nw)
 static size_t small_states_need_upto(const kbest_ctx *ctx, int B, int maxRow, int maxCol, int k, bool weights)
 {
     size_t need = 0;
-    const int tiers[3] = {B, B < 12 * ctx->nCU ? B : 12 * ctx->nCU, B < ctx->nCU ? B : ctx->nCU};
+    const int tiers[3] = {B, B < 6 * ctx->nCU ? B : 6 * ctx->nCU, B < ctx->nCU ? B : ctx->nCU};
     const int shapes[4] = {2, 4, 8, 16};
     for (int t = 0; t < 3; t++)
         for (int i = 0; i < 4; i++) {

@@ -56,7 +56,7 @@ m = p.mean(axis=0)
 # (the library's routing rule, kbest_capi.cpp: small-problem kernel for rectangular or chip-underfilling batches of <= 32 rows)
 small = N <= 32 and not os.environ.get("KBEST_NO_SMALL") and (os.environ.get("KBEST_FORCE_SMALL") or M < N or (B <= 512 and kw))
 if small:
-    nw = int(os.environ.get("KBEST_SMALL_NW", "16" if B <= 256 else ("8" if B <= 3072 else "4")))
+    nw = int(os.environ.get("KBEST_SMALL_NW", "16" if B <= 256 else ("8" if B <= 1536 else "4")))
     names = ["tile set-up", "root (+barrier)", "rounds", "select+emission", "node load", "filter", "child dijkstra", "finish completed",
              "wait after children", "wait after filter", "rows scanned", "child passes", "merge", "wait after merge", "epilogue", "kernel cyc (sum over waves)"]
     tot = m[15]
