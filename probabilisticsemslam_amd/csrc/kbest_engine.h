@@ -273,6 +273,8 @@ constexpr int TINY_MAX_COL = 8;        // kbest_tiny.hip: measurements per frame
 constexpr int TINY_MAX_ROW = 64;       //   rows of the raw block (landmarks + measurements),
 constexpr int TINY_MAX_COUNT = 1 << 20; //   assignments of the frame in all: (nL + nM)! / nL!,
 constexpr int TINY_CAP = 1024;         //   candidates kept for the final sort
+// feasible prefixes kept in LDS for the passes (1 024-thread workgroups: a lone frame on its CU; 256: batches, four per CU)
+__host__ __device__ constexpr int tiny_prefix_cap(int nThreads) { return nThreads >= 1024 ? 2048 : 512; }
 constexpr int SMALL_MAX_RAW_ROWS = 2048;  // rows of the unconditioned block (assoc mode)
 
 struct SmallParams {
@@ -433,7 +435,7 @@ hipError_t launch_kbest_small(const SmallParams &p, int B, int nWaves, hipStream
 // kbest_tiny.hip: the fused association path by exhaustive enumeration, for frames whose assignments are few (condition + gate +
 // cutoff mode of SmallParams only); nf = -2: the frame is for the enumeration kernels after all
 hipError_t launch_kbest_tiny(const SmallParams &p, int B, bool many, hipStream_t stream);
-int tiny_lds_bytes(int k);
+int tiny_lds_bytes(int k, int nThreads = 1024);
 hipError_t launch_kbest(const Params &p, int B, int nWaves, hipStream_t stream);
 hipError_t launch_kbest_wide(const WideParams &p, int grid, hipStream_t stream);
 hipError_t launch_quadric_costs(const QuadricParams &p, int B, hipStream_t stream);

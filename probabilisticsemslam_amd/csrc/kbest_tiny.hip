@@ -15,7 +15,9 @@
 //   * what kBest2DCutoff emits is the ascending run of the k smallest gains up to gainBest[0] + cutoff (cpp:705-719); what
 //     assignmentProb makes of it (assignment.cpp:616-648) does not depend on the order of equal gains (equal gains have equal
 //     weights, every probs[col][row] receives the same values in the same order);
-//   * pass 1: all threads walk the assignments (thread = a prefix of nM - 1 rows, loop over the last column's free rows),
+//   * a greedy assignment bounds what can be emitted at all (greedy + cutoff); the prefixes (rows of the first nM - 1 or
+//     nM - 2 columns) that stay below it and off the +inf entries are decoded ONCE into an LDS list;
+//   * pass 1: the threads share the list's work items (prefix x free row of the next column; loop over the last column),
 //     reduce the minimum and fill a 1 024-bucket histogram of the gains over [0, 42 nM] (conditioned entries lie in [0, 42]);
 //     the first bucket at which the cumulated count reaches k bounds the k-th gain; pass 2 collects the assignments up to
 //     that bucket (a few more than k), a rank sort orders them by (gain, index), the first min(k, those within the cutoff)
@@ -47,6 +49,7 @@ struct TCtrl {
     int bStar;                   // bucket of the k-th smallest gain
     int total;                   // feasible assignments seen
     double limit;                // greedy assignment + cutoff: nothing beyond it is ever emitted
+    int nFeas;                   // feasible prefixes found (kept: the first tiny_prefix_cap)
 };
 
 // the q-th prefix (rows of the columns 0 .. D-1, lexicographic in "which of the still free rows"): rows packed one byte per
@@ -125,6 +128,54 @@ __device__ __forceinline__ void tiny_walk(const double *Cs, int N, int M, u32 nP
     }
 }
 
+// The same walk over a COMPACTED list of the feasible prefixes (rows packed, partial sum, prefix number): work item = (prefix,
+// which of its free rows the first inner column takes), so that the threads share what is left evenly -- on gated frames nine
+// prefixes in ten run through a +inf entry, and in the walk above their lanes idle while the tenth loops.
+template <int INNER, typename F>
+__device__ __forceinline__ void tiny_walk_list(const double *Cs, int N, int M, const u64 *preRows, const double *preAcc, const u32 *preQ,
+                                               int nFeas, int tid, int nThreads, double limit, F f)
+{
+    const double INF = d_inf();
+    const u64 rowsAll = (N >= 64) ? ~0ull : ((1ull << N) - 1ull);
+    const double *Clast = Cs + (M - 1) * TN_LDT;
+    const int D = M - INNER;
+    if (INNER == 1) {  // one column left: the prefix' own loop over its free rows (an item per row would re-find it by counting)
+        for (u32 i = (u32)tid; i < (u32)nFeas; i += (u32)nThreads) {
+            const u64 rows = preRows[i];
+            const double acc = preAcc[i];
+            const u32 q = preQ[i];
+            u64 used = 0ull;
+            for (int c = 0; c < D; c++) used |= 1ull << ((rows >> (8 * c)) & 63ull);
+            for (u64 fm = rowsAll & ~used; fm; fm &= fm - 1ull) {
+                const int r = __builtin_ctzll(fm);
+                const double g = acc + Clast[r];
+                if (g < INF) f(g, (q << 6) | (u32)r);
+            }
+        }
+        return;
+    }
+    const u32 F1 = (u32)(N - D);  // rows still free behind a prefix
+    const u32 nItems = (u32)nFeas * F1;
+    for (u32 t = (u32)tid; t < nItems; t += (u32)nThreads) {
+        const u32 i = t / F1, j = t - i * F1;
+        const u64 rows = preRows[i];
+        const double acc = preAcc[i];
+        const u32 q = preQ[i];
+        u64 used = 0ull;
+        for (int c = 0; c < D; c++) used |= 1ull << ((rows >> (8 * c)) & 63ull);
+        u64 fm1 = rowsAll & ~used;
+        for (u32 x = 0; x < j; x++) fm1 &= fm1 - 1ull;
+        const int r1 = __builtin_ctzll(fm1);
+        const double acc1 = acc + Cs[r1 + (M - 2) * TN_LDT];
+        if (!(acc1 < INF) || acc1 > limit) continue;
+        for (u64 fm = rowsAll & ~used & ~(1ull << r1); fm; fm &= fm - 1ull) {
+            const int r = __builtin_ctzll(fm);
+            const double g = acc1 + Clast[r];
+            if (g < INF) f(g, (q << 12) | ((u32)r1 << 6) | (u32)r);
+        }
+    }
+}
+
 }  // namespace
 
 template <int NT>
@@ -146,7 +197,7 @@ __global__ void __launch_bounds__(NT) kbest_tiny_kernel(SmallParams p)
     double *Cs = reinterpret_cast<double *>(smem + o);       o += TINY_MAX_COL * TN_LDT * 8;
     double *stage = reinterpret_cast<double *>(smem + o);    o += TINY_MAX_COL * TINY_MAX_ROW * 8;
     double *colMin = reinterpret_cast<double *>(smem + o);   o += TINY_MAX_COL * 8;
-    TCtrl *ctl = reinterpret_cast<TCtrl *>(smem + o);        o += 32;
+    TCtrl *ctl = reinterpret_cast<TCtrl *>(smem + o);        o += 40;
     u64 *keepW = reinterpret_cast<u64 *>(smem + o);          o += 8;
     unsigned short *rowIdx = reinterpret_cast<unsigned short *>(smem + o);  o += TINY_MAX_ROW * 2;
     u32 *hist = reinterpret_cast<u32 *>(smem + o);           o += TN_BUCKETS * 4;
@@ -157,7 +208,12 @@ __global__ void __launch_bounds__(NT) kbest_tiny_kernel(SmallParams p)
     u32 *solI = reinterpret_cast<u32 *>(smem + o);           o += k * 4;
     o = (o + 7) & ~7;
     double *wts = reinterpret_cast<double *>(smem + o);      o += k * 8;
-    unsigned char *rTab = smem + o;  // [k][M]
+    unsigned char *rTab = smem + o;                          o += k * TINY_MAX_COL;  // [k][M]
+    o = (o + 7) & ~7;
+    constexpr int PCAP = tiny_prefix_cap(NT);  // feasible prefixes kept for the passes
+    u64 *preRows = reinterpret_cast<u64 *>(smem + o);        o += PCAP * 8;
+    double *preAcc = reinterpret_cast<double *>(smem + o);   o += PCAP * 8;
+    u32 *preQ = reinterpret_cast<u32 *>(smem + o);
 
     auto signal_done = [&]() {  // (as in kbest_small.hip: the host polls this counter on one-frame calls)
         if (p.done) {
@@ -189,6 +245,7 @@ __global__ void __launch_bounds__(NT) kbest_tiny_kernel(SmallParams p)
         ctl->nWithin = 0;
         ctl->bStar = TN_BUCKETS - 1;
         ctl->total = 0;
+        ctl->nFeas = 0;
     }
     __syncthreads();
     int N;
@@ -281,6 +338,22 @@ __global__ void __launch_bounds__(NT) kbest_tiny_kernel(SmallParams p)
     }
     __syncthreads();
     const double limit = ctl->limit;
+    // ---- the feasible prefixes, once: decoded (divisions, free-row walks), checked against +inf and the bound, kept in a list;
+    //      the passes below then share the list's work items evenly.  More of them than the list holds: the plain walk.
+    for (u32 q = (u32)tid; q < nPre; q += NT) {
+        u64 rows, used;
+        double acc;
+        if (!tiny_prefix(Cs, N, inner2 ? M - 2 : M - 1, q, rows, used, acc) || acc > limit) continue;
+        const int pos = atomicAdd(&ctl->nFeas, 1);
+        if (pos < PCAP) {
+            preRows[pos] = rows;
+            preAcc[pos] = acc;
+            preQ[pos] = q;
+        }
+    }
+    __syncthreads();
+    const int nFeas = ctl->nFeas;
+    const bool listed = nFeas <= PCAP;
     // ---- pass 1: minimum and histogram (or, when everything fits the list, the list itself) -----------------------------------
     {
         double mn = INF;
@@ -298,8 +371,13 @@ __global__ void __launch_bounds__(NT) kbest_tiny_kernel(SmallParams p)
                 atomicAdd(&hist[bk], 1u);
             }
         };
-        if (inner2) tiny_walk<2>(Cs, N, M, nPre, tid, NT, limit, visit);
-        else tiny_walk<1>(Cs, N, M, nPre, tid, NT, limit, visit);
+        if (listed) {
+            if (inner2) tiny_walk_list<2>(Cs, N, M, preRows, preAcc, preQ, nFeas, tid, NT, limit, visit);
+            else tiny_walk_list<1>(Cs, N, M, preRows, preAcc, preQ, nFeas, tid, NT, limit, visit);
+        } else {
+            if (inner2) tiny_walk<2>(Cs, N, M, nPre, tid, NT, limit, visit);
+            else tiny_walk<1>(Cs, N, M, nPre, tid, NT, limit, visit);
+        }
         mn = wave_min_f64(mn);
         if (lane == 0 && mn < INF) atomicMin(&ctl->minBits, (unsigned long long)__double_as_longlong(mn));
         if (cnt) atomicAdd(&ctl->total, cnt);
@@ -350,8 +428,13 @@ __global__ void __launch_bounds__(NT) kbest_tiny_kernel(SmallParams p)
         // (nothing above the k-th bucket's upper edge, nothing beyond the cutoff)
         const double edge = (double)(bStar + 1) / scale * (1.0 + 1e-12);
         const double lim2 = (bStar < TN_BUCKETS - 1 && edge < cutG) ? edge : (cutG < limit ? cutG : limit);
-        if (inner2) tiny_walk<2>(Cs, N, M, nPre, tid, NT, lim2, collect);
-        else tiny_walk<1>(Cs, N, M, nPre, tid, NT, lim2, collect);
+        if (listed) {  // (the list was made against the looser bound: a prefix beyond lim2 gives its items nothing to do)
+            if (inner2) tiny_walk_list<2>(Cs, N, M, preRows, preAcc, preQ, nFeas, tid, NT, lim2, collect);
+            else tiny_walk_list<1>(Cs, N, M, preRows, preAcc, preQ, nFeas, tid, NT, lim2, collect);
+        } else {
+            if (inner2) tiny_walk<2>(Cs, N, M, nPre, tid, NT, lim2, collect);
+            else tiny_walk<1>(Cs, N, M, nPre, tid, NT, lim2, collect);
+        }
     }
     for (int i = tid; i < TINY_CAP; i += NT) rankA[i] = 0;
     __syncthreads();
@@ -456,18 +539,20 @@ __global__ void __launch_bounds__(NT) kbest_tiny_kernel(SmallParams p)
     signal_done();
 }
 
-int tiny_lds_bytes(int k)
+int tiny_lds_bytes(int k, int nThreads)
 {
-    int o = TINY_MAX_COL * TN_LDT * 8 + TINY_MAX_COL * TINY_MAX_ROW * 8 + TINY_MAX_COL * 8 + 32 + 8 + TINY_MAX_ROW * 2 +
+    int o = TINY_MAX_COL * TN_LDT * 8 + TINY_MAX_COL * TINY_MAX_ROW * 8 + TINY_MAX_COL * 8 + 40 + 8 + TINY_MAX_ROW * 2 +
             TN_BUCKETS * 4 + TINY_CAP * 16 + k * 12;
     o = (o + 7) & ~7;
-    return o + k * 8 + k * TINY_MAX_COL + 16;
+    o += k * 8 + k * TINY_MAX_COL;
+    o = (o + 7) & ~7;
+    return o + tiny_prefix_cap(nThreads) * 20 + 16;
 }
 
 template <int NT>
 static hipError_t launch_tiny_nt(const SmallParams &p, int B, hipStream_t stream)
 {
-    const int lds = tiny_lds_bytes(p.k);
+    const int lds = tiny_lds_bytes(p.k, NT);
     static std::atomic<int> granted[16];
     int dev = 0;
     (void)hipGetDevice(&dev);
