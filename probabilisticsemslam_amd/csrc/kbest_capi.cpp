@@ -104,6 +104,7 @@ struct kbest_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};  // the other pieces of a large host-entry batch (kbest_batch_f64)
+    int prioMain = 0, prioAux[3] = {0, 0, 0};          // their stream priorities (kbest_create)
     unsigned char *states = nullptr;  // hypothesis-state workspace (+ the slot -> state table behind it)
     size_t statesBytes = 0;
         unsigned char *wide = nullptr;    // work space of the general-size kernel (kbest_wide.hip)
@@ -357,7 +358,18 @@ int kbest_create(kbest_ctx **out, int device)
     if (hipSetDevice(device) != hipSuccess) return KBEST_ERR_NO_DEVICE;
     kbest_ctx *ctx = new kbest_ctx;
     ctx->device = device;
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+    // Stream priorities: the pieces of a large host-entry batch run on the context's stream and three auxiliary ones; with the
+    // first piece on the highest priority and the later ones below it the pieces FINISH one after the other instead of all at the
+    // end, and the host half of a piece (widening its tables) overlaps the later pieces' kernels (KBEST_PIECE_PRIO=0: all equal).
+    {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; (void)hipGetLastError(); }
+        const bool prio = !(getenv("KBEST_PIECE_PRIO") && atoi(getenv("KBEST_PIECE_PRIO")) == 0);
+        ctx->prioMain = prio ? greatest : 0;
+        ctx->prioAux[0] = prio ? (greatest + least) / 2 : 0;
+        ctx->prioAux[1] = ctx->prioAux[2] = prio ? least : 0;
+    }
+    if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, ctx->prioMain) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->lastEvent, hipEventDisableTiming) != hipSuccess) {
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
         delete ctx;
@@ -1183,7 +1195,7 @@ int kbest_batch_f64_keep(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxR
         const double *devC = zc ? mCost : dCostN.as<double>();
         const int nP = (B >= 4 * ctx->nCU) ? 4 : 1;
         for (int i = 0; i < 3 && nP > 1; i++)
-            if (!ctx->aux[i]) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking));
+            if (!ctx->aux[i]) HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->aux[i], hipStreamNonBlocking, ctx->prioAux[i]));
         kbest_opts o8 = *opts;
         o8.flags |= KBEST_FLAG_TABLES_I8;
         hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}, start = nullptr;
@@ -1311,7 +1323,7 @@ int kbest_batch_f64_keep(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxR
     const int nPiece = canPiece ? (ctx->pieces > 0 ? ctx->pieces : ((zcCost && direct) ? 1 : 4)) : 1;
     if (nPiece > 1)
         for (int i = 0; i < 3; i++)
-            if (!ctx->aux[i]) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking));
+            if (!ctx->aux[i]) HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->aux[i], hipStreamNonBlocking, ctx->prioAux[i]));
     if (nRow) {
         HIP_TRY(ctx, dNR.alloc(ctx, (size_t)B * 4));
         HIP_TRY(ctx, dNC.alloc(ctx, (size_t)B * 4));
