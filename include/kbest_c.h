@@ -219,7 +219,8 @@ int kbest_condition_costs_f64(kbest_ctx *ctx, int B, const int32_t *nRow, const 
  * the device.  Same argument layout as kbest_weights_batch_f64; cost blocks are the UNconditioned
  * (nL+nM) x nM matrices of computeQuadricCostMatrix (assignment.cpp:705-722); probs is [nM][nL+1] per problem.
  * One launch for frame-sized blocks: the fused association kernel (kbest_small.hip), or -- when every frame of the
- * call has so few assignments in all, (nL+nM)!/nL! <= 2^20 with 2 <= nM <= 8 and nL+nM <= 64: the reference's real
+ * call has so few assignments in all, (nL+nM)!/nL! <= 2^23 (and <= 2^15 choices for the first nM-2 columns) with
+ * 2 <= nM <= 8 and nL+nM <= 64: the reference's real
  * frames of 3-5 measurements (README.md:11) -- the exhaustive kernel (kbest_tiny.hip), which looks at every assignment
  * instead of enumerating the k best: same gains bit for bit (calcGain's sum), same solutions, same probabilities; only
  * when two DIFFERENT assignments with exactly equal gains sit on both sides of slot k can the emitted sets differ (the

@@ -1601,9 +1601,12 @@ static bool tiny_takes(const kbest_ctx *ctx, int B, const int32_t *nL, const int
         const int m = nM[b], l = nL[b];
         if (m == 0) continue;  // (an empty frame: answered by either kernel at its shape test)
         if (m < 2 || m > kb::TINY_MAX_COL || l < 0 || l + m > kb::TINY_MAX_ROW) return false;
-        long long cnt = 1;
-        for (int c = 0; c < m; c++) cnt *= (l + m - c);
-        if (cnt > kb::TINY_MAX_COUNT) return false;
+        long long cnt = 1, pre = 1;
+        for (int c = 0; c < m; c++) {
+            cnt *= (l + m - c);
+            if (c < m - 2) pre *= (l + m - c);
+        }
+        if (cnt > kb::TINY_MAX_COUNT || pre > kb::TINY_MAX_PREFIX) return false;
     }
     return true;
 }

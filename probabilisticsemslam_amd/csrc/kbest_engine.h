@@ -271,7 +271,8 @@ constexpr int SMALL_MAX_DIM = 32;
 constexpr int SMALL_MAX_K = 1024;
 constexpr int TINY_MAX_COL = 8;        // kbest_tiny.hip: measurements per frame,
 constexpr int TINY_MAX_ROW = 64;       //   rows of the raw block (landmarks + measurements),
-constexpr int TINY_MAX_COUNT = 1 << 20; //   assignments of the frame in all: (nL + nM)! / nL!,
+constexpr int TINY_MAX_COUNT = 1 << 23; //   assignments of the frame in all: (nL + nM)! / nL!,
+constexpr int TINY_MAX_PREFIX = 1 << 15; //  ... and prefixes of nM - 2 columns (each is decoded once by some thread),
 constexpr int TINY_CAP = 1024;         //   candidates kept for the final sort
 // feasible prefixes kept in LDS for the passes (1 024-thread workgroups: a lone frame on its CU; 256: batches, four per CU)
 __host__ __device__ constexpr int tiny_prefix_cap(int nThreads) { return nThreads >= 1024 ? 2048 : 512; }

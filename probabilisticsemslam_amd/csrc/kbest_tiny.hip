@@ -15,7 +15,8 @@
 //   * what kBest2DCutoff emits is the ascending run of the k smallest gains up to gainBest[0] + cutoff (cpp:705-719); what
 //     assignmentProb makes of it (assignment.cpp:616-648) does not depend on the order of equal gains (equal gains have equal
 //     weights, every probs[col][row] receives the same values in the same order);
-//   * a greedy assignment bounds what can be emitted at all (greedy + cutoff); the prefixes (rows of the first nM - 1 or
+//   * a greedy assignment bounds what can be emitted at all (greedy + cutoff; on large frames the k-th cheapest of its one- and
+//     two-column neighbours, which are assignments too, bounds the k-th best gain more tightly); the prefixes (rows of the first nM - 1 or
 //     nM - 2 columns) that stay below it and off the +inf entries are decoded ONCE into an LDS list;
 //   * pass 1: the threads share the list's work items (prefix x free row of the next column; loop over the last column),
 //     reduce the minimum and fill a 1 024-bucket histogram of the gains over [0, 42 nM] (conditioned entries lie in [0, 42]);
@@ -50,6 +51,7 @@ struct TCtrl {
     int total;                   // feasible assignments seen
     double limit;                // greedy assignment + cutoff: nothing beyond it is ever emitted
     int nFeas;                   // feasible prefixes found (kept: the first tiny_prefix_cap)
+    u64 greedyUsed;              // rows of the greedy assignment (0: there is none)
 };
 
 // the q-th prefix (rows of the columns 0 .. D-1, lexicographic in "which of the still free rows"): rows packed one byte per
@@ -197,7 +199,8 @@ __global__ void __launch_bounds__(NT) kbest_tiny_kernel(SmallParams p)
     double *Cs = reinterpret_cast<double *>(smem + o);       o += TINY_MAX_COL * TN_LDT * 8;
     double *stage = reinterpret_cast<double *>(smem + o);    o += TINY_MAX_COL * TINY_MAX_ROW * 8;
     double *colMin = reinterpret_cast<double *>(smem + o);   o += TINY_MAX_COL * 8;
-    TCtrl *ctl = reinterpret_cast<TCtrl *>(smem + o);        o += 40;
+    TCtrl *ctl = reinterpret_cast<TCtrl *>(smem + o);        o += 48;
+    unsigned char *gRow = smem + o;                          o += 8;   // the greedy assignment's rows
     u64 *keepW = reinterpret_cast<u64 *>(smem + o);          o += 8;
     unsigned short *rowIdx = reinterpret_cast<unsigned short *>(smem + o);  o += TINY_MAX_ROW * 2;
     u32 *hist = reinterpret_cast<u32 *>(smem + o);           o += TN_BUCKETS * 4;
@@ -331,12 +334,100 @@ __global__ void __launch_bounds__(NT) kbest_tiny_kernel(SmallParams p)
             const double m = wave_min_f64(x);
             const u64 at = __ballot(x == m && x < INF);
             if (!at) { gsum = INF; break; }
-            used |= 1ull << __builtin_ctzll(at);
+            const int rr = __builtin_ctzll(at);
+            used |= 1ull << rr;
             gsum = gsum + m;
+            if (lane == 0) gRow[c] = (unsigned char)rr;
         }
-        if (lane == 0) ctl->limit = (gsum < INF) ? gsum + p.cutoff : INF;
+        if (lane == 0) {
+            ctl->limit = (gsum < INF) ? gsum + p.cutoff : INF;
+            ctl->greedyUsed = (gsum < INF) ? used : 0ull;
+        }
     }
     __syncthreads();
+    // A tighter bound where the frame is large: the greedy assignment's NEIGHBOURS -- one column on another free row, or two
+    // columns on two other free rows -- are real assignments too; when at least k of them are feasible, the k-th smallest of
+    // their gains (exact sums, as for any assignment) is an upper bound of the k-th best gain of all.  On dense frames this
+    // is what keeps the passes from visiting every assignment below greedy + 42: the prefixes beyond it are dropped.
+    {
+        const u64 usedG = ctl->greedyUsed;
+        const int F = N - M;  // free rows beside the greedy assignment
+        const long long nSingle = (long long)M * F, nPair = (long long)(M * (M - 1) / 2) * F * (F - 1);
+        // (not on frames whose passes are short anyway: the bound costs a pass over the neighbours and three barriers)
+        const bool large = (unsigned long long)nPre2 * (unsigned)(N - (M - 2)) * (unsigned)(N - (M - 1)) > (1ull << 17);
+        const bool tighten = usedG != 0ull && large && nSingle + nPair >= k && nSingle + nPair <= (1 << 16);
+        if (tighten) {
+            const u64 freeG = ((N >= 64) ? ~0ull : ((1ull << N) - 1ull)) & ~usedG;
+            auto nth_free = [&](int f) {
+                u64 m = freeG;
+                for (int i = 0; i < f; i++) m &= m - 1ull;
+                return __builtin_ctzll(m);
+            };
+            int cnt = 0;
+            for (int t = tid; t < (int)(nSingle + nPair); t += NT) {
+                int c1, c2 = -1, r1, r2 = -1;
+                if (t < nSingle) {
+                    c1 = t / F;
+                    r1 = nth_free(t - c1 * F);
+                } else {
+                    int u = t - (int)nSingle;
+                    const int per = F * (F - 1);
+                    int pr = u / per;
+                    u -= pr * per;
+                    c1 = 0;
+                    while (pr >= M - 1 - c1) { pr -= M - 1 - c1; c1++; }  // pair number -> (c1 < c2)
+                    c2 = c1 + 1 + pr;
+                    const int f1 = u / (F - 1);
+                    int f2 = u - f1 * (F - 1);
+                    f2 += (f2 >= f1) ? 1 : 0;
+                    r1 = nth_free(f1);
+                    r2 = nth_free(f2);
+                }
+                double g = 0.0;
+                for (int c = 0; c < M; c++) {  // calcGain's order
+                    const int r = (c == c1) ? r1 : (c == c2) ? r2 : (int)gRow[c];
+                    g = g + Cs[r + c * TN_LDT];
+                }
+                if (g < INF) {
+                    int bk = (int)(g * scale);
+                    bk = bk > TN_BUCKETS - 1 ? TN_BUCKETS - 1 : bk;
+                    atomicAdd(&hist[bk], 1u);
+                    cnt++;
+                }
+            }
+            if (cnt) atomicAdd(&ctl->total, cnt);
+        }
+        __syncthreads();
+        if (tighten && ctl->total >= k && wave == 0) {  // the bucket of the k-th smallest neighbour: its upper edge bounds the k-th best
+            constexpr int PER = TN_BUCKETS / 64;
+            u32 mine = 0;
+            for (int i = 0; i < PER; i++) mine += hist[lane * PER + i];
+            u32 incl = mine;
+            for (int d = 1; d < 64; d <<= 1) {
+                const u32 t = (u32)__shfl_up((int)incl, d);
+                if (lane >= d) incl += t;
+            }
+            const u32 excl = incl - mine;
+            if ((int)excl < k && (int)incl >= k) {
+                u32 run = excl;
+                for (int i = 0; i < PER; i++) {
+                    run += hist[lane * PER + i];
+                    if ((int)run >= k) {
+                        const int b0 = lane * PER + i;
+                        const double edge = (double)(b0 + 1) / scale * (1.0 + 1e-12);
+                        if (b0 < TN_BUCKETS - 1 && edge < ctl->limit) ctl->limit = edge;
+                        break;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (tighten) {
+            for (int i = tid; i < TN_BUCKETS; i += NT) hist[i] = 0u;
+            if (tid == 0) ctl->total = 0;
+        }
+        __syncthreads();
+    }
     const double limit = ctl->limit;
     // ---- the feasible prefixes, once: decoded (divisions, free-row walks), checked against +inf and the bound, kept in a list;
     //      the passes below then share the list's work items evenly.  More of them than the list holds: the plain walk.
@@ -541,7 +632,7 @@ __global__ void __launch_bounds__(NT) kbest_tiny_kernel(SmallParams p)
 
 int tiny_lds_bytes(int k, int nThreads)
 {
-    int o = TINY_MAX_COL * TN_LDT * 8 + TINY_MAX_COL * TINY_MAX_ROW * 8 + TINY_MAX_COL * 8 + 40 + 8 + TINY_MAX_ROW * 2 +
+    int o = TINY_MAX_COL * TN_LDT * 8 + TINY_MAX_COL * TINY_MAX_ROW * 8 + TINY_MAX_COL * 8 + 56 + 8 + TINY_MAX_ROW * 2 +
             TN_BUCKETS * 4 + TINY_CAP * 16 + k * 12;
     o = (o + 7) & ~7;
     o += k * 8 + k * TINY_MAX_COL;

@@ -46,7 +46,7 @@ while time.time() - t0 < budget:
     nM = int(rng.integers(2, 9))
     while True:
         nL = int(rng.integers(0, 63 - nM))
-        if count(nL, nM) <= (1 << 20):
+        if count(nL, nM) <= (1 << 23) and count(nL + 2, nM - 2) * 1 <= (1 << 15) if nM > 2 else count(nL, nM) <= (1 << 23):
             break
     B = int(rng.choice([1, 1, 2, 7, 40, 700])) if count(nL, nM) < 70000 else int(rng.choice([1, 1, 3, 20]))
     k = int(rng.choice([1, 5, 50, 200, 200, 1024]))

@@ -18,7 +18,7 @@ tiny = pk.KBestEngine(0)
 os.environ["KBEST_NO_TINY"] = "1"
 plain = pk.KBestEngine(0)
 rng = np.random.default_rng(5)
-for nL, nM in ((6, 3), (6, 5), (12, 5), (20, 4), (10, 6), (40, 3), (6, 6)):
+for nL, nM in ((6, 3), (6, 5), (12, 5), (20, 4), (10, 6), (40, 3), (6, 6), (20, 5), (50, 4), (30, 4), (14, 6)):
     fr = wl.kitti_like_frames(32, nL=nL, nM=nM, seed=77 + nL)
     nR = nL + nM
     dense = []

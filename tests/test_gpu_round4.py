@@ -301,12 +301,12 @@ def _assoc_expected(frame, nL, nM, k):
     return want, nf
 
 
-TINY_SHAPES = [(6, 3), (6, 5), (4, 2), (9, 4), (0, 3), (12, 3), (3, 6), (0, 8), (5, 5), (40, 2), (62, 2), (1, 2)]
+TINY_SHAPES = [(6, 3), (6, 5), (4, 2), (9, 4), (0, 3), (12, 3), (3, 6), (0, 8), (5, 5), (40, 2), (62, 2), (1, 2), (20, 5), (30, 4), (12, 5)]
 
 
 @pytest.mark.parametrize("k", [200, 7])
 def test_frames_with_a_handful_of_measurements_by_exhaustive_enumeration(monkeypatch, k):
-    """kbest_tiny.hip: frames whose assignments are few in all ((nL + nM)! / nL! <= 65 536: the reference's real frame sizes,
+    """kbest_tiny.hip: frames whose assignments are few in all ((nL + nM)! / nL! <= 2^23: the reference's real frame sizes,
     README.md:11) are answered by looking at every assignment instead of enumerating the k best.  Same probabilities as the
     checker's getAssignmentProbs chain, and bit for bit those of the enumeration kernel on the same frames (same gains, same
     order of additions) -- frame by frame (one frame per call: the reference's call pattern), as one mixed batch, and as a batch
