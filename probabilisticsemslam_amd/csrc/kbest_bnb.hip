@@ -1,0 +1,611 @@
+// kbest_bnb.hip -- MI355X (gfx950): the fused association path (cost block in -> probabilities out) by a BOUNDED WALK.
+//
+// What getAssignmentProbs needs of kBest2DCutoff (assignment.cpp:57-74, 594; shortestPathCPP.cpp:646-733) is the k cheapest
+// assignments of the conditioned problem in ascending order.  Murty's enumeration finds them one shortest-path search at a
+// time -- on this device rounds of ~15 us, ten to thirty of them per frame.  But conditioned entries are >= 0
+// (conditionCosts subtracts the column minima, assignment.cpp:476-496): the partial sums of an assignment, added column by
+// column in calcGain's order (shortestPathCPP.cpp:59-80), only grow, so a depth-first walk over the columns that drops a
+// branch as soon as its partial sum exceeds a bound U visits EVERY assignment with gain <= U and little else.  With U
+// raised until k assignments lie below it, the k best are the k smallest of what the walk collected -- their gains are
+// the very sums calcGain computes (same additions, same order: same bits), and nothing about them depends on how they
+// were found.  On a 28 x 10 KITTI-like frame with k = 200 the bound search visits ~7 000 partial assignments in all its
+// passes (host model tests/dev/proto_bnb.py) where the enumeration needs ~400 shortest-path searches of 28 rows.
+//
+//   * the bound search: U starts at the gain of the greedy assignment (column by column its cheapest free row; a real
+//     assignment, so gainBest[0] <= it) and grows by 1.4 ... 2 x per pass until a pass counts >= k assignments below it (or U
+//     reaches greedy + cutoff: nothing beyond gainBest[0] + cutoff is ever emitted, cpp:705-719); every pass fills a
+//     1 024-bucket histogram over [0, U], so the last one also says in which bucket the k-th gain lies; one more walk
+//     bounded by that bucket's upper edge collects the candidates (a few more than k), a rank sort by (gain, rows) orders
+//     them, the first min(k, those within the cutoff) are the solutions; then the weights exactly as in kbest_small.hip;
+//   * one pass: breadth first while the frontier fits its LDS list -- every (partial assignment, free row) pair is one
+//     thread's work, perfectly balanced --; when a level's children do not fit, depth first from the last level that did,
+//     the threads drawing its entries from one counter;
+//   * a pass that visits more than a budget of partial assignments is abandoned and its bound halved towards the last
+//     one that was too small; a frame whose k-th bucket alone overflows the candidate list (hundreds of EQUAL gains at slot
+//     k) comes back with nf = -2 and is answered by the enumeration kernels.  The order of exactly equal gains is by rows
+//     here, by the enumeration tree there and by the heap in the reference: only when different
+//     assignments with equal gains straddle slot k can the emitted sets differ.
+// fp64 add / compare / exp only; no fast-math.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdint>
+
+#include "kbest_engine.h"
+#include "kbest_wave.h"
+
+namespace kb {
+
+namespace {
+
+constexpr double BN_GATE = 42.0;  // assignment.cpp:9
+constexpr int BN_LDT = BNB_MAX_ROW + 1;
+constexpr int BN_BUCKETS = 1024;
+
+struct BEntry {  // a partial assignment: rows of the columns 0 .. level-1 (one byte each), the set of those rows, their sum
+    u64 rowsLo, rowsHi, used;
+    double acc;
+};
+
+struct BCtrl {
+    unsigned long long minBits;  // smallest gain seen (non-negative doubles order like their bits)
+    int nA, nB;                  // entries of the two frontier lists
+    int count;                   // assignments below the bound in this pass
+    int listN;                   // candidates collected
+    int nWithin;                 // ... of which within the cutoff
+    int next;                    // depth-first phase: next frontier entry to take
+    int nodes;                   // partial assignments visited in this pass
+    int abort;                   // the pass ran over its budget
+    int bStar;                   // bucket of the k-th smallest gain
+    int negative;                // (unconditioned input) a negative entry: not this kernel's problem
+    double limit;                // greedy + cutoff
+    double maxFinite;            // largest finite entry
+};
+
+__device__ __forceinline__ int row_of(u64 lo, u64 hi, int c) { return (int)(((c < 8 ? lo : hi) >> (8 * (c & 7))) & 0xffull); }
+__device__ __forceinline__ void set_row(u64 &lo, u64 &hi, int c, int r)
+{
+    const u64 m = 0xffull << (8 * (c & 7)), v = (u64)r << (8 * (c & 7));
+    if (c < 8) lo = (lo & ~m) | v;
+    else hi = (hi & ~m) | v;
+}
+
+}  // namespace
+
+template <int NT>
+__global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NWV = NT / 64;
+    constexpr int FCAP = bnb_frontier_cap(NT);
+    const double INF = d_inf();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const int k = p.k;
+    const int M = p.imm ? p.immCol : p.nCol[b];
+    const int NR = p.imm ? p.immRow : p.nRow[b];
+    const int nLout = p.imm ? p.immL : p.nL[b];
+    const double *Cg = p.cost + (p.costOff ? p.costOff[b] : 0);
+    double *probOut = p.probs + (p.probOff ? p.probOff[b] : 0);
+    // LDS: tile | column minima | control | kept rows | row index | histogram | frontier lists A, B (the raw block first lies in A) |
+    //      candidates (gain, rows) | rank | solutions | weights | row table
+    int o = 0;
+    double *Cs = reinterpret_cast<double *>(smem + o);       o += BNB_MAX_COL * BN_LDT * 8;
+    double *colMin = reinterpret_cast<double *>(smem + o);   o += BNB_MAX_COL * 8;
+    BCtrl *ctl = reinterpret_cast<BCtrl *>(smem + o);        o += 80;
+    u64 *keepW = reinterpret_cast<u64 *>(smem + o);          o += 8;
+    unsigned short *rowIdx = reinterpret_cast<unsigned short *>(smem + o);  o += BNB_MAX_ROW * 2;
+    u32 *hist = reinterpret_cast<u32 *>(smem + o);           o += BN_BUCKETS * 4;
+    unsigned char *feasRow = smem + o;                       o += BNB_MAX_COL * BNB_MAX_ROW;  // per column: its rows with a finite entry
+    unsigned char *nFeasRow = smem + o;                      o += BNB_MAX_COL;
+    int *lvlN = reinterpret_cast<int *>(smem + o);           o += (BNB_MAX_COL + 1) * 4 + 12;  // frontier entries per level
+    unsigned char *ord = smem + o;                           o += BNB_MAX_COL;                 // the walk's column order
+    u64 *zMask = reinterpret_cast<u64 *>(smem + o);          o += BNB_MAX_COL * 8;
+    u64 *zBit = reinterpret_cast<u64 *>(smem + o);           o += BNB_MAX_COL * 8;
+    double *c0 = reinterpret_cast<double *>(smem + o);       o += BNB_MAX_COL * 8;
+    double *c1 = reinterpret_cast<double *>(smem + o);       o += BNB_MAX_COL * 8;
+    double *c0Sum = reinterpret_cast<double *>(smem + o);    o += BNB_MAX_COL * 8;
+    BEntry *listA = reinterpret_cast<BEntry *>(smem + o);    o += FCAP * 32;
+    BEntry *listB = reinterpret_cast<BEntry *>(smem + o);    o += FCAP * 32;
+    double *stage = reinterpret_cast<double *>(listA);       // (BNB_MAX_ROW x BNB_MAX_COL doubles = 8 KB <= the two lists)
+    // The candidates of the last walk lie in the frontier list that its last level does not read (the levels alternate between
+    // the two lists); the solutions, their weights and rows then take the other one, dead by then.
+    constexpr int CAP = bnb_cand_cap(NT);
+    unsigned char *lastB = reinterpret_cast<unsigned char *>(((M - 1) & 1) ? listA : listB);
+    unsigned char *lastA = reinterpret_cast<unsigned char *>(((M - 1) & 1) ? listB : listA);
+    double *candG = reinterpret_cast<double *>(lastB);
+    u64 *candLo = reinterpret_cast<u64 *>(lastB + CAP * 8);
+    u64 *candHi = reinterpret_cast<u64 *>(lastB + CAP * 16);
+    int *rankA = reinterpret_cast<int *>(lastB + CAP * 24);
+    double *solG = reinterpret_cast<double *>(lastA);
+    double *wts = reinterpret_cast<double *>(lastA + k * 8);
+    unsigned char *rTab = lastA + k * 16;                    // [k][16]
+
+    auto signal_done = [&]() {  // (as in kbest_small.hip: the host polls this counter on one-frame calls)
+        if (p.done) {
+            __syncthreads();
+            if (tid == 0) {
+                __threadfence_system();
+                __hip_atomic_fetch_add(p.done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    };
+    if (M == 0 || NR == 0) {  // an empty frame (assignment.cpp:50-51)
+        if (tid == 0) p.nf[b] = 0;
+        signal_done();
+        return;
+    }
+    if (M < 1 || M > BNB_MAX_COL || NR > BNB_MAX_ROW || NR < M || nLout + M != NR) {  // not what this kernel takes
+        if (tid == 0) p.nf[b] = -2;
+        signal_done();
+        return;
+    }
+    for (int i = tid; i < M * (nLout + 1); i += NT) probOut[i] = 0.0;
+    for (int i = tid; i < NR * M; i += NT) stage[i] = Cg[i];
+    for (int i = tid; i < BNB_MAX_COL * BN_LDT; i += NT) Cs[i] = INF;
+    if (tid == 0) {
+        ctl->minBits = 0x7ff0000000000000ull;
+        ctl->listN = 0;
+        ctl->nWithin = 0;
+        ctl->negative = 0;
+        ctl->limit = INF;
+        ctl->maxFinite = 0.0;
+    }
+    __syncthreads();
+    int N;
+    if (p.condition) {
+        // ---- conditionCosts (assignment.cpp:439-525), as in kbest_small.hip ----------------------------------------------
+        for (int c = wave; c < M; c += NWV) {  // column minima (:450-458)
+            double m = INF;
+            for (int r = lane; r < NR; r += 64) m = min_keep(m, stage[c * NR + r]);
+            m = wave_min_f64(m);
+            if (lane == 0) colMin[c] = m;
+        }
+        __syncthreads();
+        if (wave == 0) {  // a row is kept iff some entry is within 42 of its column's minimum (:462-474)
+            bool good = false;
+            if (lane < NR)
+                for (int c = 0; c < M; c++) good = good | (stage[c * NR + lane] <= colMin[c] + BN_GATE);
+            const u64 m = __ballot(good);
+            if (lane == 0) *keepW = m;
+        }
+        __syncthreads();
+        const u64 keep = *keepW;
+        N = __popcll(keep);
+        if (N < M) {  // undefined in the reference (size_t underflow at assignment.cpp:60); the enumeration kernels answer -2 as well
+            if (tid == 0) p.nf[b] = -2;
+            signal_done();
+            return;
+        }
+        if (tid < NR && ((keep >> tid) & 1ull)) {  // kept rows compacted in order; entries cost - colMin, +inf beyond the gate (:476-496)
+            const int nr = __popcll(keep & ((1ull << tid) - 1ull));
+            rowIdx[nr] = (unsigned short)tid;
+            for (int c = 0; c < M; c++) {
+                const double x = stage[c * NR + tid];
+                Cs[nr + c * BN_LDT] = (x <= colMin[c] + BN_GATE) ? (x - colMin[c]) : INF;
+            }
+        }
+    } else {
+        // assignmentProb on a block that is conditioned already (assignment.cpp:58-62).  kBest2DCutoff shifts the matrix by its
+        // smallest entry (makeCostMatrixSafe, cpp:534-569) and adds CDelta * numCol back to every gain (cpp:583, 626-630): with an
+        // exact 0.0 as the smallest entry -- every column of a conditioned block holds one -- the shift is the identity and the
+        // gains are calcGain's sums as they stand.  Any other block is not this kernel's: -2.
+        N = NR;
+        double mn = INF;
+        for (int i = tid; i < NR * M; i += NT) {
+            const double x = stage[i];
+            mn = min_keep(mn, x);
+            const int c = i / NR, r = i - c * NR;
+            Cs[r + c * BN_LDT] = (x == x) ? x : INF;
+        }
+        mn = wave_min_f64(mn);
+        if (lane == 0) {
+            if (mn < 0.0) atomicAdd(&ctl->negative, 1);
+            else atomicMin(&ctl->minBits, (unsigned long long)__double_as_longlong(mn));
+        }
+        if (tid < NR) rowIdx[tid] = (unsigned short)tid;
+        __syncthreads();
+        const bool notMine = ctl->minBits != 0ull || ctl->negative != 0;
+        __syncthreads();
+        if (notMine) {
+            if (tid == 0) p.nf[b] = -2;
+            signal_done();
+            return;
+        }
+        if (tid == 0) ctl->minBits = 0x7ff0000000000000ull;
+    }
+    __syncthreads();
+    const int nLc = N - M;  // condL (assignment.cpp:60)
+    // ---- single column: assignmentProb's fast path (assignment.cpp:554-570), as in kbest_small.hip -------------------------
+    if (M == 1) {
+        if (tid == 0) {
+            double norm = 0.0;
+            int cnt = 0;
+            for (int i = 0; i <= nLc; i++) {
+                const double c = Cs[i];
+                if (c < BN_GATE) { norm += exp(-c); cnt++; }
+            }
+            norm = 1.0 / norm;
+            for (int i = 0; i <= nLc; i++) {
+                const double c = Cs[i];
+                const double q = (c < BN_GATE) ? exp(-c) : 0.0;
+                probOut[(i >= nLc) ? nLout : (int)rowIdx[i]] = q * norm;
+            }
+            p.nf[b] = cnt < k ? cnt : k;
+        }
+        signal_done();
+        return;
+    }
+    // the largest finite entry (an upper bound of any gain: M times it), and the greedy assignment's gain
+    {
+        double mx = 0.0;
+        for (int i = tid; i < M * N; i += NT) {
+            const int c = i / N, r = i - c * N;
+            const double x = Cs[r + c * BN_LDT];
+            if (x < INF && x > mx) mx = x;
+        }
+        for (int d = 32; d; d >>= 1) {
+            const double t = __shfl_xor(mx, d);
+            mx = t > mx ? t : mx;
+        }
+        if (lane == 0 && mx > 0.0) atomicMax(reinterpret_cast<unsigned long long *>(&ctl->maxFinite), (unsigned long long)__double_as_longlong(mx));
+    }
+    double gsum = INF;
+    if (wave == 0) {
+        u64 used = 0ull;
+        double gs = 0.0;
+        for (int c = 0; c < M; c++) {
+            const double x = (lane < N && !((used >> lane) & 1ull)) ? Cs[lane + c * BN_LDT] : INF;
+            const double m = wave_min_f64(x);
+            const u64 at = __ballot(x == m && x < INF);
+            if (!at) { gs = INF; break; }
+            used |= 1ull << __builtin_ctzll(at);
+            gs = gs + m;
+        }
+        if (lane == 0) ctl->limit = gs;
+    }
+    __syncthreads();
+    gsum = ctl->limit;
+    const double gAll = ctl->maxFinite * (double)M * (1.0 + 1e-12) + 1e-300;  // no gain lies beyond this
+    // nothing beyond greedy + cutoff is ever emitted (cpp:705-719: gainBest[0] <= greedy)
+    const double Umax = (gsum < INF && gsum + p.cutoff < gAll) ? gsum + p.cutoff : gAll;
+
+    // the rows of each column that can be taken at all (finite entries), cheapest first: a frontier entry is only tried against
+    // those, in that order (the first one beyond the bound ends the column), and the cheapest row of a column that an entry has
+    // not used yet is a lower bound of what that column will add
+    for (int c = wave; c < M; c += NWV) {
+        const double mine = lane < N ? Cs[lane + c * BN_LDT] : INF;
+        const bool fin = mine < INF;
+        int rank = 0;
+        for (int j = 0; j < N; j++) {
+            const double other = Cs[j + c * BN_LDT];
+            rank += (other < INF && (other < mine || (other == mine && j < lane))) ? 1 : 0;
+        }
+        if (fin) feasRow[c * BNB_MAX_ROW + rank] = (unsigned char)lane;
+        const u64 m = __ballot(fin);
+        if (lane == 0) nFeasRow[c] = (unsigned char)__popcll(m);
+    }
+    __syncthreads();
+    // The walk takes the columns with the fewest feasible rows first (fewer partial assignments per level: 208 instead of 330 at
+    // most on the KITTI-like frames, host model); its partial sums -- in walk order -- only prune, with a margin far above their
+    // rounding; the gain of an assignment that reaches the last level is summed again in calcGain's order.
+    if (wave == 0) {
+        const int nfl = lane < M ? (int)nFeasRow[lane] : 1 << 20;
+        int rank = 0;
+        for (int j = 0; j < M; j++) {
+            const int nj = __builtin_amdgcn_readlane(nfl, j);
+            rank += (nj < nfl || (nj == nfl && j < lane)) ? 1 : 0;
+        }
+        if (lane < M) ord[rank] = (unsigned char)lane;
+        wave_fence();
+        // Lower bound of what the columns behind a level must still add: each its cheapest entry -- or, where an entry has
+        // used that row, its second cheapest (which bounds every other row of the column from below).  By walk level: zBit the
+        // cheapest row's bit, c0 / c1 the two costs; zMask[level] the cheapest rows of all columns behind `level` (an entry that
+        // has used none of them is bounded by the sum of the c0 alone, c0Sum[level])
+        if (lane < M) {
+            const int c = ord[lane], n = nFeasRow[c];
+            const unsigned char *f = feasRow + c * BNB_MAX_ROW;
+            zBit[lane] = n >= 1 ? 1ull << f[0] : 0ull;
+            c0[lane] = n >= 1 ? Cs[f[0] + c * BN_LDT] : INF;
+            c1[lane] = n >= 2 ? Cs[f[1] + c * BN_LDT] : INF;
+        }
+        wave_fence();
+        if (lane < M) {
+            u64 z = 0ull;
+            double s0 = 0.0;
+            for (int l2 = lane + 1; l2 < M; l2++) { z |= zBit[l2]; s0 = s0 + c0[l2]; }
+            zMask[lane] = z;
+            c0Sum[lane] = s0;
+        }
+    }
+    __syncthreads();
+
+    // ---- one walk: every assignment whose partial sums stay <= U reaches `leaf`; breadth first, level by level: every
+    //      (partial assignment, feasible row) pair is one thread's work.  A level whose children do not fit the list ends the
+    //      walk (the bound is too large for this kernel's lists: the search below steps back).
+    // mode 0: count + histogram over [0, U] + minimum; mode 1: collect (gain, rows) of those <= U
+    auto walk = [&](const double U, const int mode) {
+        const double scale = (double)BN_BUCKETS / (U > 0.0 ? U : 1.0);
+        const double Uprune = U * (1.0 + 1e-12);
+        double mn = INF;
+        int cnt = 0;
+        if (tid == 0) {
+            listA[0].rowsLo = 0ull; listA[0].rowsHi = 0ull; listA[0].used = 0ull; listA[0].acc = 0.0;
+            ctl->count = 0;
+            ctl->abort = 0;
+            ctl->nodes = 0;
+        }
+        if (tid <= M) lvlN[tid] = tid == 0 ? 1 : 0;
+        if (mode == 0)
+            for (int i = tid; i < BN_BUCKETS; i += NT) hist[i] = 0u;
+        __syncthreads();
+        BEntry *A = listA, *B = listB;
+        for (int level = 0; level < M; level++) {
+            const int nA = lvlN[level];
+            if (nA == 0) break;
+            if (nA > FCAP) {  // (seen by every thread alike: the counter was final at the barrier)
+                if (tid == 0) ctl->abort = 1;
+                break;
+            }
+            const bool last = level == M - 1;
+            const int col = ord[level];
+            const double *Ccol = Cs + col * BN_LDT;
+            const int nf_ = nFeasRow[col];
+            const unsigned char *fr = feasRow + col * BNB_MAX_ROW;
+            const u64 zHere = zMask[level];
+            const double c0Here = c0Sum[level];
+            // 2^sh threads share a frontier entry's feasible rows (as many as keep the workgroup busy; no division)
+            int sh = 0;
+            while (sh < 5 && (nA << (sh + 1)) <= NT && (1 << sh) < nf_) sh++;
+            for (int e = tid >> sh; e < nA; e += NT >> sh)
+            for (int j = tid & ((1 << sh) - 1); j < nf_; j += 1 << sh) {
+                const int r = fr[j];
+                const u64 used = A[e].used;
+                double a = A[e].acc + Ccol[r];
+                if (!(a <= Uprune)) break;  // (cheapest first: the rest of the column is beyond the bound too)
+                if ((used >> r) & 1ull) continue;
+                // what the columns still to come must add at least: each its cheapest row that is still free
+                const u64 used2 = used | (1ull << r);
+                if (used2 & zHere) {  // (some column behind has lost its cheapest row to this entry)
+                    double lb = a;
+                    for (int l2 = level + 1; l2 < M; l2++) lb = lb + ((used2 & zBit[l2]) ? c1[l2] : c0[l2]);
+                    if (!(lb <= Uprune)) continue;
+                } else if (!(a + c0Here <= Uprune))
+                    continue;
+                u64 lo = A[e].rowsLo, hi = A[e].rowsHi;
+                set_row(lo, hi, col, r);
+                if (last) {
+                    a = 0.0;  // calcGain (cpp:59-80): column by column from 0.0, left to right
+                    for (int c = 0; c < M; c++) a = a + Cs[row_of(lo, hi, c) + c * BN_LDT];
+                    if (!(a <= U)) continue;
+                    if (mode == 0) {
+                        mn = min_keep(mn, a);
+                        cnt++;
+                        int bk = (int)(a * scale);
+                        bk = bk > BN_BUCKETS - 1 ? BN_BUCKETS - 1 : bk;
+                        atomicAdd(&hist[bk], 1u);
+                    } else {
+                        const int pos = atomicAdd(&ctl->listN, 1);
+                        if (pos < CAP) { candG[pos] = a; candLo[pos] = lo; candHi[pos] = hi; }
+                    }
+                } else {
+                    const int pos = atomicAdd(&lvlN[level + 1], 1);
+                    if (pos < FCAP) { B[pos].rowsLo = lo; B[pos].rowsHi = hi; B[pos].used = used | (1ull << r); B[pos].acc = a; }
+                }
+            }
+            __syncthreads();
+            BEntry *T = A; A = B; B = T;
+        }
+        if (mode == 0) {
+            mn = wave_min_f64(mn);
+            if (lane == 0 && mn < INF) atomicMin(&ctl->minBits, (unsigned long long)__double_as_longlong(mn));
+            if (cnt) atomicAdd(&ctl->count, cnt);
+        }
+        __syncthreads();
+    };
+
+    // ---- the bound search: the smallest workable U with k assignments below it --------------------------------------------
+    double U = gsum < INF ? gsum : BN_GATE / 32.0;
+    if (U < BN_GATE / 32.0) U = BN_GATE / 32.0;
+    if (U > Umax) U = Umax;
+    double Ulo = 0.0, Uhi = INF;  // a pass at Ulo counted < k; a pass at Uhi did not fit the lists
+    int count = 0;
+    bool found = false;
+    // (diagnostics, kbest_set_profile_buffer: [0] passes, [1] passes that did not fit, [3] candidates, [5] cycles)
+    unsigned long long dPass = 0, dOver = 0;
+    const unsigned long long dT0 = __builtin_readcyclecounter();
+    for (int it = 0; it < 40; it++) {
+        walk(U, 0);
+        const bool over = ctl->abort != 0;
+        count = ctl->count;
+        dPass++;
+        dOver += over ? 1 : 0;
+        __syncthreads();
+        if (over) {
+            Uhi = U;
+            if (!(Uhi - Ulo > 1e-9 * Uhi)) break;
+            U = 0.5 * (Ulo + Uhi);
+            continue;
+        }
+        if (count >= k || U >= Umax) { found = true; break; }
+        Ulo = U;
+        // leaves grow like a power of the bound: aim at 2 k of them, by a factor between 1.1 and 2
+        double f = 2.0;
+        if (count > 0) {
+            f = sqrt(sqrt(2.0 * (double)k / (double)count));
+            f = f < 1.1 ? 1.1 : (f > 2.0 ? 2.0 : f);
+        }
+        double nxt = U * f;
+        if (Uhi < INF && nxt >= Uhi) nxt = 0.5 * (U + Uhi);
+        if (nxt > Umax) nxt = Umax;
+        if (!(nxt > U)) break;
+        U = nxt;
+    }
+    if (!found) {  // (no bound with k assignments below it fits the lists -- masses of equal or nearly equal gains: the enumeration kernels)
+        if (p.prof && tid == 0) {
+            unsigned long long *d = p.prof + (long long)b * 16;
+            d[0] = dPass; d[1] = dOver; d[6] = 1; d[7] = (unsigned long long)count;
+            d[8] = (unsigned long long)__double_as_longlong(Ulo); d[9] = (unsigned long long)__double_as_longlong(Uhi);
+        }
+        if (tid == 0) p.nf[b] = -2;
+        signal_done();
+        return;
+    }
+    if (count == 0) {  // infeasible: kBest2D returns 0 (cpp:588-593)
+        if (tid == 0) p.nf[b] = 0;
+        signal_done();
+        return;
+    }
+    const double best = __longlong_as_double((long long)ctl->minBits);  // gainBest[0] (CDelta = 0 on a conditioned matrix)
+    const double cutG = best + p.cutoff;                                  // cpp:681
+    // the first bucket at which the cumulated count reaches k: its upper edge bounds the k-th gain
+    if (tid == 0) ctl->bStar = BN_BUCKETS - 1;
+    __syncthreads();
+    if (wave == 0 && count >= k) {
+        constexpr int PER = BN_BUCKETS / 64;
+        u32 mine = 0;
+        for (int i = 0; i < PER; i++) mine += hist[lane * PER + i];
+        u32 incl = mine;
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 t = (u32)__shfl_up((int)incl, d);
+            if (lane >= d) incl += t;
+        }
+        const u32 excl = incl - mine;
+        if ((int)excl < k && (int)incl >= k) {
+            u32 run = excl;
+            for (int i = 0; i < PER; i++) {
+                run += hist[lane * PER + i];
+                if ((int)run >= k) { ctl->bStar = lane * PER + i; break; }
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int bStar = ctl->bStar;
+        double E = (bStar < BN_BUCKETS - 1) ? (double)(bStar + 1) * (U / (double)BN_BUCKETS) * (1.0 + 1e-12) : U;
+        if (E > U) E = U;
+        if (cutG < E) E = cutG;  // (what lies beyond the cutoff is never emitted: cpp:709-719)
+        walk(E, 1);
+    }
+    const int n = ctl->listN;
+    if (n > CAP || ctl->abort) {
+        if (tid == 0) p.nf[b] = -2;
+        signal_done();
+        return;
+    }
+    // ---- rank sort by (gain, rows); several threads share an element's comparisons ---------------------------------------
+    for (int i = tid; i < CAP; i += NT) rankA[i] = 0;
+    __syncthreads();
+    {
+        const int per = (n > 0 && NT / n > 0) ? NT / n : 1;
+        for (int e0 = 0; e0 < n; e0 += NT / per) {
+            const int e = e0 + tid / per, part = tid % per;
+            if (e < n && tid / per < NT / per) {
+                const double g = candG[e];
+                const u64 lo = candLo[e], hi = candHi[e];
+                int rk = 0;
+                for (int j = part; j < n; j += per) {
+                    const double g2 = candG[j];
+                    const bool before = g2 < g || (g2 == g && (candHi[j] < hi || (candHi[j] == hi && candLo[j] < lo)));
+                    rk += before ? 1 : 0;
+                }
+                if (rk) atomicAdd(&rankA[e], rk);
+            }
+        }
+    }
+    for (int e = tid; e < n; e += NT)  // cpp:709-719: solutions are counted while not beyond gainBest[0] + cutoff
+        if (!(candG[e] > cutG)) atomicAdd(&ctl->nWithin, 1);
+    __syncthreads();
+    int nf = ctl->nWithin;
+    nf = nf < k ? nf : k;
+    for (int e = tid; e < n; e += NT) {
+        const int rk = rankA[e];
+        if (rk < nf) {
+            solG[rk] = candG[e];
+            const u64 lo = candLo[e], hi = candHi[e];
+            for (int c = 0; c < M; c++) rTab[rk * 16 + c] = (unsigned char)row_of(lo, hi, c);
+        }
+    }
+    __syncthreads();
+    // ---- the weights (assignment.cpp:616-648), as in kbest_small.hip ------------------------------------------------------
+    for (int s = tid; s < nf; s += NT) {
+        const double g = solG[s];
+        wts[s] = (p.gate && !(best + BN_GATE > g)) ? -1.0 : exp(best - g);  // :622-626 (-1: skipped)
+    }
+    __syncthreads();
+    const int nAcc = M * (nLc + 1);
+    for (int i = tid; i < nAcc; i += NT) {
+        const int accC = i / (nLc + 1), accR = i - accC * (nLc + 1);
+        double total2 = 0.0, acc = 0.0;
+        const unsigned char *rp = rTab + accC;
+        // solutions ascending; total and every probs[col][row] summed sequentially (:633-638); four solutions' reads in flight
+        int s = 0;
+        for (; s + 4 <= nf; s += 4) {
+            double w[4];
+            int r[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                w[q] = wts[s + q];
+                r[q] = rp[(s + q) * 16];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const bool on = !(w[q] < 0.0);
+                const double t2 = total2 + w[q], a2 = acc + w[q];
+                total2 = on ? t2 : total2;
+                acc = (on && ((r[q] >= nLc) ? nLc : r[q]) == accR) ? a2 : acc;
+            }
+        }
+        for (; s < nf; s++) {
+            const double w = wts[s];
+            const int r = rp[s * 16];
+            const bool on = !(w < 0.0);
+            const double t2 = total2 + w, a2 = acc + w;
+            total2 = on ? t2 : total2;
+            acc = (on && ((r >= nLc) ? nLc : r) == accR) ? a2 : acc;
+        }
+        const double norm = 1.0 / total2;  // :643
+        // scatter back to the caller's landmark numbering (getAssignmentProbs, assignment.cpp:68-74)
+        const int ro = (accR >= nLc) ? nLout : (int)rowIdx[accR];
+        probOut[accC * (nLout + 1) + ro] = acc * norm;
+    }
+    if (tid == 0) p.nf[b] = nf;
+    if (p.prof && tid == 0) {
+        unsigned long long *d = p.prof + (long long)b * 16;
+        d[0] = dPass; d[1] = dOver; d[3] = (unsigned long long)n;
+        d[5] = __builtin_readcyclecounter() - dT0;
+    }
+    signal_done();
+}
+
+int bnb_lds_bytes(int k, int nThreads)
+{
+    int o = BNB_MAX_COL * BN_LDT * 8 + BNB_MAX_COL * 8 + 80 + 8 + BNB_MAX_ROW * 2 + BN_BUCKETS * 4 + BNB_MAX_COL * BNB_MAX_ROW + BNB_MAX_COL + (BNB_MAX_COL + 1) * 4 + 12 +
+            BNB_MAX_COL + BNB_MAX_COL * 40 + 2 * bnb_frontier_cap(nThreads) * 32;
+    return (o + 31) & ~15;
+}
+
+template <int NT>
+static hipError_t launch_bnb_nt(const SmallParams &p, int B, hipStream_t stream)
+{
+    const int lds = bnb_lds_bytes(p.k, NT);
+    static std::atomic<int> granted[16];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (lds > granted[dev & 15].load(std::memory_order_relaxed)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kbest_bnb_kernel<NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        granted[dev & 15].store(lds, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL((kbest_bnb_kernel<NT>), dim3(B), dim3(NT), lds, stream, p);
+    return hipGetLastError();
+}
+
+// many = the batch fills the chip: smaller workgroups
+hipError_t launch_kbest_bnb(const SmallParams &p, int B, bool many, hipStream_t stream)
+{
+    return many ? launch_bnb_nt<256>(p, B, stream) : launch_bnb_nt<1024>(p, B, stream);
+}
+
+}  // namespace kb

@@ -116,6 +116,7 @@ struct kbest_ctx {
     int ldsPerCU = 160 * 1024;
     int nCU = 256;
     int smallWaves = 0;  // waves per problem of the small-problem kernel; 0 = choose per launch (KBEST_SMALL_NW)
+    bool noBnb = false;  // KBEST_NO_BNB: no bounded-walk kernel (kbest_bnb.hip) on the association path (A/B, tests)
     bool noTiny = false; // KBEST_NO_TINY: frames with a handful of measurements through the enumeration kernels too (A/B, tests)
     bool noT0 = false;        // KBEST_NO_T0: no a-priori threshold in the 64-row kernel (A/B tests)
     int wideNw = 0;           // KBEST_WIDE_NW: waves per problem of the general-size kernel (8 / 16; A/B tests)
@@ -400,6 +401,7 @@ int kbest_create(kbest_ctx **out, int device)
     ctx->noSplit = getenv("KBEST_NO_SPLIT") != nullptr;
     if (const char *e = getenv("KBEST_SPLIT")) { const int w = atoi(e); if (w == 2 || w == 4) ctx->splitForce = w; }
     ctx->noTiny = getenv("KBEST_NO_TINY") != nullptr;
+    ctx->noBnb = getenv("KBEST_NO_BNB") != nullptr;
     if (const char *e = getenv("KBEST_ZC_COST")) ctx->zcCost = atoi(e);
     ctx->noReorder = getenv("KBEST_NO_REORDER") != nullptr;
     if (const char *e = getenv("KBEST_PIECES")) { const int w = atoi(e); if (w == 1 || w == 2 || w == 4) ctx->pieces = w; }
@@ -1611,6 +1613,21 @@ static bool tiny_takes(const kbest_ctx *ctx, int B, const int32_t *nL, const int
     return true;
 }
 
+// Frame-sized blocks of up to 16 measurements and 64 rows: the bounded walk (kbest_bnb.hip) finds the k best without
+// enumerating -- every assignment below a bound that is raised until k lie below it.  assignmentProb's mode only, whole batch.
+static bool bnb_takes(const kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM, int k, bool bruteForce)
+{
+    const int nThreads = B > ctx->nCU ? 256 : 1024;  // (launch_kbest_bnb: a batch that fills the chip takes the small workgroups)
+    if (ctx->noBnb || bruteForce || k > kb::SMALL_MAX_K || k > kb::bnb_max_k(nThreads)) return false;
+    if (kb::bnb_lds_bytes(k, nThreads) > ctx->ldsLimit) return false;
+    for (int b = 0; b < B; b++) {
+        const int m = nM[b], l = nL[b];
+        if (m == 0) continue;
+        if (m < 2 || m > kb::BNB_MAX_COL || l < 0 || l + m > kb::BNB_MAX_ROW) return false;
+    }
+    return true;
+}
+
 // The association path on the small-problem kernel (kbest_small.hip): conditionCosts -> kBest2DCutoff(42) -> weights
 // -> scatter back, ONE launch, only [nM][nL+1] doubles per frame come back.  Returns 1 when some frame does not fit
 // that kernel (more than 32 kept rows, ...): the caller then runs the general pipeline.
@@ -1618,7 +1635,7 @@ struct QuadricHost;
 static int weights_small(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM, const int32_t *nRow, const double *cost,
                          const double *d_cost, const int64_t *costOff, int k, double *probs, const int64_t *probOff,
                          int32_t *nf, bool condition, bool bruteForce, int rawMaxRow, int maxCol, size_t nCost, size_t nProb,
-                         std::vector<int> *unfit = nullptr)
+                         std::vector<int> *unfit = nullptr, bool allowFast = true)
 {
     const int capRow = rawMaxRow < kb::SMALL_MAX_DIM ? rawMaxRow : kb::SMALL_MAX_DIM;
     int nw = 0;
@@ -1709,14 +1726,17 @@ static int weights_small(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t
     // First the exhaustive kernel where the whole batch qualifies (tiny_takes); a frame it hands back (-2: thousands of equal
     // gains at slot k, or -- without conditioning -- a block that is not a conditioned one) sends the batch through the fused
     // enumeration kernel after all, whose own -2 (more rows kept than it takes) goes to the general pipeline.
-    bool useTiny = tiny_takes(ctx, B, nL, nM, k, condition, bruteForce);
+    // 1: the exhaustive kernel, 2: the bounded walk, 0: the fused enumeration kernel
+    int fast = !allowFast ? 0 : tiny_takes(ctx, B, nL, nM, k, condition, bruteForce) ? 1 : bnb_takes(ctx, B, nL, nM, k, bruteForce) ? 2 : 0;
     for (;;) {
         // (a few frames only: with hundreds of workgroups the counter's system-scope atomics cost more than the wake-up saves)
         if (zeroCopy && !ctx->noPoll && B <= 8) {
             *hdone = 0;
             sp.done = reinterpret_cast<int *>(dout + outBytes);
         }
-        hipError_t e = useTiny ? kb::launch_kbest_tiny(sp, B, B > 2 * ctx->nCU, ctx->stream) : kb::launch_kbest_small(sp, B, nw, ctx->stream);
+        hipError_t e = fast == 1   ? kb::launch_kbest_tiny(sp, B, B > 2 * ctx->nCU, ctx->stream)
+                       : fast == 2 ? kb::launch_kbest_bnb(sp, B, B > ctx->nCU, ctx->stream)
+                                   : kb::launch_kbest_small(sp, B, nw, ctx->stream);
         if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "association kernel launch", e);
         if (!zeroCopy) HIP_TRY(ctx, hipMemcpyAsync(hout, dout, outBytes, hipMemcpyDeviceToHost, ctx->stream));
         if (sp.done) {
@@ -1735,11 +1755,33 @@ static int weights_small(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t
         }
         anyUnfit = false;
         for (int b = 0; b < B; b++) anyUnfit = anyUnfit || hnf[b] == -2;
-        if (useTiny && anyUnfit) {
-            useTiny = false;
-            continue;
-        }
         break;
+    }
+    if (fast && anyUnfit) {
+        // the frames the fast kernel handed back -- and only those -- through the fused enumeration kernel
+        if (!mProbs) memcpy(probs, hout, nProb * 8);
+        if (nf) memcpy(nf, hnf, (size_t)B * 4);
+        std::vector<int> idx;
+        for (int b = 0; b < B; b++)
+            if (hnf[b] == -2) idx.push_back(b);
+        for (int b = 0; b < B; b++)
+            if (hnf[b] < 0 && hnf[b] != -2) return fail(ctx, KBEST_ERR_INTERNAL, "association kernel: a frame came back with nf < 0");
+        const int n = (int)idx.size();
+        std::vector<int32_t> sL(n), sM(n), sRow(n), sNf(n);
+        std::vector<int64_t> sCo(n), sPo(n);
+        for (int i = 0; i < n; i++) { sL[i] = nL[idx[i]]; sM[i] = nM[idx[i]]; sRow[i] = nRow[idx[i]]; sCo[i] = costOff[idx[i]]; sPo[i] = probOff[idx[i]]; }
+        std::vector<int> sub;
+        const int rc = weights_small(ctx, n, sL.data(), sM.data(), sRow.data(), cost, d_cost, sCo.data(), k, probs, sPo.data(), sNf.data(),
+                                     condition, bruteForce, rawMaxRow, maxCol, nCost, nProb, &sub, false);
+        if (rc != KBEST_OK && rc != 1) return rc;
+        if (nf)
+            for (int i = 0; i < n; i++) nf[idx[i]] = sNf[i];
+        if (rc == 1) {
+            if (!unfit) return 1;
+            for (int j : sub) unfit->push_back(idx[j]);
+            return 1;
+        }
+        return KBEST_OK;
     }
     if (anyUnfit && unfit)
         for (int b = 0; b < B; b++)
@@ -1800,7 +1842,12 @@ extern "C" int kbest_assoc_probs_batch_f64_dev(kbest_ctx *ctx, int B, int maxRaw
     sp.gate = 1;
     sp.probs = d_probs;
     sp.prof = ctx->prof;
-    hipError_t e = kb::launch_kbest_small(sp, B, nw, s);
+    // frame-sized blocks of up to 16 measurements and 64 rows: the bounded walk (kbest_bnb.hip; a frame it hands back has
+    // d_nf = -2 like one beyond the fused enumeration kernel: the host-pointer entry re-runs such frames by itself)
+    const int bnbThreads = B > ctx->nCU ? 256 : 1024;
+    const bool useBnb = !ctx->noBnb && maxRawRow <= kb::BNB_MAX_ROW && maxCol <= kb::BNB_MAX_COL && k <= kb::bnb_max_k(bnbThreads) &&
+                        kb::bnb_lds_bytes(k, bnbThreads) <= ctx->ldsLimit;
+    hipError_t e = useBnb ? kb::launch_kbest_bnb(sp, B, B > ctx->nCU, s) : kb::launch_kbest_small(sp, B, nw, s);
     if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "association kernel launch", e);
     return KBEST_OK;
 }

@@ -276,6 +276,13 @@ constexpr int TINY_MAX_PREFIX = 1 << 15; //  ... and prefixes of nM - 2 columns 
 constexpr int TINY_CAP = 1024;         //   candidates kept for the final sort
 // feasible prefixes kept in LDS for the passes (1 024-thread workgroups: a lone frame on its CU; 256: batches, four per CU)
 __host__ __device__ constexpr int tiny_prefix_cap(int nThreads) { return nThreads >= 1024 ? 2048 : 512; }
+constexpr int BNB_MAX_COL = 16;        // kbest_bnb.hip: measurements per frame (rows of an assignment packed one byte each in 16 bytes),
+constexpr int BNB_MAX_ROW = 64;        //   rows of the raw block,
+// entries of each of the two frontier lists (1 024-thread workgroups: a lone frame on its CU; 256: batches)
+__host__ __device__ constexpr int bnb_frontier_cap(int nThreads) { return nThreads >= 1024 ? 1536 : 512; }
+// candidates kept for the final sort (they lie in one frontier list: 28 bytes each), and the largest k that leaves them room
+__host__ __device__ constexpr int bnb_cand_cap(int nThreads) { return bnb_frontier_cap(nThreads) * 32 / 28 - 4; }
+__host__ __device__ constexpr int bnb_max_k(int nThreads) { return bnb_cand_cap(nThreads) - 64 < bnb_frontier_cap(nThreads) ? bnb_cand_cap(nThreads) - 64 : bnb_frontier_cap(nThreads); }
 constexpr int SMALL_MAX_RAW_ROWS = 2048;  // rows of the unconditioned block (assoc mode)
 
 struct SmallParams {
@@ -436,6 +443,10 @@ hipError_t launch_kbest_small(const SmallParams &p, int B, int nWaves, hipStream
 // kbest_tiny.hip: the fused association path by exhaustive enumeration, for frames whose assignments are few (condition + gate +
 // cutoff mode of SmallParams only); nf = -2: the frame is for the enumeration kernels after all
 hipError_t launch_kbest_tiny(const SmallParams &p, int B, bool many, hipStream_t stream);
+// kbest_bnb.hip: the fused association path by a bounded depth-first walk over the columns (every assignment whose partial sums
+// stay below a bound that is raised until k assignments lie below it); same modes and -2 convention as kbest_tiny.hip
+hipError_t launch_kbest_bnb(const SmallParams &p, int B, bool many, hipStream_t stream);
+int bnb_lds_bytes(int k, int nThreads = 1024);
 int tiny_lds_bytes(int k, int nThreads = 1024);
 hipError_t launch_kbest(const Params &p, int B, int nWaves, hipStream_t stream);
 hipError_t launch_kbest_wide(const WideParams &p, int grid, hipStream_t stream);

@@ -13,6 +13,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 tiny = pk.KBestEngine(0)
 os.environ["KBEST_NO_TINY"] = "1"
+os.environ["KBEST_NO_BNB"] = "1"
 plain = pk.KBestEngine(0)
 
 def count(nL, nM):
@@ -43,12 +44,15 @@ def frame(nL, nM, kind):
 t0 = time.time()
 cases = frames_n = ties = 0
 while time.time() - t0 < budget:
-    nM = int(rng.integers(2, 9))
+    big = os.environ.get("SOAK_BNB") and rng.random() < 0.7  # frames for the bounded walk (kbest_bnb.hip): up to 16 measurements, 64 rows
+    nM = int(rng.integers(2, 17 if big else 9))
     while True:
         nL = int(rng.integers(0, 63 - nM))
+        if big:
+            break
         if count(nL, nM) <= (1 << 23) and count(nL + 2, nM - 2) * 1 <= (1 << 15) if nM > 2 else count(nL, nM) <= (1 << 23):
             break
-    B = int(rng.choice([1, 1, 2, 7, 40, 700])) if count(nL, nM) < 70000 else int(rng.choice([1, 1, 3, 20]))
+    B = int(rng.choice([1, 1, 2, 7, 40, 700])) if count(nL, nM) < 70000 else int(rng.choice([1, 1, 3, 20, 300] if big else [1, 1, 3, 20]))
     k = int(rng.choice([1, 5, 50, 200, 200, 1024]))
     kind = int(rng.integers(0, 4))
     fr = [frame(nL, nM, kind) for _ in range(B)]
@@ -71,16 +75,20 @@ while time.time() - t0 < budget:
         cl = len(idx) - nM
         # An EXACT tie between the k-th and the (k+1)-th gain?  Then which of the two is emitted is the tie order's choice (the
         # reference's is its heap's; documented deviation): not a mismatch.
-        if len(bad) <= 3 and count(len(idx) - nM, nM) <= 200000 and nf[i] == nfr[i] == k:
-            Cc = cond.reshape(nM, len(idx))
-            gs = []
-            for rows in itertools.permutations(range(len(idx)), nM):
-                g = 0.0
-                for c in range(nM):
-                    g = g + Cc[c][rows[c]]
-                if np.isfinite(g):
-                    gs.append(g)
-            gs.sort()
+        if len(bad) <= 3 and nf[i] == nfr[i] == k:
+            if count(len(idx) - nM, nM) <= 200000:
+                Cc = cond.reshape(nM, len(idx))
+                gs = []
+                for rows in itertools.permutations(range(len(idx)), nM):
+                    g = 0.0
+                    for c in range(nM):
+                        g = g + Cc[c][rows[c]]
+                    if np.isfinite(g):
+                        gs.append(g)
+                gs.sort()
+            else:  # (too many to list: the checker's own k + 1 best)
+                onf, _, _, og = ol.orc_kbest(cond, len(idx), nM, k + 1, cutoff=42.0)
+                gs = list(og[:onf])
             if len(gs) > k and gs[k - 1] == gs[k]:
                 ties += 1
                 cases += 1
