@@ -409,7 +409,8 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
     if (U < BN_GATE / 32.0) U = BN_GATE / 32.0;
     if (U > Umax) U = Umax;
     double Ulo = 0.0, Uhi = INF;  // a pass at Ulo counted < k; a pass at Uhi did not fit the lists
-    int count = 0;
+    int count = 0, cPrev = 0;
+    double uPrev = 0.0;
     bool found = false;
     // (diagnostics, kbest_set_profile_buffer: [0] passes, [1] passes that did not fit, [3] candidates, [5] cycles)
     unsigned long long dPass = 0, dOver = 0;
@@ -428,13 +429,21 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
             continue;
         }
         if (count >= k || U >= Umax) { found = true; break; }
-        Ulo = U;
-        // leaves grow like a power of the bound: aim at 2 k of them, by a factor between 1.1 and 2
+        // the number of assignments below a bound grows like a power of it: the exponent from the last two passes that counted
+        // (4 without them), the next bound aimed at 1.5 k assignments, a factor between 1.05 and 2
         double f = 2.0;
         if (count > 0) {
-            f = sqrt(sqrt(2.0 * (double)k / (double)count));
-            f = f < 1.1 ? 1.1 : (f > 2.0 ? 2.0 : f);
+            double pw = 4.0;
+            if (cPrev > 0 && count > cPrev && U > uPrev) {
+                pw = log((double)count / (double)cPrev) / log(U / uPrev);
+                pw = pw < 2.0 ? 2.0 : (pw > 12.0 ? 12.0 : pw);
+            }
+            f = exp(log(1.5 * (double)k / (double)count) / pw);
+            f = f < 1.05 ? 1.05 : (f > 2.0 ? 2.0 : f);
+            cPrev = count;
+            uPrev = U;
         }
+        Ulo = U;
         double nxt = U * f;
         if (Uhi < INF && nxt >= Uhi) nxt = 0.5 * (U + Uhi);
         if (nxt > Umax) nxt = Umax;
