@@ -391,3 +391,80 @@ def test_exhaustive_enumeration_with_ties_and_with_too_many_of_them(monkeypatch)
     np.testing.assert_allclose(out[0].sum(axis=1), np.ones(4), rtol=0, atol=1e-12)
     assert (out[0] >= 0).all()
     eng.close()
+
+
+BNB_SHAPES = [(20, 10), (40, 12), (30, 16), (50, 8), (25, 6), (60, 4), (10, 9), (0, 10)]
+
+
+@pytest.mark.parametrize("k", [200, 7, 500])
+def test_frame_sized_blocks_by_the_bounded_walk(monkeypatch, k):
+    """kbest_bnb.hip: frame-sized association problems (up to 16 measurements, 64 rows) are answered by walking every assignment
+    whose partial sums stay below a bound that is raised until k assignments lie below it -- no enumeration.  Same counts and,
+    bit for bit, the same probabilities as the enumeration kernels on the same frames (same gains: calcGain's sums; same order
+    of additions in the weights), and the checker's getAssignmentProbs chain within 1e-12: one frame per call (the reference's
+    call pattern), one mixed batch, a batch that fills the chip (small workgroups), and assignmentProb alone on conditioned
+    blocks."""
+    from probabilisticsemslam_amd import workloads as wl
+    fast = pk.KBestEngine(0)
+    plain = engine_with(monkeypatch, KBEST_NO_TINY=1, KBEST_NO_BNB=1)
+    frames, nLs, nMs = [], [], []
+    for i, (nL, nM) in enumerate(BNB_SHAPES):
+        for f in wl.kitti_like_frames(3, nL=nL, nM=nM, seed=0xB0B + 31 * i) if nL > 0 else [None] * 2:
+            if f is None:
+                f = np.full(nM * nM, np.inf)
+                for c in range(nM):
+                    f[c * nM + c] = 10.0
+            frames.append(f)
+            nLs.append(nL)
+            nMs.append(nM)
+    for j, (f, nL, nM) in enumerate(zip(frames, nLs, nMs)):
+        out, nf = fast.weights([f], [nL], [nM], k, condition=True)
+        ref, nfr = plain.weights([f], [nL], [nM], k, condition=True)
+        assert nf[0] == nfr[0], (nL, nM, nf, nfr)
+        assert np.array_equal(out[0], ref[0]), (nL, nM)
+        if j % 3 == 0:
+            want, nfw = _assoc_expected(f, nL, nM, k)
+            assert nf[0] == nfw
+            np.testing.assert_allclose(out[0], want, rtol=0, atol=1e-12)
+    out, nf = fast.weights(frames, nLs, nMs, k, condition=True)
+    ref, nfr = plain.weights(frames, nLs, nMs, k, condition=True)
+    assert (nf == nfr).all() and all(np.array_equal(a, b) for a, b in zip(out, ref))
+    many = wl.kitti_like_frames(400, nL=20, nM=10, seed=0xFACE)
+    out, nf = fast.weights(many, [20] * 400, [10] * 400, k, condition=True)
+    ref, nfr = plain.weights(many, [20] * 400, [10] * 400, k, condition=True)
+    assert (nf == nfr).all() and all(np.array_equal(a, b) for a, b in zip(out, ref))
+    conds, cls, cms = [], [], []
+    for f, nL, nM in zip(frames, nLs, nMs):
+        if nL == 0:
+            continue
+        c, idx = ol.condition_costs(f, nL + nM, nM)
+        conds.append(c)
+        cls.append(len(idx) - nM)
+        cms.append(nM)
+    out, nf = fast.weights(conds, cls, cms, k)
+    ref, nfr = plain.weights(conds, cls, cms, k)
+    assert (nf == nfr).all() and all(np.array_equal(a, b) for a, b in zip(out, ref))
+    fast.close()
+    plain.close()
+
+
+def test_bounded_walk_hands_back_what_it_cannot_bound(monkeypatch):
+    """All costs equal: every one of the 20!/10! assignments has the same gain -- no bound separates k of them from the rest.  The
+    frame comes back through the enumeration kernels (nf = -2 inside) with valid probabilities; its neighbours in the batch are
+    answered by the walk."""
+    from probabilisticsemslam_amd import workloads as wl
+    eng = pk.KBestEngine(0)
+    fr = wl.kitti_like_frames(3, nL=10, nM=10, seed=5)
+    flat = np.full(20 * 10, np.inf)
+    for c in range(10):
+        flat[c * 20: c * 20 + 10] = 1.0
+        flat[c * 20 + 10 + c] = 1.0
+    batch = [fr[0], flat, fr[1], fr[2]]
+    out, nf = eng.weights(batch, [10] * 4, [10] * 4, 200, condition=True)
+    assert nf[1] == 200
+    np.testing.assert_allclose(out[1].sum(axis=1), np.ones(10), rtol=0, atol=1e-12)
+    for i, f in ((0, fr[0]), (2, fr[1]), (3, fr[2])):
+        want, nfw = _assoc_expected(f, 10, 10, 200)
+        assert nf[i] == nfw
+        np.testing.assert_allclose(out[i], want, rtol=0, atol=1e-12)
+    eng.close()
