@@ -218,7 +218,12 @@ int kbest_condition_costs_f64(kbest_ctx *ctx, int B, const int32_t *nRow, const 
  * original landmark numbering, i.e. getAssignmentProbs (assignment.cpp:57-74) from the cost matrix on, all on
  * the device.  Same argument layout as kbest_weights_batch_f64; cost blocks are the UNconditioned
  * (nL+nM) x nM matrices of computeQuadricCostMatrix (assignment.cpp:705-722); probs is [nM][nL+1] per problem.
- * One launch for frame-sized blocks: the fused association kernel (kbest_small.hip), or -- when every frame of the
+ * One launch for frame-sized blocks.  Frames of up to 16 measurements and 64 rows (all frames of the call) are not
+ * enumerated at all: conditioned costs are >= 0, so a walk over the columns that drops every partial assignment whose
+ * partial sum exceeds a bound visits exactly the assignments below the bound; the bound is raised until k assignments
+ * lie below it and the k cheapest of those are the answer (kbest_bnb.hip) -- gains bit for bit calcGain's sums, same
+ * solutions, same probabilities as the enumeration; KBEST_NO_BNB=1 at kbest_create switches it off.  Larger frames take
+ * the fused association kernel (kbest_small.hip), and -- when every frame of the
  * call has so few assignments in all, (nL+nM)!/nL! <= 2^23 (and <= 2^15 choices for the first nM-2 columns) with
  * 2 <= nM <= 8 and nL+nM <= 64: the reference's real
  * frames of 3-5 measurements (README.md:11) -- the exhaustive kernel (kbest_tiny.hip), which looks at every assignment
@@ -234,9 +239,10 @@ int kbest_assoc_probs_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const 
                                 const int64_t *probOff, int32_t *nf);
 
 /*
- * The same on device buffers, asynchronous on `stream` (NULL = the context's stream): ONE launch of the fused
- * association kernel (kbest_small.hip) -- conditionCosts while the cost tile is loaded, kBest2DCutoff(k, 42), the
- * exp-weights, the scatter back -- for callers whose cost blocks are produced on the GPU.
+ * The same on device buffers, asynchronous on `stream` (NULL = the context's stream): ONE launch -- of the bounded walk
+ * (kbest_bnb.hip) when maxRawRow <= 64 and maxCol <= 16, else of the fused association kernel (kbest_small.hip):
+ * conditionCosts while the cost tile is loaded, the k best within the cutoff 42, the exp-weights, the scatter back --
+ * for callers whose cost blocks are produced on the GPU.
  *   d_nRow[b] = d_nL[b] + d_nM[b] rows of the cost block of frame b; condition = 0: the blocks are already
  *   conditioned (assignmentProb only).  Limits of the fused kernel: nM <= 32, k <= 1024, at most 32 rows kept by
  *   conditionCosts (a frame beyond that comes back with d_nf[b] = -2 and zero probabilities: re-run it through the

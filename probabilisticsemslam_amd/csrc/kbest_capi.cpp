@@ -116,6 +116,7 @@ struct kbest_ctx {
     int ldsPerCU = 160 * 1024;
     int nCU = 256;
     int smallWaves = 0;  // waves per problem of the small-problem kernel; 0 = choose per launch (KBEST_SMALL_NW)
+    int bnbSmallFrom = -1; // KBEST_BNB_SMALL_FROM: batch size from which the bounded walk runs in 256-thread workgroups (-1 = nCU + 1)
     bool noBnb = false;  // KBEST_NO_BNB: no bounded-walk kernel (kbest_bnb.hip) on the association path (A/B, tests)
     bool noTiny = false; // KBEST_NO_TINY: frames with a handful of measurements through the enumeration kernels too (A/B, tests)
     bool noT0 = false;        // KBEST_NO_T0: no a-priori threshold in the 64-row kernel (A/B tests)
@@ -402,6 +403,7 @@ int kbest_create(kbest_ctx **out, int device)
     if (const char *e = getenv("KBEST_SPLIT")) { const int w = atoi(e); if (w == 2 || w == 4) ctx->splitForce = w; }
     ctx->noTiny = getenv("KBEST_NO_TINY") != nullptr;
     ctx->noBnb = getenv("KBEST_NO_BNB") != nullptr;
+    if (const char *e = getenv("KBEST_BNB_SMALL_FROM")) ctx->bnbSmallFrom = atoi(e);
     if (const char *e = getenv("KBEST_ZC_COST")) ctx->zcCost = atoi(e);
     ctx->noReorder = getenv("KBEST_NO_REORDER") != nullptr;
     if (const char *e = getenv("KBEST_PIECES")) { const int w = atoi(e); if (w == 1 || w == 2 || w == 4) ctx->pieces = w; }
@@ -1613,11 +1615,13 @@ static bool tiny_takes(const kbest_ctx *ctx, int B, const int32_t *nL, const int
     return true;
 }
 
+static bool bnb_many(const kbest_ctx *ctx, int B) { return B >= (ctx->bnbSmallFrom >= 0 ? ctx->bnbSmallFrom : ctx->nCU + 1); }
+
 // Frame-sized blocks of up to 16 measurements and 64 rows: the bounded walk (kbest_bnb.hip) finds the k best without
 // enumerating -- every assignment below a bound that is raised until k lie below it.  assignmentProb's mode only, whole batch.
 static bool bnb_takes(const kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM, int k, bool bruteForce)
 {
-    const int nThreads = B > ctx->nCU ? 256 : 1024;  // (launch_kbest_bnb: a batch that fills the chip takes the small workgroups)
+    const int nThreads = bnb_many(ctx, B) ? 256 : 1024;  // (launch_kbest_bnb: a batch that fills the chip takes the small workgroups)
     if (ctx->noBnb || bruteForce || k > kb::SMALL_MAX_K || k > kb::bnb_max_k(nThreads)) return false;
     if (kb::bnb_lds_bytes(k, nThreads) > ctx->ldsLimit) return false;
     for (int b = 0; b < B; b++) {
@@ -1735,7 +1739,7 @@ static int weights_small(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t
             sp.done = reinterpret_cast<int *>(dout + outBytes);
         }
         hipError_t e = fast == 1   ? kb::launch_kbest_tiny(sp, B, B > 2 * ctx->nCU, ctx->stream)
-                       : fast == 2 ? kb::launch_kbest_bnb(sp, B, B > ctx->nCU, ctx->stream)
+                       : fast == 2 ? kb::launch_kbest_bnb(sp, B, bnb_many(ctx, B), ctx->stream)
                                    : kb::launch_kbest_small(sp, B, nw, ctx->stream);
         if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "association kernel launch", e);
         if (!zeroCopy) HIP_TRY(ctx, hipMemcpyAsync(hout, dout, outBytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -1844,10 +1848,10 @@ extern "C" int kbest_assoc_probs_batch_f64_dev(kbest_ctx *ctx, int B, int maxRaw
     sp.prof = ctx->prof;
     // frame-sized blocks of up to 16 measurements and 64 rows: the bounded walk (kbest_bnb.hip; a frame it hands back has
     // d_nf = -2 like one beyond the fused enumeration kernel: the host-pointer entry re-runs such frames by itself)
-    const int bnbThreads = B > ctx->nCU ? 256 : 1024;
+    const int bnbThreads = bnb_many(ctx, B) ? 256 : 1024;
     const bool useBnb = !ctx->noBnb && maxRawRow <= kb::BNB_MAX_ROW && maxCol <= kb::BNB_MAX_COL && k <= kb::bnb_max_k(bnbThreads) &&
                         kb::bnb_lds_bytes(k, bnbThreads) <= ctx->ldsLimit;
-    hipError_t e = useBnb ? kb::launch_kbest_bnb(sp, B, B > ctx->nCU, s) : kb::launch_kbest_small(sp, B, nw, s);
+    hipError_t e = useBnb ? kb::launch_kbest_bnb(sp, B, bnb_many(ctx, B), s) : kb::launch_kbest_small(sp, B, nw, s);
     if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "association kernel launch", e);
     return KBEST_OK;
 }
