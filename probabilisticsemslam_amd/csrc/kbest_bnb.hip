@@ -39,8 +39,7 @@ namespace kb {
 namespace {
 
 constexpr double BN_GATE = 42.0;  // assignment.cpp:9
-constexpr int BN_LDT = BNB_MAX_ROW + 1;
-constexpr int BN_BUCKETS = 1024;
+constexpr int BN_BUCKETS = 512;
 
 struct BEntry {  // a partial assignment: rows of the columns 0 .. level-1 (one byte each), the set of those rows, their sum
     u64 rowsLo, rowsHi, used;
@@ -85,18 +84,23 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
     const int M = p.imm ? p.immCol : p.nCol[b];
     const int NR = p.imm ? p.immRow : p.nRow[b];
     const int nLout = p.imm ? p.immL : p.nL[b];
+    const unsigned long long dStart = __builtin_readcyclecounter();
     const double *Cg = p.cost + (p.costOff ? p.costOff[b] : 0);
     double *probOut = p.probs + (p.probOff ? p.probOff[b] : 0);
     // LDS: tile | column minima | control | kept rows | row index | histogram | frontier lists A, B (the raw block first lies in A) |
     //      candidates (gain, rows) | rank | solutions | weights | row table
+    // (tile, row lists: for the largest block of the LAUNCH -- what is not needed is room for one more workgroup on the CU)
+    const int tileCol = p.maxCol < BNB_MAX_COL ? p.maxCol : BNB_MAX_COL;
+    const int tileRow = (p.bnbRow > 0 && p.bnbRow < BNB_MAX_ROW) ? p.bnbRow : BNB_MAX_ROW;
+    const int BN_LDT = tileRow + 1;
     int o = 0;
-    double *Cs = reinterpret_cast<double *>(smem + o);       o += BNB_MAX_COL * BN_LDT * 8;
+    double *Cs = reinterpret_cast<double *>(smem + o);       o += tileCol * BN_LDT * 8;
     double *colMin = reinterpret_cast<double *>(smem + o);   o += BNB_MAX_COL * 8;
     BCtrl *ctl = reinterpret_cast<BCtrl *>(smem + o);        o += 80;
     u64 *keepW = reinterpret_cast<u64 *>(smem + o);          o += 8;
     unsigned short *rowIdx = reinterpret_cast<unsigned short *>(smem + o);  o += BNB_MAX_ROW * 2;
     u32 *hist = reinterpret_cast<u32 *>(smem + o);           o += BN_BUCKETS * 4;
-    unsigned char *feasRow = smem + o;                       o += BNB_MAX_COL * BNB_MAX_ROW;  // per column: its rows with a finite entry
+    unsigned char *feasRow = smem + o;                       o += (tileCol * tileRow + 7) & ~7;  // per column: its rows with a finite entry
     unsigned char *nFeasRow = smem + o;                      o += BNB_MAX_COL;
     int *lvlN = reinterpret_cast<int *>(smem + o);           o += (BNB_MAX_COL + 1) * 4 + 12;  // frontier entries per level
     unsigned char *ord = smem + o;                           o += BNB_MAX_COL;                 // the walk's column order
@@ -135,14 +139,14 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
         signal_done();
         return;
     }
-    if (M < 1 || M > BNB_MAX_COL || NR > BNB_MAX_ROW || NR < M || nLout + M != NR) {  // not what this kernel takes
+    if (M < 1 || M > tileCol || NR > tileRow || NR < M || nLout + M != NR) {  // not what this kernel takes
         if (tid == 0) p.nf[b] = -2;
         signal_done();
         return;
     }
     for (int i = tid; i < M * (nLout + 1); i += NT) probOut[i] = 0.0;
     for (int i = tid; i < NR * M; i += NT) stage[i] = Cg[i];
-    for (int i = tid; i < BNB_MAX_COL * BN_LDT; i += NT) Cs[i] = INF;
+    for (int i = tid; i < tileCol * BN_LDT; i += NT) Cs[i] = INF;
     if (tid == 0) {
         ctl->minBits = 0x7ff0000000000000ull;
         ctl->listN = 0;
@@ -281,7 +285,7 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
             const double other = Cs[j + c * BN_LDT];
             rank += (other < INF && (other < mine || (other == mine && j < lane))) ? 1 : 0;
         }
-        if (fin) feasRow[c * BNB_MAX_ROW + rank] = (unsigned char)lane;
+        if (fin) feasRow[c * tileRow + rank] = (unsigned char)lane;
         const u64 m = __ballot(fin);
         if (lane == 0) nFeasRow[c] = (unsigned char)__popcll(m);
     }
@@ -304,7 +308,7 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
         // has used none of them is bounded by the sum of the c0 alone, c0Sum[level])
         if (lane < M) {
             const int c = ord[lane], n = nFeasRow[c];
-            const unsigned char *f = feasRow + c * BNB_MAX_ROW;
+            const unsigned char *f = feasRow + c * tileRow;
             zBit[lane] = n >= 1 ? 1ull << f[0] : 0ull;
             c0[lane] = n >= 1 ? Cs[f[0] + c * BN_LDT] : INF;
             c1[lane] = n >= 2 ? Cs[f[1] + c * BN_LDT] : INF;
@@ -351,7 +355,7 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
             const int col = ord[level];
             const double *Ccol = Cs + col * BN_LDT;
             const int nf_ = nFeasRow[col];
-            const unsigned char *fr = feasRow + col * BNB_MAX_ROW;
+            const unsigned char *fr = feasRow + col * tileRow;
             const u64 zHere = zMask[level];
             const double c0Here = c0Sum[level];
             // 2^sh threads share a frontier entry's feasible rows (as many as keep the workgroup busy; no division)
@@ -415,6 +419,7 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
     // (diagnostics, kbest_set_profile_buffer: [0] passes, [1] passes that did not fit, [3] candidates, [5] cycles)
     unsigned long long dPass = 0, dOver = 0;
     const unsigned long long dT0 = __builtin_readcyclecounter();
+    unsigned long long dT1 = 0, dT2 = 0;
     for (int it = 0; it < 40; it++) {
         walk(U, 0);
         const bool over = ctl->abort != 0;
@@ -465,6 +470,7 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
         signal_done();
         return;
     }
+    dT1 = __builtin_readcyclecounter();
     const double best = __longlong_as_double((long long)ctl->minBits);  // gainBest[0] (CDelta = 0 on a conditioned matrix)
     const double cutG = best + p.cutoff;                                  // cpp:681
     // the first bucket at which the cumulated count reaches k: its upper edge bounds the k-th gain
@@ -496,6 +502,7 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
         if (cutG < E) E = cutG;  // (what lies beyond the cutoff is never emitted: cpp:709-719)
         walk(E, 1);
     }
+    dT2 = __builtin_readcyclecounter();
     const int n = ctl->listN;
     if (n > CAP || ctl->abort) {
         if (tid == 0) p.nf[b] = -2;
@@ -583,21 +590,25 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
         unsigned long long *d = p.prof + (long long)b * 16;
         d[0] = dPass; d[1] = dOver; d[3] = (unsigned long long)n;
         d[5] = __builtin_readcyclecounter() - dT0;
+        d[10] = dT0 - dStart; d[11] = dT1 - dT0; d[12] = dT2 - dT1; d[13] = __builtin_readcyclecounter() - dT2;
     }
     signal_done();
 }
 
-int bnb_lds_bytes(int k, int nThreads)
+int bnb_lds_bytes(int k, int nThreads, int maxRow, int maxCol)
 {
-    int o = BNB_MAX_COL * BN_LDT * 8 + BNB_MAX_COL * 8 + 80 + 8 + BNB_MAX_ROW * 2 + BN_BUCKETS * 4 + BNB_MAX_COL * BNB_MAX_ROW + BNB_MAX_COL + (BNB_MAX_COL + 1) * 4 + 12 +
-            BNB_MAX_COL + BNB_MAX_COL * 40 + 2 * bnb_frontier_cap(nThreads) * 32;
+    (void)k;
+    const int tileCol = maxCol < BNB_MAX_COL ? maxCol : BNB_MAX_COL;
+    const int tileRow = (maxRow > 0 && maxRow < BNB_MAX_ROW) ? maxRow : BNB_MAX_ROW;
+    int o = tileCol * (tileRow + 1) * 8 + BNB_MAX_COL * 8 + 80 + 8 + BNB_MAX_ROW * 2 + BN_BUCKETS * 4 + ((tileCol * tileRow + 7) & ~7) + BNB_MAX_COL +
+            (BNB_MAX_COL + 1) * 4 + 12 + BNB_MAX_COL + BNB_MAX_COL * 40 + 2 * bnb_frontier_cap(nThreads) * 32;
     return (o + 31) & ~15;
 }
 
 template <int NT>
 static hipError_t launch_bnb_nt(const SmallParams &p, int B, hipStream_t stream)
 {
-    const int lds = bnb_lds_bytes(p.k, NT);
+    const int lds = bnb_lds_bytes(p.k, NT, p.bnbRow, p.maxCol);
     static std::atomic<int> granted[16];
     int dev = 0;
     (void)hipGetDevice(&dev);

@@ -1700,6 +1700,7 @@ static int weights_small(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t
     sp.nL = reinterpret_cast<const int *>(din + 2 * B8 + 2 * B4);
     sp.maxRow = capRow;
     sp.maxCol = maxCol;
+    sp.bnbRow = rawMaxRow < kb::BNB_MAX_ROW ? rawMaxRow : kb::BNB_MAX_ROW;
     sp.ldRow = capRow;
     sp.ldCol = maxCol;
     sp.k = k;
@@ -1832,6 +1833,7 @@ extern "C" int kbest_assoc_probs_batch_f64_dev(kbest_ctx *ctx, int B, int maxRaw
     sp.nL = d_nL;
     sp.maxRow = capRow;
     sp.maxCol = maxCol;
+    sp.bnbRow = maxRawRow < kb::BNB_MAX_ROW ? maxRawRow : kb::BNB_MAX_ROW;
     sp.ldRow = capRow;
     sp.ldCol = maxCol;
     sp.k = k;

@@ -279,7 +279,10 @@ __host__ __device__ constexpr int tiny_prefix_cap(int nThreads) { return nThread
 constexpr int BNB_MAX_COL = 16;        // kbest_bnb.hip: measurements per frame (rows of an assignment packed one byte each in 16 bytes),
 constexpr int BNB_MAX_ROW = 64;        //   rows of the raw block,
 // entries of each of the two frontier lists (1 024-thread workgroups: a lone frame on its CU; 256: batches)
-__host__ __device__ constexpr int bnb_frontier_cap(int nThreads) { return nThreads >= 1024 ? 1536 : 512; }
+#ifndef KB_BNB_FCAP_SMALL
+#define KB_BNB_FCAP_SMALL 512
+#endif
+__host__ __device__ constexpr int bnb_frontier_cap(int nThreads) { return nThreads >= 1024 ? 1536 : KB_BNB_FCAP_SMALL; }
 // candidates kept for the final sort (they lie in one frontier list: 28 bytes each), and the largest k that leaves them room
 __host__ __device__ constexpr int bnb_cand_cap(int nThreads) { return bnb_frontier_cap(nThreads) * 32 / 28 - 4; }
 __host__ __device__ constexpr int bnb_max_k(int nThreads) { return bnb_cand_cap(nThreads) - 64 < bnb_frontier_cap(nThreads) ? bnb_cand_cap(nThreads) - 64 : bnb_frontier_cap(nThreads); }
@@ -313,6 +316,7 @@ struct SmallParams {
     int imm, immRow, immCol, immL;  // imm = 1 (B = 1): the shape of the one problem travels in the kernel arguments
     int tabI8;                // 1: row4col / col4row are int8 tables (KBEST_FLAG_TABLES_I8)
     int *done;                // host-mapped completion counter (zero-copy calls) or nullptr
+    int bnbRow;               // kbest_bnb.hip: rows of the largest raw block of the launch (<= 64; sizes its tile)
 };
 
 __host__ __device__ inline long long small_state_stride(int maxRow, int maxCol)
@@ -446,7 +450,7 @@ hipError_t launch_kbest_tiny(const SmallParams &p, int B, bool many, hipStream_t
 // kbest_bnb.hip: the fused association path by a bounded depth-first walk over the columns (every assignment whose partial sums
 // stay below a bound that is raised until k assignments lie below it); same modes and -2 convention as kbest_tiny.hip
 hipError_t launch_kbest_bnb(const SmallParams &p, int B, bool many, hipStream_t stream);
-int bnb_lds_bytes(int k, int nThreads = 1024);
+int bnb_lds_bytes(int k, int nThreads = 1024, int maxRow = 64, int maxCol = 16);
 int tiny_lds_bytes(int k, int nThreads = 1024);
 hipError_t launch_kbest(const Params &p, int B, int nWaves, hipStream_t stream);
 hipError_t launch_kbest_wide(const WideParams &p, int grid, hipStream_t stream);

@@ -14,6 +14,7 @@ for F in (1, 8, 300, 1000):
     p = prof.cpu().numpy()
     print(f"F={F}: passes mean {p[:,0].mean():.1f} max {p[:,0].max()}, passes that did not fit {p[:,1].sum()}, candidates mean {p[:,3].mean():.0f} max {p[:,3].max()}, cycles mean {p[:,5].mean():.0f} max {p[:,5].max()}, nf min {nf.min()}")
 
+    print("   cycles: set-up %.0f, counting passes %.0f, collecting walk %.0f, sort + weights %.0f" % tuple(p[:, 10:14].mean(axis=0)))
     bad = np.nonzero(p[:, 6] != 0)[0]
     for i in bad[:6]:
         print("   handed back: frame", int(i), "passes", int(p[i, 0]), "did not fit", int(p[i, 1]), "last count", int(p[i, 7]), "Ulo", p[i, 8:9].view(np.float64)[0], "Uhi", p[i, 9:10].view(np.float64)[0])
