@@ -240,7 +240,8 @@ int kbest_assoc_probs_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const 
 
 /*
  * The same on device buffers, asynchronous on `stream` (NULL = the context's stream): ONE launch -- of the bounded walk
- * (kbest_bnb.hip) when maxRawRow <= 64 and maxCol <= 16, else of the fused association kernel (kbest_small.hip):
+ * (kbest_bnb.hip) when maxRawRow <= 64 and maxCol <= 16 (followed by a launch of the enumeration kernel that looks only at
+ * what the walk handed back: frames with masses of equal gains), else of the fused association kernel (kbest_small.hip):
  * conditionCosts while the cost tile is loaded, the k best within the cutoff 42, the exp-weights, the scatter back --
  * for callers whose cost blocks are produced on the GPU.
  *   d_nRow[b] = d_nL[b] + d_nM[b] rows of the cost block of frame b; condition = 0: the blocks are already

@@ -1854,6 +1854,12 @@ extern "C" int kbest_assoc_probs_batch_f64_dev(kbest_ctx *ctx, int B, int maxRaw
     const bool useBnb = !ctx->noBnb && maxRawRow <= kb::BNB_MAX_ROW && maxCol <= kb::BNB_MAX_COL && k <= kb::bnb_max_k(bnbThreads) &&
                         kb::bnb_lds_bytes(k, bnbThreads) <= ctx->ldsLimit;
     hipError_t e = useBnb ? kb::launch_kbest_bnb(sp, B, bnb_many(ctx, B), s) : kb::launch_kbest_small(sp, B, nw, s);
+    if (useBnb && e == hipSuccess) {
+        // what the walk hands back (d_nf = -2: masses of equal gains) is answered by the fused enumeration kernel in a second
+        // launch that looks at nothing else: the entry stays total and asynchronous
+        sp.onlyUnfit = 1;
+        e = kb::launch_kbest_small(sp, B, nw, s);
+    }
     if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "association kernel launch", e);
     return KBEST_OK;
 }

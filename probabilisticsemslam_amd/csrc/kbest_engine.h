@@ -317,6 +317,7 @@ struct SmallParams {
     int tabI8;                // 1: row4col / col4row are int8 tables (KBEST_FLAG_TABLES_I8)
     int *done;                // host-mapped completion counter (zero-copy calls) or nullptr
     int bnbRow;               // kbest_bnb.hip: rows of the largest raw block of the launch (<= 64; sizes its tile)
+    int onlyUnfit;            // kbest_small.hip: 1 = answer only the problems whose nf is -2 (handed back by the launch before)
 };
 
 __host__ __device__ inline long long small_state_stride(int maxRow, int maxCol)

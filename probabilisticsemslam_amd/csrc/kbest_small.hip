@@ -559,6 +559,8 @@ kbest_small_kernel(SmallParams p)
             }
         }
     };
+    // (behind a launch of the bounded walk, kbest_bnb.hip: only what that kernel handed back)
+    if (p.onlyUnfit && p.nf[b] != -2) return;
     // ---- shapes ---------------------------------------------------------------------------------------------
     if (M == 0 || NR == 0) {  // an empty frame (getAssignmentProbs returns an empty result, assignment.cpp:50-51)
         if (tid == 0) p.nf[b] = 0;

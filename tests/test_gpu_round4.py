@@ -468,4 +468,21 @@ def test_bounded_walk_hands_back_what_it_cannot_bound(monkeypatch):
         want, nfw = _assoc_expected(f, 10, 10, 200)
         assert nf[i] == nfw
         np.testing.assert_allclose(out[i], want, rtol=0, atol=1e-12)
+    # the device-pointer entry stays total and asynchronous: a second launch answers the frame that was handed back
+    import torch
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    F, nL, nM, nR, k = 4, 10, 10, 20, 200
+    d_probs = torch.zeros(F * nM * (nL + 1), dtype=torch.float64, device=dev)
+    d_nf = torch.zeros(F, dtype=torch.int32, device=dev)
+    eng.reserve_assoc(F, nR, nM, k)
+    eng.assoc_probs_dev(F, nR, nM, t(np.full(F, nL, np.int32)), t(np.full(F, nM, np.int32)), t(np.full(F, nR, np.int32)), t(np.concatenate(batch)),
+                        t(np.arange(F, dtype=np.int64) * nR * nM), k, d_probs, t(np.arange(F, dtype=np.int64) * nM * (nL + 1)), d_nf,
+                        stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert (d_nf.cpu().numpy() == nf).all()
+    dp = d_probs.cpu().numpy().reshape(F, nM, nL + 1)
+    for i in (0, 2, 3):
+        assert np.array_equal(dp[i], out[i])
+    np.testing.assert_allclose(dp[1].sum(axis=1), np.ones(10), rtol=0, atol=1e-12)
     eng.close()
