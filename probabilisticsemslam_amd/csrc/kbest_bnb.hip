@@ -519,8 +519,22 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
             if (e < n && tid / per < NT / per) {
                 const double g = candG[e];
                 const u64 lo = candLo[e], hi = candHi[e];
-                int rk = 0;
-                for (int j = part; j < n; j += per) {
+                int rk = 0, j = part;
+                for (; j + 3 * per < n; j += 4 * per) {  // (four reads in flight; the rows only break exact ties)
+                    double g2[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) g2[q] = candG[j + q * per];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        bool before = g2[q] < g;
+                        if (g2[q] == g) {
+                            const int jj = j + q * per;
+                            before = candHi[jj] < hi || (candHi[jj] == hi && candLo[jj] < lo);
+                        }
+                        rk += before ? 1 : 0;
+                    }
+                }
+                for (; j < n; j += per) {
                     const double g2 = candG[j];
                     const bool before = g2 < g || (g2 == g && (candHi[j] < hi || (candHi[j] == hi && candLo[j] < lo)));
                     rk += before ? 1 : 0;
