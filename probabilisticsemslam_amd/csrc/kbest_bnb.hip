@@ -11,20 +11,27 @@
 // were found.  On a 28 x 10 KITTI-like frame with k = 200 the bound search visits ~7 000 partial assignments in all its
 // passes (host model tests/dev/proto_bnb.py) where the enumeration needs ~400 shortest-path searches of 28 rows.
 //
+//   * the bound: a partial assignment is dropped when its partial sum PLUS a lower bound of what the columns still to come
+//     must add exceeds U -- per column its cheapest entry, or its second cheapest where the partial assignment has used the
+//     cheapest one's row (the rows of a column are sorted by cost once).  With it a level holds about as many partial
+//     assignments as there are assignments below U; without it frames whose cheapest rows collide overflow any list just above
+//     their best gain;
+//   * one pass: breadth first, level by level, the columns with the fewest feasible rows first; the partial assignments of a
+//     level lie in one LDS list (rows packed a byte per column, the set of used rows, the partial sum), their children are
+//     written to the other; a (partial assignment, feasible row) pair is one thread's work; one barrier per level.  An
+//     assignment that reaches the last level has its gain summed again in calcGain's order, from 0.0, left to right;
 //   * the bound search: U starts at the gain of the greedy assignment (column by column its cheapest free row; a real
-//     assignment, so gainBest[0] <= it) and grows by 1.4 ... 2 x per pass until a pass counts >= k assignments below it (or U
-//     reaches greedy + cutoff: nothing beyond gainBest[0] + cutoff is ever emitted, cpp:705-719); every pass fills a
-//     1 024-bucket histogram over [0, U], so the last one also says in which bucket the k-th gain lies; one more walk
-//     bounded by that bucket's upper edge collects the candidates (a few more than k), a rank sort by (gain, rows) orders
-//     them, the first min(k, those within the cutoff) are the solutions; then the weights exactly as in kbest_small.hip;
-//   * one pass: breadth first while the frontier fits its LDS list -- every (partial assignment, free row) pair is one
-//     thread's work, perfectly balanced --; when a level's children do not fit, depth first from the last level that did,
-//     the threads drawing its entries from one counter;
-//   * a pass that visits more than a budget of partial assignments is abandoned and its bound halved towards the last
-//     one that was too small; a frame whose k-th bucket alone overflows the candidate list (hundreds of EQUAL gains at slot
-//     k) comes back with nf = -2 and is answered by the enumeration kernels.  The order of exactly equal gains is by rows
-//     here, by the enumeration tree there and by the heap in the reference: only when different
-//     assignments with equal gains straddle slot k can the emitted sets differ.
+//     assignment, so gainBest[0] <= it), every pass fills a 512-bucket histogram over [0, U]; a pass that counts fewer than
+//     k assignments raises U (by the growth exponent of the last two counts, aimed at 1.5 k), a pass whose level does not fit
+//     its list lowers it to the middle of what is known; nothing beyond greedy + cutoff is ever emitted (cpp:705-719), so U
+//     stops there.  The first pass with k assignments below its bound also gives the bucket of the k-th gain; one more walk
+//     bounded by that bucket's upper edge collects the candidates (k + ~4), a rank sort by (gain, rows) orders them, the
+//     first min(k, those within the cutoff) are the solutions; then the weights exactly as in kbest_small.hip;
+//   * a frame for which no bound has k assignments below it AND levels that fit (masses of equal or nearly equal gains)
+//     comes back with nf = -2 and is answered by the enumeration kernel -- re-run alone by the host entry, by a second launch
+//     that looks at nothing else behind the device entry.  The order of exactly equal gains is by rows here, by the
+//     enumeration tree there and by the heap in the reference: only when different assignments with
+//     equal gains straddle slot k can the emitted sets differ.
 // fp64 add / compare / exp only; no fast-math.
 #include <hip/hip_runtime.h>
 
