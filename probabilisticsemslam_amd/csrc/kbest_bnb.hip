@@ -4,7 +4,7 @@
 // assignments of the conditioned problem in ascending order.  Murty's enumeration finds them one shortest-path search at a
 // time -- on this device rounds of ~15 us, ten to thirty of them per frame.  But conditioned entries are >= 0
 // (conditionCosts subtracts the column minima, assignment.cpp:476-496): the partial sums of an assignment, added column by
-// column in calcGain's order (shortestPathCPP.cpp:59-80), only grow, so a depth-first walk over the columns that drops a
+// column in calcGain's order (shortestPathCPP.cpp:59-80), only grow, so a walk over the columns (level by level) that drops a
 // branch as soon as its partial sum exceeds a bound U visits EVERY assignment with gain <= U and little else.  With U
 // raised until k assignments lie below it, the k best are the k smallest of what the walk collected -- their gains are
 // the very sums calcGain computes (same additions, same order: same bits), and nothing about them depends on how they
