@@ -22,8 +22,12 @@
 //     assignment that reaches the last level has its gain summed again in calcGain's order, from 0.0, left to right;
 //   * the bound search: U starts at the gain of the greedy assignment (column by column its cheapest free row; a real
 //     assignment, so gainBest[0] <= it), every pass fills a 512-bucket histogram over [0, U]; a pass that counts fewer than
-//     k assignments raises U (by the growth exponent of the last two counts, aimed at 1.5 k), a pass whose level does not fit
-//     its list lowers it to the middle of what is known; nothing beyond greedy + cutoff is ever emitted (cpp:705-719), so U
+//     k assignments raises U (by the growth exponent of the last two counts, aimed at 1.5 k).  A pass whose level outgrows
+//     its list does not start over: it histograms the lower bounds of that level's children over (the last bound that fitted,
+//     U], lowers U to the largest bucket edge at which they fit, and goes on under that bound -- what it counts in the end is
+//     exact for the bound it returns (levels walked under the looser bound only carried entries that die now).  A lowered pass
+//     that still counts fewer than k narrows the window 512-fold per pass; when it stops moving no bound both fits and has k
+//     below it.  Nothing beyond greedy + cutoff is ever emitted (cpp:705-719), so U
 //     stops there.  The first pass with k assignments below its bound also gives the bucket of the k-th gain; one more walk
 //     bounded by that bucket's upper edge collects the candidates (k + ~4), a rank sort by (gain, rows) orders them, the
 //     first min(k, those within the cutoff) are the solutions; then the weights exactly as in kbest_small.hip;
@@ -47,6 +51,16 @@ namespace {
 
 constexpr double BN_GATE = 42.0;  // assignment.cpp:9
 constexpr int BN_BUCKETS = 512;
+#ifndef KB_BNB_FILL
+#define KB_BNB_FILL 16  // sixteenths of a list that a lowered bound may fill
+#endif
+#ifndef KB_BNB_AIM
+#define KB_BNB_AIM 1.5   // a bound that counted fewer than k is raised to where this many k are expected,
+#define KB_BNB_FMAX 2.0  // by this factor at most
+#endif
+#ifndef KB_BNB_START
+#define KB_BNB_START 1.0  // the first bound, in greedy gains
+#endif
 
 struct BEntry {  // a partial assignment: rows of the columns 0 .. level-1 (one byte each), the set of those rows, their sum
     u64 rowsLo, rowsHi, used;
@@ -335,9 +349,13 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
     //      (partial assignment, feasible row) pair is one thread's work.  A level whose children do not fit the list ends the
     //      walk (the bound is too large for this kernel's lists: the search below steps back).
     // mode 0: count + histogram over [0, U] + minimum; mode 1: collect (gain, rows) of those <= U
-    auto walk = [&](const double U, const int mode) {
-        const double scale = (double)BN_BUCKETS / (U > 0.0 ? U : 1.0);
-        const double Uprune = U * (1.0 + 1e-12);
+    // A counting pass (mode 0) whose frontier outgrows the lists at some level does not give up: it histograms the lower bounds
+    // of that level's children, lowers the bound to the largest that still fits a list and goes on from there -- what it
+    // counts in the end is exact for the bound it RETURNS.
+    auto walk = [&](double U, const int mode, const double base) -> double {  // (base: a bound known to fit the lists; < 0: no lowering)
+        double scale = (double)BN_BUCKETS / (U > 0.0 ? U : 1.0);
+        double Uprune = U * (1.0 + 1e-12);
+        int tight = 0;
         double mn = INF;
         int cnt = 0;
         if (tid == 0) {
@@ -354,10 +372,6 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
         for (int level = 0; level < M; level++) {
             const int nA = lvlN[level];
             if (nA == 0) break;
-            if (nA > FCAP) {  // (seen by every thread alike: the counter was final at the barrier)
-                if (tid == 0) ctl->abort = 1;
-                break;
-            }
             const bool last = level == M - 1;
             const int col = ord[level];
             const double *Ccol = Cs + col * BN_LDT;
@@ -368,6 +382,8 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
             // 2^sh threads share a frontier entry's feasible rows (as many as keep the workgroup busy; no division)
             int sh = 0;
             while (sh < 5 && (nA << (sh + 1)) <= NT && (1 << sh) < nf_) sh++;
+            bool histo = false, stop = false;  // (alike in every thread)
+            for (;;) {
             for (int e = tid >> sh; e < nA; e += NT >> sh)
             for (int j = tid & ((1 << sh) - 1); j < nf_; j += 1 << sh) {
                 const int r = fr[j];
@@ -377,12 +393,18 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
                 if ((used >> r) & 1ull) continue;
                 // what the columns still to come must add at least: each its cheapest row that is still free
                 const u64 used2 = used | (1ull << r);
+                double lb = a + c0Here;
                 if (used2 & zHere) {  // (some column behind has lost its cheapest row to this entry)
-                    double lb = a;
+                    lb = a;
                     for (int l2 = level + 1; l2 < M; l2++) lb = lb + ((used2 & zBit[l2]) ? c1[l2] : c0[l2]);
-                    if (!(lb <= Uprune)) continue;
-                } else if (!(a + c0Here <= Uprune))
+                }
+                if (!(lb <= Uprune)) continue;
+                if (histo) {  // (buckets over (base, U]: what is within base is known to fit)
+                    int bk = lb <= base ? 0 : (int)((lb - base) * ((double)BN_BUCKETS / (U - base)));
+                    bk = bk > BN_BUCKETS - 1 ? BN_BUCKETS - 1 : bk;
+                    atomicAdd(&hist[bk], 1u);
                     continue;
+                }
                 u64 lo = A[e].rowsLo, hi = A[e].rowsHi;
                 set_row(lo, hi, col, r);
                 if (last) {
@@ -405,6 +427,52 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
                 }
             }
             __syncthreads();
+            if (histo) {
+                // the last bucket up to which the children still fit a list: its upper edge is the new bound
+                if (wave == 0) {
+                    constexpr int PER = BN_BUCKETS / 64;
+                    u32 mine = 0;
+                    for (int i = 0; i < PER; i++) mine += hist[lane * PER + i];
+                    u32 incl = mine;
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const u32 t = (u32)__shfl_up((int)incl, d);
+                        if (lane >= d) incl += t;
+                    }
+                    u32 run = incl - mine;
+                    int fit = 0;  // buckets of this lane's share that still fit
+                    for (int i = 0; i < PER; i++) {
+                        run += hist[lane * PER + i];
+                        if (run <= (u32)(FCAP * KB_BNB_FILL / 16)) fit = i + 1;
+                    }
+                    const u64 full = __ballot(fit == PER);
+                    const int firstShort = full == ~0ull ? 64 : __ffsll((long long)~full) - 1;
+                    const int nb = firstShort * PER + __shfl(fit, firstShort < 64 ? firstShort : 63);
+                    if (lane == 0) ctl->limit = firstShort == 64 ? U : base + (double)nb * ((U - base) / (double)BN_BUCKETS);
+                }
+                __syncthreads();
+                const double nu = ctl->limit;
+                for (int i = tid; i < BN_BUCKETS; i += NT) hist[i] = 0u;
+                if (tid == 0) lvlN[level + 1] = 0;
+                __syncthreads();
+                if (!(nu > base) || !(nu < U)) { stop = true; break; }  // (one bucket alone overfills the list)
+                U = nu;
+                scale = (double)BN_BUCKETS / U;
+                Uprune = U * (1.0 + 1e-12);
+                tight++;
+                histo = false;
+                continue;  // (this level again, under the new bound)
+            }
+            if (!last && lvlN[level + 1] > FCAP) {
+                if (mode != 0 || base < 0.0 || tight >= 8) { stop = true; break; }
+                histo = true;  // (mode 0 before the last level: the histogram is all zero)
+                continue;
+            }
+            break;
+            }
+            if (stop) {
+                if (tid == 0) ctl->abort = 1;
+                break;
+            }
             BEntry *T = A; A = B; B = T;
         }
         if (mode == 0) {
@@ -413,10 +481,11 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
             if (cnt) atomicAdd(&ctl->count, cnt);
         }
         __syncthreads();
+        return U;
     };
 
     // ---- the bound search: the smallest workable U with k assignments below it --------------------------------------------
-    double U = gsum < INF ? gsum : BN_GATE / 32.0;
+    double U = gsum < INF ? gsum * KB_BNB_START : BN_GATE / 32.0;
     if (U < BN_GATE / 32.0) U = BN_GATE / 32.0;
     if (U > Umax) U = Umax;
     double Ulo = 0.0, Uhi = INF;  // a pass at Ulo counted < k; a pass at Uhi did not fit the lists
@@ -428,30 +497,34 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
     const unsigned long long dT0 = __builtin_readcyclecounter();
     unsigned long long dT1 = 0, dT2 = 0;
     for (int it = 0; it < 40; it++) {
-        walk(U, 0);
+        const double Uin = U;
+        U = walk(Uin, 0, Ulo);  // (may come back lowered: the count is exact for what comes back)
         const bool over = ctl->abort != 0;
+        const bool lowered = U < Uin;
         count = ctl->count;
         dPass++;
-        dOver += over ? 1 : 0;
+        dOver += (over || lowered) ? 1 : 0;
         __syncthreads();
         if (over) {
-            Uhi = U;
+            Uhi = Uin;
             if (!(Uhi - Ulo > 1e-9 * Uhi)) break;
             U = 0.5 * (Ulo + Uhi);
             continue;
         }
-        if (count >= k || U >= Umax) { found = true; break; }
+        if (lowered) Uhi = Uin < Uhi ? Uin : Uhi;
+        if (count >= k || (!lowered && U >= Umax)) { found = true; break; }
+        if (lowered && !(U - Ulo > 1e-7 * U)) break;  // (the largest bound that fits the lists has fewer than k below it)
         // the number of assignments below a bound grows like a power of it: the exponent from the last two passes that counted
         // (4 without them), the next bound aimed at 1.5 k assignments, a factor between 1.05 and 2
-        double f = 2.0;
+        double f = KB_BNB_FMAX;
         if (count > 0) {
             double pw = 4.0;
             if (cPrev > 0 && count > cPrev && U > uPrev) {
                 pw = log((double)count / (double)cPrev) / log(U / uPrev);
                 pw = pw < 2.0 ? 2.0 : (pw > 12.0 ? 12.0 : pw);
             }
-            f = exp(log(1.5 * (double)k / (double)count) / pw);
-            f = f < 1.05 ? 1.05 : (f > 2.0 ? 2.0 : f);
+            f = exp(log(KB_BNB_AIM * (double)k / (double)count) / pw);
+            f = f < 1.05 ? 1.05 : (f > KB_BNB_FMAX ? KB_BNB_FMAX : f);
             cPrev = count;
             uPrev = U;
         }
@@ -507,7 +580,7 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
         double E = (bStar < BN_BUCKETS - 1) ? (double)(bStar + 1) * (U / (double)BN_BUCKETS) * (1.0 + 1e-12) : U;
         if (E > U) E = U;
         if (cutG < E) E = cutG;  // (what lies beyond the cutoff is never emitted: cpp:709-719)
-        walk(E, 1);
+        walk(E, 1, -1.0);
     }
     dT2 = __builtin_readcyclecounter();
     const int n = ctl->listN;
