@@ -58,6 +58,13 @@ constexpr int BN_BUCKETS = 512;
 #define KB_BNB_AIM 1.5   // a bound that counted fewer than k is raised to where this many k are expected,
 #define KB_BNB_FMAX 2.0  // by this factor at most
 #endif
+#ifndef KB_BNB_FILLK
+#define KB_BNB_FILLK 1000.0  // ... and no more than this many k (no gain from limiting it: measured 2.5, 4)
+#endif
+#ifndef KB_BNB_LOWER
+#define KB_BNB_LOWER 2  // in-pass lowering of the bound: 0 never, 1 always, 2 in the 256-thread (batch) shape only -- a batch lasts as
+#endif                  // long as its slowest frame (lowering cuts the passes of those: C5 0.32 -> 0.23 ms), a frame by itself is
+                        // ~6 % slower with it (the lowered bound fills the 1 536-entry lists: more work than a bisection step)
 #ifndef KB_BNB_START
 #define KB_BNB_START 1.0  // the first bound, in greedy gains
 #endif
@@ -439,10 +446,11 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
                         if (lane >= d) incl += t;
                     }
                     u32 run = incl - mine;
+                    const u32 fillTo = (u32)(FCAP * KB_BNB_FILL / 16) < (u32)(KB_BNB_FILLK * k) ? (u32)(FCAP * KB_BNB_FILL / 16) : (u32)(KB_BNB_FILLK * k);
                     int fit = 0;  // buckets of this lane's share that still fit
                     for (int i = 0; i < PER; i++) {
                         run += hist[lane * PER + i];
-                        if (run <= (u32)(FCAP * KB_BNB_FILL / 16)) fit = i + 1;
+                        if (run <= fillTo) fit = i + 1;
                     }
                     const u64 full = __ballot(fit == PER);
                     const int firstShort = full == ~0ull ? 64 : __ffsll((long long)~full) - 1;
@@ -498,7 +506,7 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
     unsigned long long dT1 = 0, dT2 = 0;
     for (int it = 0; it < 40; it++) {
         const double Uin = U;
-        U = walk(Uin, 0, Ulo);  // (may come back lowered: the count is exact for what comes back)
+        U = walk(Uin, 0, (KB_BNB_LOWER == 1 || (KB_BNB_LOWER == 2 && NT == 256)) ? Ulo : -1.0);  // (may come back lowered: the count is exact for what comes back)
         const bool over = ctl->abort != 0;
         const bool lowered = U < Uin;
         count = ctl->count;
