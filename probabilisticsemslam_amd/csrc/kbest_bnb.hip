@@ -184,6 +184,7 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
         ctl->maxFinite = 0.0;
     }
     __syncthreads();
+    const unsigned long long dSA = __builtin_readcyclecounter();
     int N;
     if (p.condition) {
         // ---- conditionCosts (assignment.cpp:439-525), as in kbest_small.hip ----------------------------------------------
@@ -247,6 +248,7 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
         if (tid == 0) ctl->minBits = 0x7ff0000000000000ull;
     }
     __syncthreads();
+    const unsigned long long dSB = __builtin_readcyclecounter();
     const int nLc = N - M;  // condL (assignment.cpp:60)
     // ---- single column: assignmentProb's fast path (assignment.cpp:554-570), as in kbest_small.hip -------------------------
     if (M == 1) {
@@ -297,6 +299,7 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
         if (lane == 0) ctl->limit = gs;
     }
     __syncthreads();
+    const unsigned long long dSC = __builtin_readcyclecounter();
     gsum = ctl->limit;
     const double gAll = ctl->maxFinite * (double)M * (1.0 + 1e-12) + 1e-300;  // no gain lies beyond this
     // nothing beyond greedy + cutoff is ever emitted (cpp:705-719: gainBest[0] <= greedy)
@@ -318,6 +321,7 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
         if (lane == 0) nFeasRow[c] = (unsigned char)__popcll(m);
     }
     __syncthreads();
+    const unsigned long long dSD = __builtin_readcyclecounter();
     // The walk takes the columns with the fewest feasible rows first (fewer partial assignments per level: 208 instead of 330 at
     // most on the KITTI-like frames, host model); its partial sums -- in walk order -- only prune, with a margin far above their
     // rounding; the gain of an assignment that reaches the last level is summed again in calcGain's order.
@@ -607,25 +611,26 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
             if (e < n && tid / per < NT / per) {
                 const double g = candG[e];
                 const u64 lo = candLo[e], hi = candHi[e];
-                int rk = 0, j = part;
-                for (; j + 3 * per < n; j += 4 * per) {  // (four reads in flight; the rows only break exact ties)
-                    double g2[4];
+                // gains below mine, and gains equal to mine (myself among them, once, in one part): the rows break exact ties only
+                int rk = 0, eq = 0, j = part;
+                for (; j + 7 * per < n; j += 8 * per) {  // (eight reads in flight)
+                    double g2[8];
 #pragma unroll
-                    for (int q = 0; q < 4; q++) g2[q] = candG[j + q * per];
+                    for (int q = 0; q < 8; q++) g2[q] = candG[j + q * per];
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        bool before = g2[q] < g;
-                        if (g2[q] == g) {
-                            const int jj = j + q * per;
-                            before = candHi[jj] < hi || (candHi[jj] == hi && candLo[jj] < lo);
-                        }
-                        rk += before ? 1 : 0;
+                    for (int q = 0; q < 8; q++) {
+                        rk += g2[q] < g ? 1 : 0;
+                        eq += g2[q] == g ? 1 : 0;
                     }
                 }
                 for (; j < n; j += per) {
                     const double g2 = candG[j];
-                    const bool before = g2 < g || (g2 == g && (candHi[j] < hi || (candHi[j] == hi && candLo[j] < lo)));
-                    rk += before ? 1 : 0;
+                    rk += g2 < g ? 1 : 0;
+                    eq += g2 == g ? 1 : 0;
+                }
+                if (eq > ((e % per) == part ? 1 : 0)) {  // (some OTHER candidate has my gain, bit for bit: rare)
+                    for (j = part; j < n; j += per)
+                        if (candG[j] == g && (candHi[j] < hi || (candHi[j] == hi && candLo[j] < lo))) rk++;
                 }
                 if (rk) atomicAdd(&rankA[e], rk);
             }
@@ -634,6 +639,7 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
     for (int e = tid; e < n; e += NT)  // cpp:709-719: solutions are counted while not beyond gainBest[0] + cutoff
         if (!(candG[e] > cutG)) atomicAdd(&ctl->nWithin, 1);
     __syncthreads();
+    const unsigned long long dE1 = __builtin_readcyclecounter();
     int nf = ctl->nWithin;
     nf = nf < k ? nf : k;
     for (int e = tid; e < n; e += NT) {
@@ -641,58 +647,77 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
         if (rk < nf) {
             solG[rk] = candG[e];
             const u64 lo = candLo[e], hi = candHi[e];
-            for (int c = 0; c < M; c++) rTab[rk * 16 + c] = (unsigned char)row_of(lo, hi, c);
+            for (int c = 0; c < M; c++) {  // (every unassigned measurement's own row counts as "no landmark": row nLc, :634-637)
+                const int r = row_of(lo, hi, c);
+                rTab[rk * 16 + c] = (unsigned char)(r >= nLc ? nLc : r);
+            }
         }
     }
     __syncthreads();
+    const unsigned long long dE2 = __builtin_readcyclecounter();
     // ---- the weights (assignment.cpp:616-648), as in kbest_small.hip ------------------------------------------------------
     for (int s = tid; s < nf; s += NT) {
         const double g = solG[s];
-        wts[s] = (p.gate && !(best + BN_GATE > g)) ? -1.0 : exp(best - g);  // :622-626 (-1: skipped)
+        wts[s] = (p.gate && !(best + BN_GATE > g)) ? 0.0 : exp(best - g);  // :622-626 (0.0: skipped -- x + 0.0 is x, bit for bit, for the x >= +0.0 here)
     }
     __syncthreads();
+    const unsigned long long dE3 = __builtin_readcyclecounter();
+    // probs[col][row] = the weights of the solutions that give `row` to `col`, added in ascending order of the solutions, over the
+    // total of all weights added the same way (:633-643).  A wave per column, a lane per row: the wave goes through the solutions
+    // in order (weight and row: one address for all lanes), the lane whose row it is adds -- the additions of the reference's
+    // loop and no others; every wave adds up the total as well.  (As many columns to a wave as have room in its 64 lanes.)
     const int nAcc = M * (nLc + 1);
-    for (int i = tid; i < nAcc; i += NT) {
-        const int accC = i / (nLc + 1), accR = i - accC * (nLc + 1);
-        double total2 = 0.0, acc = 0.0;
-        const unsigned char *rp = rTab + accC;
-        // solutions ascending; total and every probs[col][row] summed sequentially (:633-638); four solutions' reads in flight
-        int s = 0;
-        for (; s + 4 <= nf; s += 4) {
-            double w[4];
-            int r[4];
+    double *accS = reinterpret_cast<double *>(lastB);  // [M][nLc + 1] (the candidates are dead)
+    const int nRowA = nLc + 1;
+    const int cpw = 64 / nRowA;  // columns per wave (>= 1: nLc + 1 <= 64 - M + 1)
+    const int myCl = lane / nRowA, myR = lane - myCl * nRowA;
+    for (int c0w = wave * cpw; c0w < M; c0w += NWV * cpw) {
+        const int myC = c0w + myCl;
+        const bool mineOn = myCl < cpw && myC < M;
+        double acc = 0.0, total2 = 0.0;
+        const unsigned char *rp = rTab + (mineOn ? myC : 0);
+        const int want = mineOn ? myR : -1;
+        int s2 = 0;
+        for (; s2 + 8 <= nf; s2 += 8) {
+            double w[8];
+            int r[8];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                w[q] = wts[s + q];
-                r[q] = rp[(s + q) * 16];
+            for (int q = 0; q < 8; q++) {
+                w[q] = wts[s2 + q];
+                r[q] = rp[(s2 + q) * 16];
             }
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const bool on = !(w[q] < 0.0);
-                const double t2 = total2 + w[q], a2 = acc + w[q];
-                total2 = on ? t2 : total2;
-                acc = (on && ((r[q] >= nLc) ? nLc : r[q]) == accR) ? a2 : acc;
+            for (int q = 0; q < 8; q++) {
+                const double a2 = acc + w[q];
+                total2 = total2 + w[q];
+                acc = (r[q] == want) ? a2 : acc;
             }
         }
-        for (; s < nf; s++) {
-            const double w = wts[s];
-            const int r = rp[s * 16];
-            const bool on = !(w < 0.0);
-            const double t2 = total2 + w, a2 = acc + w;
-            total2 = on ? t2 : total2;
-            acc = (on && ((r >= nLc) ? nLc : r) == accR) ? a2 : acc;
+        for (; s2 < nf; s2++) {
+            const double w = wts[s2];
+            const double a2 = acc + w;
+            total2 = total2 + w;
+            acc = ((int)rp[s2 * 16] == want) ? a2 : acc;
         }
-        const double norm = 1.0 / total2;  // :643
-        // scatter back to the caller's landmark numbering (getAssignmentProbs, assignment.cpp:68-74)
-        const int ro = (accR >= nLc) ? nLout : (int)rowIdx[accR];
-        probOut[accC * (nLout + 1) + ro] = acc * norm;
+        if (mineOn) accS[myC * nRowA + myR] = acc;
+        if (c0w == 0 && lane == 0) ctl->limit = total2;
+    }
+    __syncthreads();
+    {
+        const double norm = 1.0 / ctl->limit;  // :643
+        for (int i = tid; i < nAcc; i += NT) {
+            const int accC = i / (nLc + 1), accR = i - accC * (nLc + 1);
+            // scatter back to the caller's landmark numbering (getAssignmentProbs, assignment.cpp:68-74)
+            const int ro = (accR >= nLc) ? nLout : (int)rowIdx[accR];
+            probOut[accC * (nLout + 1) + ro] = accS[i] * norm;
+        }
     }
     if (tid == 0) p.nf[b] = nf;
     if (p.prof && tid == 0) {
         unsigned long long *d = p.prof + (long long)b * 16;
         d[0] = dPass; d[1] = dOver; d[3] = (unsigned long long)n;
         d[5] = __builtin_readcyclecounter() - dT0;
-        d[10] = dT0 - dStart; d[11] = dT1 - dT0; d[12] = dT2 - dT1; d[13] = __builtin_readcyclecounter() - dT2;
+        d[6] = dE1 - dT2; d[7] = dE2 - dE1; d[8] = dE3 - dE2; d[9] = __builtin_readcyclecounter() - dE3; d[10] = dT0 - dStart; d[2] = dSA - dStart; d[4] = dSB - dSA; d[14] = dSC - dSB; d[15] = dSD - dSC; d[11] = dT1 - dT0; d[12] = dT2 - dT1; d[13] = __builtin_readcyclecounter() - dT2;
     }
     signal_done();
 }
