@@ -1184,7 +1184,7 @@ kbest_small_kernel(SmallParams p)
         const double best = EG[0];
         for (int s = tid; s < nf; s += NT) {
             const double g = EG[s];
-            wts[s] = (p.gate && !(best + SM_GATE > g)) ? -1.0 : exp(best - g);  // :622-626 (-1: skipped)
+            wts[s] = (p.gate && !(best + SM_GATE > g)) ? 0.0 : exp(best - g);  // :622-626 (0.0: skipped -- x + 0.0 is x, bit for bit, for the x >= +0.0 here)
         }
         const int nAcc = M * (nLc + 1);
         const bool direct = nAcc <= NT;
@@ -1198,45 +1198,43 @@ kbest_small_kernel(SmallParams p)
             __syncthreads();
             for (int i = tid; i < ns * M; i += NT) {
                 const int s = i / M, c = i - s * M;
-                rTab[i] = stBase[(long long)ES[s0 + s] * p.stateStride + offR4C + c];
+                const int r = stBase[(long long)ES[s0 + s] * p.stateStride + offR4C + c];
+                rTab[i] = (unsigned char)(r >= nLc ? nLc : r);  // (every unassigned measurement's own row counts as "no landmark": :634-637)
             }
             __syncthreads();
             if (direct && wave * 64 < nAcc) {  // (only the waves that hold entries of the table walk)
                 const unsigned char *rp = rTab + accC;
                 const double *wp = wts + s0;
                 int s = 0;
-                for (; s + 4 <= ns; s += 4) {  // (four solutions' reads in flight; the additions stay in order)
-                    double w[4];
-                    int r[4];
+                for (; s + 8 <= ns; s += 8) {  // (eight solutions' reads in flight; the additions stay in order)
+                    double w[8];
+                    int r[8];
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
+                    for (int q = 0; q < 8; q++) {
                         w[q] = wp[s + q];
                         r[q] = rp[(s + q) * M];
                     }
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const bool on = !(w[q] < 0.0);
-                        const double t2 = total + w[q], a2 = acc + w[q];
-                        total = on ? t2 : total;
-                        acc = (on && ((r[q] >= nLc) ? nLc : r[q]) == accR) ? a2 : acc;  // :633-638
+                    for (int q = 0; q < 8; q++) {
+                        const double a2 = acc + w[q];
+                        total = total + w[q];
+                        acc = (r[q] == accR) ? a2 : acc;  // :633-638
                     }
                 }
                 for (; s < ns; s++) {
                     const double w = wp[s];
-                    const int r = rp[s * M];
-                    const bool on = !(w < 0.0);
-                    const double t2 = total + w, a2 = acc + w;
-                    total = on ? t2 : total;
-                    acc = (on && ((r >= nLc) ? nLc : r) == accR) ? a2 : acc;
+                    const double a2 = acc + w;
+                    total = total + w;
+                    acc = ((int)rp[s * M] == accR) ? a2 : acc;
                 }
             } else if (!direct && wave == 0) {
                 for (int s = 0; s < ns; s++) {
                     const double w = wts[s0 + s];
-                    if (w < 0.0) continue;
+                    if (w == 0.0) continue;  // (skipped, or underflowed to nothing)
                     total += w;
                     if (lane < M) {
                         const int r = rTab[s * M + lane];
-                        prob[lane * (nLc + 1) + ((r >= nLc) ? nLc : r)] += w;  // :633-638
+                        prob[lane * (nLc + 1) + r] += w;  // :633-638
                     }
                 }
             }

@@ -583,11 +583,21 @@ __global__ void __launch_bounds__(NT) kbest_tiny_kernel(SmallParams p)
         double acc;
         const int D = inner2 ? M - 2 : M - 1;
         tiny_prefix(Cs, N, D, inner2 ? id >> 12 : id >> 6, rows, used, acc);
-        for (int c = 0; c < D; c++) rTab[s * M + c] = (unsigned char)((rows >> (8 * c)) & 0xffull);
-        if (inner2) rTab[s * M + M - 2] = (unsigned char)((id >> 6) & 63u);
-        rTab[s * M + M - 1] = (unsigned char)(id & 63u);
+        // (every unassigned measurement's own row counts as "no landmark": row nLc, :634-637)
+        for (int c = 0; c < D; c++) {
+            const int r = (int)((rows >> (8 * c)) & 0xffull);
+            rTab[s * M + c] = (unsigned char)(r >= nLc ? nLc : r);
+        }
+        if (inner2) {
+            const int r = (int)((id >> 6) & 63u);
+            rTab[s * M + M - 2] = (unsigned char)(r >= nLc ? nLc : r);
+        }
+        {
+            const int r = (int)(id & 63u);
+            rTab[s * M + M - 1] = (unsigned char)(r >= nLc ? nLc : r);
+        }
         const double g = solG[s];
-        wts[s] = (p.gate && !(best + TN_GATE > g)) ? -1.0 : exp(best - g);  // :622-626 (-1: skipped)
+        wts[s] = (p.gate && !(best + TN_GATE > g)) ? 0.0 : exp(best - g);  // :622-626 (0.0: skipped -- x + 0.0 is x, bit for bit, for the x >= +0.0 here)
     }
     __syncthreads();
     const int nAcc = M * (nLc + 1);
@@ -595,31 +605,28 @@ __global__ void __launch_bounds__(NT) kbest_tiny_kernel(SmallParams p)
         const int accC = i / (nLc + 1), accR = i - accC * (nLc + 1);
         double total2 = 0.0, acc = 0.0;
         const unsigned char *rp = rTab + accC;
-        // solutions ascending; total and every probs[col][row] summed sequentially (:633-638); four solutions' reads in flight
+        // solutions ascending; total and every probs[col][row] summed sequentially (:633-638); eight solutions' reads in flight
         int s = 0;
-        for (; s + 4 <= nf; s += 4) {
-            double w[4];
-            int r[4];
+        for (; s + 8 <= nf; s += 8) {
+            double w[8];
+            int r[8];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < 8; q++) {
                 w[q] = wts[s + q];
                 r[q] = rp[(s + q) * M];
             }
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const bool on = !(w[q] < 0.0);
-                const double t2 = total2 + w[q], a2 = acc + w[q];
-                total2 = on ? t2 : total2;
-                acc = (on && ((r[q] >= nLc) ? nLc : r[q]) == accR) ? a2 : acc;
+            for (int q = 0; q < 8; q++) {
+                const double a2 = acc + w[q];
+                total2 = total2 + w[q];
+                acc = (r[q] == accR) ? a2 : acc;
             }
         }
         for (; s < nf; s++) {
             const double w = wts[s];
-            const int r = rp[s * M];
-            const bool on = !(w < 0.0);
-            const double t2 = total2 + w, a2 = acc + w;
-            total2 = on ? t2 : total2;
-            acc = (on && ((r >= nLc) ? nLc : r) == accR) ? a2 : acc;
+            const double a2 = acc + w;
+            total2 = total2 + w;
+            acc = ((int)rp[s * M] == accR) ? a2 : acc;
         }
         const double norm = 1.0 / total2;  // :643
         // scatter back to the caller's landmark numbering (getAssignmentProbs, assignment.cpp:68-74)
