@@ -3,6 +3,8 @@
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...        (WORLD_SIZE unset: launches the line above itself, as a child process, before
+                                         anything touches the GPU; rc 2 and one line if the node has fewer than N GPUs)
 
 One "step" = one pass of the hot path (one batched kernel launch) over one batch of synthetic inputs that already
 live in HBM.  Headline workload (config.workload): BASELINE.json configs[3] shape -- 1024 dense 64x64 cost matrices,
@@ -689,6 +691,41 @@ def run_c5(eng, torch, steps, warmup, dev, tstream, no_cpu, F=1000, k=200, nL=20
     return out
 
 
+def visible_gpus():
+    """Number of GPUs, learnt in a throw-away child so that the launcher itself never loads the HIP runtime."""
+    import subprocess
+    r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                       capture_output=True, text=True, timeout=600)
+    try:
+        return int(r.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        return 0
+
+
+def launcher_command(n_gpus, argv, port=None):
+    """The command `python bench.py --gpus N ...` turns itself into: one rank per GPU under torch.distributed.run."""
+    port = port or int(os.environ.get("MASTER_PORT", "29517"))
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n_gpus, argv, count=visible_gpus):
+    """Spawn the ranks as a child process group, forward their output, return their exit code.  Fails fast (rc 2, one
+    line on stderr, nothing spawned) when the node has fewer GPUs than asked for."""
+    import subprocess
+    have = count()
+    if have < n_gpus:
+        print(f"bench.py: --gpus {n_gpus} but this node shows {have} GPU(s): nothing launched", file=sys.stderr, flush=True)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this pool
+    p = subprocess.Popen(launcher_command(n_gpus, argv), env=env, stdout=subprocess.PIPE, stderr=None, text=True)
+    for ln in p.stdout:  # the ranks' stdout (rank 0's JSON line last) is this process' stdout
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+    return p.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -704,6 +741,12 @@ def main():
     ap.add_argument("--no-host", action="store_true", help="skip value_host_inclusive (under the profiler: only the timed launches)")
     ap.add_argument("--kernel-only", action="store_true", help="c5 under the profiler: only the timed launches of the fused kernel")
     args = ap.parse_args()
+
+    # (KBEST_BENCH_SELF_LAUNCH=1 takes the launcher path with one rank too: how it is exercised on a 1-GPU box)
+    if (args.gpus > 1 or os.environ.get("KBEST_BENCH_SELF_LAUNCH") == "1") and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: this process becomes the launcher.  Nothing here has touched HIP (no torch
+        # import yet), and the ranks are CHILD processes -- a process that has initialised the GPU is never re-exec'd.
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist

@@ -98,3 +98,21 @@ def test_subtree_mode_world2_merges_to_global_kbest():
             G, R, Nf, wg, wr = ret[rank]
             assert (Nf == G.shape[1]).all()
             assert (G.view(np.int64) == wg.view(np.int64)).all() and (R == wr).all()
+
+
+def test_bench_launcher_command_and_fail_fast(capsys):
+    """`python bench.py --gpus N` (no WORLD_SIZE) turns itself into the torch.distributed.run line the bench contract names,
+    as a child process; with too few GPUs it returns 2 without spawning anything."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cmd = bench.launcher_command(8, ["--gpus", "8", "--steps", "5", "--warmup", "1"], port=29600)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29600"
+    i = cmd.index(os.path.abspath(bench.__file__))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "5", "--warmup", "1"]
+    assert bench.self_launch(4, ["--gpus", "4"], count=lambda: 1) == 2
+    assert "nothing launched" in capsys.readouterr().err

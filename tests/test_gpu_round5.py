@@ -1,0 +1,78 @@
+"""GPU tests added in round 5: the HIP engine inside a real process group (world 2, gloo, both ranks on GPU 0),
+bench.py's self-launch failing fast on a node with too few GPUs."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import probabilisticsemslam_amd as pk
+from probabilisticsemslam_amd import workloads as wl
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.int64)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_engine_in_a_process_group_world2(engine, tmp_path):
+    """SURVEY 8(e) with the product on every rank: two child processes, one gloo group, each rank a KBestEngine on
+    GPU 0.  Batch mode (contiguous shards + ONE packed all-gather) and subtree mode (root_shard + k-way merge to the
+    global k-best heap) must give, on every rank, the single-rank engine's tables, which are the checker's."""
+    B, Bsub, world = 13, 3, 2  # 13: uneven shards
+    out = str(tmp_path / "dist")
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_engine_worker.py"), out, str(B), str(Bsub)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+
+    cases = {"batch": wl.dense_config("c2", B=B), "sub": wl.dense_config("c2", B=Bsub),
+             "sub64": (wl.dense_config("c4", B=2)[0], 64, 64, 60)}
+    for tag, (costs, N, M, k) in cases.items():
+        nf, r4c, c4r, g = engine.kbest(costs, N, M, k)            # the single-rank engine
+        onf, or4c, oc4r, og, _ = ol.orc_kbest_batch(costs, N, M, k)  # the checker
+        assert (nf == onf).all() and (r4c == or4c).all() and (bits(g) == bits(og)).all(), tag
+        for rank in range(world):
+            z = np.load(f"{out}.rank{rank}.npz")
+            assert (z[f"{tag}_nf"] == nf).all(), (tag, rank)
+            assert (z[f"{tag}_r"] == r4c).all(), (tag, rank)
+            assert (bits(z[f"{tag}_g"]) == bits(g)).all(), (tag, rank)
+
+
+def test_bench_self_launch_refuses_more_gpus_than_the_node_has():
+    """`python bench.py --gpus N` without WORLD_SIZE is the launcher: with fewer than N GPUs it says so in one line and
+    exits 2 at once -- no rank is spawned, nothing hangs."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 2
+    assert f"--gpus {n}" in r.stderr and "nothing launched" in r.stderr
+    assert r.stdout.strip() == ""
