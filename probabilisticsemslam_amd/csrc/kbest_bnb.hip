@@ -88,6 +88,7 @@ struct BCtrl {
     double limit;                // greedy + cutoff
     double maxFinite;            // largest finite entry
 };
+static_assert(sizeof(BCtrl) <= 80, "the LDS carve-up of kbest_bnb_kernel gives BCtrl 80 bytes");
 
 __device__ __forceinline__ int row_of(u64 lo, u64 hi, int c) { return (int)(((c < 8 ? lo : hi) >> (8 * (c & 7))) & 0xffull); }
 __device__ __forceinline__ void set_row(u64 &lo, u64 &hi, int c, int r)

@@ -138,11 +138,12 @@ hipError_t launch_fill_unused(const int *nf, const int *nRow, const int *nCol, i
 __global__ void __launch_bounds__(256) widen_i8_kernel(const signed char *src, int *dst, long long n)
 {
     const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i0 + 4 <= n) {
+    // (a piece of the batch starts at b0 * k * maxCol entries: with an odd product neither pointer need be vector-aligned)
+    if (i0 + 4 <= n && (reinterpret_cast<uintptr_t>(src + i0) & 3) == 0 && (reinterpret_cast<uintptr_t>(dst + i0) & 15) == 0) {
         const char4 v = *reinterpret_cast<const char4 *>(src + i0);
         *reinterpret_cast<int4 *>(dst + i0) = make_int4((int)v.x, (int)v.y, (int)v.z, (int)v.w);
     } else {
-        for (long long i = i0; i < n; i++) dst[i] = (int)src[i];
+        for (long long i = i0; i < n && i < i0 + 4; i++) dst[i] = (int)src[i];
     }
 }
 

@@ -53,6 +53,7 @@ struct TCtrl {
     int nFeas;                   // feasible prefixes found (kept: the first tiny_prefix_cap)
     u64 greedyUsed;              // rows of the greedy assignment (0: there is none)
 };
+static_assert(sizeof(TCtrl) <= 48, "the LDS carve-up of kbest_tiny_kernel gives TCtrl 48 bytes");
 
 // the q-th prefix (rows of the columns 0 .. D-1, lexicographic in "which of the still free rows"): rows packed one byte per
 // column, the set of used rows; false: the prefix runs through a +inf entry

@@ -76,3 +76,46 @@ def test_bench_self_launch_refuses_more_gpus_than_the_node_has():
     assert r.returncode == 2
     assert f"--gpus {n}" in r.stderr and "nothing launched" in r.stderr
     assert r.stdout.strip() == ""
+
+
+def test_reference_caller_object_runs_on_the_engine(tmp_path):
+    """Link-level drop-in with the reference's OWN caller code: oracle/_ref/ref_caller_on_engine holds the verbatim
+    slices of assignment.cpp (conditionCosts, assignmentProb :547-683, bruteForceProb :835-964) compiled against the
+    reference's own shortestPathCPP.hpp and linked to libkbest_amd.so in place of shortestPathCPP.cpp -- so the call
+    sites assignment.cpp:594 (kBest2DCutoff) and :880 (kBest2D) run unchanged on the GPU.  Its probabilities must be the
+    goldens recorded from the all-reference build (same host libm, bit-identical assignments and gains from the engine:
+    tolerance 1e-12 relative, far inside the north star's 1e-6)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_caller_on_engine")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_caller_on_engine not built (needs /root/reference at build time)")
+    syms = subprocess.check_output(["nm", "-D", "--undefined-only", exe], text=True)
+    assert "kBest2DCutoff" in syms and "_Z7kBest2Dmmmb" in syms  # the solver is NOT in the binary: it comes from the engine
+    z = np.load(os.path.join(HERE, "golden", "weights_golden.npz"))
+    names = [str(n) for n in z["names"]]
+    req = [np.array([len(names)], np.int32).tobytes()]
+    for n in names:
+        nL, nM, k, good, brute = (int(x) for x in z[n + "/meta"])
+        req.append(np.array([brute, nL, nM, k], np.int32).tobytes())
+        req.append(np.ascontiguousarray(z[n + "/raw"], np.float64).tobytes())
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    fin.write_bytes(b"".join(req))
+    subprocess.check_call([exe, str(fin), str(fout)], timeout=600)
+    buf = fout.read_bytes()
+    o = 0
+    for n in names:
+        nL, nM, k, good, brute = (int(x) for x in z[n + "/meta"])
+        g, w = np.frombuffer(buf, np.int32, 2, o)
+        o += 8
+        assert g == good, n
+        want = z[n + "/probs"]
+        p = np.frombuffer(buf, np.float64, nM * w, o).reshape(nM, w)
+        o += 8 * nM * w
+        assert p.shape == want.shape, n
+        np.testing.assert_allclose(p, want, rtol=1e-12, atol=1e-300, err_msg=n)
+        if brute:
+            w2 = int(np.frombuffer(buf, np.int32, 1, o)[0])
+            o += 4
+            q = np.frombuffer(buf, np.float64, nM * w2, o).reshape(nM, w2)
+            o += 8 * nM * w2
+            np.testing.assert_allclose(q, z[n + "/brute"], rtol=1e-12, atol=1e-300, err_msg=n)
+    assert o == len(buf)
