@@ -1792,7 +1792,12 @@ static int weights_small(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t
         for (int b = 0; b < B; b++)
             if (hnf[b] == -2) unfit->push_back(b);  // a frame that keeps more rows than the fused kernel takes: general pipeline
     if (anyUnfit && !unfit) return 1;
-    if (!mProbs) memcpy(probs, hout, nProb * 8);
+    if (!mProbs) {
+        if (allowFast) memcpy(probs, hout, nProb * 8);
+        else  // the re-run of the frames a fast kernel handed back: a sub-batch, whose frames' own ranges only are this launch's to write
+            for (int b = 0; b < B; b++)
+                memcpy(probs + probOff[b], reinterpret_cast<const double *>(hout) + probOff[b], (size_t)nM[b] * (nL[b] + 1) * 8);
+    }
     if (nf) memcpy(nf, hnf, (size_t)B * 4);
     for (int b = 0; b < B; b++)
         if (hnf[b] < 0 && hnf[b] != -2) return fail(ctx, KBEST_ERR_INTERNAL, "association kernel: a frame came back with nf < 0");

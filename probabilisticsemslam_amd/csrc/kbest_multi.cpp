@@ -200,7 +200,8 @@ void drain(kbest_multi *m)
         }
 }
 
-template <class T> int grow(kbest_multi *m, Dev &d, T *&p, size_t &have, size_t need)
+// (runs on the device's own worker thread: a failure is written to the DEVICE's message, never to the shared one)
+template <class T> int grow(kbest_multi *, Dev &d, T *&p, size_t &have, size_t need)
 {
     if (need <= have) return KBEST_OK;
     if (p) {  // an earlier (asynchronous) call may still use the old buffer
@@ -210,7 +211,10 @@ template <class T> int grow(kbest_multi *m, Dev &d, T *&p, size_t &have, size_t 
     p = nullptr;
     have = 0;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), need);
-    if (e != hipSuccess) return mfail(m, KBEST_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    if (e != hipSuccess) {
+        d.werr = std::string("hipMalloc: ") + hipGetErrorString(e);
+        return KBEST_ERR_NOMEM;
+    }
     have = need;
     return KBEST_OK;
 }
@@ -234,7 +238,8 @@ int gather_packed(kbest_multi *m, size_t perDev)
     for (auto &d : m->dev) d.t[4] = kb::now_s() - m->t0;
     if (m->local) {
         // logical devices on one GPU: every device's slice is copied into every other device's table, stream-ordered behind
-        // the producer's kernels (event) and in front of whatever the receiver does next (event back)
+        // the producer's kernels (event); what orders the copies in front of the NEXT call's writes is the end of this call --
+        // every device's stream is synchronised before the entry returns
         for (int g = 0; g < G; g++) {
             Dev &d = m->dev[g];
             if (hipSetDevice(d.id) != hipSuccess || hipEventRecord(d.ev, d.stream) != hipSuccess) { drain(m); return mfail(m, KBEST_ERR_HIP, "local gather: event"); }
@@ -376,7 +381,7 @@ int kbest_batch_f64_multi_ex(kbest_multi *m, const kbest_opts *opts, int mode, i
 #define W_TRY(d, expr)                                              \
     do {                                                            \
         const int rc_ = (expr);                                     \
-        if (rc_ != KBEST_OK) { wfail(d, rc_, m->err); return; }     \
+        if (rc_ != KBEST_OK) { d.rc = rc_; return; }  /* (grow() has left its message in d.werr) */ \
     } while (0)
 
     if (mode == KBEST_MULTI_BATCH) {
