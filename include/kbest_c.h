@@ -80,10 +80,20 @@ enum {
 #define KBEST_FLAG_EXACT_ROOT 16u  /* root LAP by the reference's own sequence of augmentations (no column reduction first)  */
 #define KBEST_FLAG_NO_REORDER 128u /* 64-row kernel: enumerate in the reference's column order (A/B tests; same results)          */
 #define KBEST_FLAG_NO_OPT 256u     /* 64-row kernel: no optimistic bounds / re-split tickets (A/B tests; same results)           */
+#define KBEST_FLAG_NO_TIE_CHECK 512u /* do not enumerate the (k+1)-th solution / order exact ties canonically (see "Order of exact ties") */
+#define KBEST_FLAG_NO_TIE_RESOLVE 1024u /* synchronous entries: report a tie at slot k (KBEST_TIE_BOUNDARY), do not complete its gain level */
 #define KBEST_FLAG_TABLES_I8 64u   /* kbest_batch_f64 / kbest_batch_f64_dev: row4col / col4row are tables of int8_t (same shapes, */
                                    /* same values, -1 = unassigned / unused) instead of int32_t: every index of a problem of up   */
                                    /* to 127 rows fits a byte, and a quarter of the bytes cross PCIe.  numRow > 127:              */
                                    /* KBEST_ERR_UNSUPPORTED.  Not with the multi-GPU entries (their merge reads int32 tables).     */
+
+/* per-problem tie flags (kbest_opts.tie_flags / kbest_set_tie_flags; see "Order of exact ties" above) */
+#define KBEST_TIE_INSIDE 1            /* some of the emitted gains are exactly equal (they are in the canonical order)        */
+#define KBEST_TIE_BOUNDARY 2          /* the k-th and the (k+1)-th best gains are exactly equal: the k best are not unique    */
+#define KBEST_TIE_RESOLVED 4          /* ... and the entry completed that gain level: the lexicographically first were kept   */
+#define KBEST_TIE_UNORDERED (1 << 29) /* a run of more than 1 024 equal gains was left in the kernel's own order               */
+#define KBEST_TIE_UNRESOLVED (1 << 30) /* BOUNDARY without RESOLVED: the emitted set is one of several equally good ones       */
+#define KBEST_TIE_CAP 64              /* members of the gain level at slot k beyond k that a synchronous entry enumerates      */
 
 typedef struct kbest_opts {
     int32_t  maximize;     /* reference `maximize` argument                       */
@@ -97,6 +107,8 @@ typedef struct kbest_opts {
                               /* child on column c keeps the root's rows on columns 0 .. c-1): a sharded run enumerates in    */
                               /* the reference's column order whatever kernel or launch shape runs it, so shards computed by  */
                               /* differently configured ranks still partition the problem.                                     */
+    int32_t *tie_flags;       /* [B] KBEST_TIE_* per problem, or NULL: a host pointer for the host-buffer entries, a device     */
+                              /* pointer for the _dev entries                                                                  */
 } kbest_opts;
 
 void kbest_default_opts(kbest_opts *o);

@@ -130,8 +130,10 @@ struct kbest_ctx {
     bool noSmall = false;  // KBEST_NO_SMALL: problems of <= 32 rows through the 64-row kernel as well (A/B tests)
     bool forceWide = false;   // KBEST_FORCE_WIDE: everything through the general-size kernel (test hook; read once at create)
     bool noSplit = false;     // KBEST_NO_SPLIT: never split one matrix over several workgroups (A/B tests)
+    bool noTie = false;       // KBEST_NO_TIE: no extra solution / canonical order of exact ties (A/B tests; kbest_ties.h)
     int splitForce = 0;       // KBEST_SPLIT: workgroups per matrix (2 / 4) whenever the split is possible (A/B tests)
     DevBufRaw splitBuf;       // per-share result tables + shared thresholds of the split
+    DevBufRaw tieBuf;         // [B] fp64: gain of the solution behind the tables (exact ties, kbest_ties.h)
     bool noReorder = false;   // KBEST_NO_REORDER: the 64-row kernel enumerates in the reference's column order (A/B tests)
     int zcCost = 1;           // KBEST_ZC_COST=0: cost blocks in registered memory are copied up first instead of read in place (A/B tests)
     int pieces = 0;           // KBEST_PIECES: pieces of a large host-entry batch (1 / 2 / 4; A/B tests); 0 = choose
@@ -319,6 +321,7 @@ void kbest_default_opts(kbest_opts *o)
     o->flags = 0;
     o->root_col_offset = 0;
     o->root_col_stride = 0;
+    o->tie_flags = nullptr;
 }
 
 const char *kbest_strerror(int code)
@@ -400,6 +403,7 @@ int kbest_create(kbest_ctx **out, int device)
     ctx->forceWide = getenv("KBEST_FORCE_WIDE") != nullptr;
     ctx->noLane = getenv("KBEST_NO_LANE") != nullptr;
     ctx->noSplit = getenv("KBEST_NO_SPLIT") != nullptr;
+    ctx->noTie = getenv("KBEST_NO_TIE") != nullptr;
     if (const char *e = getenv("KBEST_SPLIT")) { const int w = atoi(e); if (w == 2 || w == 4) ctx->splitForce = w; }
     ctx->noTiny = getenv("KBEST_NO_TINY") != nullptr;
     ctx->noBnb = getenv("KBEST_NO_BNB") != nullptr;
@@ -455,6 +459,7 @@ int kbest_destroy(kbest_ctx *ctx)
     if (ctx->stageIn.p) (void)hipFree(ctx->stageIn.p);
     if (ctx->stageOut.p) (void)hipFree(ctx->stageOut.p);
     if (ctx->splitBuf.p) (void)hipFree(ctx->splitBuf.p);
+    if (ctx->tieBuf.p) (void)hipFree(ctx->tieBuf.p);
     if (ctx->lastEvent) (void)hipEventDestroy(ctx->lastEvent);
     for (auto &a : ctx->aux)
         if (a) (void)hipStreamDestroy(a);
@@ -652,12 +657,23 @@ static int ensure_states(kbest_ctx *ctx, size_t need, bool grow)
     return KBEST_OK;
 }
 
+static int reserve_for(kbest_ctx *ctx, int B, int maxRow, int k);
+
 int kbest_reserve(kbest_ctx *ctx, int B, int maxRow, int k)
 {
     if (!ctx || B < 0 || maxRow < 1 || k < 1) return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_reserve: bad argument");
     if (maxRow > KBEST_MAX_DIM_WIDE) return fail(ctx, KBEST_ERR_UNSUPPORTED, "numRow > KBEST_MAX_DIM_WIDE");
     if (B == 0) return KBEST_OK;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    // a launch enumerates k + 1 solutions unless told not to (exact ties, kbest_ties.h): room for either
+    int rc = reserve_for(ctx, B, maxRow, k);
+    if (rc != KBEST_OK || ctx->noTie) return rc;
+    rc = reserve_for(ctx, B, maxRow, k + 1);
+    return rc != KBEST_OK ? rc : raw_reserve(ctx, ctx->tieBuf, (size_t)B * 8);
+}
+
+static int reserve_for(kbest_ctx *ctx, int B, int maxRow, int k)
+{
     const int fastRow = maxRow < KBEST_MAX_DIM ? maxRow : KBEST_MAX_DIM;
     const bool kFits = k_fits_fast(ctx, B, fastRow, k, 0, nullptr) || k_fits_fast(ctx, B, fastRow, k, KBEST_FLAG_COUNT_PUSHED, nullptr);
     // "launches of up to B problems" (kbest_c.h): a smaller batch may pick another kernel or launch shape than B itself --
@@ -761,6 +777,12 @@ static int split_factor(const kbest_ctx *ctx, const kbest_opts *opts, int B, int
 
 // grow: the host-pointer entries (which synchronise anyway) let the workspace grow on demand; the asynchronous
 // device-pointer entry never allocates or synchronises -- it needs kbest_reserve up front.
+static bool tie_mode(const kbest_ctx *ctx, const kbest_opts *opts, bool rootOnly)
+{
+    return !ctx->noTie && !rootOnly && opts->root_col_stride <= 1 &&
+           !(opts->flags & (KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_PRUNE | KBEST_FLAG_RECT_ROOT | KBEST_FLAG_NO_SHIFT | KBEST_FLAG_NO_TIE_CHECK));
+}
+
 static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, int maxCol,
                           const int32_t *d_nRow, const int32_t *d_nCol, const double *d_cost,
                           const int64_t *d_costOff, int k, int32_t *d_row4col, int32_t *d_col4row,
@@ -785,6 +807,13 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
     const int fastCol = maxCol < fastRow ? maxCol : fastRow;
     const int LB = sub ? sub->logicalB : B;          // the batch that decides kernel, shape and workspace
     const size_t base = sub ? (size_t)sub->blockBase : 0;  // first problem of this piece in that batch
+    // Exact ties (kbest_ties.h): the kernels enumerate ONE solution more than the tables hold -- kT slots per problem, kernel-side
+    // k = kT + 1 -- and order runs of equal gains canonically.  Not in the modes that reproduce the reference's own order of
+    // operations (push counting, the unpruned run, the root-only entries) nor under root-subtree sharding (the merge orders ties).
+    const bool tieMode = tie_mode(ctx, opts, extra != nullptr);
+    const int kT = k;
+    if (tieMode) k = k + 1;
+    int32_t *d_tie = (tieMode && opts->tie_flags) ? opts->tie_flags + base : nullptr;
     Shape shape;
     const bool kFits = k_fits_fast(ctx, LB, fastRow, k, opts->flags, &shape);
     const bool forceWide = ctx->forceWide && !extra;  // test hook: everything through the general-size kernel
@@ -799,6 +828,22 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         if (rc != KBEST_OK) return rc;
     }
     const Launched mark{ctx, sub ? ctx->stream : s};
+    double *d_tieGain = nullptr;
+    if (tieMode) {
+        if ((size_t)LB * 8 > ctx->tieBuf.bytes) {
+            if (!grow) return fail(ctx, KBEST_ERR_NOT_RESERVED, "tie work space too small: call kbest_reserve first");
+            const int rc = raw_reserve(ctx, ctx->tieBuf, (size_t)LB * 8);
+            if (rc != KBEST_OK) return rc;
+        }
+        d_tieGain = static_cast<double *>(ctx->tieBuf.p) + base;
+    }
+    // the launch behind the enumeration: runs of equal gains into the canonical order, the tie flags (kbest_ties.h)
+    auto finish = [&]() -> int {
+        if (!tieMode) return KBEST_OK;
+        hipError_t e = kb::launch_finish_tables(d_nf, d_nRow, d_nCol, B, kT, maxCol, maxRow, d_row4col, d_col4row, d_gain, tabI8, d_tieGain, d_tie,
+                                                false, s);
+        return e == hipSuccess ? KBEST_OK : fail(ctx, KBEST_ERR_HIP, "tie-order kernel launch", e);
+    };
     // Problems of up to 32 rows: the small-problem kernel (half-wave workers, implicit zero columns).  The modes that
     // need the reference's exact order of splits (push counting), no pruning, subtree sharding or the duals of the
     // padded formulation stay on the 64-row kernel.
@@ -856,9 +901,11 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         p.spec = lsh.spec;
         p.prof = ctx->prof;
         p.slotSid = reinterpret_cast<unsigned short *>(ctx->states + slotOff) + base * (size_t)kb::slot_table_stride(k);
+        p.kTab = kT;
+        p.tieGain = d_tieGain;
         hipError_t e = kb::launch_kbest_lane(p, B, lsh.nWaves, lsh.lanes, s);
         if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "lane-per-child kbest kernel launch", e);
-        return KBEST_OK;
+        return finish();
     }
     int snw = 0;
     const bool smallWins = ctx->forceSmall || maxCol < maxRow || (LB <= 2 * ctx->nCU && !squareU);
@@ -889,14 +936,17 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         sp.statesPerProblem = kb::small_states_per_problem(k, snw, maxCol);
         sp.states = ctx->states + base * (size_t)sp.statesPerProblem * (size_t)sp.stateStride;
         sp.prof = ctx->prof;
+        sp.kTab = kT;
+        sp.tieGain = d_tieGain;
         hipError_t e = kb::launch_kbest_small(sp, B, snw, s);
         if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "small-problem kbest kernel launch", e);
-        return KBEST_OK;
+        return finish();
     }
 
     if (sub && runWide) return fail(ctx, KBEST_ERR_INTERNAL, "a piece of a batch on the general-size kernel");
     if (runFast) {
-        const int S = sub ? 1 : split_factor(ctx, opts, B, maxRow, maxCol, k, d_nRow == nullptr && d_costOff == nullptr, extra == nullptr);
+        // (a split launch merges per-share lists of k: it runs without the extra solution; the merge orders ties by the assignment)
+        const int S = (sub || tieMode) ? 1 : split_factor(ctx, opts, B, maxRow, maxCol, k, d_nRow == nullptr && d_costOff == nullptr, extra == nullptr);
         const int PB = LB * S;  // workgroups = problems of the launch as the kernel sees them
         Shape shp = shape;
         if (S > 1 && !k_fits_fast(ctx, PB, fastRow, k, opts->flags, &shp)) return fail(ctx, KBEST_ERR_INTERNAL, "split launch shape");
@@ -947,6 +997,8 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         p.dualU = extra ? extra->dualU : nullptr;
         p.dualV = extra ? extra->dualV : nullptr;
         p.gainCols = extra ? extra->gainCols : 0;
+        p.kTab = kT;
+        p.tieGain = d_tieGain;
         p.split = S;
         p.splitB = B;
         p.sharedT = S > 1 ? reinterpret_cast<unsigned long long *>(sb + sl.offT) : nullptr;
@@ -1062,10 +1114,12 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         p.freeList = reinterpret_cast<int *>(base);
         p.freeStride = w.freeStride;
         p.prof = ctx->prof;
+        p.kTab = kT;
+        p.tieGain = d_tieGain;
         hipError_t e = kb::launch_kbest_wide(p, w.grid, s);
         if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "general-size kbest kernel launch", e);
     }
-    return KBEST_OK;
+    return finish();
 }
 
 int kbest_batch_f64_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, int maxCol,
@@ -1154,6 +1208,7 @@ int kbest_batch_f64_keep(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxR
         nCost = (size_t)B * maxRow * maxCol;
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int kk = tie_mode(ctx, opts, false) ? k + 1 : k;  // what the kernels enumerate (exact ties, kbest_ties.h)
     const size_t nR4C = (size_t)B * k * maxCol, nC4R = (size_t)B * k * maxRow, nG = (size_t)B * k;
     const bool tabI8 = (opts->flags & KBEST_FLAG_TABLES_I8) != 0;  // row4col / col4row are int8 tables behind the int32_t pointers
     const size_t esz = tabI8 ? 1 : 4;
@@ -1174,7 +1229,7 @@ int kbest_batch_f64_keep(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxR
     // int8 tables).  Not for the general-size kernel (it re-reads costs from memory at every step), and not together with
     // copies back of pageable tables (measured slower: they share the link).
     const bool zcCost = pinnedCost && direct && ctx->zcCost && maxRow <= KBEST_MAX_DIM && !ctx->forceWide &&
-                        k_fits_fast(ctx, B, maxRow < KBEST_MAX_DIM ? maxRow : KBEST_MAX_DIM, k, opts->flags, nullptr);
+                        k_fits_fast(ctx, B, maxRow < KBEST_MAX_DIM ? maxRow : KBEST_MAX_DIM, kk, opts->flags, nullptr);
     // Narrow staging: the reference's int32 tables are 107 MB for 1 024 x 64x64, k = 200, and the link, not the kernel, set the time
     // of this entry (3.1 ms against 1.8).  Every index fits a byte and col4row is the inverse of row4col on a square problem, so
     // the kernels write row4col as BYTES into pinned staging memory (13 MB, as the slots become final), in pieces, and host
@@ -1182,7 +1237,7 @@ int kbest_batch_f64_keep(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxR
     // up to 64 rows (every row has a column: the inverse is complete); everything else takes the path below.
     const bool narrow = (!keep || keep->row4col8) && !tabI8 && !pushed && !nRow && !costOff && maxRow == maxCol && maxRow <= KBEST_MAX_DIM && !ctx->forceWide &&
                         !ctx->noNarrow && outBytesHint(B, k, maxRow, maxCol) >= ((size_t)8 << 20) &&
-                        k_fits_fast(ctx, B, maxRow, k, opts->flags, nullptr);
+                        k_fits_fast(ctx, B, maxRow, kk, opts->flags, nullptr);
     if (narrow) {
         std::lock_guard<std::mutex> narrowLock(ctx->narrowMu);
         const size_t offG = (nR4C + 63) & ~(size_t)63, offN = offG + nG * 8, tabBytes = offN + (size_t)B * 4;
@@ -1329,7 +1384,7 @@ int kbest_batch_f64_keep(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxR
     const size_t outBytes = (nR4C + (col4row ? nC4R : 0)) * esz + nG * 8;
     const int fastRow = maxRow < KBEST_MAX_DIM ? maxRow : KBEST_MAX_DIM;
     const bool canPiece = !costOff && maxRow <= KBEST_MAX_DIM && !ctx->forceWide && B >= 4 * ctx->nCU && outBytes >= ((size_t)32 << 20) &&
-                          k_fits_fast(ctx, B, fastRow, k, opts->flags, nullptr);
+                          k_fits_fast(ctx, B, fastRow, kk, opts->flags, nullptr);
     const int nPiece = canPiece ? (ctx->pieces > 0 ? ctx->pieces : ((zcCost && direct) ? 1 : 4)) : 1;
     if (nPiece > 1)
         for (int i = 0; i < 3; i++)
@@ -1435,7 +1490,66 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
                     const int64_t *costOff, int k, int32_t *row4col, int32_t *col4row, double *gain,
                     int32_t *nf, int64_t *pushed)
 {
-    return kbest_batch_f64_keep(ctx, opts, B, maxRow, maxCol, nRow, nCol, cost, costOff, k, row4col, col4row, gain, nf, pushed, nullptr);
+    if (!ctx || !opts || B <= 0 || k < 1 || !tie_mode(ctx, opts, false))
+        return kbest_batch_f64_keep(ctx, opts, B, maxRow, maxCol, nRow, nCol, cost, costOff, k, row4col, col4row, gain, nf, pushed, nullptr);
+    // Exact ties (kbest_ties.h; "Order of exact ties" in kbest_c.h).  The launch reports per problem whether the k-th and the
+    // (k+1)-th best gains are equal; this synchronous entry then completes that gain level for those problems -- the same call
+    // again for them alone with k + KBEST_TIE_CAP solutions, whose table comes back in the canonical order -- and keeps the
+    // lexicographically first assignments of the level: the answer no longer depends on the kernel the batch was routed to.
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf dFlags;
+    HIP_TRY(ctx, dFlags.alloc(ctx, (size_t)B * 4));
+    kbest_opts o = *opts;
+    o.tie_flags = dFlags.as<int32_t>();
+    int rc = kbest_batch_f64_keep(ctx, &o, B, maxRow, maxCol, nRow, nCol, cost, costOff, k, row4col, col4row, gain, nf, pushed, nullptr);
+    if (rc != KBEST_OK) return rc;
+    std::vector<int32_t> fl((size_t)B);
+    HIP_TRY(ctx, hipMemcpy(fl.data(), dFlags.as<int32_t>(), (size_t)B * 4, hipMemcpyDeviceToHost));
+    std::vector<int> idx;
+    for (int b = 0; b < B; b++)
+        if (fl[b] & KBEST_TIE_BOUNDARY) idx.push_back(b);
+    if (!idx.empty() && !(opts->flags & KBEST_FLAG_NO_TIE_RESOLVE)) {
+        const int n = (int)idx.size(), k2 = k + KBEST_TIE_CAP;
+        const bool i8 = (opts->flags & KBEST_FLAG_TABLES_I8) != 0;
+        const size_t esz = i8 ? 1 : 4;
+        std::vector<int32_t> sRow(n), sCol(n), sNf(n);
+        std::vector<int64_t> sOff(n);
+        size_t tot = 0;
+        for (int i = 0; i < n; i++) {
+            sRow[i] = nRow ? nRow[idx[i]] : maxRow;
+            sCol[i] = nCol ? nCol[idx[i]] : maxCol;
+            sOff[i] = (int64_t)tot;
+            tot += (size_t)sRow[i] * sCol[i];
+        }
+        std::vector<double> sCost(tot), sGain((size_t)n * k2);
+        for (int i = 0; i < n; i++) {
+            const size_t src = costOff ? (size_t)costOff[idx[i]] : (size_t)idx[i] * maxRow * maxCol;
+            memcpy(sCost.data() + sOff[i], cost + src, (size_t)sRow[i] * sCol[i] * 8);
+        }
+        std::vector<char> sR((size_t)n * k2 * maxCol * esz), sC(col4row ? (size_t)n * k2 * maxRow * esz : 0);
+        kbest_opts o2 = *opts;
+        o2.tie_flags = nullptr;
+        rc = kbest_batch_f64_keep(ctx, &o2, n, maxRow, maxCol, sRow.data(), sCol.data(), sCost.data(), sOff.data(), k2,
+                                  reinterpret_cast<int32_t *>(sR.data()), col4row ? reinterpret_cast<int32_t *>(sC.data()) : nullptr, sGain.data(),
+                                  sNf.data(), nullptr, nullptr);
+        if (rc != KBEST_OK) return rc;
+        for (int i = 0; i < n; i++) {
+            const int b = idx[i];
+            const double *g2 = sGain.data() + (size_t)i * k2;
+            // the level is complete when the table goes on beyond it (or the problem has no more assignments)
+            const bool complete = sNf[i] < k2 || g2[k2 - 1] != g2[k - 1];
+            if (sNf[i] < k) return fail(ctx, KBEST_ERR_INTERNAL, "kbest_batch_f64: the tie re-run found fewer solutions than the run before");
+            memcpy(reinterpret_cast<char *>(row4col) + (size_t)b * k * maxCol * esz, sR.data() + (size_t)i * k2 * maxCol * esz, (size_t)k * maxCol * esz);
+            if (col4row)
+                memcpy(reinterpret_cast<char *>(col4row) + (size_t)b * k * maxRow * esz, sC.data() + (size_t)i * k2 * maxRow * esz, (size_t)k * maxRow * esz);
+            memcpy(gain + (size_t)b * k, g2, (size_t)k * 8);
+            fl[b] |= complete ? KBEST_TIE_RESOLVED : 0;
+        }
+    }
+    for (int b = 0; b < B; b++)
+        if ((fl[b] & KBEST_TIE_BOUNDARY) && !(fl[b] & KBEST_TIE_RESOLVED)) fl[b] |= KBEST_TIE_UNRESOLVED;
+    if (opts->tie_flags) memcpy(opts->tie_flags, fl.data(), (size_t)B * 4);
+    return KBEST_OK;
 }
 
 int kbest_merge_topk_f64_dev(kbest_ctx *ctx, int B, int nShard, int k, int maxCol, int maximize, const void *d_gain,
@@ -1704,6 +1818,7 @@ static int weights_small(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t
     sp.ldRow = capRow;
     sp.ldCol = maxCol;
     sp.k = k;
+    sp.kTab = k;
     sp.maximize = 0;
     sp.useCutoff = bruteForce ? 0 : 1;  // assignment.cpp:594: kBest2DCutoff(..., cutoff = 42); :880: plain kBest2D
     sp.cutoff = 42.0;
@@ -1842,6 +1957,7 @@ extern "C" int kbest_assoc_probs_batch_f64_dev(kbest_ctx *ctx, int B, int maxRaw
     sp.ldRow = capRow;
     sp.ldCol = maxCol;
     sp.k = k;
+    sp.kTab = k;
     sp.useCutoff = 1;  // assignment.cpp:594
     sp.cutoff = 42.0;
     sp.nf = d_nf;

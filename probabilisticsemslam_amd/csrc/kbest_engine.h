@@ -51,6 +51,10 @@ struct Params {
     float optRho0, optRho1, optSlope;  // optSlope = (optRho1 - optRho0) / (optPhi * k), by the host: no loop-invariant float arithmetic in the kernel
     double optKappa;          // a ticket's re-split goes at least optKappa * (key - optimum) beyond its key
     int optMinPool;           // candidates the pool must hold before a quantile of it is used
+    // exact ties (kbest_ties.h): the tables hold kTab slots per problem -- k, or k - 1: the k-th solution is then enumerated for its
+    // gain only, which goes to tieGain[problem] (NaN: there is none)
+    int kTab;
+    double *tieGain;
 };
 
 struct CondParams {
@@ -192,6 +196,8 @@ struct WideParams {
     int *freeList;            // stack of free state slots
     long long freeStride;
     unsigned long long *prof; // diagnostic builds (KB_PROFILE): [B][16] cycle sums over the waves
+    int kTab;                 // exact ties (kbest_ties.h), as in Params
+    double *tieGain;
 };
 
 // bytes of one saved hypothesis of the general-size kernel: u[D] v[D] (fp64), row4col[D] col4row[D] (i32),
@@ -318,6 +324,9 @@ struct SmallParams {
     int *done;                // host-mapped completion counter (zero-copy calls) or nullptr
     int bnbRow;               // kbest_bnb.hip: rows of the largest raw block of the launch (<= 64; sizes its tile)
     int onlyUnfit;            // kbest_small.hip: 1 = answer only the problems whose nf is -2 (handed back by the launch before)
+    int kTab;                 // exact ties (kbest_ties.h), as in Params (the weights are those of the first kTab solutions)
+    double *tieGain;
+    int *tieFlags;            // fused association launches (no tables for the finishing kernel to look at): [B] KBEST_TIE_* or nullptr
 };
 
 __host__ __device__ inline long long small_state_stride(int maxRow, int maxCol)
@@ -443,6 +452,11 @@ double now_s();
 hipError_t launch_merge_topk(const MergeParams &p, int B, hipStream_t stream);
 hipError_t launch_fill_unused(const int *nf, const int *nRow, const int *nCol, int B, int k, int ldCol, int ldRow, int *row4col,
                               int *col4row, double *gain, bool tablesI8, hipStream_t stream);
+// The kernel behind every enumeration launch (kbest_merge.hip, kbest_ties.h): runs of equal gains into the canonical order,
+// KBEST_TIE_* flags from tieGain (the gain of the solution behind the tables; nullptr: none was enumerated) into tieFlags (or
+// nullptr), and -- fill -- the unused slots / the padding of a ragged batch as launch_fill_unused defines them.
+hipError_t launch_finish_tables(const int *nf, const int *nRow, const int *nCol, int B, int k, int ldCol, int ldRow, int *row4col,
+                                int *col4row, double *gain, bool tablesI8, const double *tieGain, int *tieFlags, bool fill, hipStream_t stream);
 hipError_t launch_kbest_lane(const Params &p, int B, int nWaves, int lanesPerChild, hipStream_t stream);
 hipError_t launch_kbest_small(const SmallParams &p, int B, int nWaves, hipStream_t stream);
 // kbest_tiny.hip: the fused association path by exhaustive enumeration, for frames whose assignments are few (condition + gate +

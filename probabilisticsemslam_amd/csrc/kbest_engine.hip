@@ -334,6 +334,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     const int N = p.nRow ? p.nRow[b] : p.maxRow;
     const int M = p.nCol ? p.nCol[b] : p.maxCol;
     const int k = p.k;
+    if (p.tieGain && tid == 0) p.tieGain[blk] = __longlong_as_double(0x7ff8000000000000LL);  // no solution behind the tables (yet)
     if (N < 1 || M < 1 || N < M || N > p.maxRow || M > p.maxCol) {  // undefined in the reference
         if (tid == 0) p.nf[blk] = (M == 0 || N == 0) ? 0 : -1;          // (an empty frame: nothing to assign, nothing found)
         return;
@@ -487,7 +488,11 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     const int offDone = ((18 * p.maxRow + 7) & ~7) + 24;  // saved state: columns whose child has been completed
     unsigned char *rootMap = smem + L.offRootMap;  // the optimum's col4row (lane = row)
     // saved hypothesis (HBM): u[D'] v[D'] (fp64) | row4col[D'] col4row[D'] (u8) | forb, gain, activeCol
-    const long long outBase = (long long)blk * k;
+    // exact ties (kbest_ties.h): the tables hold kTab = k - 1 slots, the k-th solution is enumerated for its gain only
+    // (p.kTab is read where it is needed: a kernel argument is re-loaded from the argument segment, a local would be one more value
+    //  live across the round loop)
+#define kTab (p.kTab)
+    const long long outBase = (long long)blk * kTab;
     const int DS = p.maxRow;
     const int offR4C = 16 * DS, offC4R = 17 * DS, offTail = (18 * DS + 7) & ~7;
 
@@ -1012,6 +1017,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 if (lane == 0) t = atomicAdd(&ctrl->outTicket, 1);
                 const int sOut = outDone + uni32(t);
                 if (sOut >= emitted) break;
+                if (sOut >= kTab) continue;  // (the solution behind the tables: its gain is all that is kept)
                 const unsigned char *st = stBase + (long long)slotSid[sOut] * p.stateStride;
                 // (the states are in the enumeration's column order: the tables in the reference's)
                 if (lane < M) put_index(p.row4col, (outBase + sOut) * p.ldCol + colOf[lane], st[offR4C + lane], tabI8);
@@ -1438,7 +1444,8 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 int run = (~plainM == 0ull) ? 64 : __builtin_ctzll(~plainM);  // leading entries that simply go out
                 if (run > k - e) run = k - e;
                 if (lane < run) {
-                    p.gain[outBase + e + lane] = gu;
+                    if (e + lane < kTab) p.gain[outBase + e + lane] = gu;
+                    else p.tieGain[blk] = gu;  // (tie mode only: the solution behind the tables)
                     slotSid[e + lane] = (unsigned short)psid;
                 }
                 e += run;
@@ -1453,7 +1460,8 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
                 if ((__ballot(tickB) >> run) & 1ull) break;  // behind a ticket: wait for its node's re-split
                 if (!tSplit && nselNew <= tSel) break;  // not split and not selected this round: wait
                 if (lane == run) {
-                    p.gain[outBase + e] = gu;
+                    if (e < kTab) p.gain[outBase + e] = gu;
+                    else if (!tCut) p.tieGain[blk] = gu;  // (beyond the cutoff: written in the reference, never counted)
                     slotSid[e] = (unsigned short)(tSplit ? psid : sidFirst);
                 }
                 if (tCut) { stop = 1; break; }  // cpp:709-719: slot written, not counted
@@ -1537,7 +1545,8 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         KB_ACC(12, __builtin_readcyclecounter() - tA1);  // [12] wait at the barrier after A
     }
     const int stopCode = uni32(ctrl->stop);
-    const int nf = (stopCode == 2) ? -3 : uni32(ctrl->emitted);
+    const int nfAll = (stopCode == 2) ? -3 : uni32(ctrl->emitted);
+    const int nf = nfAll > kTab ? kTab : nfAll;
     // ---- phase 3: outputs.  Slot s holds hypothesis slotSid[s]: widen its saved row4col / col4row (the slots that were not
     //      written during the rounds: those emitted in the last one) --------
     const int outDoneEnd = uni32(ctrl->outDone);
@@ -1554,6 +1563,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         p.nf[blk] = nf;
         if (p.pushed) p.pushed[blk] = ctrl->pushed;
     }
+#undef kTab
 #ifdef KB_PROFILE
     profAcc[13] = __builtin_readcyclecounter() - profT0;  // [13] whole kernel (this wave)
     if (p.prof && lane == 0)

@@ -134,6 +134,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
     const int N = p.nRow ? p.nRow[b] : p.maxRow;
     const int M = p.nCol ? p.nCol[b] : p.maxCol;
     const int k = p.k;
+    // exact ties (kbest_ties.h): the tables hold p.kTab slots (k, or k - 1: the k-th solution is enumerated for its gain only)
+    if (p.tieGain && tid == 0) p.tieGain[b] = __longlong_as_double(0x7ff8000000000000LL);  // no solution behind the tables (yet)
     if (N < 1 || M < 1 || N < M || N > p.maxRow || M > p.maxCol) {  // undefined in the reference
         if (tid == 0) p.nf[b] = (M == 0 || N == 0) ? 0 : -1;            // (an empty frame: nothing to assign, nothing found)
         return;
@@ -163,7 +165,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
     const u64 allRows = (D >= 64) ? ~0ull : ((1ull << D) - 1ull);
     const int nSlots = p.statesPerProblem;
     unsigned char *stBase = p.states + (long long)b * nSlots * p.stateStride;
-    const long long outBase = (long long)b * k;
+    const long long outBase = (long long)b * p.kTab;
 #ifdef KB_PROFILE
     unsigned long long profAcc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long profT0 = __builtin_readcyclecounter();
@@ -903,7 +905,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
                 int run = (~plainM == 0ull) ? 64 : __builtin_ctzll(~plainM);  // leading entries that simply go out
                 if (run > k - e) run = k - e;
                 if (lane < run) {
-                    p.gain[outBase + e + lane] = gu;
+                    if (e + lane < p.kTab) p.gain[outBase + e + lane] = gu;
+                    else p.tieGain[b] = gu;  // (tie mode only: the solution behind the tables)
                     slotSid[e + lane] = (unsigned short)psid;
                 }
                 e += run;
@@ -915,7 +918,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
                 const bool tSplit = (__ballot((meta & LN_SPLIT) != 0) >> run) & 1ull, tCut = (__ballot(cutB) >> run) & 1ull;
                 if (!tSplit && nselNew == 0) break;  // not split and not selected this round: wait
                 if (lane == run) {
-                    p.gain[outBase + e] = gu;
+                    if (e < p.kTab) p.gain[outBase + e] = gu;
+                    else if (!tCut) p.tieGain[b] = gu;  // (beyond the cutoff: written in the reference, never counted)
                     slotSid[e] = (unsigned short)(tSplit ? psid : sid0);
                 }
                 if (tCut) { stop = 1; break; }  // cpp:709-719: slot written, not counted
@@ -968,7 +972,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
         KB_ACC(12, __builtin_readcyclecounter() - tA1);  // [12] wait at the barrier after A
     }
     const int stopCode = uni32(ctrl->stop);
-    const int nf = (stopCode == 2) ? -3 : uni32(ctrl->emitted);
+    const int nfAll = (stopCode == 2) ? -3 : uni32(ctrl->emitted);
+    const int nf = nfAll > p.kTab ? p.kTab : nfAll;
     // ---- phase 3: outputs.  Slot s holds hypothesis slotSid[s]: widen its saved row4col / col4row --------
     for (int idx = tid; idx < nf * (N + M); idx += NT) {
         const int s = idx / (N + M), j = idx - s * (N + M);

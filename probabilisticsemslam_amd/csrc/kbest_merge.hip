@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kbest_engine.h"
+#include "kbest_ties.h"
 
 namespace kb {
 
@@ -120,6 +121,59 @@ __global__ void __launch_bounds__(256) fill_unused_kernel(const int *nf, const i
     if (col4row)
         for (int i = threadIdx.x + n * ldRow; i < k * ldRow; i += 256) col4row[base * ldRow + i] = -1;
     for (int i = threadIdx.x + n; i < k; i += 256) gain[base + i] = 0.0;
+}
+
+// The launch behind every enumeration launch: one workgroup per problem.  Wave 0 brings runs of equal gains into the one order
+// all kernels share -- (gain, row4col lexicographic), kbest_ties.h -- and reports the problem's KBEST_TIE_* flags (tieGain: the
+// gain of the solution behind the tables, which the kernels enumerate for this purpose); the other waves define the unused
+// slots and the padding of ragged batches as fill_unused_kernel does (FILL).  The two touch different entries of the tables.
+template <typename T, bool FILL>
+__global__ void __launch_bounds__(256) finish_tables_kernel(const int *nf, const int *nRow, const int *nCol, int k, int ldCol, int ldRow,
+                                                            T *row4col, T *col4row, double *gain, const double *tieGain, int *tieFlags)
+{
+    __shared__ unsigned short scr[3 * TIE_RUN_CAP];
+    const int b = blockIdx.x;
+    int n = nf[b];
+    n = n < 0 ? 0 : (n > k ? k : n);
+    const long long base = (long long)b * k;
+    const int M = nCol ? (nCol[b] < ldCol ? (nCol[b] > 0 ? nCol[b] : 0) : ldCol) : ldCol;
+    const int N = nRow ? (nRow[b] < ldRow ? (nRow[b] > 0 ? nRow[b] : 0) : ldRow) : ldRow;
+    if (threadIdx.x < 64) {
+        const double extra = tieGain ? tieGain[b] : __longlong_as_double(0x7ff8000000000000LL);
+        const int fl = tie_tail(gain + base, reinterpret_cast<int *>(row4col), base * ldCol, reinterpret_cast<int *>(col4row), base * ldRow, n, M, N,
+                                ldCol, ldRow, sizeof(T) == 1, scr, TIE_RUN_CAP, n == k && extra == extra, extra);
+        if (tieFlags && threadIdx.x == 0) tieFlags[b] = fl;
+        if (FILL) return;
+    }
+    if (!FILL) return;
+    const int t = threadIdx.x - 64;
+    if (nRow) {  // the padding of the emitted slots
+        const int padC = ldCol - M, padR = ldRow - N;
+        for (int i = t; i < n * padC; i += 192) row4col[(base + i / padC) * ldCol + M + i % padC] = -1;
+        if (col4row)
+            for (int i = t; i < n * padR; i += 192) col4row[(base + i / padR) * ldRow + N + i % padR] = -1;
+    }
+    if (n >= k) return;
+    for (int i = t + n * ldCol; i < k * ldCol; i += 192) row4col[base * ldCol + i] = -1;
+    if (col4row)
+        for (int i = t + n * ldRow; i < k * ldRow; i += 192) col4row[base * ldRow + i] = -1;
+    for (int i = t + n; i < k; i += 192) gain[base + i] = 0.0;
+}
+
+hipError_t launch_finish_tables(const int *nf, const int *nRow, const int *nCol, int B, int k, int ldCol, int ldRow, int *row4col, int *col4row,
+                                double *gain, bool tablesI8, const double *tieGain, int *tieFlags, bool fill, hipStream_t stream)
+{
+    if (B <= 0) return hipSuccess;
+    signed char *r8 = reinterpret_cast<signed char *>(row4col), *c8 = reinterpret_cast<signed char *>(col4row);
+    const dim3 g(B), bl(fill ? 256 : 64);
+    if (tablesI8) {
+        if (fill) hipLaunchKernelGGL((finish_tables_kernel<signed char, true>), g, bl, 0, stream, nf, nRow, nCol, k, ldCol, ldRow, r8, c8, gain, tieGain, tieFlags);
+        else hipLaunchKernelGGL((finish_tables_kernel<signed char, false>), g, bl, 0, stream, nf, nRow, nCol, k, ldCol, ldRow, r8, c8, gain, tieGain, tieFlags);
+    } else {
+        if (fill) hipLaunchKernelGGL((finish_tables_kernel<int, true>), g, bl, 0, stream, nf, nRow, nCol, k, ldCol, ldRow, row4col, col4row, gain, tieGain, tieFlags);
+        else hipLaunchKernelGGL((finish_tables_kernel<int, false>), g, bl, 0, stream, nf, nRow, nCol, k, ldCol, ldRow, row4col, col4row, gain, tieGain, tieFlags);
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_fill_unused(const int *nf, const int *nRow, const int *nCol, int B, int k, int ldCol, int ldRow, int *row4col, int *col4row,

@@ -540,7 +540,7 @@ kbest_small_kernel(SmallParams p)
 
     const long long costBase = p.costOff ? p.costOff[b] : (long long)b * p.ldRow * p.ldCol;
     const double *Cg = p.cost + costBase;
-    const long long outBase = (long long)b * k;
+    const long long outBase = (long long)b * p.kTab;  // (exact ties, kbest_ties.h: the tables hold kTab slots -- k, or k - 1)
     double *probOut = p.weights ? p.probs + (p.probOff ? p.probOff[b] : 0) : nullptr;
     const int nLout = p.weights ? (p.imm ? p.immL : p.nL[b]) : 0;  // landmarks in the caller's numbering
 
@@ -561,6 +561,10 @@ kbest_small_kernel(SmallParams p)
     };
     // (behind a launch of the bounded walk, kbest_bnb.hip: only what that kernel handed back)
     if (p.onlyUnfit && p.nf[b] != -2) return;
+    if (tid == 0) {
+        if (p.tieGain) p.tieGain[b] = __longlong_as_double(0x7ff8000000000000LL);  // no solution behind the tables (yet)
+        if (p.tieFlags) p.tieFlags[b] = 0;
+    }
     // ---- shapes ---------------------------------------------------------------------------------------------
     if (M == 0 || NR == 0) {  // an empty frame (getAssignmentProbs returns an empty result, assignment.cpp:50-51)
         if (tid == 0) p.nf[b] = 0;
@@ -694,7 +698,7 @@ kbest_small_kernel(SmallParams p)
                 const double q = (c < SM_GATE) ? exp(-c) : 0.0;
                 probOut[(i >= nLc) ? nLout : (p.condition ? (int)rowIdx[i] : i)] = q * norm;
             }
-            p.nf[b] = cnt < k ? cnt : k;
+            p.nf[b] = cnt < p.kTab ? cnt : p.kTab;
         }
         signal_done();
         return;
@@ -1153,7 +1157,12 @@ kbest_small_kernel(SmallParams p)
     }
     KS_T(tOut);
     __syncthreads();
-    const int nf = E;
+    // exact ties: the solution behind the tables was enumerated for its gain only
+    const int nf = E > p.kTab ? p.kTab : E;
+    if (E > p.kTab && tid == 0) {
+        if (p.tieGain) p.tieGain[b] = EG[p.kTab];
+        if (p.tieFlags && EG[p.kTab] == EG[p.kTab - 1]) p.tieFlags[b] = KBEST_TIE_BOUNDARY;
+    }
 
     // ---- phase 3: outputs ------------------------------------------------------------------------------------------
     if (p.row4col || p.col4row || p.gain) {
@@ -1168,7 +1177,7 @@ kbest_small_kernel(SmallParams p)
             }
         }
         if (p.gain)
-            for (int s = tid; s < nf + extraSlot; s += NT) p.gain[outBase + s] = EG[s];
+            for (int s = tid; s < nf + extraSlot && s < p.kTab; s += NT) p.gain[outBase + s] = EG[s];
     }
     if (p.weights) {
         // assignmentProb's accumulation (assignment.cpp:616-648), in the reference's order: solutions ascending,

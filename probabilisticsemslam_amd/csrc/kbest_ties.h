@@ -1,0 +1,133 @@
+// kbest_ties.h -- ONE order of exact ties for every kernel (device code only).
+//
+// Hypotheses with exactly equal gain have no defined relative order in the reference: what comes out of kBest2D is an
+// artefact of std::priority_queue's binary heap (shortestPathCPP.cpp:30-42, 574).  Every kernel of this engine enumerates in
+// an order of its own (pool order, (parent, column), bucket order, ...), so without a rule the SAME problem could come back
+// differently depending on which kernel the batch it travels in is routed to.  The rule, applied by all of them:
+//
+//   * solutions are ordered by (gain, row4col), row4col compared lexicographically in the REFERENCE's column order
+//     (distinct assignments differ in some column, so the order is total);
+//   * when the k-th and the (k+1)-th best gains are equal the k best are not a unique set: the kernel says so
+//     (TIE_FLAG_BOUNDARY) and the entry point either completes the gain level and keeps the lexicographically first
+//     assignments of it, or hands the flag to the caller (include/kbest_c.h, "Order of exact ties").
+//
+// The enumeration kernels get there with two small changes: they enumerate ONE solution more than asked for (its gain is all
+// that is kept: measured free, tests/dev/kplus1.py) and, when their tables are complete, one wave runs tie_tail() below over
+// the problem's own tables: a scan of the gains (the common, tie-free case ends there) and a rank sort of every run of equal
+// gains.  The exhaustive kernel and the bounded walk see every assignment up to the k-th gain's bucket anyway: their rank sorts
+// compare (gain, row4col) directly.
+#ifndef KBEST_TIES_H
+#define KBEST_TIES_H
+
+#include <hip/hip_runtime.h>
+
+#include "kbest_wave.h"
+
+namespace kb {
+
+constexpr int TIE_RUN_CAP = 1024;  // longest run of equal gains that tie_tail() orders (3 x u16 of LDS scratch per entry)
+
+// Loads that do not go through the CU's L1: the tables are written by OTHER waves of the workgroup (visible in L2 after the
+// barrier), and a line of the gain table is shared with the neighbouring problem, whose workgroup may run on this CU later and
+// must not find our copy of the line.
+__device__ __forceinline__ double tie_ld_gain(const double *p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ int tie_ld_index(const int *table, long long i, bool i8)
+{
+    if (i8) return (int)__hip_atomic_load(reinterpret_cast<const signed char *>(table) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load(table + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// true iff assignment a comes before assignment b: the first column (reference order) on which their rows differ decides
+__device__ __forceinline__ bool tie_lex_less(const int *row4col, long long a, long long b, int M, bool i8)
+{
+    for (int c = 0; c < M; c++) {
+        const int ra = tie_ld_index(row4col, a + c, i8), rb = tie_ld_index(row4col, b + c, i8);
+        if (ra != rb) return ra < rb;
+    }
+    return false;
+}
+
+// One wave (all 64 lanes), after the workgroup's last table write and a barrier.  gain points at slot 0 of ONE problem's
+// gains; row4col / col4row are the launch's tables (int32, or int8 when i8), r4cBase / c4rBase the ELEMENT index of the
+// problem's slot 0 in them (col4row may be null); nf slots are filled; scr: >= 3 * scrEntries u16 of LDS nobody else uses any
+// more.  haveExtra / extra: the gain of the (nf+1)-th solution, when the kernel enumerated it (nf == the caller's k then).
+// Returns KBEST_TIE_* flags (wave-uniform).
+__device__ __attribute__((noinline)) int tie_tail(const double *gain, int *row4col, long long r4cBase, int *col4row, long long c4rBase, int nf,
+                                                  int M, int N, int ldCol, int ldRow, bool i8, unsigned short *scr, int scrEntries,
+                                                  bool haveExtra, double extra)
+{
+    const int lane = threadIdx.x & 63;
+    int flags = 0;
+    if (nf < 1) return 0;
+    if (haveExtra && tie_ld_gain(gain + nf - 1) == extra) flags |= KBEST_TIE_BOUNDARY;
+    bool any = false;
+    for (int s = lane; s + 1 < nf; s += 64) any = any || (tie_ld_gain(gain + s) == tie_ld_gain(gain + s + 1));
+    if (__ballot(any) == 0ull) return flags;  // no two equal gains: what every tie-free problem pays
+    flags |= KBEST_TIE_INSIDE;
+    const int cap = scrEntries < TIE_RUN_CAP ? scrEntries : TIE_RUN_CAP;
+    unsigned short *inv = scr, *pos = scr + cap, *at = scr + 2 * cap;
+    int s = 0;
+    while (s + 1 < nf) {
+        // end of the run of gains equal to slot s (uniform)
+        const double g = tie_ld_gain(gain + s);
+        int e = s + 1;
+        for (;;) {
+            const int i = e + lane;
+            const u64 diff = __ballot(i >= nf || !(tie_ld_gain(gain + (i < nf ? i : nf - 1)) == g));
+            if (diff) { e += __builtin_ctzll(diff); break; }
+            e += 64;
+        }
+        const int L = e - s;
+        if (L > 1 && L <= cap) {
+            // rank of every entry of the run among the run (row4col lexicographic; distinct assignments: a permutation)
+            for (int i = lane; i < L; i += 64) {
+                int rank = 0;
+                for (int j = 0; j < L; j++) rank += (j != i && tie_lex_less(row4col, r4cBase + (long long)(s + j) * ldCol, r4cBase + (long long)(s + i) * ldCol, M, i8)) ? 1 : 0;
+                inv[rank] = (unsigned short)i;
+                pos[i] = (unsigned short)i;
+                at[i] = (unsigned short)i;
+            }
+            wave_fence();
+            // in place, by swaps: position q of the run receives the entry of rank q
+            for (int q = 0; q < L; q++) {
+                const int en = inv[q], cur = pos[en];
+                if (cur != q) {
+                    const long long a = r4cBase + (long long)(s + q) * ldCol, b = r4cBase + (long long)(s + cur) * ldCol;
+                    for (int c = lane; c < M; c += 64) {
+                        const int x = tie_ld_index(row4col, a + c, i8), y = tie_ld_index(row4col, b + c, i8);
+                        put_index(row4col, a + c, y, i8);
+                        put_index(row4col, b + c, x, i8);
+                    }
+                    if (col4row) {
+                        const long long a2 = c4rBase + (long long)(s + q) * ldRow, b2 = c4rBase + (long long)(s + cur) * ldRow;
+                        for (int r = lane; r < N; r += 64) {
+                            const int x = tie_ld_index(col4row, a2 + r, i8), y = tie_ld_index(col4row, b2 + r, i8);
+                            put_index(col4row, a2 + r, y, i8);
+                            put_index(col4row, b2 + r, x, i8);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");  // the next swap may read what this one wrote
+                    if (lane == 0) {
+                        const int other = at[q];
+                        at[cur] = (unsigned short)other;
+                        pos[other] = (unsigned short)cur;
+                        at[q] = (unsigned short)en;
+                        pos[en] = (unsigned short)q;
+                    }
+                    wave_fence();
+                }
+            }
+        } else if (L > cap) {
+            flags |= KBEST_TIE_UNORDERED;
+        }
+        s = e;
+    }
+    return flags;
+}
+
+}  // namespace kb
+#endif

@@ -372,6 +372,8 @@ __global__ void __launch_bounds__(NWV * 64, (R >= 16 ? 1 : (NWV == 16 ? 4 : (R <
         const int N = p.nRow ? p.nRow[b] : p.maxRow;
         const int M = p.nCol ? p.nCol[b] : p.maxCol;
         if (N >= 1 && M >= 1 && N >= M && N < p.minRows) continue;  // the LDS kernel's share of a mixed batch
+        // exact ties (kbest_ties.h): the tables hold p.kTab slots (k, or k - 1: the k-th solution is enumerated for its gain only)
+        if (p.tieGain && tid == 0) p.tieGain[b] = __longlong_as_double(0x7ff8000000000000LL);  // no solution behind the tables (yet)
         if (N < 1 || M < 1 || N < M || N > p.maxRow || M > p.maxCol || N > 64 * R) {  // undefined in the reference
             if (tid == 0) p.nf[b] = -1;
             continue;
@@ -385,7 +387,7 @@ __global__ void __launch_bounds__(NWV * 64, (R >= 16 ? 1 : (NWV == 16 ? 4 : (R <
                           p.spec * L.nodeStride >= 64 * (1 + R) * 8 + 128 && p.spec * p.maxCol >= M;
         if (t0On)
             for (int c = tid; c < M; c += NT) atoms[(long long)c * (1 + R)] = 0x7ff0000000000000ull;  // +inf: no such child
-        const long long outBase = (long long)b * k;
+        const long long outBase = (long long)b * p.kTab;
 #ifdef KB_PROFILE
         unsigned long long profAcc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         const unsigned long long profT0 = __builtin_readcyclecounter();
@@ -747,8 +749,9 @@ __global__ void __launch_bounds__(NWV * 64, (R >= 16 ? 1 : (NWV == 16 ? 4 : (R <
                 }
                 for (int j = lane; j < nEmit + (cutStop ? 1 : 0); j += 64)
                     if (emitted + j < k) {
-                        const double g = srcG[j];
-                        p.gain[outBase + emitted + j] = maximize ? (-g + ctrl->cdelta) : (g + ctrl->cdelta);  // cpp:626-630
+                        const double g = srcG[j], gu = maximize ? (-g + ctrl->cdelta) : (g + ctrl->cdelta);  // cpp:626-630
+                        if (emitted + j < p.kTab) p.gain[outBase + emitted + j] = gu;
+                        else if (j < nEmit) p.tieGain[b] = gu;  // (tie mode only: the counted solution behind the tables)
                     }
                 wave_fence();
                 if (lane < nsel) {  // the nodes of this round: state slot, gain, active column
@@ -776,6 +779,7 @@ __global__ void __launch_bounds__(NWV * 64, (R >= 16 ? 1 : (NWV == 16 ? 4 : (R <
             // -- outputs of the hypotheses emitted in this round (cpp:618-630): from their saved states
             for (int idx = tid; idx < nEmit * (N + M); idx += NT) {
                 const int j = idx / (N + M), q = idx - j * (N + M);
+                if (emitted + j >= p.kTab) continue;  // (the solution behind the tables: its gain is all that is kept)
                 const unsigned char *E = stBase + (long long)(srcS[j] & WIDE_SID_MASK) * p.stateStride;
                 // (the states are in the enumeration's column order: the tables in the reference's)
                 if (q < M) put_index(p.row4col, (outBase + emitted + j) * p.ldCol + colOf[q], reinterpret_cast<const int *>(E + offR4C)[q], tabI8);
@@ -1071,7 +1075,7 @@ __global__ void __launch_bounds__(NWV * 64, (R >= 16 ? 1 : (NWV == 16 ? 4 : (R <
             for (int i = 0; i < 16; i++) atomicAdd(p.prof + (long long)b * 16 + i, profAcc[i]);
 #endif
         if (tid == 0) {
-            p.nf[b] = (ctrl->stop == 2) ? -3 : ctrl->emitted;
+            p.nf[b] = (ctrl->stop == 2) ? -3 : (ctrl->emitted > p.kTab ? p.kTab : ctrl->emitted);
             if (p.pushed) p.pushed[b] = ctrl->pushed;
         }
     }

@@ -14,6 +14,12 @@ KBEST_FLAG_NO_PRUNE = 1
 KBEST_FLAG_COUNT_PUSHED = 2
 KBEST_FLAG_TABLES_I8 = 64
 KBEST_FLAG_NO_REORDER = 128
+KBEST_FLAG_NO_TIE_CHECK = 512
+KBEST_FLAG_NO_TIE_RESOLVE = 1024
+# per-problem tie flags (kbest_c.h, "Order of exact ties")
+KBEST_TIE_INSIDE, KBEST_TIE_BOUNDARY, KBEST_TIE_RESOLVED = 1, 2, 4
+KBEST_TIE_UNORDERED, KBEST_TIE_UNRESOLVED = 1 << 29, 1 << 30
+KBEST_TIE_CAP = 64
 KBEST_MAX_DIM = 64        # rows handled by the LDS-resident kernel
 KBEST_MAX_DIM_WIDE = 1024  # rows handled at all (general-size kernel beyond KBEST_MAX_DIM)
 
@@ -39,7 +45,7 @@ class KBestError(RuntimeError):
 
 class KBestOpts(C.Structure):
     _fields_ = [("maximize", C.c_int32), ("use_cutoff", C.c_int32), ("cutoff", C.c_double), ("flags", C.c_uint32),
-                ("root_col_offset", C.c_int32), ("root_col_stride", C.c_int32)]
+                ("root_col_offset", C.c_int32), ("root_col_stride", C.c_int32), ("tie_flags", C.c_void_p)]
 
 
 def lib_path() -> str:
@@ -152,11 +158,13 @@ class KBestEngine:
 
     # ---- host buffers -----------------------------------------------------------------
     def kbest(self, costs, N, M, k, maximize=False, cutoff=None, nRow=None, nCol=None, costOff=None,
-              count_pushed=False, prune=True, root_shard=None, tables_i8=False, reorder=True):
+              count_pushed=False, prune=True, root_shard=None, tables_i8=False, reorder=True, tie_flags=False,
+              tie_check=True, tie_resolve=True):
         """Batched kBest2D / kBest2DCutoff.  costs: (B, N*M) for uniform shapes, or a flat packed
         array with per-problem nRow/nCol/costOff (N, M are then the maxima).
         Returns (nf[B], row4col[B,k,M], col4row[B,k,N], gain[B,k]) (+ pushed[B] if count_pushed).
-        tables_i8: the two tables come back as int8 (KBEST_FLAG_TABLES_I8; N <= 127)."""
+        tables_i8: the two tables come back as int8 (KBEST_FLAG_TABLES_I8; N <= 127).
+        tie_flags: also return the per-problem KBEST_TIE_* flags (last element of the tuple)."""
         costs = np.ascontiguousarray(costs, dtype=np.float64)
         if nRow is None:
             costs = costs.reshape(-1, N * M)
@@ -173,14 +181,17 @@ class KBestEngine:
         nf = np.empty(B, np.int32)
         pushed = np.zeros(B, np.int64) if count_pushed else None
         flags = ((KBEST_FLAG_COUNT_PUSHED if count_pushed else 0) | (0 if prune else KBEST_FLAG_NO_PRUNE) |
-                 (KBEST_FLAG_TABLES_I8 if tables_i8 else 0) | (0 if reorder else KBEST_FLAG_NO_REORDER))
+                 (KBEST_FLAG_TABLES_I8 if tables_i8 else 0) | (0 if reorder else KBEST_FLAG_NO_REORDER) |
+                 (0 if tie_check else KBEST_FLAG_NO_TIE_CHECK) | (0 if tie_resolve else KBEST_FLAG_NO_TIE_RESOLVE))
         o = self._opts(maximize, cutoff, flags, root_shard)
+        tf = np.zeros(B, np.int32) if tie_flags else None
+        if tf is not None:
+            o.tie_flags = tf.ctypes.data
         self._check(self.lib.kbest_batch_f64(self.ctx, C.byref(o), B, N, M, _ptr(nRow), _ptr(nCol), _ptr(costs),
                                              _ptr(costOff), k, _ptr(r4c), _ptr(c4r), _ptr(gain), _ptr(nf),
                                              _ptr(pushed)))
-        if count_pushed:
-            return nf, r4c, c4r, gain, pushed
-        return nf, r4c, c4r, gain
+        out = (nf, r4c, c4r, gain) + ((pushed,) if count_pushed else ()) + ((tf,) if tie_flags else ())
+        return out
 
     def assign(self, costs, N, M, maximize=False, shift=True, gain_cols=0):
         """Batched assign2D (shift=True) / shortestPathCPP (shift=False) on uniform N x M problems, costs (B, N*M).
@@ -300,12 +311,15 @@ class KBestEngine:
 
     def kbest_dev(self, d_cost, B, N, M, k, d_row4col, d_col4row, d_gain, d_nf, maximize=False, cutoff=None,
                   d_pushed=None, prune=True, stream=None, root_shard=None, d_nRow=None, d_nCol=None, d_costOff=None,
-                  tables_i8=False):
+                  tables_i8=False, d_tie_flags=None, tie_check=True):
         """Asynchronous launch on `stream` (a raw hipStream_t integer, e.g.
-        torch.cuda.current_stream().cuda_stream).  All d_* are torch CUDA tensors (tables_i8: d_row4col / d_col4row int8)."""
+        torch.cuda.current_stream().cuda_stream).  All d_* are torch CUDA tensors (tables_i8: d_row4col / d_col4row int8;
+        d_tie_flags: int32 [B], receives the KBEST_TIE_* flags)."""
         flags = ((KBEST_FLAG_COUNT_PUSHED if d_pushed is not None else 0) | (0 if prune else KBEST_FLAG_NO_PRUNE) |
-                 (KBEST_FLAG_TABLES_I8 if tables_i8 else 0))
+                 (KBEST_FLAG_TABLES_I8 if tables_i8 else 0) | (0 if tie_check else KBEST_FLAG_NO_TIE_CHECK))
         o = self._opts(maximize, cutoff, flags, root_shard)
+        if d_tie_flags is not None:
+            o.tie_flags = d_tie_flags.data_ptr()
         # the C entry never allocates (kbest_c.h): size the workspace here (a no-op once it is large enough)
         self.reserve(B, N, k)
 

@@ -267,3 +267,24 @@ def asgn_bb(bbL, bbR, gate):
     asg = np.full(len(bbL), -1, np.int32)
     oracle().orc_asgn_bb(bbL.reshape(-1), len(bbL), bbR.reshape(-1), len(bbR), float(gate), asg)
     return asg
+
+
+def canonical_kbest(cost, N, M, k, maximize=False, cutoff=None, cap=64):
+    """The k best in the engine's ONE order of exact ties (include/kbest_c.h, "Order of exact ties"), from the checker:
+    solutions ordered by (gain, row4col lexicographic); when the k-th and the (k+1)-th best gains are equal, the
+    lexicographically first assignments of that gain level.  Returns (nf, row4col[nf, M], gain[nf], boundary, resolved):
+    boundary = such a tie exists, resolved = its gain level ends within `cap` solutions beyond k (what a synchronous
+    entry completes, KBEST_TIE_CAP).  The level itself is enumerated completely here, whatever its size."""
+    big = k + cap
+    while True:
+        nf, r4c, c4r, g = orc_kbest(cost, N, M, big, maximize=maximize, cutoff=cutoff)
+        if nf < big or nf <= k or g[nf - 1] != g[k - 1]:
+            break
+        big *= 2
+    r4c, g = np.asarray(r4c[:nf]), np.asarray(g[:nf])
+    keys = [r4c[:, c] for c in range(M - 1, -1, -1)] + [(-g if maximize else g)]
+    order = np.lexsort(keys)  # last key first: gain, then the columns from the first to the last
+    boundary = bool(nf > k and g[order[k]] == g[order[k - 1]])
+    resolved = boundary and (nf < k + cap or g[order[k + cap - 1]] != g[order[k - 1]])
+    n = min(nf, k)
+    return n, r4c[order[:n]], g[order[:n]], boundary, resolved

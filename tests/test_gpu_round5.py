@@ -119,3 +119,71 @@ def test_reference_caller_object_runs_on_the_engine(tmp_path):
             o += 8 * nM * w2
             np.testing.assert_allclose(q, z[n + "/brute"], rtol=1e-12, atol=1e-300, err_msg=n)
     assert o == len(buf)
+
+
+# ---------------------------------------------------------------------------------------------- exact ties
+def _int_costs(rng, B, N, M, hi):
+    return rng.integers(0, hi, size=(B, N * M)).astype(np.float64)
+
+
+def engine_with(monkeypatch, **env):
+    for key, val in env.items():
+        monkeypatch.setenv(key, str(val))
+    eng = pk.KBestEngine(0)
+    for key in env:
+        monkeypatch.delenv(key)
+    return eng
+
+
+TIE_ROUTES = [{}, {"KBEST_NO_LANE": 1, "KBEST_NO_SMALL": 1}, {"KBEST_FORCE_SMALL": 1}, {"KBEST_FORCE_LANE": 1}, {"KBEST_FORCE_WIDE": 1}]
+
+
+@pytest.mark.parametrize("shape", [(10, 10, 30, 3), (8, 8, 20, 40), (16, 16, 50, 30), (12, 7, 30, 25), (40, 40, 60, 200), (20, 20, 100, 1000)])
+def test_exact_ties_one_answer_whatever_the_kernel(monkeypatch, shape):
+    """Integer costs: masses of exactly equal gains.  Every kernel the batch can be routed to returns the SAME tables --
+    solutions in (gain, row4col lexicographic) order, and where the k-th and (k+1)-th gains are equal the lexicographically
+    first assignments of that gain level (completed by the synchronous entry up to KBEST_TIE_CAP beyond k) -- and they are
+    the checker's k best brought into that order.  A level larger than the cap is flagged KBEST_TIE_UNRESOLVED: there the
+    gains (a multiset) and the validity of every assignment are checked.  shortestPathCPP.cpp:30-42, 574."""
+    N, M, k, hi = shape
+    rng = np.random.default_rng(1000 * N + k)
+    B = 12
+    costs = _int_costs(rng, B, N, M, hi)
+    want = [ol.canonical_kbest(costs[b], N, M, k, cap=pk.engine.KBEST_TIE_CAP) for b in range(B)]
+    seen_boundary = seen_resolved = 0
+    first = None
+    for knobs in TIE_ROUTES:
+        if knobs.get("KBEST_FORCE_SMALL") and N > 32 or knobs.get("KBEST_FORCE_LANE") and N > 32:
+            continue
+        eng = engine_with(monkeypatch, **knobs)
+        nf, r4c, c4r, g, fl = eng.kbest(costs, N, M, k, tie_flags=True)
+        for b in range(B):
+            wn, wr, wg, boundary, resolved = want[b]
+            assert nf[b] == wn, (knobs, b)
+            assert bool(fl[b] & pk.engine.KBEST_TIE_BOUNDARY) == boundary, (knobs, b, fl[b])
+            assert (bits(g[b, :wn]) == bits(wg)).all(), (knobs, b)          # gains: always the checker's, bit for bit
+            if boundary and not resolved:
+                assert fl[b] & pk.engine.KBEST_TIE_UNRESOLVED, (knobs, b)
+                for s in range(wn):                                           # valid, distinct assignments with the gain they claim
+                    assert len(set(r4c[b, s])) == M
+                    assert costs[b].reshape(M, N)[np.arange(M), r4c[b, s]].sum() == g[b, s]
+                assert len({tuple(r) for r in r4c[b, :wn]}) == wn
+                continue
+            assert not (fl[b] & pk.engine.KBEST_TIE_UNRESOLVED), (knobs, b)
+            assert bool(fl[b] & pk.engine.KBEST_TIE_RESOLVED) == boundary, (knobs, b)
+            assert (r4c[b, :wn] == wr).all(), (knobs, b, np.argwhere(r4c[b, :wn] != wr)[:3])
+            inv = np.full(N, -1)
+            for s in range(wn):                                               # col4row is the inverse on the real columns
+                inv[:] = -1
+                inv[r4c[b, s]] = np.arange(M)
+                got = c4r[b, s].copy()
+                got[got >= M] = -1
+                assert (got == inv).all(), (knobs, b, s)
+            seen_boundary += boundary
+            seen_resolved += resolved
+        if first is None:
+            first = (nf.copy(), r4c.copy(), g.copy(), fl.copy())
+        else:  # bit-identical tables across routings wherever the answer is defined
+            ok = (first[3] & pk.engine.KBEST_TIE_UNRESOLVED) == 0
+            assert (first[1][ok] == r4c[ok]).all() and (bits(first[2][ok]) == bits(g[ok])).all() and (first[3][ok] == fl[ok]).all(), knobs
+    assert seen_boundary > 0 or hi >= 1000  # (the generator does produce ties at slot k in the small-range cases)
