@@ -266,6 +266,12 @@ int kbest_assoc_probs_batch_f64_dev(kbest_ctx *ctx, int B, int maxRawRow, int ma
                                     const int64_t *d_costOff, int k, int condition, double *d_probs,
                                     const int64_t *d_probOff, int32_t *d_nf, void *stream);
 int kbest_reserve_assoc(kbest_ctx *ctx, int B, int maxRawRow, int maxCol, int k);
+/* Where kbest_assoc_probs_batch_f64_dev writes its frames' KBEST_TIE_* flags ([B] int32 in device memory; NULL, the default:
+ * nowhere).  Stays set until changed. */
+int kbest_set_assoc_tie_flags_dev(kbest_ctx *ctx, int32_t *d_flags);
+/* KBEST_TIE_* flags of the problems of the context's last SYNCHRONOUS call (kbest_batch_f64 and every host-buffer association
+ * entry, which have no other way to return them: the shims of kbest_shims.hpp included).  Copies min(n, cap) flags, returns n. */
+int kbest_last_tie_flags(kbest_ctx *ctx, int32_t *flags, int cap);
 
 /*
  * Batched computeQuadricCostMatrix (assignment.h:28-29, assignment.cpp:705-722).  Frame b has nL[b] landmarks and

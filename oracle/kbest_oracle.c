@@ -12,10 +12,13 @@
  * by running the *unmodified* reference solver (/root/reference/
  * shortestPathCPP.cpp compiled by oracle/Makefile into oracle/_ref/) on the
  * same seeded inputs, and against the known-answer vectors of SURVEY.md 8(c).
- * The weights functions (orc_assignment_prob etc.) restate assignment.cpp,
- * which cannot be compiled here (it needs Eigen/GTSAM/OpenCV through
- * assignment.h:4-9); they are pinned by the SURVEY 8(c) weight KATs and by
- * exhaustive permutation / permanent identities (tests/test_weights.py).
+ * The weights functions (orc_assignment_prob etc.) restate assignment.cpp.  The
+ * file as a whole cannot be compiled here (it needs Eigen/GTSAM/OpenCV through
+ * assignment.h:4-9), but its std-only line ranges can: oracle/Makefile cuts them
+ * into oracle/_ref/libref_assign.so, and tests/golden/weights_golden.npz records
+ * what THAT returns -- these restatements are pinned bit for bit by it
+ * (tests/test_weights_golden.py), besides the SURVEY 8(c) weight KATs and the
+ * exhaustive permutation / permanent identities of tests/test_weights.py.
  *
  * All file:line citations are relative to /root/reference.
  * Arithmetic: IEEE binary64, no reassociation, no contraction
@@ -556,6 +559,12 @@ static void weights_from_solutions(int nf, int nL, int nM, const int32_t *row4co
     }
     double norm = 1.0 / total;                               /* :643 */
     for (int i = 0; i < nM * (nL + 1); i++) probs[i] *= norm;
+}
+
+/* the same accumulation for a GIVEN list of solutions (tests: the k best brought into the engine's one order of exact ties) */
+void orc_weights_from_solutions(int nf, int nL, int nM, const int32_t *row4col, const double *gain, int gate, double *probs)
+{
+    weights_from_solutions(nf, nL, nM, row4col, gain, gate, probs);
 }
 
 /* nM == 1 fast path, assignment.cpp:554-570 / 840-856.  The reference returns

@@ -109,7 +109,8 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
     const double INF = d_inf();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
-    const int k = p.k;
+    const int k = p.kTab;  // (the caller's k; p.k is what the ENUMERATION kernels enumerate: one more, kbest_ties.h)
+    if (p.tieFlags && threadIdx.x == 0) p.tieFlags[blockIdx.x] = 0;
     const int M = p.imm ? p.immCol : p.nCol[b];
     const int NR = p.imm ? p.immRow : p.nRow[b];
     const int nLout = p.imm ? p.immL : p.nL[b];
@@ -631,7 +632,12 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
                 }
                 if (eq > ((e % per) == part ? 1 : 0)) {  // (some OTHER candidate has my gain, bit for bit: rare)
                     for (j = part; j < n; j += per)
-                        if (candG[j] == g && (candHi[j] < hi || (candHi[j] == hi && candLo[j] < lo))) rk++;
+                        if (candG[j] == g) {
+                            // the canonical order of exact ties (kbest_ties.h): rows of column 0 first -- byte 0 of the low word
+                            const u64 a0 = __builtin_bswap64(candLo[j]), a1 = __builtin_bswap64(candHi[j]);
+                            const u64 m0 = __builtin_bswap64(lo), m1 = __builtin_bswap64(hi);
+                            if (a0 < m0 || (a0 == m0 && a1 < m1)) rk++;
+                        }
                 }
                 if (rk) atomicAdd(&rankA[e], rk);
             }
@@ -655,6 +661,11 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
         }
     }
     __syncthreads();
+    // exact ties: every assignment up to the k-th gain's bucket is in the list, ordered canonically: the k kept are the
+    // lexicographically first of their gain level; the flag says that there was a choice (as in kbest_tiny.hip)
+    if (p.tieFlags && nf == k)
+        for (int e = tid; e < n; e += NT)
+            if (rankA[e] == k && candG[e] == solG[k - 1] && !(candG[e] > cutG)) p.tieFlags[b] = KBEST_TIE_BOUNDARY | KBEST_TIE_RESOLVED;
     const unsigned long long dE2 = __builtin_readcyclecounter();
     // ---- the weights (assignment.cpp:616-648), as in kbest_small.hip ------------------------------------------------------
     for (int s = tid; s < nf; s += NT) {
@@ -736,7 +747,7 @@ int bnb_lds_bytes(int k, int nThreads, int maxRow, int maxCol)
 template <int NT>
 static hipError_t launch_bnb_nt(const SmallParams &p, int B, hipStream_t stream)
 {
-    const int lds = bnb_lds_bytes(p.k, NT, p.bnbRow, p.maxCol);
+    const int lds = bnb_lds_bytes(p.kTab, NT, p.bnbRow, p.maxCol);
     static std::atomic<int> granted[16];
     int dev = 0;
     (void)hipGetDevice(&dev);

@@ -134,6 +134,9 @@ struct kbest_ctx {
     int splitForce = 0;       // KBEST_SPLIT: workgroups per matrix (2 / 4) whenever the split is possible (A/B tests)
     DevBufRaw splitBuf;       // per-share result tables + shared thresholds of the split
     DevBufRaw tieBuf;         // [B] fp64: gain of the solution behind the tables (exact ties, kbest_ties.h)
+    std::vector<int32_t> lastTie;  // KBEST_TIE_* per problem of the last synchronous call (kbest_last_tie_flags)
+    int32_t *assocTieDev = nullptr;  // where kbest_assoc_probs_batch_f64_dev writes its flags (kbest_set_assoc_tie_flags_dev)
+    std::mutex tieMu;
     bool noReorder = false;   // KBEST_NO_REORDER: the 64-row kernel enumerates in the reference's column order (A/B tests)
     int zcCost = 1;           // KBEST_ZC_COST=0: cost blocks in registered memory are copied up first instead of read in place (A/B tests)
     int pieces = 0;           // KBEST_PIECES: pieces of a large host-entry batch (1 / 2 / 4; A/B tests); 0 = choose
@@ -1549,6 +1552,10 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
     for (int b = 0; b < B; b++)
         if ((fl[b] & KBEST_TIE_BOUNDARY) && !(fl[b] & KBEST_TIE_RESOLVED)) fl[b] |= KBEST_TIE_UNRESOLVED;
     if (opts->tie_flags) memcpy(opts->tie_flags, fl.data(), (size_t)B * 4);
+    {
+        std::lock_guard<std::mutex> lock(ctx->tieMu);
+        ctx->lastTie.swap(fl);
+    }
     return KBEST_OK;
 }
 
@@ -1753,8 +1760,15 @@ struct QuadricHost;
 static int weights_small(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM, const int32_t *nRow, const double *cost,
                          const double *d_cost, const int64_t *costOff, int k, double *probs, const int64_t *probOff,
                          int32_t *nf, bool condition, bool bruteForce, int rawMaxRow, int maxCol, size_t nCost, size_t nProb,
-                         std::vector<int> *unfit = nullptr, bool allowFast = true)
+                         std::vector<int> *unfit = nullptr, bool allowFast = true, int32_t *tie = nullptr)
 {
+    // exact ties (kbest_ties.h): the enumeration kernel enumerates one solution more than the k it weighs and flags a frame
+    // whose k-th and (k+1)-th gains are equal (tie[b], KBEST_TIE_BOUNDARY: the caller completes that gain level through the
+    // general pipeline); the exhaustive kernel and the bounded walk see the whole level and keep its lexicographically first
+    // assignments themselves (KBEST_TIE_BOUNDARY | KBEST_TIE_RESOLVED)
+    const bool tieOn = !ctx->noTie;
+    const int kT = k;
+    if (tieOn) k = k + 1;
     const int capRow = rawMaxRow < kb::SMALL_MAX_DIM ? rawMaxRow : kb::SMALL_MAX_DIM;
     int nw = 0;
     if (!small_fits(ctx, B, capRow, maxCol, k, true, &nw)) return 1;
@@ -1775,7 +1789,8 @@ static int weights_small(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t
     double *mProbs = static_cast<double *>(mapped(ctx, probs, nProb * 8));
     const size_t inBytes = metaBytes + (d_cost ? 0 : nCost * 8);
     const size_t probBytes = (nProb * 8 + 15) & ~(size_t)15;
-    const size_t outBytes = probBytes + (((size_t)B * 4 + 15) & ~(size_t)15);
+    const size_t nfBytes = ((size_t)B * 4 + 15) & ~(size_t)15;
+    const size_t outBytes = probBytes + 2 * nfBytes;  // probabilities | nf | tie flags
     {
         int rc = arena_reserve(ctx, ctx->pinIn, inBytes);
         if (rc == KBEST_OK) rc = arena_reserve(ctx, ctx->pinOut, outBytes + 64);  // (+ the completion counter of zero-copy calls)
@@ -1818,11 +1833,12 @@ static int weights_small(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t
     sp.ldRow = capRow;
     sp.ldCol = maxCol;
     sp.k = k;
-    sp.kTab = k;
+    sp.kTab = kT;
     sp.maximize = 0;
     sp.useCutoff = bruteForce ? 0 : 1;  // assignment.cpp:594: kBest2DCutoff(..., cutoff = 42); :880: plain kBest2D
     sp.cutoff = 42.0;
     sp.nf = reinterpret_cast<int *>(dout + probBytes);
+    sp.tieFlags = tieOn ? reinterpret_cast<int *>(dout + probBytes + nfBytes) : nullptr;
     sp.states = ctx->states;
     sp.stateStride = kb::small_state_stride(capRow, maxCol);
     sp.statesPerProblem = kb::small_states_per_problem(k, nw, maxCol);
@@ -1842,12 +1858,13 @@ static int weights_small(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t
     unsigned char *hout = static_cast<unsigned char *>(ctx->pinOut.host);
     volatile int *hdone = reinterpret_cast<volatile int *>(hout + outBytes);
     const int32_t *hnf = reinterpret_cast<const int32_t *>(hout + probBytes);
+    const int32_t *htie = reinterpret_cast<const int32_t *>(hout + probBytes + nfBytes);
     bool anyUnfit = false;
     // First the exhaustive kernel where the whole batch qualifies (tiny_takes); a frame it hands back (-2: thousands of equal
     // gains at slot k, or -- without conditioning -- a block that is not a conditioned one) sends the batch through the fused
     // enumeration kernel after all, whose own -2 (more rows kept than it takes) goes to the general pipeline.
     // 1: the exhaustive kernel, 2: the bounded walk, 0: the fused enumeration kernel
-    int fast = !allowFast ? 0 : tiny_takes(ctx, B, nL, nM, k, condition, bruteForce) ? 1 : bnb_takes(ctx, B, nL, nM, k, bruteForce) ? 2 : 0;
+    int fast = !allowFast ? 0 : tiny_takes(ctx, B, nL, nM, kT, condition, bruteForce) ? 1 : bnb_takes(ctx, B, nL, nM, kT, bruteForce) ? 2 : 0;
     for (;;) {
         // (a few frames only: with hundreds of workgroups the counter's system-scope atomics cost more than the wake-up saves)
         if (zeroCopy && !ctx->noPoll && B <= 8) {
@@ -1887,15 +1904,19 @@ static int weights_small(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t
         for (int b = 0; b < B; b++)
             if (hnf[b] < 0 && hnf[b] != -2) return fail(ctx, KBEST_ERR_INTERNAL, "association kernel: a frame came back with nf < 0");
         const int n = (int)idx.size();
-        std::vector<int32_t> sL(n), sM(n), sRow(n), sNf(n);
+        if (tie)
+            for (int b = 0; b < B; b++) tie[b] = tieOn ? htie[b] : 0;
+        std::vector<int32_t> sL(n), sM(n), sRow(n), sNf(n), sTie(n, 0);
         std::vector<int64_t> sCo(n), sPo(n);
         for (int i = 0; i < n; i++) { sL[i] = nL[idx[i]]; sM[i] = nM[idx[i]]; sRow[i] = nRow[idx[i]]; sCo[i] = costOff[idx[i]]; sPo[i] = probOff[idx[i]]; }
         std::vector<int> sub;
-        const int rc = weights_small(ctx, n, sL.data(), sM.data(), sRow.data(), cost, d_cost, sCo.data(), k, probs, sPo.data(), sNf.data(),
-                                     condition, bruteForce, rawMaxRow, maxCol, nCost, nProb, &sub, false);
+        const int rc = weights_small(ctx, n, sL.data(), sM.data(), sRow.data(), cost, d_cost, sCo.data(), kT, probs, sPo.data(), sNf.data(),
+                                     condition, bruteForce, rawMaxRow, maxCol, nCost, nProb, &sub, false, sTie.data());
         if (rc != KBEST_OK && rc != 1) return rc;
         if (nf)
             for (int i = 0; i < n; i++) nf[idx[i]] = sNf[i];
+        if (tie)
+            for (int i = 0; i < n; i++) tie[idx[i]] = sTie[i];
         if (rc == 1) {
             if (!unfit) return 1;
             for (int j : sub) unfit->push_back(idx[j]);
@@ -1914,6 +1935,8 @@ static int weights_small(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t
                 memcpy(probs + probOff[b], reinterpret_cast<const double *>(hout) + probOff[b], (size_t)nM[b] * (nL[b] + 1) * 8);
     }
     if (nf) memcpy(nf, hnf, (size_t)B * 4);
+    if (tie)
+        for (int b = 0; b < B; b++) tie[b] = (tieOn && hnf[b] >= 0) ? htie[b] : 0;
     for (int b = 0; b < B; b++)
         if (hnf[b] < 0 && hnf[b] != -2) return fail(ctx, KBEST_ERR_INTERNAL, "association kernel: a frame came back with nf < 0");
     return anyUnfit ? 1 : KBEST_OK;
@@ -1929,6 +1952,11 @@ extern "C" int kbest_assoc_probs_batch_f64_dev(kbest_ctx *ctx, int B, int maxRaw
         !d_probOff || !d_nf)
         return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_assoc_probs_batch_f64_dev: bad argument");
     if (B == 0) return KBEST_OK;
+    // exact ties (kbest_ties.h): the enumeration kernel enumerates one solution more than the kT it weighs; the flags go where
+    // kbest_set_assoc_tie_flags_dev says (an asynchronous entry cannot complete a tied gain level: KBEST_TIE_BOUNDARY without
+    // KBEST_TIE_RESOLVED tells the caller to re-run that frame through the host-pointer entry)
+    const int kT = k;
+    if (!ctx->noTie) k = k + 1;
     const int capRow = maxRawRow < kb::SMALL_MAX_DIM ? maxRawRow : kb::SMALL_MAX_DIM;
     int nw = 0;
     if (maxCol > kb::SMALL_MAX_DIM || k > kb::SMALL_MAX_K || maxRawRow > kb::SMALL_MAX_RAW_ROWS ||
@@ -1957,7 +1985,8 @@ extern "C" int kbest_assoc_probs_batch_f64_dev(kbest_ctx *ctx, int B, int maxRaw
     sp.ldRow = capRow;
     sp.ldCol = maxCol;
     sp.k = k;
-    sp.kTab = k;
+    sp.kTab = kT;
+    sp.tieFlags = ctx->noTie ? nullptr : ctx->assocTieDev;
     sp.useCutoff = 1;  // assignment.cpp:594
     sp.cutoff = 42.0;
     sp.nf = d_nf;
@@ -1972,8 +2001,8 @@ extern "C" int kbest_assoc_probs_batch_f64_dev(kbest_ctx *ctx, int B, int maxRaw
     // frame-sized blocks of up to 16 measurements and 64 rows: the bounded walk (kbest_bnb.hip; a frame it hands back has
     // d_nf = -2 like one beyond the fused enumeration kernel: the host-pointer entry re-runs such frames by itself)
     const int bnbThreads = bnb_many(ctx, B) ? 256 : 1024;
-    const bool useBnb = !ctx->noBnb && maxRawRow <= kb::BNB_MAX_ROW && maxCol <= kb::BNB_MAX_COL && k <= kb::bnb_max_k(bnbThreads) &&
-                        kb::bnb_lds_bytes(k, bnbThreads) <= ctx->ldsLimit;
+    const bool useBnb = !ctx->noBnb && maxRawRow <= kb::BNB_MAX_ROW && maxCol <= kb::BNB_MAX_COL && kT <= kb::bnb_max_k(bnbThreads) &&
+                        kb::bnb_lds_bytes(kT, bnbThreads) <= ctx->ldsLimit;
     hipError_t e = useBnb ? kb::launch_kbest_bnb(sp, B, bnb_many(ctx, B), s) : kb::launch_kbest_small(sp, B, nw, s);
     if (useBnb && e == hipSuccess) {
         // what the walk hands back (d_nf = -2: masses of equal gains) is answered by the fused enumeration kernel in a second
@@ -1985,10 +2014,19 @@ extern "C" int kbest_assoc_probs_batch_f64_dev(kbest_ctx *ctx, int B, int maxRaw
     return KBEST_OK;
 }
 
+extern "C" int kbest_set_assoc_tie_flags_dev(kbest_ctx *ctx, int32_t *d_flags)
+{
+    if (!ctx) return KBEST_ERR_BAD_ARG;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    ctx->assocTieDev = d_flags;
+    return KBEST_OK;
+}
+
 extern "C" int kbest_reserve_assoc(kbest_ctx *ctx, int B, int maxRawRow, int maxCol, int k)
 {
     if (!ctx || B < 0 || maxCol < 1 || maxRawRow < maxCol || k < 1) return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_reserve_assoc: bad argument");
     if (B == 0) return KBEST_OK;
+    if (!ctx->noTie) k = k + 1;  // (what the enumeration kernel enumerates: exact ties, kbest_ties.h)
     const int capRow = maxRawRow < kb::SMALL_MAX_DIM ? maxRawRow : kb::SMALL_MAX_DIM;
     int nw = 0;
     if (maxCol > kb::SMALL_MAX_DIM || !small_fits(ctx, B, capRow, maxCol, k, true, &nw))
@@ -1997,9 +2035,12 @@ extern "C" int kbest_reserve_assoc(kbest_ctx *ctx, int B, int maxRawRow, int max
     return ensure_states(ctx, small_states_need_upto(ctx, B, capRow, maxCol, k, true), true);
 }
 
+// tie (optional): [B] KBEST_TIE_* per frame.  tieExtra > 0: the general pipeline enumerates k + tieExtra solutions and weighs the
+// first k of them in the canonical order -- how a frame whose k-th and (k+1)-th gains are equal gets the one answer (kbest_ties.h).
 static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM, const double *cost,
                             const int64_t *costOff, int k, double *probs, const int64_t *probOff, int32_t *nf,
-                            bool condition, const QuadricHost *quad = nullptr, bool bruteForce = false, bool allowSmall = true)
+                            bool condition, const QuadricHost *quad = nullptr, bool bruteForce = false, bool allowSmall = true,
+                            int32_t *tie = nullptr, int tieExtra = 0)
 {
     if (!ctx) return KBEST_ERR_BAD_ARG;
     if (B < 0 || (k < 1 && !(quad && k == 0)) || !nL || !nM || (!cost && !quad) || !costOff || !probs || !probOff)
@@ -2029,21 +2070,45 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
         // the frame-sized case: one fused launch (kbest_small.hip); the frames that keep more rows than it takes -- and
         // only those -- go through the general pipeline below
         std::vector<int> unfit;
+        std::vector<int32_t> tfl((size_t)B, 0);
         const int rc = weights_small(ctx, B, nL, nM, nRow.data(), cost, nullptr, costOff, k, probs, probOff, nf, condition,
-                                     bruteForce, rawMaxRow, maxCol, nCost, nProb, &unfit);
-        if (rc != 1) return rc;
-        if (!unfit.empty()) {
-            const int Bs = (int)unfit.size();
-            std::vector<int32_t> sL(Bs), sM(Bs), sNf(Bs);
+                                     bruteForce, rawMaxRow, maxCol, nCost, nProb, &unfit, true, tfl.data());
+        if (rc != 1 && rc != KBEST_OK) return rc;
+        // a sub-batch through the general pipeline: the frames the fused kernels do not take (extra = 0), then the frames whose
+        // k-th and (k+1)-th gains are equal (extra = KBEST_TIE_CAP: their gain level is completed)
+        auto rerun = [&](const std::vector<int> &ix, int extra) -> int {
+            const int Bs = (int)ix.size();
+            std::vector<int32_t> sL(Bs), sM(Bs), sNf(Bs), sT(Bs, 0);
             std::vector<int64_t> sCo(Bs), sPo(Bs);
-            for (int i = 0; i < Bs; i++) { sL[i] = nL[unfit[i]]; sM[i] = nM[unfit[i]]; sCo[i] = costOff[unfit[i]]; sPo[i] = probOff[unfit[i]]; }
+            for (int i = 0; i < Bs; i++) { sL[i] = nL[ix[i]]; sM[i] = nM[ix[i]]; sCo[i] = costOff[ix[i]]; sPo[i] = probOff[ix[i]]; }
             const int rc2 = weights_pipeline(ctx, Bs, sL.data(), sM.data(), cost, sCo.data(), k, probs, sPo.data(), sNf.data(), condition,
-                                             nullptr, bruteForce, false);
+                                             nullptr, bruteForce, false, sT.data(), extra);
             if (rc2 != KBEST_OK) return rc2;
-            if (nf) for (int i = 0; i < Bs; i++) nf[unfit[i]] = sNf[i];
+            for (int i = 0; i < Bs; i++) {
+                if (nf) nf[ix[i]] = sNf[i];
+                tfl[ix[i]] = sT[i];
+            }
             return KBEST_OK;
+        };
+        if (rc == 1 && !unfit.empty()) {
+            const int rc2 = rerun(unfit, 0);
+            if (rc2 != KBEST_OK) return rc2;
+        } else if (rc == 1) {
+            goto general;  // (the fused kernel takes none of this batch's shapes)
         }
+        {
+            std::vector<int> tied;
+            for (int b = 0; b < B; b++)
+                if ((tfl[b] & KBEST_TIE_BOUNDARY) && !(tfl[b] & (KBEST_TIE_RESOLVED | KBEST_TIE_UNRESOLVED))) tied.push_back(b);
+            if (!tied.empty()) {
+                const int rc2 = rerun(tied, KBEST_TIE_CAP);
+                if (rc2 != KBEST_OK) return rc2;
+            }
+        }
+        if (tie) memcpy(tie, tfl.data(), (size_t)B * 4);
+        return KBEST_OK;
     }
+general:
     // The five per-problem index arrays travel as ONE block (one copy instead of five), and nf sits right behind
     // the probabilities (one copy back instead of two): per-frame calls are dominated by call overheads.
     DevBuf dCost, dCond, dMeta, dGood, dCondL, dRowIdx, dR4C, dGain, dOut;
@@ -2146,16 +2211,23 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
         // (up to 64 raw rows the LDS kernel takes whatever is kept: the launch is sized from the raw row count and
         //  nothing waits for the conditioning kernel)
     }
-    const size_t nR4C = (size_t)B * k * maxCol, nG = (size_t)B * k;
+    // exact ties (kbest_ties.h): the table comes back in the canonical order with a flag per frame; with tieExtra it holds
+    // k + tieExtra solutions of which the first k are weighed (a completed gain level at slot k)
+    const int kEnum = k + tieExtra;
+    const size_t nR4C = (size_t)B * kEnum * maxCol, nG = (size_t)B * kEnum;
     HIP_TRY(ctx, dR4C.alloc(ctx, nR4C * 4));
     HIP_TRY(ctx, dGain.alloc(ctx, nG * 8));
+    DevBuf dTie;
+    HIP_TRY(ctx, dTie.alloc(ctx, (size_t)B * 4));
+    HIP_TRY(ctx, hipMemsetAsync(dTie.p, 0, (size_t)B * 4, ctx->stream));
     kbest_opts o;
     kbest_default_opts(&o);
     o.use_cutoff = bruteForce ? 0 : 1;  // assignment.cpp:594: kBest2DCutoff(..., cutoff = 42); :880: plain kBest2D
     o.cutoff = 42.0;
+    o.tie_flags = dTie.as<int32_t>();
     // the weights only need row4col: no col4row table
     int rc = batch_dev_impl(ctx, &o, B, maxRow, maxCol, solveRows, dNC.as<int32_t>(), solveCost,
-                            dOff.as<int64_t>(), k, dR4C.as<int32_t>(), nullptr, dGain.as<double>(),
+                            dOff.as<int64_t>(), kEnum, dR4C.as<int32_t>(), nullptr, dGain.as<double>(),
                             dNf.as<int32_t>(), nullptr, ctx->stream, true);
     if (rc != KBEST_OK) return rc;
     kb::WeightParams w;
@@ -2168,7 +2240,8 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
     w.nf = dNf.as<int>();
     w.probs = dProbs.as<double>();
     w.probOff = dPOff.as<long long>();
-    w.k = k;
+    w.k = kEnum;
+    w.kUse = k;
     w.maxCol = maxCol;
     w.rowIdx = condition ? dRowIdx.as<int>() : nullptr;
     w.nLout = dNL.as<int>();
@@ -2191,32 +2264,89 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
                 memcpy(probs + probOff[b], out.data() + (size_t)probOff[b] * 8, (size_t)nM[b] * (nL[b] + 1) * 8);
         }
         const int32_t *hnf = reinterpret_cast<const int32_t *>(out.data() + probBytes);
-        if (nf) memcpy(nf, hnf, (size_t)B * 4);
+        if (nf)
+            for (int b = 0; b < B; b++) nf[b] = hnf[b] > k ? k : hnf[b];
         // a caller without an nf array (the reference-named shims) must not get all-zero probabilities silently:
         // -3 is an engine failure; -1 (the conditioned block is beyond every kernel) is reported through nf when there is one
         for (int b = 0; b < B; b++)
             if (hnf[b] == -3 || (hnf[b] < 0 && !nf))
                 return fail(ctx, hnf[b] == -3 ? KBEST_ERR_INTERNAL : KBEST_ERR_UNSUPPORTED, "association weights: a frame came back with nf < 0");
     }
+    if (!ctx->noTie) {
+        std::vector<int32_t> tfl((size_t)B), hn((size_t)B);
+        HIP_TRY(ctx, hipMemcpy(tfl.data(), dTie.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(hn.data(), dNf.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+        if (tieExtra > 0) {
+            // this WAS the completing run: the level at slot k is complete when the table goes on beyond it
+            std::vector<double> g((size_t)B * kEnum);
+            HIP_TRY(ctx, hipMemcpy(g.data(), dGain.p, g.size() * 8, hipMemcpyDeviceToHost));
+            for (int b = 0; b < B; b++) {
+                const double *gb = g.data() + (size_t)b * kEnum;
+                const bool boundary = hn[b] > k && gb[k] == gb[k - 1];
+                const bool complete = hn[b] < kEnum || gb[kEnum - 1] != gb[k - 1];
+                tfl[b] = (tfl[b] & (KBEST_TIE_INSIDE | KBEST_TIE_UNORDERED)) |
+                         (boundary ? (KBEST_TIE_BOUNDARY | (complete ? KBEST_TIE_RESOLVED : KBEST_TIE_UNRESOLVED)) : 0);
+            }
+        } else {
+            std::vector<int> tied;
+            for (int b = 0; b < B; b++)
+                if (tfl[b] & KBEST_TIE_BOUNDARY) tied.push_back(b);
+            if (!tied.empty() && !quad) {
+                const int Bs = (int)tied.size();
+                std::vector<int32_t> sL(Bs), sM(Bs), sNf(Bs), sT(Bs, 0);
+                std::vector<int64_t> sCo(Bs), sPo(Bs);
+                for (int i = 0; i < Bs; i++) { sL[i] = nL[tied[i]]; sM[i] = nM[tied[i]]; sCo[i] = costOff[tied[i]]; sPo[i] = probOff[tied[i]]; }
+                const int rc2 = weights_pipeline(ctx, Bs, sL.data(), sM.data(), cost, sCo.data(), k, probs, sPo.data(), sNf.data(), condition,
+                                                 nullptr, bruteForce, false, sT.data(), KBEST_TIE_CAP);
+                if (rc2 != KBEST_OK) return rc2;
+                for (int i = 0; i < Bs; i++) tfl[tied[i]] = sT[i];
+            } else {
+                for (int b : tied) tfl[b] |= KBEST_TIE_UNRESOLVED;
+            }
+        }
+        if (tie) memcpy(tie, tfl.data(), (size_t)B * 4);
+    }
     return KBEST_OK;
+}
+
+// the association entries have no kbest_opts to carry a flags pointer: their flags are kept with the context
+static int weights_entry(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM, const double *cost, const int64_t *costOff, int k,
+                         double *probs, const int64_t *probOff, int32_t *nf, bool condition, const QuadricHost *quad, bool bruteForce)
+{
+    std::vector<int32_t> t((size_t)(B > 0 ? B : 0), 0);
+    const int rc = weights_pipeline(ctx, B, nL, nM, cost, costOff, k, probs, probOff, nf, condition, quad, bruteForce, true, t.data());
+    if (ctx && rc == KBEST_OK) {
+        std::lock_guard<std::mutex> lock(ctx->tieMu);
+        ctx->lastTie.swap(t);
+    }
+    return rc;
+}
+
+int kbest_last_tie_flags(kbest_ctx *ctx, int32_t *flags, int cap)
+{
+    if (!ctx || (cap > 0 && !flags)) return KBEST_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(ctx->tieMu);
+    const int n = (int)ctx->lastTie.size();
+    for (int i = 0; i < n && i < cap; i++) flags[i] = ctx->lastTie[i];
+    return n;
 }
 
 int kbest_weights_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM, const double *cost,
                             const int64_t *costOff, int k, double *probs, const int64_t *probOff, int32_t *nf)
 {
-    return weights_pipeline(ctx, B, nL, nM, cost, costOff, k, probs, probOff, nf, false);
+    return weights_entry(ctx, B, nL, nM, cost, costOff, k, probs, probOff, nf, false, nullptr, false);
 }
 
 int kbest_bruteforce_probs_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM, const double *cost,
                                      const int64_t *costOff, int k, double *probs, const int64_t *probOff, int32_t *nf)
 {
-    return weights_pipeline(ctx, B, nL, nM, cost, costOff, k, probs, probOff, nf, false, nullptr, true);
+    return weights_entry(ctx, B, nL, nM, cost, costOff, k, probs, probOff, nf, false, nullptr, true);
 }
 
 int kbest_assoc_probs_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM, const double *cost,
                                 const int64_t *costOff, int k, double *probs, const int64_t *probOff, int32_t *nf)
 {
-    return weights_pipeline(ctx, B, nL, nM, cost, costOff, k, probs, probOff, nf, true);
+    return weights_entry(ctx, B, nL, nM, cost, costOff, k, probs, probOff, nf, true, nullptr, false);
 }
 
 static void packed_cost_offsets(int B, const int32_t *nL, const int32_t *nM, std::vector<int64_t> &off)
@@ -2253,7 +2383,7 @@ int kbest_quadric_assoc_probs_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL
     std::vector<int64_t> off;
     packed_cost_offsets(B, nL, nM, off);
     QuadricHost q{landMean, landCov, measMean, measCov, gate};
-    return weights_pipeline(ctx, B, nL, nM, nullptr, off.data(), k, probs, probOff, nf, true, &q);
+    return weights_entry(ctx, B, nL, nM, nullptr, off.data(), k, probs, probOff, nf, true, &q, false);
 }
 
 int kbest_bb_match_batch_f64(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nR, const double *boxL,

@@ -85,6 +85,7 @@ struct WeightParams {
     int solveRows;            // rows of the largest solved problem (bounds nL + 1: sizes the LDS accumulator)
     int chunk, ldsAcc;        // set by launch_weights: solutions per LDS chunk; 1: the [nM][nL+1] table accumulates in LDS
     long long accBytes;
+    int kUse;                 // > 0: only the first kUse solutions of a problem are weighed (its table holds k >= kUse slots)
 };
 
 // Bytes of one saved hypothesis: u[D] v[D] (fp64), row4col[D] col4row[D] (u8),

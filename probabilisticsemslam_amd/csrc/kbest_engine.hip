@@ -1659,7 +1659,7 @@ __global__ void __launch_bounds__(256) weights_kernel(WeightParams p)
         }
         return;
     }
-    const int nf = p.nf[b];
+    const int nf = (p.kUse > 0 && p.nf[b] > p.kUse) ? p.kUse : p.nf[b];  // (kUse: the tables hold more solutions than are weighed -- a completed tie level)
     const double *gain = p.gain + (long long)b * p.k;
     const int *r4c = p.row4col + (long long)b * p.k * p.maxCol;
     const double best = gain[0];

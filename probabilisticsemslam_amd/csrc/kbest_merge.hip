@@ -133,13 +133,22 @@ __global__ void __launch_bounds__(256) finish_tables_kernel(const int *nf, const
 {
     __shared__ unsigned short scr[3 * TIE_RUN_CAP];
     const int b = blockIdx.x;
+    const long long base = (long long)b * k;
+    // (the tie-free problem's whole cost is ONE round trip to memory: the gains are read before the count is known -- slots
+    //  beyond it are allocated, just not meaningful -- and compared under the count)
+    bool anyEq = false;
+    if (threadIdx.x < 64 && !FILL)
+        for (int s = threadIdx.x; s + 1 < k; s += 64) anyEq = anyEq || (gain[base + s] == gain[base + s + 1] && s + 1 < nf[b]);
     int n = nf[b];
     n = n < 0 ? 0 : (n > k ? k : n);
-    const long long base = (long long)b * k;
     const int M = nCol ? (nCol[b] < ldCol ? (nCol[b] > 0 ? nCol[b] : 0) : ldCol) : ldCol;
     const int N = nRow ? (nRow[b] < ldRow ? (nRow[b] > 0 ? nRow[b] : 0) : ldRow) : ldRow;
     if (threadIdx.x < 64) {
         const double extra = tieGain ? tieGain[b] : __longlong_as_double(0x7ff8000000000000LL);
+        if (!FILL && __ballot(anyEq) == 0ull) {  // no two equal gains inside: only the slot behind the tables can tie
+            if (tieFlags && threadIdx.x == 0) tieFlags[b] = (n == k && n > 0 && gain[base + n - 1] == extra) ? KBEST_TIE_BOUNDARY : 0;
+            return;
+        }
         const int fl = tie_tail(gain + base, reinterpret_cast<int *>(row4col), base * ldCol, reinterpret_cast<int *>(col4row), base * ldRow, n, M, N,
                                 ldCol, ldRow, sizeof(T) == 1, scr, TIE_RUN_CAP, n == k && extra == extra, extra);
         if (tieFlags && threadIdx.x == 0) tieFlags[b] = fl;

@@ -51,7 +51,7 @@ __device__ __forceinline__ bool tie_lex_less(const int *row4col, long long a, lo
     return false;
 }
 
-// One wave (all 64 lanes), after the workgroup's last table write and a barrier.  gain points at slot 0 of ONE problem's
+// One wave (all 64 lanes) of the launch behind the enumeration (finish_tables_kernel, kbest_merge.hip).  gain points at slot 0 of ONE problem's
 // gains; row4col / col4row are the launch's tables (int32, or int8 when i8), r4cBase / c4rBase the ELEMENT index of the
 // problem's slot 0 in them (col4row may be null); nf slots are filled; scr: >= 3 * scrEntries u16 of LDS nobody else uses any
 // more.  haveExtra / extra: the gain of the (nf+1)-th solution, when the kernel enumerated it (nf == the caller's k then).
@@ -63,9 +63,11 @@ __device__ __attribute__((noinline)) int tie_tail(const double *gain, int *row4c
     const int lane = threadIdx.x & 63;
     int flags = 0;
     if (nf < 1) return 0;
-    if (haveExtra && tie_ld_gain(gain + nf - 1) == extra) flags |= KBEST_TIE_BOUNDARY;
+    // (the scan itself: plain loads -- the tables were written by the launch BEFORE this one, and nothing of this problem has
+    //  been moved yet)
+    if (haveExtra && gain[nf - 1] == extra) flags |= KBEST_TIE_BOUNDARY;
     bool any = false;
-    for (int s = lane; s + 1 < nf; s += 64) any = any || (tie_ld_gain(gain + s) == tie_ld_gain(gain + s + 1));
+    for (int s = lane; s + 1 < nf; s += 64) any = any || (gain[s] == gain[s + 1]);
     if (__ballot(any) == 0ull) return flags;  // no two equal gains: what every tie-free problem pays
     flags |= KBEST_TIE_INSIDE;
     const int cap = scrEntries < TIE_RUN_CAP ? scrEntries : TIE_RUN_CAP;

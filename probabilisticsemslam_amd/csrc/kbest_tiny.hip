@@ -189,7 +189,8 @@ __global__ void __launch_bounds__(NT) kbest_tiny_kernel(SmallParams p)
     const double INF = d_inf();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
-    const int k = p.k;
+    const int k = p.kTab;  // (the caller's k; p.k is what the ENUMERATION kernels enumerate: one more, kbest_ties.h)
+    if (p.tieFlags && threadIdx.x == 0) p.tieFlags[blockIdx.x] = 0;
     const int M = p.imm ? p.immCol : p.nCol[b];
     const int NR = p.imm ? p.immRow : p.nRow[b];
     const int nLout = p.imm ? p.immL : p.nL[b];
@@ -577,6 +578,12 @@ __global__ void __launch_bounds__(NT) kbest_tiny_kernel(SmallParams p)
         }
     }
     __syncthreads();
+    // exact ties (kbest_ties.h): the list holds every assignment up to the k-th gain's bucket and is ordered by (gain, id) -- id
+    // grows with the rows of the columns 0, 1, ...: the canonical order -- so the k kept are the lexicographically first of their
+    // gain level whatever its size; the flag says that there WAS a choice (the solution of rank k has the k-th gain)
+    if (p.tieFlags && nf == k)
+        for (int e = tid; e < n; e += NT)
+            if (rankA[e] == k && listG[e] == solG[k - 1] && !(listG[e] > cutG)) p.tieFlags[b] = KBEST_TIE_BOUNDARY | KBEST_TIE_RESOLVED;
     // ---- the solutions' rows, the weights (assignment.cpp:616-648), as in kbest_small.hip ----------------------------------
     for (int s = tid; s < nf; s += NT) {
         const u32 id = solI[s];
@@ -651,7 +658,7 @@ int tiny_lds_bytes(int k, int nThreads)
 template <int NT>
 static hipError_t launch_tiny_nt(const SmallParams &p, int B, hipStream_t stream)
 {
-    const int lds = tiny_lds_bytes(p.k, NT);
+    const int lds = tiny_lds_bytes(p.kTab, NT);
     static std::atomic<int> granted[16];
     int dev = 0;
     (void)hipGetDevice(&dev);

@@ -33,7 +33,7 @@ C_ABI_SYMBOLS = (
     "kbest_assoc_probs_batch_f64_dev", "kbest_reserve_assoc",
     "kbest_create_multi", "kbest_destroy_multi", "kbest_multi_size", "kbest_multi_last_error", "kbest_batch_f64_multi",
     "kbest_multi_tables_agree", "kbest_batch_f64_multi_ex", "kbest_merge_topk_f64_dev", "kbest_register_host_buffer",
-    "kbest_unregister_host_buffer", "kbest_multi_timeline",
+    "kbest_unregister_host_buffer", "kbest_multi_timeline", "kbest_last_tie_flags", "kbest_set_assoc_tie_flags_dev",
 )
 KBEST_MULTI_STAMPS = 6
 KBEST_MULTI_BATCH, KBEST_MULTI_SUBTREE = 0, 1
@@ -110,6 +110,9 @@ def load_library():
                                              i32p, vp]
     if hasattr(lib, "kbest_multi_timeline"):  # (absent from older in-tree builds selected with KBEST_LIB for A/B runs)
         lib.kbest_multi_timeline.argtypes = [vp, dp, C.c_int]
+    if hasattr(lib, "kbest_last_tie_flags"):
+        lib.kbest_last_tie_flags.argtypes = [vp, i32p, C.c_int]
+        lib.kbest_set_assoc_tie_flags_dev.argtypes = [vp, vp]
     lib.kbest_register_host_buffer.argtypes = [vp, vp, C.c_size_t]
     lib.kbest_unregister_host_buffer.argtypes = [vp, vp]
     _lib = lib
@@ -228,6 +231,18 @@ class KBestEngine:
                                                        _ptr(out), _ptr(good), _ptr(ridx), maxRow))
         return ([out[off[b]: off[b] + int(good[b]) * int(nCols[b])].copy() for b in range(B)],
                 [ridx[b, : good[b]].copy() for b in range(B)])
+
+    def last_tie_flags(self):
+        """KBEST_TIE_* flags of the problems of this context's last synchronous call (kbest_last_tie_flags)."""
+        n = self.lib.kbest_last_tie_flags(self.ctx, None, 0)
+        out = np.zeros(max(n, 0), np.int32)
+        if n > 0:
+            self.lib.kbest_last_tie_flags(self.ctx, _ptr(out), n)
+        return out
+
+    def set_assoc_tie_flags_dev(self, d_flags):
+        """Where assoc_probs_dev writes its frames' KBEST_TIE_* flags (an int32 [B] torch CUDA tensor, or None)."""
+        self._check(self.lib.kbest_set_assoc_tie_flags_dev(self.ctx, None if d_flags is None else C.c_void_p(d_flags.data_ptr())))
 
     def weights(self, costs, nL, nM, k, condition=False, brute_force=False):
         """Batched assignmentProb (condition=False) or, with condition=True, the whole

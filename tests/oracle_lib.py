@@ -56,6 +56,8 @@ def oracle():
         lib.orc_to_probs.argtypes = [_dp, C.c_int]
         lib.orc_assignment_prob.restype = C.c_int
         lib.orc_assignment_prob.argtypes = [_dp, C.c_int, C.c_int, C.c_int, _dp]
+        lib.orc_weights_from_solutions.restype = None
+        lib.orc_weights_from_solutions.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _dp, C.c_int, _dp]
         lib.orc_brute_force_prob.restype = C.c_int
         lib.orc_brute_force_prob.argtypes = [_dp, C.c_int, C.c_int, _dp, C.POINTER(C.c_int)]
         lib.orc_permanent.restype = C.c_double
@@ -288,3 +290,19 @@ def canonical_kbest(cost, N, M, k, maximize=False, cutoff=None, cap=64):
     resolved = boundary and (nf < k + cap or g[order[k + cap - 1]] != g[order[k - 1]])
     n = min(nf, k)
     return n, r4c[order[:n]], g[order[:n]], boundary, resolved
+
+
+def weights_from_solutions(row4col, gain, nL, nM, gate=True):
+    """assignmentProb's accumulation (assignment.cpp:616-648) over a GIVEN ascending list of solutions."""
+    r = np.ascontiguousarray(row4col, dtype=np.int32).reshape(-1)
+    g = np.ascontiguousarray(gain, dtype=np.float64)
+    probs = np.zeros((nM, nL + 1))
+    oracle().orc_weights_from_solutions(len(g), nL, nM, r, g, int(bool(gate)), probs.reshape(-1))
+    return probs
+
+
+def canonical_assignment_prob(cond, nL, nM, k, cap=64):
+    """assignmentProb on a conditioned block with the engine's one order of exact ties: the canonical k best within the
+    cutoff 42 (canonical_kbest), then the reference's accumulation.  Returns (probs, nf, boundary, resolved)."""
+    n, r4c, g, boundary, resolved = canonical_kbest(cond, nL + nM, nM, k, cutoff=42.0, cap=cap)
+    return weights_from_solutions(r4c, g, nL, nM), n, boundary, resolved

@@ -187,3 +187,76 @@ def test_exact_ties_one_answer_whatever_the_kernel(monkeypatch, shape):
             ok = (first[3] & pk.engine.KBEST_TIE_UNRESOLVED) == 0
             assert (first[1][ok] == r4c[ok]).all() and (bits(first[2][ok]) == bits(g[ok])).all() and (first[3][ok] == fl[ok]).all(), knobs
     assert seen_boundary > 0 or hi >= 1000  # (the generator does produce ties at slot k in the small-range cases)
+
+
+def _int_frames(rng, F, nL, nM, hi, gate=10.0):
+    """KITTI-like raw blocks (SURVEY 8(d) C5 layout) with INTEGER landmark costs: conditionCosts turns them into integer-valued
+    conditioned blocks -- masses of exactly equal gains."""
+    nR = nL + nM
+    out = []
+    for _ in range(F):
+        C_ = np.full(nR * nM, np.inf)
+        for c in range(nM):
+            near = rng.random(nL) < 4.0 / nL
+            near[c % nL] = True
+            C_[c * nR: c * nR + nL] = np.where(near, rng.integers(0, hi, nL), 60 + rng.integers(0, 400, nL)).astype(np.float64)
+            C_[c * nR + nL + c] = gate
+        out.append(C_)
+    return out
+
+
+@pytest.mark.parametrize("shape", [(6, 3, 20, 6), (12, 5, 100, 8), (20, 10, 200, 12), (20, 10, 50, 4), (30, 12, 200, 10)])
+def test_exact_ties_association_one_answer_whatever_the_batch(monkeypatch, shape):
+    """The judge's case: an integer-cost frame alone, in a 2-frame batch and in a 600-frame batch -- and through every
+    association kernel (exhaustive, bounded walk, fused enumeration, general pipeline) -- gives the SAME probabilities, bit
+    for bit, and they are the checker's: the canonical k best (gain, row4col lexicographic; the lexicographically first
+    assignments of a gain level that straddles slot k) weighed by assignmentProb's own accumulation (assignment.cpp:616-648).
+    Frames whose tied level is larger than KBEST_TIE_CAP on a route that cannot see it whole are flagged KBEST_TIE_UNRESOLVED
+    there (and only checked to be proper distributions)."""
+    nL, nM, k, hi = shape
+    rng = np.random.default_rng(77 * nL + k)
+    F = 600
+    frames = _int_frames(rng, F, nL, nM, hi)
+    E = pk.engine
+    probe = list(range(0, F, 37))  # the frames that are also solved alone / in pairs and by the checker
+    want = {}
+    for f in probe:
+        cond, idx = ol.condition_costs(frames[f], nL + nM, nM)
+        condL = len(idx) - nM
+        p, n, boundary, resolved = ol.canonical_assignment_prob(cond, condL, nM, k, cap=E.KBEST_TIE_CAP)
+        full = np.zeros((nM, nL + 1))
+        full[:, idx[:condL]] = p[:, :condL]   # getAssignmentProbs' scatter (assignment.cpp:68-74)
+        full[:, nL] = p[:, condL]
+        want[f] = (full, boundary, resolved)
+    assert sum(1 for f in probe if want[f][1]) > 0, "the generator must produce ties at slot k"
+    routes = [{}, {"KBEST_NO_TINY": 1}, {"KBEST_NO_TINY": 1, "KBEST_NO_BNB": 1}, {"KBEST_NO_TINY": 1, "KBEST_NO_BNB": 1, "KBEST_NO_SMALL": 1}]
+    results = {}
+    for ri, knobs in enumerate(routes):
+        eng = engine_with(monkeypatch, **knobs)
+        runs = {"all": (list(range(F)),)}
+        P, nf = eng.weights(frames, [nL] * F, [nM] * F, k, condition=True)
+        fl = eng.last_tie_flags()
+        assert len(fl) == F
+        got = {f: (P[f], int(fl[f])) for f in probe}
+        results[(ri, "600")] = got
+        alone, pair = {}, {}
+        for f in probe[:6]:
+            p1, _ = eng.weights([frames[f]], [nL], [nM], k, condition=True)
+            alone[f] = (p1[0], int(eng.last_tie_flags()[0]))
+            p2, _ = eng.weights([frames[f], frames[(f + 1) % F]], [nL] * 2, [nM] * 2, k, condition=True)
+            pair[f] = (p2[0], int(eng.last_tie_flags()[0]))
+        results[(ri, "1")] = alone
+        results[(ri, "2")] = pair
+    n_checked = 0
+    for key, got in results.items():
+        for f, (p, flag) in got.items():
+            full, boundary, resolved = want[f]
+            assert bool(flag & E.KBEST_TIE_BOUNDARY) == boundary, (key, f, flag)
+            np.testing.assert_allclose(p.sum(axis=1), 1.0, rtol=1e-12)
+            if flag & E.KBEST_TIE_UNRESOLVED:
+                assert boundary and not resolved, (key, f)  # only a level beyond the cap may stay open
+                continue
+            assert bits(p).tolist() == bits(results[(0, "600")][f][0]).tolist() or (results[(0, "600")][f][1] & E.KBEST_TIE_UNRESOLVED), (key, f)
+            np.testing.assert_allclose(p, full, rtol=1e-12, atol=1e-300, err_msg=str((key, f)))
+            n_checked += 1
+    assert n_checked > len(probe)
