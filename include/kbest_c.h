@@ -30,13 +30,23 @@
  * solutions found is returned per problem, 0 = infeasible (cpp:588-593).
  * The solver never throws; negative return values are engine errors.
  *
- * Order of exact ties.  Hypotheses with EXACTLY equal gain have no defined relative order in the reference (it is
- * an artefact of std::priority_queue's binary heap, cpp:574).  The engine orders them deterministically -- old pool
- * entries before fresh ones, fresh ones by (parent hypothesis, column in the enumeration's own column order, DESIGN.md
- * section 2 point 8) -- which is in general NOT the reference's order.  For continuous costs ties have probability zero and every output is bit-identical; for integer-like costs
- * (conditionCosts produces exact zeros) the multiset of gains and the validity of every assignment are the
- * reference's, but when a tie group straddles slot k (or the best + cutoff gate) the emitted SET, and with it
- * assignmentProb's weights, may differ from the reference's by more than rounding.
+ * Order of exact ties.  Hypotheses with EXACTLY equal gain have no defined relative order in the reference (it is an
+ * artefact of std::priority_queue's binary heap, shortestPathCPP.cpp:30-42, 574; which of them fill the last slots of a
+ * call is an artefact too).  The engine defines one, the same in every kernel and for every batch a problem may travel in:
+ *   * solutions are ordered by (gain, row4col), row4col compared lexicographically in the reference's column order;
+ *   * when the k-th and the (k+1)-th best gains are equal -- the k best are then not a unique set -- the lexicographically
+ *     first assignments of that gain level are the ones kept.
+ * For continuous costs ties have probability zero and every output is the reference's, bit for bit.  For integer-like costs
+ * (conditionCosts produces exact zeros) the multiset of gains and the validity of every assignment are the reference's; the
+ * order inside a run of equal gains, and the members of a gain level that straddles slot k, are this rule's.
+ * How it is done: every enumeration launch enumerates ONE solution more than asked for (its gain only; measured free) and is
+ * followed by a small launch that brings runs of equal gains into the order above and reports, per problem, KBEST_TIE_* flags
+ * (kbest_opts.tie_flags).  A tie at slot k (KBEST_TIE_BOUNDARY) is completed by the SYNCHRONOUS entries themselves: the
+ * problem is enumerated again with k + KBEST_TIE_CAP solutions and the first k of the ordered table are kept
+ * (KBEST_TIE_RESOLVED; a level with more than KBEST_TIE_CAP members beyond k stays KBEST_TIE_UNRESOLVED: the emitted set is
+ * then one of several equally good ones and may depend on the kernel).  The asynchronous _dev entries only report the flags.
+ * The exhaustive association kernel and the bounded walk see a whole gain level and keep its lexicographically first
+ * members themselves, whatever its size.  KBEST_FLAG_NO_TIE_CHECK switches all of it off (the kernels' own orders, round 4).
  * Index outputs are int32 (the reference ABI uses ptrdiff_t; the C++ shims in
  * include/kbest_shims.hpp widen on the host).
  *
@@ -133,6 +143,8 @@ int kbest_device_count(void);
  *   d_nf      [B] int32   number found, 0 = infeasible (return value of kBest2D)
  *   d_pushed  [B] int64 or NULL; with KBEST_FLAG_COUNT_PUSHED the number of
  *             feasible children the reference would push (SURVEY 8(d) "P")
+ *   opts->tie_flags  [B] int32 in device memory or NULL: KBEST_TIE_* per problem (this entry reports a tie at slot k,
+ *             it cannot complete it: no synchronisation inside)
  *   stream    hipStream_t (NULL = the context's own stream).  Asynchronous:
  *             returns after enqueueing; no host synchronisation and no allocation
  *             inside -- the workspace must have been sized by kbest_reserve(B, maxRow, k)
@@ -239,9 +251,8 @@ int kbest_condition_costs_f64(kbest_ctx *ctx, int B, const int32_t *nRow, const 
  * call has so few assignments in all, (nL+nM)!/nL! <= 2^23 (and <= 2^15 choices for the first nM-2 columns) with
  * 2 <= nM <= 8 and nL+nM <= 64: the reference's real
  * frames of 3-5 measurements (README.md:11) -- the exhaustive kernel (kbest_tiny.hip), which looks at every assignment
- * instead of enumerating the k best: same gains bit for bit (calcGain's sum), same solutions, same probabilities; only
- * when two DIFFERENT assignments with exactly equal gains sit on both sides of slot k can the emitted sets differ (the
- * order of exact ties is the reference heap's artefact and unspecified there too).  KBEST_NO_TINY=1 at kbest_create
+ * instead of enumerating the k best: same gains bit for bit (calcGain's sum), same solutions, same probabilities -- exact
+ * ties included ("Order of exact ties" above: the flags of these entries are read with kbest_last_tie_flags).  KBEST_NO_TINY=1 at kbest_create
  * switches it off.  kbest_weights_batch_f64 on blocks that are conditioned already (all entries >= 0, an exact zero
  * somewhere: what conditionCosts returns and assignment.cpp:58-62 passes on) takes the same kernel; any other block
  * is answered by the enumeration kernels.

@@ -1095,7 +1095,7 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         p.k = k;
         p.maximize = opts->maximize;
         p.useCutoff = opts->use_cutoff;
-        p.flags = opts->flags;
+        p.flags = opts->flags | (ctx->noT0 ? KBEST_FLAG_NO_T0 : 0u) | (ctx->noReorder ? KBEST_FLAG_NO_REORDER : 0u);
         p.cutoff = opts->cutoff;
         p.rootColOffset = opts->root_col_offset;
         p.rootColStride = opts->root_col_stride;
@@ -1531,16 +1531,21 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
         }
         std::vector<char> sR((size_t)n * k2 * maxCol * esz), sC(col4row ? (size_t)n * k2 * maxRow * esz : 0);
         kbest_opts o2 = *opts;
-        o2.tie_flags = nullptr;
+        DevBuf dFlags2;
+        HIP_TRY(ctx, dFlags2.alloc(ctx, (size_t)n * 4));
+        o2.tie_flags = dFlags2.as<int32_t>();
         rc = kbest_batch_f64_keep(ctx, &o2, n, maxRow, maxCol, sRow.data(), sCol.data(), sCost.data(), sOff.data(), k2,
                                   reinterpret_cast<int32_t *>(sR.data()), col4row ? reinterpret_cast<int32_t *>(sC.data()) : nullptr, sGain.data(),
                                   sNf.data(), nullptr, nullptr);
         if (rc != KBEST_OK) return rc;
+        std::vector<int32_t> fl2((size_t)n);
+        HIP_TRY(ctx, hipMemcpy(fl2.data(), dFlags2.as<int32_t>(), (size_t)n * 4, hipMemcpyDeviceToHost));
         for (int i = 0; i < n; i++) {
             const int b = idx[i];
             const double *g2 = sGain.data() + (size_t)i * k2;
-            // the level is complete when the table goes on beyond it (or the problem has no more assignments)
-            const bool complete = sNf[i] < k2 || g2[k2 - 1] != g2[k - 1];
+            // the level is complete when the table goes on beyond it (or the problem has no more assignments) -- and the table is
+            // in the canonical order throughout (a run of more than 1 024 equal gains is left as the kernel emitted it)
+            const bool complete = (sNf[i] < k2 || g2[k2 - 1] != g2[k - 1]) && !(fl2[i] & KBEST_TIE_UNORDERED);
             if (sNf[i] < k) return fail(ctx, KBEST_ERR_INTERNAL, "kbest_batch_f64: the tie re-run found fewer solutions than the run before");
             memcpy(reinterpret_cast<char *>(row4col) + (size_t)b * k * maxCol * esz, sR.data() + (size_t)i * k2 * maxCol * esz, (size_t)k * maxCol * esz);
             if (col4row)
@@ -2283,7 +2288,7 @@ general:
             for (int b = 0; b < B; b++) {
                 const double *gb = g.data() + (size_t)b * kEnum;
                 const bool boundary = hn[b] > k && gb[k] == gb[k - 1];
-                const bool complete = hn[b] < kEnum || gb[kEnum - 1] != gb[k - 1];
+                const bool complete = (hn[b] < kEnum || gb[kEnum - 1] != gb[k - 1]) && !(tfl[b] & KBEST_TIE_UNORDERED);
                 tfl[b] = (tfl[b] & (KBEST_TIE_INSIDE | KBEST_TIE_UNORDERED)) |
                          (boundary ? (KBEST_TIE_BOUNDARY | (complete ? KBEST_TIE_RESOLVED : KBEST_TIE_UNRESOLVED)) : 0);
             }

@@ -775,6 +775,13 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
             if (tid == 0 && b < 4) printf("T0DBG b=%d round=%d t0gap=%.6f poolT=%.6f nOld=%d extra=%d\n", b, roundNo, ctrl->t0 - __longlong_as_double((long long)atoms[2 * D]),
                                           (ctrl->nq - ctrl->head >= k - ctrl->emitted) ? PG[ctrl->head + k - ctrl->emitted - 1] - __longlong_as_double((long long)atoms[2 * D]) : -1.0, ctrl->nq - ctrl->head, (int)atoms[2 * D + 1]);
 #endif
+            // Every wave must have LEFT the function before its scratch is re-armed: the waves return one by one (behind the
+            // function's last barrier each still reads the sorted atoms / the counters, through FLAT loads -- the function is
+            // not inlined and takes generic pointers), and a wave that re-armed the minima under a slower one's reads gave
+            // that wave another view of them.  Found in round 5 by the soak of 2-column frames at k = 1 025 (the first k
+            // beyond the fused kernel once every launch enumerates k + 1): one problem in ten thousand came back with nf = 2;
+            // with this barrier none in 560 000 (tests/test_gpu_round5.py::test_apriori_threshold_scratch_is_not_rearmed_early).
+            __syncthreads();
             for (int i = tid; i < spec * 64; i += NT) lbKey[i] = ~0ull;  // re-arm the filter minima
             __syncthreads();
         }

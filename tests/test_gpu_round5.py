@@ -260,3 +260,35 @@ def test_exact_ties_association_one_answer_whatever_the_batch(monkeypatch, shape
             np.testing.assert_allclose(p, full, rtol=1e-12, atol=1e-300, err_msg=str((key, f)))
             n_checked += 1
     assert n_checked > len(probe)
+
+
+def test_apriori_threshold_scratch_is_not_rearmed_early(monkeypatch):
+    """Regression (round 5): 700 ragged 2-column frames at k = 1 025 through the 64-row kernel's 8-wave shape -- the shape with
+    the a-priori threshold, whose LDS scratch the caller re-arms afterwards.  Without a barrier between the two, one problem
+    in ten thousand came back with nf = 2 (non-deterministically); the checker's counts are required on every problem of
+    every repetition."""
+    eng = engine_with(monkeypatch, KBEST_NO_SMALL=1, KBEST_NO_LANE=1)
+    rng = np.random.default_rng(11)
+    F = 700
+    for rep in range(40):
+        nL0 = int(rng.integers(3, 40))
+        conds = []
+        for _ in range(F):
+            nL = nL0 - int(rng.integers(0, 3))
+            nR = nL + 2
+            C_ = np.full(nR * 2, np.inf)
+            for c in range(2):
+                col = 60.0 + 400.0 * rng.random(nL)
+                pick = rng.random(nL) < 3.0 / max(nL, 1)
+                col[pick] = 12.0 * rng.random(pick.sum()) * rng.random(pick.sum())
+                C_[c * nR: c * nR + nL] = col
+                C_[c * nR + nL + c] = 10.0
+            conds.append(ol.condition_costs(C_, nR, 2)[0])
+        nRow = np.array([len(c) // 2 for c in conds], np.int32)
+        nCol = np.full(F, 2, np.int32)
+        off = np.zeros(F, np.int64)
+        off[1:] = np.cumsum(nRow[:-1].astype(np.int64) * 2)
+        flat = np.concatenate(conds)
+        nf, r4c, c4r, g = eng.kbest(flat, int(nRow.max()), 2, 1025, cutoff=42.0, nRow=nRow, nCol=nCol, costOff=off)
+        want = np.array([ol.orc_kbest(conds[f], int(nRow[f]), 2, 1025, cutoff=42.0)[0] for f in range(F)])
+        assert (nf == want).all(), (rep, np.nonzero(nf != want)[0][:5], nf[nf != want][:5], want[nf != want][:5])
