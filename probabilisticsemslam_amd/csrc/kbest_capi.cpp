@@ -672,7 +672,8 @@ int kbest_reserve(kbest_ctx *ctx, int B, int maxRow, int k)
     int rc = reserve_for(ctx, B, maxRow, k);
     if (rc != KBEST_OK || ctx->noTie) return rc;
     rc = reserve_for(ctx, B, maxRow, k + 1);
-    return rc != KBEST_OK ? rc : raw_reserve(ctx, ctx->tieBuf, (size_t)B * 8);
+    if (rc != KBEST_OK) return rc;
+    return raw_reserve(ctx, ctx->tieBuf, (size_t)B * 8);
 }
 
 static int reserve_for(kbest_ctx *ctx, int B, int maxRow, int k)

@@ -391,6 +391,14 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
 #ifdef KB_PROFILE
     unsigned long long profAcc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long profT0 = __builtin_readcyclecounter();
+    // (behind the [B][16] stamps: [B][3] -- start / end of the workgroup on the 100 MHz wall clock, and the CU it ran on: the
+    //  launch's timeline, tools/tail_profile.py)
+    if (p.prof && threadIdx.x == 0) {
+        const unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID: SE, CU, SIMD, wave slot
+        const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+        p.prof[(long long)gridDim.x * 16 + (long long)blockIdx.x * 3] = wall_clock64();
+        p.prof[(long long)gridDim.x * 16 + (long long)blockIdx.x * 3 + 2] = ((unsigned long long)(xcc & 0xf) << 32) | hwid;
+    }
 #endif
 
     // ---- phase 0: makeCostMatrixSafe + zero padding (cpp:534-569, 582-585) --
@@ -1573,6 +1581,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
 #undef kTab
 #ifdef KB_PROFILE
     profAcc[13] = __builtin_readcyclecounter() - profT0;  // [13] whole kernel (this wave)
+    if (p.prof && threadIdx.x == 0) p.prof[(long long)gridDim.x * 16 + (long long)blockIdx.x * 3 + 1] = wall_clock64();
     if (p.prof && lane == 0)
         for (int i = 0; i < 16; i++) atomicAdd(p.prof + (long long)blk * 16 + i, profAcc[i]);
 #endif

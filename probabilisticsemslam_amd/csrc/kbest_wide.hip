@@ -373,7 +373,6 @@ __global__ void __launch_bounds__(NWV * 64, (R >= 16 ? 1 : (NWV == 16 ? 4 : (R <
         const int M = p.nCol ? p.nCol[b] : p.maxCol;
         if (N >= 1 && M >= 1 && N >= M && N < p.minRows) continue;  // the LDS kernel's share of a mixed batch
         // exact ties (kbest_ties.h): the tables hold p.kTab slots (k, or k - 1: the k-th solution is enumerated for its gain only)
-        if (p.tieGain && tid == 0) p.tieGain[b] = __longlong_as_double(0x7ff8000000000000LL);  // no solution behind the tables (yet)
         if (N < 1 || M < 1 || N < M || N > p.maxRow || M > p.maxCol || N > 64 * R) {  // undefined in the reference
             if (tid == 0) p.nf[b] = -1;
             continue;
@@ -440,6 +439,7 @@ __global__ void __launch_bounds__(NWV * 64, (R >= 16 ? 1 : (NWV == 16 ? 4 : (R <
                 ctrl->nChild = 0;
                 ctrl->nextTicket = 0;
                 ctrl->t0 = INF;
+                if (p.tieGain) p.tieGain[b] = __longlong_as_double(0x7ff8000000000000LL);  // exact ties (kbest_ties.h): no solution behind the tables (yet)
             }
             __syncthreads();
         }
