@@ -622,6 +622,11 @@ static Shape lane_shape(const kbest_ctx *ctx, int B, int maxRow, int maxCol, int
     // except for short enumerations (k = 10: 4 are 6 % faster)
     s.nWaves = B <= 4 * ctx->nCU ? 4 : 2;
     s.spec = (k <= 16 && B > 4 * ctx->nCU) ? 4 : 8;
+    // re-scanned in round 5 (tests/dev/c2_sweep.py, <= 16 rows, ms at 8 / 10 / 12 / 14 / 16 hypotheses per round): 1 024 x 16x16,
+    // k = 50: 0.185 / 0.179 / 0.173 / 0.181 / 0.184; 600: 0.174 / 0.158 / 0.163 / .. ; 2 048: 0.232 / 0.224 / 0.227 / ..; 4 096: 0.466 /
+    // 0.449 / 0.467 / ..; k = 200: 1 024: 0.525 / 0.480 / 0.454 / 0.432 / 0.414, 8 192: 2.65 / 2.50 / 2.40 / 2.33 / 2.29 -- a long
+    // enumeration wants every speculative split it can get (its rounds are what costs), a short one a few more than eight
+    if (maxRow <= 16 && s.spec == 8) s.spec = k >= 100 ? 16 : (B <= 4 * ctx->nCU ? 12 : 10);
     if (ctx->laneNw > 0) s.nWaves = ctx->laneNw;
     if (ctx->laneSpec > 0) s.spec = ctx->laneSpec;
     s.lanes = ctx->laneG > 0 ? ctx->laneG : 4;
