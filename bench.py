@@ -852,6 +852,10 @@ def main():
                 for cfg in ("c2", "c3"):
                     extra[cfg] = dense_entry(eng, torch, cfg, 5, 1, dev, tstream, cpu_samples[cfg], args.no_cpu)
                 extra["c5"] = run_c5(eng, torch, 5, 1, dev, tstream, args.no_cpu)
+                try:  # (not a BASELINE config: the general-size kernel's profile case, 512 x 128x128 -- its roofline line)
+                    extra["w128"] = dense_entry(eng, torch, "w128", 3, 1, dev, tstream, None, True)
+                except Exception as ex:
+                    extra["w128"] = {"error": repr(ex)}
                 # BASELINE configs[3] AS WRITTEN -- 1 024 matrices over 8 GPUs -- gives each rank 128: measurable on one GPU.
                 # Kernel alone, then the same with the RCCL path (one packed all-gather per step, world 1) inside the step.
                 share = {}

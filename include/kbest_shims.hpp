@@ -27,6 +27,11 @@
 // value are identical (the reference's own callers read only row4colBest, assignment.cpp:629).  KBEST_EXACT_ROOT=1 (or
 // KBEST_FLAG_EXACT_ROOT) makes the root run the reference's own sequence of augmentations instead.
 //
+// Exact ties: hypotheses with exactly equal gains come back in the engine's one order -- (gain, row4col lexicographic), and
+// the lexicographically first assignments of a gain level that straddles slot k (kbest_c.h, "Order of exact ties") -- not in
+// the order of the reference's heap, which is an artefact (cpp:30-42, 574).  The flags of the last call are read with
+// kbest_last_tie_flags on the shims' context (kbest_shims_context()).
+//
 // Error behaviour follows the reference: no exceptions from the solver, the
 // return value is the number of solutions found and 0 means infeasible.  An
 // engine failure (no GPU, unsupported size) cannot be expressed in that
@@ -108,5 +113,10 @@ void toProbs(std::vector<double> &costMatrix);
 // assignment.h:26 (assignment.cpp:439-525)
 std::vector<double> conditionCosts(const std::vector<double> &costs, size_t nRows, size_t nCols,
                                    std::vector<ptrdiff_t> &rowIdxOut);
+
+// Not in the reference: the engine context behind the functions above (created on first use, GPU 0), for the entries of
+// kbest_c.h that take one -- e.g. kbest_last_tie_flags after a call.
+struct kbest_ctx;
+kbest_ctx *kbest_shims_context();
 
 #endif

@@ -215,3 +215,5 @@ std::vector<std::vector<double>> bruteForceProb(const std::vector<double> &costM
         for (size_t j = 0; j <= nL; j++) probs[c][j] = flat[c * (nL + 1) + j];
     return probs;
 }
+
+kbest_ctx *kbest_shims_context() { return global_ctx(); }

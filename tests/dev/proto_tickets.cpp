@@ -41,6 +41,9 @@ struct Solver {
     double rho = 1.0, kappa = 0.25, rho1 = 1.0, phi = 1e9, rhoNow = 1.0, adaptA = 0.0, adaptB = 0.0, rhoMin = 0.0;
     int minPool = 8;
     double Tcap = INF;       // an upper bound of the k-th best gain known from the start (the cutoff variant fed the answer)
+    int beamW = 0, beamE = 6;  // beam width / rows tried per entry and column (0: no beam)
+    long beamWork = 0;
+    double beamGap = 0;      // the beam's bound on (k-th best gain - optimum)
     double lastGain = 0;     // gain of the last hypothesis emitted
     double rootGain = 0;
 
@@ -181,6 +184,50 @@ struct Solver {
             std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] > key[b]; });
         }
         rootGain = root.gain;
+        if (beamW > 0) {
+            // A BEAM in reduced-cost space as a bound generator: the gain of any assignment is the optimum plus the
+            // sum of its reduced costs (C - u - v >= 0 at the root), so a walk over the columns that keeps only the beamW best partial
+            // assignments per level -- by partial sum + a lower bound of what the columns to come must add (0 where a column's optimal
+            // row is still free, its cheapest other free row's reduced cost where not) -- ends with <= beamW DISTINCT complete
+            // assignments: the k-th smallest of their sums bounds the k-th best gain from above, whatever the beam threw away.
+            struct BE { u64 used; double sum, pri; };
+            std::vector<BE> cur{{0ull, 0.0, 0.0}}, nxt;
+            std::vector<std::vector<std::pair<double, int>>> byCol(D);
+            for (int c = 0; c < D; c++) {
+                for (int r = 0; r < D; r++) byCol[c].push_back({std::max(0.0, rc(root, r, c)), r});
+                std::sort(byCol[c].begin(), byCol[c].end());
+            }
+            for (int lvl = 0; lvl < D; lvl++) {
+                const int c = order[lvl];
+                nxt.clear();
+                for (const BE &e : cur) {
+                    int taken = 0;
+                    for (auto &pr : byCol[c]) {
+                        if ((e.used >> pr.second) & 1ull) continue;
+                        if (taken++ >= beamE) break;
+                        beamWork++;
+                        BE n{e.used | (1ull << pr.second), e.sum + pr.first, 0.0};
+                        double lb = n.sum;
+                        for (int l2 = lvl + 1; l2 < D; l2++) {  // columns to come: optimal row free -> 0, else the cheapest free row
+                            const int c2 = order[l2];
+                            if (!((n.used >> root.r4c[c2]) & 1ull)) continue;
+                            double m = INF;
+                            for (auto &q : byCol[c2]) if (!((n.used >> q.second) & 1ull)) { m = q.first; break; }
+                            lb += m;
+                        }
+                        n.pri = lb;
+                        if (lb < INF) nxt.push_back(n);
+                    }
+                }
+                std::sort(nxt.begin(), nxt.end(), [](const BE &a, const BE &b) { return a.pri < b.pri; });
+                if ((int)nxt.size() > beamW) nxt.resize(beamW);
+                cur.swap(nxt);
+            }
+            std::vector<double> leaves;
+            for (auto &e : cur) leaves.push_back(e.sum);
+            std::sort(leaves.begin(), leaves.end());
+            if ((int)leaves.size() >= k) { beamGap = leaves[k - 1]; if (root.gain + beamGap < Tcap) Tcap = root.gain + beamGap * (1.0 + 1e-9) + 1e-12; }
+        }
         root.activeCol = order[0];
         root.forb = 1ull << root.r4c[order[0]];
         root.fixed = 0;
@@ -329,7 +376,8 @@ int main(int argc, char **argv)
         const int minPool = argc > cfg + 2 ? atoi(argv[cfg + 2]) : 8;
         sm_state = 0x5EED0000ull + 1000 * N + k;
         Counters tot;
-        double chk = 0;
+        double chk = 0, beamRatio = 0;
+        long beamWorkTot = 0;
         for (int b = 0; b < B; b++) {
             std::vector<double> C((size_t)N * N);
             for (auto &x : C) x = u01();
@@ -342,7 +390,11 @@ int main(int argc, char **argv)
             if (getenv("ADAPT_B")) S.adaptB = atof(getenv("ADAPT_B"));
             S.rhoMin = getenv("RHO_MIN") ? atof(getenv("RHO_MIN")) : rho;
             if (t0slack > 0) { Solver S0; S0.mode = 1; S0.run(k, spec, N, C.data()); S.Tcap = S0.rootGain + t0slack * (S0.lastGain - S0.rootGain); }
+            if (getenv("BEAM")) S.beamW = atoi(getenv("BEAM"));
+            if (getenv("BEAM_E")) S.beamE = atoi(getenv("BEAM_E"));
             S.run(k, spec, N, C.data());
+            beamRatio += S.beamGap / (S.lastGain - S.rootGain);
+            beamWorkTot += S.beamWork;
             chk += S.lastGain;
             tot.started += S.ct.started; tot.filtered += S.ct.filtered; tot.steps += S.ct.steps; tot.visits += S.ct.visits;
             tot.completed += S.ct.completed; tot.rounds += S.ct.rounds; tot.keyPasses += S.ct.keyPasses;
@@ -350,6 +402,7 @@ int main(int argc, char **argv)
         printf("N=%d k=%d spec=%d rho %.2f kappa %.2f minPool %d: children filtered %.0f, pass %.0f, steps %.0f, row visits %.0f, completed %.0f, rounds %.1f, tickets %.1f  [sum of k-th gains %.12f]\n",
                N, k, spec, rho, kappa, minPool, (double)tot.filtered / B, (double)tot.started / B, (double)tot.steps / B, (double)tot.visits / B,
                (double)tot.completed / B, (double)tot.rounds / B, (double)tot.keyPasses / B, chk);
+        if (getenv("BEAM")) printf("   beam %s x %s rows: bound / true gap %.3f, (entry, row) expansions per problem %.0f\n", getenv("BEAM"), getenv("BEAM_E") ? getenv("BEAM_E") : "6", beamRatio / B, (double)beamWorkTot / B);
     }
     return 0;
 }

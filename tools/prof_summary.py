@@ -34,7 +34,8 @@ if main is not None:
     # ... or the kernel that shares the timed launches with it and takes most of their time (the association entry follows the
     # bounded walk by a launch of the enumeration kernel that only looks for frames handed back: microseconds)
     t_from = sorted(t for t, _ in dur[main])[-K:][0]
-    timed = lambda k: sum(d for t, d in sorted(dur[k])[-K:] if t >= t_from - 5_000_000)
+    # (a kernel that ran ONCE in front of the timed launches -- the untimed push-counting launch -- is not part of them, however long it took)
+    timed = lambda k: sum(d for t, d in sorted(dur[k])[-K:] if t >= t_from - 5_000_000) if sum(1 for t, _ in dur[k] if t >= t_from - 5_000_000) >= K else 0.0
     main = max(cands, key=timed)
 res["kernel"] = main
 for k, v in sorted(dur.items(), key=lambda kv: -sum(d for _, d in kv[1])):
