@@ -345,7 +345,11 @@ int kbest_merge_topk_f64_dev(kbest_ctx *ctx, int B, int nShard, int k, int maxCo
  * host outputs of a block come from the device that solved it (col4row is not part of the exchange).  device_ids may
  * name one GPU several times ("logical devices", e.g. {0, 0, 0, 0}): the slices then travel by device-to-device copies
  * instead of RCCL -- the same host path, testable on one GPU.  Same argument meaning as kbest_batch_f64
- * (uniform packing b*maxRow*maxCol; nRow/nCol optional).  RCCL is bound at run time (dlopen): without it
+ * (uniform packing b*maxRow*maxCol; nRow/nCol optional).  Exact ties: every device's tables come back in the one order of
+ * equal gains ("Order of exact ties" above); a gain level that straddles slot k is NOT completed by these entries (their tables
+ * stay on the devices for the exchange) and no flags are returned: a caller with integer-like costs that needs the canonical
+ * members of such a level runs kbest_batch_f64 on the problems kbest_batch_f64_dev / kbest_batch_f64 flag.
+ * RCCL is bound at run time (dlopen): without it
  * kbest_create_multi returns KBEST_ERR_NO_DEVICE and every single-device entry still works.
  */
 typedef struct kbest_multi kbest_multi;
