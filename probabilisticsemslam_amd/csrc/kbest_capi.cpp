@@ -134,6 +134,11 @@ struct kbest_ctx {
     int splitForce = 0;       // KBEST_SPLIT: workgroups per matrix (2 / 4) whenever the split is possible (A/B tests)
     DevBufRaw splitBuf;       // per-share result tables + shared thresholds of the split
     DevBufRaw tieBuf;         // [B] fp64: gain of the solution behind the tables (exact ties, kbest_ties.h)
+    DevBufRaw relayBuf;       // relay launches of the 64-row kernel: [B] LDS images (kbest_engine.hip)
+    DevBufRaw relayFlags;     // ... and [B] progress words (zeroed when the buffer is made)
+    unsigned relayEpoch = 0;  // ... whose values only grow: no clearing between launches
+    int relay = -1;           // KBEST_RELAY: pieces per matrix (0 / 1: never; -1: choose per launch)
+    int relayFirst = 0;       // KBEST_RELAY_FIRST: the first piece hands over at k * this / 1024 solutions (0: choose per launch shape)
     std::vector<int32_t> lastTie;  // KBEST_TIE_* per problem of the last synchronous call (kbest_last_tie_flags)
     int32_t *assocTieDev = nullptr;  // where kbest_assoc_probs_batch_f64_dev writes its flags (kbest_set_assoc_tie_flags_dev)
     std::mutex tieMu;
@@ -407,6 +412,8 @@ int kbest_create(kbest_ctx **out, int device)
     ctx->noLane = getenv("KBEST_NO_LANE") != nullptr;
     ctx->noSplit = getenv("KBEST_NO_SPLIT") != nullptr;
     ctx->noTie = getenv("KBEST_NO_TIE") != nullptr;
+    if (const char *e = getenv("KBEST_RELAY")) ctx->relay = atoi(e);
+    if (const char *e = getenv("KBEST_RELAY_FIRST")) { const int v = atoi(e); if (v >= 1 && v <= 1023) ctx->relayFirst = v; }
     if (const char *e = getenv("KBEST_SPLIT")) { const int w = atoi(e); if (w == 2 || w == 4) ctx->splitForce = w; }
     ctx->noTiny = getenv("KBEST_NO_TINY") != nullptr;
     ctx->noBnb = getenv("KBEST_NO_BNB") != nullptr;
@@ -463,6 +470,8 @@ int kbest_destroy(kbest_ctx *ctx)
     if (ctx->stageOut.p) (void)hipFree(ctx->stageOut.p);
     if (ctx->splitBuf.p) (void)hipFree(ctx->splitBuf.p);
     if (ctx->tieBuf.p) (void)hipFree(ctx->tieBuf.p);
+    if (ctx->relayBuf.p) (void)hipFree(ctx->relayBuf.p);
+    if (ctx->relayFlags.p) (void)hipFree(ctx->relayFlags.p);
     if (ctx->lastEvent) (void)hipEventDestroy(ctx->lastEvent);
     for (auto &a : ctx->aux)
         if (a) (void)hipStreamDestroy(a);
@@ -666,6 +675,8 @@ static int ensure_states(kbest_ctx *ctx, size_t need, bool grow)
 }
 
 static int reserve_for(kbest_ctx *ctx, int B, int maxRow, int k);
+static int relay_plan(const kbest_ctx *ctx, int B, int fastRow, int k, unsigned flags, const Shape &shp, size_t *imgOut);
+static int relay_reserve(kbest_ctx *ctx, int B, size_t img, bool grow);
 
 int kbest_reserve(kbest_ctx *ctx, int B, int maxRow, int k)
 {
@@ -709,6 +720,12 @@ static int reserve_for(kbest_ctx *ctx, int B, int maxRow, int k)
         // (a small batch of 33 ... 64-row problems may run split: up to four workgroups, i.e. four work spaces, per matrix)
         const int Bs = (ctx->splitForce && !ctx->noSplit && maxRow > 32 && maxRow <= KBEST_MAX_DIM) ? ((4 * B <= ctx->nCU) ? 4 * B : ((2 * B <= ctx->nCU) ? 2 * B : B)) : B;
         int rc = reserve_states(ctx, B, fastRow, k, true);
+        if (rc == KBEST_OK) {  // (relay launches: the LDS images of the shape this batch size runs in)
+            Shape shp;
+            size_t img = 0;
+            (void)k_fits_fast(ctx, B, fastRow, k, 0, &shp);
+            if (relay_plan(ctx, B, fastRow, k, 0, shp, &img) > 1) rc = relay_reserve(ctx, B, img, true);
+        }
         if (rc == KBEST_OK && Bs > B) rc = reserve_states(ctx, Bs, fastRow, k, true);
         if (rc == KBEST_OK && Bs > B) {
             const SplitLayout sl(B, Bs / B, k, maxRow);
@@ -786,6 +803,47 @@ static int split_factor(const kbest_ctx *ctx, const kbest_opts *opts, int B, int
 
 // grow: the host-pointer entries (which synchronise anyway) let the workspace grow on demand; the asynchronous
 // device-pointer entry never allocates or synchronises -- it needs kbest_reserve up front.
+// Relay launches of the 64-row kernel (kbest_engine.hip): pieces per matrix for a batch of B matrices in launch shape `shp`, and
+// the bytes of one LDS image.  A launch of a few generations of resident workgroups ends with the slot whose matrices add up to
+// the most (25 % of a C4 launch's slot-time is idle, NOTES 10.3); pieces a fraction of a lifetime long let the slots even out.
+static int relay_plan(const kbest_ctx *ctx, int B, int fastRow, int k, unsigned flags, const Shape &shp, size_t *imgOut)
+{
+    const int ldsB = kb::lds_layout(fastRow, k, shp.spec, shp.nWaves).total;
+    if (imgOut) *imgOut = ((size_t)ldsB + 16 + 127) & ~(size_t)127;
+    if ((flags & (KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_PRUNE | KBEST_FLAG_RECT_ROOT | KBEST_FLAG_NO_SHIFT)) || k < 16) return 1;
+    // (the relay instantiations of the kernel: 4 / 8 / 12 waves, pool entries one per thread -- launch_nw, kbest_engine.hip)
+    if (!(shp.nWaves == 4 || shp.nWaves == 8 || shp.nWaves == 12) || k > shp.nWaves * 64) return 1;
+    int perCU = ctx->ldsPerCU / (ldsB > 0 ? ldsB : 1);
+    const int byWaves = (6 * 4) / shp.nWaves;  // six waves per SIMD (80 VGPRs)
+    perCU = perCU < byWaves ? perCU : byWaves;
+    const double gens = (double)B / (double)((perCU > 0 ? perCU : 1) * ctx->nCU);
+    if (ctx->relay < 0 && gens <= 1.0) return 1;  // (KBEST_RELAY forces the pieces on any batch: tests)
+    // measured (tests/dev/relay_ab.py, 64x64, k = 200, ms without / with 2 / 3 / 4 / 6 pieces): 700 matrices (1.4 generations) 1.46 /
+    // 1.32 / 1.32 / 1.27 / 1.38; 768: 1.62 / 1.46 / 1.40 / 1.37 / 1.47; 1 024 (2.0): 1.90 / 1.72 / 1.72 / 1.77 / 1.94; 1 536 (3.0):
+    // 2.64 / 2.47 / 2.53 / 2.58 / 2.85; 4 096 x 32x32 (2.7): 3.71 / 3.46 / 3.49 / 3.51 / 3.82 -- every hand-over costs ~25 us of a
+    // slot (the LDS image out and in, a workgroup's start): a launch that ends in a PARTIAL generation gains most from short pieces,
+    // whole generations from two
+    int P = ctx->relay >= 0 ? ctx->relay : (gens <= 1.05 ? 1 : (gens < 1.9 ? 4 : (gens <= 6.0 ? 2 : 1)));
+    return P > 8 ? 8 : (P < 1 ? 1 : P);
+}
+
+static int relay_reserve(kbest_ctx *ctx, int B, size_t img, bool grow)
+{
+    const size_t need = (size_t)B * img, needF = (size_t)B * 4;
+    if (need <= ctx->relayBuf.bytes && needF <= ctx->relayFlags.bytes) return KBEST_OK;
+    if (!grow) return KBEST_ERR_NOT_RESERVED;
+    int rc = raw_reserve(ctx, ctx->relayBuf, need);
+    if (rc != KBEST_OK) return rc;
+    if (needF > ctx->relayFlags.bytes) {
+        rc = raw_reserve(ctx, ctx->relayFlags, needF);
+        if (rc != KBEST_OK) return rc;
+        HIP_TRY(ctx, hipMemset(ctx->relayFlags.p, 0, ctx->relayFlags.bytes));
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        ctx->relayEpoch = 0;
+    }
+    return KBEST_OK;
+}
+
 static bool tie_mode(const kbest_ctx *ctx, const kbest_opts *opts, bool rootOnly)
 {
     return !ctx->noTie && !rootOnly && opts->root_col_stride <= 1 &&
@@ -1034,6 +1092,27 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
                 p.optKappa = (double)ctx->optKappa;
                 p.optMinPool = ctx->optMinPool > 1 ? ctx->optMinPool : 2;
             }
+        }
+        // Relay: a launch of a few generations ends with the slot whose matrices add up to the most; enumerating every matrix in
+        // pieces (workgroups that hand the matrix' LDS on through HBM) lets the slots even out (kbest_engine.hip; NOTES 10.3,
+        // 10.6).  Whole launches of the plain enumeration only, where the batch is 1.2 ... 6 generations of resident workgroups.
+        size_t relayImg = 0;
+        const int relayP = (!sub && !extra && S == 1) ? relay_plan(ctx, B, fastRow, k, opts->flags, shp, &relayImg) : 1;
+        if (relayP > 1) {
+            rc = relay_reserve(ctx, B, relayImg, grow);
+            if (rc == KBEST_OK) {
+                p.relayP = relayP;
+                p.relayB = B;
+                // (the first half of the solutions takes 3/4 of a matrix' time: 571 + 206 us at k / 2; measured, ms at a first cut of 3/8 / 7/16 /
+                //  1/2 / 9/16 / 5/8 / 3/4 k: C4 1.700 / 1.687 / 1.713 / 1.707 / 1.727 / 1.789; C3 at 1/2 / 5/8: 3.454 / 3.396)
+                p.relayFirst = ctx->relayFirst > 0 ? ctx->relayFirst : (shp.nWaves >= 8 ? 512 : 640);
+                p.relayEpoch = ++ctx->relayEpoch;
+                p.relayBuf = static_cast<unsigned char *>(ctx->relayBuf.p);
+                p.relayStride = (long long)relayImg;
+                p.relayFlag = static_cast<unsigned *>(ctx->relayFlags.p);
+            } else if (rc != KBEST_ERR_NOT_RESERVED) {
+                return rc;
+            }  // (not reserved: an asynchronous entry never allocates -- the launch runs without the relay)
         }
         hipError_t e = kb::launch_kbest(p, B * S, shp.nWaves, s);
         if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "kbest kernel launch", e);

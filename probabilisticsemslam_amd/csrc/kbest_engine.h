@@ -55,6 +55,16 @@ struct Params {
     // gain only, which goes to tieGain[problem] (NaN: there is none)
     int kTab;
     double *tieGain;
+    // relay (kbest_engine.hip): relayP > 1: every matrix is enumerated by relayP workgroups one after the other (grid = relayB x
+    // relayP); relayBuf: [relayB] LDS images of relayStride bytes (L.total + the round number); relayFlag: [relayB] progress words
+    // (relayEpoch * 16 + pieces done, + 15: finished), never cleared: the epoch grows with every launch
+    int relayP, relayB;
+    int relayFirst;           // the first piece hands over once k * relayFirst / 1024 solutions are out, the later ones at even steps from there
+                              // to k (the makespan ends with a generation of LAST pieces: they should be short; scalar integer arithmetic only)
+    unsigned relayEpoch;
+    unsigned char *relayBuf;
+    long long relayStride;
+    unsigned *relayFlag;
 };
 
 struct CondParams {
@@ -127,7 +137,7 @@ __host__ __device__ inline Lds lds_layout(int maxRow, int k, int spec, int nWave
     o = (o + 3) & ~3;
     L.offPerm = o;       o += 128;                   // column order of the enumeration: original column of a position, and back
     o = (o + 7) & ~7;
-    L.offCtrl = o;       o += 232;                   // struct Ctrl
+    L.offCtrl = o;       o += 240;                   // struct Ctrl
     o = (o + 7) & ~7;
     L.offOpt = o;        o += OPT_BYTES;             // struct Opt: optimistic bounds, per-node accumulators, re-split tickets
     o = (o + 15) & ~15;

@@ -100,8 +100,10 @@ struct Ctrl {
     int outDone;               // output slots whose row4col / col4row tables have been written
     int outTicket;             // work queue of the output writes of this round
     double tShared;            // split launches: the smallest threshold any share of this matrix has published (+inf: none)
+    int relayCut;              // relay launches: this workgroup hands the matrix over once so many solutions are out (else INT_MAX)
+    int relayRound;            // ... and the round the next piece starts with (part of the LDS image)
 };
-static_assert(sizeof(Ctrl) <= 232, "Ctrl must fit the LDS slot reserved by lds_layout");
+static_assert(sizeof(Ctrl) <= 240, "Ctrl must fit the LDS slot reserved by lds_layout");
 
 // Optimistic bounds and re-split tickets.  The pool's threshold T (the gain of its last entry once it holds k - emitted
 // candidates) is a VALID bound, but a loose one for most of the run: half of the children that complete under it never make
@@ -314,7 +316,11 @@ __device__ __forceinline__ NodeRef node_ref(unsigned char *base, int maxRow)
 //  six spills and more waves on an issue-bound kernel)
 constexpr int min_waves_per_simd(int nw) { return nw <= 12 ? 6 : 4; }
 
-template <int NW, int EPT>  // EPT: pool entries per thread held in registers across the in-place merge (k <= EPT * NW * 64)
+// EPT: pool entries per thread held in registers across the in-place merge (k <= EPT * NW * 64)
+// RELAY: the instantiation of relay launches (below).  Plain launches run an instantiation without a line of it: these kernels sit at
+// the 80-register cliff, where every added line moves spills around -- and where the compiler has produced wrong code more than once
+// (an 8-wave build WITH the resume block faulted on plain launches that never execute it; NOTES 10.6).
+template <int NW, int EPT, bool RELAY>
 __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -326,7 +332,14 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     // split > 1: ONE matrix is enumerated by `split` workgroups, each taking the root's children on columns c % split == share
     // (Murty's partition of the root is disjoint, cpp:455-532) into its own tables [share][matrix]; a k-way merge follows
     // (kbest_merge.hip).  They share an upper bound of the k-th best gain through sharedT (see the top of the round loop).
-    const int blk = blockIdx.x;  // index of this workgroup's work space and output tables
+    // Relay (round 5): a matrix is enumerated by gridDim.y workgroups ONE AFTER THE OTHER -- workgroup (blockIdx.y = piece,
+    // blockIdx.x = matrix) takes the matrix up to a share of its k solutions, leaves its whole LDS in HBM and ends; the workgroup of
+    // the next piece (dispatched later, to whatever slot is free then) picks it up.  A launch of a few generations ends with the
+    // slot whose matrices add up to the most (25 % of a C4 launch's slot-time is idle, NOTES 10.3): pieces a fraction of a
+    // lifetime long let the slots even out.  Same rounds, same arithmetic, same results.  (Piece and matrix are block indices --
+    // registers the hardware provides --, the epoch and the buffers kernel arguments: nothing of the relay is live across a round.)
+    const int blk = blockIdx.x;  // index of this matrix' work space and output tables
+    const bool fresh = RELAY ? blockIdx.y == 0 : true;
     const int S = p.split > 1 ? p.split : 1;
     const int share = S > 1 ? blk / p.splitB : 0;
     const int b = S > 1 ? blk - share * p.splitB : blk;  // the matrix (inputs)
@@ -334,10 +347,10 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     const int N = p.nRow ? p.nRow[b] : p.maxRow;
     const int M = p.nCol ? p.nCol[b] : p.maxCol;
     const int k = p.k;
-    if (p.tieGain && tid == 0) p.tieGain[blk] = __longlong_as_double(0x7ff8000000000000LL);  // no solution behind the tables (yet)
+    if (fresh && p.tieGain && tid == 0) p.tieGain[blk] = __longlong_as_double(0x7ff8000000000000LL);  // no solution behind the tables (yet)
     if (N < 1 || M < 1 || N < M || N > p.maxRow || M > p.maxCol) {  // undefined in the reference
-        if (tid == 0) p.nf[blk] = (M == 0 || N == 0) ? 0 : -1;          // (an empty frame: nothing to assign, nothing found)
-        return;
+        if (fresh && tid == 0) p.nf[blk] = (M == 0 || N == 0) ? 0 : -1;  // (an empty frame: nothing to assign, nothing found)
+        return;  // (every piece's workgroup sees the same shape: none of them waits)
     }
     // odd column stride of the LDS cost tile: row-wise (lane = row) and column-wise (lane = column) walks are
     // both bank-conflict free
@@ -353,7 +366,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     // global: state slot of each output slot.  One whole number of 128-byte lines per matrix: the table is written
     // and later re-read by this workgroup through its CU's L1, and a line shared with a neighbouring matrix could
     // have been pulled into that L1 earlier by another workgroup of the same CU (stale bytes for our half).
-    unsigned short *slotSid = p.slotSid + (long long)blockIdx.x * slot_table_stride(k);
+    unsigned short *slotSid = p.slotSid + (long long)blk * slot_table_stride(k);
     double *red = freshG;  // cross-wave reduction scratch of phase 0
     unsigned short *surv = reinterpret_cast<unsigned short *>(smem + L.offSurv);
     // last-arc minima of the current nodes' children (high words).  Shares its LDS with the fresh list's meta words,
@@ -396,14 +409,37 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     if (p.prof && threadIdx.x == 0) {
         const unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID: SE, CU, SIMD, wave slot
         const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
-        p.prof[(long long)gridDim.x * 16 + (long long)blockIdx.x * 3] = wall_clock64();
-        p.prof[(long long)gridDim.x * 16 + (long long)blockIdx.x * 3 + 2] = ((unsigned long long)(xcc & 0xf) << 32) | hwid;
+        // (relay launches: one record per workgroup = (piece, matrix), piece-major)
+        const long long wg = (long long)blockIdx.y * gridDim.x + blockIdx.x, nwg = (long long)gridDim.x * gridDim.y;
+        p.prof[nwg * 16 + wg * 3] = wall_clock64();
+        p.prof[nwg * 16 + wg * 3 + 2] = ((unsigned long long)(xcc & 0xf) << 32) | hwid;
     }
 #endif
 
     // ---- phase 0: makeCostMatrixSafe + zero padding (cpp:534-569, 582-585) --
     double cdelTile = 0.0;  // the shift of the tile (kept for phase 1b, which loads the columns again in another order)
-    {
+    if (RELAY && !fresh) {
+        // a later piece: wait for the workgroup before it (it was dispatched earlier: it runs or has run), take over its LDS
+        unsigned f = 0;
+        const unsigned relayBase = p.relayEpoch * 16u;  // (the progress words only ever grow: no clearing between launches)
+        if (tid == 0) {
+            for (;;) {
+                f = __hip_atomic_load(p.relayFlag + blk, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if (f >= relayBase + blockIdx.y && f <= relayBase + 15u) break;
+                __builtin_amdgcn_s_sleep(32);
+            }
+            red[0] = __longlong_as_double((long long)f);
+        }
+        __syncthreads();
+        f = (unsigned)uni32((int)(unsigned)__double_as_longlong(red[0]));  // (uniform: the return below is a scalar branch)
+        if (f == relayBase + 15u) return;  // the matrix was finished by an earlier piece
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.relayBuf + (long long)blk * p.relayStride);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        __syncthreads();
+        for (int i = tid; i < L.total / 16; i += NT) dst[i] = src[i];
+    }
+    if (fresh) {
         if (tid < 64) { colOf[tid] = (unsigned char)tid; posOf[tid] = (unsigned char)tid; }
         double mn = INF;  // min of C, or min of -C when maximising (max C = -min(-C), exact)
         for (int c = wave; c < M; c += NW)
@@ -479,8 +515,8 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     //  the global k-th best from this share's atoms is exactly what it may prune with)
     const bool t0On = prune && k >= 3 && (p.rootColStride <= 1 || S > 1) && !(p.flags & (KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_T0)) &&
                       !rect && NW >= 8 && spec >= 3 && maxSid < nSlots;
-    if (t0On && tid < D) atoms[2 * tid] = 0x7ff0000000000000ull;  // +inf: no such child (yet)
-    if (t0On && tid == 0) atoms[2 * D + 1] = 0ull;                 // atoms learnt in round 1
+    if (fresh && t0On && tid < D) atoms[2 * tid] = 0x7ff0000000000000ull;  // +inf: no such child (yet)
+    if (fresh && t0On && tid == 0) atoms[2 * D + 1] = 0ull;                 // atoms learnt in round 1
     // the second, sharper threshold (atoms learnt in round 1) needs the "one connected change" test: permutation cycles,
     // i.e. square problems (on rectangular ones a change can be an open path through the unassigned rows)
     const bool t1On = t0On && N == M && spec * 64 >= T0_SCRATCH + 64;
@@ -538,7 +574,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     };
 
     // ---- phase 1: root LAP (shortestPathCPP, cpp:119-238) on wave 0 -> node 0, state 0, slot 0 ----
-    if (wave == 0) {
+    if (fresh && wave == 0) {
         const NodeRef nd = node_ref(smem + L.offNodes, p.maxRow);
         if (lane < D) nd.u[lane] = 0.0;
         double v = 0.0, spc, delta;
@@ -673,6 +709,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     __syncthreads();
     if (uni32(ctrl->stop) == 3) {  // infeasible: kBest2D returns 0 (cpp:588-593)
         if (tid == 0) { p.nf[blk] = 0; if (p.pushed) p.pushed[blk] = 0; }
+        if (RELAY && tid == 0) __hip_atomic_store(p.relayFlag + blk, p.relayEpoch * 16u + 15u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
 
@@ -693,7 +730,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     //  of kbest_c.h are those of the reference's order, whatever kernel, launch shape or key arithmetic a rank uses)
     const bool reorder = !rect && prune && S == 1 && p.rootColStride <= 1 && M >= 3 && k >= 3 &&
                          !(p.flags & (KBEST_FLAG_EXACT_ROOT | KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_REORDER));
-    if (reorder) {
+    if (fresh && reorder) {
         double *key = reinterpret_cast<double *>(smem + L.offGainW);  // (wave 0's line of gain terms: free between the root and round 0)
         const NodeRef nd0 = node_ref(smem + L.offNodes, p.maxRow);
         // All the keys at once: in the graph whose nodes are the columns and whose arc j -> j' costs what column j pays for the
@@ -767,9 +804,25 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         __syncthreads();
     }
 
+    // relay: the first piece hands over once k * relayFirst / 1024 solutions are out, the later ones at even steps from there to
+    // k (scalar integer arithmetic; the last piece and plain launches never: INT_MAX).  Kept in LDS and tested by the ONE lane
+    // that counts the emitted solutions (phase D), which ends the round loop through ctrl->stop = 4: a test at the top of every
+    // round by every wave (gridDim comes from memory) cost 2 % on every launch.
+    if (RELAY) {
+        if (tid == 0) {
+            ctrl->relayCut = (blockIdx.y + 1 < gridDim.y)
+                                 ? (int)(((long long)p.k * (p.relayFirst * (gridDim.y - 1) + (1024 - p.relayFirst) * blockIdx.y)) / (1024 * (gridDim.y - 1)))
+                                 : 0x7fffffff;
+            if (fresh) ctrl->relayRound = 0;
+            if (ctrl->stop == 4) ctrl->stop = 0;  // (a later piece: the image it took over ends with the hand-over code)
+        }
+        __syncthreads();
+    }
     KB_ACC(0, __builtin_readcyclecounter() - profT0);  // [0] set-up + root solve
     // ---- phase 2: rounds ----------------------------------------------------------------------------
-    for (int roundNo = 0; uni32(ctrl->stop) == 0; roundNo++) {
+    int roundNo = RELAY ? uni32(ctrl->relayRound) : 0;  // (a later piece goes on with the round the image was taken before)
+    for (; uni32(ctrl->stop) == 0; roundNo++) {
+        // relay: this piece hands over once its share of the k solutions is out (the last piece runs to the end)
         // The compiler hoists every cheap expression of the lane number out of this loop (addresses, lane masks: two dozen of
         // them) and then has to spill them at 80 VGPRs: a scratch load per use instead of one or two vector instructions.
         // Making the lane number opaque once per round keeps those expressions where they are used.
@@ -1501,6 +1554,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
 #pragma unroll
                 for (int w = 0; w < MS; w++) { ctrl->selIdx[w] = (short)sIdx[w]; ctrl->selSid[w] = (unsigned short)sSid[w]; }
                 if (stop) ctrl->stop = 1;
+                else if (RELAY && e >= ctrl->relayCut) ctrl->stop = 4;  // relay: this piece's share is out -- the round ends as usual, the loop with it
             }
         }
         if (haveNode) {
@@ -1560,6 +1614,24 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         KB_ACC(12, __builtin_readcyclecounter() - tA1);  // [12] wait at the barrier after A
     }
     const int stopCode = uni32(ctrl->stop);
+    if (RELAY && stopCode == 4) {  // relay: this piece's share of the solutions is out (phase D saw it): the next workgroup goes on from here
+        // hand over: the whole LDS (pool, nodes, tile, control, minima: everything a round starts from), the round number in it
+        if (tid == 0) ctrl->relayRound = roundNo;
+        __syncthreads();
+        uint4 *dst = reinterpret_cast<uint4 *>(p.relayBuf + (long long)blk * p.relayStride);
+        const uint4 *src = reinterpret_cast<const uint4 *>(smem);
+        for (int i = tid; i < L.total / 16; i += NT) dst[i] = src[i];
+        __syncthreads();  // (every thread's stores have been acknowledged: s_waitcnt vmcnt(0) in front of the barrier)
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_store(p.relayFlag + blk, p.relayEpoch * 16u + blockIdx.y + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#ifdef KB_PROFILE
+        if (p.prof && threadIdx.x == 0)
+            p.prof[(long long)gridDim.x * gridDim.y * 16 + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 3 + 1] = wall_clock64();
+#endif
+        return;
+    }
     const int nfAll = (stopCode == 2) ? -3 : uni32(ctrl->emitted);
     const int nf = nfAll > kTab ? kTab : nfAll;
     // ---- phase 3: outputs.  Slot s holds hypothesis slotSid[s]: widen its saved row4col / col4row (the slots that were not
@@ -1578,10 +1650,13 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         p.nf[blk] = nf;
         if (p.pushed) p.pushed[blk] = ctrl->pushed;
     }
+    // (relay: this matrix is finished -- the workgroups of its later pieces have nothing to do)
+    if (RELAY && tid == 0) __hip_atomic_store(p.relayFlag + blk, p.relayEpoch * 16u + 15u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 #undef kTab
 #ifdef KB_PROFILE
     profAcc[13] = __builtin_readcyclecounter() - profT0;  // [13] whole kernel (this wave)
-    if (p.prof && threadIdx.x == 0) p.prof[(long long)gridDim.x * 16 + (long long)blockIdx.x * 3 + 1] = wall_clock64();
+    if (p.prof && threadIdx.x == 0)
+        p.prof[(long long)gridDim.x * gridDim.y * 16 + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 3 + 1] = wall_clock64();
     if (p.prof && lane == 0)
         for (int i = 0; i < 16; i++) atomicAdd(p.prof + (long long)blk * 16 + i, profAcc[i]);
 #endif
@@ -1731,22 +1806,30 @@ __global__ void __launch_bounds__(256) weights_kernel(WeightParams p)
 }
 
 // ------------------------------------------------------------------- launchers
-template <int NW, int EPT>
+template <int NW, int EPT, bool RELAY>
 static hipError_t launch_nw_ept(const Params &p, int B, hipStream_t stream)
 {
     const Lds L = lds_layout(p.maxRow, p.k, p.spec, NW);
     static const int pad = getenv("KBEST_LDS_PAD") ? atoi(getenv("KBEST_LDS_PAD")) : 0;  // residency experiments only
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kbest_kernel<NW, EPT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kbest_kernel<NW, EPT, RELAY>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, L.total + pad);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((kbest_kernel<NW, EPT>), dim3(B), dim3(NW * 64), L.total + pad, stream, p);
+    // (relay launches: y = the piece of a matrix' enumeration; x runs fastest, so every matrix' piece j is dispatched before any piece j + 1)
+    hipLaunchKernelGGL((kbest_kernel<NW, EPT, RELAY>), dim3(B, RELAY ? p.relayP : 1), dim3(NW * 64), L.total + pad, stream, p);
     return hipGetLastError();
 }
 
 template <int NW>
 static hipError_t launch_nw(const Params &p, int B, hipStream_t stream)
 {
-    return (p.k <= NW * 64) ? launch_nw_ept<NW, 1>(p, B, stream) : launch_nw_ept<NW, 4>(p, B, stream);
+    // (relay launches: the shapes relay_shape_ok() names, one instantiation each)
+    if (p.relayP > 1) {
+        if constexpr (NW == 4 || NW == 8 || NW == 12) {
+            if (p.k <= NW * 64) return launch_nw_ept<NW, 1, true>(p, B, stream);
+        }
+        return hipErrorInvalidValue;
+    }
+    return (p.k <= NW * 64) ? launch_nw_ept<NW, 1, false>(p, B, stream) : launch_nw_ept<NW, 4, false>(p, B, stream);
 }
 
 hipError_t launch_kbest(const Params &p, int B, int nWaves, hipStream_t stream)

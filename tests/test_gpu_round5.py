@@ -292,3 +292,42 @@ def test_apriori_threshold_scratch_is_not_rearmed_early(monkeypatch):
         nf, r4c, c4r, g = eng.kbest(flat, int(nRow.max()), 2, 1025, cutoff=42.0, nRow=nRow, nCol=nCol, costOff=off)
         want = np.array([ol.orc_kbest(conds[f], int(nRow[f]), 2, 1025, cutoff=42.0)[0] for f in range(F)])
         assert (nf == want).all(), (rep, np.nonzero(nf != want)[0][:5], nf[nf != want][:5], want[nf != want][:5])
+
+
+@pytest.mark.parametrize("pieces", [2, 3, 5, 8])
+def test_relay_pieces_leave_the_tables_unchanged(monkeypatch, pieces):
+    """Relay launches (round 5): a matrix is enumerated by `pieces` workgroups one after the other, the LDS handed on through
+    HBM.  Forced (KBEST_RELAY) on small batches of every shape the 64-row kernel runs the relay in -- 4, 8 and 12 waves; square,
+    rectangular, ragged; with a cutoff; maximising; k above and below the pieces' shares -- the tables are the checker's, bit
+    for bit (shortestPathCPP.cpp:574-760 order)."""
+    eng = engine_with(monkeypatch, KBEST_RELAY=pieces, KBEST_NO_SMALL=1, KBEST_NO_LANE=1, KBEST_NO_TINY=1, KBEST_NO_BNB=1)
+    rng = np.random.default_rng(77 + pieces)
+    cases = [(24, 24, 200, 300, {}), (33, 33, 200, 40, {}), (64, 64, 200, 24, {}), (48, 40, 100, 30, {}),
+             (64, 64, 17, 20, {}), (40, 40, 120, 20, {"maximize": True}), (30, 10, 200, 64, {"cutoff": 3.0}),
+             (20, 20, 256, 20, {}), (64, 3, 150, 20, {})]
+    for N, M, k, B, kw in cases:
+        costs = rng.random((B, N * M))
+        nf, r4c, c4r, g = eng.kbest(costs, N, M, k, **kw)
+        wn, wr, wc, wg, _ = ol.orc_kbest_batch(costs, N, M, k, **kw)
+        assert (nf == wn).all(), (N, M, k)
+        for b in range(B):
+            n = int(wn[b])
+            assert (bits(g[b, :n]) == bits(wg[b, :n])).all(), (N, M, k, b)
+            assert (r4c[b, :n] == wr[b, :n]).all(), (N, M, k, b)
+            assert (c4r[b, :n, :][wc[b, :n, :] < M] == wc[b, :n, :][wc[b, :n, :] < M]).all(), (N, M, k, b)
+
+
+def test_relay_is_chosen_for_batches_of_several_generations_and_changes_nothing(monkeypatch):
+    """The launch plan itself: 1 024 dense 64x64 (two generations of resident workgroups) and 2 048 dense 32x32 run as relays
+    by default; the same engine with KBEST_RELAY=0 runs them plain.  Identical tables, same context used twice in a row
+    (the progress words are never cleared: the epoch moves on)."""
+    plain = engine_with(monkeypatch, KBEST_RELAY=0)
+    auto = pk.KBestEngine(0)
+    for name, B in (("c4", 1024), ("c3", 2048), ("c4", 700)):
+        costs, N, M, k = wl.dense_config(name, B=B)
+        a = plain.kbest(costs, N, M, k)
+        for _ in range(2):
+            b = auto.kbest(costs, N, M, k)
+            assert (a[0] == b[0]).all()
+            assert (a[1] == b[1]).all() and (a[2] == b[2]).all()
+            assert (bits(a[3]) == bits(b[3])).all()

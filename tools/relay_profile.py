@@ -1,0 +1,54 @@
+"""Diagnostic (PROFILE build): the timeline of a RELAY launch of the 64-row kernel -- start / end of every (piece, matrix)
+workgroup: lifetimes per piece, the gap between a piece's end and the next piece's start, idle share of the slots.
+Run on the GPU box:  KBEST_RELAY=P python tools/relay_profile.py [config]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("KBEST_LIB", "libkbest_amd_prof.so")
+import numpy as np
+import torch
+import probabilisticsemslam_amd as pk
+from probabilisticsemslam_amd import workloads as wl
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "c4"
+P = int(os.environ.get("KBEST_RELAY", "2"))
+dev = torch.device("cuda", 0)
+eng = pk.KBestEngine(0)
+Bc, N, M, k, seed = wl.DENSE_CONFIGS[cfg]
+B = Bc
+d_cost = torch.from_numpy(wl.dense_batch(B, N, M, seed)).to(dev)
+d_r4c = torch.empty((B, k, M), dtype=torch.int32, device=dev)
+d_c4r = torch.empty((B, k, N), dtype=torch.int32, device=dev)
+d_gain = torch.empty((B, k), dtype=torch.float64, device=dev)
+d_nf = torch.empty(B, dtype=torch.int32, device=dev)
+W = B * max(P, 1)
+prof = torch.zeros(W * 19, dtype=torch.int64, device=dev)
+eng.lib.kbest_set_profile_buffer(eng.ctx, C.c_void_p(prof.data_ptr()))
+s = torch.cuda.Stream()
+for it in range(3):
+    prof.zero_()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(s):
+        e0.record()
+        eng.kbest_dev(d_cost, B, N, M, k, d_r4c, d_c4r, d_gain, d_nf, stream=s.cuda_stream, tie_check=False)
+        e1.record()
+    torch.cuda.synchronize()
+ms = e0.elapsed_time(e1)
+t = prof.cpu().numpy()[W * 16:].reshape(max(P, 1), B, 3)
+t0 = t[:, :, 0][t[:, :, 0] > 0].min()
+start, end = (t[:, :, 0] - t0) / 100.0, (t[:, :, 1] - t0) / 100.0
+print(f"{cfg}, relay {P}: launch {ms:.3f} ms, makespan {end.max():.0f} us")
+for j in range(max(P, 1)):
+    life = end[j] - start[j]
+    line = f"  piece {j}: start mean {start[j].mean():7.0f} (min {start[j].min():6.0f}, max {start[j].max():6.0f})  lifetime mean {life.mean():6.1f} p95 {np.percentile(life, 95):6.1f} max {life.max():6.1f}"
+    if j > 0:
+        gap = start[j] - end[j - 1]
+        line += f"   gap to the piece before: mean {gap.mean():7.1f} min {gap.min():7.1f} (negative: it waited {(-gap[gap < 0]).sum():.0f} us in all, {int((gap < 0).sum())} workgroups)"
+    print(line)
+busy = (end - start).sum()
+nslot = int((start[0] < 5.0).sum())
+print(f"  slots {nslot}: busy {busy:.0f} us of {nslot * end.max():.0f} -> idle {100 * (1 - busy / (nslot * end.max())):.1f} %; sum of all lifetimes / slots = {busy / nslot:.0f} us")
