@@ -675,7 +675,7 @@ static int ensure_states(kbest_ctx *ctx, size_t need, bool grow)
 }
 
 static int reserve_for(kbest_ctx *ctx, int B, int maxRow, int k);
-static int relay_plan(const kbest_ctx *ctx, int B, int fastRow, int k, unsigned flags, const Shape &shp, size_t *imgOut);
+static int relay_plan(const kbest_ctx *ctx, int B, int fastRow, int k, unsigned flags, const Shape &shp, size_t *imgOut, double *gensOut = nullptr);
 static int relay_reserve(kbest_ctx *ctx, int B, size_t img, bool grow);
 
 int kbest_reserve(kbest_ctx *ctx, int B, int maxRow, int k)
@@ -806,8 +806,9 @@ static int split_factor(const kbest_ctx *ctx, const kbest_opts *opts, int B, int
 // Relay launches of the 64-row kernel (kbest_engine.hip): pieces per matrix for a batch of B matrices in launch shape `shp`, and
 // the bytes of one LDS image.  A launch of a few generations of resident workgroups ends with the slot whose matrices add up to
 // the most (25 % of a C4 launch's slot-time is idle, NOTES 10.3); pieces a fraction of a lifetime long let the slots even out.
-static int relay_plan(const kbest_ctx *ctx, int B, int fastRow, int k, unsigned flags, const Shape &shp, size_t *imgOut)
+static int relay_plan(const kbest_ctx *ctx, int B, int fastRow, int k, unsigned flags, const Shape &shp, size_t *imgOut, double *gensOut)
 {
+    if (gensOut) *gensOut = 0.0;
     const int ldsB = kb::lds_layout(fastRow, k, shp.spec, shp.nWaves).total;
     if (imgOut) *imgOut = ((size_t)ldsB + 16 + 127) & ~(size_t)127;
     if ((flags & (KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_PRUNE | KBEST_FLAG_RECT_ROOT | KBEST_FLAG_NO_SHIFT)) || k < 16) return 1;
@@ -818,12 +819,13 @@ static int relay_plan(const kbest_ctx *ctx, int B, int fastRow, int k, unsigned 
     perCU = perCU < byWaves ? perCU : byWaves;
     const double gens = (double)B / (double)((perCU > 0 ? perCU : 1) * ctx->nCU);
     if (ctx->relay < 0 && gens <= 1.0) return 1;  // (KBEST_RELAY forces the pieces on any batch: tests)
-    // measured (tests/dev/relay_ab.py, 64x64, k = 200, ms without / with 2 / 3 / 4 / 6 pieces): 700 matrices (1.4 generations) 1.46 /
-    // 1.32 / 1.32 / 1.27 / 1.38; 768: 1.62 / 1.46 / 1.40 / 1.37 / 1.47; 1 024 (2.0): 1.90 / 1.72 / 1.72 / 1.77 / 1.94; 1 536 (3.0):
-    // 2.64 / 2.47 / 2.53 / 2.58 / 2.85; 4 096 x 32x32 (2.7): 3.71 / 3.46 / 3.49 / 3.51 / 3.82 -- every hand-over costs ~25 us of a
-    // slot (the LDS image out and in, a workgroup's start): a launch that ends in a PARTIAL generation gains most from short pieces,
-    // whole generations from two
-    int P = ctx->relay >= 0 ? ctx->relay : (gens <= 1.05 ? 1 : (gens < 1.9 ? 4 : (gens <= 6.0 ? 2 : 1)));
+    // measured (tests/dev/relay_sweep.py, ms plain / best relay; NOTES 10.6): 64x64, k = 200: 600 matrices (1.2 generations) 1.367 /
+    // 1.176, 700: 1.411 / 1.204, 1 024 (2.0): 1.820 / 1.570, 1 536: 2.591 / 2.298, 3 072 (6.0): 4.746 / 4.522; 32x32: 2 048: 2.161 /
+    // 1.884, 3 072: 3.011 / 2.776, 4 096: 3.581 / 3.238, 8 192: 6.584 / 6.331.  Three pieces are at or within 1 % of the best of
+    // 2 ... 8 everywhere up to six generations (a hand-over costs ~11 us of a slot: the image out and in, a workgroup's start, a cold
+    // L1); beyond that two.
+    if (gensOut) *gensOut = gens;
+    int P = ctx->relay >= 0 ? ctx->relay : (gens <= 1.05 ? 1 : (gens <= 6.5 ? 3 : (gens <= 10.0 ? 2 : 1)));
     return P > 8 ? 8 : (P < 1 ? 1 : P);
 }
 
@@ -1097,15 +1099,17 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         // pieces (workgroups that hand the matrix' LDS on through HBM) lets the slots even out (kbest_engine.hip; NOTES 10.3,
         // 10.6).  Whole launches of the plain enumeration only, where the batch is 1.2 ... 6 generations of resident workgroups.
         size_t relayImg = 0;
-        const int relayP = (!sub && !extra && S == 1) ? relay_plan(ctx, B, fastRow, k, opts->flags, shp, &relayImg) : 1;
+        double relayGens = 0.0;
+        const int relayP = (!sub && !extra && S == 1) ? relay_plan(ctx, B, fastRow, k, opts->flags, shp, &relayImg, &relayGens) : 1;
         if (relayP > 1) {
             rc = relay_reserve(ctx, B, relayImg, grow);
             if (rc == KBEST_OK) {
                 p.relayP = relayP;
                 p.relayB = B;
-                // (the first half of the solutions takes 3/4 of a matrix' time: 571 + 206 us at k / 2; measured, ms at a first cut of 3/8 / 7/16 /
-                //  1/2 / 9/16 / 5/8 / 3/4 k: C4 1.700 / 1.687 / 1.713 / 1.707 / 1.727 / 1.789; C3 at 1/2 / 5/8: 3.454 / 3.396)
-                p.relayFirst = ctx->relayFirst > 0 ? ctx->relayFirst : (shp.nWaves >= 8 ? 512 : 640);
+                // (where the first piece ends, in solutions: the 12-wave shape's matrices -- 64 rows -- emit their first 3/8 in about 60 %
+                //  of their time, and up to two generations that is the best first cut: 1.570 against 1.602 / 1.674 at 1/2 / 5/8;
+                //  everywhere else 5/8 -- tests/dev/relay_sweep.py)
+                p.relayFirst = ctx->relayFirst > 0 ? ctx->relayFirst : ((shp.nWaves == 12 && relayGens <= 2.2) ? 384 : 640);
                 p.relayEpoch = ++ctx->relayEpoch;
                 p.relayBuf = static_cast<unsigned char *>(ctx->relayBuf.p);
                 p.relayStride = (long long)relayImg;

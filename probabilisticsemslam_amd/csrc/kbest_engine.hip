@@ -411,33 +411,39 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
         // (relay launches: one record per workgroup = (piece, matrix), piece-major)
         const long long wg = (long long)blockIdx.y * gridDim.x + blockIdx.x, nwg = (long long)gridDim.x * gridDim.y;
-        p.prof[nwg * 16 + wg * 3] = wall_clock64();
-        p.prof[nwg * 16 + wg * 3 + 2] = ((unsigned long long)(xcc & 0xf) << 32) | hwid;
+        p.prof[nwg * 16 + wg * 5] = wall_clock64();
+        p.prof[nwg * 16 + wg * 5 + 2] = ((unsigned long long)(xcc & 0xf) << 32) | hwid;
     }
 #endif
 
     // ---- phase 0: makeCostMatrixSafe + zero padding (cpp:534-569, 582-585) --
     double cdelTile = 0.0;  // the shift of the tile (kept for phase 1b, which loads the columns again in another order)
     if (RELAY && !fresh) {
-        // a later piece: wait for the workgroup before it (it was dispatched earlier: it runs or has run), take over its LDS
-        unsigned f = 0;
+        // a later piece: wait for the workgroup before it (it was dispatched earlier: it runs or has run), take over its LDS.
+        // One lane polls with RELAXED loads (an acquire per poll would invalidate this CU's L1 under its other workgroups
+        // every time), then ONE agent-scope acquire, waited for, in front of the barrier behind which everybody loads.
         const unsigned relayBase = p.relayEpoch * 16u;  // (the progress words only ever grow: no clearing between launches)
         if (tid == 0) {
+            unsigned f;
             for (;;) {
-                f = __hip_atomic_load(p.relayFlag + blk, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                f = __hip_atomic_load(p.relayFlag + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (f >= relayBase + blockIdx.y && f <= relayBase + 15u) break;
                 __builtin_amdgcn_s_sleep(32);
             }
             red[0] = __longlong_as_double((long long)f);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
-        f = (unsigned)uni32((int)(unsigned)__double_as_longlong(red[0]));  // (uniform: the return below is a scalar branch)
+        const unsigned f = (unsigned)uni32((int)(unsigned)__double_as_longlong(red[0]));  // (uniform: the return below is a scalar branch)
         if (f == relayBase + 15u) return;  // the matrix was finished by an earlier piece
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         const uint4 *src = reinterpret_cast<const uint4 *>(p.relayBuf + (long long)blk * p.relayStride);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         __syncthreads();
         for (int i = tid; i < L.total / 16; i += NT) dst[i] = src[i];
+#ifdef KB_PROFILE
+        if (p.prof && threadIdx.x == 0) p.prof[(long long)gridDim.x * gridDim.y * 16 + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 5 + 3] = wall_clock64();  // the image is in
+#endif
     }
     if (fresh) {
         if (tid < 64) { colOf[tid] = (unsigned char)tid; posOf[tid] = (unsigned char)tid; }
@@ -709,7 +715,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     __syncthreads();
     if (uni32(ctrl->stop) == 3) {  // infeasible: kBest2D returns 0 (cpp:588-593)
         if (tid == 0) { p.nf[blk] = 0; if (p.pushed) p.pushed[blk] = 0; }
-        if (RELAY && tid == 0) __hip_atomic_store(p.relayFlag + blk, p.relayEpoch * 16u + 15u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (RELAY && tid == 0) __hip_atomic_store(p.relayFlag + blk, p.relayEpoch * 16u + 15u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
 
@@ -1618,17 +1624,29 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         // hand over: the whole LDS (pool, nodes, tile, control, minima: everything a round starts from), the round number in it
         if (tid == 0) ctrl->relayRound = roundNo;
         __syncthreads();
+#ifdef KB_PROFILE
+        if (p.prof && threadIdx.x == 0) p.prof[(long long)gridDim.x * gridDim.y * 16 + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 5 + 4] = wall_clock64();  // the rounds are over
+#endif
         uint4 *dst = reinterpret_cast<uint4 *>(p.relayBuf + (long long)blk * p.relayStride);
         const uint4 *src = reinterpret_cast<const uint4 *>(smem);
         for (int i = tid; i < L.total / 16; i += NT) dst[i] = src[i];
-        __syncthreads();  // (every thread's stores have been acknowledged: s_waitcnt vmcnt(0) in front of the barrier)
+        // every wave's stores -- the image's and, from the rounds, the hypothesis states' -- have left the CU before the barrier
+        // (a workgroup barrier alone does not wait for them), then one lane writes the XCD's L2 back and, once THAT is done,
+        // raises the flag (the wait is spelled in asm: the compiler drops its own behind a release fence when it believes the
+        // wave has nothing outstanding)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         if (tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __hip_atomic_store(p.relayFlag + blk, p.relayEpoch * 16u + blockIdx.y + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(p.relayFlag + blk, p.relayEpoch * 16u + blockIdx.y + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #ifdef KB_PROFILE
+        profAcc[13] = __builtin_readcyclecounter() - profT0;     // [13] whole kernel (this wave)
         if (p.prof && threadIdx.x == 0)
-            p.prof[(long long)gridDim.x * gridDim.y * 16 + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 3 + 1] = wall_clock64();
+            p.prof[(long long)gridDim.x * gridDim.y * 16 + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 5 + 1] = wall_clock64();
+        if (p.prof && lane == 0)
+            for (int i = 0; i < 16; i++) atomicAdd(p.prof + (long long)blk * 16 + i, profAcc[i]);
 #endif
         return;
     }
@@ -1651,12 +1669,12 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         if (p.pushed) p.pushed[blk] = ctrl->pushed;
     }
     // (relay: this matrix is finished -- the workgroups of its later pieces have nothing to do)
-    if (RELAY && tid == 0) __hip_atomic_store(p.relayFlag + blk, p.relayEpoch * 16u + 15u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (RELAY && tid == 0) __hip_atomic_store(p.relayFlag + blk, p.relayEpoch * 16u + 15u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #undef kTab
 #ifdef KB_PROFILE
     profAcc[13] = __builtin_readcyclecounter() - profT0;  // [13] whole kernel (this wave)
     if (p.prof && threadIdx.x == 0)
-        p.prof[(long long)gridDim.x * gridDim.y * 16 + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 3 + 1] = wall_clock64();
+        p.prof[(long long)gridDim.x * gridDim.y * 16 + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 5 + 1] = wall_clock64();
     if (p.prof && lane == 0)
         for (int i = 0; i < 16; i++) atomicAdd(p.prof + (long long)blk * 16 + i, profAcc[i]);
 #endif

@@ -25,7 +25,7 @@ d_c4r = torch.empty((B, k, N), dtype=torch.int32, device=dev)
 d_gain = torch.empty((B, k), dtype=torch.float64, device=dev)
 d_nf = torch.empty(B, dtype=torch.int32, device=dev)
 W = B * max(P, 1)
-prof = torch.zeros(W * 19, dtype=torch.int64, device=dev)
+prof = torch.zeros(W * 21, dtype=torch.int64, device=dev)
 eng.lib.kbest_set_profile_buffer(eng.ctx, C.c_void_p(prof.data_ptr()))
 s = torch.cuda.Stream()
 for it in range(3):
@@ -38,7 +38,7 @@ for it in range(3):
         e1.record()
     torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
-t = prof.cpu().numpy()[W * 16:].reshape(max(P, 1), B, 3)
+t = prof.cpu().numpy()[W * 16:].reshape(max(P, 1), B, 5)
 t0 = t[:, :, 0][t[:, :, 0] > 0].min()
 start, end = (t[:, :, 0] - t0) / 100.0, (t[:, :, 1] - t0) / 100.0
 print(f"{cfg}, relay {P}: launch {ms:.3f} ms, makespan {end.max():.0f} us")
@@ -49,6 +49,24 @@ for j in range(max(P, 1)):
         gap = start[j] - end[j - 1]
         line += f"   gap to the piece before: mean {gap.mean():7.1f} min {gap.min():7.1f} (negative: it waited {(-gap[gap < 0]).sum():.0f} us in all, {int((gap < 0).sum())} workgroups)"
     print(line)
+if P > 1:
+    tin, tout = (t[:, :, 3] - t0) / 100.0, (t[:, :, 4] - t0) / 100.0
+    for j in range(P):
+        m_in = t[j, :, 3] > 0
+        m_out = t[j, :, 4] > 0
+        msg = f"  piece {j}:"
+        if m_in.any():
+            msg += f" start -> image in LDS: mean {(tin[j] - start[j])[m_in].mean():6.2f} us (max {(tin[j] - start[j])[m_in].max():6.1f});"
+        if m_out.any():
+            msg += f" rounds over -> end (image out, L2 written back, flag): mean {(end[j] - tout[j])[m_out].mean():6.2f} us (max {(end[j] - tout[j])[m_out].max():6.1f}), {int(m_out.sum())} hand-overs"
+        print(msg)
+acc = prof.cpu().numpy()[:B * 16].reshape(B, 16).astype(np.float64)
+names = ["setup+root", "B busy", "merge", "A/D busy", "4", "5", "6", "rounds", "8", "9", "finish", "wait after B", "wait after A", "whole (lane-0 sum over waves)", "round prologue", "filter"]
+print("  accumulators, mean per matrix (cycle-counter ticks, summed over the waves' lane 0 and over the pieces): " + ", ".join(f"{n} {acc[:, i].mean():.0f}" for i, n in enumerate(names)))
+grid = np.arange(0.0, end.max() + 50.0, 50.0)
+st_, en_ = np.sort(start.ravel()), np.sort(end[end > 0].ravel())
+active = [int(np.searchsorted(st_, x, side="right") - np.searchsorted(en_, x, side="right")) for x in grid]
+print("  resident workgroups every 50 us: " + " ".join(str(a) for a in active))
 busy = (end - start).sum()
 nslot = int((start[0] < 5.0).sum())
 print(f"  slots {nslot}: busy {busy:.0f} us of {nslot * end.max():.0f} -> idle {100 * (1 - busy / (nslot * end.max())):.1f} %; sum of all lifetimes / slots = {busy / nslot:.0f} us")

@@ -25,7 +25,7 @@ d_r4c = torch.empty((B, k, M), dtype=torch.int32, device=dev)
 d_c4r = torch.empty((B, k, N), dtype=torch.int32, device=dev)
 d_gain = torch.empty((B, k), dtype=torch.float64, device=dev)
 d_nf = torch.empty(B, dtype=torch.int32, device=dev)
-prof = torch.zeros(B * 19, dtype=torch.int64, device=dev)
+prof = torch.zeros(B * 21, dtype=torch.int64, device=dev)
 eng.lib.kbest_set_profile_buffer(eng.ctx, C.c_void_p(prof.data_ptr()))
 s = torch.cuda.Stream()
 for it in range(3):
@@ -39,7 +39,7 @@ for it in range(3):
     torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
 p = prof.cpu().numpy()
-t = p[B * 16:].reshape(B, 3)
+t = p[B * 16:].reshape(B, 5)
 start, end = (t[:, 0] - t[:, 0].min()) / 100.0, (t[:, 1] - t[:, 0].min()) / 100.0  # microseconds
 life = end - start
 hw = t[:, 2]
