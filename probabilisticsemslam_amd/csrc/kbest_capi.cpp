@@ -139,6 +139,7 @@ struct kbest_ctx {
     unsigned relayEpoch = 0;  // ... whose values only grow: no clearing between launches
     int relay = -1;           // KBEST_RELAY: pieces per matrix (0 / 1: never; -1: choose per launch)
     int relayFirst = 0;       // KBEST_RELAY_FIRST: the first piece hands over at k * this / 1024 solutions (0: choose per launch shape)
+    int relayStep = 0;        // KBEST_RELAY_STEP: the later pieces hand over this / 1024 of k apart (0: even steps up to k)
     std::vector<int32_t> lastTie;  // KBEST_TIE_* per problem of the last synchronous call (kbest_last_tie_flags)
     int32_t *assocTieDev = nullptr;  // where kbest_assoc_probs_batch_f64_dev writes its flags (kbest_set_assoc_tie_flags_dev)
     std::mutex tieMu;
@@ -414,6 +415,7 @@ int kbest_create(kbest_ctx **out, int device)
     ctx->noTie = getenv("KBEST_NO_TIE") != nullptr;
     if (const char *e = getenv("KBEST_RELAY")) ctx->relay = atoi(e);
     if (const char *e = getenv("KBEST_RELAY_FIRST")) { const int v = atoi(e); if (v >= 1 && v <= 1023) ctx->relayFirst = v; }
+    if (const char *e = getenv("KBEST_RELAY_STEP")) { const int v = atoi(e); if (v >= 1 && v <= 1023) ctx->relayStep = v; }
     if (const char *e = getenv("KBEST_SPLIT")) { const int w = atoi(e); if (w == 2 || w == 4) ctx->splitForce = w; }
     ctx->noTiny = getenv("KBEST_NO_TINY") != nullptr;
     ctx->noBnb = getenv("KBEST_NO_BNB") != nullptr;
@@ -1106,10 +1108,15 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
             if (rc == KBEST_OK) {
                 p.relayP = relayP;
                 p.relayB = B;
-                // (where the first piece ends, in solutions: the 12-wave shape's matrices -- 64 rows -- emit their first 3/8 in about 60 %
-                //  of their time, and up to two generations that is the best first cut: 1.570 against 1.602 / 1.674 at 1/2 / 5/8;
-                //  everywhere else 5/8 -- tests/dev/relay_sweep.py)
-                p.relayFirst = ctx->relayFirst > 0 ? ctx->relayFirst : ((shp.nWaves == 12 && relayGens <= 2.2) ? 384 : 640);
+                // (where the pieces end, in solutions -- tests/dev/relay_sweep.py, three pieces: the 12-wave shape's matrices -- 64 rows --
+                //  up to two generations: cuts at 3/8 and 3/4 of k: 1.563 ms against 1.580 at 3/8, 11/16 and 1.602 at 1/2, 3/4; everything
+                //  else at 5/8 and 7/8: 4 096 x 32x32 3.16 ms against 3.21 at 5/8, 13/16 and 3.27 at 1/2, 3/4.  The last pieces are the
+                //  launch's last generation: short ones let it drain evenly, and the late solutions are the cheap ones)
+                const bool wide12 = shp.nWaves == 12 && relayGens <= 2.2;
+                p.relayFirst = ctx->relayFirst > 0 ? ctx->relayFirst : (wide12 ? 384 : 640);
+                p.relayStep = ctx->relayStep > 0 ? ctx->relayStep
+                              : (ctx->relay >= 0 ? (1024 - p.relayFirst) / (relayP - 1)   // (a forced count: even steps, every piece hands over)
+                                                 : (wide12 ? 384 : 256));
                 p.relayEpoch = ++ctx->relayEpoch;
                 p.relayBuf = static_cast<unsigned char *>(ctx->relayBuf.p);
                 p.relayStride = (long long)relayImg;

@@ -59,8 +59,8 @@ struct Params {
     // relayP); relayBuf: [relayB] LDS images of relayStride bytes (L.total + the round number); relayFlag: [relayB] progress words
     // (relayEpoch * 16 + pieces done, + 15: finished), never cleared: the epoch grows with every launch
     int relayP, relayB;
-    int relayFirst;           // the first piece hands over once k * relayFirst / 1024 solutions are out, the later ones at even steps from there
-                              // to k (the makespan ends with a generation of LAST pieces: they should be short; scalar integer arithmetic only)
+    int relayFirst, relayStep;  // piece j hands over once k * (relayFirst + j * relayStep) / 1024 solutions are out (the last piece runs to the end;
+                                // the launch ends with a generation of LAST pieces: they should be short; scalar integer arithmetic only)
     unsigned relayEpoch;
     unsigned char *relayBuf;
     long long relayStride;

@@ -810,14 +810,14 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         __syncthreads();
     }
 
-    // relay: the first piece hands over once k * relayFirst / 1024 solutions are out, the later ones at even steps from there to
+    // relay: the first piece hands over once k * relayFirst / 1024 solutions are out, the later ones relayStep / 1024 of k apart from there to
     // k (scalar integer arithmetic; the last piece and plain launches never: INT_MAX).  Kept in LDS and tested by the ONE lane
     // that counts the emitted solutions (phase D), which ends the round loop through ctrl->stop = 4: a test at the top of every
     // round by every wave (gridDim comes from memory) cost 2 % on every launch.
     if (RELAY) {
         if (tid == 0) {
             ctrl->relayCut = (blockIdx.y + 1 < gridDim.y)
-                                 ? (int)(((long long)p.k * (p.relayFirst * (gridDim.y - 1) + (1024 - p.relayFirst) * blockIdx.y)) / (1024 * (gridDim.y - 1)))
+                                 ? (int)(((long long)p.k * (p.relayFirst + p.relayStep * (int)blockIdx.y)) >> 10)
                                  : 0x7fffffff;
             if (fresh) ctrl->relayRound = 0;
             if (ctrl->stop == 4) ctrl->stop = 0;  // (a later piece: the image it took over ends with the hand-over code)

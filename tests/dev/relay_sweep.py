@@ -29,10 +29,15 @@ d_g = torch.empty((B, k), dtype=torch.float64, device=dev); d_n = torch.empty(B,
 st = torch.cuda.Stream()
 pieces = [int(x) for x in os.environ.get("SWEEP_P", "2,3,4,5,6,8").split(",")]
 firsts = [int(x) for x in os.environ.get("SWEEP_F", "256,384,512,640").split(",")]
+step = os.environ.get("SWEEP_STEP")  # with it: the columns are steps (later cuts, / 1024 of k apart) at the ONE first cut SWEEP_F names
 names, engs = ["plain"], [engine(KBEST_RELAY=0)]
+if step:
+    F0 = firsts[0]
+    firsts = [int(x) for x in step.split(",")]
 for P in pieces:
     for F in firsts:
-        names.append(f"P{P} F{F}"); engs.append(engine(KBEST_RELAY=P, KBEST_RELAY_FIRST=F))
+        names.append(f"P{P} F{F}")
+        engs.append(engine(KBEST_RELAY=P, KBEST_RELAY_FIRST=F0, KBEST_RELAY_STEP=F) if step else engine(KBEST_RELAY=P, KBEST_RELAY_FIRST=F))
 res = {n: [] for n in names}
 for rnd in range(3):
     for n, e in zip(names, engs):
@@ -46,4 +51,4 @@ for rnd in range(3):
         res[n].append(min(ts[1:]))
 print(f"{cfg} B={B}: plain {np.median(res['plain']):.3f}")
 for P in pieces:
-    print(f"  {P} pieces, first cut " + "  ".join(f"{F}/1024: {np.median(res[f'P{P} F{F}']):.3f}" for F in firsts), flush=True)
+    print(f"  {P} pieces, " + (f"first cut {F0}, steps " if step else "first cut ") + "  ".join(f"{F}/1024: {np.median(res[f'P{P} F{F}']):.3f}" for F in firsts), flush=True)
