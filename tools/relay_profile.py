@@ -1,6 +1,6 @@
 """Diagnostic (PROFILE build): the timeline of a RELAY launch of the 64-row kernel -- start / end of every (piece, matrix)
 workgroup: lifetimes per piece, the gap between a piece's end and the next piece's start, idle share of the slots.
-Run on the GPU box:  KBEST_RELAY=P python tools/relay_profile.py [config]"""
+Run on the GPU box:  [KBEST_RELAY=P [KBEST_RELAY_FIRST=.. KBEST_RELAY_STEP=..]] python tools/relay_profile.py [config]"""
 import ctypes as C
 import os
 import sys
@@ -14,7 +14,11 @@ import probabilisticsemslam_amd as pk
 from probabilisticsemslam_amd import workloads as wl
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c4"
-P = int(os.environ.get("KBEST_RELAY", "2"))
+if "KBEST_RELAY" not in os.environ:  # the launch plan's own choice for the bench configs (kbest_capi.cpp, relay_plan): the record layout depends on it
+    os.environ["KBEST_RELAY"] = "3"
+    os.environ.setdefault("KBEST_RELAY_FIRST", "384" if cfg == "c4" else "640")
+    os.environ.setdefault("KBEST_RELAY_STEP", "384" if cfg == "c4" else "256")
+P = int(os.environ["KBEST_RELAY"])
 dev = torch.device("cuda", 0)
 eng = pk.KBestEngine(0)
 Bc, N, M, k, seed = wl.DENSE_CONFIGS[cfg]
@@ -67,6 +71,16 @@ grid = np.arange(0.0, end.max() + 50.0, 50.0)
 st_, en_ = np.sort(start.ravel()), np.sort(end[end > 0].ravel())
 active = [int(np.searchsorted(st_, x, side="right") - np.searchsorted(en_, x, side="right")) for x in grid]
 print("  resident workgroups every 50 us: " + " ".join(str(a) for a in active))
+hw = t[:, :, 2].ravel()
+cu = ((hw >> 32) & 0xf) * 1000 + ((hw >> 13) & 0x7) * 100 + ((hw >> 8) & 0xf)  # (XCC, SE, CU)
+gaps = []
+for c in np.unique(cu):
+    m = cu == c
+    en = np.sort(end.ravel()[m]); stl = np.sort(start.ravel()[m]); stl = stl[stl > 5.0]
+    n = min(len(en), len(stl))
+    gaps.extend((stl[:n] - en[:n]).tolist())   # the j-th later start of a CU follows its j-th end
+gaps = np.array(gaps)
+print(f"  a slot between two workgroups (end stamp -> next start stamp on that CU, {len(gaps)} turnovers): median {np.median(gaps):.1f} us, mean {gaps.mean():.1f}, p90 {np.percentile(gaps, 90):.1f}, p99 {np.percentile(gaps, 99):.1f}")
 busy = (end - start).sum()
 nslot = int((start[0] < 5.0).sum())
 print(f"  slots {nslot}: busy {busy:.0f} us of {nslot * end.max():.0f} -> idle {100 * (1 - busy / (nslot * end.max())):.1f} %; sum of all lifetimes / slots = {busy / nslot:.0f} us")
