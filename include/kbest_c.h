@@ -199,7 +199,12 @@ int kbest_to_probs_f64(kbest_ctx *ctx, double *x, int64_t n);
 
 /* Size the context's workspace for launches of up to B problems of up to maxRow rows and k solutions.
  * Required before kbest_batch_f64_dev; the host-pointer entries call it implicitly.  When it has to
- * grow the workspace it waits for the device to go idle (hipDeviceSynchronize) and reallocates. */
+ * grow the workspace it waits for the device to go idle (hipDeviceSynchronize) and reallocates.
+ * The workspace is: the hypothesis states ([B][k + 64 + up to 1 024] records of 18 maxRow + 24 bytes), the slot tables, the
+ * gains behind the tables (exact ties) and -- for batches of more than one generation of resident workgroups, which the 64-row
+ * kernel enumerates as a relay of several workgroups per matrix -- one LDS image per matrix (25 KB at 32 rows, 70 KB at 64;
+ * at most ~400 MB: larger batches are not relayed).  A kbest_batch_f64_dev call whose batch was not reserved for fails with
+ * KBEST_ERR_NOT_RESERVED; one whose relay images alone are missing (reserved with a smaller B) runs as a plain launch. */
 int kbest_reserve(kbest_ctx *ctx, int B, int maxRow, int k);
 
 /* Diagnostic builds only (make -C probabilisticsemslam_amd/csrc PROFILE=1): device buffer of B*16 uint64
