@@ -750,6 +750,10 @@ struct DevExtra {  // optional outputs / modes of kbest_assign_batch_f64 (root s
 // piece uses the workspace slice of its problems (`blockBase` = index of its first problem) and may run concurrently with
 // the other pieces on another stream (it is not ordered behind the context's previous launch).
 struct SubBatch { int logicalB = 0, blockBase = 0; };
+// (A launch with a SubBatch is never a relay: pieces of one batch run side by side on streams of their own, each at most a generation
+//  of workgroups; and the host entries pass one -- {B, 0}: the whole batch -- whenever the kernel writes its tables into HOST memory
+//  over the link: a relay's hand-over waits for the write-back of everything its workgroup has stored, and all matrices of a relay finish
+//  together at the end instead of one after the other: 2.5 -> 3.1 ms per 1 024 x 64x64, k = 200 through kbest_batch_f64.)
 
 // Order this launch (on stream s) behind the previous launch of the context when that ran on another stream: both
 // use the context's one hypothesis workspace.  Called with ctx->mu held.  A caller-owned stream may be destroyed by its
@@ -1417,7 +1421,7 @@ int kbest_batch_f64_keep(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxR
             double *pG = keep ? keep->gain + (size_t)b0 * k : reinterpret_cast<double *>(d8 + offG) + (size_t)b0 * k;
             int32_t *pN = keep ? keep->nf + b0 : reinterpret_cast<int32_t *>(d8 + offN) + b0;
             rc = batch_dev_impl(ctx, &o8, nb, maxRow, maxCol, nullptr, nullptr, devC + (size_t)b0 * per, nullptr, k, pR, nullptr, pG, pN, nullptr,
-                                st[c], true, nullptr, nP > 1 ? &sub : nullptr);
+                                st[c], true, nullptr, (nP > 1 || !keep) ? &sub : nullptr);  // (tables in host memory: never a relay -- see SubBatch)
             if (rc != KBEST_OK) break;
             e = kb::launch_fill_unused(pN, nullptr, nullptr, nb, k, maxCol, maxRow, pR, nullptr, pG, true, st[c]);
             if (e != hipSuccess) { rc = fail(ctx, KBEST_ERR_HIP, "fill kernel launch", e); break; }
@@ -1534,7 +1538,7 @@ int kbest_batch_f64_keep(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxR
                             costOff ? devCost : devCost + (size_t)b0 * per, costOff ? dOff.as<int64_t>() + b0 : nullptr,
                             k, reinterpret_cast<int32_t *>(oR4C + (size_t)b0 * k * maxCol * esz),
                             oC4R ? reinterpret_cast<int32_t *>(oC4R + (size_t)b0 * k * maxRow * esz) : nullptr, oGain + (size_t)b0 * k, oNf + b0,
-                            pushed ? dPushed.as<int64_t>() + b0 : nullptr, st[c], true, nullptr, nPiece > 1 ? &sub : nullptr);
+                            pushed ? dPushed.as<int64_t>() + b0 : nullptr, st[c], true, nullptr, (nPiece > 1 || direct) ? &sub : nullptr);
         if (rc != KBEST_OK) break;
         if (keep && keep->stamps && c == 0) keep->stamps[1] = kb::now_s();
         // slots beyond nf are never written by the kernels, nor is the padding of a ragged batch's emitted slots: give them
