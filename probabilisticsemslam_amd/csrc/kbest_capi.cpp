@@ -818,8 +818,8 @@ static int relay_plan(const kbest_ctx *ctx, int B, int fastRow, int k, unsigned 
     const int ldsB = kb::lds_layout(fastRow, k, shp.spec, shp.nWaves).total;
     if (imgOut) *imgOut = ((size_t)ldsB + 16 + 127) & ~(size_t)127;
     if ((flags & (KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_PRUNE | KBEST_FLAG_RECT_ROOT | KBEST_FLAG_NO_SHIFT)) || k < 16) return 1;
-    // (the relay instantiations of the kernel: 4 / 8 / 12 waves, pool entries one per thread -- launch_nw, kbest_engine.hip)
-    if (!(shp.nWaves == 4 || shp.nWaves == 8 || shp.nWaves == 12) || k > shp.nWaves * 64) return 1;
+    // (the relay instantiations of the kernel: 4 / 8 / 12 waves -- launch_nw, kbest_engine.hip)
+    if (!(shp.nWaves == 4 || shp.nWaves == 8 || shp.nWaves == 12)) return 1;
     int perCU = ctx->ldsPerCU / (ldsB > 0 ? ldsB : 1);
     const int byWaves = (6 * 4) / shp.nWaves;  // six waves per SIMD (80 VGPRs)
     perCU = perCU < byWaves ? perCU : byWaves;

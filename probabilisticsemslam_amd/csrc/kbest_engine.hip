@@ -1842,9 +1842,8 @@ static hipError_t launch_nw(const Params &p, int B, hipStream_t stream)
 {
     // (relay launches: the shapes relay_shape_ok() names, one instantiation each)
     if (p.relayP > 1) {
-        if constexpr (NW == 4 || NW == 8 || NW == 12) {
-            if (p.k <= NW * 64) return launch_nw_ept<NW, 1, true>(p, B, stream);
-        }
+        if constexpr (NW == 4 || NW == 8 || NW == 12)
+            return (p.k <= NW * 64) ? launch_nw_ept<NW, 1, true>(p, B, stream) : launch_nw_ept<NW, 4, true>(p, B, stream);
         return hipErrorInvalidValue;
     }
     return (p.k <= NW * 64) ? launch_nw_ept<NW, 1, false>(p, B, stream) : launch_nw_ept<NW, 4, false>(p, B, stream);

@@ -20,7 +20,7 @@ def engine(**env):
 st = torch.cuda.Stream()
 rng = np.random.default_rng(5)
 for (N, M, k, B, cutoff) in ((64, 64, 50, 1024, None), (64, 64, 20, 2048, None), (48, 48, 100, 2000, None), (40, 40, 200, 1500, None), (64, 32, 200, 1024, None),
-                             (64, 64, 200, 1024, 0.15), (33, 33, 200, 3000, None), (56, 56, 256, 900, None), (64, 64, 700, 800, None), (24, 24, 200, 6000, None)):
+                             (64, 64, 200, 1024, 0.15), (33, 33, 200, 3000, None), (56, 56, 256, 900, None), (64, 64, 700, 800, None), (24, 24, 200, 6000, None), (64, 64, 1000, 700, None), (32, 32, 600, 2500, None)):
     costs = rng.random((B, N * M))
     d_cost = torch.from_numpy(costs).to(dev)
     d_r = torch.empty((B, k, M), dtype=torch.int32, device=dev); d_c = torch.empty((B, k, N), dtype=torch.int32, device=dev)

@@ -304,7 +304,7 @@ def test_relay_pieces_leave_the_tables_unchanged(monkeypatch, pieces):
     rng = np.random.default_rng(77 + pieces)
     cases = [(24, 24, 200, 300, {}), (33, 33, 200, 40, {}), (64, 64, 200, 24, {}), (48, 40, 100, 30, {}),
              (64, 64, 17, 20, {}), (40, 40, 120, 20, {"maximize": True}), (30, 10, 200, 64, {"cutoff": 3.0}),
-             (20, 20, 256, 20, {}), (64, 3, 150, 20, {})]
+             (20, 20, 256, 20, {}), (64, 3, 150, 20, {}), (24, 24, 700, 12, {}), (64, 64, 900, 6, {}), (40, 40, 600, 300, {})]
     for N, M, k, B, kw in cases:
         costs = rng.random((B, N * M))
         nf, r4c, c4r, g = eng.kbest(costs, N, M, k, **kw)
