@@ -753,7 +753,8 @@ struct SubBatch { int logicalB = 0, blockBase = 0; };
 // (A launch with a SubBatch is never a relay: pieces of one batch run side by side on streams of their own, each at most a generation
 //  of workgroups; and the host entries pass one -- {B, 0}: the whole batch -- whenever the kernel writes its tables into HOST memory
 //  over the link: a relay's hand-over waits for the write-back of everything its workgroup has stored, and all matrices of a relay finish
-//  together at the end instead of one after the other: 2.5 -> 3.1 ms per 1 024 x 64x64, k = 200 through kbest_batch_f64.)
+//  together at the end instead of one after the other.  1 024 x 64x64, k = 200 through kbest_batch_f64 (tests/dev/host_pieces.sh): four pieces
+//  2.5 - 2.66 ms, two 2.65 - 2.70, ONE launch 3.32 - 3.36, one launch as a relay 3.1 - 3.6.)
 
 // Order this launch (on stream s) behind the previous launch of the context when that ran on another stream: both
 // use the context's one hypothesis workspace.  Called with ctx->mu held.  A caller-owned stream may be destroyed by its
@@ -1360,7 +1361,7 @@ int kbest_batch_f64_keep(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxR
         if (!zcCostOK(pinnedCost, ctx)) HIP_TRY(ctx, dCostN.alloc(ctx, nCost * 8));
         const bool zc = zcCostOK(pinnedCost, ctx);
         const double *devC = zc ? mCost : dCostN.as<double>();
-        const int nP = (B >= 4 * ctx->nCU) ? 4 : 1;
+        const int nP = (B >= 4 * ctx->nCU) ? (ctx->pieces > 0 ? ctx->pieces : 4) : 1;
         for (int i = 0; i < 3 && nP > 1; i++)
             if (!ctx->aux[i]) HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->aux[i], hipStreamNonBlocking, ctx->prioAux[i]));
         if (nP > 1 && !ctx->hi) HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->hi, hipStreamNonBlocking, ctx->prioMain));
