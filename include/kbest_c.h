@@ -288,6 +288,9 @@ int kbest_set_assoc_tie_flags_dev(kbest_ctx *ctx, int32_t *d_flags);
 /* KBEST_TIE_* flags of the problems of the context's last SYNCHRONOUS call (kbest_batch_f64 and every host-buffer association
  * entry, which have no other way to return them: the shims of kbest_shims.hpp included).  Copies min(n, cap) flags, returns n. */
 int kbest_last_tie_flags(kbest_ctx *ctx, int32_t *flags, int cap);
+/* Diagnostic: launches of the 64-row kernel this context has made as a relay (several workgroups per matrix in turn; the
+ * comment of kbest_reserve, NOTES.md 10.6) since it was created -- for tests that must know the path they exercise was taken. */
+long long kbest_relay_launches(kbest_ctx *ctx);
 
 /*
  * Batched computeQuadricCostMatrix (assignment.h:28-29, assignment.cpp:705-722).  Frame b has nL[b] landmarks and

@@ -137,6 +137,7 @@ struct kbest_ctx {
     DevBufRaw relayBuf;       // relay launches of the 64-row kernel: [B] LDS images (kbest_engine.hip)
     DevBufRaw relayFlags;     // ... and [B] progress words (zeroed when the buffer is made)
     unsigned relayEpoch = 0;  // ... whose values only grow: no clearing between launches
+    long long relayLaunches = 0;  // relay launches made (kbest_relay_launches)
     int relay = -1;           // KBEST_RELAY: pieces per matrix (0 / 1: never; -1: choose per launch)
     int relayFirst = 0;       // KBEST_RELAY_FIRST: the first piece hands over at k * this / 1024 solutions (0: choose per launch shape)
     int relayStep = 0;        // KBEST_RELAY_STEP: the later pieces hand over this / 1024 of k apart (0: even steps up to k)
@@ -1122,10 +1123,20 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
                 p.relayStep = ctx->relayStep > 0 ? ctx->relayStep
                               : (ctx->relay >= 0 ? (1024 - p.relayFirst) / (relayP - 1)   // (a forced count: even steps, every piece hands over)
                                                  : (wide12 ? 384 : 256));
+                ctx->relayLaunches++;
                 p.relayEpoch = ++ctx->relayEpoch;
                 p.relayBuf = static_cast<unsigned char *>(ctx->relayBuf.p);
                 p.relayStride = (long long)relayImg;
                 p.relayFlag = static_cast<unsigned *>(ctx->relayFlags.p);
+                // (inside a stream capture the launch will be REPLAYED with this very epoch: the progress words are cleared by a node of
+                //  the graph in front of the kernel -- zero is below every epoch's range, and whatever a later launch outside the
+                //  graph leaves there is gone before the next replay)
+#ifndef KB_NO_CAPTURE_MEMSET
+                if (capturing(s)) {
+                    hipError_t me = hipMemsetAsync(p.relayFlag, 0, (size_t)B * 4, s);
+                    if (me != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "relay progress words (capture)", me);
+                }
+#endif
             } else if (rc != KBEST_ERR_NOT_RESERVED) {
                 return rc;
             }  // (not reserved: an asynchronous entry never allocates -- the launch runs without the relay)
@@ -2426,6 +2437,13 @@ static int weights_entry(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t
         ctx->lastTie.swap(t);
     }
     return rc;
+}
+
+long long kbest_relay_launches(kbest_ctx *ctx)
+{
+    if (!ctx) return KBEST_ERR_BAD_ARG;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    return ctx->relayLaunches;
 }
 
 int kbest_last_tie_flags(kbest_ctx *ctx, int32_t *flags, int cap)

@@ -34,6 +34,7 @@ C_ABI_SYMBOLS = (
     "kbest_create_multi", "kbest_destroy_multi", "kbest_multi_size", "kbest_multi_last_error", "kbest_batch_f64_multi",
     "kbest_multi_tables_agree", "kbest_batch_f64_multi_ex", "kbest_merge_topk_f64_dev", "kbest_register_host_buffer",
     "kbest_unregister_host_buffer", "kbest_multi_timeline", "kbest_last_tie_flags", "kbest_set_assoc_tie_flags_dev",
+    "kbest_relay_launches",
 )
 KBEST_MULTI_STAMPS = 6
 KBEST_MULTI_BATCH, KBEST_MULTI_SUBTREE = 0, 1
@@ -110,6 +111,9 @@ def load_library():
                                              i32p, vp]
     if hasattr(lib, "kbest_multi_timeline"):  # (absent from older in-tree builds selected with KBEST_LIB for A/B runs)
         lib.kbest_multi_timeline.argtypes = [vp, dp, C.c_int]
+    if hasattr(lib, "kbest_relay_launches"):
+        lib.kbest_relay_launches.argtypes = [vp]
+        lib.kbest_relay_launches.restype = C.c_longlong
     if hasattr(lib, "kbest_last_tie_flags"):
         lib.kbest_last_tie_flags.argtypes = [vp, i32p, C.c_int]
         lib.kbest_set_assoc_tie_flags_dev.argtypes = [vp, vp]
@@ -231,6 +235,10 @@ class KBestEngine:
                                                        _ptr(out), _ptr(good), _ptr(ridx), maxRow))
         return ([out[off[b]: off[b] + int(good[b]) * int(nCols[b])].copy() for b in range(B)],
                 [ridx[b, : good[b]].copy() for b in range(B)])
+
+    def relay_launches(self):
+        """Launches of the 64-row kernel this context has made as a relay (diagnostic, kbest_relay_launches)."""
+        return int(self.lib.kbest_relay_launches(self.ctx))
 
     def last_tie_flags(self):
         """KBEST_TIE_* flags of the problems of this context's last synchronous call (kbest_last_tie_flags)."""

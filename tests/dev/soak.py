@@ -13,4 +13,4 @@ ncase, nprob, bad = soak_lib.run(eng, seed, seconds=budget, big_frac=float(os.en
                                  big_max=int(os.environ.get("SOAK_BIGMAX", "200")))
 if bad:
     print("MISMATCH", bad); sys.exit(1)
-print(f"soak ok: {ncase} cases, {nprob} problems (seed {seed})")
+print(f"soak ok: {ncase} cases, {nprob} problems (seed {seed}); {eng.relay_launches()} launches of the 64-row kernel were relays")

@@ -294,20 +294,39 @@ def test_apriori_threshold_scratch_is_not_rearmed_early(monkeypatch):
         assert (nf == want).all(), (rep, np.nonzero(nf != want)[0][:5], nf[nf != want][:5], want[nf != want][:5])
 
 
-@pytest.mark.parametrize("pieces", [2, 3, 5, 8])
-def test_relay_pieces_leave_the_tables_unchanged(monkeypatch, pieces):
+def dev_kbest(eng, costs, N, M, k, **kw):
+    """The asynchronous device entry (the one that launches relays: the host entries write their tables into host memory and
+    never do) on fresh device buffers; returns numpy (nf, row4col, col4row, gain)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    B = costs.shape[0]
+    d_cost = torch.from_numpy(np.ascontiguousarray(costs)).to(dev)
+    d_r = torch.full((B, k, M), -7, dtype=torch.int32, device=dev)
+    d_c = torch.full((B, k, N), -7, dtype=torch.int32, device=dev)
+    d_g = torch.full((B, k), float("nan"), dtype=torch.float64, device=dev)
+    d_n = torch.full((B,), -7, dtype=torch.int32, device=dev)
+    eng.kbest_dev(d_cost, B, N, M, k, d_r, d_c, d_g, d_n, stream=torch.cuda.current_stream().cuda_stream, **kw)
+    torch.cuda.synchronize()
+    return d_n.cpu().numpy(), d_r.cpu().numpy(), d_c.cpu().numpy(), d_g.cpu().numpy()
+
+
+@pytest.mark.parametrize("pieces,nwaves", [(2, 4), (3, 4), (3, 8), (5, 8), (3, 12), (8, 12)])
+def test_relay_pieces_leave_the_tables_unchanged(monkeypatch, pieces, nwaves):
     """Relay launches (round 5): a matrix is enumerated by `pieces` workgroups one after the other, the LDS handed on through
     HBM.  Forced (KBEST_RELAY) on small batches of every shape the 64-row kernel runs the relay in -- 4, 8 and 12 waves; square,
     rectangular, ragged; with a cutoff; maximising; k above and below the pieces' shares -- the tables are the checker's, bit
     for bit (shortestPathCPP.cpp:574-760 order)."""
-    eng = engine_with(monkeypatch, KBEST_RELAY=pieces, KBEST_NO_SMALL=1, KBEST_NO_LANE=1, KBEST_NO_TINY=1, KBEST_NO_BNB=1)
-    rng = np.random.default_rng(77 + pieces)
+    eng = engine_with(monkeypatch, KBEST_RELAY=pieces, KBEST_NWAVES=nwaves, KBEST_NO_SMALL=1, KBEST_NO_LANE=1, KBEST_NO_TINY=1, KBEST_NO_BNB=1)
+    rng = np.random.default_rng(77 + pieces + nwaves)
+    relayed = 0
     cases = [(24, 24, 200, 300, {}), (33, 33, 200, 40, {}), (64, 64, 200, 24, {}), (48, 40, 100, 30, {}),
              (64, 64, 17, 20, {}), (40, 40, 120, 20, {"maximize": True}), (30, 10, 200, 64, {"cutoff": 3.0}),
              (20, 20, 256, 20, {}), (64, 3, 150, 20, {}), (24, 24, 700, 12, {}), (64, 64, 900, 6, {}), (40, 40, 600, 300, {})]
     for N, M, k, B, kw in cases:
         costs = rng.random((B, N * M))
-        nf, r4c, c4r, g = eng.kbest(costs, N, M, k, **kw)
+        before = eng.relay_launches()
+        nf, r4c, c4r, g = dev_kbest(eng, costs, N, M, k, **kw)
+        relayed += eng.relay_launches() > before
         wn, wr, wc, wg, _ = ol.orc_kbest_batch(costs, N, M, k, **kw)
         assert (nf == wn).all(), (N, M, k)
         for b in range(B):
@@ -315,6 +334,7 @@ def test_relay_pieces_leave_the_tables_unchanged(monkeypatch, pieces):
             assert (bits(g[b, :n]) == bits(wg[b, :n])).all(), (N, M, k, b)
             assert (r4c[b, :n] == wr[b, :n]).all(), (N, M, k, b)
             assert (c4r[b, :n, :][wc[b, :n, :] < M] == wc[b, :n, :][wc[b, :n, :] < M]).all(), (N, M, k, b)
+    assert relayed >= len(cases) - 2, relayed  # (the launches WERE relays: all but the shapes the forced wave count cannot take)
 
 
 def test_relay_is_chosen_for_batches_of_several_generations_and_changes_nothing(monkeypatch):
@@ -325,9 +345,57 @@ def test_relay_is_chosen_for_batches_of_several_generations_and_changes_nothing(
     auto = pk.KBestEngine(0)
     for name, B in (("c4", 1024), ("c3", 2048), ("c4", 700)):
         costs, N, M, k = wl.dense_config(name, B=B)
-        a = plain.kbest(costs, N, M, k)
+        a = dev_kbest(plain, costs, N, M, k)
+        assert plain.relay_launches() == 0
         for _ in range(2):
-            b = auto.kbest(costs, N, M, k)
+            before = auto.relay_launches()
+            b = dev_kbest(auto, costs, N, M, k)
+            assert auto.relay_launches() == before + 1, name
             assert (a[0] == b[0]).all()
             assert (a[1] == b[1]).all() and (a[2] == b[2]).all()
             assert (bits(a[3]) == bits(b[3])).all()
+
+
+def test_relay_launch_inside_a_graph_is_replayable(monkeypatch):
+    """A captured relay launch is replayed with the epoch it was captured with: its progress words are cleared by a node of the
+    graph.  96 x 64x64, k = 200 as a forced relay of three pieces (every piece resident from the start: a stale progress word
+    would be read at once), captured once, replayed on new inputs with a plain relay launch of the same context in between (it
+    moves the epoch on); every replay equals a plain launch (KBEST_RELAY=0) of the same input."""
+    import torch
+    dev = torch.device("cuda", 0)
+    plain = engine_with(monkeypatch, KBEST_RELAY=0)
+    eng = engine_with(monkeypatch, KBEST_RELAY=3, KBEST_NWAVES=12)  # (the shape of large batches: small ones run 16 waves, never relayed)
+    _, N, M, k, seed = wl.DENSE_CONFIGS["c4"]
+    B = 96
+    costs = wl.dense_batch(B, N, M, seed)
+    d_cost = torch.from_numpy(costs).to(dev)
+    d_other = torch.from_numpy(wl.dense_batch(B, N, M, seed, first=200)).to(dev)
+    d_r4c = torch.empty((B, k, M), dtype=torch.int32, device=dev)
+    d_c4r = torch.empty((B, k, N), dtype=torch.int32, device=dev)
+    d_g = torch.empty((B, k), dtype=torch.float64, device=dev)
+    d_nf = torch.empty(B, dtype=torch.int32, device=dev)
+    d_r2, d_c2, d_g2, d_n2 = torch.empty_like(d_r4c), torch.empty_like(d_c4r), torch.empty_like(d_g), torch.empty_like(d_nf)
+    eng.reserve(B, N, k)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        eng.kbest_dev(d_cost, B, N, M, k, d_r4c, d_c4r, d_g, d_nf, stream=s.cuda_stream)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        eng.kbest_dev(d_cost, B, N, M, k, d_r4c, d_c4r, d_g, d_nf, stream=s.cuda_stream)
+    for it, first in enumerate((5000, 9000, 13000, 17000)):
+        c2 = wl.dense_batch(B, N, M, seed, first=first)
+        d_cost.copy_(torch.from_numpy(c2))
+        d_g.zero_(); d_nf.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        want = plain.kbest(c2, N, M, k)
+        assert eng.relay_launches() >= 2
+        assert (d_nf.cpu().numpy() == want[0]).all(), first
+        assert (d_r4c.cpu().numpy() == want[1]).all() and (bits(d_g.cpu().numpy()) == bits(want[3])).all(), first
+        if it % 2 == 0:
+            continue  # (the next replay follows this one directly: it finds the words as this one left them)
+        with torch.cuda.stream(s):  # a relay launch of the same context outside the graph
+            eng.kbest_dev(d_other, B, N, M, k, d_r2, d_c2, d_g2, d_n2, stream=s.cuda_stream)
+        torch.cuda.synchronize()
+        assert (d_n2.cpu().numpy() == k).all()

@@ -11,7 +11,9 @@ t=$((secs * 3 + 120))
 {
 echo "# soak of $(git rev-parse --short HEAD 2>/dev/null || echo 'the working tree'), $secs s per leg, seeds $seed.."
 echo "k-best tables, every kernel against the checker: $(timeout $t python3 tests/dev/soak.py $secs $seed 2>&1 | tail -1)"
-echo "k-best tables, the 64-row kernel as a relay of three pieces (KBEST_RELAY=3 KBEST_NO_SMALL KBEST_NO_LANE) against the checker: $(KBEST_RELAY=3 KBEST_NO_SMALL=1 KBEST_NO_LANE=1 timeout $t python3 tests/dev/soak.py $secs $((seed + 5)) 2>&1 | tail -1)"
+for nw in 4 8 12; do
+echo "k-best tables, every 64-row launch forced into a relay of three pieces of the $nw-wave shape (KBEST_RELAY=3 KBEST_NWAVES=$nw KBEST_NO_SMALL KBEST_NO_LANE) against the checker: $(KBEST_RELAY=3 KBEST_NWAVES=$nw KBEST_NO_SMALL=1 KBEST_NO_LANE=1 timeout $t python3 tests/dev/soak.py $secs $((seed + 5 + nw)) 2>&1 | tail -1)"
+done
 echo "association path against the checker: $(timeout $t python3 tests/dev/soak_assoc.py $secs $((seed + 1)) 2>&1 | tail -1)"
 echo "association path on the enumeration kernels only (KBEST_NO_TINY KBEST_NO_BNB) against the checker: $(KBEST_NO_TINY=1 KBEST_NO_BNB=1 timeout $t python3 tests/dev/soak_assoc.py $secs $((seed + 2)) 2>&1 | tail -1)"
 echo "exhaustive kernel against the enumeration kernels, exact ties included: $(timeout $t python3 tests/dev/soak_tiny.py $secs $((seed + 3)) 2>&1 | tail -1)"
