@@ -752,8 +752,8 @@ struct DevExtra {  // optional outputs / modes of kbest_assign_batch_f64 (root s
 // the other pieces on another stream (it is not ordered behind the context's previous launch).
 struct SubBatch { int logicalB = 0, blockBase = 0; };
 // (A launch with a SubBatch is never a relay: pieces of one batch run side by side on streams of their own, each at most a generation
-//  of workgroups; and the host entries pass one -- {B, 0}: the whole batch -- whenever the kernel writes its tables into HOST memory
-//  over the link: a relay's hand-over waits for the write-back of everything its workgroup has stored, and all matrices of a relay finish
+//  of workgroups; nor is one of a host entry whose kernel writes its tables into HOST memory over the link -- batch_dev_impl's
+//  hostTables: a relay's hand-over waits for the write-back of everything its workgroup has stored, and all matrices of a relay finish
 //  together at the end instead of one after the other.  1 024 x 64x64, k = 200 through kbest_batch_f64 (tests/dev/host_pieces.sh): four pieces
 //  2.5 - 2.66 ms, two 2.65 - 2.70, ONE launch 3.32 - 3.36, one launch as a relay 3.1 - 3.6.)
 
@@ -864,7 +864,7 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
                           const int32_t *d_nRow, const int32_t *d_nCol, const double *d_cost,
                           const int64_t *d_costOff, int k, int32_t *d_row4col, int32_t *d_col4row,
                           double *d_gain, int32_t *d_nf, int64_t *d_pushed, void *stream, bool grow,
-                          const DevExtra *extra = nullptr, const SubBatch *sub = nullptr)
+                          const DevExtra *extra = nullptr, const SubBatch *sub = nullptr, bool hostTables = false)
 {
     if (!ctx) return KBEST_ERR_BAD_ARG;
     if (!opts || B < 0 || k < 1 || maxCol < 1 || maxRow < maxCol || !d_cost || !d_row4col || !d_gain || !d_nf)
@@ -1108,7 +1108,7 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         // 10.6).  Whole launches of the plain enumeration only, where the batch is 1.2 ... 6 generations of resident workgroups.
         size_t relayImg = 0;
         double relayGens = 0.0;
-        const int relayP = (!sub && !extra && S == 1) ? relay_plan(ctx, B, fastRow, k, opts->flags, shp, &relayImg, &relayGens) : 1;
+        const int relayP = (!sub && !extra && S == 1 && !hostTables) ? relay_plan(ctx, B, fastRow, k, opts->flags, shp, &relayImg, &relayGens) : 1;
         if (relayP > 1) {
             rc = relay_reserve(ctx, B, relayImg, grow);
             if (rc == KBEST_OK) {
@@ -1433,7 +1433,7 @@ int kbest_batch_f64_keep(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxR
             double *pG = keep ? keep->gain + (size_t)b0 * k : reinterpret_cast<double *>(d8 + offG) + (size_t)b0 * k;
             int32_t *pN = keep ? keep->nf + b0 : reinterpret_cast<int32_t *>(d8 + offN) + b0;
             rc = batch_dev_impl(ctx, &o8, nb, maxRow, maxCol, nullptr, nullptr, devC + (size_t)b0 * per, nullptr, k, pR, nullptr, pG, pN, nullptr,
-                                st[c], true, nullptr, (nP > 1 || !keep) ? &sub : nullptr);  // (tables in host memory: never a relay -- see SubBatch)
+                                st[c], true, nullptr, nP > 1 ? &sub : nullptr, !keep);  // (!keep: tables in host memory -- never a relay, see SubBatch)
             if (rc != KBEST_OK) break;
             e = kb::launch_fill_unused(pN, nullptr, nullptr, nb, k, maxCol, maxRow, pR, nullptr, pG, true, st[c]);
             if (e != hipSuccess) { rc = fail(ctx, KBEST_ERR_HIP, "fill kernel launch", e); break; }
@@ -1550,7 +1550,7 @@ int kbest_batch_f64_keep(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxR
                             costOff ? devCost : devCost + (size_t)b0 * per, costOff ? dOff.as<int64_t>() + b0 : nullptr,
                             k, reinterpret_cast<int32_t *>(oR4C + (size_t)b0 * k * maxCol * esz),
                             oC4R ? reinterpret_cast<int32_t *>(oC4R + (size_t)b0 * k * maxRow * esz) : nullptr, oGain + (size_t)b0 * k, oNf + b0,
-                            pushed ? dPushed.as<int64_t>() + b0 : nullptr, st[c], true, nullptr, (nPiece > 1 || direct) ? &sub : nullptr);
+                            pushed ? dPushed.as<int64_t>() + b0 : nullptr, st[c], true, nullptr, nPiece > 1 ? &sub : nullptr, direct);
         if (rc != KBEST_OK) break;
         if (keep && keep->stamps && c == 0) keep->stamps[1] = kb::now_s();
         // slots beyond nf are never written by the kernels, nor is the padding of a ragged batch's emitted slots: give them
