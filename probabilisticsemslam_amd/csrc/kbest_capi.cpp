@@ -1108,7 +1108,7 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         // 10.6).  Whole launches of the plain enumeration only, where the batch is 1.2 ... 6 generations of resident workgroups.
         size_t relayImg = 0;
         double relayGens = 0.0;
-        const int relayP = (!sub && !extra && S == 1 && !hostTables) ? relay_plan(ctx, B, fastRow, k, opts->flags, shp, &relayImg, &relayGens) : 1;
+        const int relayP = (!sub && !extra && S == 1 && !hostTables && opts->root_col_stride <= 1) ? relay_plan(ctx, B, fastRow, k, opts->flags, shp, &relayImg, &relayGens) : 1;
         if (relayP > 1) {
             rc = relay_reserve(ctx, B, relayImg, grow);
             if (rc == KBEST_OK) {
