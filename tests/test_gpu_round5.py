@@ -399,3 +399,48 @@ def test_relay_launch_inside_a_graph_is_replayable(monkeypatch):
             eng.kbest_dev(d_other, B, N, M, k, d_r2, d_c2, d_g2, d_n2, stream=s.cuda_stream)
         torch.cuda.synchronize()
         assert (d_n2.cpu().numpy() == k).all()
+
+
+@pytest.mark.parametrize("nwaves", [4, 8, 12])
+def test_relay_ragged_batch_with_infeasible_and_empty_frames(monkeypatch, nwaves):
+    """A forced relay over a RAGGED batch (per-problem numRow / numCol, packed cost blocks) that also holds infeasible problems
+    (a column of +inf: kBest2D returns 0, shortestPathCPP.cpp:588-593), problems with fewer than k assignments, and problems
+    whose shape is undefined in the reference (numRow < numCol: nf = -1) -- every later piece of those must find the matrix
+    finished and leave.  Against the checker, problem by problem."""
+    import torch
+    dev = torch.device("cuda", 0)
+    eng = engine_with(monkeypatch, KBEST_RELAY=3, KBEST_NWAVES=nwaves, KBEST_NO_SMALL=1, KBEST_NO_LANE=1, KBEST_NO_TINY=1, KBEST_NO_BNB=1)
+    rng = np.random.default_rng(900 + nwaves)
+    B, maxRow, maxCol, k = 90, 40, 40, 120
+    nRow = rng.integers(1, maxRow + 1, B).astype(np.int32)
+    nCol = np.array([int(rng.integers(1, r + 1)) for r in nRow], np.int32)
+    nRow[5], nCol[5] = 3, 7            # undefined shape
+    nRow[11], nCol[11] = 3, 3          # 6 assignments in all: fewer than k
+    blocks = [rng.random(int(r) * int(c)) for r, c in zip(nRow, nCol)]
+    blocks[17][: int(nRow[17])] = np.inf   # first column all +inf: infeasible
+    blocks[23][:] = np.inf
+    off = np.zeros(B, np.int64)
+    off[1:] = np.cumsum([len(b_) for b_ in blocks[:-1]])
+    flat = np.concatenate(blocks)
+    d_cost = torch.from_numpy(flat).to(dev)
+    d_nR, d_nC, d_off = torch.from_numpy(nRow).to(dev), torch.from_numpy(nCol).to(dev), torch.from_numpy(off).to(dev)
+    d_r = torch.full((B, k, maxCol), -7, dtype=torch.int32, device=dev)
+    d_c = torch.full((B, k, maxRow), -7, dtype=torch.int32, device=dev)
+    d_g = torch.full((B, k), float("nan"), dtype=torch.float64, device=dev)
+    d_n = torch.full((B,), -7, dtype=torch.int32, device=dev)
+    before = eng.relay_launches()
+    eng.kbest_dev(d_cost, B, maxRow, maxCol, k, d_r, d_c, d_g, d_n, stream=torch.cuda.current_stream().cuda_stream,
+                  d_nRow=d_nR, d_nCol=d_nC, d_costOff=d_off)
+    torch.cuda.synchronize()
+    assert eng.relay_launches() == before + 1
+    nf, r4c, g = d_n.cpu().numpy(), d_r.cpu().numpy(), d_g.cpu().numpy()
+    for b in range(B):
+        N, M = int(nRow[b]), int(nCol[b])
+        if N < M:
+            assert nf[b] == -1, b
+            continue
+        wn, wr, wc, wg = ol.orc_kbest(blocks[b], N, M, k)
+        assert nf[b] == wn, (b, N, M, nf[b], wn)
+        assert (bits(g[b, :wn]) == bits(wg[:wn])).all(), b
+        assert (r4c[b, :wn, :M] == wr[:wn]).all(), b
+    assert nf[17] == 0 and nf[23] == 0 and nf[11] == 6
