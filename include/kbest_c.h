@@ -204,8 +204,7 @@ int kbest_to_probs_f64(kbest_ctx *ctx, double *x, int64_t n);
  * gains behind the tables (exact ties) and -- for batches of more than one generation of resident workgroups, which the 64-row
  * kernel enumerates as a relay of several workgroups per matrix -- one LDS image per matrix (25 KB at 32 rows, 70 KB at 64;
  * at most ~400 MB: larger batches are not relayed).  A kbest_batch_f64_dev call whose batch was not reserved for fails with
- * KBEST_ERR_NOT_RESERVED; one whose relay images alone are missing (reserved with a smaller B) runs as a plain launch.
- * Inside a stream capture a relay launch is two nodes: a memset of its progress words and the kernel. */
+ * KBEST_ERR_NOT_RESERVED; one whose relay images alone are missing (reserved with a smaller B) runs as a plain launch. */
 int kbest_reserve(kbest_ctx *ctx, int B, int maxRow, int k);
 
 /* Diagnostic builds only (make -C probabilisticsemslam_amd/csrc PROFILE=1): device buffer of B*16 uint64

@@ -135,8 +135,7 @@ struct kbest_ctx {
     DevBufRaw splitBuf;       // per-share result tables + shared thresholds of the split
     DevBufRaw tieBuf;         // [B] fp64: gain of the solution behind the tables (exact ties, kbest_ties.h)
     DevBufRaw relayBuf;       // relay launches of the 64-row kernel: [B] LDS images (kbest_engine.hip)
-    DevBufRaw relayFlags;     // ... and [B] progress words (zeroed when the buffer is made)
-    unsigned relayEpoch = 0;  // ... whose values only grow: no clearing between launches
+    DevBufRaw relayFlags;     // ... and three words per matrix: claimed / done / gone (zeroed when the buffer is made, put back to zero by every launch)
     long long relayLaunches = 0;  // relay launches made (kbest_relay_launches)
     int relay = -1;           // KBEST_RELAY: pieces per matrix (0 / 1: never; -1: choose per launch)
     int relayFirst = 0;       // KBEST_RELAY_FIRST: the first piece hands over at k * this / 1024 solutions (0: choose per launch shape)
@@ -839,7 +838,7 @@ static int relay_plan(const kbest_ctx *ctx, int B, int fastRow, int k, unsigned 
 
 static int relay_reserve(kbest_ctx *ctx, int B, size_t img, bool grow)
 {
-    const size_t need = (size_t)B * img, needF = (size_t)B * 4;
+    const size_t need = (size_t)B * img, needF = (size_t)B * 16;  // (three arrays of words in quarters of the buffer)
     if (need <= ctx->relayBuf.bytes && needF <= ctx->relayFlags.bytes) return KBEST_OK;
     if (!grow) return KBEST_ERR_NOT_RESERVED;
     int rc = raw_reserve(ctx, ctx->relayBuf, need);
@@ -849,7 +848,6 @@ static int relay_reserve(kbest_ctx *ctx, int B, size_t img, bool grow)
         if (rc != KBEST_OK) return rc;
         HIP_TRY(ctx, hipMemset(ctx->relayFlags.p, 0, ctx->relayFlags.bytes));
         HIP_TRY(ctx, hipDeviceSynchronize());
-        ctx->relayEpoch = 0;
     }
     return KBEST_OK;
 }
@@ -1124,19 +1122,11 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
                               : (ctx->relay >= 0 ? (1024 - p.relayFirst) / (relayP - 1)   // (a forced count: even steps, every piece hands over)
                                                  : (wide12 ? 384 : 256));
                 ctx->relayLaunches++;
-                p.relayEpoch = ++ctx->relayEpoch;
                 p.relayBuf = static_cast<unsigned char *>(ctx->relayBuf.p);
                 p.relayStride = (long long)relayImg;
                 p.relayFlag = static_cast<unsigned *>(ctx->relayFlags.p);
-                // (inside a stream capture the launch will be REPLAYED with this very epoch: the progress words are cleared by a node of
-                //  the graph in front of the kernel -- zero is below every epoch's range, and whatever a later launch outside the
-                //  graph leaves there is gone before the next replay)
-#ifndef KB_NO_CAPTURE_MEMSET
-                if (capturing(s)) {
-                    hipError_t me = hipMemsetAsync(p.relayFlag, 0, (size_t)B * 4, s);
-                    if (me != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "relay progress words (capture)", me);
-                }
-#endif
+                p.relayClaim = p.relayFlag + ctx->relayFlags.bytes / 16;  // (quarters of the buffer, wherever a smaller batch ends)
+                p.relayGone = p.relayFlag + ctx->relayFlags.bytes / 8;
             } else if (rc != KBEST_ERR_NOT_RESERVED) {
                 return rc;
             }  // (not reserved: an asynchronous entry never allocates -- the launch runs without the relay)

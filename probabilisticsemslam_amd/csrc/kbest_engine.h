@@ -56,15 +56,16 @@ struct Params {
     int kTab;
     double *tieGain;
     // relay (kbest_engine.hip): relayP > 1: every matrix is enumerated by relayP workgroups one after the other (grid = relayB x
-    // relayP); relayBuf: [relayB] LDS images of relayStride bytes (L.total + the round number); relayFlag: [relayB] progress words
-    // (relayEpoch * 16 + pieces done, + 15: finished), never cleared: the epoch grows with every launch
+    // relayP); relayBuf: [relayB] LDS images of relayStride bytes; three words per matrix, all zero between launches (the last of a
+    // matrix' workgroups to leave clears them): relayClaim -- pieces claimed (a workgroup's piece is what it claims), relayFlag --
+    // pieces done (15: the matrix is finished), relayGone -- workgroups that have left
     int relayP, relayB;
     int relayFirst, relayStep;  // piece j hands over once k * (relayFirst + j * relayStep) / 1024 solutions are out (the last piece runs to the end;
                                 // the launch ends with a generation of LAST pieces: they should be short; scalar integer arithmetic only)
-    unsigned relayEpoch;
     unsigned char *relayBuf;
     long long relayStride;
     unsigned *relayFlag;
+    unsigned *relayClaim, *relayGone;
 };
 
 struct CondParams {

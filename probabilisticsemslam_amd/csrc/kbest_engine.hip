@@ -332,14 +332,44 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     // split > 1: ONE matrix is enumerated by `split` workgroups, each taking the root's children on columns c % split == share
     // (Murty's partition of the root is disjoint, cpp:455-532) into its own tables [share][matrix]; a k-way merge follows
     // (kbest_merge.hip).  They share an upper bound of the k-th best gain through sharedT (see the top of the round loop).
-    // Relay (round 5): a matrix is enumerated by gridDim.y workgroups ONE AFTER THE OTHER -- workgroup (blockIdx.y = piece,
-    // blockIdx.x = matrix) takes the matrix up to a share of its k solutions, leaves its whole LDS in HBM and ends; the workgroup of
-    // the next piece (dispatched later, to whatever slot is free then) picks it up.  A launch of a few generations ends with the
-    // slot whose matrices add up to the most (25 % of a C4 launch's slot-time is idle, NOTES 10.3): pieces a fraction of a
-    // lifetime long let the slots even out.  Same rounds, same arithmetic, same results.  (Piece and matrix are block indices --
-    // registers the hardware provides --, the epoch and the buffers kernel arguments: nothing of the relay is live across a round.)
+    // Relay (round 5): a matrix is enumerated by gridDim.y workgroups ONE AFTER THE OTHER -- a workgroup takes the matrix up to a
+    // share of its k solutions, leaves its whole LDS in HBM and ends; the workgroup of the next piece (dispatched later, to
+    // whatever slot is free then) picks it up.  A launch of a few generations ends with the slot whose matrices add up to the
+    // most (25 % of a C4 launch's slot-time is idle, NOTES 10.3): pieces a fraction of a lifetime long let the slots even out.
+    // Same rounds, same arithmetic, same results.
+    // WHICH piece a workgroup enumerates is not its block index but the order in which the gridDim.y workgroups of its matrix
+    // arrive: each CLAIMS the next piece of the matrix (one atomic on a word per matrix).  A piece therefore only ever waits for
+    // pieces that have been claimed, i.e.
+    // whose workgroups are running: no deadlock whatever order the hardware dispatches workgroups in (it dispatches them in
+    // ascending order, x fastest -- then block (x, j) claims piece j --, but HIP promises nothing of the kind).
     const int blk = blockIdx.x;  // index of this matrix' work space and output tables
-    const bool fresh = RELAY ? blockIdx.y == 0 : true;
+    int piece = 0;
+    if constexpr (RELAY) {
+        unsigned *word = reinterpret_cast<unsigned *>(smem);
+        if (threadIdx.x == 0) {
+            *word = atomicAdd(p.relayClaim + blk, 1u);
+        }
+        __syncthreads();
+        piece = __builtin_amdgcn_readfirstlane((int)*word);
+        __syncthreads();
+    }
+    const bool fresh = RELAY ? piece == 0 : true;
+    // The words of a matrix -- pieces claimed, progress, workgroups gone -- are zero between launches: the LAST of the matrix'
+    // gridDim.y workgroups to leave (whatever way it leaves) puts them back.  Nothing is cleared from outside and nothing depends on
+    // a launch number: a captured launch can be replayed as it is (a memset node in front of the kernel did NOT work: the claim
+    // words, updated by atomics, stay in L2, and the graph's memset went to memory past them).
+    auto relay_depart = [&]() {
+        if constexpr (RELAY) {
+            if (threadIdx.x == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this lane's store to the progress word, if any, has arrived)
+                if (atomicAdd(p.relayGone + blk, 1u) == gridDim.y - 1u) {
+                    __hip_atomic_store(p.relayFlag + blk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(p.relayClaim + blk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(p.relayGone + blk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    };
     const int S = p.split > 1 ? p.split : 1;
     const int share = S > 1 ? blk / p.splitB : 0;
     const int b = S > 1 ? blk - share * p.splitB : blk;  // the matrix (inputs)
@@ -350,6 +380,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     if (fresh && p.tieGain && tid == 0) p.tieGain[blk] = __longlong_as_double(0x7ff8000000000000LL);  // no solution behind the tables (yet)
     if (N < 1 || M < 1 || N < M || N > p.maxRow || M > p.maxCol) {  // undefined in the reference
         if (fresh && tid == 0) p.nf[blk] = (M == 0 || N == 0) ? 0 : -1;  // (an empty frame: nothing to assign, nothing found)
+        relay_depart();
         return;  // (every piece's workgroup sees the same shape: none of them waits)
     }
     // odd column stride of the LDS cost tile: row-wise (lane = row) and column-wise (lane = column) walks are
@@ -410,7 +441,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         const unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID: SE, CU, SIMD, wave slot
         const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
         // (relay launches: one record per workgroup = (piece, matrix), piece-major)
-        const long long wg = (long long)blockIdx.y * gridDim.x + blockIdx.x, nwg = (long long)gridDim.x * gridDim.y;
+        const long long wg = (long long)piece * gridDim.x + blockIdx.x, nwg = (long long)gridDim.x * gridDim.y;
         p.prof[nwg * 16 + wg * 5] = wall_clock64();
         p.prof[nwg * 16 + wg * 5 + 2] = ((unsigned long long)(xcc & 0xf) << 32) | hwid;
     }
@@ -419,15 +450,14 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     // ---- phase 0: makeCostMatrixSafe + zero padding (cpp:534-569, 582-585) --
     double cdelTile = 0.0;  // the shift of the tile (kept for phase 1b, which loads the columns again in another order)
     if (RELAY && !fresh) {
-        // a later piece: wait for the workgroup before it (it was dispatched earlier: it runs or has run), take over its LDS.
+        // a later piece: wait for the workgroup before it (it claimed its piece earlier: it runs or has run), take over its LDS.
         // One lane polls with RELAXED loads (an acquire per poll would invalidate this CU's L1 under its other workgroups
         // every time), then ONE agent-scope acquire, waited for, in front of the barrier behind which everybody loads.
-        const unsigned relayBase = p.relayEpoch * 16u;  // (the progress words only ever grow: no clearing between launches)
         if (tid == 0) {
             unsigned f;
             for (;;) {
                 f = __hip_atomic_load(p.relayFlag + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (f >= relayBase + blockIdx.y && f <= relayBase + 15u) break;
+                if (f >= (unsigned)piece) break;  // (pieces done: piece j hands over with j + 1; 15: the matrix is finished)
                 __builtin_amdgcn_s_sleep(32);
             }
             red[0] = __longlong_as_double((long long)f);
@@ -436,13 +466,13 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         }
         __syncthreads();
         const unsigned f = (unsigned)uni32((int)(unsigned)__double_as_longlong(red[0]));  // (uniform: the return below is a scalar branch)
-        if (f == relayBase + 15u) return;  // the matrix was finished by an earlier piece
+        if (f == 15u) { relay_depart(); return; }  // the matrix was finished by an earlier piece
         const uint4 *src = reinterpret_cast<const uint4 *>(p.relayBuf + (long long)blk * p.relayStride);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         __syncthreads();
         for (int i = tid; i < L.total / 16; i += NT) dst[i] = src[i];
 #ifdef KB_PROFILE
-        if (p.prof && threadIdx.x == 0) p.prof[(long long)gridDim.x * gridDim.y * 16 + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 5 + 3] = wall_clock64();  // the image is in
+        if (p.prof && threadIdx.x == 0) p.prof[(long long)gridDim.x * gridDim.y * 16 + ((long long)piece * gridDim.x + blockIdx.x) * 5 + 3] = wall_clock64();  // the image is in
 #endif
     }
     if (fresh) {
@@ -715,7 +745,8 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     __syncthreads();
     if (uni32(ctrl->stop) == 3) {  // infeasible: kBest2D returns 0 (cpp:588-593)
         if (tid == 0) { p.nf[blk] = 0; if (p.pushed) p.pushed[blk] = 0; }
-        if (RELAY && tid == 0) __hip_atomic_store(p.relayFlag + blk, p.relayEpoch * 16u + 15u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (RELAY && tid == 0) __hip_atomic_store(p.relayFlag + blk, 15u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        relay_depart();
         return;
     }
 
@@ -816,8 +847,8 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     // round by every wave (gridDim comes from memory) cost 2 % on every launch.
     if (RELAY) {
         if (tid == 0) {
-            ctrl->relayCut = (blockIdx.y + 1 < gridDim.y)
-                                 ? (int)(((long long)p.k * (p.relayFirst + p.relayStep * (int)blockIdx.y)) >> 10)
+            ctrl->relayCut = (piece + 1 < (int)gridDim.y)
+                                 ? (int)(((long long)p.k * (p.relayFirst + p.relayStep * piece)) >> 10)
                                  : 0x7fffffff;
             if (fresh) ctrl->relayRound = 0;
             if (ctrl->stop == 4) ctrl->stop = 0;  // (a later piece: the image it took over ends with the hand-over code)
@@ -1625,7 +1656,7 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         if (tid == 0) ctrl->relayRound = roundNo;
         __syncthreads();
 #ifdef KB_PROFILE
-        if (p.prof && threadIdx.x == 0) p.prof[(long long)gridDim.x * gridDim.y * 16 + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 5 + 4] = wall_clock64();  // the rounds are over
+        if (p.prof && threadIdx.x == 0) p.prof[(long long)gridDim.x * gridDim.y * 16 + ((long long)piece * gridDim.x + blockIdx.x) * 5 + 4] = wall_clock64();  // the rounds are over
 #endif
         uint4 *dst = reinterpret_cast<uint4 *>(p.relayBuf + (long long)blk * p.relayStride);
         const uint4 *src = reinterpret_cast<const uint4 *>(smem);
@@ -1639,12 +1670,13 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         if (tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(p.relayFlag + blk, p.relayEpoch * 16u + blockIdx.y + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.relayFlag + blk, (unsigned)piece + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        relay_depart();
 #ifdef KB_PROFILE
         profAcc[13] = __builtin_readcyclecounter() - profT0;     // [13] whole kernel (this wave)
         if (p.prof && threadIdx.x == 0)
-            p.prof[(long long)gridDim.x * gridDim.y * 16 + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 5 + 1] = wall_clock64();
+            p.prof[(long long)gridDim.x * gridDim.y * 16 + ((long long)piece * gridDim.x + blockIdx.x) * 5 + 1] = wall_clock64();
         if (p.prof && lane == 0)
             for (int i = 0; i < 16; i++) atomicAdd(p.prof + (long long)blk * 16 + i, profAcc[i]);
 #endif
@@ -1669,12 +1701,13 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         if (p.pushed) p.pushed[blk] = ctrl->pushed;
     }
     // (relay: this matrix is finished -- the workgroups of its later pieces have nothing to do)
-    if (RELAY && tid == 0) __hip_atomic_store(p.relayFlag + blk, p.relayEpoch * 16u + 15u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (RELAY && tid == 0) __hip_atomic_store(p.relayFlag + blk, 15u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    relay_depart();
 #undef kTab
 #ifdef KB_PROFILE
     profAcc[13] = __builtin_readcyclecounter() - profT0;  // [13] whole kernel (this wave)
     if (p.prof && threadIdx.x == 0)
-        p.prof[(long long)gridDim.x * gridDim.y * 16 + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 5 + 1] = wall_clock64();
+        p.prof[(long long)gridDim.x * gridDim.y * 16 + ((long long)piece * gridDim.x + blockIdx.x) * 5 + 1] = wall_clock64();
     if (p.prof && lane == 0)
         for (int i = 0; i < 16; i++) atomicAdd(p.prof + (long long)blk * 16 + i, profAcc[i]);
 #endif
@@ -1832,7 +1865,7 @@ static hipError_t launch_nw_ept(const Params &p, int B, hipStream_t stream)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kbest_kernel<NW, EPT, RELAY>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, L.total + pad);
     if (e != hipSuccess) return e;
-    // (relay launches: y = the piece of a matrix' enumeration; x runs fastest, so every matrix' piece j is dispatched before any piece j + 1)
+    // (relay launches: gridDim.y workgroups per matrix; the order of their arrival is the order of the pieces)
     hipLaunchKernelGGL((kbest_kernel<NW, EPT, RELAY>), dim3(B, RELAY ? p.relayP : 1), dim3(NW * 64), L.total + pad, stream, p);
     return hipGetLastError();
 }

@@ -357,10 +357,11 @@ def test_relay_is_chosen_for_batches_of_several_generations_and_changes_nothing(
 
 
 def test_relay_launch_inside_a_graph_is_replayable(monkeypatch):
-    """A captured relay launch is replayed with the epoch it was captured with: its progress words are cleared by a node of the
-    graph.  96 x 64x64, k = 200 as a forced relay of three pieces (every piece resident from the start: a stale progress word
-    would be read at once), captured once, replayed on new inputs with a plain relay launch of the same context in between (it
-    moves the epoch on); every replay equals a plain launch (KBEST_RELAY=0) of the same input."""
+    """A captured relay launch replays as it is: the three words of a matrix (pieces claimed / done / workgroups gone) are put
+    back to zero by the last of its workgroups to leave, nothing outside the kernel clears them (a memset node in front of the kernel
+    did not reach the claim words, which live in L2: the second replay hung).  96 x 64x64, k = 200 as a forced relay of three
+    pieces (every piece resident from the start), captured once, replayed four times -- back to back and with another relay launch
+    of the same context in between; every replay equals a plain launch (KBEST_RELAY=0) of the same input."""
     import torch
     dev = torch.device("cuda", 0)
     plain = engine_with(monkeypatch, KBEST_RELAY=0)
