@@ -677,7 +677,7 @@ static int ensure_states(kbest_ctx *ctx, size_t need, bool grow)
 }
 
 static int reserve_for(kbest_ctx *ctx, int B, int maxRow, int k);
-static int relay_plan(const kbest_ctx *ctx, int B, int fastRow, int k, unsigned flags, const Shape &shp, size_t *imgOut, double *gensOut = nullptr);
+static int relay_plan(const kbest_ctx *ctx, int B, int fastRow, int k, unsigned flags, const Shape &shp, size_t *imgOut, double *gensOut = nullptr, bool useCutoff = false);
 static int relay_reserve(kbest_ctx *ctx, int B, size_t img, bool grow);
 
 int kbest_reserve(kbest_ctx *ctx, int B, int maxRow, int k)
@@ -813,7 +813,7 @@ static int split_factor(const kbest_ctx *ctx, const kbest_opts *opts, int B, int
 // Relay launches of the 64-row kernel (kbest_engine.hip): pieces per matrix for a batch of B matrices in launch shape `shp`, and
 // the bytes of one LDS image.  A launch of a few generations of resident workgroups ends with the slot whose matrices add up to
 // the most (25 % of a C4 launch's slot-time is idle, NOTES 10.3); pieces a fraction of a lifetime long let the slots even out.
-static int relay_plan(const kbest_ctx *ctx, int B, int fastRow, int k, unsigned flags, const Shape &shp, size_t *imgOut, double *gensOut)
+static int relay_plan(const kbest_ctx *ctx, int B, int fastRow, int k, unsigned flags, const Shape &shp, size_t *imgOut, double *gensOut, bool useCutoff)
 {
     if (gensOut) *gensOut = 0.0;
     const int ldsB = kb::lds_layout(fastRow, k, shp.spec, shp.nWaves).total;
@@ -833,6 +833,11 @@ static int relay_plan(const kbest_ctx *ctx, int B, int fastRow, int k, unsigned 
     // L1); beyond that two.
     if (gensOut) *gensOut = gens;
     int P = ctx->relay >= 0 ? ctx->relay : (gens <= 1.05 ? 1 : (gens <= 6.5 ? 3 : (gens <= 10.0 ? 2 : 1)));
+    // (with a cutoff a matrix may end long before its k-th solution: its later pieces' workgroups then start only to find it
+    //  finished -- ~5 us of a slot each.  tests/dev/relay_cutoff.py, plain / three pieces: 6 000 x 32x32 with 1.2 solutions per matrix
+    //  inside the cutoff 0.276 / 0.305 ms, with 6: 0.723 / 0.747; 2 048 x 64x64 with 57: 1.684 / 1.636, with 197: 3.27 / 2.98 -- two
+    //  pieces risk half of that)
+    if (ctx->relay < 0 && useCutoff && P > 2) P = 2;
     return P > 8 ? 8 : (P < 1 ? 1 : P);
 }
 
@@ -1106,7 +1111,7 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         // 10.6).  Whole launches of the plain enumeration only, where the batch is 1.2 ... 6 generations of resident workgroups.
         size_t relayImg = 0;
         double relayGens = 0.0;
-        const int relayP = (!sub && !extra && S == 1 && !hostTables && opts->root_col_stride <= 1) ? relay_plan(ctx, B, fastRow, k, opts->flags, shp, &relayImg, &relayGens) : 1;
+        const int relayP = (!sub && !extra && S == 1 && !hostTables && opts->root_col_stride <= 1) ? relay_plan(ctx, B, fastRow, k, opts->flags, shp, &relayImg, &relayGens, opts->use_cutoff != 0) : 1;
         if (relayP > 1) {
             rc = relay_reserve(ctx, B, relayImg, grow);
             if (rc == KBEST_OK) {
