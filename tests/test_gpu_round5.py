@@ -305,6 +305,7 @@ def dev_kbest(eng, costs, N, M, k, **kw):
     d_c = torch.full((B, k, N), -7, dtype=torch.int32, device=dev)
     d_g = torch.full((B, k), float("nan"), dtype=torch.float64, device=dev)
     d_n = torch.full((B,), -7, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()  # (the fills above ran on torch's stream; a NULL stream means the context's own to the engine)
     eng.kbest_dev(d_cost, B, N, M, k, d_r, d_c, d_g, d_n, stream=torch.cuda.current_stream().cuda_stream, **kw)
     torch.cuda.synchronize()
     return d_n.cpu().numpy(), d_r.cpu().numpy(), d_c.cpu().numpy(), d_g.cpu().numpy()
@@ -430,6 +431,7 @@ def test_relay_ragged_batch_with_infeasible_and_empty_frames(monkeypatch, nwaves
     d_g = torch.full((B, k), float("nan"), dtype=torch.float64, device=dev)
     d_n = torch.full((B,), -7, dtype=torch.int32, device=dev)
     before = eng.relay_launches()
+    torch.cuda.synchronize()
     eng.kbest_dev(d_cost, B, maxRow, maxCol, k, d_r, d_c, d_g, d_n, stream=torch.cuda.current_stream().cuda_stream,
                   d_nRow=d_nR, d_nCol=d_nC, d_costOff=d_off)
     torch.cuda.synchronize()
