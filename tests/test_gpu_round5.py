@@ -447,3 +447,12 @@ def test_relay_ragged_batch_with_infeasible_and_empty_frames(monkeypatch, nwaves
         assert (bits(g[b, :wn]) == bits(wg[:wn])).all(), b
         assert (r4c[b, :wn, :M] == wr[:wn]).all(), b
     assert nf[17] == 0 and nf[23] == 0 and nf[11] == 6
+
+
+def test_relay_under_load_equals_plain_launches():
+    """A bounded slice of tests/dev/relay_stress.py: batches of 1.2 - 4 generations (every slot busy, pieces of different matrices
+    sharing CUs, warm L1s -- where a sloppy hand-over would go stale), the plan's relay and 2 / 5 / 8 forced pieces against plain
+    launches of the same build, every word of every table compared on the device."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "dev", "relay_stress.py"), "10", "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "relay stress ok" in r.stdout, (r.stdout[-800:], r.stderr[-800:])
