@@ -339,9 +339,9 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
     // Same rounds, same arithmetic, same results.
     // WHICH piece a workgroup enumerates is not its block index but the order in which the gridDim.y workgroups of its matrix
     // arrive: each CLAIMS the next piece of the matrix (one atomic on a word per matrix).  A piece therefore only ever waits for
-    // pieces that have been claimed, i.e.
-    // whose workgroups are running: no deadlock whatever order the hardware dispatches workgroups in (it dispatches them in
-    // ascending order, x fastest -- then block (x, j) claims piece j --, but HIP promises nothing of the kind).
+    // pieces that have been claimed, i.e. whose workgroups are running: no deadlock whatever order the hardware dispatches
+    // workgroups in (it dispatches them in ascending order, x fastest -- then block (x, j) claims piece j --, but HIP promises
+    // nothing of the kind).
     const int blk = blockIdx.x;  // index of this matrix' work space and output tables
     int piece = 0;
     if constexpr (RELAY) {
