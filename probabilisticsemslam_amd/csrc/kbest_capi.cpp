@@ -110,6 +110,8 @@ struct kbest_ctx {
     size_t statesBytes = 0;
         unsigned char *wide = nullptr;    // work space of the general-size kernel (kbest_wide.hip)
     size_t wideBytes = 0;
+    unsigned *wideQueue = nullptr;  // the general-size kernel's problem queue (two words, zero between launches)
+    bool noWideQueue = false;       // KBEST_NO_WIDE_QUEUE: fixed stride over the batch (A/B)
     int ldsLimit = 65536;
     int nWaves = 0;   // waves per cost matrix (workgroup = nWaves * 64 threads); 0 = choose per launch
     int spec = 0;     // candidates re-solved / split per round; 0 = choose per launch (choose_spec)
@@ -411,6 +413,7 @@ int kbest_create(kbest_ctx **out, int device)
     ctx->noSmall = getenv("KBEST_NO_SMALL") != nullptr;
     ctx->forceWide = getenv("KBEST_FORCE_WIDE") != nullptr;
     ctx->noLane = getenv("KBEST_NO_LANE") != nullptr;
+    ctx->noWideQueue = getenv("KBEST_NO_WIDE_QUEUE") != nullptr;
     ctx->noSplit = getenv("KBEST_NO_SPLIT") != nullptr;
     ctx->noTie = getenv("KBEST_NO_TIE") != nullptr;
     if (const char *e = getenv("KBEST_RELAY")) ctx->relay = atoi(e);
@@ -464,6 +467,7 @@ int kbest_destroy(kbest_ctx *ctx)
     for (auto &r : ctx->regs) (void)hipHostUnregister(r.host);
     if (ctx->states) (void)hipFree(ctx->states);
     if (ctx->wide) (void)hipFree(ctx->wide);
+    if (ctx->wideQueue) (void)hipFree(ctx->wideQueue);
     for (auto &b : ctx->cache) (void)hipFree(b.p);
     if (ctx->pinIn.host) (void)hipHostFree(ctx->pinIn.host);
     if (ctx->pinOut.host) (void)hipHostFree(ctx->pinOut.host);
@@ -532,6 +536,10 @@ static int reserve_wide(kbest_ctx *ctx, const WidePlan &w, bool grow)
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->wide), need);
     if (e != hipSuccess) return fail(ctx, KBEST_ERR_NOMEM, "hipMalloc(general-size work space)", e);
     ctx->wideBytes = need;
+    if (!ctx->wideQueue) {
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->wideQueue), 128));
+        HIP_TRY(ctx, hipMemset(ctx->wideQueue, 0, 128));
+    }
     return KBEST_OK;
 }
 
@@ -1226,6 +1234,7 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         p.prof = ctx->prof;
         p.kTab = kT;
         p.tieGain = d_tieGain;
+        p.queue = (ctx->noWideQueue || capturing(s)) ? nullptr : ctx->wideQueue;  // (a captured launch: fixed stride -- nothing to go wrong on a replay)
         hipError_t e = kb::launch_kbest_wide(p, w.grid, s);
         if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "general-size kbest kernel launch", e);
     }

@@ -210,6 +210,7 @@ struct WideParams {
     unsigned long long *prof; // diagnostic builds (KB_PROFILE): [B][16] cycle sums over the waves
     int kTab;                 // exact ties (kbest_ties.h), as in Params
     double *tieGain;
+    unsigned *queue;          // [0] problems taken beyond the first gridDim.x, [1] workgroups that have left (zero between launches); null: fixed stride
 };
 
 // bytes of one saved hypothesis of the general-size kernel: u[D] v[D] (fp64), row4col[D] col4row[D] (i32),

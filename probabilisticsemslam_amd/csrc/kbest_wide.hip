@@ -51,6 +51,7 @@ struct WideCtrl {
     int nsel;        // hypotheses split in this round
     int nEmit;       // pool entries emitted in this round (the first nEmit)
     int lastSel;     // pool index of the last selected entry: every not yet split entry up to it is selected
+    int nextB;       // the problem this workgroup takes next (the batch's queue)
     int selIdx[WIDE_MAX_SPEC], selSid[WIDE_MAX_SPEC], selA[WIDE_MAX_SPEC], selOff[WIDE_MAX_SPEC + 1];  // the selected
     double selG[WIDE_MAX_SPEC];  // entries: pool index, state slot, active column, first ticket, gain
 };
@@ -367,7 +368,18 @@ __global__ void __launch_bounds__(NWV * 64, (R >= 16 ? 1 : (NWV == 16 ? 4 : (R <
     // saved hypothesis: u[DS] v[DS] (fp64) | row4col[DS] col4row[DS] (i32) | forbidden rows (u32 per lane) | gain, activeCol
     const long long offV = 8LL * DS, offR4C = 16LL * DS, offC4R = 20LL * DS, offForb = 24LL * DS, offTail = 24LL * DS + 256;
 
-    for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
+    // The grid is as many workgroups as the chip holds; a batch larger than that is a QUEUE: a workgroup that has finished a problem
+    // takes the next one nobody has taken (one atomic; the first gridDim.x problems need none), so that the launch ends within one
+    // problem's time of the moment the queue runs dry -- with a fixed stride it ended with the workgroup whose problems add up to
+    // the most.  The last workgroup to leave puts the queue's two words back to zero.
+    auto next_problem = [&](int bNow) -> int {
+        if (!p.queue) return bNow + (int)gridDim.x;
+        __syncthreads();
+        if (tid == 0) ctrl->nextB = (int)gridDim.x + (int)atomicAdd(p.queue, 1u);
+        __syncthreads();
+        return uni32(ctrl->nextB);
+    };
+    for (int b = blockIdx.x; b < p.B; b = next_problem(b)) {
         __syncthreads();  // the previous problem of this workgroup is finished
         const int N = p.nRow ? p.nRow[b] : p.maxRow;
         const int M = p.nCol ? p.nCol[b] : p.maxCol;
@@ -1078,6 +1090,10 @@ __global__ void __launch_bounds__(NWV * 64, (R >= 16 ? 1 : (NWV == 16 ? 4 : (R <
             p.nf[b] = (ctrl->stop == 2) ? -3 : (ctrl->emitted > p.kTab ? p.kTab : ctrl->emitted);
             if (p.pushed) p.pushed[b] = ctrl->pushed;
         }
+    }
+    if (p.queue && tid == 0 && atomicAdd(p.queue + 1, 1u) == gridDim.x - 1u) {
+        __hip_atomic_store(p.queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p.queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

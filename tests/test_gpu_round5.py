@@ -456,3 +456,20 @@ def test_relay_under_load_equals_plain_launches():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "dev", "relay_stress.py"), "10", "3"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "relay stress ok" in r.stdout, (r.stdout[-800:], r.stderr[-800:])
+
+
+@pytest.mark.parametrize("shape", [(70, 70, 12, 1000), (80, 30, 25, 1300)])
+def test_general_size_kernel_takes_a_large_batch_as_a_queue(monkeypatch, shape):
+    """More problems than the general-size kernel has workgroups (768 at up to 128 rows): a workgroup that finishes a problem takes the
+    next one off a queue (kbest_wide.hip); the fixed stride (KBEST_NO_WIDE_QUEUE) gives the same tables, and both the checker's."""
+    N, M, k, B = shape
+    rng = np.random.default_rng(N * 1000 + B)
+    costs = rng.random((B, N * M))
+    want = ol.orc_kbest_batch(costs, N, M, k)
+    for knobs in ({}, {"KBEST_NO_WIDE_QUEUE": 1}):
+        eng = engine_with(monkeypatch, **knobs)
+        for rep in range(2):  # (the queue's words are back at zero after a launch)
+            nf, r4c, c4r, g = eng.kbest(costs, N, M, k)
+            assert (nf == want[0]).all(), knobs
+            assert (r4c == want[1]).all() and (bits(g) == bits(want[3])).all(), knobs
+            assert (c4r[want[2] < M] == want[2][want[2] < M]).all(), knobs
