@@ -797,8 +797,10 @@ def main():
             B = Btot // world
         else:
             B = args.batch or Bc
+        relays_before = eng.relay_launches()
         m = run_dense(eng, torch, dist if use_dist else None, args.config, B, args.steps, args.warmup, rank, world, dev, tstream,
                       use_dist, rank * B)
+        relayed = eng.relay_launches() - relays_before  # (of this rank's warm-up + timed launches)
         t = torch.tensor([m["dt"], m["kern_ms"]], dtype=torch.float64, device=dev)
         tot = torch.tensor([m["found"], m["balg"]], dtype=torch.float64, device=dev)
         if use_dist:
@@ -824,6 +826,9 @@ def main():
                 "problems_per_s": B * world * args.steps / dt_max,
                 "kernel_ms": kern_ms_max,
                 "parity_prune_vs_noprune": m["parity_self"],
+                "launch": {"relay_launches": relayed, "of": args.steps + args.warmup,
+                           "what": "launches of the 64-row kernel that ran as a relay: every matrix enumerated by three workgroups in turn, its LDS "
+                                   "handed on through HBM (DESIGN.md section 2 point 12; KBEST_RELAY=0 launches it plainly)"},
                 "roofline": roofline_block(args.config, B, balg_all / world, kern_ms_max,
                                            {"mean_pushed_per_matrix": float(m["pushed"].mean())}),
             }
