@@ -78,6 +78,25 @@ def test_bench_self_launch_refuses_more_gpus_than_the_node_has():
     assert r.stdout.strip() == ""
 
 
+def test_bench_launches_its_own_rank_and_steps_over_rccl():
+    """The driver's multi-GPU command on the one GPU there is: `bench.py --gpus 1` made to take the launcher path
+    (KBEST_BENCH_SELF_LAUNCH) and the distributed step (KBEST_BENCH_FORCE_DIST: a 1-rank RCCL communicator, one packed all-gather per
+    step overlapped with the next step's kernel).  One JSON line, parity flag set, the headline's launches are relays."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(KBEST_BENCH_SELF_LAUNCH="1", KBEST_BENCH_FORCE_DIST="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--no-cpu", "--no-extra", "--no-host"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["steps"] == 4 and out["parity_prune_vs_noprune"] is True
+    assert "all-gather" in out["config"]["collective"]
+    assert out["launch"]["relay_launches"] == out["launch"]["of"] == 5
+    assert out["roofline"]["frac"] > 0.5 and out["value"] > 5e7
+
+
 def test_reference_caller_object_runs_on_the_engine(tmp_path):
     """Link-level drop-in with the reference's OWN caller code: oracle/_ref/ref_caller_on_engine holds the verbatim
     slices of assignment.cpp (conditionCosts, assignmentProb :547-683, bruteForceProb :835-964) compiled against the
