@@ -840,7 +840,11 @@ static int relay_plan(const kbest_ctx *ctx, int B, int fastRow, int k, unsigned 
     // 2 ... 8 everywhere up to six generations (a hand-over costs ~11 us of a slot: the image out and in, a workgroup's start, a cold
     // L1); beyond that two.
     if (gensOut) *gensOut = gens;
-    int P = ctx->relay >= 0 ? ctx->relay : (gens <= 1.05 ? 1 : (gens <= 6.5 ? 3 : (gens <= 10.0 ? 2 : 1)));
+    // A batch of BARELY more than one generation is where a plain launch is worst -- 513 matrices on 512 slots take two lifetimes --
+    // and where fine slices pay most: up to 1.8 generations four pieces at quarters of k (tests/dev/relay_edge.sh, ms plain / 3 pieces at
+    // 3/8, 3/4 / 4 pieces at quarters: 513 x 64x64 1.195 / 1.027 / 0.939, 530: 1.273 / 1.082 / 1.022, 600: 1.406 / 1.200 / 1.141, 700: 1.433 /
+    // 1.211 / 1.164, 768: 1.547 / 1.287 / 1.242; 1 100 x 32x32 (8 waves): 1.350 / 1.161 / 1.101).
+    int P = ctx->relay >= 0 ? ctx->relay : (gens <= 1.8 ? 4 : (gens <= 6.5 ? 3 : (gens <= 10.0 ? 2 : 1)));
     // (with a cutoff a matrix may end long before its k-th solution: its later pieces' workgroups then start only to find it
     //  finished -- ~5 us of a slot each.  tests/dev/relay_cutoff.py, plain / three pieces: 6 000 x 32x32 with 1.2 solutions per matrix
     //  inside the cutoff 0.276 / 0.305 ms, with 6: 0.723 / 0.747; 2 048 x 64x64 with 57: 1.684 / 1.636, with 197: 3.27 / 2.98 -- two
@@ -1129,11 +1133,11 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
                 //  up to two generations: cuts at 3/8 and 3/4 of k: 1.563 ms against 1.580 at 3/8, 11/16 and 1.602 at 1/2, 3/4; everything
                 //  else at 5/8 and 7/8: 4 096 x 32x32 3.16 ms against 3.21 at 5/8, 13/16 and 3.27 at 1/2, 3/4.  The last pieces are the
                 //  launch's last generation: short ones let it drain evenly, and the late solutions are the cheap ones)
-                const bool wide12 = shp.nWaves == 12 && relayGens <= 2.2;
-                p.relayFirst = ctx->relayFirst > 0 ? ctx->relayFirst : (wide12 ? 384 : 640);
+                const bool wide12 = shp.nWaves == 12 && relayGens <= 2.2, quarters = relayGens <= 1.8 && ctx->relay < 0;
+                p.relayFirst = ctx->relayFirst > 0 ? ctx->relayFirst : (quarters ? (relayP >= 4 ? 256 : 512) : (wide12 ? 384 : 640));
                 p.relayStep = ctx->relayStep > 0 ? ctx->relayStep
                               : (ctx->relay >= 0 ? (1024 - p.relayFirst) / (relayP - 1)   // (a forced count: even steps, every piece hands over)
-                                                 : (wide12 ? 384 : 256));
+                                                 : (quarters ? 256 : (wide12 ? 384 : 256)));
                 ctx->relayLaunches++;
                 p.relayBuf = static_cast<unsigned char *>(ctx->relayBuf.p);
                 p.relayStride = (long long)relayImg;
