@@ -138,9 +138,10 @@ def cpu_dense(costs, N, M, k, sample):
         dt = time.perf_counter() - t0
         total = int(nf.sum())
         kind = "port"
+    ref = (np.asarray(nf).reshape(-1), np.asarray(r4c).reshape(sample, k, M), np.asarray(c4r).reshape(sample, k, N), np.asarray(g).reshape(sample, k))
     return {"value": total / dt, "unit": "assignments/s", "cores": 1, "kind": kind,
             "sample": f"first {sample} of the {costs.shape[0]} {N}x{M} k={k} matrices of rank 0's batch, "
-                      f"one kBest2D call each, single thread, {dt:.1f} s"}, r4c, g, pushed
+                      f"one kBest2D call each, single thread, {dt:.1f} s"}, ref, pushed
 
 
 def cpu_all_cores(costs, N, M, k):
@@ -163,104 +164,180 @@ def cpu_all_cores(costs, N, M, k):
     bounds = [B * i // T for i in range(T + 1)]
     c = np.ascontiguousarray(costs)
 
+    # the reference's tables of the WHOLE batch are kept: the GPU result of every matrix is compared with them (tables_parity)
+    C4R = np.empty((B, k, N), np.int64)
+    R4C = np.empty((B, k, M), np.int64)
+    G = np.empty((B, k))
+    NF = np.empty(B, np.int64)
+
     def work(i):
         lo, hi = bounds[i], bounds[i + 1]
         n = hi - lo
         if n == 0:
             return 0
-        c4r = np.empty(n * k * N, np.int64)
-        r4c = np.empty(n * k * M, np.int64)
-        g = np.empty(n * k)
-        nf = np.empty(n, np.int64)
-        return int(lib.ref_kbest2d_batch(n, k, N, M, 0, c[lo:hi].reshape(-1), c4r, r4c, g, nf))  # ctypes drops the GIL
+        return int(lib.ref_kbest2d_batch(n, k, N, M, 0, c[lo:hi].reshape(-1), C4R[lo:hi].reshape(-1), R4C[lo:hi].reshape(-1),
+                                         G[lo:hi].reshape(-1), NF[lo:hi]))  # ctypes drops the GIL
 
     t0 = time.perf_counter()
     with cf.ThreadPoolExecutor(max_workers=T) as ex:
         total = sum(ex.map(work, range(T)))
     dt = time.perf_counter() - t0
     return {"value": total / dt, "unit": "assignments/s", "cores": T, "kind": "reference",
-            "sample": f"all {B} matrices of rank 0's batch, one kBest2D call each, {T} threads, {dt:.1f} s"}
+            "sample": f"all {B} matrices of rank 0's batch, one kBest2D call each, {T} threads, {dt:.1f} s"}, (NF, R4C, C4R, G)
+
+
+def tables_parity(m, ref, ns=None):
+    """The timed launch's tables (nf, row4col, col4row, gain bits) against the reference's on the first ns matrices (None: all).
+    col4row on zero-padded columns (values >= numCol) is compared after mapping to -1."""
+    NF, R4C, C4R, G = ref
+    N, M, k = m["N"], m["M"], m["k"]
+    ns = len(NF) if ns is None else min(ns, len(NF))
+    nf_ok = bool((m["nf"][:ns] == NF[:ns]).all())
+    sl = np.arange(k)[None, :] < np.asarray(NF[:ns])[:, None]  # slots the reference filled
+    g_ok = bool((np.where(sl, m["g"][:ns].view(np.int64), 0) == np.where(sl, np.asarray(G[:ns]).reshape(ns, k).view(np.int64), 0)).all())
+    r_ok = bool((np.where(sl[:, :, None], m["r4c"][:ns], 0) == np.where(sl[:, :, None], np.asarray(R4C[:ns]).reshape(ns, k, M), 0)).all())
+    a = m["c4r"][:ns].astype(np.int64)
+    b = np.asarray(C4R[:ns]).reshape(ns, k, N).astype(np.int64)
+    a = np.where(a >= M, -1, a)
+    b = np.where(b >= M, -1, b)
+    c_ok = bool((np.where(sl[:, :, None], a, 0) == np.where(sl[:, :, None], b, 0)).all())
+    return {"nf": nf_ok, "gain_bits": g_ok, "row4col": r_ok, "col4row": c_ok, "matrices": int(ns), "all": nf_ok and g_ok and r_ok and c_ok}
 
 
 # ------------------------------------------------------------------------------------------------ dense configs
-def run_dense(eng, torch, dist, cfg, B, steps, warmup, rank, world, dev, tstream, use_dist, first):
+class Exchange:
+    """The one collective of a step: ONE all-gather of this rank's packed slice into the global table, asynchronous,
+    so that it travels while the next step's kernel runs.  Backend "nccl" (= RCCL over xGMI: what the driver's multi-GPU run uses)
+    gathers device buffers directly.  Backend "gloo" (KBEST_BENCH_BACKEND=gloo: how every line of the world > 1 path runs where
+    RCCL cannot -- two ranks on ONE GPU, tests/test_gpu_round6.py) moves the same packed bytes through pinned host memory."""
+
+    def __init__(self, torch, dist, backend, dev, world, slice_bytes, nbuf, stream):
+        self.torch, self.dist, self.backend, self.world, self.stream = torch, dist, backend, world, stream
+        self.g_pack = [torch.empty(world * slice_bytes, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+        if backend == "gloo":
+            self.h_pack = [torch.empty(slice_bytes, dtype=torch.uint8).pin_memory() for _ in range(nbuf)]
+            self.h_gpack = [torch.empty(world * slice_bytes, dtype=torch.uint8).pin_memory() for _ in range(nbuf)]
+            self.ev = [torch.cuda.Event() for _ in range(nbuf)]
+
+    def start(self, b, d_pack):
+        """Called right after step's kernel was enqueued on the stream; returns what wait() needs."""
+        if self.backend != "gloo":
+            return [self.dist.all_gather_into_tensor(self.g_pack[b], d_pack, async_op=True)]
+        with self.torch.cuda.stream(self.stream):
+            self.h_pack[b].copy_(d_pack, non_blocking=True)
+            self.ev[b].record(self.stream)
+        self.ev[b].synchronize()  # (the host bounce cannot start before the kernel has ended: no overlap on this backend)
+        return [self.dist.all_gather_into_tensor(self.h_gpack[b], self.h_pack[b], async_op=True), b]
+
+    def wait(self, pending):
+        pending[0].wait()
+        if self.backend == "gloo":
+            b = pending[1]
+            with self.torch.cuda.stream(self.stream):
+                self.g_pack[b].copy_(self.h_gpack[b], non_blocking=True)
+
+
+def all_reduce_(torch, dist, backend, t, op):
+    """dist.all_reduce of a small device tensor; through the host on the gloo backend."""
+    if backend == "gloo":
+        c = t.cpu()
+        dist.all_reduce(c, op=op)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
+def run_dense(eng, torch, dist, cfg, B, steps, warmup, rank, world, dev, tstream, use_dist, first, backend="nccl", no_gather_leg=False):
     """C2 / C3 / C4: B dense matrices resident in HBM, one launch per step.  Returns the measurements of this rank."""
     from probabilisticsemslam_amd import workloads as wl
     _, N, M, k, seed = wl.DENSE_CONFIGS[cfg]
     costs = wl.dense_batch(B, N, M, seed, first=first)  # rank-private slice of the one seeded stream
     stream = tstream.cuda_stream
     d_cost = torch.from_numpy(costs).to(dev)
-    d_c4r = torch.empty((B, k, N), dtype=torch.int32, device=dev)
+    # What a rank contributes to the exchange is as narrow as the problem allows: every index of a problem of up to 127 rows fits a
+    # byte, so with N > 1 the kernel writes row4col (and col4row, which stays local) as int8 tables (KBEST_FLAG_TABLES_I8) --
+    # 8 + M instead of 8 + 4 M bytes per solution.  One GPU, no exchange: the int32 tables of the interface.
+    i8 = bool(use_dist and N <= 127 and os.environ.get("KBEST_BENCH_WIDE_SLICES") != "1")
+    tdt, esz = (torch.int8, 1) if i8 else (torch.int32, 4)
+    d_c4r = torch.empty((B, k, N), dtype=tdt, device=dev)
     d_pushed = torch.zeros(B, dtype=torch.int64, device=dev)
     nbuf = 2 if use_dist else 1
-    # One packed slice per rank -- gain[B][k] fp64 | row4col[B][k][M] i32 | nf[B] i32, each part 16-byte aligned -- so that
+    # One packed slice per rank -- gain[B][k] fp64 | row4col[B][k][M] (int8 / i32) | nf[B] i32, each part 16-byte aligned -- so that
     # the exchange is ONE all-gather of bytes per step (SURVEY 8(e)); the kernel writes straight into views of the slice.
     up16 = lambda x: (x + 15) & ~15  # noqa: E731
     off_r = up16(B * k * 8)
-    off_n = off_r + up16(B * k * M * 4)
+    off_n = off_r + up16(B * k * M * esz)
     slice_bytes = off_n + up16(B * 4)
     d_pack = [torch.zeros(slice_bytes, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     d_gain = [pk[: B * k * 8].view(torch.float64).view(B, k) for pk in d_pack]
-    d_r4c = [pk[off_r: off_r + B * k * M * 4].view(torch.int32).view(B, k, M) for pk in d_pack]
+    d_r4c = [pk[off_r: off_r + B * k * M * esz].view(tdt).view(B, k, M) for pk in d_pack]
     d_nf = [pk[off_n: off_n + B * 4].view(torch.int32) for pk in d_pack]
     # global result table of the all-gather: the ranks' slices one after the other
-    g_pack = [torch.empty(world * slice_bytes, dtype=torch.uint8, device=dev) for _ in range(nbuf)] if use_dist else None
+    ex = Exchange(torch, dist, backend, dev, world, slice_bytes, nbuf, tstream) if use_dist else None
 
     def g_view(b, r):
-        s = g_pack[b][r * slice_bytes: (r + 1) * slice_bytes]
-        return (s[: B * k * 8].view(torch.float64).view(B, k), s[off_r: off_r + B * k * M * 4].view(torch.int32).view(B, k, M),
+        s = ex.g_pack[b][r * slice_bytes: (r + 1) * slice_bytes]
+        return (s[: B * k * 8].view(torch.float64).view(B, k), s[off_r: off_r + B * k * M * esz].view(tdt).view(B, k, M),
                 s[off_n: off_n + B * 4].view(torch.int32))
     eng.reserve(B, N, k)
     torch.cuda.synchronize()  # the allocations / fills above ran on the default stream
     # untimed: the reference's push count P per matrix (no-prune mode), for the algorithmic byte count
-    eng.kbest_dev(d_cost, B, N, M, k, d_r4c[0], d_c4r, d_gain[0], d_nf[0], d_pushed=d_pushed, prune=False, stream=stream)
+    eng.kbest_dev(d_cost, B, N, M, k, d_r4c[0], d_c4r, d_gain[0], d_nf[0], d_pushed=d_pushed, prune=False, stream=stream, tables_i8=i8)
     torch.cuda.synchronize()
     pushed = d_pushed.cpu().numpy()
     nf_ref = d_nf[0].cpu().numpy().copy()
     g_ref = d_gain[0].cpu().numpy().copy()
     pending = [None] * nbuf
 
-    def step(i, ev=None):
+    def step(i, ev=None, gather=True):
         b = i % nbuf
         if pending[b] is not None:
-            for w in pending[b]:
-                w.wait()  # the gathers of step i-2 have read this set of tables
+            ex.wait(pending[b])  # the gather of step i-2 has read this set of tables
             pending[b] = None
         if ev is not None:
             ev[0].record()
-        eng.kbest_dev(d_cost, B, N, M, k, d_r4c[b], d_c4r, d_gain[b], d_nf[b], stream=stream)
+        eng.kbest_dev(d_cost, B, N, M, k, d_r4c[b], d_c4r, d_gain[b], d_nf[b], stream=stream, tables_i8=i8)
         if ev is not None:
             ev[1].record()
-        if use_dist:  # the packed per-rank slice travels while the next step's kernel runs: one collective per step
-            pending[b] = [dist.all_gather_into_tensor(g_pack[b], d_pack[b], async_op=True)]
+        if use_dist and gather:  # the packed per-rank slice travels while the next step's kernel runs: one collective per step
+            pending[b] = ex.start(b, d_pack[b])
 
     def drain():
         for b in range(nbuf):
             if pending[b] is not None:
-                for w in pending[b]:
-                    w.wait()
+                ex.wait(pending[b])
                 pending[b] = None
 
-    for i in range(warmup):
-        step(i)
-    drain()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    t0 = time.perf_counter()
-    for i in range(steps):
-        step(i, ev[i])
-    drain()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(gather):
+        for i in range(warmup):
+            step(i, gather=gather)
+        drain()
+        barrier()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i, ev[i], gather=gather)
+        drain()
+        barrier()
+        return time.perf_counter() - t0, float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    # the same K steps WITHOUT the exchange first (N > 1 only; untimed as far as `value` goes): the collective's exposed time is
+    # the difference of the two legs
+    dt_nog = kern_nog = None
+    if use_dist and not no_gather_leg:
+        dt_nog, kern_nog = timed(False)
+    dt, kern_ms = timed(True)
     last = (steps - 1) % nbuf
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     nf = d_nf[last].cpu().numpy()
     g = d_gain[last].cpu().numpy()
-    r4c = d_r4c[last].cpu().numpy()
+    r4c = d_r4c[last].cpu().numpy().astype(np.int32)
+    c4r = d_c4r.cpu().numpy().astype(np.int32)
     # the timed (pruning) path must reproduce the no-prune run bit for bit
     parity_self = bool((nf == nf_ref).all() and (g.view(np.int64) == g_ref.view(np.int64)).all())
     if use_dist:  # every rank must hold the same global table, and its own slice of it must be what it solved
@@ -271,11 +348,33 @@ def run_dense(eng, torch, dist, cfg, B, steps, warmup, rank, world, dev, tstream
         chk = torch.stack([sum(p[0].sum() for p in parts), sum(p[1].double().sum() for p in parts),
                            sum(p[2].double().sum() for p in parts)])
         lo, hi = chk.clone(), chk.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        all_reduce_(torch, dist, backend, lo, dist.ReduceOp.MIN)
+        all_reduce_(torch, dist, backend, hi, dist.ReduceOp.MAX)
         assert torch.equal(lo, hi), "ranks hold different global tables"
-    return dict(costs=costs, N=N, M=M, k=k, seed=seed, B=B, dt=dt, kern_ms=kern_ms, nf=nf, g=g, r4c=r4c, pushed=pushed,
-                parity_self=parity_self, found=int(nf.sum()), balg=algorithmic_bytes(N, M, k, nf, pushed))
+        # ... and every other rank's slice must be what THAT rank's matrices give: the neighbour's first matrix, solved here
+        nb = (rank + 1) % world
+        if first == rank * B:  # (how main() deals the one seeded stream of matrices: rank r starts at matrix r * B)
+            c1 = torch.from_numpy(wl.dense_batch(1, N, M, seed, first=nb * B)).to(dev)
+            r1 = torch.empty((1, k, M), dtype=tdt, device=dev)
+            q1 = torch.empty((1, k, N), dtype=tdt, device=dev)
+            g1 = torch.empty((1, k), dtype=torch.float64, device=dev)
+            n1 = torch.empty(1, dtype=torch.int32, device=dev)
+            eng.kbest_dev(c1, 1, N, M, k, r1, q1, g1, n1, stream=stream, tables_i8=i8)
+            torch.cuda.synchronize()
+            assert torch.equal(parts[nb][0][0], g1[0]) and torch.equal(parts[nb][1][0], r1[0]) and int(parts[nb][2][0]) == int(n1[0]), \
+                "the neighbour's slice of the global table is not what its first matrix gives"
+    coll = None
+    if use_dist:
+        coll = {"what": "ONE all-gather per step of the packed per-rank slice (gain[k] fp64 | row4col[k*M] "
+                        f"{'int8' if i8 else 'int32'} | nf per matrix), overlapped with the next step's kernel",
+                "backend": backend, "row4col_dtype": "int8" if i8 else "int32",
+                "bytes_per_rank_per_step": slice_bytes, "bytes_inbound_per_rank_per_step": (world - 1) * slice_bytes,
+                "inbound_GBps_per_rank_at_this_step_rate": (world - 1) * slice_bytes / (dt / steps) / 1e9,
+                "ms_per_step_without_the_gather": None if dt_nog is None else 1e3 * dt_nog / steps,
+                "exposed_ms": None if dt_nog is None else 1e3 * (dt - dt_nog) / steps,
+                "kernel_ms_without_the_gather": kern_nog}
+    return dict(costs=costs, N=N, M=M, k=k, seed=seed, B=B, dt=dt, kern_ms=kern_ms, nf=nf, g=g, r4c=r4c, c4r=c4r, pushed=pushed,
+                parity_self=parity_self, found=int(nf.sum()), balg=algorithmic_bytes(N, M, k, nf, pushed), collective=coll)
 
 
 def host_inclusive_dense(eng, costs, N, M, k):
@@ -293,18 +392,23 @@ def host_inclusive_dense(eng, costs, N, M, k):
     o = eng._opts(False, None)
     p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
 
-    def timed(with_c4r=True):
-        best = None
-        for _ in range(4):
+    legs = {}  # per leg: every call's time (two untimed calls first), so that the line carries median / min / max, not one shot
+
+    def timed(with_c4r=True, leg=None, calls=11):
+        ts = []
+        for i in range(-2, calls):
             t0 = time.perf_counter()
             rc = eng.lib.kbest_batch_f64(eng.ctx, C.byref(o), B, N, M, None, None, p(costs), None, k, p(r4c), p(c4r) if with_c4r else None,
                                          p(gain), p(nf), None)
             dt = time.perf_counter() - t0
             assert rc == 0
-            best = dt if best is None or dt < best else best
-        return best
+            if i >= 0:
+                ts.append(dt)
+        if leg:
+            legs[leg] = {"median_ms": 1e3 * float(np.median(ts)), "min_ms": 1e3 * min(ts), "max_ms": 1e3 * max(ts), "calls": len(ts)}
+        return float(np.median(ts))
 
-    pageable = timed()
+    pageable = timed(leg="pageable")
     ref = (r4c.copy(), c4r.copy(), gain.copy(), nf.copy())
     for a in (r4c, c4r, gain, nf):
         a[...] = 0
@@ -328,10 +432,10 @@ def host_inclusive_dense(eng, costs, N, M, k):
         except pk_engine.KBestError as ex:  # only a failed registration falls back to the pageable number
             err = repr(ex)
         else:
-            registered = timed()
+            registered = timed(leg="registered")
             # (a mismatch on any of the paths below is a failure of the bench, not a reason to fall back)
             assert all(np.array_equal(x, y) for x, y in zip(ref, (r4c, c4r, gain, nf))), "registered-buffer path differs from the copying path"
-            no_c4r = timed(with_c4r=False)
+            no_c4r = timed(with_c4r=False, leg="registered_without_col4row")
             unregister(r4c, c4r)
             # the same tables as int8 (KBEST_FLAG_TABLES_I8): every index of a 64-row problem fits a byte
             register(r8, c8)
@@ -339,9 +443,9 @@ def host_inclusive_dense(eng, costs, N, M, k):
             r4c_keep, c4r_keep = r4c, c4r
             r4c, c4r = r8, c8
             try:
-                i8 = timed()
+                i8 = timed(leg="int8_tables")
                 assert np.array_equal(r8, ref[0]) and np.array_equal(c8, ref[1]) and np.array_equal(gain, ref[2]), "int8 tables differ from the int32 tables"
-                i8_no_c4r = timed(with_c4r=False)
+                i8_no_c4r = timed(with_c4r=False, leg="int8_tables_without_col4row")
             finally:
                 r4c, c4r = r4c_keep, c4r_keep
                 o.flags &= ~pk_engine.KBEST_FLAG_TABLES_I8
@@ -363,7 +467,7 @@ def host_inclusive_dense(eng, costs, N, M, k):
         eng_main, eng = eng, eng_w
         try:
             eng_w.register_host(costs, r4c, c4r, gain, nf)
-            wide_ms = 1e3 * timed()
+            wide_ms = 1e3 * timed(leg="int32_tables_over_the_link", calls=5)
             assert all(np.array_equal(x, y) for x, y in zip(ref, (r4c, c4r, gain, nf))), "narrow staging differs from the int32 tables written by the kernel"
         finally:
             for a in (costs, r4c, c4r, gain, nf):
@@ -376,10 +480,12 @@ def host_inclusive_dense(eng, costs, N, M, k):
     except pk_engine.KBestError:
         os.environ.pop("KBEST_NO_NARROW", None)
     out = {"value": float(nf.sum()) / best, "unit": "assignments/s", "ms": 1e3 * best,
+           "ms_is": "the MEDIAN of 11 calls (after two untimed ones) of the better leg; every leg's median / min / max in `legs`",
+           "legs": legs,
            "includes": "H2D of the cost blocks, kernel, D2H of row4col / col4row / gain / nf (host buffers in and out: kbest_batch_f64), into the "
                        "caller's int32 tables: the kernels write row4col as bytes into pinned staging, in four pieces; host threads of the "
                        "context widen a piece into row4col and its inverse col4row while the GPU works on the next one",
-           "buffers": "caller-owned numpy arrays, reused across calls: the better of plain (pageable) arrays and of arrays registered once with "
+           "buffers": "caller-owned numpy arrays, reused across calls: the better (by median) of plain (pageable) arrays and of arrays registered once with "
                       "kbest_register_host_buffer (cost blocks then read in place by the kernel)",
            "registered_ms": None if registered is None else 1e3 * registered,
            "pageable_ms": 1e3 * pageable,
@@ -487,10 +593,10 @@ def dense_entry(eng, torch, cfg, steps, warmup, dev, tstream, cpu_sample, no_cpu
     if iss:
         e["issue"] = iss
     if not no_cpu:
-        cb, r4c_cpu, g_cpu, p_cpu = cpu_dense(m["costs"], N, M, k, cpu_sample)
-        ns = min(cpu_sample, Bc)
-        cb["parity_vs_gpu"] = bool((g_cpu.reshape(-1, k)[:ns].view(np.int64) == m["g"][:ns].view(np.int64)).all()
-                                   and (np.asarray(r4c_cpu).reshape(-1, k, M)[:ns] == m["r4c"][:ns]).all())
+        cb, ref, p_cpu = cpu_dense(m["costs"], N, M, k, cpu_sample)
+        tp = tables_parity(m, ref)
+        cb["parity_vs_gpu"] = tp["all"]
+        cb["parity_tables"] = tp
         e["cpu_baseline"] = cb
         e["speedup_vs_cpu_1core"] = e["value"] / cb["value"]
     return e
@@ -746,7 +852,9 @@ def main():
     if (args.gpus > 1 or os.environ.get("KBEST_BENCH_SELF_LAUNCH") == "1") and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` by itself: this process becomes the launcher.  Nothing here has touched HIP (no torch
         # import yet), and the ranks are CHILD processes -- a process that has initialised the GPU is never re-exec'd.
-        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+        # (KBEST_BENCH_BACKEND=gloo deals the ranks to the GPUs there are -- two ranks on one GPU, the one-GPU test of this path)
+        gloo = os.environ.get("KBEST_BENCH_BACKEND") == "gloo"
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:], count=(lambda: args.gpus) if gloo else visible_gpus))
 
     import torch
     import torch.distributed as dist
@@ -759,6 +867,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # KBEST_BENCH_BACKEND=gloo: the ranks' packed slices travel through the host (gloo) instead of RCCL, and the ranks are dealt to
+    # the GPUs there are (LOCAL_RANK modulo the device count) -- RCCL refuses two ranks on one GPU, gloo does not: how EVERY line of
+    # the world > 1 path (sharding, overlapped exchange, cross-rank checks, weak and strong scaling) runs on a one-GPU box
+    backend = os.environ.get("KBEST_BENCH_BACKEND", "nccl")
+    if backend not in ("nccl", "gloo"):
+        raise SystemExit(f"KBEST_BENCH_BACKEND={backend}: nccl or gloo")
+    if backend == "gloo":
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # KBEST_BENCH_FORCE_DIST=1 runs the RCCL code path (init, all-gather, all-reduce) even with one rank: the only
@@ -769,7 +885,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     eng = pk.KBestEngine(local)
     # a dedicated (non-null) HIP stream: the kernel, the timing events and the collective all go through it
     tstream = torch.cuda.Stream(device=dev)
@@ -799,15 +918,18 @@ def main():
             B = args.batch or Bc
         relays_before = eng.relay_launches()
         m = run_dense(eng, torch, dist if use_dist else None, args.config, B, args.steps, args.warmup, rank, world, dev, tstream,
-                      use_dist, rank * B)
-        relayed = eng.relay_launches() - relays_before  # (of this rank's warm-up + timed launches)
-        t = torch.tensor([m["dt"], m["kern_ms"]], dtype=torch.float64, device=dev)
+                      use_dist, rank * B, backend=backend)
+        relayed = eng.relay_launches() - relays_before  # (of this rank's launches: the no-prune run, the warm-ups, the timed steps)
+        coll = m["collective"]
+        t = torch.tensor([m["dt"], m["kern_ms"], (coll or {}).get("exposed_ms") or 0.0], dtype=torch.float64, device=dev)
         tot = torch.tensor([m["found"], m["balg"]], dtype=torch.float64, device=dev)
         if use_dist:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            all_reduce_(torch, dist, backend, t, dist.ReduceOp.MAX)
+            all_reduce_(torch, dist, backend, tot, dist.ReduceOp.SUM)
         dt_max, kern_ms_max = float(t[0]), float(t[1])
         found_all, balg_all = float(tot[0]), float(tot[1])
+        if coll and coll.get("exposed_ms") is not None:
+            coll["exposed_ms_max_over_ranks"] = float(t[2])
         if rank == 0:
             what = "per GPU" if args.scaling == "weak" else f"in all, {B} per GPU"
             out = {
@@ -821,17 +943,18 @@ def main():
                 "config": {"workload": f"{B if args.scaling == 'weak' else B * world} dense {N}x{M} cost matrices {what}, k={k} "
                                        f"(BASELINE configs[3] shape, splitmix64 seed {seed:#x}), kBest2D semantics",
                            "matrices_per_gpu": B, "numRow": N, "numCol": M, "k": k, "parallelism": f"batch-sharded x{world}",
-                           "collective": "ONE all-gather per step of the packed per-rank slice (gain[k] | row4col[k*M] | nf per matrix), overlapped with the next step"
-                                         if use_dist else "none (one GPU)"},
+                           "collective": coll["what"] if use_dist else "none (one GPU)"},
                 "problems_per_s": B * world * args.steps / dt_max,
                 "kernel_ms": kern_ms_max,
                 "parity_prune_vs_noprune": m["parity_self"],
-                "launch": {"relay_launches": relayed, "of": args.steps + args.warmup,
+                "launch": {"relay_launches": relayed, "of": (args.steps + args.warmup) * (2 if coll and coll.get("exposed_ms") is not None else 1),
                            "what": "launches of the 64-row kernel that ran as a relay: every matrix enumerated by three workgroups in turn, its LDS "
                                    "handed on through HBM (DESIGN.md section 2 point 12; KBEST_RELAY=0 launches it plainly)"},
                 "roofline": roofline_block(args.config, B, balg_all / world, kern_ms_max,
                                            {"mean_pushed_per_matrix": float(m["pushed"].mean())}),
             }
+            if coll:
+                out["collective"] = coll
             iss = issue_block(args.config)
             if iss:
                 out["issue"] = iss
@@ -839,16 +962,25 @@ def main():
                 out["value_host_inclusive"] = host_inclusive_dense(eng, m["costs"], N, M, k)
             if world == 1 and not args.no_cpu:
                 sample = args.cpu_sample or cpu_samples[args.config]
-                cb, r4c_cpu, g_cpu, p_cpu = cpu_dense(m["costs"], N, M, k, sample)
+                cb, ref, p_cpu = cpu_dense(m["costs"], N, M, k, sample)
                 ns = min(sample, B)
-                cb["parity_vs_gpu"] = bool((g_cpu.reshape(-1, k)[:ns].view(np.int64) == m["g"][:ns].view(np.int64)).all()
-                                           and (np.asarray(r4c_cpu).reshape(-1, k, M)[:ns] == m["r4c"][:ns]).all())
+                tp = tables_parity(m, ref)
+                cb["parity_vs_gpu"] = tp["all"]
+                cb["parity_tables"] = tp
                 if p_cpu is not None:
                     cb["pushed_matches_gpu"] = bool((p_cpu[:ns] == m["pushed"][:ns]).all())
                 out["cpu_baseline"] = cb
                 out["speedup_vs_cpu_1core"] = out["value"] / cb["value"]
                 ca = cpu_all_cores(m["costs"], N, M, k)
                 if ca is not None:
+                    # the all-core run solves EVERY matrix of the batch with the reference: the tables of the timed launches (the
+                    # relay path) are compared with all of them -- nf, gain bits, row4col, col4row
+                    ca, ref_all = ca
+                    tpa = tables_parity(m, ref_all)
+                    ca["parity_vs_gpu"] = tpa["all"]
+                    ca["parity_tables"] = tpa
+                    cb["parity_vs_gpu"] = bool(cb["parity_vs_gpu"] and tpa["all"])
+                    cb["parity_sample"] = f"all {tpa['matrices']} matrices of the timed launch (nf, gain bits, row4col, col4row) against the reference's tables from the all-core run"
                     out["cpu_baseline_all_cores"] = ca
                     out["speedup_vs_cpu_all_cores"] = out["value"] / ca["value"]
             if world == 1 and not args.no_extra and args.config == "c4" and args.batch is None:
@@ -879,8 +1011,15 @@ def main():
                     else:
                         own_pg = False
                     md = run_dense(eng, torch, dist, "c4", Bc // 8, 10, 2, 0, 1, dev, tstream, True, 0)
-                    share["with_rccl_allgather"] = {"ms_per_step": 1e3 * md["dt"] / 10, "kernel_ms": md["kern_ms"],
+                    share["with_rccl_allgather"] = {"ms_per_step": 1e3 * md["dt"] / 10, "kernel_ms": md["kern_ms"], "collective": md["collective"],
                                                     "what": "KBEST_BENCH_FORCE_DIST path: one packed all-gather per step on a 1-rank RCCL communicator, overlapped with the next step's kernel"}
+                    # the headline's own batch with the exchange in the step (a 1-rank RCCL communicator: the call path, the packed int8
+                    # slice, the overlap) -- what the exchange costs a step of the full-size workload
+                    mf = run_dense(eng, torch, dist, "c4", Bc, 10, 2, 0, 1, dev, tstream, True, 0)
+                    extra["c4_with_rccl_allgather"] = {"workload": f"{Bc} dense {N}x{M} matrices, k={k}: the headline batch, KBEST_BENCH_FORCE_DIST path",
+                                                       "ms_per_step": 1e3 * mf["dt"] / 10, "kernel_ms": mf["kern_ms"], "collective": mf["collective"],
+                                                       "vs_plain_step": (1e3 * mf["dt"] / 10) / out["ms_per_step"],
+                                                       "parity_prune_vs_noprune": mf["parity_self"]}
                     if own_pg:
                         dist.destroy_process_group()
                     # strong scaling of configs[3] on 8 GPUs cannot beat (time of all 1 024 on one GPU) / (time of one share)

@@ -95,7 +95,8 @@ enum {
 #define KBEST_FLAG_TABLES_I8 64u   /* kbest_batch_f64 / kbest_batch_f64_dev: row4col / col4row are tables of int8_t (same shapes, */
                                    /* same values, -1 = unassigned / unused) instead of int32_t: every index of a problem of up   */
                                    /* to 127 rows fits a byte, and a quarter of the bytes cross PCIe.  numRow > 127:              */
-                                   /* KBEST_ERR_UNSUPPORTED.  Not with the multi-GPU entries (their merge reads int32 tables).     */
+                                   /* KBEST_ERR_UNSUPPORTED.  Not with the multi-GPU entries: the caller's tables are int32 there  */
+                                   /* (what travels BETWEEN the devices is in bytes by itself wherever the indices fit them).      */
 
 /* per-problem tie flags (kbest_opts.tie_flags / kbest_set_tie_flags; see "Order of exact ties" above) */
 #define KBEST_TIE_INSIDE 1            /* some of the emitted gains are exactly equal (they are in the canonical order)        */
@@ -342,6 +343,26 @@ int kbest_unregister_host_buffer(kbest_ctx *ctx, void *ptr);
 int kbest_merge_topk_f64_dev(kbest_ctx *ctx, int B, int nShard, int k, int maxCol, int maximize, const void *d_gain,
                              const void *d_row4col, const void *d_nf, int64_t shardStrideBytes, double *d_outGain,
                              int32_t *d_outRow4col, int32_t *d_outNf, void *stream);
+/* The same with the shards' row4col tables as int8 ([B][k][maxCol] bytes: what KBEST_FLAG_TABLES_I8 launches write and what the
+ * exchange of problems of up to 127 rows moves); the merged table is int32. */
+int kbest_merge_topk_i8_f64_dev(kbest_ctx *ctx, int B, int nShard, int k, int maxCol, int maximize, const void *d_gain,
+                                const void *d_row4col8, const void *d_nf, int64_t shardStrideBytes, double *d_outGain,
+                                int32_t *d_outRow4col, int32_t *d_outNf, void *stream);
+/*
+ * The global k-best heap from the shards' COSTS alone (the north star's "allgather of per-rank top-k costs into a global k-best
+ * heap"): d_gain [nShard][B][k] fp64 and d_nf [nShard][B] i32 are what an all-gather of every rank's (gain, nf) leaves on every
+ * rank -- 8 k + 4 bytes per matrix and shard --; d_ownRow4col8 [B][k][maxCol] int8 are the rows of THIS rank's shard `ownShard`
+ * (a KBEST_FLAG_TABLES_I8 launch with root_col_offset / stride).  Writes the merged gains d_outGain [B][k] and counts d_outNf [B]
+ * in full (identical on every rank), and into d_outRow4col8 [B][k][maxCol] -- which the caller has ZEROED -- the rows of this
+ * rank's own winners at their merged positions: ONE sum all-reduce of that byte table over the ranks (k maxCol bytes per matrix,
+ * whatever the number of ranks; every entry is non-zero on at most one rank) completes it everywhere; slots beyond d_outNf stay 0.
+ * *d_tied (one int32, zeroed by the caller) is set when two candidates of some matrix have EXACTLY the same gain within the k best
+ * or at slot k: their order is the assignments' ("Order of exact ties" above), which this merge does not see -- the caller then
+ * exchanges the whole lists and merges with kbest_merge_topk_i8_f64_dev.  numRow <= 127.  Asynchronous on `stream`.
+ */
+int kbest_merge_gains_f64_dev(kbest_ctx *ctx, int B, int nShard, int k, int maxCol, int maximize, const double *d_gain,
+                              const int32_t *d_nf, int ownShard, const int8_t *d_ownRow4col8, double *d_outGain,
+                              int8_t *d_outRow4col8, int32_t *d_outNf, int32_t *d_tied, void *stream);
 
 /*
  * Multi-device entries (BASELINE.json config 4): one engine context + one stream per GPU and an
@@ -349,7 +370,8 @@ int kbest_merge_topk_f64_dev(kbest_ctx *ctx, int B, int nShard, int k, int maxCo
  * contiguous blocks (device g solves matrices [g*ceil(B/G), ...)), each device solving its block with the kernels of
  * the single-device entries straight into its packed slice (gain | row4col | nf) of a global table; ONE in-place
  * ncclAllGather of those slices then leaves EVERY device with the same global k-best table (there is no
- * other collective: the matrices are independent).  Every device is fed and read back by a host thread of its own: the
+ * other collective: the matrices are independent).  Between the devices row4col travels as int8 wherever every index fits a
+ * byte (numRow <= 127: 8 + numCol instead of 8 + 4 numCol bytes per solution); the caller's tables are int32 as ever.  Every device is fed and read back by a host thread of its own: the
  * host outputs of a block come from the device that solved it (col4row is not part of the exchange).  device_ids may
  * name one GPU several times ("logical devices", e.g. {0, 0, 0, 0}): the slices then travel by device-to-device copies
  * instead of RCCL -- the same host path, testable on one GPU.  Same argument meaning as kbest_batch_f64
@@ -373,10 +395,13 @@ int kbest_batch_f64_multi(kbest_multi *m, const kbest_opts *opts, int B, int max
  * north star's "per-rank top-k into a global k-best heap"): every device receives ALL B matrices; shard s of nShard
  * (0 = one per device; more than devices: dealt round robin, a device runs its shards one after the other) expands only
  * the root's children on columns c % nShard == s (reference partition: split, shortestPathCPP.cpp:455-532) and enumerates
- * its own k best; ONE all-gather of the packed per-shard lists, then every device merges them into the global k best
- * (kbest_merge_topk_f64_dev).  Results are those of the batch mode for tie-free costs (exact ties: ordered by the
- * assignment); col4row, which is not part of the exchange, is returned as the inverse of row4col with -1 for rows
- * without a real column.  opts->root_col_offset / stride must be unset.
+ * its own k best.  The exchange is gains first (numRow <= 127): ONE all-gather of every shard's top-k COSTS (gain[k] + nf), the merge
+ * into the global k-best heap on every device (kbest_merge_gains_f64_dev), and ONE sum all-reduce of the byte table that holds every
+ * winner's row at its merged position -- 8 k S + k numCol bytes per matrix instead of (8 + 4 numCol) k S.  A call in which two
+ * candidates have exactly the same gain (integer-like costs: their order is the assignments'), and problems of more than 127 rows,
+ * all-gather the whole per-shard lists and merge those (kbest_merge_topk[_i8]_f64_dev).  Results are those of the batch mode for
+ * tie-free costs (exact ties: ordered by the assignment); col4row, which is not part of the exchange, is returned as the inverse of
+ * row4col with -1 for rows without a real column.  opts->root_col_offset / stride must be unset.
  */
 #define KBEST_MULTI_BATCH 0
 #define KBEST_MULTI_SUBTREE 1
@@ -385,6 +410,9 @@ int kbest_batch_f64_multi_ex(kbest_multi *m, const kbest_opts *opts, int mode, i
                              int32_t *col4row, double *gain, int32_t *nf);
 /* 1 when every device holds the same global table after the last kbest_batch_f64_multi[_ex] call, 0 when not (test aid). */
 int kbest_multi_tables_agree(kbest_multi *m);
+/* Bytes ONE device contributed to the exchanges of the last kbest_batch_f64_multi[_ex] call (the all-gather's send count, plus the
+ * all-reduced table in subtree mode); *path (optional): 0 batch mode, 1 subtree mode gains first, 2 subtree mode whole lists. */
+long long kbest_multi_exchange_bytes(const kbest_multi *m, int *path);
 /*
  * Host timeline of the last kbest_batch_f64_multi[_ex] call: out[g * KBEST_MULTI_STAMPS + i], seconds since the call was
  * entered, for device g: [0] its worker thread started, [1] its first upload was issued, [2] its first kernel was issued,

@@ -1446,9 +1446,10 @@ int kbest_batch_f64_keep(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxR
             e = kb::launch_fill_unused(pN, nullptr, nullptr, nb, k, maxCol, maxRow, pR, nullptr, pG, true, st[c]);
             if (e != hipSuccess) { rc = fail(ctx, KBEST_ERR_HIP, "fill kernel launch", e); break; }
             if (keep) {
-                // the device keeps int32 row4col (its slice of the global table); the bytes, the gains and the counts go home
+                // the device keeps row4col as its slice of the global table holds it (int32: widened here; bytes: as written); the bytes,
+                // the gains and the counts go home
                 const size_t nEnt = (size_t)nb * k * maxCol;
-                e = kb::launch_widen_i8(reinterpret_cast<const signed char *>(pR), keep->row4col + (size_t)b0 * k * maxCol, (long long)nEnt, st[c]);
+                if (!keep->keepI8) e = kb::launch_widen_i8(reinterpret_cast<const signed char *>(pR), keep->row4col + (size_t)b0 * k * maxCol, (long long)nEnt, st[c]);
                 // (by copy kernels on the piece's stream into the host-mapped staging: kbest_merge.hip, launch_copy_words)
                 if (e == hipSuccess && nEnt % 4 == 0) e = kb::launch_copy_words(pR, d8 + (size_t)b0 * k * maxCol, (long long)nEnt, st[c]);
                 else if (e == hipSuccess) e = hipMemcpyAsync(h8 + (size_t)b0 * k * maxCol, pR, nEnt, hipMemcpyDeviceToHost, st[c]);
@@ -1482,7 +1483,8 @@ int kbest_batch_f64_keep(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxR
     DevBuf dCost, dOff, dNR, dNC, dR4C, dC4R, dGain, dNf, dPushed;
     if (!zcCost) HIP_TRY(ctx, dCost.alloc(ctx, nCost * 8));
     const double *devCost = zcCost ? mCost : dCost.as<double>();
-    if (keep && (tabI8 || (col4row && !keep->col4row))) return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_batch_f64_keep: bad device tables");
+    if (keep && (tabI8 || !keep->row4col || (col4row && !keep->col4row) || (keep->keepI8 && !keep->row4col8)))
+        return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_batch_f64_keep: bad device tables");
     if (!direct && !keep) {
         HIP_TRY(ctx, dR4C.alloc(ctx, nR4C * esz));
         if (col4row) HIP_TRY(ctx, dC4R.alloc(ctx, nC4R * esz));
@@ -1568,6 +1570,11 @@ int kbest_batch_f64_keep(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxR
                                    oC4R ? reinterpret_cast<int32_t *>(oC4R + (size_t)b0 * k * maxRow * esz) : nullptr, oGain + (size_t)b0 * k, tabI8,
                                    st[c]);
         if (e != hipSuccess) { rc = fail(ctx, KBEST_ERR_HIP, "fill kernel launch", e); break; }
+        if (keep && keep->keepI8) {  // the kept table is the byte table (the multi-device exchange travels in bytes)
+            e = kb::launch_narrow_i32(reinterpret_cast<const int *>(sR4C) + (size_t)b0 * k * maxCol, keep->row4col8 + (size_t)b0 * k * maxCol,
+                                      (long long)nb * k * maxCol, st[c]);
+            if (e != hipSuccess) { rc = fail(ctx, KBEST_ERR_HIP, "narrowing kernel launch", e); break; }
+        }
         if (nPiece > 1 &&
             (hipEventCreateWithFlags(&done[c], hipEventDisableTiming) != hipSuccess || hipEventRecord(done[c], st[c]) != hipSuccess))
             rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: event", hipGetLastError());
@@ -1684,9 +1691,9 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
     return KBEST_OK;
 }
 
-int kbest_merge_topk_f64_dev(kbest_ctx *ctx, int B, int nShard, int k, int maxCol, int maximize, const void *d_gain,
-                             const void *d_row4col, const void *d_nf, int64_t shardStrideBytes, double *d_outGain,
-                             int32_t *d_outRow4col, int32_t *d_outNf, void *stream)
+static int merge_topk_impl(kbest_ctx *ctx, int B, int nShard, int k, int maxCol, int maximize, const void *d_gain,
+                           const void *d_row4col, const void *d_nf, int64_t shardStrideBytes, double *d_outGain,
+                           int32_t *d_outRow4col, int32_t *d_outNf, void *stream, bool inI8)
 {
     if (!ctx) return KBEST_ERR_BAD_ARG;
     if (B < 0 || nShard < 1 || k < 1 || maxCol < 1 || !d_gain || !d_row4col || !d_nf || !d_outGain || !d_outRow4col || !d_outNf ||
@@ -1711,7 +1718,56 @@ int kbest_merge_topk_f64_dev(kbest_ctx *ctx, int B, int nShard, int k, int maxCo
     p.ldRow = 0;
     p.strideR4C = 0;
     p.strideNf = 0;
+    p.inI8 = inI8 ? 1 : 0;
+    p.spd = 1;
     hipError_t e = kb::launch_merge_topk(p, B, stream ? static_cast<hipStream_t>(stream) : ctx->stream);
+    if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "merge kernel launch", e);
+    return KBEST_OK;
+}
+
+int kbest_merge_topk_f64_dev(kbest_ctx *ctx, int B, int nShard, int k, int maxCol, int maximize, const void *d_gain,
+                             const void *d_row4col, const void *d_nf, int64_t shardStrideBytes, double *d_outGain,
+                             int32_t *d_outRow4col, int32_t *d_outNf, void *stream)
+{
+    return merge_topk_impl(ctx, B, nShard, k, maxCol, maximize, d_gain, d_row4col, d_nf, shardStrideBytes, d_outGain, d_outRow4col, d_outNf, stream, false);
+}
+
+int kbest_merge_topk_i8_f64_dev(kbest_ctx *ctx, int B, int nShard, int k, int maxCol, int maximize, const void *d_gain,
+                                const void *d_row4col8, const void *d_nf, int64_t shardStrideBytes, double *d_outGain,
+                                int32_t *d_outRow4col, int32_t *d_outNf, void *stream)
+{
+    return merge_topk_impl(ctx, B, nShard, k, maxCol, maximize, d_gain, d_row4col8, d_nf, shardStrideBytes, d_outGain, d_outRow4col, d_outNf, stream, true);
+}
+
+int kbest_merge_gains_f64_dev(kbest_ctx *ctx, int B, int nShard, int k, int maxCol, int maximize, const double *d_gain, const int32_t *d_nf,
+                              int ownShard, const int8_t *d_ownRow4col8, double *d_outGain, int8_t *d_outRow4col8, int32_t *d_outNf,
+                              int32_t *d_tied, void *stream)
+{
+    if (!ctx) return KBEST_ERR_BAD_ARG;
+    if (B < 0 || nShard < 1 || k < 1 || maxCol < 1 || !d_gain || !d_nf || ownShard < 0 || ownShard >= nShard || !d_ownRow4col8 || !d_outGain ||
+        !d_outRow4col8 || !d_outNf || !d_tied)
+        return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_merge_gains_f64_dev: bad argument");
+    if (B == 0) return KBEST_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    kb::MergeGainsParams q;
+    memset(&q, 0, sizeof(q));
+    q.gain = reinterpret_cast<const unsigned char *>(d_gain);
+    q.nf = reinterpret_cast<const unsigned char *>(d_nf);
+    q.blockStride = 0;
+    q.spd = nShard;  // plain [nShard][B][...] arrays: one block
+    q.ownRow8 = reinterpret_cast<const signed char *>(d_ownRow4col8);
+    q.ownLo = ownShard;
+    q.ownHi = ownShard + 1;
+    q.nShard = nShard;
+    q.B = B;
+    q.k = k;
+    q.maxCol = maxCol;
+    q.maximize = maximize;
+    q.outGain = d_outGain;
+    q.outRow8 = reinterpret_cast<signed char *>(d_outRow4col8);
+    q.outNf = d_outNf;
+    q.tied = d_tied;
+    hipError_t e = kb::launch_merge_gains(q, stream ? static_cast<hipStream_t>(stream) : ctx->stream);
     if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "merge kernel launch", e);
     return KBEST_OK;
 }

@@ -453,16 +453,40 @@ struct MergeParams {
     int *outNf;                    // [B]
     int *outCol4row;               // [B][k][ldRow] or nullptr: the inverse of the merged row4col, -1 for rows without a column
     int ldRow;
+    int inI8;                      // the shards' row4col tables are int8 (the merged table is int32 either way)
+    int spd;                       // > 1: every block (shardStride apart) holds this many shards, tables of B problems back to back
+};
+// The merge from the shards' gains alone (kbest_merge.hip, merge_gains_kernel): all shards' gains and counts, the device's own
+// shards' rows; out: merged gains and counts (whole), the own winners' rows at their merged positions in a byte table (zero
+// elsewhere: a sum all-reduce completes it), and one word that is set when two candidates of a matrix have exactly the same gain.
+struct MergeGainsParams {
+    const unsigned char *gain;     // block 0: [spd][B][k] fp64; block j (a device's share of the all-gather) blockStride bytes behind
+    const unsigned char *nf;       // block 0: [spd][B] i32
+    long long blockStride;
+    int spd;                       // shards per block (<= 1: one)
+    const signed char *ownRow8;    // [ownHi - ownLo][B][k][maxCol]: the rows of shards ownLo .. ownHi-1
+    int ownLo, ownHi;
+    int nShard, B, k, maxCol, maximize;
+    double *outGain;               // [B][k]
+    signed char *outRow8;          // [B][k][maxCol], zeroed by the caller
+    int *outNf;                    // [B]
+    int *tied;                     // one word, zeroed by the caller
 };
 // kbest_batch_f64 with the tables staged in (and left in) caller-owned device buffers: the multi-device entry's per-device step
 // (kbest_capi.cpp).  stamps (optional): host times (seconds, steady clock) at which the first upload / the first kernel was issued.
-// row4col8 (optional): device scratch for the block's row4col as bytes -- the narrow staging of uniform square batches then
-// runs with it (bytes cross PCIe, row4col is widened into `row4col` on the device, col4row is rebuilt on the host and not kept).
-struct KeepTables { int32_t *row4col, *col4row; double *gain; int32_t *nf; double *stamps; signed char *row4col8; };
+// row4col8 (optional): device memory for the block's row4col as bytes -- the narrow staging of uniform square batches then
+// runs with it (bytes cross PCIe, col4row is rebuilt on the host and not kept).  keepI8 = 0: the table that is KEPT is the int32
+// `row4col` (the narrow-staged path widens the bytes into it on the device); keepI8 = 1: the kept table is the byte table
+// `row4col8` (a device's slice of the multi-device exchange, which travels in bytes) and `row4col` is int32 staging for the paths
+// whose kernels write int32 (they narrow it into row4col8 on the device).
+struct KeepTables { int32_t *row4col, *col4row; double *gain; int32_t *nf; double *stamps; signed char *row4col8; int keepI8; };
 hipError_t launch_widen_i8(const signed char *src, int *dst, long long n, hipStream_t stream);
 hipError_t launch_copy_words(const void *src, void *dst, long long bytes, hipStream_t stream);  // bytes: a multiple of 4
 double now_s();
 hipError_t launch_merge_topk(const MergeParams &p, int B, hipStream_t stream);
+hipError_t launch_merge_gains(const MergeGainsParams &p, hipStream_t stream);
+hipError_t launch_narrow_i32(const int *src, signed char *dst, long long n, hipStream_t stream);
+hipError_t launch_add_i8(signed char *dst, const signed char *src, long long n, hipStream_t stream);
 hipError_t launch_fill_unused(const int *nf, const int *nRow, const int *nCol, int B, int k, int ldCol, int ldRow, int *row4col,
                               int *col4row, double *gain, bool tablesI8, hipStream_t stream);
 // The kernel behind every enumeration launch (kbest_merge.hip, kbest_ties.h): runs of equal gains into the canonical order,

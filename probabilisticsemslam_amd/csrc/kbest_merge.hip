@@ -19,7 +19,7 @@ namespace kb {
 namespace {
 
 // (gain, assignment) of candidate A strictly before candidate B in the merged order?
-__device__ __forceinline__ bool before(double ga, const int *ra, double gb, const int *rb, int M, bool maximize)
+template <typename T> __device__ __forceinline__ bool before(double ga, const T *ra, double gb, const T *rb, int M, bool maximize)
 {
     if (ga != gb) return maximize ? (ga > gb) : (ga < gb);
     for (int c = 0; c < M; c++)
@@ -29,15 +29,21 @@ __device__ __forceinline__ bool before(double ga, const int *ra, double gb, cons
 
 }  // namespace
 
-__global__ void __launch_bounds__(256) merge_topk_kernel(MergeParams p)
+// T: the type of the SHARDS' row4col tables (int32, or int8 when every index fits a byte: the multi-device exchange); the merged
+// table is int32 either way.
+template <typename T> __global__ void __launch_bounds__(256) merge_topk_kernel(MergeParams p)
 {
     const int b = blockIdx.x, tid = threadIdx.x;
     const int S = p.nShard, k = p.k, M = p.maxCol;
     const bool maximize = p.maximize != 0;
-    auto gainOf = [&](int s) { return reinterpret_cast<const double *>(p.gain + (long long)s * p.shardStride) + (long long)b * k; };
+    // shard s: block s / spd (blocks shardStride bytes apart: the devices' slices), table s % spd inside the block (tables of
+    // gridDim.x problems back to back); spd <= 1: one shard per block, as the packed per-rank slices are
+    const int spd = p.spd > 1 ? p.spd : 1;
+    const long long nB = gridDim.x;
+    auto gainOf = [&](int s) { return reinterpret_cast<const double *>(p.gain + (long long)(s / spd) * p.shardStride) + ((long long)(s % spd) * nB + b) * k; };
     const long long sR = p.strideR4C ? p.strideR4C : p.shardStride, sN = p.strideNf ? p.strideNf : p.shardStride;
-    auto rowsOf = [&](int s) { return reinterpret_cast<const int *>(p.row4col + (long long)s * sR) + (long long)b * k * p.ldCol; };
-    auto nfOf = [&](int s) { return reinterpret_cast<const int *>(p.nf + (long long)s * sN)[b]; };
+    auto rowsOf = [&](int s) { return reinterpret_cast<const T *>(p.row4col + (long long)(s / spd) * sR) + ((long long)(s % spd) * nB + b) * k * p.ldCol; };
+    auto nfOf = [&](int s) { return reinterpret_cast<const int *>(p.nf + (long long)(s / spd) * sN)[(long long)(s % spd) * nB + b]; };
     double *og = p.outGain + (long long)b * k;
     int *orow = p.outRow4col + (long long)b * k * p.ldCol;
     const int nf0 = nfOf(0);
@@ -50,7 +56,7 @@ __global__ void __launch_bounds__(256) merge_topk_kernel(MergeParams p)
     __syncthreads();
     // the root: slot 0 of shard 0
     if (tid == 0) og[0] = gainOf(0)[0];
-    for (int c = tid; c < M; c += 256) orow[c] = rowsOf(0)[c];
+    for (int c = tid; c < M; c += 256) orow[c] = (int)rowsOf(0)[c];
     int mine = 0;
     for (int idx = tid; idx < S * k; idx += 256) {
         const int s = idx / k, i = idx - s * k;
@@ -58,7 +64,7 @@ __global__ void __launch_bounds__(256) merge_topk_kernel(MergeParams p)
         if (i < 1 || i >= n) continue;  // the root, or beyond what the shard found
         mine++;
         const double g = gainOf(s)[i];
-        const int *r = rowsOf(s) + (long long)i * p.ldCol;
+        const T *r = rowsOf(s) + (long long)i * p.ldCol;
         int pos = 0;
         for (int t = 0; t < S; t++) {
             const double *gt = gainOf(t);
@@ -71,13 +77,13 @@ __global__ void __launch_bounds__(256) merge_topk_kernel(MergeParams p)
                 if (better) lo = mid + 1; else hi = mid;
             }
             pos += lo - 1;
-            const int *rt = rowsOf(t);
+            const T *rt = rowsOf(t);
             for (int j = lo; j < nt && gt[j] == g; j++)  // the run of equal gains: ordered by the assignment
                 pos += before(gt[j], rt + (long long)j * p.ldCol, g, r, M, maximize) ? 1 : 0;
         }
         if (1 + pos < k) {
             og[1 + pos] = g;
-            for (int c = 0; c < M; c++) orow[(long long)(1 + pos) * p.ldCol + c] = r[c];
+            for (int c = 0; c < M; c++) orow[(long long)(1 + pos) * p.ldCol + c] = (int)r[c];
         }
     }
     if (mine) atomicAdd(&total, mine);
@@ -243,7 +249,121 @@ hipError_t launch_copy_words(const void *src, void *dst, long long bytes, hipStr
 
 hipError_t launch_merge_topk(const MergeParams &p, int B, hipStream_t stream)
 {
-    hipLaunchKernelGGL(merge_topk_kernel, dim3(B), dim3(256), 0, stream, p);
+    if (p.inI8) hipLaunchKernelGGL(merge_topk_kernel<signed char>, dim3(B), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(merge_topk_kernel<int>, dim3(B), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+// The same merge from the shards' GAINS alone -- the north star's "allgather of per-rank top-k costs into a global k-best heap"
+// (split, shortestPathCPP.cpp:455-532).  Every device holds all shards' gain[k] and nf (8 k + 4 bytes per matrix and
+// shard: what the all-gather moved) but only ITS OWN shards' row4col lists.  One workgroup per matrix: every candidate's merged
+// position follows from the gains (per shard a binary search); the merged gains and the count are written in full -- identical on
+// every device --, and the rows of the device's own winners are scattered into a byte table that is zero elsewhere, so that ONE
+// sum all-reduce of that table (k * M bytes per matrix, whatever the number of shards) completes it everywhere.  Two candidates
+// with EXACTLY the same gain cannot be ordered without their assignments (the rule is (gain, row4col lexicographic), kbest_c.h):
+// such a matrix is flagged in `tied` and the caller falls back to the exchange of the whole lists for the call.
+__global__ void __launch_bounds__(256) merge_gains_kernel(MergeGainsParams p)
+{
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int S = p.nShard, k = p.k, M = p.maxCol;
+    const bool maximize = p.maximize != 0;
+    // shard s: block s / spd of the gathered heads (blockStride bytes apart), table s % spd inside it
+    const int spd = p.spd > 1 ? p.spd : 1;
+    auto gainOf = [&](int s) { return reinterpret_cast<const double *>(p.gain + (long long)(s / spd) * p.blockStride) + ((long long)(s % spd) * p.B + b) * k; };
+    auto nfOf = [&](int s) { return reinterpret_cast<const int *>(p.nf + (long long)(s / spd) * p.blockStride)[(long long)(s % spd) * p.B + b]; };
+    double *og = p.outGain + (long long)b * k;
+    signed char *orow = p.outRow8 + (long long)b * k * M;
+    const int nf0 = nfOf(0);
+    if (nf0 <= 0) {  // infeasible (every shard solves the same root): kBest2D returns 0 (cpp:588-593); errors pass through
+        if (tid == 0) p.outNf[b] = nf0;
+        return;
+    }
+    __shared__ int total, anyTie;
+    if (tid == 0) { total = 0; anyTie = 0; }
+    __syncthreads();
+    // the root: slot 0 of shard 0 (its row comes from the device that holds shard 0)
+    if (tid == 0) og[0] = gainOf(0)[0];
+    if (p.ownLo == 0 && p.ownHi > 0)
+        for (int c = tid; c < M; c += 256) orow[c] = p.ownRow8[(long long)b * k * M + c];
+    int mine = 0, tie = 0;
+    for (int idx = tid; idx < S * k; idx += 256) {
+        const int s = idx / k, i = idx - s * k;
+        const int n = nfOf(s);
+        if (i < 1 || i >= n) continue;  // the root, or beyond what the shard found
+        mine++;
+        const double g = gainOf(s)[i];
+        int pos = 0, equal = 0;
+        for (int t = 0; t < S; t++) {
+            const double *gt = gainOf(t);
+            const int nt = nfOf(t);
+            // entries 1 .. nt-1 of shard t are sorted by gain: [lo, up) is the run equal to g
+            int lo = 1, hi = nt > 1 ? nt : 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const bool better = maximize ? (gt[mid] > g) : (gt[mid] < g);
+                if (better) lo = mid + 1; else hi = mid;
+            }
+            int up = lo;
+            while (up < nt && gt[up] == g) up++;
+            equal += up - lo;
+            // (an order of the run by (shard, slot): only its SIZE matters -- a run of more than one is what the flag reports)
+            pos += (lo - 1) + (t < s ? up - lo : (t == s ? i - lo : 0));
+        }
+        // a winner, or the first loser (the candidate that would take slot k): an equal gain next to it leaves the order -- or the
+        // members of the level at slot k -- to the assignments
+        if (equal > 1 && 1 + pos <= k) tie = 1;
+        if (1 + pos < k) {
+            og[1 + pos] = g;
+            if (s >= p.ownLo && s < p.ownHi) {
+                const signed char *r = p.ownRow8 + (((long long)(s - p.ownLo) * p.B + b) * k + i) * M;
+                signed char *o = orow + (long long)(1 + pos) * M;
+                for (int c = 0; c < M; c++) o[c] = r[c];
+            }
+        }
+    }
+    if (mine) atomicAdd(&total, mine);
+    if (tie) atomicOr(&anyTie, 1);
+    __syncthreads();
+    if (tid == 0) {
+        p.outNf[b] = (1 + total < k) ? 1 + total : k;
+        if (anyTie) atomicOr(p.tied, 1);
+    }
+}
+
+hipError_t launch_merge_gains(const MergeGainsParams &p, hipStream_t stream)
+{
+    if (p.B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(merge_gains_kernel, dim3(p.B), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+// int32 table -> int8 table (the multi-device entry: a block's row4col staged as int32 for the caller goes into the device's slice of
+// the exchange as bytes), and dst += src on byte tables (logical devices on one GPU: the sum all-reduce of the winners' rows done by hand)
+__global__ void __launch_bounds__(256) narrow_i32_kernel(const int *src, signed char *dst, long long n)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = (signed char)src[i];
+}
+
+hipError_t launch_narrow_i32(const int *src, signed char *dst, long long n, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    long long blocks = (n + 255) / 256;
+    blocks = blocks > 4096 ? 4096 : blocks;
+    hipLaunchKernelGGL(narrow_i32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, dst, n);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) add_i8_kernel(signed char *dst, const signed char *src, long long n)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = (signed char)(dst[i] + src[i]);
+}
+
+hipError_t launch_add_i8(signed char *dst, const signed char *src, long long n, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    long long blocks = (n + 255) / 256;
+    blocks = blocks > 4096 ? 4096 : blocks;
+    hipLaunchKernelGGL(add_i8_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dst, src, n);
     return hipGetLastError();
 }
 

@@ -34,7 +34,7 @@ C_ABI_SYMBOLS = (
     "kbest_create_multi", "kbest_destroy_multi", "kbest_multi_size", "kbest_multi_last_error", "kbest_batch_f64_multi",
     "kbest_multi_tables_agree", "kbest_batch_f64_multi_ex", "kbest_merge_topk_f64_dev", "kbest_register_host_buffer",
     "kbest_unregister_host_buffer", "kbest_multi_timeline", "kbest_last_tie_flags", "kbest_set_assoc_tie_flags_dev",
-    "kbest_relay_launches",
+    "kbest_relay_launches", "kbest_merge_topk_i8_f64_dev", "kbest_merge_gains_f64_dev", "kbest_multi_exchange_bytes",
 )
 KBEST_MULTI_STAMPS = 6
 KBEST_MULTI_BATCH, KBEST_MULTI_SUBTREE = 0, 1
@@ -109,6 +109,11 @@ def load_library():
                                              C.c_int, i32p, i32p, dp, i32p]
     lib.kbest_merge_topk_f64_dev.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int64, dp, i32p,
                                              i32p, vp]
+    if hasattr(lib, "kbest_merge_gains_f64_dev"):
+        lib.kbest_merge_topk_i8_f64_dev.argtypes = lib.kbest_merge_topk_f64_dev.argtypes
+        lib.kbest_merge_gains_f64_dev.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp, i32p, C.c_int, vp, dp, vp, i32p, i32p, vp]
+        lib.kbest_multi_exchange_bytes.argtypes = [vp, C.POINTER(C.c_int)]
+        lib.kbest_multi_exchange_bytes.restype = C.c_longlong
     if hasattr(lib, "kbest_multi_timeline"):  # (absent from older in-tree builds selected with KBEST_LIB for A/B runs)
         lib.kbest_multi_timeline.argtypes = [vp, dp, C.c_int]
     if hasattr(lib, "kbest_relay_launches"):
@@ -355,13 +360,24 @@ class KBestEngine:
 
 
     def merge_topk_dev(self, B, n_shard, k, M, d_gain, d_row4col, d_nf, shard_stride_bytes, d_out_gain, d_out_row4col, d_out_nf,
-                       maximize=False, stream=None):
-        """kbest_merge_topk_f64_dev: k-way merge of per-shard k-best lists (torch tensors / device pointers)."""
+                       maximize=False, stream=None, tables_i8=False):
+        """kbest_merge_topk_f64_dev (tables_i8: kbest_merge_topk_i8_f64_dev -- the shards' row4col tables are int8): k-way merge
+        of per-shard k-best lists (torch tensors / device pointers)."""
         def dp(t):
             return None if t is None else C.c_void_p(t.data_ptr() if hasattr(t, "data_ptr") else int(t))
-        self._check(self.lib.kbest_merge_topk_f64_dev(self.ctx, B, n_shard, k, M, int(bool(maximize)), dp(d_gain), dp(d_row4col),
-                                                      dp(d_nf), int(shard_stride_bytes), dp(d_out_gain), dp(d_out_row4col),
-                                                      dp(d_out_nf), C.c_void_p(stream) if stream else None))
+        fn = self.lib.kbest_merge_topk_i8_f64_dev if tables_i8 else self.lib.kbest_merge_topk_f64_dev
+        self._check(fn(self.ctx, B, n_shard, k, M, int(bool(maximize)), dp(d_gain), dp(d_row4col), dp(d_nf), int(shard_stride_bytes),
+                       dp(d_out_gain), dp(d_out_row4col), dp(d_out_nf), C.c_void_p(stream) if stream else None))
+
+    def merge_gains_dev(self, B, n_shard, k, M, d_gain, d_nf, own_shard, d_own_row4col8, d_out_gain, d_out_row4col8, d_out_nf, d_tied,
+                        maximize=False, stream=None):
+        """kbest_merge_gains_f64_dev: the global k-best heap from all shards' gains [S,B,k] / nf [S,B] and this rank's own
+        rows (int8 [B,k,M]); d_out_row4col8 (zeroed by the caller) receives the own winners' rows, d_tied (zeroed) the tie word."""
+        def dp(t):
+            return None if t is None else C.c_void_p(t.data_ptr())
+        self._check(self.lib.kbest_merge_gains_f64_dev(self.ctx, B, n_shard, k, M, int(bool(maximize)), dp(d_gain), dp(d_nf), int(own_shard),
+                                                       dp(d_own_row4col8), dp(d_out_gain), dp(d_out_row4col8), dp(d_out_nf), dp(d_tied),
+                                                       C.c_void_p(stream) if stream else None))
 
     def reserve_assoc(self, B, maxRawRow, maxCol, k):
         self._check(self.lib.kbest_reserve_assoc(self.ctx, B, maxRawRow, maxCol, k))
@@ -424,6 +440,12 @@ class KBestMulti:
 
     def tables_agree(self):
         return self.lib.kbest_multi_tables_agree(self.m) == 1
+
+    def exchange_bytes(self):
+        """(bytes one device contributed to the exchanges of the last call, path: 0 batch, 1 subtree gains first, 2 subtree whole lists)."""
+        path = C.c_int(0)
+        n = self.lib.kbest_multi_exchange_bytes(self.m, C.byref(path))
+        return int(n), int(path.value)
 
     def timeline(self):
         """Host times of the last call per device: array [nDev, 6] of seconds since the call was entered (kbest_multi_timeline)."""

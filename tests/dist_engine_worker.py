@@ -24,17 +24,22 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     eng = pk.KBestEngine(0)  # the HIP engine: fails loudly without a GPU
     res = {}
+    # KBEST_DIST_NARROW=1 (round 6): the engine returns int8 tables (KBEST_FLAG_TABLES_I8) and the exchange moves them as they are --
+    # batch mode: int8 slices; subtree mode: gains first (all-gather of the top-k costs, sum all-reduce of the winners' rows)
+    narrow = os.environ.get("KBEST_DIST_NARROW") == "1"
     # batch mode: a contiguous block of matrices per rank, ONE packed all-gather
     costs, N, M, k = wl.dense_config("c2", B=B)
     lo, hi = kd.shard_range(B, rank, world)
-    nf, r4c, c4r, g = eng.kbest(costs[lo:hi], N, M, k)
+    nf, r4c, c4r, g = eng.kbest(costs[lo:hi], N, M, k, tables_i8=narrow)
     G, R, Nf = kd.gather_batch(torch.from_numpy(g), torch.from_numpy(r4c), torch.from_numpy(nf), B)
-    res.update(batch_g=G.numpy(), batch_r=R.numpy(), batch_nf=Nf.numpy())
-    # subtree mode: every rank enumerates the root children on its columns (reference column order), one gather, k-way merge
+    assert R.dtype == (torch.int8 if narrow else torch.int32)
+    res.update(batch_g=G.numpy(), batch_r=R.numpy().astype(np.int32), batch_nf=Nf.numpy())
+    # subtree mode: every rank enumerates the root children on its columns (reference column order), the exchange, the k-way merge
     for tag, (cc, n, m, kk) in {"sub": wl.dense_config("c2", B=Bsub), "sub64": (wl.dense_config("c4", B=2)[0], 64, 64, 60)}.items():
-        nf, r4c, c4r, g = eng.kbest(cc, n, m, kk, root_shard=(rank, world))
+        nf, r4c, c4r, g = eng.kbest(cc, n, m, kk, root_shard=(rank, world), tables_i8=narrow)
         G, R, Nf = kd.merge_subtree_topk(torch.from_numpy(g), torch.from_numpy(r4c), torch.from_numpy(nf), kk)
-        res.update({f"{tag}_g": G.numpy(), f"{tag}_r": R.numpy(), f"{tag}_nf": Nf.numpy()})
+        res.update({f"{tag}_g": G.numpy(), f"{tag}_r": R.numpy().astype(np.int32), f"{tag}_nf": Nf.numpy(),
+                    f"{tag}_path": np.array(kd.last_exchange["path"])})
     np.savez(f"{out}.rank{rank}.npz", **res)
     dist.barrier()
     dist.destroy_process_group()

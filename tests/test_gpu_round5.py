@@ -93,7 +93,9 @@ def test_bench_launches_its_own_rank_and_steps_over_rccl():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["steps"] == 4 and out["parity_prune_vs_noprune"] is True
     assert "all-gather" in out["config"]["collective"]
-    assert out["launch"]["relay_launches"] == out["launch"]["of"] == 5
+    assert out["launch"]["relay_launches"] == out["launch"]["of"] == 10  # (K + W steps without the exchange, then K + W with it)
+    assert out["collective"]["row4col_dtype"] == "int8" and out["collective"]["bytes_per_rank_per_step"] == 1024 * 200 * (8 + 64) + 1024 * 4
+    assert out["collective"]["exposed_ms"] is not None
     assert out["roofline"]["frac"] > 0.5 and out["value"] > 5e7
 
 

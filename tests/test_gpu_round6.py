@@ -1,0 +1,303 @@
+"""GPU tests added in round 6: every line of bench.py's world > 1 path executed (two gloo ranks on GPU 0, weak and strong
+scaling), the timed (relay) path pinned at full size against the checker, the narrow exchange of the multi-device entries
+(int8 slices; subtree mode gains first), the gains-only merge on the device."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import probabilisticsemslam_amd as pk
+from probabilisticsemslam_amd import workloads as wl
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.int64)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
+    return env
+
+
+# ------------------------------------------------------------------------------------ bench.py, world 2
+@pytest.mark.parametrize("scaling,launcher", [("weak", "driver"), ("strong", "driver"), ("weak", "self")])
+def test_bench_world2_over_gloo_on_one_gpu(scaling, launcher):
+    """The deliverable's world > 1 branches -- rank-private slices of the seeded stream, the packed int8 slice per rank, ONE
+    overlapped all-gather per step, the cross-rank checks (same global table on every rank; a neighbour's slice is what its
+    matrices give), max-over-ranks timing, weak AND strong scaling -- with two ranks, both on GPU 0, the slices travelling through
+    gloo (RCCL refuses two ranks on one GPU).  Launched exactly as the driver does (`python -m torch.distributed.run ...`), and once
+    through bench.py's own launcher.  SURVEY 8(e)."""
+    port = _free_port()
+    args = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--scaling", scaling]
+    if launcher == "driver":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py")] + args
+        env = _clean_env(KBEST_BENCH_BACKEND="gloo")
+    else:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+        env = _clean_env(KBEST_BENCH_BACKEND="gloo", MASTER_PORT=str(port))
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    out = json.loads(lines[0])
+    per_rank = 1024 if scaling == "weak" else 512
+    assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["steps"] == 3 and out["warmup"] == 1
+    assert out["config"]["matrices_per_gpu"] == per_rank
+    assert out["parity_prune_vs_noprune"] is True
+    c = out["collective"]
+    assert c["backend"] == "gloo" and c["row4col_dtype"] == "int8"
+    assert c["bytes_per_rank_per_step"] == per_rank * 200 * (8 + 64) + per_rank * 4
+    assert c["bytes_inbound_per_rank_per_step"] == c["bytes_per_rank_per_step"]  # world - 1 = 1 slice comes in
+    assert c["exposed_ms"] is not None and c["ms_per_step_without_the_gather"] > 0
+    # whole-job value: both ranks' assignments over the slowest rank's time
+    assert abs(out["value"] - 2 * per_rank * 200 * 3 / (out["ms_per_step"] * 3e-3)) / out["value"] < 1e-9
+    assert out["problems_per_s"] > 0 and out["roofline"]["frac"] > 0.05
+    assert "cpu_baseline" not in out and "value_host_inclusive" not in out  # rank 0 at N = 1 only
+
+
+# ------------------------------------------------------------------------------------ the timed path, pinned
+def _dev_tables(eng, costs, N, M, k, tables_i8=False):
+    import torch
+    dev = torch.device("cuda", 0)
+    B = costs.shape[0]
+    tdt = torch.int8 if tables_i8 else torch.int32
+    d_cost = torch.from_numpy(np.ascontiguousarray(costs)).to(dev)
+    d_r = torch.full((B, k, M), -7, dtype=tdt, device=dev)
+    d_c = torch.full((B, k, N), -7, dtype=tdt, device=dev)
+    d_g = torch.full((B, k), float("nan"), dtype=torch.float64, device=dev)
+    d_n = torch.full((B,), -7, dtype=torch.int32, device=dev)
+    s = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    eng.kbest_dev(d_cost, B, N, M, k, d_r, d_c, d_g, d_n, stream=s.cuda_stream, tables_i8=tables_i8)
+    torch.cuda.synchronize()
+    return d_n.cpu().numpy(), d_r.cpu().numpy().astype(np.int32), d_c.cpu().numpy().astype(np.int32), d_g.cpu().numpy()
+
+
+@pytest.mark.parametrize("name,i8", [("c4", False), ("c3", False), ("c4", True)])
+def test_timed_relay_path_at_full_size_against_the_checker(name, i8):
+    """What bench.py times -- kbest_batch_f64_dev on the FULL batch of C4 (1 024 x 64x64) / C3 (4 096 x 32x32), k = 200, which the
+    launch plan runs as a relay (several workgroups per matrix in turn, the LDS handed on through HBM) -- against the checker on
+    EVERY matrix: nf, row4col, col4row (zero-padded columns mapped to -1) and the gains' bits.  Also with int8 tables (what the
+    multi-GPU step writes into its packed slice).  shortestPathCPP.cpp:571-644."""
+    eng = pk.KBestEngine(0)
+    costs, N, M, k = wl.dense_config(name)
+    before = eng.relay_launches()
+    nf, r4c, c4r, g = _dev_tables(eng, costs, N, M, k, tables_i8=i8)
+    assert eng.relay_launches() == before + 1, "the launch was not a relay: this test no longer pins the timed path"
+    onf, or4c, oc4r, og, _ = ol.orc_kbest_batch(costs, N, M, k)
+    assert (nf == onf).all()
+    assert (r4c == or4c).all()
+    assert (bits(g) == bits(og)).all()
+    a, b = c4r.copy(), np.asarray(oc4r).copy()
+    a[a >= M] = -1
+    b[b >= M] = -1
+    assert (a == b).all()
+    eng.close()
+
+
+# ------------------------------------------------------------------------------------ the multi-device entries' exchange
+def test_multi_entry_exchanges_bytes_not_words(engine, monkeypatch):
+    """Batch mode over logical devices: the slices that travel between the devices hold row4col as int8 (every index of a 64-row
+    problem fits a byte): 8 + M bytes per solution instead of 8 + 4 M; KBEST_MULTI_WIDE=1 is round 5's int32 exchange.  Same
+    tables either way, equal to the single-device entry's."""
+    B, N, M, k = 70, 64, 64, 200
+    costs = wl.dense_batch(B, N, M, 0x4D554D)
+    want = engine.kbest(costs, N, M, k)
+    sent = {}
+    for wide in (False, True):
+        if wide:
+            monkeypatch.setenv("KBEST_MULTI_WIDE", "1")
+        multi = pk.KBestMulti([0, 0, 0, 0])
+        got = multi.kbest(costs, N, M, k)
+        assert multi.tables_agree()
+        sent[wide], path = multi.exchange_bytes()
+        assert path == 0
+        multi.close()
+        assert (got[0] == want[0]).all() and (got[1] == want[1]).all() and (bits(got[3]) == bits(want[3])).all()
+        c = got[2].copy(); c[c >= M] = -1
+        w = want[2].copy(); w[w >= M] = -1
+        assert (c == w).all()
+    monkeypatch.delenv("KBEST_MULTI_WIDE")
+    pad = (B + 3) // 4
+    assert sent[False] == pad * k * 8 + pad * k * M + ((pad * 4 + 15) & ~15)
+    assert sent[True] > 3.5 * sent[False]
+    # rectangular / ragged problems (the path whose kernels write int32 tables: narrowed into the slice on the device)
+    rng = np.random.default_rng(8)
+    Br, Nr, Mr, kr = 41, 30, 12, 40
+    nRow = rng.integers(12, Nr + 1, Br).astype(np.int32)
+    nCol = np.minimum(rng.integers(1, Mr + 1, Br), nRow).astype(np.int32)
+    packed = np.zeros((Br, Nr * Mr))
+    for b in range(Br):
+        packed[b, : nRow[b] * nCol[b]] = rng.random(int(nRow[b]) * int(nCol[b]))
+    multi = pk.KBestMulti([0, 0, 0])
+    nf, r4c, c4r, g = multi.kbest(packed, Nr, Mr, kr, nRow=nRow, nCol=nCol)
+    assert multi.tables_agree()
+    multi.close()
+    for b in range(Br):
+        n, m = int(nRow[b]), int(nCol[b])
+        onf, or4c, _, og = ol.orc_kbest(packed[b, : n * m], n, m, kr)
+        assert nf[b] == onf and (r4c[b, :onf, :m] == or4c[:onf]).all() and (bits(g[b, :onf]) == bits(og[:onf])).all()
+        assert (r4c[b, onf:] == -1).all() and (r4c[b, :onf, m:] == -1).all()
+
+
+@pytest.mark.parametrize("G,S", [(1, 4), (2, 2), (3, 8), (4, 4), (8, 8)])
+def test_subtree_mode_gains_first(engine, monkeypatch, G, S):
+    """Subtree mode, the north star's exchange: ONE all-gather of every shard's top-k COSTS (gain[k] + nf), the merge into the global
+    k-best heap on every device, ONE sum all-reduce of the winners' rows -- against the whole-list exchange (KBEST_MULTI_WHOLE_LISTS),
+    the single-device entry and the checker.  Bytes: 8 k S' + k M per matrix instead of (8 + M) k S' (S' = shards per device)."""
+    B, N, M, k = 7, 48, 48, 120
+    costs = wl.dense_batch(B, N, M, 0x535543)
+    costs[3, : N] = np.inf  # an infeasible matrix (a column of +inf): nf = 0 on every shard (cpp:588-593)
+    onf, or4c, oc4r, og, _ = ol.orc_kbest_batch(costs, N, M, k)
+    assert onf[3] == 0
+    res = {}
+    for whole in (False, True):
+        if whole:
+            monkeypatch.setenv("KBEST_MULTI_WHOLE_LISTS", "1")
+        multi = pk.KBestMulti([0] * G)
+        got = multi.kbest(costs, N, M, k, subtree=True, n_shard=S)
+        assert multi.tables_agree()
+        sent, path = multi.exchange_bytes()
+        multi.close()
+        assert path == (2 if whole else 1)
+        res[whole] = (got, sent)
+        nf, r4c, c4r, g = got
+        assert (nf == onf).all()
+        for b in range(B):
+            n = int(onf[b])
+            assert (r4c[b, :n] == or4c[b, :n]).all() and (bits(g[b, :n]) == bits(og[b, :n])).all(), (whole, b)
+            assert (r4c[b, n:] == -1).all() and (g[b, n:] == 0).all(), (whole, b)
+    monkeypatch.delenv("KBEST_MULTI_WHOLE_LISTS")
+    spd = (S + G - 1) // G
+    up16 = lambda x: (x + 15) & ~15  # noqa: E731
+    assert res[False][1] == up16(spd * B * k * 8) + up16(spd * B * 4) + B * k * M
+    assert res[True][1] > res[False][1]
+
+
+def test_subtree_mode_exact_ties_take_the_whole_lists(engine):
+    """Integer costs: candidates with exactly the same gain.  The gains-only merge cannot order them (the rule is (gain, row4col
+    lexicographic)): the call notices -- every device merges the same gains -- and exchanges the whole lists, as round 5 did.  The
+    multiset of gains and the validity of every assignment are the checker's."""
+    rng = np.random.default_rng(17)
+    B, N, M, k = 5, 10, 10, 64
+    costs = np.floor(rng.random((B, N * M)) * 3)
+    multi = pk.KBestMulti([0, 0])
+    nf, r4c, c4r, g = multi.kbest(costs, N, M, k, subtree=True, n_shard=4)
+    assert multi.tables_agree()
+    sent, path = multi.exchange_bytes()
+    multi.close()
+    assert path == 2
+    onf, or4c, _, og, _ = ol.orc_kbest_batch(costs, N, M, k)
+    for b in range(B):
+        n = int(onf[b])
+        assert nf[b] == n
+        assert (np.sort(g[b, :n]) == np.sort(og[b, :n])).all()
+        assert len({tuple(x) for x in r4c[b, :n].tolist()}) == n
+        for s in range(n):
+            assert len(set(r4c[b, s])) == M and costs[b].reshape(M, N)[np.arange(M), r4c[b, s]].sum() == g[b, s]
+
+
+@pytest.mark.parametrize("S", [1, 2, 3, 8])
+def test_device_merge_of_gains_is_the_global_kbest(engine, S):
+    """kbest_merge_gains_f64_dev (C ABI; what one process per GPU calls between its all-gather of the costs and its all-reduce of
+    the rows): every shard's call scatters its own winners; the SUM of the S byte tables is the single enumeration's table = the
+    checker's; gains and counts come out whole from every call; integer costs set the tie word."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(60 + S)
+    for (N, M, k, B, ties, maximize) in ((16, 16, 50, 6, False, False), (40, 12, 120, 3, False, False), (10, 10, 64, 5, True, False),
+                                          (24, 24, 30, 4, False, True), (5, 5, 200, 3, False, False)):
+        costs = rng.random((B, N * M))
+        if ties:
+            costs = np.floor(costs * 3)
+        lists = [engine.kbest(costs, N, M, k, root_shard=(s, S), maximize=maximize, tables_i8=True) for s in range(S)]
+        tg = torch.from_numpy(np.stack([l[3] for l in lists])).to(dev)
+        tn = torch.from_numpy(np.stack([l[0] for l in lists])).to(dev)
+        total = torch.zeros((B, k, M), dtype=torch.int32, device=dev)
+        first = None
+        any_tied = 0
+        for s in range(S):
+            own = torch.from_numpy(np.ascontiguousarray(lists[s][1])).to(dev)
+            og = torch.full((B, k), float("nan"), dtype=torch.float64, device=dev)
+            orow = torch.zeros((B, k, M), dtype=torch.int8, device=dev)
+            on = torch.full((B,), -7, dtype=torch.int32, device=dev)
+            tied = torch.zeros(4, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            engine.merge_gains_dev(B, S, k, M, tg, tn, s, own, og, orow, on, tied, maximize=maximize)
+            torch.cuda.synchronize()
+            total += orow.to(torch.int32)
+            any_tied |= int(tied[0])
+            if first is None:
+                first = (og.cpu().numpy(), on.cpu().numpy())
+            else:  # gains and counts: the same from every shard's call
+                n0 = first[1]
+                assert (on.cpu().numpy() == n0).all()
+                for b in range(B):
+                    assert (bits(og.cpu().numpy()[b, : n0[b]]) == bits(first[0][b, : n0[b]])).all()
+        onf, or4c, _, ogain, _ = ol.orc_kbest_batch(costs, N, M, k, maximize=maximize)
+        assert (first[1] == onf).all()
+        if ties:
+            assert any_tied == 1  # (ties inside one shard's list are reported as well)
+            for b in range(B):
+                n = int(onf[b])
+                assert (np.sort(first[0][b, :n]) == np.sort(ogain[b, :n])).all()
+            continue
+        assert any_tied == 0
+        tot = total.cpu().numpy()
+        for b in range(B):
+            n = int(onf[b])
+            assert (bits(first[0][b, :n]) == bits(ogain[b, :n])).all() and (tot[b, :n] == or4c[b, :n]).all()
+            assert (tot[b, n:] == 0).all()
+
+
+def test_engine_in_a_process_group_world2_narrow_exchange(engine, tmp_path):
+    """The world-2 gloo group of round 5 with the round-6 exchange: batch mode with int8 slices, subtree mode gains first (the
+    engine's int8 tables go in as they are) -- every rank ends up with the single-rank engine's tables = the checker's."""
+    B, Bsub, world = 13, 3, 2
+    out = str(tmp_path / "dist6")
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = _clean_env(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                         KBEST_DIST_NARROW="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_engine_worker.py"), out, str(B), str(Bsub)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    cases = {"batch": wl.dense_config("c2", B=B), "sub": wl.dense_config("c2", B=Bsub),
+             "sub64": (wl.dense_config("c4", B=2)[0], 64, 64, 60)}
+    for tag, (costs, N, M, k) in cases.items():
+        nf, r4c, c4r, g = engine.kbest(costs, N, M, k)
+        for rank in range(world):
+            z = np.load(f"{out}.rank{rank}.npz")
+            assert (z[f"{tag}_nf"] == nf).all(), (tag, rank)
+            assert (z[f"{tag}_r"] == r4c).all(), (tag, rank)
+            assert (bits(z[f"{tag}_g"]) == bits(g)).all(), (tag, rank)
+            if tag != "batch":
+                assert str(z[f"{tag}_path"]) == "gains_first", (tag, rank)
