@@ -42,9 +42,11 @@
  * How it is done: every enumeration launch enumerates ONE solution more than asked for (its gain only; measured free) and is
  * followed by a small launch that brings runs of equal gains into the order above and reports, per problem, KBEST_TIE_* flags
  * (kbest_opts.tie_flags).  A tie at slot k (KBEST_TIE_BOUNDARY) is completed by the SYNCHRONOUS entries themselves: the
- * problem is enumerated again with k + KBEST_TIE_CAP solutions and the first k of the ordered table are kept
- * (KBEST_TIE_RESOLVED; a level with more than KBEST_TIE_CAP members beyond k stays KBEST_TIE_UNRESOLVED: the emitted set is
- * then one of several equally good ones and may depend on the kernel).  The asynchronous _dev entries only report the flags.
+ * problem is enumerated again with k + 64, then k + 256, then k + KBEST_TIE_CAP solutions until the level ends inside the table,
+ * and the first k of the ordered table are kept (KBEST_TIE_RESOLVED; a level with more than KBEST_TIE_CAP members beyond k -- or
+ * of more than 1 024 members in all -- stays KBEST_TIE_UNRESOLVED: the emitted set is then one of several equally good ones and
+ * may depend on the kernel; a re-run that fails leaves the first pass' tables and that flag).  The asynchronous _dev entries only
+ * report the flags; kbest_resolve_ties_dev completes their tables afterwards, and the multi-device batch entry does so by itself.
  * The exhaustive association kernel and the bounded walk see a whole gain level and keep its lexicographically first
  * members themselves, whatever its size.  KBEST_FLAG_NO_TIE_CHECK switches all of it off (the kernels' own orders, round 4).
  * Index outputs are int32 (the reference ABI uses ptrdiff_t; the C++ shims in
@@ -98,13 +100,17 @@ enum {
                                    /* KBEST_ERR_UNSUPPORTED.  Not with the multi-GPU entries: the caller's tables are int32 there  */
                                    /* (what travels BETWEEN the devices is in bytes by itself wherever the indices fit them).      */
 
-/* per-problem tie flags (kbest_opts.tie_flags / kbest_set_tie_flags; see "Order of exact ties" above) */
+/* per-problem tie flags (kbest_opts.tie_flags, kbest_set_assoc_tie_flags_dev, kbest_last_tie_flags; see "Order of exact ties" above) */
 #define KBEST_TIE_INSIDE 1            /* some of the emitted gains are exactly equal (they are in the canonical order)        */
 #define KBEST_TIE_BOUNDARY 2          /* the k-th and the (k+1)-th best gains are exactly equal: the k best are not unique    */
 #define KBEST_TIE_RESOLVED 4          /* ... and the entry completed that gain level: the lexicographically first were kept   */
+#define KBEST_TIE_UNCHECKED (1 << 28) /* k sits at the limit of the kernel the problem ran on (e.g. k = 1 024 on the fused          */
+                                      /* association kernel): the (k+1)-th solution was not enumerated, so a tie at slot k would  */
+                                      /* not have been seen (runs of equal gains INSIDE the tables are ordered as ever)           */
 #define KBEST_TIE_UNORDERED (1 << 29) /* a run of more than 1 024 equal gains was left in the kernel's own order               */
 #define KBEST_TIE_UNRESOLVED (1 << 30) /* BOUNDARY without RESOLVED: the emitted set is one of several equally good ones       */
-#define KBEST_TIE_CAP 64              /* members of the gain level at slot k beyond k that a synchronous entry enumerates      */
+#define KBEST_TIE_CAP 1024            /* members of the gain level at slot k beyond k that a synchronous entry enumerates at     */
+                                      /* most (it tries 64, then 256, then 1 024)                                               */
 
 typedef struct kbest_opts {
     int32_t  maximize;     /* reference `maximize` argument                       */
@@ -160,6 +166,17 @@ int kbest_batch_f64_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRo
                         const int32_t *d_nRow, const int32_t *d_nCol, const double *d_cost,
                         const int64_t *d_costOff, int k, int32_t *d_row4col, int32_t *d_col4row,
                         double *d_gain, int32_t *d_nf, int64_t *d_pushed, void *stream);
+/*
+ * The second call for callers of kbest_batch_f64_dev whose costs can tie exactly (integer-like costs): SYNCHRONOUS.  Same
+ * arguments as the launch it follows (same opts, shapes, cost blocks, tables -- all still on the device), d_tie_flags = the
+ * opts->tie_flags the launch wrote.  Waits for `stream`, and for every problem flagged KBEST_TIE_BOUNDARY completes the gain level
+ * at slot k as the synchronous entries do (the problem again with k + 64 / 256 / KBEST_TIE_CAP solutions), writes the first k of the
+ * canonically ordered table over the problem's slots of d_row4col / d_col4row / d_gain and updates its flag (KBEST_TIE_RESOLVED, or
+ * KBEST_TIE_UNRESOLVED where the level is larger than the cap).  A batch without flagged problems costs one small copy.
+ */
+int kbest_resolve_ties_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, int maxCol, const int32_t *d_nRow,
+                           const int32_t *d_nCol, const double *d_cost, const int64_t *d_costOff, int k, int32_t *d_row4col,
+                           int32_t *d_col4row, double *d_gain, int32_t *d_tie_flags, void *stream);
 
 /*
  * Same with host buffers (copies in, runs, copies out, synchronises; col4row may be NULL = not wanted).  Uniform square batches
@@ -291,7 +308,16 @@ int kbest_set_assoc_tie_flags_dev(kbest_ctx *ctx, int32_t *d_flags);
 int kbest_last_tie_flags(kbest_ctx *ctx, int32_t *flags, int cap);
 /* Diagnostic: launches of the 64-row kernel this context has made as a relay (several workgroups per matrix in turn; the
  * comment of kbest_reserve, NOTES.md 10.6) since it was created -- for tests that must know the path they exercise was taken. */
-long long kbest_relay_launches(kbest_ctx *ctx);
+long long kbest_relay_launches(kbest_ctx *ctx);  /* (-1: null context) */
+/* Diagnostic: the kernel(s) the context's last k-best launch (kbest_batch_f64[_dev] and whatever goes through them) was routed
+ * to -- KBEST_ROUTE_* bits -- for tests that must know the path they exercise was taken.  -1: null context. */
+#define KBEST_ROUTE_LANE 1    /* the lane-per-child kernel: <= 32 rows, dense batches                   */
+#define KBEST_ROUTE_SMALL 2   /* the small-problem kernel: <= 32 rows, rectangular / chip-underfilling  */
+#define KBEST_ROUTE_FAST 4    /* the 64-row kernel                                                      */
+#define KBEST_ROUTE_WIDE 8    /* the general-size kernel: any size, any k                               */
+#define KBEST_ROUTE_RELAY 16  /* ... as a relay of several workgroups per matrix                        */
+#define KBEST_ROUTE_EXTRA 32  /* the launch enumerated the solution behind the k-th (exact ties checked) */
+int kbest_last_route(kbest_ctx *ctx);
 
 /*
  * Batched computeQuadricCostMatrix (assignment.h:28-29, assignment.cpp:705-722).  Frame b has nL[b] landmarks and
@@ -410,9 +436,12 @@ int kbest_batch_f64_multi_ex(kbest_multi *m, const kbest_opts *opts, int mode, i
                              int32_t *col4row, double *gain, int32_t *nf);
 /* 1 when every device holds the same global table after the last kbest_batch_f64_multi[_ex] call, 0 when not (test aid). */
 int kbest_multi_tables_agree(kbest_multi *m);
-/* Bytes ONE device contributed to the exchanges of the last kbest_batch_f64_multi[_ex] call (the all-gather's send count, plus the
- * all-reduced table in subtree mode); *path (optional): 0 batch mode, 1 subtree mode gains first, 2 subtree mode whole lists. */
+/* Bytes that ARRIVE at one device in the exchanges of the last kbest_batch_f64_multi[_ex] call: an all-gather of b bytes per device
+ * brings (G - 1) b, the ring all-reduce of the n-byte table of subtree mode 2 n (G - 1) / G; *path (optional): 0 batch mode,
+ * 1 subtree mode gains first, 2 subtree mode whole lists. */
 long long kbest_multi_exchange_bytes(const kbest_multi *m, int *path);
+/* KBEST_TIE_* flags of the problems of the last kbest_batch_f64_multi call (batch mode): copies min(n, cap) flags, returns n. */
+int kbest_multi_last_tie_flags(kbest_multi *m, int32_t *flags, int cap);
 /*
  * Host timeline of the last kbest_batch_f64_multi[_ex] call: out[g * KBEST_MULTI_STAMPS + i], seconds since the call was
  * entered, for device g: [0] its worker thread started, [1] its first upload was issued, [2] its first kernel was issued,

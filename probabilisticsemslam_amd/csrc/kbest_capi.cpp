@@ -139,6 +139,7 @@ struct kbest_ctx {
     DevBufRaw relayBuf;       // relay launches of the 64-row kernel: [B] LDS images (kbest_engine.hip)
     DevBufRaw relayFlags;     // ... and three words per matrix: claimed / done / gone (zeroed when the buffer is made, put back to zero by every launch)
     long long relayLaunches = 0;  // relay launches made (kbest_relay_launches)
+    int lastRoute = 0;            // which kernel(s) the last k-best launch went to (kbest_last_route)
     int relay = -1;           // KBEST_RELAY: pieces per matrix (0 / 1: never; -1: choose per launch)
     int relayFirst = 0;       // KBEST_RELAY_FIRST: the first piece hands over at k * this / 1024 solutions (0: choose per launch shape)
     int relayStep = 0;        // KBEST_RELAY_STEP: the later pieces hand over this / 1024 of k apart (0: even steps up to k)
@@ -904,7 +905,18 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
     // operations (push counting, the unpruned run, the root-only entries) nor under root-subtree sharding (the merge orders ties).
     const bool tieMode = tie_mode(ctx, opts, extra != nullptr);
     const int kT = k;
-    if (tieMode) k = k + 1;
+    // The CALLER's k decides the kernel: where k sits exactly at a limit of the kernel that takes it (k = 4 x waves x 64 of the
+    // 64-row kernel's pool merge, SMALL_MAX_K, an LDS pool that is just full) the launch runs WITHOUT the extra solution -- same
+    // kernel, same speed as before ties were checked -- and its problems are flagged KBEST_TIE_UNCHECKED (a tie at slot k
+    // would not be seen; runs inside the tables are ordered as ever).
+    bool extraSol = tieMode;
+    if (tieMode) {
+        const bool fastA = k_fits_fast(ctx, LB, fastRow, kT, opts->flags, nullptr), fastB = k_fits_fast(ctx, LB, fastRow, kT + 1, opts->flags, nullptr);
+        const bool laneA = lane_fits(ctx, LB, maxRow, maxCol, kT, nullptr), laneB = lane_fits(ctx, LB, maxRow, maxCol, kT + 1, nullptr);
+        const bool smallA = small_fits(ctx, LB, maxRow, maxCol, kT, false, nullptr), smallB = small_fits(ctx, LB, maxRow, maxCol, kT + 1, false, nullptr);
+        if ((fastA && !fastB) || (laneA && !laneB) || (smallA && !smallB)) extraSol = false;
+    }
+    if (extraSol) k = k + 1;
     int32_t *d_tie = (tieMode && opts->tie_flags) ? opts->tie_flags + base : nullptr;
     Shape shape;
     const bool kFits = k_fits_fast(ctx, LB, fastRow, k, opts->flags, &shape);
@@ -921,7 +933,7 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
     }
     const Launched mark{ctx, sub ? ctx->stream : s};
     double *d_tieGain = nullptr;
-    if (tieMode) {
+    if (extraSol) {
         if ((size_t)LB * 8 > ctx->tieBuf.bytes) {
             if (!grow) return fail(ctx, KBEST_ERR_NOT_RESERVED, "tie work space too small: call kbest_reserve first");
             const int rc = raw_reserve(ctx, ctx->tieBuf, (size_t)LB * 8);
@@ -933,7 +945,7 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
     auto finish = [&]() -> int {
         if (!tieMode) return KBEST_OK;
         hipError_t e = kb::launch_finish_tables(d_nf, d_nRow, d_nCol, B, kT, maxCol, maxRow, d_row4col, d_col4row, d_gain, tabI8, d_tieGain, d_tie,
-                                                false, s);
+                                                false, s, extraSol ? 0 : KBEST_TIE_UNCHECKED);
         return e == hipSuccess ? KBEST_OK : fail(ctx, KBEST_ERR_HIP, "tie-order kernel launch", e);
     };
     // Problems of up to 32 rows: the small-problem kernel (half-wave workers, implicit zero columns).  The modes that
@@ -997,6 +1009,7 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         p.tieGain = d_tieGain;
         hipError_t e = kb::launch_kbest_lane(p, B, lsh.nWaves, lsh.lanes, s);
         if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "lane-per-child kbest kernel launch", e);
+        ctx->lastRoute = KBEST_ROUTE_LANE | (extraSol ? KBEST_ROUTE_EXTRA : 0);
         return finish();
     }
     int snw = 0;
@@ -1032,10 +1045,12 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         sp.tieGain = d_tieGain;
         hipError_t e = kb::launch_kbest_small(sp, B, snw, s);
         if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "small-problem kbest kernel launch", e);
+        ctx->lastRoute = KBEST_ROUTE_SMALL | (extraSol ? KBEST_ROUTE_EXTRA : 0);
         return finish();
     }
 
     if (sub && runWide) return fail(ctx, KBEST_ERR_INTERNAL, "a piece of a batch on the general-size kernel");
+    ctx->lastRoute = (runFast ? KBEST_ROUTE_FAST : 0) | (runWide ? KBEST_ROUTE_WIDE : 0) | (extraSol ? KBEST_ROUTE_EXTRA : 0);
     if (runFast) {
         // (a split launch merges per-share lists of k: it runs without the extra solution; the merge orders ties by the assignment)
         const int S = (sub || tieMode) ? 1 : split_factor(ctx, opts, B, maxRow, maxCol, k, d_nRow == nullptr && d_costOff == nullptr, extra == nullptr);
@@ -1139,6 +1154,7 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
                               : (ctx->relay >= 0 ? (1024 - p.relayFirst) / (relayP - 1)   // (a forced count: even steps, every piece hands over)
                                                  : (quarters ? 256 : (wide12 ? 384 : 256)));
                 ctx->relayLaunches++;
+                ctx->lastRoute |= KBEST_ROUTE_RELAY;
                 p.relayBuf = static_cast<unsigned char *>(ctx->relayBuf.p);
                 p.relayStride = (long long)relayImg;
                 p.relayFlag = static_cast<unsigned *>(ctx->relayFlags.p);
@@ -1623,9 +1639,9 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
     if (!ctx || !opts || B <= 0 || k < 1 || !tie_mode(ctx, opts, false))
         return kbest_batch_f64_keep(ctx, opts, B, maxRow, maxCol, nRow, nCol, cost, costOff, k, row4col, col4row, gain, nf, pushed, nullptr);
     // Exact ties (kbest_ties.h; "Order of exact ties" in kbest_c.h).  The launch reports per problem whether the k-th and the
-    // (k+1)-th best gains are equal; this synchronous entry then completes that gain level for those problems -- the same call
-    // again for them alone with k + KBEST_TIE_CAP solutions, whose table comes back in the canonical order -- and keeps the
-    // lexicographically first assignments of the level: the answer no longer depends on the kernel the batch was routed to.
+    // (k+1)-th best gains are equal; this synchronous entry then completes that gain level for those problems (kb_complete_tie_levels)
+    // and keeps the lexicographically first assignments of the level: the answer no longer depends on the kernel the batch was
+    // routed to.
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DevBuf dFlags;
     HIP_TRY(ctx, dFlags.alloc(ctx, (size_t)B * 4));
@@ -1635,13 +1651,41 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
     if (rc != KBEST_OK) return rc;
     std::vector<int32_t> fl((size_t)B);
     HIP_TRY(ctx, hipMemcpy(fl.data(), dFlags.as<int32_t>(), (size_t)B * 4, hipMemcpyDeviceToHost));
-    std::vector<int> idx;
+    if (!(opts->flags & KBEST_FLAG_NO_TIE_RESOLVE))
+        kb_complete_tie_levels(ctx, opts, B, maxRow, maxCol, nRow, nCol, cost, costOff, k, row4col, col4row, gain, fl.data(), nullptr);
     for (int b = 0; b < B; b++)
-        if (fl[b] & KBEST_TIE_BOUNDARY) idx.push_back(b);
-    if (!idx.empty() && !(opts->flags & KBEST_FLAG_NO_TIE_RESOLVE)) {
-        const int n = (int)idx.size(), k2 = k + KBEST_TIE_CAP;
-        const bool i8 = (opts->flags & KBEST_FLAG_TABLES_I8) != 0;
-        const size_t esz = i8 ? 1 : 4;
+        if ((fl[b] & KBEST_TIE_BOUNDARY) && !(fl[b] & KBEST_TIE_RESOLVED)) fl[b] |= KBEST_TIE_UNRESOLVED;
+    if (opts->tie_flags) memcpy(opts->tie_flags, fl.data(), (size_t)B * 4);
+    {
+        std::lock_guard<std::mutex> lock(ctx->tieMu);
+        ctx->lastTie.swap(fl);
+    }
+    return KBEST_OK;
+}
+
+}  // extern "C"
+
+// Completes the gain levels that straddle slot k (fl[b] & KBEST_TIE_BOUNDARY without KBEST_TIE_RESOLVED): those problems again,
+// alone, with k + 64, then k + 256, then k + KBEST_TIE_CAP solutions -- whichever kernel takes that k; the table comes back in the
+// canonical order -- until the level ends inside the table; the first k of the ordered table then replace the problem's slots in the
+// caller's HOST tables (row4col / col4row: int32, or int8 with KBEST_FLAG_TABLES_I8; col4row may be null) and the problem is flagged
+// KBEST_TIE_RESOLVED.  Nothing of a problem is touched before its re-run has validated; a re-run that fails (beyond a kernel's
+// limits, out of memory) or a level of more than KBEST_TIE_CAP members beyond k leaves the first pass' tables and the flags as they
+// are (the caller marks such a problem KBEST_TIE_UNRESOLVED).  changed (optional): the problems whose tables were replaced.
+// cost / costOff / nRow / nCol: as kbest_batch_f64's (host).
+void kb_complete_tie_levels(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, int maxCol, const int32_t *nRow, const int32_t *nCol,
+                            const double *cost, const int64_t *costOff, int k, void *row4col, void *col4row, double *gain, int32_t *fl,
+                            std::vector<int> *changed)
+{
+    static const int steps[3] = {64, 256, KBEST_TIE_CAP};
+    const bool i8 = (opts->flags & KBEST_FLAG_TABLES_I8) != 0;
+    const size_t esz = i8 ? 1 : 4;
+    for (int step = 0; step < 3; step++) {
+        std::vector<int> idx;
+        for (int b = 0; b < B; b++)
+            if ((fl[b] & KBEST_TIE_BOUNDARY) && !(fl[b] & KBEST_TIE_RESOLVED)) idx.push_back(b);
+        if (idx.empty()) return;
+        const int n = (int)idx.size(), k2 = k + steps[step];
         std::vector<int32_t> sRow(n), sCol(n), sNf(n);
         std::vector<int64_t> sOff(n);
         size_t tot = 0;
@@ -1659,34 +1703,94 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
         std::vector<char> sR((size_t)n * k2 * maxCol * esz), sC(col4row ? (size_t)n * k2 * maxRow * esz : 0);
         kbest_opts o2 = *opts;
         DevBuf dFlags2;
-        HIP_TRY(ctx, dFlags2.alloc(ctx, (size_t)n * 4));
+        if (dFlags2.alloc(ctx, (size_t)n * 4) != hipSuccess) return;
         o2.tie_flags = dFlags2.as<int32_t>();
-        rc = kbest_batch_f64_keep(ctx, &o2, n, maxRow, maxCol, sRow.data(), sCol.data(), sCost.data(), sOff.data(), k2,
-                                  reinterpret_cast<int32_t *>(sR.data()), col4row ? reinterpret_cast<int32_t *>(sC.data()) : nullptr, sGain.data(),
-                                  sNf.data(), nullptr, nullptr);
-        if (rc != KBEST_OK) return rc;
+        const int rc = kbest_batch_f64_keep(ctx, &o2, n, maxRow, maxCol, sRow.data(), sCol.data(), sCost.data(), sOff.data(), k2,
+                                            reinterpret_cast<int32_t *>(sR.data()), col4row ? reinterpret_cast<int32_t *>(sC.data()) : nullptr, sGain.data(),
+                                            sNf.data(), nullptr, nullptr);
+        if (rc != KBEST_OK) return;  // (the first pass' tables stand; the problems stay flagged)
         std::vector<int32_t> fl2((size_t)n);
-        HIP_TRY(ctx, hipMemcpy(fl2.data(), dFlags2.as<int32_t>(), (size_t)n * 4, hipMemcpyDeviceToHost));
+        if (hipMemcpy(fl2.data(), dFlags2.as<int32_t>(), (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return;
         for (int i = 0; i < n; i++) {
             const int b = idx[i];
             const double *g2 = sGain.data() + (size_t)i * k2;
             // the level is complete when the table goes on beyond it (or the problem has no more assignments) -- and the table is
             // in the canonical order throughout (a run of more than 1 024 equal gains is left as the kernel emitted it)
-            const bool complete = (sNf[i] < k2 || g2[k2 - 1] != g2[k - 1]) && !(fl2[i] & KBEST_TIE_UNORDERED);
-            if (sNf[i] < k) return fail(ctx, KBEST_ERR_INTERNAL, "kbest_batch_f64: the tie re-run found fewer solutions than the run before");
-            memcpy(reinterpret_cast<char *>(row4col) + (size_t)b * k * maxCol * esz, sR.data() + (size_t)i * k2 * maxCol * esz, (size_t)k * maxCol * esz);
+            const bool complete = sNf[i] >= k && (sNf[i] < k2 || g2[k2 - 1] != g2[k - 1]) && !(fl2[i] & KBEST_TIE_UNORDERED);
+            if (!complete) continue;
+            memcpy(static_cast<char *>(row4col) + (size_t)b * k * maxCol * esz, sR.data() + (size_t)i * k2 * maxCol * esz, (size_t)k * maxCol * esz);
             if (col4row)
-                memcpy(reinterpret_cast<char *>(col4row) + (size_t)b * k * maxRow * esz, sC.data() + (size_t)i * k2 * maxRow * esz, (size_t)k * maxRow * esz);
+                memcpy(static_cast<char *>(col4row) + (size_t)b * k * maxRow * esz, sC.data() + (size_t)i * k2 * maxRow * esz, (size_t)k * maxRow * esz);
             memcpy(gain + (size_t)b * k, g2, (size_t)k * 8);
-            fl[b] |= complete ? KBEST_TIE_RESOLVED : 0;
+            fl[b] |= KBEST_TIE_RESOLVED;
+            if (changed) changed->push_back(b);
         }
     }
+}
+
+extern "C" {
+
+// The asynchronous entries report a tie at slot k, they cannot complete it.  This SYNCHRONOUS helper does, for the tables of an
+// earlier kbest_batch_f64_dev call that are still on the device: it waits for `stream`, reads the flags, completes the flagged gain
+// levels (kb_complete_tie_levels: the flagged problems again with k + 64 / 256 / 1 024 solutions) and patches those problems' slots
+// of the device tables and flags in place.
+int kbest_resolve_ties_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, int maxCol, const int32_t *d_nRow,
+                           const int32_t *d_nCol, const double *d_cost, const int64_t *d_costOff, int k, int32_t *d_row4col,
+                           int32_t *d_col4row, double *d_gain, int32_t *d_tie_flags, void *stream)
+{
+    if (!ctx) return KBEST_ERR_BAD_ARG;
+    if (!opts || B < 0 || k < 1 || maxCol < 1 || maxRow < maxCol || !d_cost || !d_row4col || !d_gain || !d_tie_flags ||
+        (d_nRow == nullptr) != (d_nCol == nullptr) || (d_costOff && !d_nRow))
+        return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_resolve_ties_dev: bad argument");
+    if (B == 0) return KBEST_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(stream ? static_cast<hipStream_t>(stream) : ctx->stream));
+    std::vector<int32_t> fl((size_t)B);
+    HIP_TRY(ctx, hipMemcpy(fl.data(), d_tie_flags, (size_t)B * 4, hipMemcpyDeviceToHost));
+    std::vector<int> idx;
     for (int b = 0; b < B; b++)
-        if ((fl[b] & KBEST_TIE_BOUNDARY) && !(fl[b] & KBEST_TIE_RESOLVED)) fl[b] |= KBEST_TIE_UNRESOLVED;
-    if (opts->tie_flags) memcpy(opts->tie_flags, fl.data(), (size_t)B * 4);
-    {
-        std::lock_guard<std::mutex> lock(ctx->tieMu);
-        ctx->lastTie.swap(fl);
+        if ((fl[b] & KBEST_TIE_BOUNDARY) && !(fl[b] & KBEST_TIE_RESOLVED)) idx.push_back(b);
+    if (idx.empty()) return KBEST_OK;
+    // the flagged problems' cost blocks and table slots come to the host, are completed there, and go back
+    const int n = (int)idx.size();
+    const bool i8 = (opts->flags & KBEST_FLAG_TABLES_I8) != 0;
+    const size_t esz = i8 ? 1 : 4, per = (size_t)maxRow * maxCol;
+    std::vector<int32_t> hR, hC, sRow(n), sCol(n), sFl(n);
+    std::vector<int64_t> hOff, sOff(n);
+    if (d_nRow) {
+        hR.resize(B); hC.resize(B);
+        HIP_TRY(ctx, hipMemcpy(hR.data(), d_nRow, (size_t)B * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(hC.data(), d_nCol, (size_t)B * 4, hipMemcpyDeviceToHost));
+    }
+    if (d_costOff) {
+        hOff.resize(B);
+        HIP_TRY(ctx, hipMemcpy(hOff.data(), d_costOff, (size_t)B * 8, hipMemcpyDeviceToHost));
+    }
+    std::vector<double> sCost((size_t)n * per), sGain((size_t)n * k);
+    std::vector<char> sR((size_t)n * k * maxCol * esz), sC(d_col4row ? (size_t)n * k * maxRow * esz : 0);
+    for (int i = 0; i < n; i++) {
+        const int b = idx[i];
+        sRow[i] = d_nRow ? hR[b] : maxRow;
+        sCol[i] = d_nRow ? hC[b] : maxCol;
+        sOff[i] = (int64_t)i * (int64_t)per;
+        sFl[i] = fl[b];
+        const size_t src = d_costOff ? (size_t)hOff[b] : (size_t)b * per;
+        HIP_TRY(ctx, hipMemcpy(sCost.data() + (size_t)i * per, d_cost + src, (size_t)sRow[i] * sCol[i] * 8, hipMemcpyDeviceToHost));
+    }
+    std::vector<int> changed;
+    kb_complete_tie_levels(ctx, opts, n, maxRow, maxCol, sRow.data(), sCol.data(), sCost.data(), sOff.data(), k, sR.data(), d_col4row ? sC.data() : nullptr,
+                           sGain.data(), sFl.data(), &changed);
+    for (int i : changed) {
+        const int b = idx[i];
+        HIP_TRY(ctx, hipMemcpy(reinterpret_cast<char *>(d_row4col) + (size_t)b * k * maxCol * esz, sR.data() + (size_t)i * k * maxCol * esz, (size_t)k * maxCol * esz, hipMemcpyHostToDevice));
+        if (d_col4row)
+            HIP_TRY(ctx, hipMemcpy(reinterpret_cast<char *>(d_col4row) + (size_t)b * k * maxRow * esz, sC.data() + (size_t)i * k * maxRow * esz, (size_t)k * maxRow * esz, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(d_gain + (size_t)b * k, sGain.data() + (size_t)i * k, (size_t)k * 8, hipMemcpyHostToDevice));
+    }
+    for (int i = 0; i < n; i++) {
+        int32_t f = sFl[i];
+        if ((f & KBEST_TIE_BOUNDARY) && !(f & KBEST_TIE_RESOLVED)) f |= KBEST_TIE_UNRESOLVED;
+        HIP_TRY(ctx, hipMemcpy(d_tie_flags + idx[i], &f, 4, hipMemcpyHostToDevice));
     }
     return KBEST_OK;
 }
@@ -1949,9 +2053,11 @@ static int weights_small(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t
     // assignments themselves (KBEST_TIE_BOUNDARY | KBEST_TIE_RESOLVED)
     const bool tieOn = !ctx->noTie;
     const int kT = k;
-    if (tieOn) k = k + 1;
     const int capRow = rawMaxRow < kb::SMALL_MAX_DIM ? rawMaxRow : kb::SMALL_MAX_DIM;
     int nw = 0;
+    // (k at the kernel's limit: no solution behind the k-th, the frames' flags carry KBEST_TIE_UNCHECKED -- see batch_dev_impl)
+    const bool extraSol = tieOn && small_fits(ctx, B, capRow, maxCol, kT + 1, true, nullptr);
+    if (extraSol) k = k + 1;
     if (!small_fits(ctx, B, capRow, maxCol, k, true, &nw)) return 1;
     if (!condition && rawMaxRow > kb::SMALL_MAX_DIM) return 1;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
@@ -2020,6 +2126,7 @@ static int weights_small(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t
     sp.cutoff = 42.0;
     sp.nf = reinterpret_cast<int *>(dout + probBytes);
     sp.tieFlags = tieOn ? reinterpret_cast<int *>(dout + probBytes + nfBytes) : nullptr;
+    sp.tieBase = (tieOn && !extraSol) ? KBEST_TIE_UNCHECKED : 0;
     sp.states = ctx->states;
     sp.stateStride = kb::small_state_stride(capRow, maxCol);
     sp.statesPerProblem = kb::small_states_per_problem(k, nw, maxCol);
@@ -2137,9 +2244,12 @@ extern "C" int kbest_assoc_probs_batch_f64_dev(kbest_ctx *ctx, int B, int maxRaw
     // kbest_set_assoc_tie_flags_dev says (an asynchronous entry cannot complete a tied gain level: KBEST_TIE_BOUNDARY without
     // KBEST_TIE_RESOLVED tells the caller to re-run that frame through the host-pointer entry)
     const int kT = k;
-    if (!ctx->noTie) k = k + 1;
     const int capRow = maxRawRow < kb::SMALL_MAX_DIM ? maxRawRow : kb::SMALL_MAX_DIM;
     int nw = 0;
+    // (the caller's k against the limits: at k = 1 024, or where k + 1 no longer fits the LDS, the launch runs without the
+    //  solution behind the k-th and the frames' flags carry KBEST_TIE_UNCHECKED)
+    const bool extraSol = !ctx->noTie && maxCol <= kb::SMALL_MAX_DIM && small_fits(ctx, B, capRow, maxCol, kT + 1, true, nullptr);
+    if (extraSol) k = k + 1;
     if (maxCol > kb::SMALL_MAX_DIM || k > kb::SMALL_MAX_K || maxRawRow > kb::SMALL_MAX_RAW_ROWS ||
         (!condition && maxRawRow > kb::SMALL_MAX_DIM) || !small_fits(ctx, B, capRow, maxCol, k, true, &nw))
         return fail(ctx, KBEST_ERR_UNSUPPORTED, "kbest_assoc_probs_batch_f64_dev: frames beyond the fused association kernel "
@@ -2168,6 +2278,7 @@ extern "C" int kbest_assoc_probs_batch_f64_dev(kbest_ctx *ctx, int B, int maxRaw
     sp.k = k;
     sp.kTab = kT;
     sp.tieFlags = ctx->noTie ? nullptr : ctx->assocTieDev;
+    sp.tieBase = (!ctx->noTie && !extraSol) ? KBEST_TIE_UNCHECKED : 0;
     sp.useCutoff = 1;  // assignment.cpp:594
     sp.cutoff = 42.0;
     sp.nf = d_nf;
@@ -2207,9 +2318,10 @@ extern "C" int kbest_reserve_assoc(kbest_ctx *ctx, int B, int maxRawRow, int max
 {
     if (!ctx || B < 0 || maxCol < 1 || maxRawRow < maxCol || k < 1) return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_reserve_assoc: bad argument");
     if (B == 0) return KBEST_OK;
-    if (!ctx->noTie) k = k + 1;  // (what the enumeration kernel enumerates: exact ties, kbest_ties.h)
     const int capRow = maxRawRow < kb::SMALL_MAX_DIM ? maxRawRow : kb::SMALL_MAX_DIM;
     int nw = 0;
+    // (what the enumeration kernel enumerates: one more than k where that fits -- exact ties, kbest_ties.h)
+    if (!ctx->noTie && maxCol <= kb::SMALL_MAX_DIM && small_fits(ctx, B, capRow, maxCol, k + 1, true, nullptr)) k = k + 1;
     if (maxCol > kb::SMALL_MAX_DIM || !small_fits(ctx, B, capRow, maxCol, k, true, &nw))
         return fail(ctx, KBEST_ERR_UNSUPPORTED, "kbest_reserve_assoc: frames beyond the fused association kernel");
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
@@ -2277,13 +2389,16 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
         } else if (rc == 1) {
             goto general;  // (the fused kernel takes none of this batch's shapes)
         }
-        {
+        // (64, then 256, then KBEST_TIE_CAP solutions beyond k: until the level ends inside the table)
+        for (int extra : {64, 256, KBEST_TIE_CAP}) {
             std::vector<int> tied;
             for (int b = 0; b < B; b++)
-                if ((tfl[b] & KBEST_TIE_BOUNDARY) && !(tfl[b] & (KBEST_TIE_RESOLVED | KBEST_TIE_UNRESOLVED))) tied.push_back(b);
-            if (!tied.empty()) {
-                const int rc2 = rerun(tied, KBEST_TIE_CAP);
-                if (rc2 != KBEST_OK) return rc2;
+                if ((tfl[b] & KBEST_TIE_BOUNDARY) && !(tfl[b] & KBEST_TIE_RESOLVED) && (extra == 64 ? !(tfl[b] & KBEST_TIE_UNRESOLVED) : true)) tied.push_back(b);
+            if (tied.empty()) break;
+            const int rc2 = rerun(tied, extra);
+            if (rc2 != KBEST_OK) {
+                if (extra == 64) return rc2;
+                break;  // (a larger re-run that fails leaves the answer of the one before: the frames stay KBEST_TIE_UNRESOLVED)
             }
         }
         if (tie) memcpy(tie, tfl.data(), (size_t)B * 4);
@@ -2473,14 +2588,25 @@ general:
             for (int b = 0; b < B; b++)
                 if (tfl[b] & KBEST_TIE_BOUNDARY) tied.push_back(b);
             if (!tied.empty() && !quad) {
-                const int Bs = (int)tied.size();
-                std::vector<int32_t> sL(Bs), sM(Bs), sNf(Bs), sT(Bs, 0);
-                std::vector<int64_t> sCo(Bs), sPo(Bs);
-                for (int i = 0; i < Bs; i++) { sL[i] = nL[tied[i]]; sM[i] = nM[tied[i]]; sCo[i] = costOff[tied[i]]; sPo[i] = probOff[tied[i]]; }
-                const int rc2 = weights_pipeline(ctx, Bs, sL.data(), sM.data(), cost, sCo.data(), k, probs, sPo.data(), sNf.data(), condition,
-                                                 nullptr, bruteForce, false, sT.data(), KBEST_TIE_CAP);
-                if (rc2 != KBEST_OK) return rc2;
-                for (int i = 0; i < Bs; i++) tfl[tied[i]] = sT[i];
+                for (int extra : {64, 256, KBEST_TIE_CAP}) {
+                    const int Bs = (int)tied.size();
+                    std::vector<int32_t> sL(Bs), sM(Bs), sNf(Bs), sT(Bs, 0);
+                    std::vector<int64_t> sCo(Bs), sPo(Bs);
+                    for (int i = 0; i < Bs; i++) { sL[i] = nL[tied[i]]; sM[i] = nM[tied[i]]; sCo[i] = costOff[tied[i]]; sPo[i] = probOff[tied[i]]; }
+                    const int rc2 = weights_pipeline(ctx, Bs, sL.data(), sM.data(), cost, sCo.data(), k, probs, sPo.data(), sNf.data(), condition,
+                                                     nullptr, bruteForce, false, sT.data(), extra);
+                    if (rc2 != KBEST_OK) {
+                        if (extra == 64) return rc2;
+                        break;
+                    }
+                    std::vector<int> still;
+                    for (int i = 0; i < Bs; i++) {
+                        tfl[tied[i]] = sT[i];
+                        if ((sT[i] & KBEST_TIE_BOUNDARY) && !(sT[i] & KBEST_TIE_RESOLVED)) still.push_back(tied[i]);
+                    }
+                    tied.swap(still);
+                    if (tied.empty()) break;
+                }
             } else {
                 for (int b : tied) tfl[b] |= KBEST_TIE_UNRESOLVED;
             }
@@ -2505,9 +2631,16 @@ static int weights_entry(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t
 
 long long kbest_relay_launches(kbest_ctx *ctx)
 {
-    if (!ctx) return KBEST_ERR_BAD_ARG;
+    if (!ctx) return -1;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     return ctx->relayLaunches;
+}
+
+int kbest_last_route(kbest_ctx *ctx)
+{
+    if (!ctx) return -1;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    return ctx->lastRoute;
 }
 
 int kbest_last_tie_flags(kbest_ctx *ctx, int32_t *flags, int cap)

@@ -340,6 +340,7 @@ struct SmallParams {
     int kTab;                 // exact ties (kbest_ties.h), as in Params (the weights are those of the first kTab solutions)
     double *tieGain;
     int *tieFlags;            // fused association launches (no tables for the finishing kernel to look at): [B] KBEST_TIE_* or nullptr
+    int tieBase;              // ... what a frame's flags start from (KBEST_TIE_UNCHECKED when k sits at the kernel's limit: no solution behind the k-th)
 };
 
 __host__ __device__ inline long long small_state_stride(int maxRow, int maxCol)
@@ -493,7 +494,8 @@ hipError_t launch_fill_unused(const int *nf, const int *nRow, const int *nCol, i
 // KBEST_TIE_* flags from tieGain (the gain of the solution behind the tables; nullptr: none was enumerated) into tieFlags (or
 // nullptr), and -- fill -- the unused slots / the padding of a ragged batch as launch_fill_unused defines them.
 hipError_t launch_finish_tables(const int *nf, const int *nRow, const int *nCol, int B, int k, int ldCol, int ldRow, int *row4col,
-                                int *col4row, double *gain, bool tablesI8, const double *tieGain, int *tieFlags, bool fill, hipStream_t stream);
+                                int *col4row, double *gain, bool tablesI8, const double *tieGain, int *tieFlags, bool fill, hipStream_t stream,
+                                int baseFlags = 0);  // baseFlags: or-ed into every problem's flags (KBEST_TIE_UNCHECKED)
 hipError_t launch_kbest_lane(const Params &p, int B, int nWaves, int lanesPerChild, hipStream_t stream);
 hipError_t launch_kbest_small(const SmallParams &p, int B, int nWaves, hipStream_t stream);
 // kbest_tiny.hip: the fused association path by exhaustive enumeration, for frames whose assignments are few (condition + gate +
@@ -516,6 +518,13 @@ hipError_t launch_to_probs(double *x, long long n, hipStream_t stream);
 
 }  // namespace kb
 
+// kbest_capi.cpp: completes the gain levels that straddle slot k in the caller's HOST tables (see there)
+#ifdef __cplusplus
+#include <vector>
+void kb_complete_tie_levels(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, int maxCol, const int32_t *nRow, const int32_t *nCol,
+                            const double *cost, const int64_t *costOff, int k, void *row4col, void *col4row, double *gain, int32_t *fl,
+                            std::vector<int> *changed);
+#endif
 int kbest_batch_f64_keep(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, int maxCol, const int32_t *nRow,
                          const int32_t *nCol, const double *cost, const int64_t *costOff, int k, int32_t *row4col,
                          int32_t *col4row, double *gain, int32_t *nf, int64_t *pushed, const kb::KeepTables *keep);

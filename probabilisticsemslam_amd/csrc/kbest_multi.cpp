@@ -103,6 +103,8 @@ struct Dev {
     unsigned char *heads = nullptr;   // subtree mode: every device's (gain | nf) of its shards, gathered
     signed char *mRow8 = nullptr;     // ... the winners' rows at their merged positions (own ones, then all: the sum all-reduce)
     int *tied = nullptr;              // ... one word: two candidates of some matrix have exactly the same gain
+    int32_t *tieFl = nullptr;         // batch mode: KBEST_TIE_* of this device's problems
+    size_t tieFlB = 0;
     size_t costB = 0, shapeB = 0, c4rB = 0, packedB = 0, mGainB = 0, mR4CB = 0, mNfB = 0, headsB = 0, mRow8B = 0, tiedB = 0;
 };
 
@@ -177,7 +179,8 @@ struct kbest_multi {
     // shape of the last call (for kbest_multi_tables_agree)
     int lastB = 0, lastK = 0, lastCol = 0, lastMode = 0;
     size_t lastBytes = 0;  // bytes of the packed global table
-    size_t lastSent = 0;   // bytes one device contributed to the exchanges of the last call (kbest_multi_exchange_bytes)
+    size_t lastSent = 0;   // bytes that arrived at one device in the exchanges of the last call (kbest_multi_exchange_bytes)
+    std::vector<int32_t> lastTie;  // batch mode: KBEST_TIE_* per problem of the last call (kbest_multi_last_tie_flags)
     int lastPath = 0;      // subtree mode: 1 = gains first (all-gather of the costs + sum all-reduce of the winners' rows), 2 = whole lists
 };
 
@@ -269,7 +272,7 @@ template <class T> int grow(kbest_multi *, Dev &d, T *&p, size_t &have, size_t n
 template <class Send, class Recv> int gather_bytes(kbest_multi *m, size_t bytes, Send send, Recv recv)
 {
     const int G = (int)m->dev.size();
-    m->lastSent += bytes;
+    m->lastSent += (size_t)(G - 1) * bytes;  // what arrives at one device
     if (m->local) {
         // logical devices on one GPU: every device's contribution is copied into every other device's buffer, stream-ordered behind
         // the producer's kernels (event); what orders the copies in front of the NEXT call's writes is the end of this call --
@@ -322,7 +325,7 @@ int gather_packed(kbest_multi *m, size_t perDev)
 int allreduce_rows(kbest_multi *m, size_t n)
 {
     const int G = (int)m->dev.size();
-    m->lastSent += n;
+    m->lastSent += 2 * n * (size_t)(G - 1) / (size_t)G;  // what a ring all-reduce moves into one device: reduce-scatter + all-gather
     if (m->local) {
         for (int g = 0; g < G; g++) {
             Dev &d = m->dev[g];
@@ -412,7 +415,7 @@ int kbest_destroy_multi(kbest_multi *m)
         if (d.stream) (void)hipStreamSynchronize(d.stream);
         if (d.comm && m->rccl.CommDestroy) (void)m->rccl.CommDestroy(d.comm);
         for (void *p : {(void *)d.cost, (void *)d.shape, (void *)d.c4r, (void *)d.packed, (void *)d.mGain, (void *)d.mR4C, (void *)d.mNf, (void *)d.r8, (void *)d.r32, (void *)d.heads,
-                        (void *)d.mRow8, (void *)d.tied})
+                        (void *)d.mRow8, (void *)d.tied, (void *)d.tieFl})
             if (p) (void)hipFree(p);
         if (d.stream) (void)hipStreamDestroy(d.stream);
         if (d.ev) (void)hipEventDestroy(d.ev);
@@ -449,6 +452,7 @@ int kbest_batch_f64_multi_ex(kbest_multi *m, const kbest_opts *opts, int mode, i
     m->t0 = kb::now_s();
     m->lastSent = 0;
     m->lastPath = 0;
+    m->lastTie.clear();
     for (auto &d : m->dev) {
         d.issued = false;
         d.rc = KBEST_OK;
@@ -482,6 +486,7 @@ int kbest_batch_f64_multi_ex(kbest_multi *m, const kbest_opts *opts, int mode, i
         const int pad = (B + G - 1) / G;  // matrices per device (the last devices may hold fewer): equal all-gather counts
         const Slice sl((size_t)pad, k, maxCol, esz);
         m->lastB = B; m->lastK = k; m->lastCol = maxCol; m->lastMode = mode; m->lastBytes = (size_t)G * sl.bytes;
+        m->lastTie.assign((size_t)B, 0);
         // 1. every device, in its own thread: its block of cost matrices in, its slice of the global table solved in place and
         //    copied back into the caller's tables -- the single-device host path (kbest_batch_f64: pieces whose uploads,
         //    kernels and copies back overlap), with the tables staged in the device's slice, where they stay for the exchange
@@ -505,18 +510,49 @@ int kbest_batch_f64_multi_ex(kbest_multi *m, const kbest_opts *opts, int mode, i
                 W_HIP(d, hipStreamSynchronize(d.stream));
             }
             if (nb == 0) { d.t[1] = d.t[2] = d.t[3] = kb::now_s() - m->t0; return; }
+            W_TRY(d, grow(m, d, d.tieFl, d.tieFlB, (size_t)pad * 4));
+            W_HIP(d, hipMemsetAsync(d.tieFl, 0, (size_t)pad * 4, d.stream));
+            W_HIP(d, hipStreamSynchronize(d.stream));  // (the pieces of the host path run on streams of the context's own)
+            kbest_opts ot = *opts;
+            ot.tie_flags = d.tieFl;
             double stamps[2] = {0.0, 0.0};
             const kb::KeepTables keep{esz == 1 ? d.r32 : reinterpret_cast<int32_t *>(mine + sl.offR4C), col4row ? d.c4r : nullptr,
                                       reinterpret_cast<double *>(mine + sl.offGain), reinterpret_cast<int32_t *>(mine + sl.offNf), stamps,
                                       esz == 1 ? reinterpret_cast<signed char *>(mine + sl.offR4C) : d.r8, esz == 1 ? 1 : 0};
-            const int rc = kbest_batch_f64_keep(d.ctx, opts, nb, maxRow, maxCol, nRow ? nRow + b0 : nullptr, nCol ? nCol + b0 : nullptr,
+            const int rc = kbest_batch_f64_keep(d.ctx, &ot, nb, maxRow, maxCol, nRow ? nRow + b0 : nullptr, nCol ? nCol + b0 : nullptr,
                                                 cost + (size_t)b0 * per, nullptr, k, row4col + (size_t)b0 * k * maxCol,
                                                 col4row ? col4row + (size_t)b0 * k * maxRow : nullptr, gain + (size_t)b0 * k, nf + b0,
                                                 nullptr, &keep);
             d.t[1] = stamps[0] - m->t0;
             d.t[2] = stamps[1] - m->t0;
+            if (rc != KBEST_OK) { d.t[3] = kb::now_s() - m->t0; wfail(d, rc, kbest_last_error(d.ctx)); return; }
+            // exact ties (kbest_c.h): a gain level that straddles slot k is completed as the synchronous single-device entry does -- in
+            // the caller's tables, and in this device's slice of the global table before it travels
+            int32_t *fl = m->lastTie.data() + b0;
+            W_HIP(d, hipMemcpy(fl, d.tieFl, (size_t)nb * 4, hipMemcpyDeviceToHost));
+            bool any = false;
+            for (int i = 0; i < nb; i++) any = any || (fl[i] & KBEST_TIE_BOUNDARY);
+            if (any && !(opts->flags & KBEST_FLAG_NO_TIE_RESOLVE)) {
+                std::vector<int> changed;
+                kb_complete_tie_levels(d.ctx, opts, nb, maxRow, maxCol, nRow ? nRow + b0 : nullptr, nCol ? nCol + b0 : nullptr, cost + (size_t)b0 * per,
+                                       nullptr, k, row4col + (size_t)b0 * k * maxCol, col4row ? col4row + (size_t)b0 * k * maxRow : nullptr,
+                                       gain + (size_t)b0 * k, fl, &changed);
+                std::vector<signed char> r8((size_t)k * maxCol);
+                for (int i : changed) {
+                    const int32_t *src = row4col + ((size_t)b0 + i) * k * maxCol;
+                    unsigned char *dst = mine + sl.offR4C + (size_t)i * k * maxCol * esz;
+                    if (esz == 1) {
+                        for (size_t j = 0; j < r8.size(); j++) r8[j] = (signed char)src[j];
+                        W_HIP(d, hipMemcpy(dst, r8.data(), r8.size(), hipMemcpyHostToDevice));
+                    } else {
+                        W_HIP(d, hipMemcpy(dst, src, (size_t)k * maxCol * 4, hipMemcpyHostToDevice));
+                    }
+                    W_HIP(d, hipMemcpy(mine + sl.offGain + (size_t)i * k * 8, gain + ((size_t)b0 + i) * k, (size_t)k * 8, hipMemcpyHostToDevice));
+                }
+            }
+            for (int i = 0; i < nb; i++)
+                if ((fl[i] & KBEST_TIE_BOUNDARY) && !(fl[i] & KBEST_TIE_RESOLVED)) fl[i] |= KBEST_TIE_UNRESOLVED;
             d.t[3] = kb::now_s() - m->t0;
-            if (rc != KBEST_OK) wfail(d, rc, kbest_last_error(d.ctx));
         }));
         // 2. the one exchange: ONE all-gather of the packed (gain[k], row4col[k*M], nf) slices; every device then
         //    holds the global table (the host has its results already: each device's own slice came back in step 1)
@@ -716,6 +752,14 @@ int kbest_batch_f64_multi(kbest_multi *m, const kbest_opts *opts, int B, int max
                           int32_t *nf)
 {
     return kbest_batch_f64_multi_ex(m, opts, KBEST_MULTI_BATCH, 0, B, maxRow, maxCol, nRow, nCol, cost, k, row4col, col4row, gain, nf);
+}
+
+int kbest_multi_last_tie_flags(kbest_multi *m, int32_t *flags, int cap)
+{
+    if (!m || (cap > 0 && !flags)) return KBEST_ERR_BAD_ARG;
+    const int n = (int)m->lastTie.size();
+    for (int i = 0; i < n && i < cap; i++) flags[i] = m->lastTie[i];
+    return n;
 }
 
 long long kbest_multi_exchange_bytes(const kbest_multi *m, int *path)

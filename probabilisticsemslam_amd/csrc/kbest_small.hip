@@ -563,7 +563,7 @@ kbest_small_kernel(SmallParams p)
     if (p.onlyUnfit && p.nf[b] != -2) return;
     if (tid == 0) {
         if (p.tieGain) p.tieGain[b] = __longlong_as_double(0x7ff8000000000000LL);  // no solution behind the tables (yet)
-        if (p.tieFlags) p.tieFlags[b] = 0;
+        if (p.tieFlags) p.tieFlags[b] = p.tieBase;
     }
     // ---- shapes ---------------------------------------------------------------------------------------------
     if (M == 0 || NR == 0) {  // an empty frame (getAssignmentProbs returns an empty result, assignment.cpp:50-51)
@@ -1161,7 +1161,7 @@ kbest_small_kernel(SmallParams p)
     const int nf = E > p.kTab ? p.kTab : E;
     if (E > p.kTab && tid == 0) {
         if (p.tieGain) p.tieGain[b] = EG[p.kTab];
-        if (p.tieFlags && EG[p.kTab] == EG[p.kTab - 1]) p.tieFlags[b] = KBEST_TIE_BOUNDARY;
+        if (p.tieFlags && EG[p.kTab] == EG[p.kTab - 1]) p.tieFlags[b] = p.tieBase | KBEST_TIE_BOUNDARY;
     }
 
     // ---- phase 3: outputs ------------------------------------------------------------------------------------------

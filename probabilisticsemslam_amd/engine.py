@@ -18,8 +18,9 @@ KBEST_FLAG_NO_TIE_CHECK = 512
 KBEST_FLAG_NO_TIE_RESOLVE = 1024
 # per-problem tie flags (kbest_c.h, "Order of exact ties")
 KBEST_TIE_INSIDE, KBEST_TIE_BOUNDARY, KBEST_TIE_RESOLVED = 1, 2, 4
-KBEST_TIE_UNORDERED, KBEST_TIE_UNRESOLVED = 1 << 29, 1 << 30
-KBEST_TIE_CAP = 64
+KBEST_TIE_UNCHECKED, KBEST_TIE_UNORDERED, KBEST_TIE_UNRESOLVED = 1 << 28, 1 << 29, 1 << 30
+KBEST_ROUTE_LANE, KBEST_ROUTE_SMALL, KBEST_ROUTE_FAST, KBEST_ROUTE_WIDE, KBEST_ROUTE_RELAY, KBEST_ROUTE_EXTRA = 1, 2, 4, 8, 16, 32
+KBEST_TIE_CAP = 1024
 KBEST_MAX_DIM = 64        # rows handled by the LDS-resident kernel
 KBEST_MAX_DIM_WIDE = 1024  # rows handled at all (general-size kernel beyond KBEST_MAX_DIM)
 
@@ -35,6 +36,7 @@ C_ABI_SYMBOLS = (
     "kbest_multi_tables_agree", "kbest_batch_f64_multi_ex", "kbest_merge_topk_f64_dev", "kbest_register_host_buffer",
     "kbest_unregister_host_buffer", "kbest_multi_timeline", "kbest_last_tie_flags", "kbest_set_assoc_tie_flags_dev",
     "kbest_relay_launches", "kbest_merge_topk_i8_f64_dev", "kbest_merge_gains_f64_dev", "kbest_multi_exchange_bytes",
+    "kbest_last_route", "kbest_resolve_ties_dev", "kbest_multi_last_tie_flags",
 )
 KBEST_MULTI_STAMPS = 6
 KBEST_MULTI_BATCH, KBEST_MULTI_SUBTREE = 0, 1
@@ -119,6 +121,11 @@ def load_library():
     if hasattr(lib, "kbest_relay_launches"):
         lib.kbest_relay_launches.argtypes = [vp]
         lib.kbest_relay_launches.restype = C.c_longlong
+    if hasattr(lib, "kbest_last_route"):
+        lib.kbest_last_route.argtypes = [vp]
+        lib.kbest_resolve_ties_dev.argtypes = [vp, C.POINTER(KBestOpts), C.c_int, C.c_int, C.c_int, i32p, i32p, dp, i64p, C.c_int, i32p, i32p, dp,
+                                               i32p, vp]
+        lib.kbest_multi_last_tie_flags.argtypes = [vp, i32p, C.c_int]
     if hasattr(lib, "kbest_last_tie_flags"):
         lib.kbest_last_tie_flags.argtypes = [vp, i32p, C.c_int]
         lib.kbest_set_assoc_tie_flags_dev.argtypes = [vp, vp]
@@ -245,6 +252,10 @@ class KBestEngine:
         """Launches of the 64-row kernel this context has made as a relay (diagnostic, kbest_relay_launches)."""
         return int(self.lib.kbest_relay_launches(self.ctx))
 
+    def last_route(self):
+        """KBEST_ROUTE_* bits of the kernel(s) this context's last k-best launch went to (diagnostic, kbest_last_route)."""
+        return int(self.lib.kbest_last_route(self.ctx))
+
     def last_tie_flags(self):
         """KBEST_TIE_* flags of the problems of this context's last synchronous call (kbest_last_tie_flags)."""
         n = self.lib.kbest_last_tie_flags(self.ctx, None, 0)
@@ -359,6 +370,18 @@ class KBestEngine:
                                                  dp(d_pushed), C.c_void_p(stream) if stream else None))
 
 
+    def resolve_ties_dev(self, d_cost, B, N, M, k, d_row4col, d_col4row, d_gain, d_tie_flags, maximize=False, cutoff=None, stream=None,
+                         d_nRow=None, d_nCol=None, d_costOff=None, tables_i8=False):
+        """kbest_resolve_ties_dev: the synchronous second call behind kbest_dev -- completes the gain levels that straddle slot k
+        in the device tables (same arguments as the launch)."""
+        o = self._opts(maximize, cutoff, KBEST_FLAG_TABLES_I8 if tables_i8 else 0)
+
+        def dp(t):
+            return None if t is None else C.c_void_p(t.data_ptr())
+        self._check(self.lib.kbest_resolve_ties_dev(self.ctx, C.byref(o), B, N, M, dp(d_nRow), dp(d_nCol), dp(d_cost), dp(d_costOff), k,
+                                                    dp(d_row4col), dp(d_col4row), dp(d_gain), dp(d_tie_flags),
+                                                    C.c_void_p(stream) if stream else None))
+
     def merge_topk_dev(self, B, n_shard, k, M, d_gain, d_row4col, d_nf, shard_stride_bytes, d_out_gain, d_out_row4col, d_out_nf,
                        maximize=False, stream=None, tables_i8=False):
         """kbest_merge_topk_f64_dev (tables_i8: kbest_merge_topk_i8_f64_dev -- the shards' row4col tables are int8): k-way merge
@@ -441,8 +464,16 @@ class KBestMulti:
     def tables_agree(self):
         return self.lib.kbest_multi_tables_agree(self.m) == 1
 
+    def last_tie_flags(self):
+        """KBEST_TIE_* flags of the problems of the last batch-mode call (kbest_multi_last_tie_flags)."""
+        n = self.lib.kbest_multi_last_tie_flags(self.m, None, 0)
+        out = np.zeros(max(n, 0), np.int32)
+        if n > 0:
+            self.lib.kbest_multi_last_tie_flags(self.m, _ptr(out), n)
+        return out
+
     def exchange_bytes(self):
-        """(bytes one device contributed to the exchanges of the last call, path: 0 batch, 1 subtree gains first, 2 subtree whole lists)."""
+        """(bytes that arrived at one device in the exchanges of the last call, path: 0 batch, 1 subtree gains first, 2 subtree whole lists)."""
         path = C.c_int(0)
         n = self.lib.kbest_multi_exchange_bytes(self.m, C.byref(path))
         return int(n), int(path.value)

@@ -137,7 +137,7 @@ def test_multi_entry_exchanges_bytes_not_words(engine, monkeypatch):
         assert (c == w).all()
     monkeypatch.delenv("KBEST_MULTI_WIDE")
     pad = (B + 3) // 4
-    assert sent[False] == pad * k * 8 + pad * k * M + ((pad * 4 + 15) & ~15)
+    assert sent[False] == 3 * (pad * k * 8 + pad * k * M + ((pad * 4 + 15) & ~15))  # three other devices' slices arrive
     assert sent[True] > 3.5 * sent[False]
     # rectangular / ragged problems (the path whose kernels write int32 tables: narrowed into the slice on the device)
     rng = np.random.default_rng(8)
@@ -162,7 +162,8 @@ def test_multi_entry_exchanges_bytes_not_words(engine, monkeypatch):
 def test_subtree_mode_gains_first(engine, monkeypatch, G, S):
     """Subtree mode, the north star's exchange: ONE all-gather of every shard's top-k COSTS (gain[k] + nf), the merge into the global
     k-best heap on every device, ONE sum all-reduce of the winners' rows -- against the whole-list exchange (KBEST_MULTI_WHOLE_LISTS),
-    the single-device entry and the checker.  Bytes: 8 k S' + k M per matrix instead of (8 + M) k S' (S' = shards per device)."""
+    the single-device entry and the checker.  Bytes arriving at a device per matrix: 8 k S' (G - 1) + 2 k M (G - 1) / G instead of
+    (8 + M) k S' (G - 1) (S' = shards per device)."""
     B, N, M, k = 7, 48, 48, 120
     costs = wl.dense_batch(B, N, M, 0x535543)
     costs[3, : N] = np.inf  # an infeasible matrix (a column of +inf): nf = 0 on every shard (cpp:588-593)
@@ -188,8 +189,11 @@ def test_subtree_mode_gains_first(engine, monkeypatch, G, S):
     monkeypatch.delenv("KBEST_MULTI_WHOLE_LISTS")
     spd = (S + G - 1) // G
     up16 = lambda x: (x + 15) & ~15  # noqa: E731
-    assert res[False][1] == up16(spd * B * k * 8) + up16(spd * B * 4) + B * k * M
-    assert res[True][1] > res[False][1]
+    head = up16(spd * B * k * 8) + up16(spd * B * 4)
+    assert res[False][1] == (G - 1) * head + 2 * B * k * M * (G - 1) // G
+    assert res[True][1] == (G - 1) * (head + up16(spd * B * k * M))
+    if G >= 3:
+        assert res[True][1] > 1.5 * res[False][1]
 
 
 def test_subtree_mode_exact_ties_take_the_whole_lists(engine):
@@ -301,3 +305,193 @@ def test_engine_in_a_process_group_world2_narrow_exchange(engine, tmp_path):
             assert (bits(z[f"{tag}_g"]) == bits(g)).all(), (tag, rank)
             if tag != "batch":
                 assert str(z[f"{tag}_path"]) == "gains_first", (tag, rank)
+
+
+# ------------------------------------------------------------------------------------ exact ties beyond 64, k at a kernel's limit
+def engine_with(monkeypatch, **env):
+    for key, val in env.items():
+        monkeypatch.setenv(key, str(val))
+    eng = pk.KBestEngine(0)
+    for key in env:
+        monkeypatch.delenv(key)
+    return eng
+
+
+TIE_ROUTES = [{}, {"KBEST_NO_LANE": 1, "KBEST_NO_SMALL": 1}, {"KBEST_FORCE_SMALL": 1}, {"KBEST_FORCE_LANE": 1}, {"KBEST_FORCE_WIDE": 1}]
+
+
+@pytest.mark.parametrize("shape", [(7, 7, 15, 3), (8, 8, 20, 4), (9, 9, 40, 5), (12, 6, 25, 4)])
+def test_tie_levels_of_more_than_64_members_are_completed_on_every_route(monkeypatch, shape):
+    """Round 6: a synchronous entry completes a gain level that straddles slot k in steps -- k + 64, k + 256, k + 1 024 solutions --
+    so levels of hundreds of members (integer costs from a small range) now come back as the ONE answer on every route: the
+    checker's canonical k best, bit for bit; levels beyond the cap (or of more than 1 024 members) stay flagged.  The cases must
+    contain levels that round 5's single step of 64 left open.  shortestPathCPP.cpp:30-42, 574."""
+    N, M, k, hi = shape
+    rng = np.random.default_rng(31 * N + k)
+    B = 10
+    costs = rng.integers(0, hi, size=(B, N * M)).astype(np.float64)
+    want = [ol.canonical_kbest(costs[b], N, M, k) for b in range(B)]
+    want64 = [ol.canonical_kbest(costs[b], N, M, k, cap=64) for b in range(B)]
+    newly = sum(1 for w, w64 in zip(want, want64) if w[4] and not w64[4])
+    assert newly > 0, "no level between 64 and 1 024 members beyond k in this case"
+    first = None
+    for knobs in TIE_ROUTES:
+        eng = engine_with(monkeypatch, **knobs)
+        nf, r4c, c4r, g, fl = eng.kbest(costs, N, M, k, tie_flags=True)
+        for b in range(B):
+            wn, wr, wg, boundary, resolved = want[b]
+            assert nf[b] == wn and (bits(g[b, :wn]) == bits(wg)).all(), (knobs, b)
+            assert bool(fl[b] & pk.engine.KBEST_TIE_BOUNDARY) == boundary, (knobs, b, fl[b])
+            if boundary and not resolved:
+                assert fl[b] & pk.engine.KBEST_TIE_UNRESOLVED, (knobs, b)
+                continue
+            assert not (fl[b] & pk.engine.KBEST_TIE_UNRESOLVED) and bool(fl[b] & pk.engine.KBEST_TIE_RESOLVED) == boundary, (knobs, b, fl[b])
+            assert (r4c[b, :wn] == wr).all(), (knobs, b)
+        if first is None:
+            first = (r4c.copy(), g.copy(), fl.copy())
+        else:
+            ok = (first[2] & pk.engine.KBEST_TIE_UNRESOLVED) == 0
+            assert (first[0][ok] == r4c[ok]).all() and (bits(first[1][ok]) == bits(g[ok])).all() and (first[2][ok] == fl[ok]).all(), knobs
+
+
+def test_resolve_ties_dev_completes_the_device_tables(engine):
+    """kbest_resolve_ties_dev: the second call behind the asynchronous entry.  Integer costs through kbest_batch_f64_dev leave
+    KBEST_TIE_BOUNDARY flags; the helper completes those levels in the DEVICE tables: afterwards they equal the synchronous
+    entry's (= the checker's canonical k best) and the flags say RESOLVED / UNRESOLVED.  Also through a multi-device batch call."""
+    import torch
+    dev = torch.device("cuda", 0)
+    E = pk.engine
+    rng = np.random.default_rng(99)
+    for (N, M, k, hi, B, i8) in ((8, 8, 20, 4, 40, False), (16, 16, 50, 30, 300, False), (40, 40, 60, 200, 24, True), (12, 7, 30, 25, 30, False)):
+        costs = rng.integers(0, hi, size=(B, N * M)).astype(np.float64)
+        want = engine.kbest(costs, N, M, k, tie_flags=True, tables_i8=i8)
+        tdt = torch.int8 if i8 else torch.int32
+        d_cost = torch.from_numpy(costs).to(dev)
+        d_r = torch.empty((B, k, M), dtype=tdt, device=dev)
+        d_c = torch.empty((B, k, N), dtype=tdt, device=dev)
+        d_g = torch.empty((B, k), dtype=torch.float64, device=dev)
+        d_n = torch.empty(B, dtype=torch.int32, device=dev)
+        d_f = torch.zeros(B, dtype=torch.int32, device=dev)
+        s = torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize()
+        engine.kbest_dev(d_cost, B, N, M, k, d_r, d_c, d_g, d_n, stream=s.cuda_stream, d_tie_flags=d_f, tables_i8=i8)
+        torch.cuda.synchronize()
+        f0 = d_f.cpu().numpy()
+        assert ((f0 & E.KBEST_TIE_BOUNDARY) != 0).sum() > 0 and ((f0 & (E.KBEST_TIE_RESOLVED | E.KBEST_TIE_UNRESOLVED)) == 0).all()
+        engine.resolve_ties_dev(d_cost, B, N, M, k, d_r, d_c, d_g, d_f, stream=s.cuda_stream, tables_i8=i8)
+        torch.cuda.synchronize()
+        f1 = d_f.cpu().numpy()
+        assert (f1 == want[4]).all()
+        ok = (f1 & E.KBEST_TIE_UNRESOLVED) == 0
+        assert ok.sum() > 0
+        assert (d_r.cpu().numpy()[ok] == want[1][ok]).all() and (bits(d_g.cpu().numpy()[ok]) == bits(want[3][ok])).all()
+        cg, cw = d_c.cpu().numpy()[ok].astype(np.int32), want[2][ok].astype(np.int32)
+        cg[cg >= M] = -1
+        cw[cw >= M] = -1
+        assert (cg == cw).all()
+    # the multi-device batch entry completes tied levels by itself: in the caller's tables AND in the devices' slices
+    N, M, k, hi, B = 10, 10, 30, 4, 50
+    costs = rng.integers(0, hi, size=(B, N * M)).astype(np.float64)
+    want = engine.kbest(costs, N, M, k, tie_flags=True)
+    multi = pk.KBestMulti([0, 0, 0])
+    got = multi.kbest(costs, N, M, k)
+    assert multi.tables_agree()
+    fl = multi.last_tie_flags()
+    multi.close()
+    assert (fl == want[4]).all() and ((fl & E.KBEST_TIE_RESOLVED) != 0).sum() > 0
+    ok = (fl & E.KBEST_TIE_UNRESOLVED) == 0
+    assert (got[0] == want[0]).all() and (got[1][ok] == want[1][ok]).all() and (bits(got[3][ok]) == bits(want[3][ok])).all()
+
+
+def _route(eng, costs, N, M, k, **kw):
+    out = eng.kbest(costs, N, M, k, tie_flags=True, **kw)
+    return out, eng.last_route()
+
+
+def test_k_at_a_kernel_limit_keeps_its_kernel(monkeypatch):
+    """with exact ties checked a launch enumerates k + 1 solutions, which moved every k limit down by one.  Now the
+    caller's k decides: at the largest k a kernel takes the launch runs on THAT kernel without the extra solution and its problems
+    carry KBEST_TIE_UNCHECKED; one below, the extra solution is enumerated.  Results: the checker's, bit for bit."""
+    E = pk.engine
+    rng = np.random.default_rng(4)
+    cases = [("fast", E.KBEST_ROUTE_FAST, dict(KBEST_NO_LANE=1, KBEST_NO_SMALL=1), 40, 40, 2),
+             ("small", E.KBEST_ROUTE_SMALL, dict(), 30, 10, 3),
+             ("lane", E.KBEST_ROUTE_LANE, dict(KBEST_FORCE_LANE=1), 12, 12, 5)]
+    for name, bit, knobs, N, M, B in cases:
+        eng = engine_with(monkeypatch, **knobs)
+        costs = rng.random((B, N * M))
+        # the largest k this kernel takes for the shape: bisection on the route (monotone in k)
+        lo, hi = 8, 8192
+        assert _route(eng, costs, N, M, lo)[1] & bit, name
+        while hi - lo > 1:
+            mid = (lo + hi) // 2
+            if _route(eng, costs, N, M, mid)[1] & bit:
+                lo = mid
+            else:
+                hi = mid
+        kmax = lo
+        assert 64 <= kmax < 8192, (name, kmax)
+        (nf, r4c, c4r, g, fl), route = _route(eng, costs, N, M, kmax)
+        assert route & bit and not (route & E.KBEST_ROUTE_EXTRA), (name, kmax, route)
+        assert (fl & E.KBEST_TIE_UNCHECKED).all(), (name, kmax)
+        onf, or4c, _, og, _ = ol.orc_kbest_batch(costs, N, M, kmax)
+        assert (nf == onf).all()
+        for b in range(B):
+            n = int(onf[b])
+            assert (r4c[b, :n] == or4c[b, :n]).all() and (bits(g[b, :n]) == bits(og[b, :n])).all(), (name, b)
+        (nf2, r2, c2, g2, fl2), route2 = _route(eng, costs, N, M, kmax - 1)
+        assert route2 & bit and route2 & E.KBEST_ROUTE_EXTRA and not (fl2 & E.KBEST_TIE_UNCHECKED).any(), (name, kmax - 1, route2)
+        (nf3, r3, c3, g3, fl3), route3 = _route(eng, costs, N, M, kmax + 1)   # beyond: another kernel, still the checker's answer
+        assert not (route3 & bit)
+        n3 = np.minimum(nf, nf3)
+        for b in range(B):
+            assert (r3[b, : n3[b]] == r4c[b, : n3[b]]).all() and (bits(g3[b, : n3[b]]) == bits(g[b, : n3[b]])).all()
+
+
+def test_fused_association_entry_takes_k_1024():
+    """kbest_assoc_probs_batch_f64_dev promises k <= 1 024 (kbest_c.h); round 5 refused k = 1 024 because it enumerated k + 1.
+    KITTI-like frames at k = 1 024 and 1 023 through the fused enumeration kernel (bounded walk off) and through the default
+    route: the checker's probabilities (assignment.cpp:547-683), rel 1e-12."""
+    import torch
+    dev = torch.device("cuda", 0)
+    F, nL, nM = 24, 20, 10
+    nR = nL + nM
+    frames = wl.kitti_like_frames(F, nL=nL, nM=nM)
+    raw = np.ascontiguousarray(np.concatenate(frames))
+    d_cost = torch.from_numpy(raw).to(dev)
+    d_nL = torch.full((F,), nL, dtype=torch.int32, device=dev)
+    d_nM = torch.full((F,), nM, dtype=torch.int32, device=dev)
+    d_nRow = torch.full((F,), nR, dtype=torch.int32, device=dev)
+    d_coff = torch.arange(F, dtype=torch.int64, device=dev) * (nR * nM)
+    d_poff = torch.arange(F, dtype=torch.int64, device=dev) * (nM * (nL + 1))
+    for k in (1024, 1023):
+        want = []
+        for f in frames:
+            cond, idx = ol.condition_costs(f, nR, nM)
+            cl = len(idx) - nM
+            q, _ = ol.assignment_prob(cond, cl, nM, k)
+            full = np.zeros((nM, nL + 1))
+            full[:, np.asarray(idx[:cl], dtype=np.int64)] = q[:, :cl]
+            full[:, nL] = q[:, cl]
+            want.append(full)
+        for knobs in ({"KBEST_NO_BNB": "1"}, {}):
+            for key, val in knobs.items():
+                os.environ[key] = val
+            eng = pk.KBestEngine(0)
+            for key in knobs:
+                del os.environ[key]
+            d_probs = torch.zeros(F * nM * (nL + 1), dtype=torch.float64, device=dev)
+            d_nf = torch.zeros(F, dtype=torch.int32, device=dev)
+            d_fl = torch.zeros(F, dtype=torch.int32, device=dev)
+            eng.reserve_assoc(F, nR, nM, k)
+            eng.set_assoc_tie_flags_dev(d_fl)
+            torch.cuda.synchronize()
+            eng.assoc_probs_dev(F, nR, nM, d_nL, d_nM, d_nRow, d_cost, d_coff, k, d_probs, d_poff, d_nf, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert (d_nf.cpu().numpy() >= 0).all(), (k, knobs)
+            p = d_probs.cpu().numpy().reshape(F, nM, nL + 1)
+            for i in range(F):
+                np.testing.assert_allclose(p[i], want[i], rtol=1e-12, atol=1e-300, err_msg=str((k, knobs, i)))
+            if knobs and k == 1024:  # the fused enumeration kernel at its limit: no solution behind the k-th
+                assert (d_fl.cpu().numpy() & pk.engine.KBEST_TIE_UNCHECKED).all()
+            eng.close()
