@@ -320,7 +320,7 @@ def engine_with(monkeypatch, **env):
 TIE_ROUTES = [{}, {"KBEST_NO_LANE": 1, "KBEST_NO_SMALL": 1}, {"KBEST_FORCE_SMALL": 1}, {"KBEST_FORCE_LANE": 1}, {"KBEST_FORCE_WIDE": 1}]
 
 
-@pytest.mark.parametrize("shape", [(7, 7, 15, 3), (8, 8, 20, 4), (9, 9, 40, 5), (12, 6, 25, 4)])
+@pytest.mark.parametrize("shape", [(12, 12, 60, 8), (8, 8, 20, 4), (9, 9, 40, 5), (12, 6, 25, 4), (10, 8, 30, 5)])
 def test_tie_levels_of_more_than_64_members_are_completed_on_every_route(monkeypatch, shape):
     """Round 6: a synchronous entry completes a gain level that straddles slot k in steps -- k + 64, k + 256, k + 1 024 solutions --
     so levels of hundreds of members (integer costs from a small range) now come back as the ONE answer on every route: the
