@@ -58,6 +58,9 @@ constexpr int BN_BUCKETS = 512;
 #define KB_BNB_AIM 1.5   // a bound that counted fewer than k is raised to where this many k are expected,
 #define KB_BNB_FMAX 2.0  // by this factor at most
 #endif
+#ifndef KB_BNB_FMAX_LONE
+#define KB_BNB_FMAX_LONE 3.0  // ... for a frame by itself (1 024 threads, bisection instead of lowering: one frame per call 78 -> 75 us; 4.0: the same)
+#endif
 #ifndef KB_BNB_FILLK
 #define KB_BNB_FILLK 1000.0  // ... and no more than this many k (no gain from limiting it: measured 2.5, 4)
 #endif
@@ -68,6 +71,18 @@ constexpr int BN_BUCKETS = 512;
 #ifndef KB_BNB_START
 #define KB_BNB_START 1.0  // the first bound, in greedy gains
 #endif
+#ifndef KB_BNB_KEEP
+#define KB_BNB_KEEP 1  // 1: the counting passes keep what they count (gain, rows) while it fits the candidate list; the pass that finds k
+#endif                 // below its bound then only drops what lies beyond the k-th gain's bucket; where the list did not hold them all,
+                       // the LAST level alone is walked again over the frontier that pass left -- no collecting walk either way
+                       // (round 6, 1 000 frames: 0.213 -> 0.191 ms, one frame per call 90 -> 80 us)
+#ifndef KB_BNB_CH
+#define KB_BNB_CH 1    // 1: a counting pass that may lower its bound histograms its children's lower bounds AS IT WALKS a level (the
+#endif                 // two halves of the leaf histogram, level by level): an overflowing level is walked twice, not three times
+                       // (round 6: 0.191 -> 0.165 ms; the launch lasts as long as its slowest frame, and those are the lowered ones)
+#ifndef KB_BNB_AGG
+#define KB_BNB_AGG 0   // 1: a wave appends its children with ONE LDS atomic (the lanes that reach the append in the same step):
+#endif                 // measured 2 % SLOWER (0.213 -> 0.217 ms) -- the per-child atomics are not what a level costs
 
 struct BEntry {  // a partial assignment: rows of the columns 0 .. level-1 (one byte each), the set of those rows, their sum
     u64 rowsLo, rowsHi, used;
@@ -96,6 +111,21 @@ __device__ __forceinline__ void set_row(u64 &lo, u64 &hi, int c, int r)
     const u64 m = 0xffull << (8 * (c & 7)), v = (u64)r << (8 * (c & 7));
     if (c < 8) lo = (lo & ~m) | v;
     else hi = (hi & ~m) | v;
+}
+
+// the next `n = 1` slots of an LDS counter for every lane that is active here: one atomic per wave (KB_BNB_AGG) or one per lane
+__device__ __forceinline__ int bn_append(int *counter)
+{
+#if KB_BNB_AGG
+    const u64 act = __ballot(1);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == __builtin_ctzll(act)) base = atomicAdd(counter, __popcll(act));
+    base = __builtin_amdgcn_readfirstlane(base);
+    return base + __popcll(act & ((1ull << lane) - 1ull));
+#else
+    return atomicAdd(counter, 1);
+#endif
 }
 
 }  // namespace
@@ -365,24 +395,27 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
     // A counting pass (mode 0) whose frontier outgrows the lists at some level does not give up: it histograms the lower bounds
     // of that level's children, lowers the bound to the largest that still fits a list and goes on from there -- what it
     // counts in the end is exact for the bound it RETURNS.
-    auto walk = [&](double U, const int mode, const double base) -> double {  // (base: a bound known to fit the lists; < 0: no lowering)
+    // from: 0, or M - 1 -- the LAST level alone, over the frontier the previous (complete) walk left in its list: what that walk
+    // counted below its bound, collected below a tighter one, for the price of one level
+    auto walk = [&](double U, const int mode, const double base, const int from = 0) -> double {  // (base: a bound known to fit the lists; < 0: no lowering)
         double scale = (double)BN_BUCKETS / (U > 0.0 ? U : 1.0);
         double Uprune = U * (1.0 + 1e-12);
         int tight = 0;
         double mn = INF;
         int cnt = 0;
         if (tid == 0) {
-            listA[0].rowsLo = 0ull; listA[0].rowsHi = 0ull; listA[0].used = 0ull; listA[0].acc = 0.0;
+            if (from == 0) { listA[0].rowsLo = 0ull; listA[0].rowsHi = 0ull; listA[0].used = 0ull; listA[0].acc = 0.0; }
             ctl->count = 0;
             ctl->abort = 0;
             ctl->nodes = 0;
+            if (KB_BNB_KEEP) ctl->listN = 0;
         }
-        if (tid <= M) lvlN[tid] = tid == 0 ? 1 : 0;
+        if (from == 0 && tid <= M) lvlN[tid] = tid == 0 ? 1 : 0;
         if (mode == 0)
             for (int i = tid; i < BN_BUCKETS; i += NT) hist[i] = 0u;
         __syncthreads();
-        BEntry *A = listA, *B = listB;
-        for (int level = 0; level < M; level++) {
+        BEntry *A = (from & 1) ? listB : listA, *B = (from & 1) ? listA : listB;
+        for (int level = from; level < M; level++) {
             const int nA = lvlN[level];
             if (nA == 0) break;
             const bool last = level == M - 1;
@@ -395,8 +428,23 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
             // 2^sh threads share a frontier entry's feasible rows (as many as keep the workgroup busy; no division)
             int sh = 0;
             while (sh < 5 && (nA << (sh + 1)) <= NT && (1 << sh) < nf_) sh++;
-            bool histo = false, stop = false;  // (alike in every thread)
+            bool stop = false;  // (alike in every thread)
+#if !KB_BNB_CH
+            bool histo = false;
+#endif
+#if KB_BNB_CH
+            // the children's lower bounds, histogrammed over (base, U] while the level is walked: half (level & 1) of `hist` (the leaf
+            // histogram: only the LAST level needs it), 256 buckets; the other half is cleared for the next level meanwhile
+            constexpr int CHB = BN_BUCKETS / 2;
+            const bool useCH = mode == 0 && base >= 0.0 && !last;
+            u32 *hc = hist + (level & 1) * CHB;
+#endif
             for (;;) {
+#if KB_BNB_CH
+            const double cscale = (double)CHB / (U - base);
+            if (useCH)  // (dead since the barrier that ended level - 1; before the last level both halves are zero again)
+                for (int i = tid; i < CHB; i += NT) hist[((level + 1) & 1) * CHB + i] = 0u;
+#endif
             for (int e = tid >> sh; e < nA; e += NT >> sh)
             for (int j = tid & ((1 << sh) - 1); j < nf_; j += 1 << sh) {
                 const int r = fr[j];
@@ -412,12 +460,20 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
                     for (int l2 = level + 1; l2 < M; l2++) lb = lb + ((used2 & zBit[l2]) ? c1[l2] : c0[l2]);
                 }
                 if (!(lb <= Uprune)) continue;
+#if KB_BNB_CH
+                if (useCH) {
+                    int bk = lb <= base ? 0 : (int)((lb - base) * cscale);
+                    bk = bk > CHB - 1 ? CHB - 1 : bk;
+                    atomicAdd(&hc[bk], 1u);
+                }
+#else
                 if (histo) {  // (buckets over (base, U]: what is within base is known to fit)
                     int bk = lb <= base ? 0 : (int)((lb - base) * ((double)BN_BUCKETS / (U - base)));
                     bk = bk > BN_BUCKETS - 1 ? BN_BUCKETS - 1 : bk;
                     atomicAdd(&hist[bk], 1u);
                     continue;
                 }
+#endif
                 u64 lo = A[e].rowsLo, hi = A[e].rowsHi;
                 set_row(lo, hi, col, r);
                 if (last) {
@@ -430,16 +486,60 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
                         int bk = (int)(a * scale);
                         bk = bk > BN_BUCKETS - 1 ? BN_BUCKETS - 1 : bk;
                         atomicAdd(&hist[bk], 1u);
-                    } else {
-                        const int pos = atomicAdd(&ctl->listN, 1);
+                    }
+                    if (mode != 0 || KB_BNB_KEEP) {  // (the last level reads the OTHER list: this one is free for the candidates)
+                        const int pos = bn_append(&ctl->listN);
                         if (pos < CAP) { candG[pos] = a; candLo[pos] = lo; candHi[pos] = hi; }
                     }
                 } else {
-                    const int pos = atomicAdd(&lvlN[level + 1], 1);
+                    const int pos = bn_append(&lvlN[level + 1]);
                     if (pos < FCAP) { B[pos].rowsLo = lo; B[pos].rowsHi = hi; B[pos].used = used | (1ull << r); B[pos].acc = a; }
                 }
             }
             __syncthreads();
+#if KB_BNB_CH
+            if (!last && lvlN[level + 1] > FCAP) {
+                if (!useCH || tight >= 8) { stop = true; break; }
+                // the last bucket up to which the children still fit a list: its upper edge is the new bound
+                if (wave == 0) {
+                    constexpr int PER = CHB / 64;
+                    u32 mine = 0;
+                    for (int i = 0; i < PER; i++) mine += hc[lane * PER + i];
+                    u32 incl = mine;
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const u32 t = (u32)__shfl_up((int)incl, d);
+                        if (lane >= d) incl += t;
+                    }
+                    u32 run = incl - mine;
+                    const u32 fillTo = (u32)(FCAP * KB_BNB_FILL / 16) < (u32)(KB_BNB_FILLK * k) ? (u32)(FCAP * KB_BNB_FILL / 16) : (u32)(KB_BNB_FILLK * k);
+                    int fit = 0;  // buckets of this lane's share that still fit
+                    for (int i = 0; i < PER; i++) {
+                        run += hc[lane * PER + i];
+                        if (run <= fillTo) fit = i + 1;
+                    }
+                    const u64 full = __ballot(fit == PER);
+                    const int firstShort = full == ~0ull ? 64 : __ffsll((long long)~full) - 1;
+                    const int nb = firstShort * PER + __shfl(fit, firstShort < 64 ? firstShort : 63);
+                    if (lane == 0) ctl->limit = firstShort == 64 ? U : base + (double)nb * ((U - base) / (double)CHB);
+                }
+                __syncthreads();
+                const double nu = ctl->limit;
+                for (int i = tid; i < CHB; i += NT) hc[i] = 0u;
+                if (tid == 0) lvlN[level + 1] = 0;
+                __syncthreads();
+                if (!(nu > base) || !(nu < U)) { stop = true; break; }  // (one bucket alone overfills the list)
+                U = nu;
+                scale = (double)BN_BUCKETS / U;
+                Uprune = U * (1.0 + 1e-12);
+                tight++;
+                continue;  // (this level again, under the new bound)
+            }
+            if (useCH && level == M - 2) {  // the last level counts into the whole histogram: this level's half goes back to zero
+                for (int i = tid; i < CHB; i += NT) hc[i] = 0u;
+                __syncthreads();
+            }
+            break;
+#else
             if (histo) {
                 // the last bucket up to which the children still fit a list: its upper edge is the new bound
                 if (wave == 0) {
@@ -482,6 +582,7 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
                 continue;
             }
             break;
+#endif
             }
             if (stop) {
                 if (tid == 0) ctl->abort = 1;
@@ -530,7 +631,8 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
         if (lowered && !(U - Ulo > 1e-7 * U)) break;  // (the largest bound that fits the lists has fewer than k below it)
         // the number of assignments below a bound grows like a power of it: the exponent from the last two passes that counted
         // (4 without them), the next bound aimed at 1.5 k assignments, a factor between 1.05 and 2
-        double f = KB_BNB_FMAX;
+        const double fmax = NT >= 1024 ? KB_BNB_FMAX_LONE : KB_BNB_FMAX;
+        double f = fmax;
         if (count > 0) {
             double pw = 4.0;
             if (cPrev > 0 && count > cPrev && U > uPrev) {
@@ -538,7 +640,7 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
                 pw = pw < 2.0 ? 2.0 : (pw > 12.0 ? 12.0 : pw);
             }
             f = exp(log(KB_BNB_AIM * (double)k / (double)count) / pw);
-            f = f < 1.05 ? 1.05 : (f > KB_BNB_FMAX ? KB_BNB_FMAX : f);
+            f = f < 1.05 ? 1.05 : (f > fmax ? fmax : f);
             cPrev = count;
             uPrev = U;
         }
@@ -594,7 +696,36 @@ __global__ void __launch_bounds__(NT) kbest_bnb_kernel(SmallParams p)
         double E = (bStar < BN_BUCKETS - 1) ? (double)(bStar + 1) * (U / (double)BN_BUCKETS) * (1.0 + 1e-12) : U;
         if (E > U) E = U;
         if (cutG < E) E = cutG;  // (what lies beyond the cutoff is never emitted: cpp:709-719)
-        walk(E, 1, -1.0);
+        if (KB_BNB_KEEP && count <= CAP) {
+            // The pass that found k assignments below its bound kept every one of them (count <= CAP: none was dropped): what the
+            // collecting walk would bring -- the assignments with gain <= E -- is a subset of the list.  Compacted in place: the kept
+            // entries beyond the first K positions move into the holes among the first K (the rank sort does not mind the order).
+            int *movers = rankA, *holes = rankA + CAP / 2;  // (at most min(K, count - K) <= CAP / 2 of each)
+            int *cnt3 = lvlN;                               // [0] kept, [1] movers, [2] holes (the level counts are dead)
+            if (tid < 3) cnt3[tid] = 0;
+            __syncthreads();
+            int kept = 0;
+            for (int e = tid; e < count; e += NT) kept += (candG[e] <= E) ? 1 : 0;
+            if (kept) atomicAdd(&cnt3[0], kept);
+            __syncthreads();
+            const int K = cnt3[0];
+            for (int e = tid; e < count; e += NT) {
+                const bool keep = candG[e] <= E;
+                if (keep && e >= K) movers[atomicAdd(&cnt3[1], 1)] = e;
+                if (!keep && e < K) holes[atomicAdd(&cnt3[2], 1)] = e;
+            }
+            __syncthreads();
+            for (int i = tid; i < cnt3[1]; i += NT) {
+                const int from = movers[i], to = holes[i];
+                candG[to] = candG[from]; candLo[to] = candLo[from]; candHi[to] = candHi[from];
+            }
+            if (tid == 0) { ctl->listN = K; ctl->abort = 0; }
+            __syncthreads();
+        } else {
+            if (tid == 0) ctl->listN = 0;
+            __syncthreads();
+            walk(E, 1, -1.0, KB_BNB_KEEP ? M - 1 : 0);  // (KEEP builds: the last level again, over the frontier the counting pass left)
+        }
     }
     dT2 = __builtin_readcyclecounter();
     const int n = ctl->listN;
