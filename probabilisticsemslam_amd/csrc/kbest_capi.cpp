@@ -3,6 +3,7 @@
 // every compute entry point needs a HIP device and fails loudly without one.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -905,12 +906,13 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
     // operations (push counting, the unpruned run, the root-only entries) nor under root-subtree sharding (the merge orders ties).
     const bool tieMode = tie_mode(ctx, opts, extra != nullptr);
     const int kT = k;
-    // The CALLER's k decides the kernel: where k sits exactly at a limit of the kernel that takes it (k = 4 x waves x 64 of the
-    // 64-row kernel's pool merge, SMALL_MAX_K, an LDS pool that is just full) the launch runs WITHOUT the extra solution -- same
-    // kernel, same speed as before ties were checked -- and its problems are flagged KBEST_TIE_UNCHECKED (a tie at slot k
-    // would not be seen; runs inside the tables are ordered as ever).
+    // Where k sits exactly at a limit of the kernel that takes it (k = 4 x waves x 64 of the 64-row kernel's pool merge,
+    // SMALL_MAX_K, an LDS pool that is just full) k + 1 no longer fits that kernel.  The SYNCHRONOUS entries (grow) then take the
+    // kernel that does take k + 1 -- slower at exactly that k, but a tie at slot k is seen and completed: the one answer --; the
+    // ASYNCHRONOUS entry keeps its kernel and its speed, runs WITHOUT the extra solution and flags its problems
+    // KBEST_TIE_UNCHECKED (a tie at slot k would not be seen; runs inside the tables are ordered as ever).
     bool extraSol = tieMode;
-    if (tieMode) {
+    if (tieMode && !grow) {
         const bool fastA = k_fits_fast(ctx, LB, fastRow, kT, opts->flags, nullptr), fastB = k_fits_fast(ctx, LB, fastRow, kT + 1, opts->flags, nullptr);
         const bool laneA = lane_fits(ctx, LB, maxRow, maxCol, kT, nullptr), laneB = lane_fits(ctx, LB, maxRow, maxCol, kT + 1, nullptr);
         const bool smallA = small_fits(ctx, LB, maxRow, maxCol, kT, false, nullptr), smallB = small_fits(ctx, LB, maxRow, maxCol, kT + 1, false, nullptr);
@@ -945,7 +947,7 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
     auto finish = [&]() -> int {
         if (!tieMode) return KBEST_OK;
         hipError_t e = kb::launch_finish_tables(d_nf, d_nRow, d_nCol, B, kT, maxCol, maxRow, d_row4col, d_col4row, d_gain, tabI8, d_tieGain, d_tie,
-                                                false, s, extraSol ? 0 : KBEST_TIE_UNCHECKED);
+                                                false, s, extraSol ? 0 : KBEST_TIE_UNCHECKED, !hostTables);
         return e == hipSuccess ? KBEST_OK : fail(ctx, KBEST_ERR_HIP, "tie-order kernel launch", e);
     };
     // Problems of up to 32 rows: the small-problem kernel (half-wave workers, implicit zero columns).  The modes that
@@ -1319,6 +1321,60 @@ static inline size_t outBytesHint(int B, int k, int maxRow, int maxCol) { return
 // registered cost blocks are read by the LDS kernels in place (one trip over the link, no upload in front of the first workgroup)
 static inline bool zcCostOK(bool pinnedCost, const kbest_ctx *ctx) { return pinnedCost && ctx->zcCost != 0; }
 
+// Runs of equal gains of ONE problem's tables in host memory into the canonical order (kbest_ties.h: row4col lexicographic in the
+// reference's column order) -- what the finishing launch does for tables in device memory; for tables the kernels wrote into HOST
+// memory (the narrow-staged and the registered-buffer paths of the host entry) the launch only reports KBEST_TIE_INSIDE and the
+// entry orders them here.  T: int32 or int8 tables; col4row may be null; M / N: the problem's columns / rows; ld*: the tables' widths.
+template <class T> static void order_ties_host(const double *gain, T *row4col, T *col4row, int nf, int M, int N, int ldCol, int ldRow)
+{
+    std::vector<int> idx;
+    std::vector<T> tmpR, tmpC;
+    for (int s = 0; s + 1 < nf;) {
+        int e = s + 1;
+        while (e < nf && gain[e] == gain[s]) e++;
+        const int L = e - s;
+        if (L > 1) {
+            idx.resize(L);
+            for (int i = 0; i < L; i++) idx[i] = s + i;
+            std::sort(idx.begin(), idx.end(), [&](int a, int b) {
+                const T *ra = row4col + (size_t)a * ldCol, *rb = row4col + (size_t)b * ldCol;
+                for (int c = 0; c < M; c++)
+                    if (ra[c] != rb[c]) return ra[c] < rb[c];
+                return false;
+            });
+            tmpR.assign(row4col + (size_t)s * ldCol, row4col + (size_t)e * ldCol);
+            if (col4row) tmpC.assign(col4row + (size_t)s * ldRow, col4row + (size_t)e * ldRow);
+            for (int i = 0; i < L; i++) {
+                const int from = idx[i] - s;
+                if (from == i) continue;
+                memcpy(row4col + (size_t)(s + i) * ldCol, tmpR.data() + (size_t)from * ldCol, (size_t)M * sizeof(T));
+                if (col4row) memcpy(col4row + (size_t)(s + i) * ldRow, tmpC.data() + (size_t)from * ldRow, (size_t)N * sizeof(T));
+            }
+        }
+        s = e;
+    }
+}
+
+// ... for every problem of a host-entry call that the launch flagged KBEST_TIE_INSIDE (flags: the device buffer the launch wrote)
+static int order_flagged_host(kbest_ctx *ctx, const int32_t *d_flags, int B, int k, int maxRow, int maxCol, const int32_t *nRow, const int32_t *nCol,
+                              const double *gain, void *row4col, void *col4row, const int32_t *nf, bool i8)
+{
+    std::vector<int32_t> fl((size_t)B);
+    HIP_TRY(ctx, hipMemcpy(fl.data(), d_flags, (size_t)B * 4, hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; b++) {
+        if (!(fl[b] & KBEST_TIE_INSIDE)) continue;
+        const int n = nf[b] < 0 ? 0 : (nf[b] > k ? k : nf[b]);
+        const int M = nCol ? nCol[b] : maxCol, N = nRow ? nRow[b] : maxRow;
+        if (i8)
+            order_ties_host<signed char>(gain + (size_t)b * k, static_cast<signed char *>(row4col) + (size_t)b * k * maxCol,
+                                         col4row ? static_cast<signed char *>(col4row) + (size_t)b * k * maxRow : nullptr, n, M, N, maxCol, maxRow);
+        else
+            order_ties_host<int32_t>(gain + (size_t)b * k, static_cast<int32_t *>(row4col) + (size_t)b * k * maxCol,
+                                     col4row ? static_cast<int32_t *>(col4row) + (size_t)b * k * maxRow : nullptr, n, M, N, maxCol, maxRow);
+    }
+    return KBEST_OK;
+}
+
 // The host-buffer entry.  `keep` (kbest_multi.cpp): the result tables are staged in the CALLER's device buffers -- a device's
 // packed slice of the multi-device global table -- and stay there after they have been copied back, so that the all-gather
 // can follow; everything else (pieces, uploads, copies back) is the single-device path.
@@ -1492,6 +1548,11 @@ int kbest_batch_f64_keep(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxR
             if (ev[c]) (void)hipEventDestroy(ev[c]);
         if (start) (void)hipEventDestroy(start);
         if (rc != KBEST_OK) return rc;
+        // (the byte tables went into pinned HOST staging: runs of equal gains were reported, not ordered -- here, in the caller's tables)
+        if (!keep && opts->tie_flags && tie_mode(ctx, opts, false)) {
+            rc = order_flagged_host(ctx, opts->tie_flags, B, k, maxRow, maxCol, nullptr, nullptr, gain, row4col, col4row, nf, false);
+            if (rc != KBEST_OK) return rc;
+        }
         for (int b = 0; b < B; b++)
             if (nf[b] < 0) return fail(ctx, nf[b] == -1 ? KBEST_ERR_UNSUPPORTED : KBEST_ERR_INTERNAL, "kbest_batch_f64: a problem came back with nf < 0");
         return KBEST_OK;
@@ -1624,6 +1685,11 @@ int kbest_batch_f64_keep(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxR
         if (done[c]) (void)hipEventDestroy(done[c]);
     if (start) (void)hipEventDestroy(start);
     if (rc != KBEST_OK) return rc;
+    // (tables written into the caller's registered HOST memory: runs of equal gains were reported, not ordered -- here)
+    if (direct && opts->tie_flags && tie_mode(ctx, opts, false)) {
+        rc = order_flagged_host(ctx, opts->tie_flags, B, k, maxRow, maxCol, nRow, nCol, gain, row4col, col4row, nf, tabI8);
+        if (rc != KBEST_OK) return rc;
+    }
     for (int b = 0; b < B; b++)  // shapes were validated above: a negative count can only be an engine failure
         if (nf[b] < 0) return fail(ctx, nf[b] == -1 ? KBEST_ERR_UNSUPPORTED : KBEST_ERR_INTERNAL, "kbest_batch_f64: a problem came back with nf < 0");
     return KBEST_OK;
@@ -1653,8 +1719,21 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
     HIP_TRY(ctx, hipMemcpy(fl.data(), dFlags.as<int32_t>(), (size_t)B * 4, hipMemcpyDeviceToHost));
     if (!(opts->flags & KBEST_FLAG_NO_TIE_RESOLVE))
         kb_complete_tie_levels(ctx, opts, B, maxRow, maxCol, nRow, nCol, cost, costOff, k, row4col, col4row, gain, fl.data(), nullptr);
-    for (int b = 0; b < B; b++)
+    for (int b = 0; b < B; b++) {
         if ((fl[b] & KBEST_TIE_BOUNDARY) && !(fl[b] & KBEST_TIE_RESOLVED)) fl[b] |= KBEST_TIE_UNRESOLVED;
+        if ((fl[b] & KBEST_TIE_UNORDERED) && !(fl[b] & KBEST_TIE_RESOLVED)) {
+            // a run of more than 1 024 equal gains inside the first pass' tables: the tables are in the caller's memory -- ordered here
+            const bool i8 = (opts->flags & KBEST_FLAG_TABLES_I8) != 0;
+            const int n = nf[b] < 0 ? 0 : (nf[b] > k ? k : nf[b]), M = nCol ? nCol[b] : maxCol, N = nRow ? nRow[b] : maxRow;
+            if (i8)
+                order_ties_host<signed char>(gain + (size_t)b * k, reinterpret_cast<signed char *>(row4col) + (size_t)b * k * maxCol,
+                                             col4row ? reinterpret_cast<signed char *>(col4row) + (size_t)b * k * maxRow : nullptr, n, M, N, maxCol, maxRow);
+            else
+                order_ties_host<int32_t>(gain + (size_t)b * k, row4col + (size_t)b * k * maxCol, col4row ? col4row + (size_t)b * k * maxRow : nullptr, n, M, N,
+                                         maxCol, maxRow);
+        }
+        fl[b] &= ~KBEST_TIE_UNORDERED;
+    }
     if (opts->tie_flags) memcpy(opts->tie_flags, fl.data(), (size_t)B * 4);
     {
         std::lock_guard<std::mutex> lock(ctx->tieMu);
@@ -1677,10 +1756,10 @@ void kb_complete_tie_levels(kbest_ctx *ctx, const kbest_opts *opts, int B, int m
                             const double *cost, const int64_t *costOff, int k, void *row4col, void *col4row, double *gain, int32_t *fl,
                             std::vector<int> *changed)
 {
-    static const int steps[3] = {64, 256, KBEST_TIE_CAP};
+    static const int steps[4] = {64, 256, 1024, KBEST_TIE_CAP};
     const bool i8 = (opts->flags & KBEST_FLAG_TABLES_I8) != 0;
     const size_t esz = i8 ? 1 : 4;
-    for (int step = 0; step < 3; step++) {
+    for (int step = 0; step < 4; step++) {
         std::vector<int> idx;
         for (int b = 0; b < B; b++)
             if ((fl[b] & KBEST_TIE_BOUNDARY) && !(fl[b] & KBEST_TIE_RESOLVED)) idx.push_back(b);
@@ -1716,8 +1795,19 @@ void kb_complete_tie_levels(kbest_ctx *ctx, const kbest_opts *opts, int B, int m
             const double *g2 = sGain.data() + (size_t)i * k2;
             // the level is complete when the table goes on beyond it (or the problem has no more assignments) -- and the table is
             // in the canonical order throughout (a run of more than 1 024 equal gains is left as the kernel emitted it)
-            const bool complete = sNf[i] >= k && (sNf[i] < k2 || g2[k2 - 1] != g2[k - 1]) && !(fl2[i] & KBEST_TIE_UNORDERED);
+            const bool complete = sNf[i] >= k && (sNf[i] < k2 || g2[k2 - 1] != g2[k - 1]);
             if (!complete) continue;
+            if (fl2[i] & KBEST_TIE_UNORDERED) {
+                // a run of more than 1 024 equal gains, which the finishing launch leaves as the kernel emitted it: ordered here (the
+                // re-run's tables are in host memory)
+                const int nn = sNf[i] < k2 ? sNf[i] : k2;
+                if (i8)
+                    order_ties_host<signed char>(g2, reinterpret_cast<signed char *>(sR.data()) + (size_t)i * k2 * maxCol,
+                                                 col4row ? reinterpret_cast<signed char *>(sC.data()) + (size_t)i * k2 * maxRow : nullptr, nn, sCol[i], sRow[i], maxCol, maxRow);
+                else
+                    order_ties_host<int32_t>(g2, reinterpret_cast<int32_t *>(sR.data()) + (size_t)i * k2 * maxCol,
+                                             col4row ? reinterpret_cast<int32_t *>(sC.data()) + (size_t)i * k2 * maxRow : nullptr, nn, sCol[i], sRow[i], maxCol, maxRow);
+            }
             memcpy(static_cast<char *>(row4col) + (size_t)b * k * maxCol * esz, sR.data() + (size_t)i * k2 * maxCol * esz, (size_t)k * maxCol * esz);
             if (col4row)
                 memcpy(static_cast<char *>(col4row) + (size_t)b * k * maxRow * esz, sC.data() + (size_t)i * k2 * maxRow * esz, (size_t)k * maxRow * esz);
@@ -2055,8 +2145,8 @@ static int weights_small(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t
     const int kT = k;
     const int capRow = rawMaxRow < kb::SMALL_MAX_DIM ? rawMaxRow : kb::SMALL_MAX_DIM;
     int nw = 0;
-    // (k at the kernel's limit: no solution behind the k-th, the frames' flags carry KBEST_TIE_UNCHECKED -- see batch_dev_impl)
-    const bool extraSol = tieOn && small_fits(ctx, B, capRow, maxCol, kT + 1, true, nullptr);
+    // (a synchronous entry: where k + 1 no longer fits this kernel the general pipeline, which does take it, answers -- see batch_dev_impl)
+    const bool extraSol = tieOn;
     if (extraSol) k = k + 1;
     if (!small_fits(ctx, B, capRow, maxCol, k, true, &nw)) return 1;
     if (!condition && rawMaxRow > kb::SMALL_MAX_DIM) return 1;
@@ -2390,7 +2480,7 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
             goto general;  // (the fused kernel takes none of this batch's shapes)
         }
         // (64, then 256, then KBEST_TIE_CAP solutions beyond k: until the level ends inside the table)
-        for (int extra : {64, 256, KBEST_TIE_CAP}) {
+        for (int extra : {64, 256, 1024}) {
             std::vector<int> tied;
             for (int b = 0; b < B; b++)
                 if ((tfl[b] & KBEST_TIE_BOUNDARY) && !(tfl[b] & KBEST_TIE_RESOLVED) && (extra == 64 ? !(tfl[b] & KBEST_TIE_UNRESOLVED) : true)) tied.push_back(b);
@@ -2588,7 +2678,7 @@ general:
             for (int b = 0; b < B; b++)
                 if (tfl[b] & KBEST_TIE_BOUNDARY) tied.push_back(b);
             if (!tied.empty() && !quad) {
-                for (int extra : {64, 256, KBEST_TIE_CAP}) {
+                for (int extra : {64, 256, 1024}) {
                     const int Bs = (int)tied.size();
                     std::vector<int32_t> sL(Bs), sM(Bs), sNf(Bs), sT(Bs, 0);
                     std::vector<int64_t> sCo(Bs), sPo(Bs);

@@ -495,7 +495,8 @@ hipError_t launch_fill_unused(const int *nf, const int *nRow, const int *nCol, i
 // nullptr), and -- fill -- the unused slots / the padding of a ragged batch as launch_fill_unused defines them.
 hipError_t launch_finish_tables(const int *nf, const int *nRow, const int *nCol, int B, int k, int ldCol, int ldRow, int *row4col,
                                 int *col4row, double *gain, bool tablesI8, const double *tieGain, int *tieFlags, bool fill, hipStream_t stream,
-                                int baseFlags = 0);  // baseFlags: or-ed into every problem's flags (KBEST_TIE_UNCHECKED)
+                                int baseFlags = 0, bool order = true);  // baseFlags: or-ed into every problem's flags (KBEST_TIE_UNCHECKED);
+                                                                        // order = false: runs of equal gains are reported, not ordered (tables in host memory)
 hipError_t launch_kbest_lane(const Params &p, int B, int nWaves, int lanesPerChild, hipStream_t stream);
 hipError_t launch_kbest_small(const SmallParams &p, int B, int nWaves, hipStream_t stream);
 // kbest_tiny.hip: the fused association path by exhaustive enumeration, for frames whose assignments are few (condition + gate +

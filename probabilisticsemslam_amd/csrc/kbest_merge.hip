@@ -135,7 +135,8 @@ __global__ void __launch_bounds__(256) fill_unused_kernel(const int *nf, const i
 // slots and the padding of ragged batches as fill_unused_kernel does (FILL).  The two touch different entries of the tables.
 template <typename T, bool FILL>
 __global__ void __launch_bounds__(256) finish_tables_kernel(const int *nf, const int *nRow, const int *nCol, int k, int ldCol, int ldRow,
-                                                            T *row4col, T *col4row, double *gain, const double *tieGain, int *tieFlags, int baseFlags)
+                                                            T *row4col, T *col4row, double *gain, const double *tieGain, int *tieFlags, int baseFlags,
+                                                            int order)
 {
     __shared__ unsigned short scr[3 * TIE_RUN_CAP];
     const int b = blockIdx.x;
@@ -156,7 +157,7 @@ __global__ void __launch_bounds__(256) finish_tables_kernel(const int *nf, const
             return;
         }
         const int fl = tie_tail(gain + base, reinterpret_cast<int *>(row4col), base * ldCol, reinterpret_cast<int *>(col4row), base * ldRow, n, M, N,
-                                ldCol, ldRow, sizeof(T) == 1, scr, TIE_RUN_CAP, n == k && extra == extra, extra);
+                                ldCol, ldRow, sizeof(T) == 1, scr, TIE_RUN_CAP, n == k && extra == extra, extra, order != 0);
         if (tieFlags && threadIdx.x == 0) tieFlags[b] = fl | baseFlags;
         if (FILL) return;
     }
@@ -176,17 +177,18 @@ __global__ void __launch_bounds__(256) finish_tables_kernel(const int *nf, const
 }
 
 hipError_t launch_finish_tables(const int *nf, const int *nRow, const int *nCol, int B, int k, int ldCol, int ldRow, int *row4col, int *col4row,
-                                double *gain, bool tablesI8, const double *tieGain, int *tieFlags, bool fill, hipStream_t stream, int baseFlags)
+                                double *gain, bool tablesI8, const double *tieGain, int *tieFlags, bool fill, hipStream_t stream, int baseFlags, bool order)
 {
+    const int ord = order ? 1 : 0;
     if (B <= 0) return hipSuccess;
     signed char *r8 = reinterpret_cast<signed char *>(row4col), *c8 = reinterpret_cast<signed char *>(col4row);
     const dim3 g(B), bl(fill ? 256 : 64);
     if (tablesI8) {
-        if (fill) hipLaunchKernelGGL((finish_tables_kernel<signed char, true>), g, bl, 0, stream, nf, nRow, nCol, k, ldCol, ldRow, r8, c8, gain, tieGain, tieFlags, baseFlags);
-        else hipLaunchKernelGGL((finish_tables_kernel<signed char, false>), g, bl, 0, stream, nf, nRow, nCol, k, ldCol, ldRow, r8, c8, gain, tieGain, tieFlags, baseFlags);
+        if (fill) hipLaunchKernelGGL((finish_tables_kernel<signed char, true>), g, bl, 0, stream, nf, nRow, nCol, k, ldCol, ldRow, r8, c8, gain, tieGain, tieFlags, baseFlags, ord);
+        else hipLaunchKernelGGL((finish_tables_kernel<signed char, false>), g, bl, 0, stream, nf, nRow, nCol, k, ldCol, ldRow, r8, c8, gain, tieGain, tieFlags, baseFlags, ord);
     } else {
-        if (fill) hipLaunchKernelGGL((finish_tables_kernel<int, true>), g, bl, 0, stream, nf, nRow, nCol, k, ldCol, ldRow, row4col, col4row, gain, tieGain, tieFlags, baseFlags);
-        else hipLaunchKernelGGL((finish_tables_kernel<int, false>), g, bl, 0, stream, nf, nRow, nCol, k, ldCol, ldRow, row4col, col4row, gain, tieGain, tieFlags, baseFlags);
+        if (fill) hipLaunchKernelGGL((finish_tables_kernel<int, true>), g, bl, 0, stream, nf, nRow, nCol, k, ldCol, ldRow, row4col, col4row, gain, tieGain, tieFlags, baseFlags, ord);
+        else hipLaunchKernelGGL((finish_tables_kernel<int, false>), g, bl, 0, stream, nf, nRow, nCol, k, ldCol, ldRow, row4col, col4row, gain, tieGain, tieFlags, baseFlags, ord);
     }
     return hipGetLastError();
 }

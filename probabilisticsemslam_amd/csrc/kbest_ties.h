@@ -55,10 +55,14 @@ __device__ __forceinline__ bool tie_lex_less(const int *row4col, long long a, lo
 // gains; row4col / col4row are the launch's tables (int32, or int8 when i8), r4cBase / c4rBase the ELEMENT index of the
 // problem's slot 0 in them (col4row may be null); nf slots are filled; scr: >= 3 * scrEntries u16 of LDS nobody else uses any
 // more.  haveExtra / extra: the gain of the (nf+1)-th solution, when the kernel enumerated it (nf == the caller's k then).
+// order = false: the tables lie in HOST memory (the kernels of a host-buffer entry write them there over the link): runs of equal
+// gains are only REPORTED (KBEST_TIE_INSIDE) -- the entry brings them into the order on the host, where the tables are anyway
+// (order_ties_host, kbest_capi.cpp); swapping rows of host memory from here costs a link round trip per access, and a soak of
+// round 6 saw a table come back corrupted that way.
 // Returns KBEST_TIE_* flags (wave-uniform).
 __device__ __attribute__((noinline)) int tie_tail(const double *gain, int *row4col, long long r4cBase, int *col4row, long long c4rBase, int nf,
                                                   int M, int N, int ldCol, int ldRow, bool i8, unsigned short *scr, int scrEntries,
-                                                  bool haveExtra, double extra)
+                                                  bool haveExtra, double extra, bool order = true)
 {
     const int lane = threadIdx.x & 63;
     int flags = 0;
@@ -70,6 +74,7 @@ __device__ __attribute__((noinline)) int tie_tail(const double *gain, int *row4c
     for (int s = lane; s + 1 < nf; s += 64) any = any || (gain[s] == gain[s + 1]);
     if (__ballot(any) == 0ull) return flags;  // no two equal gains: what every tie-free problem pays
     flags |= KBEST_TIE_INSIDE;
+    if (!order) return flags;
     const int cap = scrEntries < TIE_RUN_CAP ? scrEntries : TIE_RUN_CAP;
     unsigned short *inv = scr, *pos = scr + cap, *at = scr + 2 * cap;
     int s = 0;

@@ -20,7 +20,7 @@ KBEST_FLAG_NO_TIE_RESOLVE = 1024
 KBEST_TIE_INSIDE, KBEST_TIE_BOUNDARY, KBEST_TIE_RESOLVED = 1, 2, 4
 KBEST_TIE_UNCHECKED, KBEST_TIE_UNORDERED, KBEST_TIE_UNRESOLVED = 1 << 28, 1 << 29, 1 << 30
 KBEST_ROUTE_LANE, KBEST_ROUTE_SMALL, KBEST_ROUTE_FAST, KBEST_ROUTE_WIDE, KBEST_ROUTE_RELAY, KBEST_ROUTE_EXTRA = 1, 2, 4, 8, 16, 32
-KBEST_TIE_CAP = 1024
+KBEST_TIE_CAP = 4096
 KBEST_MAX_DIM = 64        # rows handled by the LDS-resident kernel
 KBEST_MAX_DIM_WIDE = 1024  # rows handled at all (general-size kernel beyond KBEST_MAX_DIM)
 

@@ -271,13 +271,14 @@ def asgn_bb(bbL, bbR, gate):
     return asg
 
 
-def canonical_kbest(cost, N, M, k, maximize=False, cutoff=None, cap=1024, run_cap=1024):
+def canonical_kbest(cost, N, M, k, maximize=False, cutoff=None, cap=4096, run_cap=None):
     """The k best in the engine's ONE order of exact ties (include/kbest_c.h, "Order of exact ties"), from the checker:
     solutions ordered by (gain, row4col lexicographic); when the k-th and the (k+1)-th best gains are equal, the
     lexicographically first assignments of that gain level.  Returns (nf, row4col[nf, M], gain[nf], boundary, resolved):
     boundary = such a tie exists, resolved = its gain level ends within `cap` solutions beyond k (what a synchronous
-    entry completes, KBEST_TIE_CAP) and has at most run_cap members in all (the longest run of equal gains the engine orders,
-    TIE_RUN_CAP).  The level itself is enumerated completely here, whatever its size."""
+    entry completes: KBEST_TIE_CAP = 4 096 for kbest_batch_f64, 1 024 for the association entries) and -- run_cap, association
+    entries only: 1 024 -- has at most run_cap members in all (the longest run of equal gains the device orders, TIE_RUN_CAP).
+    The level itself is enumerated completely here, whatever its size."""
     big = k + cap
     while True:
         nf, r4c, c4r, g = orc_kbest(cost, N, M, big, maximize=maximize, cutoff=cutoff)
@@ -288,7 +289,7 @@ def canonical_kbest(cost, N, M, k, maximize=False, cutoff=None, cap=1024, run_ca
     keys = [r4c[:, c] for c in range(M - 1, -1, -1)] + [(-g if maximize else g)]
     order = np.lexsort(keys)  # last key first: gain, then the columns from the first to the last
     boundary = bool(nf > k and g[order[k]] == g[order[k - 1]])
-    resolved = boundary and (nf < k + cap or g[order[k + cap - 1]] != g[order[k - 1]]) and int((g == g[order[k - 1]]).sum()) <= run_cap
+    resolved = boundary and (nf < k + cap or g[order[k + cap - 1]] != g[order[k - 1]]) and (run_cap is None or int((g == g[order[k - 1]]).sum()) <= run_cap)
     n = min(nf, k)
     return n, r4c[order[:n]], g[order[:n]], boundary, resolved
 
@@ -305,5 +306,5 @@ def weights_from_solutions(row4col, gain, nL, nM, gate=True):
 def canonical_assignment_prob(cond, nL, nM, k, cap=1024):
     """assignmentProb on a conditioned block with the engine's one order of exact ties: the canonical k best within the
     cutoff 42 (canonical_kbest), then the reference's accumulation.  Returns (probs, nf, boundary, resolved)."""
-    n, r4c, g, boundary, resolved = canonical_kbest(cond, nL + nM, nM, k, cutoff=42.0, cap=cap)
+    n, r4c, g, boundary, resolved = canonical_kbest(cond, nL + nM, nM, k, cutoff=42.0, cap=cap, run_cap=1024)
     return weights_from_solutions(r4c, g, nL, nM), n, boundary, resolved

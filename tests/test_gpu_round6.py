@@ -403,15 +403,31 @@ def test_resolve_ties_dev_completes_the_device_tables(engine):
     assert (got[0] == want[0]).all() and (got[1][ok] == want[1][ok]).all() and (bits(got[3][ok]) == bits(want[3][ok])).all()
 
 
-def _route(eng, costs, N, M, k, **kw):
-    out = eng.kbest(costs, N, M, k, tie_flags=True, **kw)
-    return out, eng.last_route()
+def _route(eng, costs, N, M, k, sync=False):
+    """(nf, row4col, col4row, gain, flags) and the route: through the asynchronous entry (sync=False) or kbest_batch_f64."""
+    if sync:
+        out = eng.kbest(costs, N, M, k, tie_flags=True)
+        return out, eng.last_route()
+    import torch
+    dev = torch.device("cuda", 0)
+    B = costs.shape[0]
+    d_cost = torch.from_numpy(np.ascontiguousarray(costs)).to(dev)
+    d_r = torch.full((B, k, M), -1, dtype=torch.int32, device=dev)
+    d_c = torch.full((B, k, N), -1, dtype=torch.int32, device=dev)
+    d_g = torch.zeros((B, k), dtype=torch.float64, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_f = torch.zeros(B, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    eng.kbest_dev(d_cost, B, N, M, k, d_r, d_c, d_g, d_n, stream=torch.cuda.current_stream().cuda_stream, d_tie_flags=d_f)
+    torch.cuda.synchronize()
+    return (d_n.cpu().numpy(), d_r.cpu().numpy(), d_c.cpu().numpy(), d_g.cpu().numpy(), d_f.cpu().numpy()), eng.last_route()
 
 
 def test_k_at_a_kernel_limit_keeps_its_kernel(monkeypatch):
-    """with exact ties checked a launch enumerates k + 1 solutions, which moved every k limit down by one.  Now the
-    caller's k decides: at the largest k a kernel takes the launch runs on THAT kernel without the extra solution and its problems
-    carry KBEST_TIE_UNCHECKED; one below, the extra solution is enumerated.  Results: the checker's, bit for bit."""
+    """with exact ties checked a launch enumerates k + 1 solutions, which moved every k limit down by one.  Now, through
+    the ASYNCHRONOUS entry, the caller's k decides: at the largest k a kernel takes the launch runs on THAT kernel without the extra
+    solution and its problems carry KBEST_TIE_UNCHECKED; one below, the extra solution is enumerated.  The SYNCHRONOUS entry at
+    that k takes a kernel that fits k + 1 (the tie at slot k stays checked).  Results: the checker's, bit for bit."""
     E = pk.engine
     rng = np.random.default_rng(4)
     cases = [("fast", E.KBEST_ROUTE_FAST, dict(KBEST_NO_LANE=1, KBEST_NO_SMALL=1), 40, 40, 2),
@@ -446,6 +462,10 @@ def test_k_at_a_kernel_limit_keeps_its_kernel(monkeypatch):
         n3 = np.minimum(nf, nf3)
         for b in range(B):
             assert (r3[b, : n3[b]] == r4c[b, : n3[b]]).all() and (bits(g3[b, : n3[b]]) == bits(g[b, : n3[b]])).all()
+        # the synchronous entry at kmax: checked (the extra solution is enumerated -- by whichever kernel takes kmax + 1)
+        (nf4, r4, c4, g4, fl4), route4 = _route(eng, costs, N, M, kmax, sync=True)
+        assert route4 & E.KBEST_ROUTE_EXTRA and not (fl4 & E.KBEST_TIE_UNCHECKED).any(), (name, route4)
+        assert (nf4 == nf).all() and (r4 == r4c).all() and (bits(g4) == bits(g)).all()
 
 
 def test_fused_association_entry_takes_k_1024():
