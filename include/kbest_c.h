@@ -225,7 +225,12 @@ int kbest_to_probs_f64(kbest_ctx *ctx, double *x, int64_t n);
  * gains behind the tables (exact ties) and -- for batches of more than one generation of resident workgroups, which the 64-row
  * kernel enumerates as a relay of several workgroups per matrix -- one LDS image per matrix (25 KB at 32 rows, 70 KB at 64;
  * at most ~400 MB: larger batches are not relayed).  A kbest_batch_f64_dev call whose batch was not reserved for fails with
- * KBEST_ERR_NOT_RESERVED; one whose relay images alone are missing (reserved with a smaller B) runs as a plain launch. */
+ * KBEST_ERR_NOT_RESERVED; one whose relay images alone are missing (reserved with a smaller B) runs as a plain launch.
+ * A graph that captured a relay launch holds the addresses of the relay work space: reserve for the largest batch BEFORE
+ * capturing -- a later kbest_reserve that would have to grow that work space returns KBEST_ERR_BAD_ARG.  A piece of a relay
+ * waits for its predecessor at most a few seconds (a healthy launch never gets there); a matrix whose hand-over did not come is
+ * reported with nf = -3 (KBEST_ERR_INTERNAL from the host entries), and the context re-zeroes its progress words before the
+ * next relay launch after any failed entry. */
 int kbest_reserve(kbest_ctx *ctx, int B, int maxRow, int k);
 
 /* Diagnostic builds only (make -C probabilisticsemslam_amd/csrc PROFILE=1): device buffer of B*16 uint64

@@ -106,6 +106,7 @@ struct kbest_ctx {
     hipStream_t stream = nullptr;
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};  // the other pieces of a large host-entry batch (kbest_batch_f64)
     hipStream_t hi = nullptr;                          // ... and the first piece's (highest priority)
+    hipStream_t copy = nullptr;                        // uploads of registered cost blocks, piece after piece (narrow staging)
     int prioMain = 0, prioAux[3] = {0, 0, 0};          // their stream priorities (kbest_create)
     unsigned char *states = nullptr;  // hypothesis-state workspace (+ the slot -> state table behind it)
     size_t statesBytes = 0;
@@ -140,6 +141,8 @@ struct kbest_ctx {
     DevBufRaw relayBuf;       // relay launches of the 64-row kernel: [B] LDS images (kbest_engine.hip)
     DevBufRaw relayFlags;     // ... and three words per matrix: claimed / done / gone (zeroed when the buffer is made, put back to zero by every launch)
     long long relayLaunches = 0;  // relay launches made (kbest_relay_launches)
+    std::atomic<bool> relayDirty{false};  // an entry of this context failed (HIP error, nf < 0): the relay's words are zeroed before the next relay launch
+    bool relayCaptured = false;   // a relay launch was captured into a graph: the graph holds the relay work space's addresses
     int lastRoute = 0;            // which kernel(s) the last k-best launch went to (kbest_last_route)
     int relay = -1;           // KBEST_RELAY: pieces per matrix (0 / 1: never; -1: choose per launch)
     int relayFirst = 0;       // KBEST_RELAY_FIRST: the first piece hands over at k * this / 1024 solutions (0: choose per launch shape)
@@ -154,7 +157,6 @@ struct kbest_ctx {
     bool forceLane = false;   // KBEST_FORCE_LANE: every plain batch of <= 32-row problems through the lane-per-child kernel
     int laneNw = 0;           // KBEST_LANE_NW: waves per problem of the lane-per-child kernel (1 / 2 / 4); 0 = choose per launch
     int laneSpec = 0;         // KBEST_LANE_SPEC: hypotheses split per round there (1 .. 16); 0 = choose per launch
-    int laneG = 0;            // KBEST_LANE_G: lanes per child there (2 / 4); 0 = choose per launch
     // optimistic bounds of the 64-row kernel (kbest_engine.hip, struct Opt); < 0: choose per launch shape (opt_defaults)
     float optRho0 = -1.0f, optRho1 = -1.0f, optPhi = -1.0f, optKappa = 0.25f;
     int optMinPool = 8;
@@ -200,6 +202,8 @@ namespace {
 int fail(kbest_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess)
 {
     if (ctx) {
+        // (a launch that failed may have left the relay's per-matrix words non-zero: kbest_engine.hip, relay_depart)
+        if (code == KBEST_ERR_HIP || code == KBEST_ERR_INTERNAL) ctx->relayDirty.store(true, std::memory_order_relaxed);
         std::lock_guard<std::mutex> lock(ctx->errMu);
         ctx->err = what;
         if (e != hipSuccess) { ctx->err += ": "; ctx->err += hipGetErrorString(e); }
@@ -430,7 +434,6 @@ int kbest_create(kbest_ctx **out, int device)
     if (const char *e = getenv("KBEST_PIECES")) { const int w = atoi(e); if (w == 1 || w == 2 || w == 4) ctx->pieces = w; }
     ctx->forceLane = getenv("KBEST_FORCE_LANE") != nullptr;
     if (const char *e = getenv("KBEST_LANE_NW")) { const int w = atoi(e); if (w == 1 || w == 2 || w == 4) ctx->laneNw = w; }
-    if (const char *e = getenv("KBEST_LANE_G")) { const int w = atoi(e); if (w == 2 || w == 4) ctx->laneG = w; }
     if (const char *e = getenv("KBEST_LANE_SPEC")) { const int w = atoi(e); if (w >= 1 && w <= kb::LANE_MAX_SPEC) ctx->laneSpec = w; }
     ctx->forceSmall = getenv("KBEST_FORCE_SMALL") != nullptr;
     ctx->noOpt = getenv("KBEST_NO_OPT") != nullptr;
@@ -484,6 +487,7 @@ int kbest_destroy(kbest_ctx *ctx)
     for (auto &a : ctx->aux)
         if (a) (void)hipStreamDestroy(a);
     if (ctx->hi) (void)hipStreamDestroy(ctx->hi);
+    if (ctx->copy) (void)hipStreamDestroy(ctx->copy);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return KBEST_OK;
@@ -650,7 +654,7 @@ static Shape lane_shape(const kbest_ctx *ctx, int B, int maxRow, int maxCol, int
     if (maxRow <= 16 && s.spec == 8) s.spec = k >= 100 ? 16 : (B <= 4 * ctx->nCU ? 12 : 10);
     if (ctx->laneNw > 0) s.nWaves = ctx->laneNw;
     if (ctx->laneSpec > 0) s.spec = ctx->laneSpec;
-    s.lanes = ctx->laneG > 0 ? ctx->laneG : 4;
+    s.lanes = 4;
     while (k > 4 * s.nWaves * 64 && s.nWaves < 4) s.nWaves *= 2;  // the in-place pool merge holds at most 4 entries per thread
     while (s.spec > 1 && kb::lane_lds_layout(maxRow, maxCol, k, s.spec, s.nWaves, s.lanes).total > ctx->ldsLimit) s.spec--;
     (void)B;
@@ -860,6 +864,9 @@ static int relay_reserve(kbest_ctx *ctx, int B, size_t img, bool grow)
     const size_t need = (size_t)B * img, needF = (size_t)B * 16;  // (three arrays of words in quarters of the buffer)
     if (need <= ctx->relayBuf.bytes && needF <= ctx->relayFlags.bytes) return KBEST_OK;
     if (!grow) return KBEST_ERR_NOT_RESERVED;
+    // a captured relay launch holds the addresses of these buffers: growing (= freeing) them under it is refused
+    if (ctx->relayCaptured && ctx->relayBuf.p)
+        return fail(ctx, KBEST_ERR_BAD_ARG, "the relay work space cannot grow while a captured launch of this context holds it: reserve for the largest batch before capturing");
     int rc = raw_reserve(ctx, ctx->relayBuf, need);
     if (rc != KBEST_OK) return rc;
     if (needF > ctx->relayFlags.bytes) {
@@ -1155,6 +1162,11 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
                 p.relayStep = ctx->relayStep > 0 ? ctx->relayStep
                               : (ctx->relay >= 0 ? (1024 - p.relayFirst) / (relayP - 1)   // (a forced count: even steps, every piece hands over)
                                                  : (quarters ? 256 : (wide12 ? 384 : 256)));
+                if (ctx->relayDirty.exchange(false)) {  // (an earlier entry of this context failed: the words may not be zero)
+                    const hipError_t ez = kb::launch_zero_words(static_cast<unsigned *>(ctx->relayFlags.p), (long long)(ctx->relayFlags.bytes / 4), s);
+                    if (ez != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "relay words: zeroing kernel launch", ez);
+                }
+                if (capturing(s)) ctx->relayCaptured = true;
                 ctx->relayLaunches++;
                 ctx->lastRoute |= KBEST_ROUTE_RELAY;
                 p.relayBuf = static_cast<unsigned char *>(ctx->relayBuf.p);
@@ -1318,8 +1330,6 @@ int kbest_unregister_host_buffer(kbest_ctx *ctx, void *ptr)
 }  // extern "C"
 
 static inline size_t outBytesHint(int B, int k, int maxRow, int maxCol) { return (size_t)B * k * ((size_t)maxRow + maxCol) * 4; }
-// registered cost blocks are read by the LDS kernels in place (one trip over the link, no upload in front of the first workgroup)
-static inline bool zcCostOK(bool pinnedCost, const kbest_ctx *ctx) { return pinnedCost && ctx->zcCost != 0; }
 
 // Runs of equal gains of ONE problem's tables in host memory into the canonical order (kbest_ties.h: row4col lexicographic in the
 // reference's column order) -- what the finishing launch does for tables in device memory; for tables the kernels wrote into HOST
@@ -1449,8 +1459,16 @@ int kbest_batch_f64_keep(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxR
         const double *hG = reinterpret_cast<const double *>(h8 + offG);
         const int32_t *hN = reinterpret_cast<const int32_t *>(h8 + offN);
         DevBuf dCostN;
-        if (!zcCostOK(pinnedCost, ctx)) HIP_TRY(ctx, dCostN.alloc(ctx, nCost * 8));
-        const bool zc = zcCostOK(pinnedCost, ctx);
+        // Registered (pinned) cost blocks: uploaded by the copy engine PIECE AFTER PIECE on a stream of their own, each piece's kernel
+        // behind its own upload -- the first piece's blocks are up after a quarter of the transfer and the rest arrives under the
+        // running kernels.  (The kernels reading the blocks in place over the link -- KBEST_ZC_COST=2, what round 4 did here -- keeps
+        // the whole first generation of workgroups waiting for 16 MB of tiles: 2.95 ms per call of 1 024 x 64x64 against 2.67 with
+        // plain pageable buffers; all four pieces' copies at once share the link and the first piece is up no sooner: 3.16.)
+        const bool zc = pinnedCost && ctx->zcCost == 2;
+        const bool chained = pinnedCost && !zc && ctx->zcCost != 0;
+        if (!zc) HIP_TRY(ctx, dCostN.alloc(ctx, nCost * 8));
+        if (chained && !ctx->copy) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
+        hipEvent_t up[4] = {nullptr, nullptr, nullptr, nullptr};
         const double *devC = zc ? mCost : dCostN.as<double>();
         const int nP = (B >= 4 * ctx->nCU) ? (ctx->pieces > 0 ? ctx->pieces : 4) : 1;
         for (int i = 0; i < 3 && nP > 1; i++)
@@ -1503,7 +1521,13 @@ int kbest_batch_f64_keep(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxR
             hipError_t e = hipSuccess;
             if (keep && keep->stamps && c == 0) keep->stamps[0] = kb::now_s();
             if (!zc) {
-                if (pinnedCost) e = hipMemcpyAsync(dCostN.as<double>() + (size_t)b0 * per, cost + (size_t)b0 * per, (size_t)nb * per * 8, hipMemcpyHostToDevice, st[c]);
+                if (chained) {
+                    if (c == 0 && start) e = hipStreamWaitEvent(ctx->copy, start, 0);  // (behind the context's previous launch, as the pieces are)
+                    if (e == hipSuccess) e = hipMemcpyAsync(dCostN.as<double>() + (size_t)b0 * per, cost + (size_t)b0 * per, (size_t)nb * per * 8, hipMemcpyHostToDevice, ctx->copy);
+                    if (e == hipSuccess) e = hipEventCreateWithFlags(&up[c], hipEventDisableTiming);
+                    if (e == hipSuccess) e = hipEventRecord(up[c], ctx->copy);
+                    if (e == hipSuccess) e = hipStreamWaitEvent(st[c], up[c], 0);
+                } else if (pinnedCost) e = hipMemcpyAsync(dCostN.as<double>() + (size_t)b0 * per, cost + (size_t)b0 * per, (size_t)nb * per * 8, hipMemcpyHostToDevice, st[c]);
                 else e = hipMemcpy(dCostN.as<double>() + (size_t)b0 * per, cost + (size_t)b0 * per, (size_t)nb * per * 8, hipMemcpyHostToDevice);
             }
             if (e != hipSuccess) { rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: upload", e); break; }
@@ -1544,8 +1568,11 @@ int kbest_batch_f64_keep(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxR
             const hipError_t e = hipStreamSynchronize(st[c]);
             if (e != hipSuccess && rc == KBEST_OK) rc = fail(ctx, KBEST_ERR_HIP, "kbest_batch_f64: synchronize", e);
         }
-        for (int c = 0; c < 4; c++)
+        if (chained) (void)hipStreamSynchronize(ctx->copy);
+        for (int c = 0; c < 4; c++) {
             if (ev[c]) (void)hipEventDestroy(ev[c]);
+            if (up[c]) (void)hipEventDestroy(up[c]);
+        }
         if (start) (void)hipEventDestroy(start);
         if (rc != KBEST_OK) return rc;
         // (the byte tables went into pinned HOST staging: runs of equal gains were reported, not ordered -- here, in the caller's tables)

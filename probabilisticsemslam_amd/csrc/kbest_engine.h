@@ -486,6 +486,7 @@ hipError_t launch_copy_words(const void *src, void *dst, long long bytes, hipStr
 double now_s();
 hipError_t launch_merge_topk(const MergeParams &p, int B, hipStream_t stream);
 hipError_t launch_merge_gains(const MergeGainsParams &p, hipStream_t stream);
+hipError_t launch_zero_words(unsigned *w, long long n, hipStream_t stream);
 hipError_t launch_narrow_i32(const int *src, signed char *dst, long long n, hipStream_t stream);
 hipError_t launch_add_i8(signed char *dst, const signed char *src, long long n, hipStream_t stream);
 hipError_t launch_fill_unused(const int *nf, const int *nRow, const int *nCol, int B, int k, int ldCol, int ldRow, int *row4col,

@@ -455,9 +455,14 @@ __global__ void __launch_bounds__(NW * 64, min_waves_per_simd(NW)) kbest_kernel(
         // every time), then ONE agent-scope acquire, waited for, in front of the barrier behind which everybody loads.
         if (tid == 0) {
             unsigned f;
+            // (bounded: ~2^21 polls of ~1 us.  A piece only waits for workgroups that are RUNNING, so the bound is never met in a healthy
+            //  launch; it is met when the words were left non-zero by a launch that faulted or was aborted -- then this matrix comes back
+            //  with nf = -3, an engine error, instead of hanging the GPU; the host re-zeroes the words before the next relay launch.)
+            unsigned polls = 0;
             for (;;) {
                 f = __hip_atomic_load(p.relayFlag + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (f >= (unsigned)piece) break;  // (pieces done: piece j hands over with j + 1; 15: the matrix is finished)
+                if (++polls > (1u << 21) || piece >= (int)gridDim.y) { p.nf[blk] = -3; f = 15u; break; }
                 __builtin_amdgcn_s_sleep(32);
             }
             red[0] = __longlong_as_double((long long)f);

@@ -1029,13 +1029,15 @@ static hipError_t launch_lane_rg(const Params &p, int B, int nWaves, hipStream_t
     }
 }
 
-// lanesPerChild: 4 (16 children per wave) or 2 (32 children per wave); the rows of a child are split evenly over them
+// lanesPerChild: 4 (16 children per wave; the rows of a child are split evenly over them).  The form with 2 lanes per child (32
+// children per wave, 8 / 16 rows per lane) was built in round 3 and removed in round 6: 214 VGPRs at 32 rows (two waves per
+// SIMD), 264 - 588 bytes of scratch per lane in its instantiations, and slower everywhere it was measured (4 096 x 32x32, k = 200:
+// 8.3 ms against 5.4; NOTES section 8, round 3) -- the passes of a round are set by its longest child, not by the child slots.
 hipError_t launch_kbest_lane(const Params &p, int B, int nWaves, int lanesPerChild, hipStream_t stream)
 {
-    if (p.maxRow > LANE_MAX_DIM || p.spec < 1 || p.spec > LANE_MAX_SPEC || p.k > 4 * nWaves * 64) return hipErrorInvalidValue;
-    if (lane_rows(p.maxRow) == 16)
-        return lanesPerChild == 2 ? launch_lane_rg<8, 2>(p, B, nWaves, stream) : launch_lane_rg<4, 4>(p, B, nWaves, stream);
-    return lanesPerChild == 2 ? launch_lane_rg<16, 2>(p, B, nWaves, stream) : launch_lane_rg<8, 4>(p, B, nWaves, stream);
+    if (p.maxRow > LANE_MAX_DIM || p.spec < 1 || p.spec > LANE_MAX_SPEC || p.k > 4 * nWaves * 64 || lanesPerChild != 4) return hipErrorInvalidValue;
+    if (lane_rows(p.maxRow) == 16) return launch_lane_rg<4, 4>(p, B, nWaves, stream);
+    return launch_lane_rg<8, 4>(p, B, nWaves, stream);
 }
 
 }  // namespace kb

@@ -249,6 +249,23 @@ hipError_t launch_copy_words(const void *src, void *dst, long long bytes, hipStr
     return hipGetLastError();
 }
 
+// words back to zero BY A KERNEL (stores through L2, where words that were updated by atomics live: a memset node did not reach
+// them, kbest_engine.hip) -- the relay's progress words after a launch that failed
+__global__ void __launch_bounds__(256) zero_words_kernel(unsigned *w, long long n)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        __hip_atomic_store(w + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+hipError_t launch_zero_words(unsigned *w, long long n, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    long long blocks = (n + 255) / 256;
+    blocks = blocks > 1024 ? 1024 : blocks;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_merge_topk(const MergeParams &p, int B, hipStream_t stream)
 {
     if (p.inI8) hipLaunchKernelGGL(merge_topk_kernel<signed char>, dim3(B), dim3(256), 0, stream, p);

@@ -17,7 +17,7 @@ d_cost = torch.from_numpy(costs).to(dev)
 d_r = torch.empty((B, k, N), dtype=torch.int32, device=dev); d_c = torch.empty((B, k, N), dtype=torch.int32, device=dev)
 d_g = torch.empty((B, k), dtype=torch.float64, device=dev); d_n = torch.empty(B, dtype=torch.int32, device=dev)
 st = torch.cuda.Stream()
-cfgs = [dict()] + [dict(KBEST_FORCE_LANE=1, KBEST_LANE_SPEC=s, KBEST_LANE_NW=w) for w in (2, 4) for s in (8, 12, 16)] + [dict(KBEST_FORCE_LANE=1, KBEST_LANE_SPEC=16, KBEST_LANE_NW=4, KBEST_LANE_G=2)]
+cfgs = [dict()] + [dict(KBEST_FORCE_LANE=1, KBEST_LANE_SPEC=s, KBEST_LANE_NW=w) for w in (2, 4) for s in (8, 12, 16)]
 ref = None
 for c in cfgs:
     try:

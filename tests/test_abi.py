@@ -76,3 +76,11 @@ def test_step_loop_is_what_the_source_says():
     if not os.path.exists(obj):
         pytest.skip("objects not built in this tree (the library was shipped prebuilt)")
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "check_step_loop.py")])
+
+
+def test_every_environment_knob_is_documented():
+    """tools/knob_table.py --check: every getenv("KBEST_*") of the sources is in the one list INTEGRATION.md section 7 is
+    generated from, nothing listed is gone, and the document holds exactly the generated table."""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "knob_table.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
