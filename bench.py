@@ -578,6 +578,36 @@ def two_in_flight(torch, dev, cfg, B, ms_single, steps=20):
                     "batches complete faster.  Secondary number: the headline and its roofline are one launch at a time"}
 
 
+def equal_costs_entry(eng, torch, dev, tstream, B=4, N=64, M=64, k=1000):
+    """ADVICE r5's case: all-EQUAL costs at a large k -- one run of k exactly equal gains per matrix, which the finishing launch has
+    to bring into the canonical order (row4col lexicographic).  Its price = the same launch with and without KBEST_FLAG_NO_TIE_CHECK."""
+    d_cost = torch.zeros((B, N * M), dtype=torch.float64, device=dev)
+    d_r = torch.empty((B, k, M), dtype=torch.int32, device=dev)
+    d_c = torch.empty((B, k, N), dtype=torch.int32, device=dev)
+    d_g = torch.empty((B, k), dtype=torch.float64, device=dev)
+    d_n = torch.empty(B, dtype=torch.int32, device=dev)
+    d_f = torch.zeros(B, dtype=torch.int32, device=dev)
+    eng.reserve(B, N, k)
+    out = {}
+    for name, tc in (("ms_with_the_canonical_order", True), ("ms_without", False)):
+        ts = []
+        for i in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng.kbest_dev(d_cost, B, N, M, k, d_r, d_c, d_g, d_n, stream=tstream.cuda_stream, d_tie_flags=d_f if tc else None, tie_check=tc)
+            torch.cuda.synchronize()
+            if i:
+                ts.append(1e3 * (time.perf_counter() - t0))
+        out[name] = float(np.median(ts))
+        if tc:
+            r = d_r.cpu().numpy()
+            out["ordered"] = bool(all([tuple(x) for x in r[b]] == sorted(tuple(x) for x in r[b]) for b in range(B)))
+            out["flags"] = [int(x) for x in d_f.cpu().numpy()]
+    out["workload"] = f"{B} x {N}x{M} matrices of all-equal costs, k={k}: one run of k equal gains each (KBEST_TIE_INSIDE | KBEST_TIE_BOUNDARY)"
+    out["what"] = "the finishing launch orders a long run by a radix sort over the columns (kbest_ties.h, round 6; L^2 lexicographic comparisons before)"
+    return out
+
+
 def dense_entry(eng, torch, cfg, steps, warmup, dev, tstream, cpu_sample, no_cpu):
     """One BASELINE config as an entry of the `configs` block (single GPU)."""
     from probabilisticsemslam_amd import workloads as wl
@@ -1030,6 +1060,10 @@ def main():
                 except Exception as ex:  # never lose the headline over the extra entry
                     share["error"] = repr(ex)
                 extra["c4_share8"] = share
+                try:
+                    extra["ties_all_equal_costs"] = equal_costs_entry(eng, torch, dev, tstream)
+                except Exception as ex:
+                    extra["ties_all_equal_costs"] = {"error": repr(ex)}
                 try:
                     extra["c4_two_batches_in_flight"] = two_in_flight(torch, dev, "c4", Bc, out["ms_per_step"])
                 except Exception as ex:

@@ -44,7 +44,7 @@
  * (kbest_opts.tie_flags).  A tie at slot k (KBEST_TIE_BOUNDARY) is completed by the SYNCHRONOUS entries themselves: the
  * problem is enumerated again with k + 64, then k + 256, k + 1 024, k + KBEST_TIE_CAP solutions until the level ends inside the
  * table, and the first k of the ordered table are kept (KBEST_TIE_RESOLVED; a level with more than KBEST_TIE_CAP members beyond k
- * -- on the association entries, whose weights are summed on the device: of more than 1 024 members in all -- stays
+ * -- on the association entries, whose weights are summed on the device: of more than 4 096 members in all -- stays
  * KBEST_TIE_UNRESOLVED: the emitted set is then one of several equally good ones and may depend on the kernel; a re-run that fails
  * leaves the first pass' tables and that flag).  The asynchronous _dev entries only
  * report the flags; kbest_resolve_ties_dev completes their tables afterwards, and the multi-device batch entry does so by itself.
@@ -109,11 +109,11 @@ enum {
                                       /* k = 1 024 on the fused association kernel): the (k+1)-th solution was not enumerated, so */
                                       /* a tie at slot k would not have been seen (runs of equal gains INSIDE the tables are       */
                                       /* ordered as ever).  The synchronous entries take a kernel that fits k + 1 instead.         */
-#define KBEST_TIE_UNORDERED (1 << 29) /* a run of more than 1 024 equal gains was left in the kernel's own order (asynchronous   */
+#define KBEST_TIE_UNORDERED (1 << 29) /* a run of more than 4 096 equal gains was left in the kernel's own order (asynchronous   */
                                       /* and association entries; kbest_batch_f64 orders such a run on the host)                */
 #define KBEST_TIE_UNRESOLVED (1 << 30) /* BOUNDARY without RESOLVED: the emitted set is one of several equally good ones       */
-#define KBEST_TIE_CAP 4096            /* members of the gain level at slot k beyond k that kbest_batch_f64 enumerates at most    */
-                                      /* (it tries 64, 256, 1 024, 4 096); the association entries stop at 1 024                */
+#define KBEST_TIE_CAP 4096            /* members of the gain level at slot k beyond k that a synchronous entry enumerates at     */
+                                      /* most (it tries 64, 256, 1 024, 4 096)                                                  */
 
 typedef struct kbest_opts {
     int32_t  maximize;     /* reference `maximize` argument                       */

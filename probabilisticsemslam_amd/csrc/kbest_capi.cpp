@@ -1749,7 +1749,7 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
     for (int b = 0; b < B; b++) {
         if ((fl[b] & KBEST_TIE_BOUNDARY) && !(fl[b] & KBEST_TIE_RESOLVED)) fl[b] |= KBEST_TIE_UNRESOLVED;
         if ((fl[b] & KBEST_TIE_UNORDERED) && !(fl[b] & KBEST_TIE_RESOLVED)) {
-            // a run of more than 1 024 equal gains inside the first pass' tables: the tables are in the caller's memory -- ordered here
+            // a run of more than 4 096 equal gains inside the first pass' tables: the tables are in the caller's memory -- ordered here
             const bool i8 = (opts->flags & KBEST_FLAG_TABLES_I8) != 0;
             const int n = nf[b] < 0 ? 0 : (nf[b] > k ? k : nf[b]), M = nCol ? nCol[b] : maxCol, N = nRow ? nRow[b] : maxRow;
             if (i8)
@@ -1821,11 +1821,11 @@ void kb_complete_tie_levels(kbest_ctx *ctx, const kbest_opts *opts, int B, int m
             const int b = idx[i];
             const double *g2 = sGain.data() + (size_t)i * k2;
             // the level is complete when the table goes on beyond it (or the problem has no more assignments) -- and the table is
-            // in the canonical order throughout (a run of more than 1 024 equal gains is left as the kernel emitted it)
+            // in the canonical order throughout (a run of more than 4 096 equal gains is left as the kernel emitted it)
             const bool complete = sNf[i] >= k && (sNf[i] < k2 || g2[k2 - 1] != g2[k - 1]);
             if (!complete) continue;
             if (fl2[i] & KBEST_TIE_UNORDERED) {
-                // a run of more than 1 024 equal gains, which the finishing launch leaves as the kernel emitted it: ordered here (the
+                // a run of more than 4 096 equal gains, which the finishing launch leaves as the kernel emitted it: ordered here (the
                 // re-run's tables are in host memory)
                 const int nn = sNf[i] < k2 ? sNf[i] : k2;
                 if (i8)
@@ -2507,7 +2507,7 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
             goto general;  // (the fused kernel takes none of this batch's shapes)
         }
         // (64, then 256, then KBEST_TIE_CAP solutions beyond k: until the level ends inside the table)
-        for (int extra : {64, 256, 1024}) {
+        for (int extra : {64, 256, 1024, KBEST_TIE_CAP}) {
             std::vector<int> tied;
             for (int b = 0; b < B; b++)
                 if ((tfl[b] & KBEST_TIE_BOUNDARY) && !(tfl[b] & KBEST_TIE_RESOLVED) && (extra == 64 ? !(tfl[b] & KBEST_TIE_UNRESOLVED) : true)) tied.push_back(b);
@@ -2705,7 +2705,7 @@ general:
             for (int b = 0; b < B; b++)
                 if (tfl[b] & KBEST_TIE_BOUNDARY) tied.push_back(b);
             if (!tied.empty() && !quad) {
-                for (int extra : {64, 256, 1024}) {
+                for (int extra : {64, 256, 1024, KBEST_TIE_CAP}) {
                     const int Bs = (int)tied.size();
                     std::vector<int32_t> sL(Bs), sM(Bs), sNf(Bs), sT(Bs, 0);
                     std::vector<int64_t> sCo(Bs), sPo(Bs);

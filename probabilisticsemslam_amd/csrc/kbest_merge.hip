@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(256) finish_tables_kernel(const int *nf, const
                                                             T *row4col, T *col4row, double *gain, const double *tieGain, int *tieFlags, int baseFlags,
                                                             int order)
 {
-    __shared__ unsigned short scr[3 * TIE_RUN_CAP];
+    __shared__ unsigned short scr[TIE_SCR_U16];
     const int b = blockIdx.x;
     const long long base = (long long)b * k;
     // (the tie-free problem's whole cost is ONE round trip to memory: the gains are read before the count is known -- slots

@@ -25,7 +25,11 @@
 
 namespace kb {
 
-constexpr int TIE_RUN_CAP = 1024;  // longest run of equal gains that tie_tail() orders (3 x u16 of LDS scratch per entry)
+constexpr int TIE_RUN_CAP = 4096;  // longest run of equal gains that tie_tail() orders (4 x u16 of LDS scratch per entry + TIE_SCR_EXTRA)
+constexpr int TIE_RANK_MAX = 48;   // runs up to this length: every entry counts the entries before it (L^2 comparisons, no set-up);
+                                   // longer runs: a radix sort over the columns (below)
+constexpr int TIE_SCR_EXTRA = 64 * 32;  // u16 counters of the radix sort: one row of 32 digit counts per lane
+constexpr int TIE_SCR_U16 = 4 * TIE_RUN_CAP + TIE_SCR_EXTRA;  // what finish_tables_kernel gives tie_tail
 
 // Loads that do not go through the CU's L1: the tables are written by OTHER waves of the workgroup (visible in L2 after the
 // barrier), and a line of the gain table is shared with the neighbouring problem, whose workgroup may run on this CU later and
@@ -53,8 +57,8 @@ __device__ __forceinline__ bool tie_lex_less(const int *row4col, long long a, lo
 
 // One wave (all 64 lanes) of the launch behind the enumeration (finish_tables_kernel, kbest_merge.hip).  gain points at slot 0 of ONE problem's
 // gains; row4col / col4row are the launch's tables (int32, or int8 when i8), r4cBase / c4rBase the ELEMENT index of the
-// problem's slot 0 in them (col4row may be null); nf slots are filled; scr: >= 3 * scrEntries u16 of LDS nobody else uses any
-// more.  haveExtra / extra: the gain of the (nf+1)-th solution, when the kernel enumerated it (nf == the caller's k then).
+// problem's slot 0 in them (col4row may be null); nf slots are filled; scr: >= 4 * scrEntries + TIE_SCR_EXTRA u16 of LDS nobody
+// else uses any more.  haveExtra / extra: the gain of the (nf+1)-th solution, when the kernel enumerated it (nf == the caller's k then).
 // order = false: the tables lie in HOST memory (the kernels of a host-buffer entry write them there over the link): runs of equal
 // gains are only REPORTED (KBEST_TIE_INSIDE) -- the entry brings them into the order on the host, where the tables are anyway
 // (order_ties_host, kbest_capi.cpp); swapping rows of host memory from here costs a link round trip per access, and a soak of
@@ -76,7 +80,7 @@ __device__ __attribute__((noinline)) int tie_tail(const double *gain, int *row4c
     flags |= KBEST_TIE_INSIDE;
     if (!order) return flags;
     const int cap = scrEntries < TIE_RUN_CAP ? scrEntries : TIE_RUN_CAP;
-    unsigned short *inv = scr, *pos = scr + cap, *at = scr + 2 * cap;
+    unsigned short *inv = scr, *pos = scr + cap, *at = scr + 2 * cap, *xtra = scr + 3 * cap;  // (xtra: cap + TIE_SCR_EXTRA entries)
     int s = 0;
     while (s + 1 < nf) {
         // end of the run of gains equal to slot s (uniform)
@@ -90,11 +94,73 @@ __device__ __attribute__((noinline)) int tie_tail(const double *gain, int *row4c
         }
         const int L = e - s;
         if (L > 1 && L <= cap) {
-            // rank of every entry of the run among the run (row4col lexicographic; distinct assignments: a permutation)
+            if (L <= TIE_RANK_MAX) {
+                // rank of every entry of the run among the run (row4col lexicographic; distinct assignments: a permutation)
+                for (int i = lane; i < L; i += 64) {
+                    int rank = 0;
+                    for (int j = 0; j < L; j++) rank += (j != i && tie_lex_less(row4col, r4cBase + (long long)(s + j) * ldCol, r4cBase + (long long)(s + i) * ldCol, M, i8)) ? 1 : 0;
+                    inv[rank] = (unsigned short)i;
+                }
+            } else {
+                // A long run (integer-like costs: hundreds to thousands of equal gains; L^2 lexicographic comparisons of Murty
+                // neighbours, which share long prefixes, took tens of milliseconds): LSD radix sort of the run's indices over the
+                // columns, last column first, two 5-bit digits per column (indices < 1 024), each pass a stable counting sort -- a
+                // lane owns a contiguous chunk of the current order and a private row of 32 counters, so nothing is atomic and
+                // equal keys keep their order.  4 096 entries x 64 columns: ~1 ms.
+                unsigned short *pa = inv, *pb = xtra, *cnt = xtra + cap;
+                const int chunk = (L + 63) >> 6, lo = lane * chunk < L ? lane * chunk : L, hi = lo + chunk < L ? lo + chunk : L;
+                for (int i = lane; i < L; i += 64) pa[i] = (unsigned short)i;
+                wave_fence();
+                for (int c = M - 1; c >= 0; c--) {
+                    for (int shift = 0; shift < 10; shift += 5) {
+                        for (int d = 0; d < 32; d++) cnt[lane * 32 + d] = 0;
+                        int seen = 0;
+                        for (int i = lo; i < hi; i++) {
+                            const int key = tie_ld_index(row4col, r4cBase + (long long)(s + pa[i]) * ldCol + c, i8);
+                            cnt[lane * 32 + ((key >> shift) & 31)]++;
+                            seen |= key;
+                        }
+                        wave_fence();
+                        // where the entries of (digit, lane) start: all smaller digits, then the same digit on the lanes before
+                        int tot = 0;
+                        if (lane < 32)
+                            for (int l2 = 0; l2 < 64; l2++) tot += cnt[l2 * 32 + lane];
+                        int incl = tot;  // (lanes 32 .. 63 carry zeros: the scan runs over the whole wave)
+                        for (int dd = 1; dd < 32; dd <<= 1) {
+                            const int t = __shfl_up(incl, dd);
+                            if (lane >= dd) incl += t;
+                        }
+                        const int base = incl - tot;
+                        const bool oneDigit = __ballot(lane < 32 && tot == L) != 0ull;  // every key has the same digit: the order stands
+                        if (!oneDigit) {
+                            if (lane < 32) {
+                                int run = base;
+                                for (int l2 = 0; l2 < 64; l2++) {
+                                    const int n = cnt[l2 * 32 + lane];
+                                    cnt[l2 * 32 + lane] = (unsigned short)run;
+                                    run += n;
+                                }
+                            }
+                            wave_fence();
+                            for (int i = lo; i < hi; i++) {
+                                const int idx = pa[i];
+                                const int key = tie_ld_index(row4col, r4cBase + (long long)(s + idx) * ldCol + c, i8);
+                                const int d = (key >> shift) & 31;
+                                pb[cnt[lane * 32 + d]++] = (unsigned short)idx;
+                            }
+                            wave_fence();
+                            unsigned short *t = pa; pa = pb; pb = t;
+                        }
+                        // (the high digit only where some key has bits there: rows below 32 need one pass per column)
+                        if (__ballot((seen >> 5) != 0) == 0ull) break;
+                    }
+                }
+                if (pa != inv) {
+                    for (int i = lane; i < L; i += 64) inv[i] = pa[i];
+                }
+            }
+            wave_fence();
             for (int i = lane; i < L; i += 64) {
-                int rank = 0;
-                for (int j = 0; j < L; j++) rank += (j != i && tie_lex_less(row4col, r4cBase + (long long)(s + j) * ldCol, r4cBase + (long long)(s + i) * ldCol, M, i8)) ? 1 : 0;
-                inv[rank] = (unsigned short)i;
                 pos[i] = (unsigned short)i;
                 at[i] = (unsigned short)i;
             }

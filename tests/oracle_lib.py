@@ -276,8 +276,8 @@ def canonical_kbest(cost, N, M, k, maximize=False, cutoff=None, cap=4096, run_ca
     solutions ordered by (gain, row4col lexicographic); when the k-th and the (k+1)-th best gains are equal, the
     lexicographically first assignments of that gain level.  Returns (nf, row4col[nf, M], gain[nf], boundary, resolved):
     boundary = such a tie exists, resolved = its gain level ends within `cap` solutions beyond k (what a synchronous
-    entry completes: KBEST_TIE_CAP = 4 096 for kbest_batch_f64, 1 024 for the association entries) and -- run_cap, association
-    entries only: 1 024 -- has at most run_cap members in all (the longest run of equal gains the device orders, TIE_RUN_CAP).
+    entry completes: KBEST_TIE_CAP = 4 096) and -- run_cap, association
+    entries only: 4 096 -- has at most run_cap members in all (the longest run of equal gains the device orders, TIE_RUN_CAP).
     The level itself is enumerated completely here, whatever its size."""
     big = k + cap
     while True:
@@ -303,8 +303,8 @@ def weights_from_solutions(row4col, gain, nL, nM, gate=True):
     return probs
 
 
-def canonical_assignment_prob(cond, nL, nM, k, cap=1024):
+def canonical_assignment_prob(cond, nL, nM, k, cap=4096):
     """assignmentProb on a conditioned block with the engine's one order of exact ties: the canonical k best within the
     cutoff 42 (canonical_kbest), then the reference's accumulation.  Returns (probs, nf, boundary, resolved)."""
-    n, r4c, g, boundary, resolved = canonical_kbest(cond, nL + nM, nM, k, cutoff=42.0, cap=cap, run_cap=1024)
+    n, r4c, g, boundary, resolved = canonical_kbest(cond, nL + nM, nM, k, cutoff=42.0, cap=cap, run_cap=4096)
     return weights_from_solutions(r4c, g, nL, nM), n, boundary, resolved

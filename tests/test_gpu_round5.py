@@ -244,7 +244,7 @@ def test_exact_ties_association_one_answer_whatever_the_batch(monkeypatch, shape
     for f in probe:
         cond, idx = ol.condition_costs(frames[f], nL + nM, nM)
         condL = len(idx) - nM
-        p, n, boundary, resolved = ol.canonical_assignment_prob(cond, condL, nM, k, cap=1024)
+        p, n, boundary, resolved = ol.canonical_assignment_prob(cond, condL, nM, k, cap=E.KBEST_TIE_CAP)
         full = np.zeros((nM, nL + 1))
         full[:, idx[:condL]] = p[:, :condL]   # getAssignmentProbs' scatter (assignment.cpp:68-74)
         full[:, nL] = p[:, condL]
