@@ -532,9 +532,29 @@ def multi_entry_dense(costs, N, M, k, G, ref_nf, ref_gain):
     out = (nf, r4c, c4r, gain)
     tl = multi.timeline()
     agree = bool(multi.tables_agree())
+    xbytes, _ = multi.exchange_bytes()
+    # the same matrices in SUBTREE mode (the north star's latency mode: every device enumerates its share of the root's subtrees of
+    # every matrix; all-gather of the top-k costs + sum all-reduce of the winners' rows), a small batch: what the exchange moves
+    sub = None
+    try:
+        Bs = 32
+        r2, c2, g2, n2 = np.zeros((Bs, k, M), np.int32), np.zeros((Bs, k, N), np.int32), np.zeros((Bs, k)), np.zeros(Bs, np.int32)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            rc = multi.lib.kbest_batch_f64_multi_ex(multi.m, C.byref(o), pk_engine.KBEST_MULTI_SUBTREE, 0, Bs, N, M, None, None, p(costs), k, p(r2), p(c2), p(g2), p(n2))
+            ts.append(time.perf_counter() - t0)
+            assert rc == 0, multi.lib.kbest_multi_last_error(multi.m)
+        sb, path = multi.exchange_bytes()
+        sub = {"matrices": Bs, "ms": 1e3 * min(ts), "bytes_inbound_per_device": sb, "path": {1: "gains first", 2: "whole lists"}.get(path, path),
+               "equals_batch_mode": bool((n2 == ref_nf[:Bs]).all() and (g2.view(np.int64) == ref_gain[:Bs].view(np.int64)).all() and (r2 == r4c[:Bs]).all()),
+               "whole_lists_would_move": (G - 1) * Bs * k * (8 + M) if G > 1 else 0}
+    except Exception as ex:  # noqa: BLE001
+        sub = {"error": repr(ex)}
     multi.close()
     assert (out[0] == ref_nf).all() and (out[3].view(np.int64) == ref_gain.view(np.int64)).all(), "multi-device entry differs from the single-device result"
     return {"devices": G, "ms": 1e3 * best, "value": float(out[0].sum()) / best, "unit": "assignments/s", "tables_agree": agree,
+            "exchange_bytes_inbound_per_device": xbytes, "subtree_mode": sub,
             "timeline_ms": {"what": "host times of the last call per device, ms since entry: worker started, first upload issued, first "
                                     "kernel issued, fed (own results back), exchange issued, done (kbest_multi_timeline)",
                             "per_device": [[round(1e3 * float(x), 3) for x in row] for row in tl]},

@@ -115,6 +115,9 @@ enum {
 #define KBEST_TIE_CAP 4096            /* members of the gain level at slot k beyond k that a synchronous entry enumerates at     */
                                       /* most (it tries 64, 256, 1 024, 4 096)                                                  */
 
+/* ALWAYS initialise a kbest_opts with kbest_default_opts() and then set what you need: the struct has grown at its end
+ * (tie_flags, round 5) and may grow again; a struct filled member by member by code compiled against an older header -- or one
+ * that was never initialised -- hands the engine an indeterminate tie_flags pointer, which the finishing launch WRITES through. */
 typedef struct kbest_opts {
     int32_t  maximize;     /* reference `maximize` argument                       */
     int32_t  use_cutoff;   /* 0: kBest2D semantics; 1: kBest2DCutoff semantics    */
