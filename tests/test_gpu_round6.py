@@ -389,6 +389,35 @@ def test_resolve_ties_dev_completes_the_device_tables(engine):
         cg[cg >= M] = -1
         cw[cw >= M] = -1
         assert (cg == cw).all()
+    # a RAGGED batch (per-problem shapes, packed blocks) through the same helper
+    B, maxRow, maxCol, k = 60, 12, 9, 25
+    nRow = rng.integers(4, maxRow + 1, B).astype(np.int32)
+    nCol = np.array([int(rng.integers(2, min(r, maxCol) + 1)) for r in nRow], np.int32)
+    blocks = [rng.integers(0, 4, int(r) * int(c)).astype(np.float64) for r, c in zip(nRow, nCol)]
+    off = np.zeros(B, np.int64)
+    off[1:] = np.cumsum([len(b_) for b_ in blocks[:-1]])
+    flat = np.concatenate(blocks)
+    want = engine.kbest(flat, maxRow, maxCol, k, nRow=nRow, nCol=nCol, costOff=off, tie_flags=True)
+    d_cost = torch.from_numpy(flat).to(dev)
+    d_nR, d_nC, d_off = torch.from_numpy(nRow).to(dev), torch.from_numpy(nCol).to(dev), torch.from_numpy(off).to(dev)
+    d_r = torch.full((B, k, maxCol), -1, dtype=torch.int32, device=dev)
+    d_c = torch.full((B, k, maxRow), -1, dtype=torch.int32, device=dev)
+    d_g = torch.zeros((B, k), dtype=torch.float64, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_f = torch.zeros(B, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    st = torch.cuda.current_stream().cuda_stream
+    engine.kbest_dev(d_cost, B, maxRow, maxCol, k, d_r, d_c, d_g, d_n, stream=st, d_tie_flags=d_f, d_nRow=d_nR, d_nCol=d_nC, d_costOff=d_off)
+    engine.resolve_ties_dev(d_cost, B, maxRow, maxCol, k, d_r, d_c, d_g, d_f, stream=st, d_nRow=d_nR, d_nCol=d_nC, d_costOff=d_off)
+    torch.cuda.synchronize()
+    f1, nfd = d_f.cpu().numpy(), d_n.cpu().numpy()
+    assert (f1 == want[4]).all() and ((f1 & E.KBEST_TIE_RESOLVED) != 0).sum() > 0 and (nfd == want[0]).all()
+    rg, gg = d_r.cpu().numpy(), d_g.cpu().numpy()
+    for b in range(B):
+        if f1[b] & E.KBEST_TIE_UNRESOLVED:
+            continue
+        n, m = int(nfd[b]), int(nCol[b])
+        assert (rg[b, :n, :m] == want[1][b, :n, :m]).all() and (bits(gg[b, :n]) == bits(want[3][b, :n])).all(), b
     # the multi-device batch entry completes tied levels by itself: in the caller's tables AND in the devices' slices
     N, M, k, hi, B = 10, 10, 30, 4, 50
     costs = rng.integers(0, hi, size=(B, N * M)).astype(np.float64)
