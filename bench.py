@@ -628,6 +628,40 @@ def equal_costs_entry(eng, torch, dev, tstream, B=4, N=64, M=64, k=1000):
     return out
 
 
+def reference_order_entry(eng, torch, dev, tstream):
+    """KBEST_FLAG_REFERENCE_ORDER (kbest_exact.hip): the reference's own order of operations on the device -- what it costs next to
+    the default kernels, on 256 of the headline's matrices and on 1 000 integer-cost 28x10 problems (masses of exact ties)."""
+    from probabilisticsemslam_amd import workloads as wl
+    out = {}
+    rng = np.random.default_rng(3)
+    for name, costs, N, M, k in (("dense_64x64_k200", wl.dense_batch(256, 64, 64, wl.DENSE_CONFIGS["c4"][4]), 64, 64, 200),
+                                 ("integer_28x10_k200", rng.integers(0, 12, size=(1000, 280)).astype(np.float64), 28, 10, 200)):
+        B = costs.shape[0]
+        d_cost = torch.from_numpy(np.ascontiguousarray(costs)).to(dev)
+        d_r = torch.empty((B, k, M), dtype=torch.int32, device=dev)
+        d_c = torch.empty((B, k, N), dtype=torch.int32, device=dev)
+        d_g = torch.empty((B, k), dtype=torch.float64, device=dev)
+        d_n = torch.empty(B, dtype=torch.int32, device=dev)
+        ms = {}
+        for mode in (True, False):
+            ts = []
+            for i in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                eng.kbest_dev(d_cost, B, N, M, k, d_r, d_c, d_g, d_n, stream=tstream.cuda_stream, reference_order=mode)
+                torch.cuda.synchronize()
+                if i:
+                    ts.append(1e3 * (time.perf_counter() - t0))
+            ms["reference_order" if mode else "default"] = min(ts)
+            if mode:
+                g_ref = d_g.cpu().numpy().copy()
+        out[name] = {"problems": B, "ms_reference_order": ms["reference_order"], "ms_default": ms["default"],
+                     "same_gains": bool((g_ref.view(np.int64) == d_g.cpu().numpy().view(np.int64)).all())}
+    out["what"] = ("kbest_batch_f64_dev with KBEST_FLAG_REFERENCE_ORDER: the reference's algorithm as it stands, one wave per problem, exact ties in "
+                   "the reference's heap order (tests: bit-identical to the compiled reference's goldens incl. col4row) -- next to the default kernels")
+    return out
+
+
 def dense_entry(eng, torch, cfg, steps, warmup, dev, tstream, cpu_sample, no_cpu):
     """One BASELINE config as an entry of the `configs` block (single GPU)."""
     from probabilisticsemslam_amd import workloads as wl
@@ -1080,6 +1114,10 @@ def main():
                 except Exception as ex:  # never lose the headline over the extra entry
                     share["error"] = repr(ex)
                 extra["c4_share8"] = share
+                try:
+                    extra["reference_order"] = reference_order_entry(eng, torch, dev, tstream)
+                except Exception as ex:
+                    extra["reference_order"] = {"error": repr(ex)}
                 try:
                     extra["ties_all_equal_costs"] = equal_costs_entry(eng, torch, dev, tstream)
                 except Exception as ex:

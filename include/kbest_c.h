@@ -73,7 +73,7 @@ enum {
     KBEST_OK = 0,
     KBEST_ERR_NO_DEVICE = -1,   /* no HIP device / HIP runtime error at create    */
     KBEST_ERR_BAD_ARG = -2,     /* null pointer, k < 1, numRow < numCol, ...      */
-    KBEST_ERR_UNSUPPORTED = -3, /* numRow > KBEST_MAX_DIM_WIDE                    */
+    KBEST_ERR_UNSUPPORTED = -3, /* numRow > KBEST_MAX_DIM_EXACT (association entries: > KBEST_MAX_DIM_WIDE kept rows) */
     KBEST_ERR_HIP = -4,         /* a HIP call failed; see kbest_last_error()      */
     KBEST_ERR_NOMEM = -5,
     KBEST_ERR_NOT_RESERVED = -6, /* kbest_batch_f64_dev: workspace too small, call kbest_reserve first   */
@@ -81,8 +81,12 @@ enum {
 };
 
 #define KBEST_MAX_DIM 64       /* rows per problem handled by the LDS-resident kernel (the fast path)      */
-#define KBEST_MAX_DIM_WIDE 1024 /* rows per problem handled at all: beyond KBEST_MAX_DIM, or with a k beyond */
-                               /* the LDS candidate pool, the general-size kernel (HBM work space) runs      */
+#define KBEST_MAX_DIM_WIDE 1024 /* rows per problem of the general-size kernel (beyond KBEST_MAX_DIM, or a k beyond the LDS    */
+                               /* candidate pool: HBM work space)                                                         */
+#define KBEST_MAX_DIM_EXACT 16384 /* rows per problem handled at all: beyond KBEST_MAX_DIM_WIDE the reference-order kernel runs */
+                               /* (kbest_exact.hip: the reference's algorithm as it stands, one wave per problem -- slow, total; */
+                               /* its work space holds one record of 25 numRow bytes per pushed hypothesis: KBEST_ERR_NOMEM    */
+                               /* where 1 + (k - 1) numCol of them do not fit 16 GiB)                                         */
 
 /* flags */
 #define KBEST_FLAG_NO_PRUNE 1u     /* disable early termination (for counting P)   */
@@ -94,6 +98,12 @@ enum {
 #define KBEST_FLAG_NO_REORDER 128u /* 64-row kernel: enumerate in the reference's column order (A/B tests; same results)          */
 #define KBEST_FLAG_NO_OPT 256u     /* 64-row kernel: no optimistic bounds / re-split tickets (A/B tests; same results)           */
 #define KBEST_FLAG_NO_TIE_CHECK 512u /* do not enumerate the (k+1)-th solution / order exact ties canonically (see "Order of exact ties") */
+#define KBEST_FLAG_REFERENCE_ORDER 2048u /* kbest_batch_f64[_dev]: the REFERENCE's own order of operations (kbest_exact.hip) -- the   */
+                                        /* zero-padded N x N formulation, one priority queue of fully solved hypotheses with libstdc++'s */
+                                        /* sift rules: hypotheses with exactly equal gains come out in the order the reference's heap  */
+                                        /* pops them (shortestPathCPP.cpp:30-42, 574) and col4row names the padded column of every      */
+                                        /* left-over row as the reference does.  Slow (one wave per problem, nothing pruned): for     */
+                                        /* callers with integer-like costs who need the reference's answer slot for slot.  No tie flags. */
 #define KBEST_FLAG_NO_TIE_RESOLVE 1024u /* synchronous entries: report a tie at slot k (KBEST_TIE_BOUNDARY), do not complete its gain level */
 #define KBEST_FLAG_TABLES_I8 64u   /* kbest_batch_f64 / kbest_batch_f64_dev: row4col / col4row are tables of int8_t (same shapes, */
                                    /* same values, -1 = unassigned / unused) instead of int32_t: every index of a problem of up   */
@@ -235,6 +245,10 @@ int kbest_to_probs_f64(kbest_ctx *ctx, double *x, int64_t n);
  * reported with nf = -3 (KBEST_ERR_INTERNAL from the host entries), and the context re-zeroes its progress words before the
  * next relay launch after any failed entry. */
 int kbest_reserve(kbest_ctx *ctx, int B, int maxRow, int k);
+/* The same for launches that run on the reference-order kernel (KBEST_FLAG_REFERENCE_ORDER, or maxRow > KBEST_MAX_DIM_WIDE): its work
+ * space -- per resident problem a padded cost copy (8 maxRow^2 bytes) and a pool of 2 + (k - 1) maxCol hypotheses of 25 maxRow bytes.
+ * kbest_batch_f64_dev needs it up front for such launches; the host entries grow it on demand. */
+int kbest_reserve_exact(kbest_ctx *ctx, int B, int maxRow, int maxCol, int k);
 
 /* Diagnostic builds only (make -C probabilisticsemslam_amd/csrc PROFILE=1): device buffer of B*16 uint64
  * that receives per-matrix cycle stamps of the kernel phases.  The regular build never touches it. */
@@ -327,6 +341,7 @@ long long kbest_relay_launches(kbest_ctx *ctx);  /* (-1: null context) */
 #define KBEST_ROUTE_FAST 4    /* the 64-row kernel                                                      */
 #define KBEST_ROUTE_WIDE 8    /* the general-size kernel: any size, any k                               */
 #define KBEST_ROUTE_RELAY 16  /* ... as a relay of several workgroups per matrix                        */
+#define KBEST_ROUTE_EXACT 64  /* the reference-order kernel (KBEST_FLAG_REFERENCE_ORDER; > 1 024 rows)   */
 #define KBEST_ROUTE_EXTRA 32  /* the launch enumerated the solution behind the k-th (exact ties checked) */
 int kbest_last_route(kbest_ctx *ctx);
 

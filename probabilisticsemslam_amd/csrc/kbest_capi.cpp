@@ -138,6 +138,7 @@ struct kbest_ctx {
     int splitForce = 0;       // KBEST_SPLIT: workgroups per matrix (2 / 4) whenever the split is possible (A/B tests)
     DevBufRaw splitBuf;       // per-share result tables + shared thresholds of the split
     DevBufRaw tieBuf;         // [B] fp64: gain of the solution behind the tables (exact ties, kbest_ties.h)
+    DevBufRaw exactBuf;       // work space of the reference-order kernel (kbest_exact.hip)
     DevBufRaw relayBuf;       // relay launches of the 64-row kernel: [B] LDS images (kbest_engine.hip)
     DevBufRaw relayFlags;     // ... and three words per matrix: claimed / done / gone (zeroed when the buffer is made, put back to zero by every launch)
     long long relayLaunches = 0;  // relay launches made (kbest_relay_launches)
@@ -482,6 +483,7 @@ int kbest_destroy(kbest_ctx *ctx)
     if (ctx->splitBuf.p) (void)hipFree(ctx->splitBuf.p);
     if (ctx->tieBuf.p) (void)hipFree(ctx->tieBuf.p);
     if (ctx->relayBuf.p) (void)hipFree(ctx->relayBuf.p);
+    if (ctx->exactBuf.p) (void)hipFree(ctx->exactBuf.p);
     if (ctx->relayFlags.p) (void)hipFree(ctx->relayFlags.p);
     if (ctx->lastEvent) (void)hipEventDestroy(ctx->lastEvent);
     for (auto &a : ctx->aux)
@@ -694,11 +696,58 @@ static int reserve_for(kbest_ctx *ctx, int B, int maxRow, int k);
 static int relay_plan(const kbest_ctx *ctx, int B, int fastRow, int k, unsigned flags, const Shape &shp, size_t *imgOut, double *gensOut = nullptr, bool useCutoff = false);
 static int relay_reserve(kbest_ctx *ctx, int B, size_t img, bool grow);
 
+// Work space of the reference-order kernel (kbest_exact.hip): per resident problem ("slot") a padded cost copy and a pool with one
+// record per hypothesis the reference would hold -- at most 1 + (k - 1) numCol pushes, plus the one being built.  The grid strides
+// over the batch: as many slots as fit 16 GiB, at most eight per CU (one wave each: latency-bound).
+struct ExactPlan { int grid, hypPerSlot; size_t slotBytes; };
+
+// (gigabytes: sized to the need, not to the next power of two as raw_reserve does)
+static int exact_reserve(kbest_ctx *ctx, size_t need)
+{
+    DevBufRaw &d = ctx->exactBuf;
+    if (need <= d.bytes) return KBEST_OK;
+    const size_t cap = (need + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    if (d.p) { HIP_TRY(ctx, hipDeviceSynchronize()); (void)hipFree(d.p); d.p = nullptr; d.bytes = 0; }
+    hipError_t e = hipMalloc(&d.p, cap);
+    if (e != hipSuccess) { d.p = nullptr; return fail(ctx, KBEST_ERR_NOMEM, "hipMalloc(reference-order work space)", e); }
+    d.bytes = cap;
+    return KBEST_OK;
+}
+
+static bool plan_exact(const kbest_ctx *ctx, int B, int maxRow, int maxCol, int k, ExactPlan *out)
+{
+    const long long hyp = 2 + (long long)(k > 1 ? k - 1 : 0) * maxCol;
+    if (hyp > 0x7fffffffLL) return false;
+    const long long slot = kb::exact_slot_bytes(maxRow, (int)hyp);
+    const long long budget = 16LL << 30;
+    long long g = budget / (slot > 0 ? slot : 1);
+    if (g < 1) return false;
+    if (g > 8LL * ctx->nCU) g = 8LL * ctx->nCU;
+    if (g > B) g = B;
+    out->grid = (int)g;
+    out->hypPerSlot = (int)hyp;
+    out->slotBytes = (size_t)slot;
+    return true;
+}
+
+int kbest_reserve_exact(kbest_ctx *ctx, int B, int maxRow, int maxCol, int k)
+{
+    if (!ctx || B < 0 || maxRow < 1 || maxCol < 1 || maxCol > maxRow || k < 1) return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_reserve_exact: bad argument");
+    if (maxRow > KBEST_MAX_DIM_EXACT) return fail(ctx, KBEST_ERR_UNSUPPORTED, "numRow > KBEST_MAX_DIM_EXACT");
+    if (B == 0) return KBEST_OK;
+    ExactPlan pl;
+    if (!plan_exact(ctx, B, maxRow, maxCol, k, &pl)) return fail(ctx, KBEST_ERR_NOMEM, "reference-order kernel: one problem's pool of hypotheses does not fit 16 GiB");
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return exact_reserve(ctx, pl.slotBytes * (size_t)pl.grid);
+}
+
 int kbest_reserve(kbest_ctx *ctx, int B, int maxRow, int k)
 {
     if (!ctx || B < 0 || maxRow < 1 || k < 1) return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_reserve: bad argument");
-    if (maxRow > KBEST_MAX_DIM_WIDE) return fail(ctx, KBEST_ERR_UNSUPPORTED, "numRow > KBEST_MAX_DIM_WIDE");
+    if (maxRow > KBEST_MAX_DIM_EXACT) return fail(ctx, KBEST_ERR_UNSUPPORTED, "numRow > KBEST_MAX_DIM_EXACT");
     if (B == 0) return KBEST_OK;
+    if (maxRow > KBEST_MAX_DIM_WIDE) return kbest_reserve_exact(ctx, B, maxRow, maxRow, k);  // (only the reference-order kernel takes such problems)
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     // a launch enumerates k + 1 solutions unless told not to (exact ties, kbest_ties.h): room for either
     int rc = reserve_for(ctx, B, maxRow, k);
@@ -881,7 +930,8 @@ static int relay_reserve(kbest_ctx *ctx, int B, size_t img, bool grow)
 static bool tie_mode(const kbest_ctx *ctx, const kbest_opts *opts, bool rootOnly)
 {
     return !ctx->noTie && !rootOnly && opts->root_col_stride <= 1 &&
-           !(opts->flags & (KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_PRUNE | KBEST_FLAG_RECT_ROOT | KBEST_FLAG_NO_SHIFT | KBEST_FLAG_NO_TIE_CHECK));
+           !(opts->flags & (KBEST_FLAG_COUNT_PUSHED | KBEST_FLAG_NO_PRUNE | KBEST_FLAG_RECT_ROOT | KBEST_FLAG_NO_SHIFT | KBEST_FLAG_NO_TIE_CHECK |
+                            KBEST_FLAG_REFERENCE_ORDER));
 }
 
 static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, int maxCol,
@@ -895,11 +945,59 @@ static int batch_dev_impl(kbest_ctx *ctx, const kbest_opts *opts, int B, int max
         return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_batch_f64_dev: bad argument");
     if ((d_nRow == nullptr) != (d_nCol == nullptr))
         return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_batch_f64_dev: give both nRow and nCol or neither");
-    if (maxRow > KBEST_MAX_DIM_WIDE) return fail(ctx, KBEST_ERR_UNSUPPORTED, "numRow > KBEST_MAX_DIM_WIDE");
+    if (maxRow > KBEST_MAX_DIM_EXACT) return fail(ctx, KBEST_ERR_UNSUPPORTED, "numRow > KBEST_MAX_DIM_EXACT");
     const bool tabI8 = (opts->flags & KBEST_FLAG_TABLES_I8) != 0;
     if (tabI8 && extra) return fail(ctx, KBEST_ERR_BAD_ARG, "KBEST_FLAG_TABLES_I8: k-best entries only");
     if (tabI8 && maxRow > 127) return fail(ctx, KBEST_ERR_UNSUPPORTED, "KBEST_FLAG_TABLES_I8: numRow > 127 does not fit int8 tables");
     if (B == 0) return KBEST_OK;
+    // The reference's own order of operations (kbest_exact.hip): asked for (KBEST_FLAG_REFERENCE_ORDER), or the only kernel for the size.
+    if (!extra && ((opts->flags & KBEST_FLAG_REFERENCE_ORDER) || maxRow > KBEST_MAX_DIM_WIDE)) {
+        if (opts->root_col_stride > 1) return fail(ctx, KBEST_ERR_BAD_ARG, "root-subtree sharding: not with the reference-order kernel");
+        ExactPlan pl;
+        const int LBx = sub ? sub->logicalB : B;
+        if (!plan_exact(ctx, LBx, maxRow, maxCol, k, &pl)) return fail(ctx, KBEST_ERR_NOMEM, "reference-order kernel: one problem's pool of hypotheses does not fit 16 GiB");
+        if (sub) return fail(ctx, KBEST_ERR_INTERNAL, "a piece of a batch on the reference-order kernel");
+        std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+        int rc = order_behind_last(ctx, s);
+        if (rc != KBEST_OK) return rc;
+        const Launched mark{ctx, s};
+        const size_t need = pl.slotBytes * (size_t)pl.grid;
+        if (need > ctx->exactBuf.bytes) {
+            if (!grow) return fail(ctx, KBEST_ERR_NOT_RESERVED, "reference-order work space too small: call kbest_reserve_exact first");
+            rc = exact_reserve(ctx, need);
+            if (rc != KBEST_OK) return rc;
+        }
+        kb::ExactParams ep;
+        memset(&ep, 0, sizeof(ep));
+        ep.cost = d_cost;
+        ep.costOff = reinterpret_cast<const long long *>(d_costOff);
+        ep.nRow = d_nRow;
+        ep.nCol = d_nCol;
+        ep.B = B;
+        ep.maxRow = maxRow;
+        ep.maxCol = maxCol;
+        ep.ldRow = maxRow;
+        ep.ldCol = maxCol;
+        ep.k = k;
+        ep.maximize = opts->maximize;
+        ep.useCutoff = opts->use_cutoff;
+        ep.flags = opts->flags;
+        ep.cutoff = opts->cutoff;
+        ep.row4col = d_row4col;
+        ep.col4row = d_col4row;
+        ep.gain = d_gain;
+        ep.nf = d_nf;
+        ep.pushed = (opts->flags & KBEST_FLAG_COUNT_PUSHED) ? reinterpret_cast<long long *>(d_pushed) : nullptr;
+        ep.work = static_cast<unsigned char *>(ctx->exactBuf.p);
+        ep.hypPerSlot = pl.hypPerSlot;
+        const hipError_t e = kb::launch_kbest_exact(ep, pl.grid, s);
+        if (e != hipSuccess) return fail(ctx, KBEST_ERR_HIP, "reference-order kbest kernel launch", e);
+        ctx->lastRoute = KBEST_ROUTE_EXACT;
+        if (opts->tie_flags) HIP_TRY(ctx, hipMemsetAsync(opts->tie_flags, 0, (size_t)B * 4, s));  // (this mode IS the reference's order: nothing to flag)
+        return KBEST_OK;
+    }
     // Two kernels share the work.  The LDS kernel (kbest_engine.hip) takes every problem of up to KBEST_MAX_DIM
     // rows as long as the candidate pool for k fits its LDS; the general-size kernel (kbest_wide.hip) takes the
     // rest: larger problems of a mixed batch (shapes on the device: both are launched, each skips the other's

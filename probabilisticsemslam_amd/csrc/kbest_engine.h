@@ -484,6 +484,24 @@ struct KeepTables { int32_t *row4col, *col4row; double *gain; int32_t *nf; doubl
 hipError_t launch_widen_i8(const signed char *src, int *dst, long long n, hipStream_t stream);
 hipError_t launch_copy_words(const void *src, void *dst, long long bytes, hipStream_t stream);  // bytes: a multiple of 4
 double now_s();
+// kbest_exact.hip: kBest2D / kBest2DCutoff in the reference's own order of operations (padded N x N formulation, one heap of fully
+// solved hypotheses with libstdc++'s sift rules), any size: KBEST_FLAG_REFERENCE_ORDER, and every problem beyond KBEST_MAX_DIM_WIDE rows
+struct ExactParams {
+    const double *cost;
+    const long long *costOff;
+    const int *nRow, *nCol;
+    int B, maxRow, maxCol, ldRow, ldCol, k, maximize, useCutoff;
+    unsigned flags;            // KBEST_FLAG_TABLES_I8
+    double cutoff;
+    int *row4col, *col4row;    // [B][k][ldCol] / [B][k][ldRow] (col4row may be null; padded columns named as the reference names them)
+    double *gain;
+    int *nf;                   // -4: the work space's pool of hypotheses ran out
+    long long *pushed;         // or null
+    unsigned char *work;       // gridDim.x slots of exact_slot_bytes(maxRow, hypPerSlot)
+    int hypPerSlot;
+};
+long long exact_slot_bytes(int maxRow, int hypPerSlot);
+hipError_t launch_kbest_exact(const ExactParams &p, int grid, hipStream_t stream);
 hipError_t launch_merge_topk(const MergeParams &p, int B, hipStream_t stream);
 hipError_t launch_merge_gains(const MergeGainsParams &p, hipStream_t stream);
 hipError_t launch_zero_words(unsigned *w, long long n, hipStream_t stream);

@@ -4,10 +4,12 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <limits>
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "kbest_c.h"
 
@@ -38,6 +40,10 @@ size_t kbest_one(size_t k, size_t numRow, size_t numCol, bool maximize, const do
     o.maximize = maximize;
     o.use_cutoff = useCut;
     o.cutoff = cutoff;
+    // KBEST_SHIM_REFERENCE_ORDER=1: the drop-in answers in the reference's own order of operations (kbest_exact.hip) -- exact ties as
+    // the reference's heap pops them, col4row on padded columns as the reference names them; slower (kbest_c.h, KBEST_FLAG_REFERENCE_ORDER)
+    static const bool refOrder = [] { const char *e = getenv("KBEST_SHIM_REFERENCE_ORDER"); return e && *e && *e != '0'; }();
+    if (refOrder) o.flags |= KBEST_FLAG_REFERENCE_ORDER;
     std::vector<int32_t> r4c(k * numCol), c4r(k * numRow);
     int32_t nf = 0;
     check(ctx, kbest_batch_f64(ctx, &o, 1, (int)numRow, (int)numCol, nullptr, nullptr, C, nullptr, (int)k, r4c.data(),

@@ -16,13 +16,16 @@ KBEST_FLAG_TABLES_I8 = 64
 KBEST_FLAG_NO_REORDER = 128
 KBEST_FLAG_NO_TIE_CHECK = 512
 KBEST_FLAG_NO_TIE_RESOLVE = 1024
+KBEST_FLAG_REFERENCE_ORDER = 2048
 # per-problem tie flags (kbest_c.h, "Order of exact ties")
 KBEST_TIE_INSIDE, KBEST_TIE_BOUNDARY, KBEST_TIE_RESOLVED = 1, 2, 4
 KBEST_TIE_UNCHECKED, KBEST_TIE_UNORDERED, KBEST_TIE_UNRESOLVED = 1 << 28, 1 << 29, 1 << 30
 KBEST_ROUTE_LANE, KBEST_ROUTE_SMALL, KBEST_ROUTE_FAST, KBEST_ROUTE_WIDE, KBEST_ROUTE_RELAY, KBEST_ROUTE_EXTRA = 1, 2, 4, 8, 16, 32
+KBEST_ROUTE_EXACT = 64
 KBEST_TIE_CAP = 4096
 KBEST_MAX_DIM = 64        # rows handled by the LDS-resident kernel
-KBEST_MAX_DIM_WIDE = 1024  # rows handled at all (general-size kernel beyond KBEST_MAX_DIM)
+KBEST_MAX_DIM_WIDE = 1024  # rows of the general-size kernel (beyond KBEST_MAX_DIM)
+KBEST_MAX_DIM_EXACT = 16384  # rows handled at all (the reference-order kernel beyond KBEST_MAX_DIM_WIDE)
 
 # every symbol include/kbest_c.h declares
 C_ABI_SYMBOLS = (
@@ -36,7 +39,7 @@ C_ABI_SYMBOLS = (
     "kbest_multi_tables_agree", "kbest_batch_f64_multi_ex", "kbest_merge_topk_f64_dev", "kbest_register_host_buffer",
     "kbest_unregister_host_buffer", "kbest_multi_timeline", "kbest_last_tie_flags", "kbest_set_assoc_tie_flags_dev",
     "kbest_relay_launches", "kbest_merge_topk_i8_f64_dev", "kbest_merge_gains_f64_dev", "kbest_multi_exchange_bytes",
-    "kbest_last_route", "kbest_resolve_ties_dev", "kbest_multi_last_tie_flags",
+    "kbest_last_route", "kbest_resolve_ties_dev", "kbest_multi_last_tie_flags", "kbest_reserve_exact",
 )
 KBEST_MULTI_STAMPS = 6
 KBEST_MULTI_BATCH, KBEST_MULTI_SUBTREE = 0, 1
@@ -80,6 +83,8 @@ def load_library():
     lib.kbest_last_error.restype = C.c_char_p
     lib.kbest_device_count.restype = C.c_int
     lib.kbest_reserve.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    if hasattr(lib, "kbest_reserve_exact"):
+        lib.kbest_reserve_exact.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.kbest_set_profile_buffer.argtypes = [vp, vp]
     lib.kbest_batch_f64_dev.argtypes = [vp, C.POINTER(KBestOpts), C.c_int, C.c_int, C.c_int, i32p, i32p, dp, i64p,
                                         C.c_int, i32p, i32p, dp, i32p, i64p, vp]
@@ -178,12 +183,14 @@ class KBestEngine:
     # ---- host buffers -----------------------------------------------------------------
     def kbest(self, costs, N, M, k, maximize=False, cutoff=None, nRow=None, nCol=None, costOff=None,
               count_pushed=False, prune=True, root_shard=None, tables_i8=False, reorder=True, tie_flags=False,
-              tie_check=True, tie_resolve=True):
+              tie_check=True, tie_resolve=True, reference_order=False):
         """Batched kBest2D / kBest2DCutoff.  costs: (B, N*M) for uniform shapes, or a flat packed
         array with per-problem nRow/nCol/costOff (N, M are then the maxima).
         Returns (nf[B], row4col[B,k,M], col4row[B,k,N], gain[B,k]) (+ pushed[B] if count_pushed).
         tables_i8: the two tables come back as int8 (KBEST_FLAG_TABLES_I8; N <= 127).
-        tie_flags: also return the per-problem KBEST_TIE_* flags (last element of the tuple)."""
+        tie_flags: also return the per-problem KBEST_TIE_* flags (last element of the tuple).
+        reference_order: KBEST_FLAG_REFERENCE_ORDER -- the reference's own order of operations (exact ties in its heap's order,
+        col4row on padded columns as the reference names them; slow)."""
         costs = np.ascontiguousarray(costs, dtype=np.float64)
         if nRow is None:
             costs = costs.reshape(-1, N * M)
@@ -201,7 +208,8 @@ class KBestEngine:
         pushed = np.zeros(B, np.int64) if count_pushed else None
         flags = ((KBEST_FLAG_COUNT_PUSHED if count_pushed else 0) | (0 if prune else KBEST_FLAG_NO_PRUNE) |
                  (KBEST_FLAG_TABLES_I8 if tables_i8 else 0) | (0 if reorder else KBEST_FLAG_NO_REORDER) |
-                 (0 if tie_check else KBEST_FLAG_NO_TIE_CHECK) | (0 if tie_resolve else KBEST_FLAG_NO_TIE_RESOLVE))
+                 (0 if tie_check else KBEST_FLAG_NO_TIE_CHECK) | (0 if tie_resolve else KBEST_FLAG_NO_TIE_RESOLVE) |
+                 (KBEST_FLAG_REFERENCE_ORDER if reference_order else 0))
         o = self._opts(maximize, cutoff, flags, root_shard)
         tf = np.zeros(B, np.int32) if tie_flags else None
         if tf is not None:
@@ -350,17 +358,21 @@ class KBestEngine:
 
     def kbest_dev(self, d_cost, B, N, M, k, d_row4col, d_col4row, d_gain, d_nf, maximize=False, cutoff=None,
                   d_pushed=None, prune=True, stream=None, root_shard=None, d_nRow=None, d_nCol=None, d_costOff=None,
-                  tables_i8=False, d_tie_flags=None, tie_check=True):
+                  tables_i8=False, d_tie_flags=None, tie_check=True, reference_order=False):
         """Asynchronous launch on `stream` (a raw hipStream_t integer, e.g.
         torch.cuda.current_stream().cuda_stream).  All d_* are torch CUDA tensors (tables_i8: d_row4col / d_col4row int8;
         d_tie_flags: int32 [B], receives the KBEST_TIE_* flags)."""
         flags = ((KBEST_FLAG_COUNT_PUSHED if d_pushed is not None else 0) | (0 if prune else KBEST_FLAG_NO_PRUNE) |
-                 (KBEST_FLAG_TABLES_I8 if tables_i8 else 0) | (0 if tie_check else KBEST_FLAG_NO_TIE_CHECK))
+                 (KBEST_FLAG_TABLES_I8 if tables_i8 else 0) | (0 if tie_check else KBEST_FLAG_NO_TIE_CHECK) |
+                 (KBEST_FLAG_REFERENCE_ORDER if reference_order else 0))
         o = self._opts(maximize, cutoff, flags, root_shard)
         if d_tie_flags is not None:
             o.tie_flags = d_tie_flags.data_ptr()
         # the C entry never allocates (kbest_c.h): size the workspace here (a no-op once it is large enough)
-        self.reserve(B, N, k)
+        if reference_order or N > KBEST_MAX_DIM_WIDE:
+            self._check(self.lib.kbest_reserve_exact(self.ctx, B, N, M, k))
+        else:
+            self.reserve(B, N, k)
 
         def dp(t):
             return None if t is None else C.c_void_p(t.data_ptr())

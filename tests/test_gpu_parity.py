@@ -207,7 +207,7 @@ def test_reference_named_mirrors(eng):
 
 def test_unsupported_and_bad_args(eng):
     with pytest.raises(pk.KBestError):
-        eng.kbest(np.zeros((1, 1025 * 2)), 1025, 2, 2)      # beyond KBEST_MAX_DIM_WIDE: loud, no fallback
+        eng.kbest(np.zeros((1, 16385 * 2)), 16385, 2, 2)    # beyond KBEST_MAX_DIM_EXACT: loud, no fallback
     with pytest.raises(pk.KBestError):
         eng.kbest(np.zeros((1, 6)), 2, 3, 2)                # numRow < numCol
 

@@ -544,3 +544,124 @@ def test_fused_association_entry_takes_k_1024():
             if knobs and k == 1024:  # the fused enumeration kernel at its limit: no solution behind the k-th
                 assert (d_fl.cpu().numpy() & pk.engine.KBEST_TIE_UNCHECKED).all()
             eng.close()
+
+
+# ------------------------------------------------------------------------------------ the reference's own order (kbest_exact.hip)
+def test_reference_order_reproduces_the_compiled_reference_goldens(engine, golden):
+    """KBEST_FLAG_REFERENCE_ORDER: the reference's algorithm as it stands (padded N x N problem, one heap of fully solved
+    hypotheses with libstdc++'s sift rules).  Every case of kbest_golden.npz -- the outputs of the UNMODIFIED reference -- slot for
+    slot and bit for bit, col4row included WITHOUT mapping the padded columns (SURVEY quirk 6 does not apply to this kernel)."""
+    E = pk.engine
+    for name in golden.names:
+        c = golden.case(name)
+        cost = np.array(c["cost"], dtype=np.float64)
+        if not np.isfinite(cost).all() and np.isnan(cost).any():
+            continue
+        nf, r4c, c4r, g = engine.kbest(cost.reshape(1, -1), c["N"], c["M"], c["k"], maximize=c["maximize"], cutoff=c["cutoff"],
+                                      reference_order=True)
+        assert engine.last_route() == E.KBEST_ROUTE_EXACT, name
+        n = c["nf"]
+        assert nf[0] == n, (name, nf[0], n)
+        assert (r4c[0, :n] == c["row4col"]).all(), name
+        assert (c4r[0, :n] == c["col4row"]).all(), name
+        assert (bits(g[0, :n]) == bits(c["gain"])).all(), name
+
+
+@pytest.mark.parametrize("shape", [(6, 6, 40, 3), (9, 9, 60, 4), (12, 7, 50, 5), (20, 20, 120, 30), (30, 10, 200, 12)])
+def test_reference_order_on_exact_ties_is_the_heap_order(engine, shape):
+    """Integer costs: masses of exactly equal gains.  With KBEST_FLAG_REFERENCE_ORDER the tables are the checker's -- whose pop order
+    of equal gains is pinned to the compiled reference's std::priority_queue (tests/test_oracle_golden.py) -- slot for slot: the
+    assignments IN THE REFERENCE'S ORDER, the raw col4row, the gains' bits, the push count; also with a cutoff and maximising.
+    The default rule ((gain, row4col) lexicographic) gives the same gains and, as a rule, another order: both are checked.
+    shortestPathCPP.cpp:30-42, 574."""
+    N, M, k, hi = shape
+    rng = np.random.default_rng(7 * N + k)
+    B = 9
+    costs = rng.integers(0, hi, size=(B, N * M)).astype(np.float64)
+    differs = 0
+    for kw in ({}, {"cutoff": float(hi)}, {"maximize": True}):
+        nf, r4c, c4r, g, pushed = engine.kbest(costs, N, M, k, reference_order=True, count_pushed=True, **kw)
+        onf, or4c, oc4r, og, opushed = ol.orc_kbest_batch(costs, N, M, k, **kw)
+        assert (nf == onf).all() and (pushed == opushed).all(), kw
+        for b in range(B):
+            n = int(onf[b])
+            assert (r4c[b, :n] == or4c[b, :n]).all(), (kw, b)
+            assert (c4r[b, :n] == oc4r[b, :n]).all(), (kw, b)
+            assert (bits(g[b, :n]) == bits(og[b, :n])).all(), (kw, b)
+        d = engine.kbest(costs, N, M, k, **kw)   # the engine's own rule: same gains, its own order of ties
+        assert (d[0] == onf).all()
+        for b in range(B):
+            n = int(onf[b])
+            assert (bits(d[3][b, :n]) == bits(og[b, :n])).all(), (kw, b)
+            differs += int((d[1][b, :n] != or4c[b, :n]).any())
+    assert differs > 0  # (the two orders of ties are different rules)
+
+
+def test_reference_order_through_the_device_entry_and_ragged(engine):
+    """The same kernel behind kbest_batch_f64_dev (kbest_reserve_exact first), on a ragged batch with an infeasible problem, a
+    problem with fewer than k assignments and int8 tables."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(21)
+    B, maxRow, maxCol, k = 40, 14, 9, 60
+    nRow = rng.integers(2, maxRow + 1, B).astype(np.int32)
+    nCol = np.array([int(rng.integers(1, min(r, maxCol) + 1)) for r in nRow], np.int32)
+    nRow[3], nCol[3] = 3, 3
+    blocks = [rng.integers(0, 6, int(r) * int(c)).astype(np.float64) for r, c in zip(nRow, nCol)]
+    blocks[7][: int(nRow[7])] = np.inf
+    off = np.zeros(B, np.int64)
+    off[1:] = np.cumsum([len(b_) for b_ in blocks[:-1]])
+    d_cost = torch.from_numpy(np.concatenate(blocks)).to(dev)
+    d_nR, d_nC, d_off = torch.from_numpy(nRow).to(dev), torch.from_numpy(nCol).to(dev), torch.from_numpy(off).to(dev)
+    d_r = torch.full((B, k, maxCol), -7, dtype=torch.int8, device=dev)
+    d_c = torch.full((B, k, maxRow), -7, dtype=torch.int8, device=dev)
+    d_g = torch.zeros((B, k), dtype=torch.float64, device=dev)
+    d_n = torch.full((B,), -7, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    engine.kbest_dev(d_cost, B, maxRow, maxCol, k, d_r, d_c, d_g, d_n, stream=torch.cuda.current_stream().cuda_stream,
+                     d_nRow=d_nR, d_nCol=d_nC, d_costOff=d_off, tables_i8=True, reference_order=True)
+    torch.cuda.synchronize()
+    assert engine.last_route() == pk.engine.KBEST_ROUTE_EXACT
+    nf, r4c, c4r, g = d_n.cpu().numpy(), d_r.cpu().numpy(), d_c.cpu().numpy(), d_g.cpu().numpy()
+    for b in range(B):
+        n_, m_ = int(nRow[b]), int(nCol[b])
+        wn, wr, wc, wg = ol.orc_kbest(blocks[b], n_, m_, k)
+        assert nf[b] == wn, b
+        assert (r4c[b, :wn, :m_] == wr[:wn]).all() and (c4r[b, :wn, :n_] == wc[:wn]).all() and (bits(g[b, :wn]) == bits(wg[:wn])).all(), b
+    assert nf[7] == 0 and nf[3] == 6
+
+
+def test_more_than_1024_rows_run_on_the_reference_order_kernel(engine):
+    """kBest2D has no size limit in the reference (cpp:571-644).  Beyond KBEST_MAX_DIM_WIDE (1 024 rows) the reference-order kernel
+    takes the problem: 1 100 x 6 and 1 300 x 3, k = 8, against the checker, slot for slot (raw col4row included)."""
+    rng = np.random.default_rng(5)
+    for (N, M, k, B) in ((1100, 6, 8, 2), (1300, 3, 5, 1)):
+        costs = rng.random((B, N * M))
+        nf, r4c, c4r, g = engine.kbest(costs, N, M, k)
+        assert engine.last_route() == pk.engine.KBEST_ROUTE_EXACT
+        onf, or4c, oc4r, og, _ = ol.orc_kbest_batch(costs, N, M, k)
+        assert (nf == onf).all() and (r4c == or4c).all() and (c4r == oc4r).all() and (bits(g) == bits(og)).all(), (N, M)
+
+
+def test_shims_in_reference_order(tmp_path):
+    """KBEST_SHIM_REFERENCE_ORDER=1: the reference-named C++ shims (kBest2D / kBest2DCutoff of include/kbest_shims.hpp) answer through
+    the reference-order kernel.  The compiled C++ caller of tests/cpp/shim_drop_in.cpp prints the same lines with and without it on
+    tie-free costs (8x8 and a rectangular 9x5 problem, whose col4row names padded columns: the shim maps nothing)."""
+    exe = str(tmp_path / "shim_drop_in")
+    libdir = os.path.join(ROOT, "probabilisticsemslam_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "shim_drop_in.cpp"),
+                           "-o", exe, "-L", libdir, "-l:libkbest_amd.so", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib",
+                           "-lamdhip64"])
+    for args in (["8", "8", "10", "12345"], ["9", "5", "12", "777"]):
+        a = subprocess.check_output([exe] + args, text=True, env=_clean_env()).splitlines()
+        b = subprocess.check_output([exe] + args, text=True, env=_clean_env(KBEST_SHIM_REFERENCE_ORDER="1")).splitlines()
+        nf = int(a[0].split()[2])
+        assert a[0] == b[0] and nf > 0
+        for s in range(nf):  # gains and row4col identical; col4row identical on the real columns (padded columns: the reference's names in b)
+            ta, tb = a[1 + s].split(), b[1 + s].split()
+            i_c4r = ta.index("c4r")
+            assert ta[: i_c4r] == tb[: i_c4r], (args, s)
+            M = int(args[1])
+            ca = [int(x) if int(x) < M else -1 for x in ta[i_c4r + 1:]]
+            cb = [int(x) if int(x) < M else -1 for x in tb[i_c4r + 1:]]
+            assert ca == cb, (args, s)
