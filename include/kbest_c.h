@@ -50,6 +50,8 @@
  * report the flags; kbest_resolve_ties_dev completes their tables afterwards, and the multi-device batch entry does so by itself.
  * The exhaustive association kernel and the bounded walk see a whole gain level and keep its lexicographically first
  * members themselves, whatever its size.  KBEST_FLAG_NO_TIE_CHECK switches all of it off (the kernels' own orders, round 4).
+ * A caller who needs the REFERENCE's own order of equal gains instead -- slot for slot what its std::priority_queue pops -- sets
+ * KBEST_FLAG_REFERENCE_ORDER: the problem then runs on the reference-order kernel (kbest_exact.hip; slow, exact).
  * Index outputs are int32 (the reference ABI uses ptrdiff_t; the C++ shims in
  * include/kbest_shims.hpp widen on the host).
  *

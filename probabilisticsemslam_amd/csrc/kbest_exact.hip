@@ -18,9 +18,11 @@
 //
 // One WAVE per problem: the lanes share the rows of a Dijkstra step (row = lane, lane + 64, ...: the reduced costs
 // ((delta + C) - u) - v left to right, the strict-'<' update, the minimum with the LOWEST row among equal values: cpp:183-191,
-// 313-320), the dual update and the copies of a hypothesis; the queue and the path flip are one lane's.  Everything lives in an
-// HBM work space (cost copy, scratch, the pool of hypotheses: 25 N + 16 bytes each, one per push): this is the slow, total,
-// literal path -- a 64 x 64, k = 200 problem takes milliseconds here against 0.7 ms on the LDS kernel -- and is only taken
+// 313-320), the dual update and the copies of a hypothesis; the queue and the path flip are one lane's.  The cost copy, the queue
+// and the pool of hypotheses (25 N + 16 bytes each, one per push) live in an HBM work space; up to 1 024 rows the scratch of a
+// search and the hypothesis being solved are in LDS (a child only reaches the pool if it is feasible and not cut).  This is the
+// slow, total, literal path -- 256 problems of 64 x 64, k = 200 take 154 ms here (0.6 ms per problem; the reference on one host core:
+// 10 ms per problem) against 0.7 ms on the LDS kernel; 1 000 integer-cost 28 x 10 problems 12 ms against 4.5 -- and is only taken
 // when asked for or when no other kernel takes the size.
 #include <hip/hip_runtime.h>
 
@@ -30,6 +32,9 @@
 namespace kb {
 
 namespace {
+
+constexpr int EXACT_LDS_ROWS = 1024;  // up to here a search's scratch (19 bytes per row) and the hypothesis being solved (25) lie in LDS
+constexpr int EXACT_LDS_C_ROWS = 64;  // ... and the padded cost copy as well
 
 struct ExLayout {  // byte offsets inside one slot of the work space (D = maxRow, H = hypotheses per slot)
     long long C, spc, pred, scanCols, scanRow, inScan, forbStart, heap, freeL, hgain, pool, hypStride, total;
@@ -48,7 +53,7 @@ struct ExLayout {  // byte offsets inside one slot of the work space (D = maxRow
         scanRow = o;   o += up(D);
         inScan = o;    o += up(D);
         forbStart = o; o += up(D);
-        heap = o;      o += up(4 * H);
+        heap = o;      o += up(16 * H);  // (gain, hypothesis) pairs: one load per comparison
         freeL = o;     o += up(4 * H);
         hgain = o;     o += up(8 * H);
         pool = o;      o += hypStride * H;
@@ -67,18 +72,37 @@ struct Hyp {
 
 long long exact_slot_bytes(int maxRow, int hypPerSlot) { return ExLayout(maxRow, hypPerSlot).total; }
 
+// MODE 0: everything in the work space (more than EXACT_LDS_ROWS rows); 1: the scratch of a search and the hypothesis being solved in
+// LDS; 2: the padded cost copy as well (up to EXACT_LDS_C_ROWS rows).  A template parameter, not a run-time choice: the pointers must
+// be LDS pointers at compile time (flat accesses to LDS cost a global access' latency).
+template <int MODE>
 __global__ void __launch_bounds__(64) kbest_exact_kernel(ExactParams p)
 {
     const int lane = threadIdx.x;
     const double INF = d_inf();
     const ExLayout L(p.maxRow, p.hypPerSlot);
     unsigned char *ws = p.work + (long long)blockIdx.x * L.total;
-    double *Cw = reinterpret_cast<double *>(ws + L.C);
-    double *spc = reinterpret_cast<double *>(ws + L.spc);
-    int *pred = reinterpret_cast<int *>(ws + L.pred);
-    int *scanCols = reinterpret_cast<int *>(ws + L.scanCols);
-    unsigned char *scanRow = ws + L.scanRow, *inScan = ws + L.inScan, *forbStart = ws + L.forbStart;
-    int *heap = reinterpret_cast<int *>(ws + L.heap);
+    // the padded cost copy: in LDS up to EXACT_LDS_C_ROWS rows (32 KB at 64), else in the work space
+    constexpr bool cInLds = MODE == 2;
+    // the scratch of a search (ScratchSpace, hpp:73-142): in LDS up to EXACT_LDS_ROWS rows, in the work space beyond
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr bool inLds = MODE >= 1;
+    const long long Dm = p.maxRow;
+    double *spc = inLds ? reinterpret_cast<double *>(lds) : reinterpret_cast<double *>(ws + L.spc);
+    int *pred = inLds ? reinterpret_cast<int *>(lds + 8 * Dm) : reinterpret_cast<int *>(ws + L.pred);
+    int *scanCols = inLds ? reinterpret_cast<int *>(lds + 12 * Dm) : reinterpret_cast<int *>(ws + L.scanCols);
+    unsigned char *scanRow = inLds ? lds + 16 * Dm : ws + L.scanRow;
+    unsigned char *inScan = inLds ? lds + 17 * Dm : ws + L.inScan;
+    unsigned char *forbStart = inLds ? lds + 18 * Dm : ws + L.forbStart;
+    // ... and so does the hypothesis that is being solved (a child is copied from its parent into LDS, solved there, and only
+    // goes to the pool in HBM if it is feasible and not cut): 25 bytes per row more
+    const long long ldsHyp0 = (19 * Dm + 63) & ~63ll;
+    const Hyp hLds{reinterpret_cast<double *>(lds + ldsHyp0), reinterpret_cast<double *>(lds + ldsHyp0 + 8 * Dm),
+                   reinterpret_cast<int *>(lds + ldsHyp0 + 16 * Dm), reinterpret_cast<int *>(lds + ldsHyp0 + 20 * Dm),
+                   lds + ldsHyp0 + 24 * Dm, reinterpret_cast<int *>(lds + ldsHyp0 + 25 * Dm + (8 - (25 * Dm) % 8) % 8)};
+    double *Cw = cInLds ? reinterpret_cast<double *>(lds + ((ldsHyp0 + 25 * Dm + 16 + 63) & ~63ll)) : reinterpret_cast<double *>(ws + L.C);
+    struct HeapE { double g; long long idx; };
+    HeapE *heap = reinterpret_cast<HeapE *>(ws + L.heap);
     int *freeL = reinterpret_cast<int *>(ws + L.freeL);
     double *hgain = reinterpret_cast<double *>(ws + L.hgain);
     const bool tabI8 = (p.flags & KBEST_FLAG_TABLES_I8) != 0;
@@ -178,11 +202,12 @@ __global__ void __launch_bounds__(64) kbest_exact_kernel(ExactParams p)
             return g;
         };
         // std::priority_queue<pMurtyHyp> with a < b <=> a.gain > b.gain (cpp:35-37): libstdc++'s __push_heap / __adjust_heap
-        auto sift_up = [&](int hole, int top, int val) {  // (lane 0)
-            const double g = hgain[val];
+        auto sift_up = [&](int hole, int top, HeapE val) {  // (lane 0)
             int parent = (hole - 1) / 2;
-            while (hole > top && hgain[heap[parent]] > g) {
-                heap[hole] = heap[parent];
+            while (hole > top) {
+                const HeapE pe = heap[parent];
+                if (!(pe.g > val.g)) break;
+                heap[hole] = pe;
                 hole = parent;
                 parent = (hole - 1) / 2;
             }
@@ -192,22 +217,24 @@ __global__ void __launch_bounds__(64) kbest_exact_kernel(ExactParams p)
             if (lane == 0) {
                 const int n = sh[0];
                 sh[0] = n + 1;
-                sift_up(n, 0, hidx);
+                sift_up(n, 0, HeapE{hgain[hidx], hidx});
             }
             sync();
         };
         auto heap_pop = [&]() -> int {
             if (lane == 0) {
-                const int top = heap[0];
+                const int top = (int)heap[0].idx;
                 const int len = sh[0] - 1;
-                const int val = heap[len];
+                const HeapE val = heap[len];
                 sh[0] = len;
                 if (len > 0) {
                     int hole = 0, child = 0;
                     while (child < (len - 1) / 2) {
                         child = 2 * (child + 1);
-                        if (hgain[heap[child]] > hgain[heap[child - 1]]) child--;
-                        heap[hole] = heap[child];
+                        HeapE ce = heap[child];
+                        const HeapE le = heap[child - 1];  // (two independent loads)
+                        if (ce.g > le.g) { child--; ce = le; }
+                        heap[hole] = ce;
                         hole = child;
                     }
                     if ((len & 1) == 0 && child == (len - 2) / 2) {
@@ -249,7 +276,8 @@ __global__ void __launch_bounds__(64) kbest_exact_kernel(ExactParams p)
         // ---- root: shortestPathCPP (cpp:119-238), N augmentations in column order on the padded problem ----
         const int root = alloc_hyp();
         if (root < 0) { if (lane == 0) p.nf[b] = -4; continue; }
-        const Hyp hr = hyp(root);
+        const Hyp hrG = hyp(root);
+        const Hyp hr = inLds ? hLds : hrG;
         for (int i = lane; i < D; i += 64) { hr.c4r[i] = -1; hr.r4c[i] = -1; hr.u[i] = 0.0; hr.v[i] = 0.0; hr.forb[i] = 0; }
         if (lane == 0) hr.act[0] = 0;
         sync();
@@ -264,10 +292,17 @@ __global__ void __launch_bounds__(64) kbest_exact_kernel(ExactParams p)
             sync();
             continue;
         }
+        // a hypothesis solved in LDS goes to its record in the pool
+        auto store_hyp = [&](const Hyp &src, const Hyp &dst) {
+            for (int i = lane; i < D; i += 64) { dst.r4c[i] = src.r4c[i]; dst.c4r[i] = src.c4r[i]; dst.u[i] = src.u[i]; dst.v[i] = src.v[i]; dst.forb[i] = src.forb[i]; }
+            if (lane == 0) dst.act[0] = src.act[0];
+            sync();
+        };
         {
             const double g = gain_of(hr, M);
             if (lane == 0) { hgain[root] = g; hr.forb[hr.r4c[0]] = 1; }  // cpp:232-235
             sync();
+            if (inLds) store_hyp(hr, hrG);
         }
         const double gain0 = emit(root, 0);
         const double cutoffGain = maximize ? (hgain[root] - p.cutoff) : (hgain[root] + p.cutoff);  // cpp:680-686
@@ -286,20 +321,30 @@ __global__ void __launch_bounds__(64) kbest_exact_kernel(ExactParams p)
                 for (int j = c + lane; j < D; j += 64) inScan[hp.r4c[j]] = 1;
                 if (c != a && lane == 0) forbStart[hp.r4c[c]] = 1;  // cpp:516
                 sync();
-                const int ch = alloc_hyp();
-                if (ch < 0) { err = 1; break; }
-                const Hyp hc = hyp(ch);
+                int ch = -1;
+                if (!inLds) {
+                    ch = alloc_hyp();
+                    if (ch < 0) { err = 1; break; }
+                }
+                const Hyp hc = inLds ? hLds : hyp(ch);
                 for (int i = lane; i < D; i += 64) {  // shortestPathUpdateCPP, cpp:262-278
                     hc.r4c[i] = hp.r4c[i]; hc.c4r[i] = hp.c4r[i]; hc.u[i] = hp.u[i]; hc.v[i] = hp.v[i]; hc.forb[i] = forbStart[i];
                 }
                 sync();
                 if (lane == 0) { hc.act[0] = c; hc.c4r[hc.r4c[c]] = -1; hc.r4c[c] = -1; }
                 sync();
-                if (augment(hc, c, true)) { free_hyp(ch); continue; }  // infeasible child: gain -1, dropped (cpp:496, 521)
+                if (augment(hc, c, true)) { if (!inLds) free_hyp(ch); continue; }  // infeasible child: gain -1, dropped (cpp:496, 521)
                 const double g = gain_of(hc, M);
                 const bool cut = p.useCutoff && (maximize ? (g < cutoffGain) : (g > cutoffGain));  // cutHyp, hpp:130-131
-                if (cut) { free_hyp(ch); continue; }
-                if (lane == 0) { hgain[ch] = g; hc.forb[hc.r4c[c]] = 1; }  // cpp:362
+                if (cut) { if (!inLds) free_hyp(ch); continue; }
+                if (lane == 0) hc.forb[hc.r4c[c]] = 1;  // cpp:362
+                sync();
+                if (inLds) {
+                    ch = alloc_hyp();
+                    if (ch < 0) { err = 1; break; }
+                    store_hyp(hc, hyp(ch));
+                }
+                if (lane == 0) hgain[ch] = g;
                 sync();
                 heap_push(ch);
                 pushed++;
@@ -307,7 +352,7 @@ __global__ void __launch_bounds__(64) kbest_exact_kernel(ExactParams p)
             if (err) break;
             free_hyp(cur);
             if (sh[0] == 0) break;
-            const double gs = emit(heap[0], sweep);
+            const double gs = emit((int)heap[0].idx, sweep);
             if (p.useCutoff) {  // cpp:709-719
                 if (!maximize) { if (gs > gain0 + p.cutoff) break; }
                 else           { if (gs < gain0 - p.cutoff) break; }
@@ -324,7 +369,11 @@ __global__ void __launch_bounds__(64) kbest_exact_kernel(ExactParams p)
 hipError_t launch_kbest_exact(const ExactParams &p, int grid, hipStream_t stream)
 {
     if (p.B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(kbest_exact_kernel, dim3(grid), dim3(64), 0, stream, p);
+    int lds = p.maxRow <= EXACT_LDS_ROWS ? ((19 * p.maxRow + 63) & ~63) + 25 * p.maxRow + 16 + 64 : 0;
+    if (p.maxRow <= EXACT_LDS_C_ROWS) lds = ((lds + 63) & ~63) + 8 * p.maxRow * p.maxRow;
+    if (p.maxRow <= EXACT_LDS_C_ROWS) hipLaunchKernelGGL(kbest_exact_kernel<2>, dim3(grid), dim3(64), lds, stream, p);
+    else if (p.maxRow <= EXACT_LDS_ROWS) hipLaunchKernelGGL(kbest_exact_kernel<1>, dim3(grid), dim3(64), lds, stream, p);
+    else hipLaunchKernelGGL(kbest_exact_kernel<0>, dim3(grid), dim3(64), lds, stream, p);
     return hipGetLastError();
 }
 
