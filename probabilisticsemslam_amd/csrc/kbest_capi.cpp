@@ -1531,14 +1531,16 @@ int kbest_batch_f64_keep(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxR
     // later generations' reads hide behind the running ones (1 024 x 64x64, k = 200: 3.74 -> 3.33 ms per call; 3.00 with
     // int8 tables).  Not for the general-size kernel (it re-reads costs from memory at every step), and not together with
     // copies back of pageable tables (measured slower: they share the link).
-    const bool zcCost = pinnedCost && direct && ctx->zcCost && maxRow <= KBEST_MAX_DIM && !ctx->forceWide &&
+    // (the reference-order kernel -- KBEST_FLAG_REFERENCE_ORDER -- runs whole batches from device memory: no pieces, no narrow staging)
+    const bool refOrder = (opts->flags & KBEST_FLAG_REFERENCE_ORDER) != 0;
+    const bool zcCost = pinnedCost && direct && ctx->zcCost && maxRow <= KBEST_MAX_DIM && !ctx->forceWide && !refOrder &&
                         k_fits_fast(ctx, B, maxRow < KBEST_MAX_DIM ? maxRow : KBEST_MAX_DIM, kk, opts->flags, nullptr);
     // Narrow staging: the reference's int32 tables are 107 MB for 1 024 x 64x64, k = 200, and the link, not the kernel, set the time
     // of this entry (3.1 ms against 1.8).  Every index fits a byte and col4row is the inverse of row4col on a square problem, so
     // the kernels write row4col as BYTES into pinned staging memory (13 MB, as the slots become final), in pieces, and host
     // threads widen a piece into the caller's row4col / col4row while the GPU works on the next one.  Uniform square batches of
     // up to 64 rows (every row has a column: the inverse is complete); everything else takes the path below.
-    const bool narrow = (!keep || keep->row4col8) && !tabI8 && !pushed && !nRow && !costOff && maxRow == maxCol && maxRow <= KBEST_MAX_DIM && !ctx->forceWide &&
+    const bool narrow = (!keep || keep->row4col8) && !tabI8 && !pushed && !nRow && !costOff && maxRow == maxCol && maxRow <= KBEST_MAX_DIM && !ctx->forceWide && !refOrder &&
                         !ctx->noNarrow && outBytesHint(B, k, maxRow, maxCol) >= ((size_t)8 << 20) &&
                         k_fits_fast(ctx, B, maxRow, kk, opts->flags, nullptr);
     if (narrow) {
@@ -1710,7 +1712,7 @@ int kbest_batch_f64_keep(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxR
     // 4.4 in two half-size launches (round 2), now four pieces; registered buffers 3.7 ms in one piece.
     const size_t outBytes = (nR4C + (col4row ? nC4R : 0)) * esz + nG * 8;
     const int fastRow = maxRow < KBEST_MAX_DIM ? maxRow : KBEST_MAX_DIM;
-    const bool canPiece = !costOff && maxRow <= KBEST_MAX_DIM && !ctx->forceWide && B >= 4 * ctx->nCU && outBytes >= ((size_t)32 << 20) &&
+    const bool canPiece = !costOff && maxRow <= KBEST_MAX_DIM && !ctx->forceWide && !refOrder && B >= 4 * ctx->nCU && outBytes >= ((size_t)32 << 20) &&
                           k_fits_fast(ctx, B, fastRow, kk, opts->flags, nullptr);
     const int nPiece = canPiece ? (ctx->pieces > 0 ? ctx->pieces : ((zcCost && direct) ? 1 : 4)) : 1;
     if (nPiece > 1)

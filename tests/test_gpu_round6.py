@@ -631,6 +631,32 @@ def test_reference_order_through_the_device_entry_and_ragged(engine):
     assert nf[7] == 0 and nf[3] == 6
 
 
+def test_reference_order_large_host_batch(engine):
+    """A batch that the host entry would send through the GPU in pieces with narrow staging (1 024 x 20x20, k = 200: 32 MB of tables)
+    runs as ONE launch of the reference-order kernel when that order is asked for; also through the multi-device entry."""
+    rng = np.random.default_rng(8)
+    B, N, M, k = 1024, 20, 20, 200
+    costs = rng.integers(0, 40, size=(B, N * M)).astype(np.float64)
+    nf, r4c, c4r, g = engine.kbest(costs, N, M, k, reference_order=True)
+    assert engine.last_route() == pk.engine.KBEST_ROUTE_EXACT
+    onf, or4c, oc4r, og, _ = ol.orc_kbest_batch(costs, N, M, k)
+    assert (nf == onf).all() and (r4c == or4c).all() and (c4r == oc4r).all() and (bits(g) == bits(og)).all()
+    import ctypes as C
+    multi = pk.KBestMulti([0, 0])
+    o = pk.engine.KBestOpts()
+    multi.lib.kbest_default_opts(C.byref(o))
+    o.flags = pk.engine.KBEST_FLAG_REFERENCE_ORDER
+    Bm = 64
+    r2, c2, g2, n2 = np.zeros((Bm, k, M), np.int32), np.zeros((Bm, k, N), np.int32), np.zeros((Bm, k)), np.zeros(Bm, np.int32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    cst = np.ascontiguousarray(costs[:Bm])
+    rc = multi.lib.kbest_batch_f64_multi(multi.m, C.byref(o), Bm, N, M, None, None, p(cst), k, p(r2), p(c2), p(g2), p(n2))
+    assert rc == 0, multi.lib.kbest_multi_last_error(multi.m)
+    assert multi.tables_agree()
+    multi.close()
+    assert (n2 == onf[:Bm]).all() and (r2 == or4c[:Bm]).all() and (c2 == oc4r[:Bm]).all() and (bits(g2) == bits(og[:Bm])).all()
+
+
 def test_more_than_1024_rows_run_on_the_reference_order_kernel(engine):
     """kBest2D has no size limit in the reference (cpp:571-644).  Beyond KBEST_MAX_DIM_WIDE (1 024 rows) the reference-order kernel
     takes the problem: 1 100 x 6 and 1 300 x 3, k = 8, against the checker, slot for slot (raw col4row included)."""
