@@ -327,6 +327,12 @@ int kbest_assoc_probs_batch_f64_dev(kbest_ctx *ctx, int B, int maxRawRow, int ma
                                     const int64_t *d_costOff, int k, int condition, double *d_probs,
                                     const int64_t *d_probOff, int32_t *d_nf, void *stream);
 int kbest_reserve_assoc(kbest_ctx *ctx, int B, int maxRawRow, int maxCol, int k);
+/* on != 0: the HOST-buffer association entries of this context (kbest_weights / assoc_probs / bruteforce / quadric_assoc) enumerate
+ * their k best in the REFERENCE's own order of operations (the reference-order kernel, as KBEST_FLAG_REFERENCE_ORDER does for
+ * kbest_batch_f64): where exactly equal gains straddle slot k the assignments that are weighed are the ones the reference's
+ * kBest2DCutoff returns (assignment.cpp:594), so the probabilities are the reference's there too (integer-like costs).  Slower: no
+ * fused kernels.  The reference-named shims switch it on with KBEST_SHIM_REFERENCE_ORDER=1. */
+int kbest_set_reference_order(kbest_ctx *ctx, int on);
 /* Where kbest_assoc_probs_batch_f64_dev writes its frames' KBEST_TIE_* flags ([B] int32 in device memory; NULL, the default:
  * nowhere).  Stays set until changed. */
 int kbest_set_assoc_tie_flags_dev(kbest_ctx *ctx, int32_t *d_flags);

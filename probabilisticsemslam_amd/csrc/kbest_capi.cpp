@@ -145,6 +145,7 @@ struct kbest_ctx {
     std::atomic<bool> relayDirty{false};  // an entry of this context failed (HIP error, nf < 0): the relay's words are zeroed before the next relay launch
     bool relayCaptured = false;   // a relay launch was captured into a graph: the graph holds the relay work space's addresses
     int lastRoute = 0;            // which kernel(s) the last k-best launch went to (kbest_last_route)
+    bool refOrder = false;        // kbest_set_reference_order: the association entries enumerate in the reference's own order (kbest_exact.hip)
     int relay = -1;           // KBEST_RELAY: pieces per matrix (0 / 1: never; -1: choose per launch)
     int relayFirst = 0;       // KBEST_RELAY_FIRST: the first piece hands over at k * this / 1024 solutions (0: choose per launch shape)
     int relayStep = 0;        // KBEST_RELAY_STEP: the later pieces hand over this / 1024 of k apart (0: even steps up to k)
@@ -2576,7 +2577,10 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
     const int rawMaxRow = maxRow;
     if (!condition && maxRow > KBEST_MAX_DIM_WIDE) return fail(ctx, KBEST_ERR_UNSUPPORTED, "nL + nM > KBEST_MAX_DIM_WIDE");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (allowSmall && !quad && k >= 1 && maxCol <= kb::SMALL_MAX_DIM && rawMaxRow <= kb::SMALL_MAX_RAW_ROWS) {
+    // (kbest_set_reference_order: the k best in the reference's own order of operations -- the general pipeline with the reference-order
+    //  kernel as its enumeration; the fused kernels have an order of ties of their own)
+    const bool refOrder = ctx->refOrder;
+    if (allowSmall && !refOrder && !quad && k >= 1 && maxCol <= kb::SMALL_MAX_DIM && rawMaxRow <= kb::SMALL_MAX_RAW_ROWS) {
         // the frame-sized case: one fused launch (kbest_small.hip); the frames that keep more rows than it takes -- and
         // only those -- go through the general pipeline below
         std::vector<int> unfit;
@@ -2680,7 +2684,7 @@ general:
             HIP_TRY(ctx, hipMemcpy(probs, dCost.p, nCost * 8, hipMemcpyDeviceToHost));
             return KBEST_OK;
         }
-        if (maxCol <= kb::SMALL_MAX_DIM && rawMaxRow <= kb::SMALL_MAX_RAW_ROWS) {
+        if (!refOrder && maxCol <= kb::SMALL_MAX_DIM && rawMaxRow <= kb::SMALL_MAX_RAW_ROWS) {
             // frame-sized: the cost blocks the quadric kernel just built go straight into the fused association kernel
             const int rc = weights_small(ctx, B, nL, nM, nRow.data(), nullptr, dCost.as<double>(), costOff, k, probs, probOff, nf,
                                          condition, bruteForce, rawMaxRow, maxCol, nCost, nProb);
@@ -2738,6 +2742,7 @@ general:
     o.use_cutoff = bruteForce ? 0 : 1;  // assignment.cpp:594: kBest2DCutoff(..., cutoff = 42); :880: plain kBest2D
     o.cutoff = 42.0;
     o.tie_flags = dTie.as<int32_t>();
+    if (refOrder) o.flags |= KBEST_FLAG_REFERENCE_ORDER;
     // the weights only need row4col: no col4row table
     int rc = batch_dev_impl(ctx, &o, B, maxRow, maxCol, solveRows, dNC.as<int32_t>(), solveCost,
                             dOff.as<int64_t>(), kEnum, dR4C.as<int32_t>(), nullptr, dGain.as<double>(),
@@ -2851,6 +2856,14 @@ long long kbest_relay_launches(kbest_ctx *ctx)
     if (!ctx) return -1;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     return ctx->relayLaunches;
+}
+
+int kbest_set_reference_order(kbest_ctx *ctx, int on)
+{
+    if (!ctx) return KBEST_ERR_BAD_ARG;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    ctx->refOrder = on != 0;
+    return KBEST_OK;
 }
 
 int kbest_last_route(kbest_ctx *ctx)

@@ -15,12 +15,21 @@
 
 namespace {
 
+bool shim_reference_order()
+{
+    static const bool on = [] { const char *e = getenv("KBEST_SHIM_REFERENCE_ORDER"); return e && *e && *e != '0'; }();
+    return on;
+}
+
 kbest_ctx *global_ctx()
 {
     static kbest_ctx *ctx = nullptr;
     static std::once_flag once;
     static int rc = KBEST_OK;
-    std::call_once(once, [] { rc = kbest_create(&ctx, 0); });
+    std::call_once(once, [] {
+        rc = kbest_create(&ctx, 0);
+        if (rc == KBEST_OK && shim_reference_order()) kbest_set_reference_order(ctx, 1);  // (assignmentProb / bruteForceProb as well)
+    });
     if (rc != KBEST_OK || !ctx) throw std::runtime_error(std::string("kbest engine: ") + kbest_strerror(rc));
     return ctx;
 }
@@ -42,8 +51,7 @@ size_t kbest_one(size_t k, size_t numRow, size_t numCol, bool maximize, const do
     o.cutoff = cutoff;
     // KBEST_SHIM_REFERENCE_ORDER=1: the drop-in answers in the reference's own order of operations (kbest_exact.hip) -- exact ties as
     // the reference's heap pops them, col4row on padded columns as the reference names them; slower (kbest_c.h, KBEST_FLAG_REFERENCE_ORDER)
-    static const bool refOrder = [] { const char *e = getenv("KBEST_SHIM_REFERENCE_ORDER"); return e && *e && *e != '0'; }();
-    if (refOrder) o.flags |= KBEST_FLAG_REFERENCE_ORDER;
+    if (shim_reference_order()) o.flags |= KBEST_FLAG_REFERENCE_ORDER;
     std::vector<int32_t> r4c(k * numCol), c4r(k * numRow);
     int32_t nf = 0;
     check(ctx, kbest_batch_f64(ctx, &o, 1, (int)numRow, (int)numCol, nullptr, nullptr, C, nullptr, (int)k, r4c.data(),

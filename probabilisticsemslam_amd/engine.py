@@ -40,6 +40,7 @@ C_ABI_SYMBOLS = (
     "kbest_unregister_host_buffer", "kbest_multi_timeline", "kbest_last_tie_flags", "kbest_set_assoc_tie_flags_dev",
     "kbest_relay_launches", "kbest_merge_topk_i8_f64_dev", "kbest_merge_gains_f64_dev", "kbest_multi_exchange_bytes",
     "kbest_last_route", "kbest_resolve_ties_dev", "kbest_multi_last_tie_flags", "kbest_reserve_exact",
+    "kbest_set_reference_order",
 )
 KBEST_MULTI_STAMPS = 6
 KBEST_MULTI_BATCH, KBEST_MULTI_SUBTREE = 0, 1
@@ -259,6 +260,11 @@ class KBestEngine:
     def relay_launches(self):
         """Launches of the 64-row kernel this context has made as a relay (diagnostic, kbest_relay_launches)."""
         return int(self.lib.kbest_relay_launches(self.ctx))
+
+    def set_reference_order(self, on=True):
+        """kbest_set_reference_order: the host-buffer association entries enumerate in the reference's own order of operations."""
+        self.lib.kbest_set_reference_order.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.lib.kbest_set_reference_order(self.ctx, int(bool(on))))
 
     def last_route(self):
         """KBEST_ROUTE_* bits of the kernel(s) this context's last k-best launch went to (diagnostic, kbest_last_route)."""

@@ -691,3 +691,39 @@ def test_shims_in_reference_order(tmp_path):
             ca = [int(x) if int(x) < M else -1 for x in ta[i_c4r + 1:]]
             cb = [int(x) if int(x) < M else -1 for x in tb[i_c4r + 1:]]
             assert ca == cb, (args, s)
+
+
+def test_association_probabilities_in_reference_order():
+    """kbest_set_reference_order: assignmentProb / getAssignmentProbs with the k best enumerated by the reference-order kernel.  On
+    integer-cost frames -- exact ties across slot k in most of them -- the probabilities are the checker's own (whose kBest2DCutoff
+    pops equal gains in the compiled reference's heap order), rel 1e-12: the reference's answer, not the engine's rule.
+    assignment.cpp:547-683."""
+    eng = pk.KBestEngine(0)
+    eng.set_reference_order(True)
+    rng = np.random.default_rng(44)
+    checked = ties = 0
+    for (nL, nM, k, hi) in ((6, 3, 20, 6), (12, 5, 100, 8), (20, 10, 200, 12), (20, 10, 50, 4)):
+        nR = nL + nM
+        frames = []
+        for _ in range(40):
+            C_ = np.full(nR * nM, np.inf)
+            for c in range(nM):
+                near = rng.random(nL) < 4.0 / nL
+                near[c % nL] = True
+                C_[c * nR: c * nR + nL] = np.where(near, rng.integers(0, hi, nL), 60 + rng.integers(0, 400, nL)).astype(np.float64)
+                C_[c * nR + nL + c] = 10.0
+            frames.append(C_)
+        P, nf = eng.weights(frames, [nL] * len(frames), [nM] * len(frames), k, condition=True)
+        for f, fr in enumerate(frames):
+            cond, idx = ol.condition_costs(fr, nR, nM)
+            cl = len(idx) - nM
+            q, n = ol.assignment_prob(cond, cl, nM, k)
+            full = np.zeros((nM, nL + 1))
+            full[:, np.asarray(idx[:cl], dtype=np.int64)] = q[:, :cl]
+            full[:, nL] = q[:, cl]
+            assert nf[f] == n, (nL, nM, k, f)
+            np.testing.assert_allclose(P[f], full, rtol=1e-12, atol=1e-300, err_msg=str((nL, nM, k, f)))
+            checked += 1
+            ties += int(ol.canonical_kbest(cond, cl + nM, nM, k, cutoff=42.0)[3])
+    assert checked == 160 and ties > 20  # (the generator does put exact ties across slot k)
+    eng.close()
