@@ -75,7 +75,7 @@ enum {
     KBEST_OK = 0,
     KBEST_ERR_NO_DEVICE = -1,   /* no HIP device / HIP runtime error at create    */
     KBEST_ERR_BAD_ARG = -2,     /* null pointer, k < 1, numRow < numCol, ...      */
-    KBEST_ERR_UNSUPPORTED = -3, /* numRow > KBEST_MAX_DIM_EXACT (association entries: > KBEST_MAX_DIM_WIDE kept rows) */
+    KBEST_ERR_UNSUPPORTED = -3, /* numRow > KBEST_MAX_DIM_EXACT                                                     */
     KBEST_ERR_HIP = -4,         /* a HIP call failed; see kbest_last_error()      */
     KBEST_ERR_NOMEM = -5,
     KBEST_ERR_NOT_RESERVED = -6, /* kbest_batch_f64_dev: workspace too small, call kbest_reserve first   */

@@ -2571,11 +2571,11 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
         if (ce > nCost) nCost = ce;
         if (pe > nProb) nProb = pe;
     }
-    if (maxCol > KBEST_MAX_DIM_WIDE) return fail(ctx, KBEST_ERR_UNSUPPORTED, "nM > KBEST_MAX_DIM_WIDE");
+    if (maxCol > KBEST_MAX_DIM_EXACT) return fail(ctx, KBEST_ERR_UNSUPPORTED, "nM > KBEST_MAX_DIM_EXACT");
     // With conditioning the RAW matrix may have any number of rows (all landmarks of the map); only what
     // conditionCosts keeps must fit the solver, and a frame where it does not comes back with nf = -1.
     const int rawMaxRow = maxRow;
-    if (!condition && maxRow > KBEST_MAX_DIM_WIDE) return fail(ctx, KBEST_ERR_UNSUPPORTED, "nL + nM > KBEST_MAX_DIM_WIDE");
+    if (!condition && maxRow > KBEST_MAX_DIM_EXACT) return fail(ctx, KBEST_ERR_UNSUPPORTED, "nL + nM > KBEST_MAX_DIM_EXACT");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // (kbest_set_reference_order: the k best in the reference's own order of operations -- the general pipeline with the reference-order
     //  kernel as its enumeration; the fused kernels have an order of ties of their own)
@@ -2723,7 +2723,7 @@ general:
             maxRow = maxCol;
             for (int b = 0; b < B; b++)
                 if (good[b] > maxRow) maxRow = good[b];
-            if (maxRow > KBEST_MAX_DIM_WIDE) maxRow = KBEST_MAX_DIM_WIDE;  // frames beyond it come back with nf = -1
+            if (maxRow > KBEST_MAX_DIM_EXACT) maxRow = KBEST_MAX_DIM_EXACT;  // frames beyond it come back with nf = -1
         }
         // (up to 64 raw rows the LDS kernel takes whatever is kept: the launch is sized from the raw row count and
         //  nothing waits for the conditioning kernel)

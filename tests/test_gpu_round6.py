@@ -727,3 +727,29 @@ def test_association_probabilities_in_reference_order():
             ties += int(ol.canonical_kbest(cond, cl + nM, nM, k, cutoff=42.0)[3])
     assert checked == 160 and ties > 20  # (the generator does put exact ties across slot k)
     eng.close()
+
+
+def test_association_with_more_than_1024_kept_rows(engine):
+    """getAssignmentProbs / assignmentProb on frames that keep more than 1 024 rows after conditionCosts (1 100 and 1 500 landmarks
+    within the gate): the general pipeline with the reference-order kernel as its enumeration; the checker's probabilities."""
+    rng = np.random.default_rng(1)
+    for (nL, nM, k) in ((1100, 3, 20), (1500, 2, 10)):
+        nR = nL + nM
+        C_ = np.full(nR * nM, np.inf)
+        for c in range(nM):
+            C_[c * nR: c * nR + nL] = 30.0 * rng.random(nL)
+            C_[c * nR + nL + c] = 10.0
+        P, nf = engine.weights([C_], [nL], [nM], k, condition=True)
+        assert engine.last_route() == pk.engine.KBEST_ROUTE_EXACT
+        cond, idx = ol.condition_costs(C_, nR, nM)
+        cl = len(idx) - nM
+        assert len(idx) > 1024
+        q, n = ol.assignment_prob(cond, cl, nM, k)
+        full = np.zeros((nM, nL + 1))
+        full[:, np.asarray(idx[:cl], dtype=np.int64)] = q[:, :cl]
+        full[:, nL] = q[:, cl]
+        assert nf[0] == n
+        np.testing.assert_allclose(P[0], full, rtol=1e-12, atol=1e-300)
+        P2, nf2 = engine.weights([cond], [cl], [nM], k)
+        assert nf2[0] == n
+        np.testing.assert_allclose(P2[0], q, rtol=1e-12, atol=1e-300)
