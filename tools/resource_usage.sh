@@ -3,7 +3,7 @@
 # one line per kernel instantiation.  usage: tools/resource_usage.sh [file.hip ...]   (default: every kernel file)
 cd "$(dirname "$0")/../probabilisticsemslam_amd/csrc" || exit 1
 files=("$@")
-[ ${#files[@]} -eq 0 ] && files=(kbest_engine.hip kbest_lane.hip kbest_small.hip kbest_tiny.hip kbest_bnb.hip kbest_wide.hip kbest_costs.hip)
+[ ${#files[@]} -eq 0 ] && files=(kbest_engine.hip kbest_lane.hip kbest_small.hip kbest_tiny.hip kbest_bnb.hip kbest_wide.hip kbest_exact.hip kbest_merge.hip kbest_costs.hip)
 for f in "${files[@]}"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I../../include -I. \
       -c -o /dev/null -x hip "$f" -Rpass-analysis=kernel-resource-usage 2>&1 |
