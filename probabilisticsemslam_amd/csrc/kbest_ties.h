@@ -111,10 +111,15 @@ __device__ __attribute__((noinline)) int tie_tail(const double *gain, int *row4c
                 const int chunk = (L + 63) >> 6, lo = lane * chunk < L ? lane * chunk : L, hi = lo + chunk < L ? lo + chunk : L;
                 for (int i = lane; i < L; i += 64) pa[i] = (unsigned short)i;
                 wave_fence();
+                // (the loops are kept rolled: unrolled, this rare path cost the finishing launch 248 registers)
+#pragma unroll 1
                 for (int c = M - 1; c >= 0; c--) {
+#pragma unroll 1
                     for (int shift = 0; shift < 10; shift += 5) {
+#pragma unroll 1
                         for (int d = 0; d < 32; d++) cnt[lane * 32 + d] = 0;
                         int seen = 0;
+#pragma unroll 1
                         for (int i = lo; i < hi; i++) {
                             const int key = tie_ld_index(row4col, r4cBase + (long long)(s + pa[i]) * ldCol + c, i8);
                             cnt[lane * 32 + ((key >> shift) & 31)]++;
@@ -123,8 +128,10 @@ __device__ __attribute__((noinline)) int tie_tail(const double *gain, int *row4c
                         wave_fence();
                         // where the entries of (digit, lane) start: all smaller digits, then the same digit on the lanes before
                         int tot = 0;
-                        if (lane < 32)
+                        if (lane < 32) {
+#pragma unroll 4
                             for (int l2 = 0; l2 < 64; l2++) tot += cnt[l2 * 32 + lane];
+                        }
                         int incl = tot;  // (lanes 32 .. 63 carry zeros: the scan runs over the whole wave)
                         for (int dd = 1; dd < 32; dd <<= 1) {
                             const int t = __shfl_up(incl, dd);
@@ -135,6 +142,7 @@ __device__ __attribute__((noinline)) int tie_tail(const double *gain, int *row4c
                         if (!oneDigit) {
                             if (lane < 32) {
                                 int run = base;
+#pragma unroll 1
                                 for (int l2 = 0; l2 < 64; l2++) {
                                     const int n = cnt[l2 * 32 + lane];
                                     cnt[l2 * 32 + lane] = (unsigned short)run;
@@ -142,6 +150,7 @@ __device__ __attribute__((noinline)) int tie_tail(const double *gain, int *row4c
                                 }
                             }
                             wave_fence();
+#pragma unroll 1
                             for (int i = lo; i < hi; i++) {
                                 const int idx = pa[i];
                                 const int key = tie_ld_index(row4col, r4cBase + (long long)(s + idx) * ldCol + c, i8);
