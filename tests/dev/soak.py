@@ -9,8 +9,9 @@ import soak_lib
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 eng = pk.KBestEngine(0)
+ref_order = os.environ.get("SOAK_REFERENCE_ORDER") == "1"  # KBEST_FLAG_REFERENCE_ORDER: everything slot for slot, ties and padded columns included
 ncase, nprob, bad = soak_lib.run(eng, seed, seconds=budget, big_frac=float(os.environ.get("SOAK_BIG", "0.12")),
-                                 big_max=int(os.environ.get("SOAK_BIGMAX", "200")))
+                                 big_max=int(os.environ.get("SOAK_BIGMAX", "200")), reference_order=ref_order)
 if bad:
     print("MISMATCH", bad); sys.exit(1)
 print(f"soak ok: {ncase} cases, {nprob} problems (seed {seed}); {eng.relay_launches()} launches of the 64-row kernel were relays")

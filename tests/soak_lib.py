@@ -43,17 +43,23 @@ def draw_case(rng, max_rows=64, big_frac=0.0, big_max=200, batches=(1, 2, 5, 9))
     return dict(N=N, M=M, k=k, B=B, maximize=maximize, cutoff=cutoff, kind=kind, C=C)
 
 
-def check_case(eng, case):
+def check_case(eng, case, reference_order=False):
     """None if the engine's result equals the oracle's (nf, gains bit for bit, assignments; equal gains as multisets),
-    else a description of the first mismatch."""
+    else a description of the first mismatch.  reference_order: KBEST_FLAG_REFERENCE_ORDER -- then EVERYTHING must be the
+    checker's, slot for slot: the order of equal gains and col4row on padded columns included."""
     N, M, k, C = case["N"], case["M"], case["k"], case["C"]
     # every third case takes its tables as int8 (KBEST_FLAG_TABLES_I8): the same values from every kernel's output phase
     i8 = N <= 127 and (N + M + k + case["B"]) % 3 == 0
-    nf, r4c, c4r, g = eng.kbest(C, N, M, k, case["maximize"], case["cutoff"], tables_i8=i8)[:4]
+    nf, r4c, c4r, g = eng.kbest(C, N, M, k, case["maximize"], case["cutoff"], tables_i8=i8, reference_order=reference_order)[:4]
     onf, or4c, oc4r, og, _ = ol.orc_kbest_batch(C, N, M, k, case["maximize"], case["cutoff"])
     for b in range(case["B"]):
         n = int(onf[b])
         ok = nf[b] == n and (g[b, :n].view(np.int64) == og[b, :n].view(np.int64)).all()
+        if reference_order:
+            ok = ok and (r4c[b, :n] == or4c[b, :n]).all() and (c4r[b, :n] == oc4r[b, :n]).all()
+            if not ok:
+                return dict(b=b, nf=int(nf[b]), onf=n, reference_order=True, **{key: case[key] for key in ("N", "M", "k", "B", "maximize", "cutoff", "kind")})
+            continue
         if ok and not (r4c[b, :n] == or4c[b, :n]).all():
             # equal gains may come out in another order (SURVEY 8(a) quirk 7): assignments as multisets below the last gain
             got = sorted((float(g[b, i]), tuple(r4c[b, i].tolist())) for i in range(n))
@@ -65,14 +71,14 @@ def check_case(eng, case):
     return None
 
 
-def run(eng, seed, n_cases=None, seconds=None, **draw_kw):
+def run(eng, seed, n_cases=None, seconds=None, reference_order=False, **draw_kw):
     """Fixed number of cases (reproducible) or a time budget.  Returns (cases, problems, first mismatch or None)."""
     rng = np.random.default_rng(seed)
     t0 = time.time()
     ncase = nprob = 0
     while (n_cases is None or ncase < n_cases) and (seconds is None or time.time() - t0 < seconds):
         case = draw_case(rng, **draw_kw)
-        bad = check_case(eng, case)
+        bad = check_case(eng, case, reference_order)
         if bad is not None:
             bad["seed"] = seed
             bad["case_no"] = ncase
