@@ -21,7 +21,7 @@
 // 313-320), the dual update and the copies of a hypothesis; the queue and the path flip are one lane's.  The cost copy, the queue
 // and the pool of hypotheses (25 N + 16 bytes each, one per push) live in an HBM work space; up to 1 024 rows the scratch of a
 // search and the hypothesis being solved are in LDS (a child only reaches the pool if it is feasible and not cut).  This is the
-// slow, total, literal path -- 256 problems of 64 x 64, k = 200 take 154 ms here (0.6 ms per problem; the reference on one host core:
+// slow, total, literal path -- 256 problems of 64 x 64, k = 200 take 138 ms here (0.54 ms per problem; the reference on one host core:
 // 10 ms per problem) against 0.7 ms on the LDS kernel; 1 000 integer-cost 28 x 10 problems 12 ms against 4.5 -- and is only taken
 // when asked for or when no other kernel takes the size.
 #include <hip/hip_runtime.h>
@@ -196,9 +196,15 @@ __global__ void __launch_bounds__(64) kbest_exact_kernel(ExactParams p)
             return 0;
         };
         // calcGain (cpp:59-80): serial, left to right, from 0.0 (every lane the same sum)
+        // (the terms of 64 columns are fetched by the lanes at once; the additions stay one after the other, in column order)
         auto gain_of = [&](const Hyp &h, int nCol4Gain) {
             double g = 0.0;
-            for (int c = 0; c < nCol4Gain; c++) g = g + Cw[(long long)c * D + h.r4c[c]];
+            for (int c0 = 0; c0 < nCol4Gain; c0 += 64) {
+                const int c = c0 + lane;
+                const double term = c < nCol4Gain ? Cw[(long long)c * D + h.r4c[c]] : 0.0;
+                const int n = nCol4Gain - c0 < 64 ? nCol4Gain - c0 : 64;
+                for (int j = 0; j < n; j++) g = g + readlane_f64(term, j);
+            }
             return g;
         };
         // std::priority_queue<pMurtyHyp> with a < b <=> a.gain > b.gain (cpp:35-37): libstdc++'s __push_heap / __adjust_heap
