@@ -51,7 +51,10 @@
  * The exhaustive association kernel and the bounded walk see a whole gain level and keep its lexicographically first
  * members themselves, whatever its size.  KBEST_FLAG_NO_TIE_CHECK switches all of it off (the kernels' own orders, round 4).
  * A caller who needs the REFERENCE's own order of equal gains instead -- slot for slot what its std::priority_queue pops -- sets
- * KBEST_FLAG_REFERENCE_ORDER: the problem then runs on the reference-order kernel (kbest_exact.hip; slow, exact).
+ * KBEST_FLAG_REFERENCE_ORDER: the problem then runs on the reference-order kernel (kbest_exact.hip; slow, exact) -- or
+ * KBEST_FLAG_REFERENCE_TIES: the batch runs on the fast kernels and only the problems that DO have an exact tie among their k + 1
+ * best gains are enumerated again by that kernel (a tie-free problem's tables are the reference's anyway): the same answer, at the
+ * fast kernels' speed wherever nothing ties.
  * Index outputs are int32 (the reference ABI uses ptrdiff_t; the C++ shims in
  * include/kbest_shims.hpp widen on the host).
  *
@@ -106,6 +109,15 @@ enum {
                                         /* pops them (shortestPathCPP.cpp:30-42, 574) and col4row names the padded column of every      */
                                         /* left-over row as the reference does.  Slow (one wave per problem, nothing pruned): for     */
                                         /* callers with integer-like costs who need the reference's answer slot for slot.  No tie flags. */
+#define KBEST_FLAG_REFERENCE_TIES 4096u /* synchronous k-best entries, kbest_resolve_ties_dev, the multi-device batch entry: the     */
+                                       /* REFERENCE's answer wherever gains tie.  The batch runs on the fast kernels; every problem */
+                                       /* whose k + 1 best gains hold an exact tie (inside the table or across slot k; or that      */
+                                       /* could not be checked) is then enumerated AGAIN by the reference-order kernel and its      */
+                                       /* tables replaced (KBEST_TIE_REFERENCE).  Tie-free problems keep the fast kernels' tables,  */
+                                       /* which are the reference's bit for bit: the whole call then answers as the reference does  */
+                                       /* -- order of equal gains and members of a level across slot k included -- at the fast      */
+                                       /* kernels' speed where nothing ties.  (col4row of rows on padded columns: the reference's   */
+                                       /* names on the re-run problems, valid names elsewhere: SURVEY 8(a) quirk 6.)                */
 #define KBEST_FLAG_NO_TIE_RESOLVE 1024u /* synchronous entries: report a tie at slot k (KBEST_TIE_BOUNDARY), do not complete its gain level */
 #define KBEST_FLAG_TABLES_I8 64u   /* kbest_batch_f64 / kbest_batch_f64_dev: row4col / col4row are tables of int8_t (same shapes, */
                                    /* same values, -1 = unassigned / unused) instead of int32_t: every index of a problem of up   */
@@ -117,6 +129,7 @@ enum {
 #define KBEST_TIE_INSIDE 1            /* some of the emitted gains are exactly equal (they are in the canonical order)        */
 #define KBEST_TIE_BOUNDARY 2          /* the k-th and the (k+1)-th best gains are exactly equal: the k best are not unique    */
 #define KBEST_TIE_RESOLVED 4          /* ... and the entry completed that gain level: the lexicographically first were kept   */
+#define KBEST_TIE_REFERENCE 8         /* KBEST_FLAG_REFERENCE_TIES: the problem was enumerated again by the reference-order kernel: its tables are the reference's own */
 #define KBEST_TIE_UNCHECKED (1 << 28) /* ASYNCHRONOUS entries only: k sits at the limit of the kernel the problem ran on (e.g.     */
                                       /* k = 1 024 on the fused association kernel): the (k+1)-th solution was not enumerated, so */
                                       /* a tie at slot k would not have been seen (runs of equal gains INSIDE the tables are       */
@@ -327,11 +340,16 @@ int kbest_assoc_probs_batch_f64_dev(kbest_ctx *ctx, int B, int maxRawRow, int ma
                                     const int64_t *d_costOff, int k, int condition, double *d_probs,
                                     const int64_t *d_probOff, int32_t *d_nf, void *stream);
 int kbest_reserve_assoc(kbest_ctx *ctx, int B, int maxRawRow, int maxCol, int k);
-/* on != 0: the HOST-buffer association entries of this context (kbest_weights / assoc_probs / bruteforce / quadric_assoc) enumerate
+/* on = 1: the HOST-buffer association entries of this context (kbest_weights / assoc_probs / bruteforce / quadric_assoc) enumerate
  * their k best in the REFERENCE's own order of operations (the reference-order kernel, as KBEST_FLAG_REFERENCE_ORDER does for
  * kbest_batch_f64): where exactly equal gains straddle slot k the assignments that are weighed are the ones the reference's
  * kBest2DCutoff returns (assignment.cpp:594), so the probabilities are the reference's there too (integer-like costs).  Slower: no
- * fused kernels.  The reference-named shims switch it on with KBEST_SHIM_REFERENCE_ORDER=1. */
+ * fused kernels.  The reference-named shims switch it on with KBEST_SHIM_REFERENCE_ORDER=1.
+ * on = 2: the same answer at the fused kernels' speed wherever nothing ties (as KBEST_FLAG_REFERENCE_TIES does for kbest_batch_f64):
+ * the batch runs on the fused kernels, and only the frames whose k-th and (k+1)-th gains are exactly equal -- the only frames whose
+ * weights depend on the order of ties: inside a run of equal gains every order sums the same terms -- are enumerated again by the
+ * reference-order kernel and weighed from its table (KBEST_TIE_REFERENCE in kbest_last_tie_flags).  KBEST_SHIM_REFERENCE_ORDER=2.
+ * on = 0: the engine's own rule (the default). */
 int kbest_set_reference_order(kbest_ctx *ctx, int on);
 /* Where kbest_assoc_probs_batch_f64_dev writes its frames' KBEST_TIE_* flags ([B] int32 in device memory; NULL, the default:
  * nowhere).  Stays set until changed. */

@@ -145,7 +145,8 @@ struct kbest_ctx {
     std::atomic<bool> relayDirty{false};  // an entry of this context failed (HIP error, nf < 0): the relay's words are zeroed before the next relay launch
     bool relayCaptured = false;   // a relay launch was captured into a graph: the graph holds the relay work space's addresses
     int lastRoute = 0;            // which kernel(s) the last k-best launch went to (kbest_last_route)
-    bool refOrder = false;        // kbest_set_reference_order: the association entries enumerate in the reference's own order (kbest_exact.hip)
+    int refOrder = 0;             // kbest_set_reference_order: 1 = the association entries enumerate in the reference's own order (kbest_exact.hip);
+                                  // 2 = only the frames whose k-th and (k+1)-th gains are equal do (their weights are then the reference's)
     int relay = -1;           // KBEST_RELAY: pieces per matrix (0 / 1: never; -1: choose per launch)
     int relayFirst = 0;       // KBEST_RELAY_FIRST: the first piece hands over at k * this / 1024 solutions (0: choose per launch shape)
     int relayStep = 0;        // KBEST_RELAY_STEP: the later pieces hand over this / 1024 of k apart (0: even steps up to k)
@@ -1887,6 +1888,49 @@ void kb_complete_tie_levels(kbest_ctx *ctx, const kbest_opts *opts, int B, int m
     static const int steps[4] = {64, 256, 1024, KBEST_TIE_CAP};
     const bool i8 = (opts->flags & KBEST_FLAG_TABLES_I8) != 0;
     const size_t esz = i8 ? 1 : 4;
+    if (opts->flags & KBEST_FLAG_REFERENCE_TIES) {
+        // The REFERENCE's answer wherever gains tie (kbest_c.h): every problem whose k + 1 best gains hold an exact tie -- inside the
+        // table or across slot k -- or that could not be checked is enumerated again by the reference-order kernel (kbest_exact.hip),
+        // and its tables replace the first pass'.  Tie-free problems keep the fast kernels' tables: those ARE the reference's.
+        const int tied = KBEST_TIE_INSIDE | KBEST_TIE_BOUNDARY | KBEST_TIE_UNCHECKED | KBEST_TIE_UNORDERED;
+        std::vector<int> idx;
+        for (int b = 0; b < B; b++)
+            if ((fl[b] & tied) && !(fl[b] & KBEST_TIE_REFERENCE)) idx.push_back(b);
+        if (idx.empty()) return;
+        const int n = (int)idx.size();
+        std::vector<int32_t> sRow(n), sCol(n), sNf(n);
+        std::vector<int64_t> sOff(n);
+        size_t tot = 0;
+        for (int i = 0; i < n; i++) {
+            sRow[i] = nRow ? nRow[idx[i]] : maxRow;
+            sCol[i] = nCol ? nCol[idx[i]] : maxCol;
+            sOff[i] = (int64_t)tot;
+            tot += (size_t)sRow[i] * sCol[i];
+        }
+        std::vector<double> sCost(tot), sGain((size_t)n * k);
+        for (int i = 0; i < n; i++) {
+            const size_t src = costOff ? (size_t)costOff[idx[i]] : (size_t)idx[i] * maxRow * maxCol;
+            memcpy(sCost.data() + sOff[i], cost + src, (size_t)sRow[i] * sCol[i] * 8);
+        }
+        std::vector<char> sR((size_t)n * k * maxCol * esz), sC(col4row ? (size_t)n * k * maxRow * esz : 0);
+        kbest_opts o2 = *opts;
+        o2.flags = (o2.flags & ~KBEST_FLAG_REFERENCE_TIES) | KBEST_FLAG_REFERENCE_ORDER;
+        o2.tie_flags = nullptr;
+        const int rc = kbest_batch_f64_keep(ctx, &o2, n, maxRow, maxCol, sRow.data(), sCol.data(), sCost.data(), sOff.data(), k,
+                                            reinterpret_cast<int32_t *>(sR.data()), col4row ? reinterpret_cast<int32_t *>(sC.data()) : nullptr, sGain.data(),
+                                            sNf.data(), nullptr, nullptr);
+        if (rc != KBEST_OK) return;  // (the first pass' tables stand -- in the engine's own order; the problems stay flagged as they were)
+        for (int i = 0; i < n; i++) {
+            const int b = idx[i];
+            memcpy(static_cast<char *>(row4col) + (size_t)b * k * maxCol * esz, sR.data() + (size_t)i * k * maxCol * esz, (size_t)k * maxCol * esz);
+            if (col4row)
+                memcpy(static_cast<char *>(col4row) + (size_t)b * k * maxRow * esz, sC.data() + (size_t)i * k * maxRow * esz, (size_t)k * maxRow * esz);
+            memcpy(gain + (size_t)b * k, sGain.data() + (size_t)i * k, (size_t)k * 8);
+            fl[b] = (fl[b] & KBEST_TIE_INSIDE) | KBEST_TIE_REFERENCE;
+            if (changed) changed->push_back(b);
+        }
+        return;
+    }
     for (int step = 0; step < 4; step++) {
         std::vector<int> idx;
         for (int b = 0; b < B; b++)
@@ -1966,8 +2010,10 @@ int kbest_resolve_ties_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int ma
     std::vector<int32_t> fl((size_t)B);
     HIP_TRY(ctx, hipMemcpy(fl.data(), d_tie_flags, (size_t)B * 4, hipMemcpyDeviceToHost));
     std::vector<int> idx;
+    const bool refTies = (opts->flags & KBEST_FLAG_REFERENCE_TIES) != 0;
+    const int tied = KBEST_TIE_INSIDE | KBEST_TIE_BOUNDARY | KBEST_TIE_UNCHECKED | KBEST_TIE_UNORDERED;
     for (int b = 0; b < B; b++)
-        if ((fl[b] & KBEST_TIE_BOUNDARY) && !(fl[b] & KBEST_TIE_RESOLVED)) idx.push_back(b);
+        if (refTies ? ((fl[b] & tied) && !(fl[b] & KBEST_TIE_REFERENCE)) : ((fl[b] & KBEST_TIE_BOUNDARY) && !(fl[b] & KBEST_TIE_RESOLVED))) idx.push_back(b);
     if (idx.empty()) return KBEST_OK;
     // the flagged problems' cost blocks and table slots come to the host, are completed there, and go back
     const int n = (int)idx.size();
@@ -2548,6 +2594,8 @@ extern "C" int kbest_reserve_assoc(kbest_ctx *ctx, int B, int maxRawRow, int max
 
 // tie (optional): [B] KBEST_TIE_* per frame.  tieExtra > 0: the general pipeline enumerates k + tieExtra solutions and weighs the
 // first k of them in the canonical order -- how a frame whose k-th and (k+1)-th gains are equal gets the one answer (kbest_ties.h).
+// tieExtra < 0: the general pipeline with the reference-order kernel as its enumeration, whatever the context says -- how such a frame
+// gets the REFERENCE's answer (kbest_set_reference_order(ctx, 2)); its frames come back flagged KBEST_TIE_REFERENCE.
 static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int32_t *nM, const double *cost,
                             const int64_t *costOff, int k, double *probs, const int64_t *probOff, int32_t *nf,
                             bool condition, const QuadricHost *quad = nullptr, bool bruteForce = false, bool allowSmall = true,
@@ -2579,7 +2627,9 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // (kbest_set_reference_order: the k best in the reference's own order of operations -- the general pipeline with the reference-order
     //  kernel as its enumeration; the fused kernels have an order of ties of their own)
-    const bool refOrder = ctx->refOrder;
+    const bool refRerun = tieExtra < 0;
+    if (refRerun) tieExtra = 0;
+    const bool refOrder = ctx->refOrder == 1 || refRerun;
     if (allowSmall && !refOrder && !quad && k >= 1 && maxCol <= kb::SMALL_MAX_DIM && rawMaxRow <= kb::SMALL_MAX_RAW_ROWS) {
         // the frame-sized case: one fused launch (kbest_small.hip); the frames that keep more rows than it takes -- and
         // only those -- go through the general pipeline below
@@ -2609,6 +2659,17 @@ static int weights_pipeline(kbest_ctx *ctx, int B, const int32_t *nL, const int3
             if (rc2 != KBEST_OK) return rc2;
         } else if (rc == 1) {
             goto general;  // (the fused kernel takes none of this batch's shapes)
+        }
+        if (ctx->refOrder == 2) {  // the frames with a tie at slot k: the reference's own k best (and so its weights)
+            std::vector<int> tied;
+            for (int b = 0; b < B; b++)
+                if (tfl[b] & KBEST_TIE_BOUNDARY) tied.push_back(b);
+            if (!tied.empty()) {
+                const int rc2 = rerun(tied, -1);
+                if (rc2 != KBEST_OK) return rc2;
+            }
+            if (tie) memcpy(tie, tfl.data(), (size_t)B * 4);
+            return KBEST_OK;
         }
         // (64, then 256, then KBEST_TIE_CAP solutions beyond k: until the level ends inside the table)
         for (int extra : {64, 256, 1024, KBEST_TIE_CAP}) {
@@ -2809,8 +2870,11 @@ general:
             std::vector<int> tied;
             for (int b = 0; b < B; b++)
                 if (tfl[b] & KBEST_TIE_BOUNDARY) tied.push_back(b);
-            if (!tied.empty() && !quad) {
-                for (int extra : {64, 256, 1024, KBEST_TIE_CAP}) {
+            if (refRerun) {
+                for (int b = 0; b < B; b++) tfl[b] = KBEST_TIE_REFERENCE;
+            } else if (!tied.empty() && !quad) {
+                for (int step : {64, 256, 1024, KBEST_TIE_CAP}) {
+                    const int extra = ctx->refOrder == 2 ? -1 : step;  // (kbest_set_reference_order(ctx, 2): ONE re-run, on the reference-order kernel)
                     const int Bs = (int)tied.size();
                     std::vector<int32_t> sL(Bs), sM(Bs), sNf(Bs), sT(Bs, 0);
                     std::vector<int64_t> sCo(Bs), sPo(Bs);
@@ -2818,7 +2882,7 @@ general:
                     const int rc2 = weights_pipeline(ctx, Bs, sL.data(), sM.data(), cost, sCo.data(), k, probs, sPo.data(), sNf.data(), condition,
                                                      nullptr, bruteForce, false, sT.data(), extra);
                     if (rc2 != KBEST_OK) {
-                        if (extra == 64) return rc2;
+                        if (extra == 64 || extra < 0) return rc2;
                         break;
                     }
                     std::vector<int> still;
@@ -2862,7 +2926,8 @@ int kbest_set_reference_order(kbest_ctx *ctx, int on)
 {
     if (!ctx) return KBEST_ERR_BAD_ARG;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
-    ctx->refOrder = on != 0;
+    if (on < 0 || on > 2) return fail(ctx, KBEST_ERR_BAD_ARG, "kbest_set_reference_order: 0, 1 or 2");
+    ctx->refOrder = on;
     return KBEST_OK;
 }
 

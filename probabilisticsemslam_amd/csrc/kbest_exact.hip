@@ -16,35 +16,40 @@
 // pop order of equal gains is the reference's, and col4row names the padded column every left-over row sits on exactly as the
 // reference does (SURVEY 8(a) quirks 6 and 7 do not apply to this kernel).
 //
-// One WAVE per problem: the lanes share the rows of a Dijkstra step (row = lane, lane + 64, ...: the reduced costs
-// ((delta + C) - u) - v left to right, the strict-'<' update, the minimum with the LOWEST row among equal values: cpp:183-191,
-// 313-320), the dual update and the copies of a hypothesis; the queue and the path flip are one lane's.  The cost copy, the queue
-// and the pool of hypotheses (25 N + 16 bytes each, one per push) live in an HBM work space; up to 1 024 rows the scratch of a
-// search and the hypothesis being solved are in LDS (a child only reaches the pool if it is feasible and not cut).  This is the
-// slow, total, literal path -- 256 problems of 64 x 64, k = 200 take 138 ms here (0.54 ms per problem; the reference on one host core:
-// 10 ms per problem) against 0.7 ms on the LDS kernel; 1 000 integer-cost 28 x 10 problems 12 ms against 4.5 -- and is only taken
-// when asked for or when no other kernel takes the size.
+// One WAVE per problem.  Two forms of the same sequence of operations:
+//   * up to 64 rows (kbest_exact64_kernel): the hypothesis in REGISTERS -- lane = row for v / col4row, lane = column for u /
+//     row4col, the forbidden rows a 64-bit mask --, the padded cost copy in LDS, the Dijkstra step the hand-written loop of the LDS
+//     kernels (kbest_lap.h), a child a few register copies of its parent;
+//   * beyond (kbest_exact_kernel<MODE>): the lanes share the rows of a Dijkstra step (row = lane, lane + 64, ...: the reduced costs
+//     ((delta + C) - u) - v left to right, the strict-'<' update, the minimum with the LOWEST row among equal values: cpp:183-191,
+//     313-320), the dual update and the copies of a hypothesis; the path flip is one lane's; up to 1 024 rows the scratch of a search,
+//     the hypothesis being solved and the one being split are in LDS, the cost copy in an HBM work space.
+// In both the queue is lane 0's, in HBM, and the pool of hypotheses (25 N bytes each, one per push: a child only reaches it if it is
+// feasible and not cut) too.  This is the slow, total, literal path -- 256 problems of 64 x 64, k = 200 take 52 ms here (0.2 ms per
+// problem in a batch, 1 024 of them 93 ms; the reference on one host core: 10 ms per problem) against 0.7 ms on the LDS kernel; 1 000
+// integer-cost 28 x 10 problems 9 ms against 4.5; 64 problems of 200 x 150, k = 50: 650 ms -- and is only taken when asked for
+// (KBEST_FLAG_REFERENCE_ORDER; the tied problems of a KBEST_FLAG_REFERENCE_TIES call) or when no other kernel takes the size.
 #include <hip/hip_runtime.h>
 
 #include "kbest_engine.h"
+#include "kbest_lap.h"
 #include "kbest_wave.h"
 
 namespace kb {
 
 namespace {
 
-constexpr int EXACT_LDS_ROWS = 1024;  // up to here a search's scratch (19 bytes per row) and the hypothesis being solved (25) lie in LDS
-constexpr int EXACT_LDS_C_ROWS = 64;  // ... and the padded cost copy as well
+constexpr int EXACT_LDS_ROWS = 1024;  // up to here a search's scratch (19 bytes per row), the hypothesis being solved and the one being split (25 each) lie in LDS
 
 struct ExLayout {  // byte offsets inside one slot of the work space (D = maxRow, H = hypotheses per slot)
-    long long C, spc, pred, scanCols, scanRow, inScan, forbStart, heap, freeL, hgain, pool, hypStride, total;
+    long long C, spc, pred, scanCols, scanRow, inScan, forbStart, heap, pool, hypStride, total;
     // inside one hypothesis
-    long long hu, hv, hc4r, hr4c, hforb, hact;
+    long long hu, hv, hc4r, hr4c, hforb;
     __host__ __device__ ExLayout(long long D, long long H)
     {
         auto up = [](long long x) { return (x + 63) & ~63ll; };
-        hu = 0; hv = up(8 * D); hc4r = hv + up(8 * D); hr4c = hc4r + up(4 * D); hforb = hr4c + up(4 * D); hact = hforb + up(D);
-        hypStride = up(hact + 16);
+        hu = 0; hv = up(8 * D); hc4r = hv + up(8 * D); hr4c = hc4r + up(4 * D); hforb = hr4c + up(4 * D);
+        hypStride = up(hforb + D);
         long long o = 0;
         C = o;         o += up(8 * D * D);
         spc = o;       o += up(8 * D);
@@ -53,9 +58,7 @@ struct ExLayout {  // byte offsets inside one slot of the work space (D = maxRow
         scanRow = o;   o += up(D);
         inScan = o;    o += up(D);
         forbStart = o; o += up(D);
-        heap = o;      o += up(16 * H);  // (gain, hypothesis) pairs: one load per comparison
-        freeL = o;     o += up(4 * H);
-        hgain = o;     o += up(8 * H);
+        heap = o;      o += up(16 * H);  // (gain, hypothesis | activeCol << 32) pairs: one load per comparison
         pool = o;      o += hypStride * H;
         total = up(o);
     }
@@ -65,16 +68,25 @@ struct Hyp {
     double *u, *v;
     int *c4r, *r4c;
     unsigned char *forb;
-    int *act;
 };
 
 }  // namespace
 
 long long exact_slot_bytes(int maxRow, int hypPerSlot) { return ExLayout(maxRow, hypPerSlot).total; }
 
-// MODE 0: everything in the work space (more than EXACT_LDS_ROWS rows); 1: the scratch of a search and the hypothesis being solved in
-// LDS; 2: the padded cost copy as well (up to EXACT_LDS_C_ROWS rows).  A template parameter, not a run-time choice: the pointers must
-// be LDS pointers at compile time (flat accesses to LDS cost a global access' latency).
+// 65 rows and more (up to 64: kbest_exact64_kernel below).  MODE 0: everything in the work space (more than EXACT_LDS_ROWS rows);
+// 1: the scratch of a search, the hypothesis being solved and the hypothesis being split in LDS, the padded cost copy in the work
+// space.  A template parameter, not a run-time choice: the pointers must be LDS pointers at compile time (flat accesses to LDS cost
+// a global access' latency).
+//
+// Who talks to whom through memory (one wave per problem, so "who" is a lane):
+//   * LDS: lanes read what other lanes wrote; a wave's LDS accesses execute in program order, so a compiler fence is all it takes
+//     (wave_fence(), kbest_wave.h);
+//   * the pool of hypotheses in HBM: a record is written (store_hyp) and read (the copy of the popped parent into LDS, emit) with
+//     the SAME element -> lane mapping (element i on lane i mod 64), so every lane only ever reads back what it wrote itself;
+//   * the heap in HBM: lane 0 alone; what the wave needs of it (the popped / the top entry) is broadcast from lane 0's registers;
+//   * the cost copy in HBM: written once at set-up, one real fence behind it.
+// MODE 0 has no LDS copies: there the lanes do read each other's global stores, and every hand-over is a real fence.
 template <int MODE>
 __global__ void __launch_bounds__(64) kbest_exact_kernel(ExactParams p)
 {
@@ -82,40 +94,43 @@ __global__ void __launch_bounds__(64) kbest_exact_kernel(ExactParams p)
     const double INF = d_inf();
     const ExLayout L(p.maxRow, p.hypPerSlot);
     unsigned char *ws = p.work + (long long)blockIdx.x * L.total;
-    // the padded cost copy: in LDS up to EXACT_LDS_C_ROWS rows (32 KB at 64), else in the work space
-    constexpr bool cInLds = MODE == 2;
-    // the scratch of a search (ScratchSpace, hpp:73-142): in LDS up to EXACT_LDS_ROWS rows, in the work space beyond
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr bool inLds = MODE >= 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const long long Dm = p.maxRow;
+    // the scratch of a search (ScratchSpace, hpp:73-142)
     double *spc = inLds ? reinterpret_cast<double *>(lds) : reinterpret_cast<double *>(ws + L.spc);
     int *pred = inLds ? reinterpret_cast<int *>(lds + 8 * Dm) : reinterpret_cast<int *>(ws + L.pred);
     int *scanCols = inLds ? reinterpret_cast<int *>(lds + 12 * Dm) : reinterpret_cast<int *>(ws + L.scanCols);
     unsigned char *scanRow = inLds ? lds + 16 * Dm : ws + L.scanRow;
     unsigned char *inScan = inLds ? lds + 17 * Dm : ws + L.inScan;
     unsigned char *forbStart = inLds ? lds + 18 * Dm : ws + L.forbStart;
-    // ... and so does the hypothesis that is being solved (a child is copied from its parent into LDS, solved there, and only
-    // goes to the pool in HBM if it is feasible and not cut): 25 bytes per row more
-    const long long ldsHyp0 = (19 * Dm + 63) & ~63ll;
-    const Hyp hLds{reinterpret_cast<double *>(lds + ldsHyp0), reinterpret_cast<double *>(lds + ldsHyp0 + 8 * Dm),
-                   reinterpret_cast<int *>(lds + ldsHyp0 + 16 * Dm), reinterpret_cast<int *>(lds + ldsHyp0 + 20 * Dm),
-                   lds + ldsHyp0 + 24 * Dm, reinterpret_cast<int *>(lds + ldsHyp0 + 25 * Dm + (8 - (25 * Dm) % 8) % 8)};
-    double *Cw = cInLds ? reinterpret_cast<double *>(lds + ((ldsHyp0 + 25 * Dm + 16 + 63) & ~63ll)) : reinterpret_cast<double *>(ws + L.C);
-    struct HeapE { double g; long long idx; };
+    // the hypothesis that is being solved (a child is copied from its parent, solved in LDS, and only goes to the pool in HBM if it
+    // is feasible and not cut) and the hypothesis that is being split (copied from the pool once per sweep): 25 bytes per row each
+    const long long ldsHyp0 = (19 * Dm + 63) & ~63ll, ldsHypB = (25 * Dm + 63) & ~63ll;
+    auto lds_hyp = [&](long long o) {
+        return Hyp{reinterpret_cast<double *>(lds + o), reinterpret_cast<double *>(lds + o + 8 * Dm), reinterpret_cast<int *>(lds + o + 16 * Dm),
+                   reinterpret_cast<int *>(lds + o + 20 * Dm), lds + o + 24 * Dm};
+    };
+    const Hyp hLds = lds_hyp(ldsHyp0), pLds = lds_hyp(ldsHyp0 + ldsHypB);
+    double *Cw = reinterpret_cast<double *>(ws + L.C);
+    struct HeapE { double g; long long idx; };  // idx: hypothesis | activeCol << 32
     HeapE *heap = reinterpret_cast<HeapE *>(ws + L.heap);
-    int *freeL = reinterpret_cast<int *>(ws + L.freeL);
-    double *hgain = reinterpret_cast<double *>(ws + L.hgain);
     const bool tabI8 = (p.flags & KBEST_FLAG_TABLES_I8) != 0;
     const bool maximize = p.maximize != 0;
-    __shared__ int sh[8];  // [0] heap size, [1] free count, [2] scratch
 
     auto hyp = [&](int i) {
         unsigned char *b = ws + L.pool + (long long)i * L.hypStride;
         return Hyp{reinterpret_cast<double *>(b + L.hu), reinterpret_cast<double *>(b + L.hv), reinterpret_cast<int *>(b + L.hc4r),
-                   reinterpret_cast<int *>(b + L.hr4c), b + L.hforb, reinterpret_cast<int *>(b + L.hact)};
+                   reinterpret_cast<int *>(b + L.hr4c), b + L.hforb};
     };
-    // what one lane wrote to the work space, every lane reads after this (one wave, one CU: program order + a fence)
-    auto sync = [&]() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __syncthreads(); };
+    // a real fence: what one lane wrote to the work space, every lane reads after this
+    auto full_sync = [&]() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __syncthreads(); };
+    // hand-over between the lanes through the scratch / the hypothesis being solved: LDS in MODE 1 and 2
+    auto sync = [&]() { if (inLds) wave_fence(); else full_sync(); };
+    auto first_i32 = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
+    auto first_f64 = [](double x) {
+        return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+    };
 
     for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
         const int N = p.nRow ? p.nRow[b] : p.maxRow, M = p.nCol ? p.nCol[b] : p.maxCol;
@@ -137,9 +152,10 @@ __global__ void __launch_bounds__(64) kbest_exact_kernel(ExactParams p)
         for (long long i = lane; i < (long long)N * M; i += 64) Cw[i] = (maximize ? -Cg[i] : Cg[i]) - d;
         for (long long i = (long long)N * M + lane; i < (long long)N * N; i += 64) Cw[i] = 0.0;
         const double CDelta = (maximize ? -d : d) * (double)M;  // cpp:583 (maximize: CDelta is max C)
-        for (int i = lane; i < p.hypPerSlot; i += 64) freeL[i] = p.hypPerSlot - 1 - i;  // a stack: hypothesis 0 first
-        if (lane == 0) { sh[0] = 0; sh[1] = p.hypPerSlot; }
-        sync();
+        full_sync();
+        // The pool: one record per hypothesis the reference's queue ever holds, handed out in order and never reused -- at most
+        // 1 + (k - 1) M pushes (kbest_capi.cpp: plan_exact), so the records of a problem's pool are enough by construction.
+        int nextHyp = 0, heapN = 0;  // (wave-uniform registers)
 
         // one shortest augmenting path from column `start`, the dual update, the path flip (cpp:146-230, 283-358, 82-117).
         // useForb: rows flagged in forbStart are skipped while the start column itself is scanned (cpp:310).  1 = infeasible.
@@ -207,7 +223,8 @@ __global__ void __launch_bounds__(64) kbest_exact_kernel(ExactParams p)
             }
             return g;
         };
-        // std::priority_queue<pMurtyHyp> with a < b <=> a.gain > b.gain (cpp:35-37): libstdc++'s __push_heap / __adjust_heap
+        // std::priority_queue<pMurtyHyp> with a < b <=> a.gain > b.gain (cpp:35-37): libstdc++'s __push_heap / __adjust_heap.
+        // Lane 0's alone: the heap's size is kept by every lane (heapN), its entries are read and written by lane 0 only.
         auto sift_up = [&](int hole, int top, HeapE val) {  // (lane 0)
             int parent = (hole - 1) / 2;
             while (hole > top) {
@@ -219,73 +236,59 @@ __global__ void __launch_bounds__(64) kbest_exact_kernel(ExactParams p)
             }
             heap[hole] = val;
         };
-        auto heap_push = [&](int hidx) {
-            if (lane == 0) {
-                const int n = sh[0];
-                sh[0] = n + 1;
-                sift_up(n, 0, HeapE{hgain[hidx], hidx});
-            }
-            sync();
+        auto heap_push = [&](int hidx, int act, double g) {
+            if (lane == 0) sift_up(heapN, 0, HeapE{g, (long long)hidx | ((long long)act << 32)});
+            heapN++;
         };
-        auto heap_pop = [&]() -> int {
-            if (lane == 0) {
-                const int top = (int)heap[0].idx;
-                const int len = sh[0] - 1;
+        // the top entry, in every lane's registers
+        auto heap_top = [&](double &g, int &hidx, int &act) {
+            HeapE e{0.0, 0};
+            if (lane == 0) e = heap[0];
+            g = first_f64(e.g);
+            hidx = first_i32((int)(e.idx & 0xffffffffll));
+            act = first_i32((int)(e.idx >> 32));
+        };
+        auto heap_pop = [&]() {  // (the caller has taken the top with heap_top)
+            const int len = heapN - 1;
+            if (lane == 0 && len > 0) {
                 const HeapE val = heap[len];
-                sh[0] = len;
-                if (len > 0) {
-                    int hole = 0, child = 0;
-                    while (child < (len - 1) / 2) {
-                        child = 2 * (child + 1);
-                        HeapE ce = heap[child];
-                        const HeapE le = heap[child - 1];  // (two independent loads)
-                        if (ce.g > le.g) { child--; ce = le; }
-                        heap[hole] = ce;
-                        hole = child;
-                    }
-                    if ((len & 1) == 0 && child == (len - 2) / 2) {
-                        child = 2 * (child + 1);
-                        heap[hole] = heap[child - 1];
-                        hole = child - 1;
-                    }
-                    sift_up(hole, 0, val);
+                int hole = 0, child = 0;
+                while (child < (len - 1) / 2) {
+                    child = 2 * (child + 1);
+                    HeapE ce = heap[child];
+                    const HeapE le = heap[child - 1];  // (two independent loads)
+                    if (ce.g > le.g) { child--; ce = le; }
+                    heap[hole] = ce;
+                    hole = child;
                 }
-                sh[2] = top;
+                if ((len & 1) == 0 && child == (len - 2) / 2) {
+                    child = 2 * (child + 1);
+                    heap[hole] = heap[child - 1];
+                    hole = child - 1;
+                }
+                sift_up(hole, 0, val);
             }
-            sync();
-            return sh[2];
+            heapN = len;
         };
-        auto alloc_hyp = [&]() -> int {
-            if (lane == 0) {
-                const int n = sh[1];
-                sh[2] = n > 0 ? freeL[n - 1] : -1;
-                if (n > 0) sh[1] = n - 1;
-            }
-            sync();
-            return sh[2];
+        // a hypothesis between LDS and its record in the pool: element i on lane i mod 64, both ways
+        auto copy_hyp = [&](const Hyp &src, const Hyp &dst) {
+            for (int i = lane; i < D; i += 64) { dst.r4c[i] = src.r4c[i]; dst.c4r[i] = src.c4r[i]; dst.u[i] = src.u[i]; dst.v[i] = src.v[i]; dst.forb[i] = src.forb[i]; }
         };
-        auto free_hyp = [&](int i) {
-            if (lane == 0) { freeL[sh[1]] = i; sh[1] = sh[1] + 1; }
-            sync();
-        };
-        auto emit = [&](int hidx, int slot) {
+        auto emit = [&](int hidx, double g, int slot) {
             const Hyp h = hyp(hidx);
             for (int c = lane; c < M; c += 64) put_index(p.row4col, (outBase + slot) * p.ldCol + c, h.r4c[c], tabI8);
             if (p.col4row)
                 for (int r = lane; r < N; r += 64) put_index(p.col4row, (outBase + slot) * p.ldRow + r, h.c4r[r], tabI8);
-            const double g = hgain[hidx];
             const double out = maximize ? (-g + CDelta) : (g + CDelta);  // cpp:626-630
             if (lane == 0) p.gain[outBase + slot] = out;
             return out;
         };
 
         // ---- root: shortestPathCPP (cpp:119-238), N augmentations in column order on the padded problem ----
-        const int root = alloc_hyp();
-        if (root < 0) { if (lane == 0) p.nf[b] = -4; continue; }
-        const Hyp hrG = hyp(root);
+        if (p.hypPerSlot < 2) { if (lane == 0) p.nf[b] = -4; continue; }
+        const Hyp hrG = hyp(nextHyp);
         const Hyp hr = inLds ? hLds : hrG;
         for (int i = lane; i < D; i += 64) { hr.c4r[i] = -1; hr.r4c[i] = -1; hr.u[i] = 0.0; hr.v[i] = 0.0; hr.forb[i] = 0; }
-        if (lane == 0) hr.act[0] = 0;
         sync();
         int infeasible = 0;
         for (int c = 0; c < D && !infeasible; c++) {
@@ -295,70 +298,58 @@ __global__ void __launch_bounds__(64) kbest_exact_kernel(ExactParams p)
         }
         if (infeasible) {  // kBest2D returns 0 (cpp:588-593)
             if (lane == 0) p.nf[b] = 0;
-            sync();
             continue;
         }
-        // a hypothesis solved in LDS goes to its record in the pool
-        auto store_hyp = [&](const Hyp &src, const Hyp &dst) {
-            for (int i = lane; i < D; i += 64) { dst.r4c[i] = src.r4c[i]; dst.c4r[i] = src.c4r[i]; dst.u[i] = src.u[i]; dst.v[i] = src.v[i]; dst.forb[i] = src.forb[i]; }
-            if (lane == 0) dst.act[0] = src.act[0];
-            sync();
-        };
-        {
-            const double g = gain_of(hr, M);
-            if (lane == 0) { hgain[root] = g; hr.forb[hr.r4c[0]] = 1; }  // cpp:232-235
-            sync();
-            if (inLds) store_hyp(hr, hrG);
-        }
-        const double gain0 = emit(root, 0);
-        const double cutoffGain = maximize ? (hgain[root] - p.cutoff) : (hgain[root] + p.cutoff);  // cpp:680-686
-        heap_push(root);
+        const double rootGain = gain_of(hr, M);
+        if (lane == 0) hr.forb[hr.r4c[0]] = 1;  // cpp:232-235
+        sync();
+        if (inLds) copy_hyp(hr, hrG);
+        const double gain0 = emit(nextHyp, rootGain, 0);
+        const double cutoffGain = maximize ? (rootGain - p.cutoff) : (rootGain + p.cutoff);  // cpp:680-686
+        heap_push(nextHyp, 0, rootGain);
+        nextHyp++;
         long long pushed = 0;
         int sweep = 1, err = 0;
         for (; sweep < p.k; sweep++) {  // cpp:607-634
-            const int cur = heap_pop();
-            const Hyp hp = hyp(cur);
-            const int a = hp.act[0];
+            double gTop;
+            int cur, a;
+            heap_top(gTop, cur, a);
+            heap_pop();
+            // the hypothesis that is split: once from the pool into LDS (MODE 0: read where it lies, behind a real fence)
+            const Hyp hpG = hyp(cur);
+            if (inLds) { copy_hyp(hpG, pLds); wave_fence(); } else full_sync();
+            const Hyp hp = inLds ? pLds : hpG;
             // ---- split (cpp:455-532): the children of columns a .. M-1, each fully solved, pushed in that order ----
-            for (int c = a; c < M && !err; c++) {
+            for (int c = a; c < M; c++) {
                 // rows still owned by columns >= c of the parent (cpp:480-488; 506-508, 512, 525-527)
                 for (int r = lane; r < D; r += 64) { inScan[r] = 0; forbStart[r] = (c == a) ? hp.forb[r] : 0; }  // cpp:490 / 510
                 sync();
                 for (int j = c + lane; j < D; j += 64) inScan[hp.r4c[j]] = 1;
                 if (c != a && lane == 0) forbStart[hp.r4c[c]] = 1;  // cpp:516
                 sync();
-                int ch = -1;
-                if (!inLds) {
-                    ch = alloc_hyp();
-                    if (ch < 0) { err = 1; break; }
-                }
-                const Hyp hc = inLds ? hLds : hyp(ch);
+                if (nextHyp >= p.hypPerSlot) { err = 1; break; }  // (cannot happen: see the pool above)
+                const Hyp hcG = hyp(nextHyp);
+                const Hyp hc = inLds ? hLds : hcG;
                 for (int i = lane; i < D; i += 64) {  // shortestPathUpdateCPP, cpp:262-278
                     hc.r4c[i] = hp.r4c[i]; hc.c4r[i] = hp.c4r[i]; hc.u[i] = hp.u[i]; hc.v[i] = hp.v[i]; hc.forb[i] = forbStart[i];
                 }
                 sync();
-                if (lane == 0) { hc.act[0] = c; hc.c4r[hc.r4c[c]] = -1; hc.r4c[c] = -1; }
+                if (lane == 0) { hc.c4r[hc.r4c[c]] = -1; hc.r4c[c] = -1; }
                 sync();
-                if (augment(hc, c, true)) { if (!inLds) free_hyp(ch); continue; }  // infeasible child: gain -1, dropped (cpp:496, 521)
+                if (augment(hc, c, true)) continue;  // infeasible child: gain -1, dropped (cpp:496, 521); its record is the next child's
                 const double g = gain_of(hc, M);
                 const bool cut = p.useCutoff && (maximize ? (g < cutoffGain) : (g > cutoffGain));  // cutHyp, hpp:130-131
-                if (cut) { if (!inLds) free_hyp(ch); continue; }
+                if (cut) continue;
                 if (lane == 0) hc.forb[hc.r4c[c]] = 1;  // cpp:362
                 sync();
-                if (inLds) {
-                    ch = alloc_hyp();
-                    if (ch < 0) { err = 1; break; }
-                    store_hyp(hc, hyp(ch));
-                }
-                if (lane == 0) hgain[ch] = g;
-                sync();
-                heap_push(ch);
+                if (inLds) copy_hyp(hc, hcG);
+                heap_push(nextHyp, c, g);
+                nextHyp++;
                 pushed++;
             }
-            if (err) break;
-            free_hyp(cur);
-            if (sh[0] == 0) break;
-            const double gs = emit((int)heap[0].idx, sweep);
+            if (err || heapN == 0) break;
+            heap_top(gTop, cur, a);
+            const double gs = emit(cur, gTop, sweep);
             if (p.useCutoff) {  // cpp:709-719
                 if (!maximize) { if (gs > gain0 + p.cutoff) break; }
                 else           { if (gs < gain0 - p.cutoff) break; }
@@ -368,17 +359,211 @@ __global__ void __launch_bounds__(64) kbest_exact_kernel(ExactParams p)
             p.nf[b] = err ? -4 : sweep;
             if (p.pushed) p.pushed[b] = pushed;
         }
-        sync();
+        full_sync();  // (the next problem of this slot reuses the work space)
+    }
+}
+
+// ---- up to 64 rows: the same algorithm with the hypothesis in REGISTERS --------------------------------------------------------
+// lane = row for v / col4row, lane = column for u / row4col, the forbidden rows one 64-bit mask, the padded cost copy and u in LDS:
+// the Dijkstra step is then the hand-written loop of the LDS kernels (kbest_lap.h: bit-exact against the reference's duals, tests/
+// test_assign_golden.py), the dual update and the path flip are lane reads, and a child is a handful of register copies of its
+// parent.  What the general kernel above spends per step (a pass over LDS arrays, two reductions, three hand-overs: ~1 000 cycles of
+// one wave) is ~150 here.  Everything the ORDER depends on is unchanged: the N augmentations of the padded root in column order,
+// the children of columns activeCol .. M-1 solved completely and pushed in that order, libstdc++'s heap.
+// Lane 0 keeps the heap in HBM; the entry a push will be compared with first -- the parent of the next free position -- is
+// fetched right after the push before, so the usual push (no move, or one) does not wait for memory.
+__global__ void __launch_bounds__(64) kbest_exact64_kernel(ExactParams p)
+{
+    const int lane = threadIdx.x;
+    const double INF = d_inf();
+    const ExLayout L(p.maxRow, p.hypPerSlot);
+    unsigned char *ws = p.work + (long long)blockIdx.x * L.total;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    double *uL = reinterpret_cast<double *>(lds);   // duals of the columns of the hypothesis being solved
+    double *gainW = uL + 64;                         // serial_gain's line of terms
+    double *Cs = gainW + 72;                         // padded, shifted costs: Cs[c * LDC + r]
+    struct HeapE { double g; long long idx; };       // idx: hypothesis | activeCol << 32
+    HeapE *heap = reinterpret_cast<HeapE *>(ws + L.heap);
+    const bool tabI8 = (p.flags & KBEST_FLAG_TABLES_I8) != 0;
+    const bool maximize = p.maximize != 0;
+    auto hyp = [&](int i) {
+        unsigned char *b = ws + L.pool + (long long)i * L.hypStride;
+        return Hyp{reinterpret_cast<double *>(b + L.hu), reinterpret_cast<double *>(b + L.hv), reinterpret_cast<int *>(b + L.hc4r),
+                   reinterpret_cast<int *>(b + L.hr4c), b + L.hforb};
+    };
+    auto first_f64 = [](double x) {
+        return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+    };
+
+    for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
+        const int N = p.nRow ? p.nRow[b] : p.maxRow, M = p.nCol ? p.nCol[b] : p.maxCol;
+        const long long outBase = (long long)b * p.k;
+        if (N < 1 || M < 1 || N < M || N > p.maxRow || M > p.maxCol || N > 64) {  // undefined in the reference
+            if (lane == 0) p.nf[b] = (M == 0 || N == 0) ? 0 : -1;
+            continue;
+        }
+        const int D = N, LDC = D | 1;
+        const int rl = lane < D ? lane : D - 1;
+        const u64 allRows = (D >= 64) ? ~0ull : ((1ull << D) - 1ull);
+        const double *Cg = p.cost + (p.costOff ? p.costOff[b] : (long long)b * p.maxRow * p.maxCol);
+        // ---- makeCostMatrixSafe (cpp:534-569) + zero padding (cpp:582-585, 663-666) ----
+        double d = INF;
+        for (int i = lane; i < N * M; i += 64) d = min_keep(d, maximize ? -Cg[i] : Cg[i]);
+        d = wave_min_f64(d);  // min C, or min(-C) = -max C
+        for (int c = 0; c < D; c++)
+            if (lane < D) Cs[c * LDC + lane] = c < M ? (maximize ? -Cg[c * N + lane] : Cg[c * N + lane]) - d : 0.0;
+        const double CDelta = (maximize ? -d : d) * (double)M;  // cpp:583 (maximize: CDelta is max C)
+        if (lane < D) uL[lane] = 0.0;
+        wave_fence();
+        int nextHyp = 0, heapN = 0;  // (wave-uniform)
+        HeapE nextParent{0.0, 0};    // lane 0: heap[(heapN - 1) / 2], fetched ahead
+
+        auto sift_up = [&](int hole, HeapE val, bool havePe, HeapE pe0) {  // (lane 0; libstdc++ __push_heap)
+            int parent = (hole - 1) / 2;
+            bool first = havePe;
+            while (hole > 0) {
+                const HeapE pe = first ? pe0 : heap[parent];
+                first = false;
+                if (!(pe.g > val.g)) break;
+                heap[hole] = pe;
+                hole = parent;
+                parent = (hole - 1) / 2;
+            }
+            heap[hole] = val;
+        };
+        auto fetch_ahead = [&]() { if (lane == 0 && heapN > 0) nextParent = heap[(heapN - 1) / 2]; };
+        auto heap_push = [&](int hidx, int act, double g) {
+            if (lane == 0) sift_up(heapN, HeapE{g, (long long)hidx | ((long long)act << 32)}, true, nextParent);
+            heapN++;
+            fetch_ahead();
+        };
+        auto heap_top = [&](double &g, int &hidx, int &act) {
+            HeapE e{0.0, 0};
+            if (lane == 0) e = heap[0];
+            g = first_f64(e.g);
+            hidx = __builtin_amdgcn_readfirstlane((int)(e.idx & 0xffffffffll));
+            act = __builtin_amdgcn_readfirstlane((int)(e.idx >> 32));
+        };
+        auto heap_pop = [&]() {  // (libstdc++ __adjust_heap; the caller has taken the top with heap_top)
+            const int len = heapN - 1;
+            if (lane == 0 && len > 0) {
+                const HeapE val = heap[len];
+                int hole = 0, child = 0;
+                while (child < (len - 1) / 2) {
+                    child = 2 * (child + 1);
+                    HeapE ce = heap[child];
+                    const HeapE le = heap[child - 1];  // (two independent loads)
+                    if (ce.g > le.g) { child--; ce = le; }
+                    heap[hole] = ce;
+                    hole = child;
+                }
+                if ((len & 1) == 0 && child == (len - 2) / 2) {
+                    child = 2 * (child + 1);
+                    heap[hole] = heap[child - 1];
+                    hole = child - 1;
+                }
+                sift_up(hole, val, false, val);
+            }
+            heapN = len;
+            fetch_ahead();
+        };
+        // a hypothesis and its record in the pool: element i of every array on lane i, both ways (a lane reads what it wrote)
+        auto store_hyp = [&](int hidx, double v, int c4r, int r4c, u64 forb) {
+            const Hyp h = hyp(hidx);
+            if (lane < D) { h.u[lane] = uL[lane]; h.v[lane] = v; h.c4r[lane] = c4r; h.r4c[lane] = r4c; h.forb[lane] = (unsigned char)((forb >> lane) & 1ull); }
+        };
+        auto emit = [&](int hidx, double g, int slot) {
+            const Hyp h = hyp(hidx);
+            if (lane < M) put_index(p.row4col, (outBase + slot) * p.ldCol + lane, h.r4c[lane], tabI8);
+            if (p.col4row && lane < N) put_index(p.col4row, (outBase + slot) * p.ldRow + lane, h.c4r[lane], tabI8);
+            const double out = maximize ? (-g + CDelta) : (g + CDelta);  // cpp:626-630
+            if (lane == 0) p.gain[outBase + slot] = out;
+            return out;
+        };
+
+        // ---- root: shortestPathCPP (cpp:119-238), N augmentations in column order on the padded problem ----
+        if (p.hypPerSlot < 2) { if (lane == 0) p.nf[b] = -4; continue; }
+        double v = 0.0, spc, delta;
+        int c4r = -1, r4c = -1, pred, sink = 0;
+        u64 scanned;
+        bool infeasible = false;
+        for (int c = 0; c < D; c++) {
+            if (dijkstra<false>(Cs, LDC, uL, rl, lane, v, c4r, allRows, 0ull, c, INF, spc, pred, scanned, delta, sink)) { infeasible = true; break; }
+            dual_update_flip(uL, lane, v, c4r, r4c, spc, pred, scanned, delta, sink, c);
+            wave_fence();
+        }
+        if (infeasible) {  // kBest2D returns 0 (cpp:588-593)
+            if (lane == 0) p.nf[b] = 0;
+            continue;
+        }
+        const double rootGain = serial_gain(Cs, LDC, lane, r4c, M, gainW);
+        store_hyp(0, v, c4r, r4c, bit64(__builtin_amdgcn_readlane(r4c, 0)));  // cpp:232-235
+        const double gain0 = emit(0, rootGain, 0);
+        const double cutoffGain = maximize ? (rootGain - p.cutoff) : (rootGain + p.cutoff);  // cpp:680-686
+        heap_push(0, 0, rootGain);
+        nextHyp = 1;
+        long long pushed = 0;
+        int sweep = 1, err = 0;
+        for (; sweep < p.k; sweep++) {  // cpp:607-634
+            double gTop;
+            int cur, a;
+            heap_top(gTop, cur, a);
+            heap_pop();
+            // the hypothesis that is split, into registers
+            const Hyp hp = hyp(cur);
+            double uP = 0.0, vP = 0.0;
+            int c4rP = -1, r4cP = -1, fb = 0;
+            if (lane < D) { uP = hp.u[lane]; vP = hp.v[lane]; c4rP = hp.c4r[lane]; r4cP = hp.r4c[lane]; fb = hp.forb[lane]; }
+            const u64 forbP = __ballot(fb != 0);
+            // ---- split (cpp:455-532): the children of columns a .. M-1, each fully solved, pushed in that order ----
+            for (int c = a; c < M; c++) {
+                if (nextHyp >= p.hypPerSlot) { err = 1; break; }  // (cannot happen: at most 1 + (k - 1) M pushes, plan_exact)
+                const int fr = __builtin_amdgcn_readlane(r4cP, c);         // row freed: cpp:277-278
+                const u64 cand = __ballot(lane < D && c4rP >= c);           // rows of columns >= c: cpp:480-488, 525-527
+                const u64 forbm = (c == a) ? forbP : bit64(fr);             // cpp:490 / 510-516
+                c4r = (lane == fr) ? -1 : c4rP;
+                r4c = (lane == c) ? -1 : r4cP;
+                v = vP;
+                if (lane < D) uL[lane] = uP;
+                wave_fence();
+                if (dijkstra<false>(Cs, LDC, uL, rl, lane, v, c4r, cand, forbm, c, INF, spc, pred, scanned, delta, sink)) continue;  // infeasible: cpp:496, 521
+                dual_update_flip(uL, lane, v, c4r, r4c, spc, pred, scanned, delta, sink, c);
+                wave_fence();
+                const double g = serial_gain(Cs, LDC, lane, r4c, M, gainW);
+                if (p.useCutoff && (maximize ? (g < cutoffGain) : (g > cutoffGain))) continue;  // cutHyp, hpp:130-131
+                store_hyp(nextHyp, v, c4r, r4c, forbm | bit64(__builtin_amdgcn_readlane(r4c, c)));  // cpp:362
+                heap_push(nextHyp, c, g);
+                nextHyp++;
+                pushed++;
+            }
+            if (err || heapN == 0) break;
+            heap_top(gTop, cur, a);
+            const double gs = emit(cur, gTop, sweep);
+            if (p.useCutoff) {  // cpp:709-719
+                if (!maximize) { if (gs > gain0 + p.cutoff) break; }
+                else           { if (gs < gain0 - p.cutoff) break; }
+            }
+        }
+        if (lane == 0) {
+            p.nf[b] = err ? -4 : sweep;
+            if (p.pushed) p.pushed[b] = pushed;
+        }
+        wave_fence();
     }
 }
 
 hipError_t launch_kbest_exact(const ExactParams &p, int grid, hipStream_t stream)
 {
     if (p.B <= 0) return hipSuccess;
-    int lds = p.maxRow <= EXACT_LDS_ROWS ? ((19 * p.maxRow + 63) & ~63) + 25 * p.maxRow + 16 + 64 : 0;
-    if (p.maxRow <= EXACT_LDS_C_ROWS) lds = ((lds + 63) & ~63) + 8 * p.maxRow * p.maxRow;
-    if (p.maxRow <= EXACT_LDS_C_ROWS) hipLaunchKernelGGL(kbest_exact_kernel<2>, dim3(grid), dim3(64), lds, stream, p);
-    else if (p.maxRow <= EXACT_LDS_ROWS) hipLaunchKernelGGL(kbest_exact_kernel<1>, dim3(grid), dim3(64), lds, stream, p);
+    if (p.maxRow <= 64) {
+        const int ldc = p.maxRow | 1;
+        hipLaunchKernelGGL(kbest_exact64_kernel, dim3(grid), dim3(64), (64 + 72 + p.maxRow * ldc) * 8, stream, p);
+        return hipGetLastError();
+    }
+    // LDS: the scratch of a search (19 bytes per row), the hypothesis being solved and the one being split (25 each)
+    const int hypB = (25 * p.maxRow + 63) & ~63;
+    const int lds = p.maxRow <= EXACT_LDS_ROWS ? ((19 * p.maxRow + 63) & ~63) + 2 * hypB : 0;
+    if (p.maxRow <= EXACT_LDS_ROWS) hipLaunchKernelGGL(kbest_exact_kernel<1>, dim3(grid), dim3(64), lds, stream, p);
     else hipLaunchKernelGGL(kbest_exact_kernel<0>, dim3(grid), dim3(64), lds, stream, p);
     return hipGetLastError();
 }

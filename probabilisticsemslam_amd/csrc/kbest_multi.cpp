@@ -531,7 +531,9 @@ int kbest_batch_f64_multi_ex(kbest_multi *m, const kbest_opts *opts, int mode, i
             int32_t *fl = m->lastTie.data() + b0;
             W_HIP(d, hipMemcpy(fl, d.tieFl, (size_t)nb * 4, hipMemcpyDeviceToHost));
             bool any = false;
-            for (int i = 0; i < nb; i++) any = any || (fl[i] & KBEST_TIE_BOUNDARY);
+            const int tiedMask = (opts->flags & KBEST_FLAG_REFERENCE_TIES) ? (KBEST_TIE_INSIDE | KBEST_TIE_BOUNDARY | KBEST_TIE_UNCHECKED | KBEST_TIE_UNORDERED)
+                                                                            : KBEST_TIE_BOUNDARY;
+            for (int i = 0; i < nb; i++) any = any || (fl[i] & tiedMask);
             if (any && !(opts->flags & KBEST_FLAG_NO_TIE_RESOLVE)) {
                 std::vector<int> changed;
                 kb_complete_tie_levels(d.ctx, opts, nb, maxRow, maxCol, nRow ? nRow + b0 : nullptr, nCol ? nCol + b0 : nullptr, cost + (size_t)b0 * per,

@@ -15,9 +15,11 @@
 
 namespace {
 
-bool shim_reference_order()
+// KBEST_SHIM_REFERENCE_ORDER: 1 = everything on the reference-order kernel; 2 = only what has an exact tie (KBEST_FLAG_REFERENCE_TIES /
+// kbest_set_reference_order(ctx, 2): the same answer, the fast kernels wherever nothing ties); unset / 0 = the engine's own rule
+int shim_reference_order()
 {
-    static const bool on = [] { const char *e = getenv("KBEST_SHIM_REFERENCE_ORDER"); return e && *e && *e != '0'; }();
+    static const int on = [] { const char *e = getenv("KBEST_SHIM_REFERENCE_ORDER"); return (e && *e && *e != '0') ? (*e == '2' ? 2 : 1) : 0; }();
     return on;
 }
 
@@ -28,7 +30,7 @@ kbest_ctx *global_ctx()
     static int rc = KBEST_OK;
     std::call_once(once, [] {
         rc = kbest_create(&ctx, 0);
-        if (rc == KBEST_OK && shim_reference_order()) kbest_set_reference_order(ctx, 1);  // (assignmentProb / bruteForceProb as well)
+        if (rc == KBEST_OK && shim_reference_order()) kbest_set_reference_order(ctx, shim_reference_order());  // (assignmentProb / bruteForceProb as well)
     });
     if (rc != KBEST_OK || !ctx) throw std::runtime_error(std::string("kbest engine: ") + kbest_strerror(rc));
     return ctx;
@@ -51,7 +53,9 @@ size_t kbest_one(size_t k, size_t numRow, size_t numCol, bool maximize, const do
     o.cutoff = cutoff;
     // KBEST_SHIM_REFERENCE_ORDER=1: the drop-in answers in the reference's own order of operations (kbest_exact.hip) -- exact ties as
     // the reference's heap pops them, col4row on padded columns as the reference names them; slower (kbest_c.h, KBEST_FLAG_REFERENCE_ORDER)
-    if (shim_reference_order()) o.flags |= KBEST_FLAG_REFERENCE_ORDER;
+    // (=2: KBEST_FLAG_REFERENCE_TIES -- only a problem with an exact tie among its k + 1 best gains takes that kernel)
+    if (shim_reference_order() == 1) o.flags |= KBEST_FLAG_REFERENCE_ORDER;
+    else if (shim_reference_order() == 2) o.flags |= KBEST_FLAG_REFERENCE_TIES;
     std::vector<int32_t> r4c(k * numCol), c4r(k * numRow);
     int32_t nf = 0;
     check(ctx, kbest_batch_f64(ctx, &o, 1, (int)numRow, (int)numCol, nullptr, nullptr, C, nullptr, (int)k, r4c.data(),

@@ -50,11 +50,21 @@ def check_case(eng, case, reference_order=False):
     N, M, k, C = case["N"], case["M"], case["k"], case["C"]
     # every third case takes its tables as int8 (KBEST_FLAG_TABLES_I8): the same values from every kernel's output phase
     i8 = N <= 127 and (N + M + k + case["B"]) % 3 == 0
-    nf, r4c, c4r, g = eng.kbest(C, N, M, k, case["maximize"], case["cutoff"], tables_i8=i8, reference_order=reference_order)[:4]
+    # reference_order == 2: KBEST_FLAG_REFERENCE_TIES -- the fast kernels, the tied problems again on the reference-order kernel: gains
+    # and row4col the checker's slot for slot on EVERY problem, col4row up to the names of padded columns (raw on the re-run problems)
+    ties_only = reference_order == 2
+    nf, r4c, c4r, g = eng.kbest(C, N, M, k, case["maximize"], case["cutoff"], tables_i8=i8, reference_order=reference_order is True or reference_order == 1,
+                                reference_ties=ties_only)[:4]
     onf, or4c, oc4r, og, _ = ol.orc_kbest_batch(C, N, M, k, case["maximize"], case["cutoff"])
     for b in range(case["B"]):
         n = int(onf[b])
         ok = nf[b] == n and (g[b, :n].view(np.int64) == og[b, :n].view(np.int64)).all()
+        if ties_only:
+            named = lambda t: np.where(t >= M, -1, t)  # noqa: E731
+            ok = ok and (r4c[b, :n] == or4c[b, :n]).all() and (named(c4r[b, :n].astype(np.int32)) == named(oc4r[b, :n])).all()
+            if not ok:
+                return dict(b=b, nf=int(nf[b]), onf=n, reference_ties=True, **{key: case[key] for key in ("N", "M", "k", "B", "maximize", "cutoff", "kind")})
+            continue
         if reference_order:
             ok = ok and (r4c[b, :n] == or4c[b, :n]).all() and (c4r[b, :n] == oc4r[b, :n]).all()
             if not ok:

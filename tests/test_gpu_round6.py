@@ -729,6 +729,117 @@ def test_association_probabilities_in_reference_order():
     eng.close()
 
 
+def _named(c4r, M):
+    """col4row with the padded columns' names dropped (which padded column a left-over row sits on is immaterial)."""
+    return np.where(c4r >= M, -1, c4r)
+
+
+@pytest.mark.parametrize("shape", [(6, 6, 40, 3), (12, 7, 50, 5), (20, 20, 120, 30), (30, 10, 200, 12), (64, 64, 100, 9)])
+def test_reference_ties_is_the_references_answer_on_every_problem(engine, shape):
+    """KBEST_FLAG_REFERENCE_TIES: the batch on the fast kernels, then every problem with an exact tie among its k + 1 best gains again
+    on the reference-order kernel.  A batch of integer-cost problems (ties) and continuous ones (none), alternating: EVERY problem's
+    tables are the checker's slot for slot -- gains' bits, row4col in the reference's heap order, col4row (raw on the re-run problems)
+    --, the tied problems are flagged KBEST_TIE_REFERENCE and the continuous ones are not touched.  Plain, with a cutoff, maximising."""
+    E = pk.engine
+    N, M, k, hi = shape
+    rng = np.random.default_rng(11 * N + k)
+    B = 12
+    costs = rng.random((B, N * M)) * hi
+    costs[::2] = rng.integers(0, hi, size=(B // 2, N * M)).astype(np.float64)
+    for kw in ({}, {"cutoff": float(hi)}, {"maximize": True}):
+        nf, r4c, c4r, g, fl = engine.kbest(costs, N, M, k, reference_ties=True, tie_flags=True, **kw)
+        onf, or4c, oc4r, og, _ = ol.orc_kbest_batch(costs, N, M, k, **kw)
+        assert (nf == onf).all(), kw
+        for b in range(B):
+            n = int(onf[b])
+            assert (bits(g[b, :n]) == bits(og[b, :n])).all(), (kw, b)
+            assert (r4c[b, :n] == or4c[b, :n]).all(), (kw, b, hex(int(fl[b])))
+            assert (_named(c4r[b, :n], M) == _named(oc4r[b, :n], M)).all(), (kw, b)
+            tied_inside = n > 1 and bool((og[b, 1:n] == og[b, : n - 1]).any())
+            if fl[b] & E.KBEST_TIE_REFERENCE:
+                assert (c4r[b, :n] == oc4r[b, :n]).all(), (kw, b)
+                assert not (fl[b] & (E.KBEST_TIE_BOUNDARY | E.KBEST_TIE_UNRESOLVED | E.KBEST_TIE_UNORDERED))
+            else:
+                assert fl[b] == 0 and not tied_inside, (kw, b, hex(int(fl[b])))
+        assert (fl[1::2] == 0).all(), kw                       # continuous costs: nothing ties, nothing is run again
+        assert (fl[::2] & E.KBEST_TIE_REFERENCE).any(), kw     # integer costs: ties
+
+
+def test_reference_ties_behind_the_device_entry_and_on_two_devices(engine):
+    """The asynchronous entry reports the flags; kbest_resolve_ties_dev with KBEST_FLAG_REFERENCE_TIES replaces the flagged problems'
+    device tables by the reference-order kernel's.  The multi-device batch entry does the same by itself, before its exchange: both
+    devices' global tables agree and are the checker's."""
+    import torch
+    E = pk.engine
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(31)
+    B, N, M, k = 48, 16, 16, 90
+    costs = rng.random((B, N * M)) * 7
+    costs[: B // 2] = rng.integers(0, 7, size=(B // 2, N * M)).astype(np.float64)
+    onf, or4c, oc4r, og, _ = ol.orc_kbest_batch(costs, N, M, k)
+    d_cost = torch.from_numpy(costs).to(dev)
+    d_r = torch.zeros((B, k, M), dtype=torch.int32, device=dev)
+    d_c = torch.zeros((B, k, N), dtype=torch.int32, device=dev)
+    d_g = torch.zeros((B, k), dtype=torch.float64, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_f = torch.zeros(B, dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    engine.reserve(B, N, k)
+    engine.kbest_dev(d_cost, B, N, M, k, d_r, d_c, d_g, d_n, stream=st, d_tie_flags=d_f)
+    engine.resolve_ties_dev(d_cost, B, N, M, k, d_r, d_c, d_g, d_f, stream=st, reference_ties=True)
+    torch.cuda.synchronize()
+    fl = d_f.cpu().numpy()
+    assert (d_n.cpu().numpy() == onf).all() and (bits(d_g.cpu().numpy()) == bits(og)).all()
+    assert (d_r.cpu().numpy() == or4c).all() and (d_c.cpu().numpy() == oc4r).all()
+    assert (fl[B // 2:] == 0).all() and (fl[: B // 2] & E.KBEST_TIE_REFERENCE).any()
+    multi = pk.KBestMulti([0, 0])
+    nf, r4c, c4r, g = multi.kbest(costs, N, M, k, reference_ties=True)
+    assert multi.tables_agree()
+    mfl = multi.last_tie_flags()
+    multi.close()
+    assert (nf == onf).all() and (bits(g) == bits(og)).all() and (r4c == or4c).all() and (c4r == oc4r).all()
+    assert (mfl[B // 2:] == 0).all() and (mfl[: B // 2] & E.KBEST_TIE_REFERENCE).any()
+
+
+def test_association_probabilities_reference_ties():
+    """kbest_set_reference_order(ctx, 2): the fused association kernels, and only the frames whose k-th and (k+1)-th gains are equal
+    again through the reference-order kernel.  The probabilities of EVERY frame are the checker's (the compiled reference's heap
+    order where a level straddles slot k), rel 1e-12; some frames were run again (KBEST_TIE_REFERENCE), most were not."""
+    E = pk.engine
+    eng = pk.KBestEngine(0)
+    eng.set_reference_order(2)
+    rng = np.random.default_rng(45)
+    checked = rerun = 0
+    for (nL, nM, k, hi) in ((6, 3, 20, 6), (12, 5, 100, 8), (20, 10, 200, 12), (20, 10, 50, 4)):
+        nR = nL + nM
+        frames = []
+        for i in range(40):
+            C_ = np.full(nR * nM, np.inf)
+            for c in range(nM):
+                near = rng.random(nL) < 4.0 / nL
+                near[c % nL] = True
+                vals = rng.integers(0, hi, nL).astype(np.float64) if i % 2 == 0 else hi * rng.random(nL)
+                C_[c * nR: c * nR + nL] = np.where(near, vals, 60 + rng.integers(0, 400, nL))
+                C_[c * nR + nL + c] = 10.0
+            frames.append(C_)
+        P, nf = eng.weights(frames, [nL] * len(frames), [nM] * len(frames), k, condition=True)
+        fl = eng.last_tie_flags()
+        for f, fr in enumerate(frames):
+            cond, idx = ol.condition_costs(fr, nR, nM)
+            cl = len(idx) - nM
+            q, n = ol.assignment_prob(cond, cl, nM, k)
+            full = np.zeros((nM, nL + 1))
+            full[:, np.asarray(idx[:cl], dtype=np.int64)] = q[:, :cl]
+            full[:, nL] = q[:, cl]
+            assert nf[f] == n, (nL, nM, k, f)
+            np.testing.assert_allclose(P[f], full, rtol=1e-12, atol=1e-300, err_msg=str((nL, nM, k, f, hex(int(fl[f])))))
+            assert not (fl[f] & (E.KBEST_TIE_UNRESOLVED | E.KBEST_TIE_RESOLVED))
+            checked += 1
+            rerun += int(bool(fl[f] & E.KBEST_TIE_REFERENCE))
+    assert checked == 160 and 10 < rerun < 120
+    eng.close()
+
+
 def test_association_with_more_than_1024_kept_rows(engine):
     """getAssignmentProbs / assignmentProb on frames that keep more than 1 024 rows after conditionCosts (1 100 and 1 500 landmarks
     within the gate): the general pipeline with the reference-order kernel as its enumeration; the checker's probabilities."""
