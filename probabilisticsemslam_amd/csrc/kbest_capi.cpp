@@ -1831,8 +1831,16 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
                     const int64_t *costOff, int k, int32_t *row4col, int32_t *col4row, double *gain,
                     int32_t *nf, int64_t *pushed)
 {
-    if (!ctx || !opts || B <= 0 || k < 1 || !tie_mode(ctx, opts, false))
+    if (!ctx || !opts || B <= 0 || k < 1)
         return kbest_batch_f64_keep(ctx, opts, B, maxRow, maxCol, nRow, nCol, cost, costOff, k, row4col, col4row, gain, nf, pushed, nullptr);
+    if (!tie_mode(ctx, opts, false)) {
+        // no tie check in this mode (the reference's own order, push counting, ...): nothing to flag -- and this entry's tie_flags is a
+        // HOST array, which must not travel down as the device pointer the launches take
+        kbest_opts o = *opts;
+        if (o.tie_flags) memset(o.tie_flags, 0, (size_t)B * 4);
+        o.tie_flags = nullptr;
+        return kbest_batch_f64_keep(ctx, &o, B, maxRow, maxCol, nRow, nCol, cost, costOff, k, row4col, col4row, gain, nf, pushed, nullptr);
+    }
     // Exact ties (kbest_ties.h; "Order of exact ties" in kbest_c.h).  The launch reports per problem whether the k-th and the
     // (k+1)-th best gains are equal; this synchronous entry then completes that gain level for those problems (kb_complete_tie_levels)
     // and keeps the lexicographically first assignments of the level: the answer no longer depends on the kernel the batch was

@@ -597,6 +597,17 @@ def test_reference_order_on_exact_ties_is_the_heap_order(engine, shape):
     assert differs > 0  # (the two orders of ties are different rules)
 
 
+def test_host_tie_flags_with_modes_that_check_no_ties(engine):
+    """kbest_batch_f64's tie_flags is a HOST array.  In the modes without a tie check (the reference's own order, push counting) it comes
+    back zeroed -- it used to travel down to the launch as if it were a device pointer (hipMemsetAsync: invalid argument)."""
+    rng = np.random.default_rng(2)
+    C_ = rng.integers(0, 5, (3, 36)).astype(np.float64)
+    for kw in ({"reference_order": True}, {"count_pushed": True}, {"tie_check": False}):
+        out = engine.kbest(C_, 6, 6, 30, tie_flags=True, **kw)
+        assert (out[-1] == 0).all(), kw
+        assert (out[0] == 30).all(), kw
+
+
 def test_reference_order_through_the_device_entry_and_ragged(engine):
     """The same kernel behind kbest_batch_f64_dev (kbest_reserve_exact first), on a ragged batch with an infeasible problem, a
     problem with fewer than k assignments and int8 tables."""
