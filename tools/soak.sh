@@ -19,6 +19,7 @@ echo "k-best tables with KBEST_FLAG_REFERENCE_TIES (the fast kernels; every prob
 echo "relay launches of batches of several generations (the plan, 2, 5, 8 pieces) against plain launches, every table word: $(timeout $t python3 tests/dev/relay_stress.py $secs $((seed + 30)) 2>&1 | tail -1)"
 echo "association path against the checker: $(timeout $t python3 tests/dev/soak_assoc.py $secs $((seed + 1)) 2>&1 | tail -1)"
 echo "association path on the enumeration kernels only (KBEST_NO_TINY KBEST_NO_BNB) against the checker: $(KBEST_NO_TINY=1 KBEST_NO_BNB=1 timeout $t python3 tests/dev/soak_assoc.py $secs $((seed + 2)) 2>&1 | tail -1)"
+echo "association path on INTEGER costs with kbest_set_reference_order(ctx, 2) (fused kernels; the frames with a tie at slot k again on the reference-order kernel) against the checker's probabilities -- the reference's own choice among a tied level: $(SOAK_ASSOC_REFERENCE=2 timeout $t python3 tests/dev/soak_assoc.py $secs $((seed + 42)) 2>&1 | tail -1)"
 echo "exhaustive kernel against the enumeration kernels, exact ties included: $(timeout $t python3 tests/dev/soak_tiny.py $secs $((seed + 3)) 2>&1 | tail -1)"
 echo "exhaustive kernel + bounded walk against the enumeration kernels (SOAK_BNB=1), exact ties included: $(SOAK_BNB=1 timeout $t python3 tests/dev/soak_tiny.py $secs $((seed + 4)) 2>&1 | tail -1)"
 } > $out/soak.log 2>&1
