@@ -372,6 +372,12 @@ __global__ void __launch_bounds__(64) kbest_exact_kernel(ExactParams p)
 // the children of columns activeCol .. M-1 solved completely and pushed in that order, libstdc++'s heap.
 // Lane 0 keeps the heap in HBM; the entry a push will be compared with first -- the parent of the next free position -- is
 // fetched right after the push before, so the usual push (no move, or one) does not wait for memory.
+// HEAP_LDS: the heap too lies in LDS -- where 16 bytes per hypothesis of the pool fit beside the cost copy in a quarter of a CU's LDS
+// (a 28 x 10 frame at k = 200: 2 000 entries, 32 KB): a pop is then eleven LDS round trips instead of eleven trips to HBM.  Worth 12 % on
+// one integer 28 x 10 problem, k = 200 (1.9 -> 1.7 ms): what a sweep costs on this kernel is its children's Dijkstra steps, ~0.2 us each
+// on a wave that has its SIMD to itself -- in the padded N x N formulation a child's search walks through the tied zero columns, which
+// the LDS kernels skip and this kernel, whose point is the reference's own sequence, does not.
+template <bool HEAP_LDS>
 __global__ void __launch_bounds__(64) kbest_exact64_kernel(ExactParams p)
 {
     const int lane = threadIdx.x;
@@ -383,7 +389,7 @@ __global__ void __launch_bounds__(64) kbest_exact64_kernel(ExactParams p)
     double *gainW = uL + 64;                         // serial_gain's line of terms
     double *Cs = gainW + 72;                         // padded, shifted costs: Cs[c * LDC + r]
     struct HeapE { double g; long long idx; };       // idx: hypothesis | activeCol << 32
-    HeapE *heap = reinterpret_cast<HeapE *>(ws + L.heap);
+    HeapE *heap = HEAP_LDS ? reinterpret_cast<HeapE *>(Cs + (((long long)p.maxRow * (p.maxRow | 1) + 1) & ~1ll)) : reinterpret_cast<HeapE *>(ws + L.heap);
     const bool tabI8 = (p.flags & KBEST_FLAG_TABLES_I8) != 0;
     const bool maximize = p.maximize != 0;
     auto hyp = [&](int i) {
@@ -557,7 +563,9 @@ hipError_t launch_kbest_exact(const ExactParams &p, int grid, hipStream_t stream
     if (p.B <= 0) return hipSuccess;
     if (p.maxRow <= 64) {
         const int ldc = p.maxRow | 1;
-        hipLaunchKernelGGL(kbest_exact64_kernel, dim3(grid), dim3(64), (64 + 72 + p.maxRow * ldc) * 8, stream, p);
+        const long long base = (64 + 72 + ((p.maxRow * ldc + 1) & ~1)) * 8, withHeap = base + 16ll * p.hypPerSlot;
+        if (withHeap <= 40 * 1024) hipLaunchKernelGGL(kbest_exact64_kernel<true>, dim3(grid), dim3(64), (int)withHeap, stream, p);
+        else hipLaunchKernelGGL(kbest_exact64_kernel<false>, dim3(grid), dim3(64), (int)base, stream, p);
         return hipGetLastError();
     }
     // LDS: the scratch of a search (19 bytes per row), the hypothesis being solved and the one being split (25 each)
