@@ -26,7 +26,7 @@
 //     the hypothesis being solved and the one being split are in LDS, the cost copy in an HBM work space.
 // In both the queue is lane 0's, in HBM, and the pool of hypotheses (25 N bytes each, one per push: a child only reaches it if it is
 // feasible and not cut) too.  This is the slow, total, literal path -- 256 problems of 64 x 64, k = 200 take 52 ms here (0.2 ms per
-// problem in a batch, 1 024 of them 93 ms; the reference on one host core: 10 ms per problem) against 0.7 ms on the LDS kernel; 1 000
+// problem in a batch, 1 024 of them 58 ms; the reference on one host core: 10 ms per problem) against 0.7 ms on the LDS kernel; 1 000
 // integer-cost 28 x 10 problems 9 ms against 4.5; 64 problems of 200 x 150, k = 50: 650 ms -- and is only taken when asked for
 // (KBEST_FLAG_REFERENCE_ORDER; the tied problems of a KBEST_FLAG_REFERENCE_TIES call) or when no other kernel takes the size.
 #include <hip/hip_runtime.h>
@@ -48,7 +48,10 @@ struct ExLayout {  // byte offsets inside one slot of the work space (D = maxRow
     __host__ __device__ ExLayout(long long D, long long H)
     {
         auto up = [](long long x) { return (x + 63) & ~63ll; };
-        hu = 0; hv = up(8 * D); hc4r = hv + up(8 * D); hr4c = hc4r + up(4 * D); hforb = hr4c + up(4 * D);
+        // (up to 64 rows -- kbest_exact64_kernel -- the two index arrays are bytes: 1 216 instead of 1 600 bytes per hypothesis of a
+        //  64 x 64 problem, so that the pools of 1 024 such problems at k = 200 fit the work space's budget side by side)
+        const long long idx = D <= 64 ? 1 : 4;
+        hu = 0; hv = up(8 * D); hc4r = hv + up(8 * D); hr4c = hc4r + up(idx * D); hforb = hr4c + up(idx * D);
         hypStride = up(hforb + D);
         long long o = 0;
         C = o;         o += up(8 * D * D);
@@ -392,10 +395,15 @@ __global__ void __launch_bounds__(64) kbest_exact64_kernel(ExactParams p)
     HeapE *heap = HEAP_LDS ? reinterpret_cast<HeapE *>(Cs + (((long long)p.maxRow * (p.maxRow | 1) + 1) & ~1ll)) : reinterpret_cast<HeapE *>(ws + L.heap);
     const bool tabI8 = (p.flags & KBEST_FLAG_TABLES_I8) != 0;
     const bool maximize = p.maximize != 0;
+    struct Hyp8 {  // (the record of a problem of up to 64 rows: byte indices)
+        double *u, *v;
+        signed char *c4r, *r4c;
+        unsigned char *forb;
+    };
     auto hyp = [&](int i) {
         unsigned char *b = ws + L.pool + (long long)i * L.hypStride;
-        return Hyp{reinterpret_cast<double *>(b + L.hu), reinterpret_cast<double *>(b + L.hv), reinterpret_cast<int *>(b + L.hc4r),
-                   reinterpret_cast<int *>(b + L.hr4c), b + L.hforb};
+        return Hyp8{reinterpret_cast<double *>(b + L.hu), reinterpret_cast<double *>(b + L.hv), reinterpret_cast<signed char *>(b + L.hc4r),
+                    reinterpret_cast<signed char *>(b + L.hr4c), b + L.hforb};
     };
     auto first_f64 = [](double x) {
         return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
@@ -475,11 +483,11 @@ __global__ void __launch_bounds__(64) kbest_exact64_kernel(ExactParams p)
         };
         // a hypothesis and its record in the pool: element i of every array on lane i, both ways (a lane reads what it wrote)
         auto store_hyp = [&](int hidx, double v, int c4r, int r4c, u64 forb) {
-            const Hyp h = hyp(hidx);
-            if (lane < D) { h.u[lane] = uL[lane]; h.v[lane] = v; h.c4r[lane] = c4r; h.r4c[lane] = r4c; h.forb[lane] = (unsigned char)((forb >> lane) & 1ull); }
+            const Hyp8 h = hyp(hidx);
+            if (lane < D) { h.u[lane] = uL[lane]; h.v[lane] = v; h.c4r[lane] = (signed char)c4r; h.r4c[lane] = (signed char)r4c; h.forb[lane] = (unsigned char)((forb >> lane) & 1ull); }
         };
         auto emit = [&](int hidx, double g, int slot) {
-            const Hyp h = hyp(hidx);
+            const Hyp8 h = hyp(hidx);
             if (lane < M) put_index(p.row4col, (outBase + slot) * p.ldCol + lane, h.r4c[lane], tabI8);
             if (p.col4row && lane < N) put_index(p.col4row, (outBase + slot) * p.ldRow + lane, h.c4r[lane], tabI8);
             const double out = maximize ? (-g + CDelta) : (g + CDelta);  // cpp:626-630
@@ -516,7 +524,7 @@ __global__ void __launch_bounds__(64) kbest_exact64_kernel(ExactParams p)
             heap_top(gTop, cur, a);
             heap_pop();
             // the hypothesis that is split, into registers
-            const Hyp hp = hyp(cur);
+            const Hyp8 hp = hyp(cur);
             double uP = 0.0, vP = 0.0;
             int c4rP = -1, r4cP = -1, fb = 0;
             if (lane < D) { uP = hp.u[lane]; vP = hp.v[lane]; c4rP = hp.c4r[lane]; r4cP = hp.r4c[lane]; fb = hp.forb[lane]; }
