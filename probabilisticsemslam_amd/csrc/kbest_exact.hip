@@ -16,20 +16,24 @@
 // pop order of equal gains is the reference's, and col4row names the padded column every left-over row sits on exactly as the
 // reference does (SURVEY 8(a) quirks 6 and 7 do not apply to this kernel).
 //
-// One WAVE per problem.  Two forms of the same sequence of operations:
+// Two forms of the same sequence of operations:
 //   * up to 64 rows (kbest_exact64_kernel): the hypothesis in REGISTERS -- lane = row for v / col4row, lane = column for u /
 //     row4col, the forbidden rows a 64-bit mask --, the padded cost copy in LDS, the Dijkstra step the hand-written loop of the LDS
-//     kernels (kbest_lap.h), a child a few register copies of its parent;
-//   * beyond (kbest_exact_kernel<MODE>): the lanes share the rows of a Dijkstra step (row = lane, lane + 64, ...: the reduced costs
+//     kernels (kbest_lap.h), a child a few register copies of its parent; one wave per problem, or EIGHT: the children of a sweep are
+//     independent of one another (each is solved completely from the parent), only their pushes have an order -- the waves solve
+//     them side by side, wave 0 then pushes them in column order;
+//   * beyond (kbest_exact_kernel<MODE>), one wave per problem: the lanes share the rows of a Dijkstra step (row = lane, lane + 64, ...: the reduced costs
 //     ((delta + C) - u) - v left to right, the strict-'<' update, the minimum with the LOWEST row among equal values: cpp:183-191,
 //     313-320), the dual update and the copies of a hypothesis; the path flip is one lane's; up to 1 024 rows the scratch of a search,
 //     the hypothesis being solved and the one being split are in LDS, the cost copy in an HBM work space.
 // In both the queue is lane 0's, in HBM, and the pool of hypotheses (25 N bytes each, one per push: a child only reaches it if it is
-// feasible and not cut) too.  This is the slow, total, literal path -- 256 problems of 64 x 64, k = 200 take 52 ms here (0.2 ms per
-// problem in a batch, 1 024 of them 58 ms; the reference on one host core: 10 ms per problem) against 0.7 ms on the LDS kernel; 1 000
+// feasible and not cut) too.  This is the slow, total, literal path -- 256 problems of 64 x 64, k = 200 take 15 ms here (1 024 of
+// them 34 ms, one alone 9.7 ms; the reference on one host core: 10 ms per problem) against 0.7 ms on the LDS kernel; 1 000
 // integer-cost 28 x 10 problems 9 ms against 4.5; 64 problems of 200 x 150, k = 50: 650 ms -- and is only taken when asked for
 // (KBEST_FLAG_REFERENCE_ORDER; the tied problems of a KBEST_FLAG_REFERENCE_TIES call) or when no other kernel takes the size.
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 
 #include "kbest_engine.h"
 #include "kbest_lap.h"
@@ -376,25 +380,31 @@ __global__ void __launch_bounds__(64) kbest_exact_kernel(ExactParams p)
 // Lane 0 keeps the heap in HBM; the entry a push will be compared with first -- the parent of the next free position -- is
 // fetched right after the push before, so the usual push (no move, or one) does not wait for memory.
 // HEAP_LDS: the heap too lies in LDS -- where 16 bytes per hypothesis of the pool fit beside the cost copy in a quarter of a CU's LDS
-// (a 28 x 10 frame at k = 200: 2 000 entries, 32 KB): a pop is then eleven LDS round trips instead of eleven trips to HBM.  Worth 12 % on
-// one integer 28 x 10 problem, k = 200 (1.9 -> 1.7 ms): what a sweep costs on this kernel is its children's Dijkstra steps, ~0.2 us each
-// on a wave that has its SIMD to itself -- in the padded N x N formulation a child's search walks through the tied zero columns, which
-// the LDS kernels skip and this kernel, whose point is the reference's own sequence, does not.
-template <bool HEAP_LDS>
-__global__ void __launch_bounds__(64) kbest_exact64_kernel(ExactParams p)
+// (a 28 x 10 frame at k = 200: 2 000 entries, 32 KB): a pop is then eleven LDS round trips instead of eleven trips to HBM.
+// NW waves per problem: the children of a sweep -- each solved completely from the parent, independent of one another -- are dealt to
+// the waves (child of column a + w, a + w + NW, ...); only the PUSHES have an order, and wave 0 makes them in column order once all
+// children are solved (their gains wait in LDS), then emits the new top and pops the next hypothesis: two barriers per sweep.  The
+// pool's records are handed out by an LDS counter: which record a hypothesis gets does not matter, only its place in the heap does.
+template <bool HEAP_LDS, int NW>
+__global__ void __launch_bounds__(64 * NW) kbest_exact64_kernel(ExactParams p)
 {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const double INF = d_inf();
     const ExLayout L(p.maxRow, p.hypPerSlot);
     unsigned char *ws = p.work + (long long)blockIdx.x * L.total;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    double *uL = reinterpret_cast<double *>(lds);   // duals of the columns of the hypothesis being solved
-    double *gainW = uL + 64;                         // serial_gain's line of terms
-    double *Cs = gainW + 72;                         // padded, shifted costs: Cs[c * LDC + r]
-    struct HeapE { double g; long long idx; };       // idx: hypothesis | activeCol << 32
+    double *uL = reinterpret_cast<double *>(lds) + wave * 136;  // duals of the columns of the hypothesis this wave is solving
+    double *gainW = uL + 64;                                     // serial_gain's line of terms (this wave's)
+    double *resG = reinterpret_cast<double *>(lds) + NW * 136;   // [64] gains of the sweep's children, by column
+    int *resIdx = reinterpret_cast<int *>(resG + 64);            // [64] their records, -1 = dropped
+    int *bc = resIdx + 64;                                       // [16] wave 0's words for everybody: see below
+    double *red = reinterpret_cast<double *>(bc + 16);           // [NW] cross-wave minimum of the set-up
+    double *Cs = red + ((NW + 1) & ~1);                          // padded, shifted costs: Cs[c * LDC + r]
+    struct HeapE { double g; long long idx; };                   // idx: hypothesis | activeCol << 32
     HeapE *heap = HEAP_LDS ? reinterpret_cast<HeapE *>(Cs + (((long long)p.maxRow * (p.maxRow | 1) + 1) & ~1ll)) : reinterpret_cast<HeapE *>(ws + L.heap);
     const bool tabI8 = (p.flags & KBEST_FLAG_TABLES_I8) != 0;
     const bool maximize = p.maximize != 0;
+    enum { BC_CUR = 0, BC_ACT = 1, BC_STOP = 2, BC_NEXT = 3, BC_ERR = 4 };
     struct Hyp8 {  // (the record of a problem of up to 64 rows: byte indices)
         double *u, *v;
         signed char *c4r, *r4c;
@@ -413,7 +423,7 @@ __global__ void __launch_bounds__(64) kbest_exact64_kernel(ExactParams p)
         const int N = p.nRow ? p.nRow[b] : p.maxRow, M = p.nCol ? p.nCol[b] : p.maxCol;
         const long long outBase = (long long)b * p.k;
         if (N < 1 || M < 1 || N < M || N > p.maxRow || M > p.maxCol || N > 64) {  // undefined in the reference
-            if (lane == 0) p.nf[b] = (M == 0 || N == 0) ? 0 : -1;
+            if (threadIdx.x == 0) p.nf[b] = (M == 0 || N == 0) ? 0 : -1;
             continue;
         }
         const int D = N, LDC = D | 1;
@@ -422,15 +432,21 @@ __global__ void __launch_bounds__(64) kbest_exact64_kernel(ExactParams p)
         const double *Cg = p.cost + (p.costOff ? p.costOff[b] : (long long)b * p.maxRow * p.maxCol);
         // ---- makeCostMatrixSafe (cpp:534-569) + zero padding (cpp:582-585, 663-666) ----
         double d = INF;
-        for (int i = lane; i < N * M; i += 64) d = min_keep(d, maximize ? -Cg[i] : Cg[i]);
-        d = wave_min_f64(d);  // min C, or min(-C) = -max C
-        for (int c = 0; c < D; c++)
+        for (int i = threadIdx.x; i < N * M; i += 64 * NW) d = min_keep(d, maximize ? -Cg[i] : Cg[i]);
+        d = wave_min_f64(d);
+        if (NW > 1) {
+            if (lane == 0) red[wave] = d;
+            __syncthreads();
+            d = red[0];
+            for (int w = 1; w < NW; w++) d = min_keep(d, red[w]);
+        }
+        // d = min C, or min(-C) = -max C
+        for (int c = wave; c < D; c += NW)
             if (lane < D) Cs[c * LDC + lane] = c < M ? (maximize ? -Cg[c * N + lane] : Cg[c * N + lane]) - d : 0.0;
         const double CDelta = (maximize ? -d : d) * (double)M;  // cpp:583 (maximize: CDelta is max C)
-        if (lane < D) uL[lane] = 0.0;
-        wave_fence();
-        int nextHyp = 0, heapN = 0;  // (wave-uniform)
-        HeapE nextParent{0.0, 0};    // lane 0: heap[(heapN - 1) / 2], fetched ahead
+        __syncthreads();
+        int heapN = 0;             // (wave 0's; wave-uniform)
+        HeapE nextParent{0.0, 0};  // wave 0, lane 0: heap[(heapN - 1) / 2], fetched ahead
 
         auto sift_up = [&](int hole, HeapE val, bool havePe, HeapE pe0) {  // (lane 0; libstdc++ __push_heap)
             int parent = (hole - 1) / 2;
@@ -445,9 +461,9 @@ __global__ void __launch_bounds__(64) kbest_exact64_kernel(ExactParams p)
             }
             heap[hole] = val;
         };
-        auto fetch_ahead = [&]() { if (lane == 0 && heapN > 0) nextParent = heap[(heapN - 1) / 2]; };
+        auto fetch_ahead = [&]() { if (!HEAP_LDS && lane == 0 && heapN > 0) nextParent = heap[(heapN - 1) / 2]; };
         auto heap_push = [&](int hidx, int act, double g) {
-            if (lane == 0) sift_up(heapN, HeapE{g, (long long)hidx | ((long long)act << 32)}, true, nextParent);
+            if (lane == 0) sift_up(heapN, HeapE{g, (long long)hidx | ((long long)act << 32)}, !HEAP_LDS, nextParent);
             heapN++;
             fetch_ahead();
         };
@@ -481,7 +497,8 @@ __global__ void __launch_bounds__(64) kbest_exact64_kernel(ExactParams p)
             heapN = len;
             fetch_ahead();
         };
-        // a hypothesis and its record in the pool: element i of every array on lane i, both ways (a lane reads what it wrote)
+        // a hypothesis and its record in the pool: element i of every array on lane i, both ways (whichever wave: a record is read
+        // by other waves only behind a barrier)
         auto store_hyp = [&](int hidx, double v, int c4r, int r4c, u64 forb) {
             const Hyp8 h = hyp(hidx);
             if (lane < D) { h.u[lane] = uL[lane]; h.v[lane] = v; h.c4r[lane] = (signed char)c4r; h.r4c[lane] = (signed char)r4c; h.forb[lane] = (unsigned char)((forb >> lane) & 1ull); }
@@ -495,43 +512,80 @@ __global__ void __launch_bounds__(64) kbest_exact64_kernel(ExactParams p)
             return out;
         };
 
-        // ---- root: shortestPathCPP (cpp:119-238), N augmentations in column order on the padded problem ----
-        if (p.hypPerSlot < 2) { if (lane == 0) p.nf[b] = -4; continue; }
         double v = 0.0, spc, delta;
         int c4r = -1, r4c = -1, pred, sink = 0;
         u64 scanned;
-        bool infeasible = false;
-        for (int c = 0; c < D; c++) {
-            if (dijkstra<false>(Cs, LDC, uL, rl, lane, v, c4r, allRows, 0ull, c, INF, spc, pred, scanned, delta, sink)) { infeasible = true; break; }
-            dual_update_flip(uL, lane, v, c4r, r4c, spc, pred, scanned, delta, sink, c);
-            wave_fence();
-        }
-        if (infeasible) {  // kBest2D returns 0 (cpp:588-593)
-            if (lane == 0) p.nf[b] = 0;
-            continue;
-        }
-        const double rootGain = serial_gain(Cs, LDC, lane, r4c, M, gainW);
-        store_hyp(0, v, c4r, r4c, bit64(__builtin_amdgcn_readlane(r4c, 0)));  // cpp:232-235
-        const double gain0 = emit(0, rootGain, 0);
-        const double cutoffGain = maximize ? (rootGain - p.cutoff) : (rootGain + p.cutoff);  // cpp:680-686
-        heap_push(0, 0, rootGain);
-        nextHyp = 1;
+        double gain0 = 0.0, cutoffGain = 0.0;
         long long pushed = 0;
-        int sweep = 1, err = 0;
-        for (; sweep < p.k; sweep++) {  // cpp:607-634
+        // wave 0, behind a sweep's children (and behind the root): the pushes in column order, the new top out, the next hypothesis
+        // popped -- or the end of the problem (BC_STOP: the number of solutions + 1)
+        auto turn = [&](int sweep, int a, bool root) {
+            if (!root) {
+                for (int c = a; c < M; c++) {
+                    const int idx = resIdx[c];
+                    if (idx < 0) continue;
+                    heap_push(idx, c, resG[c]);
+                    pushed++;
+                }
+            }
+            int stop = 0;
             double gTop;
-            int cur, a;
-            heap_top(gTop, cur, a);
-            heap_pop();
-            // the hypothesis that is split, into registers
+            int cur, act;
+            if (bc[BC_ERR]) stop = -1;
+            else if (heapN == 0) stop = sweep + 1;  // (never behind the root)
+            else if (!root) {
+                heap_top(gTop, cur, act);
+                const double gs = emit(cur, gTop, sweep);
+                if (p.useCutoff && (maximize ? (gs < gain0 - p.cutoff) : (gs > gain0 + p.cutoff))) stop = sweep + 1;  // cpp:709-719
+                else if (sweep + 1 >= p.k) stop = sweep + 2;
+            } else if (p.k <= 1) stop = 2;
+            if (!stop) {
+                heap_top(gTop, cur, act);
+                heap_pop();
+                if (lane == 0) { bc[BC_CUR] = cur; bc[BC_ACT] = act; }
+            }
+            if (lane == 0) bc[BC_STOP] = stop;
+        };
+
+        // ---- root: shortestPathCPP (cpp:119-238), N augmentations in column order on the padded problem (wave 0) ----
+        if (wave == 0) {
+            if (lane == 0) { bc[BC_ERR] = p.hypPerSlot < 2 ? 1 : 0; bc[BC_NEXT] = 1; }
+            if (lane < D) uL[lane] = 0.0;
+            wave_fence();
+            bool infeasible = false;
+            for (int c = 0; c < D; c++) {
+                if (dijkstra<false>(Cs, LDC, uL, rl, lane, v, c4r, allRows, 0ull, c, INF, spc, pred, scanned, delta, sink)) { infeasible = true; break; }
+                dual_update_flip(uL, lane, v, c4r, r4c, spc, pred, scanned, delta, sink, c);
+                wave_fence();
+            }
+            if (infeasible) {  // kBest2D returns 0 (cpp:588-593)
+                if (lane == 0) bc[BC_STOP] = 1;
+            } else if (p.hypPerSlot < 2) {
+                if (lane == 0) bc[BC_STOP] = -1;
+            } else {
+                const double rootGain = serial_gain(Cs, LDC, lane, r4c, M, gainW);
+                store_hyp(0, v, c4r, r4c, bit64(__builtin_amdgcn_readlane(r4c, 0)));  // cpp:232-235
+                gain0 = emit(0, rootGain, 0);
+                if (lane == 0) { resG[0] = rootGain; }
+                heap_push(0, 0, rootGain);
+                turn(0, 0, true);
+            }
+        }
+        __syncthreads();
+        // (every wave needs the cutoff's reference point: the root's shifted gain)
+        cutoffGain = maximize ? (resG[0] - p.cutoff) : (resG[0] + p.cutoff);  // cpp:680-686
+        int stop = bc[BC_STOP];
+        __syncthreads();  // (resG[0] is a child's slot from here on)
+        for (int sweep = 1; !stop; sweep++) {  // cpp:607-634
+            const int cur = bc[BC_CUR], a = bc[BC_ACT];
+            // the hypothesis that is split, into registers (every wave its own copy)
             const Hyp8 hp = hyp(cur);
             double uP = 0.0, vP = 0.0;
             int c4rP = -1, r4cP = -1, fb = 0;
             if (lane < D) { uP = hp.u[lane]; vP = hp.v[lane]; c4rP = hp.c4r[lane]; r4cP = hp.r4c[lane]; fb = hp.forb[lane]; }
             const u64 forbP = __ballot(fb != 0);
-            // ---- split (cpp:455-532): the children of columns a .. M-1, each fully solved, pushed in that order ----
-            for (int c = a; c < M; c++) {
-                if (nextHyp >= p.hypPerSlot) { err = 1; break; }  // (cannot happen: at most 1 + (k - 1) M pushes, plan_exact)
+            // ---- split (cpp:455-532): the children of columns a .. M-1, each fully solved; this wave's share ----
+            for (int c = a + wave; c < M; c += NW) {
                 const int fr = __builtin_amdgcn_readlane(r4cP, c);         // row freed: cpp:277-278
                 const u64 cand = __ballot(lane < D && c4rP >= c);           // rows of columns >= c: cpp:480-488, 525-527
                 const u64 forbm = (c == a) ? forbP : bit64(fr);             // cpp:490 / 510-516
@@ -540,29 +594,35 @@ __global__ void __launch_bounds__(64) kbest_exact64_kernel(ExactParams p)
                 v = vP;
                 if (lane < D) uL[lane] = uP;
                 wave_fence();
-                if (dijkstra<false>(Cs, LDC, uL, rl, lane, v, c4r, cand, forbm, c, INF, spc, pred, scanned, delta, sink)) continue;  // infeasible: cpp:496, 521
-                dual_update_flip(uL, lane, v, c4r, r4c, spc, pred, scanned, delta, sink, c);
-                wave_fence();
-                const double g = serial_gain(Cs, LDC, lane, r4c, M, gainW);
-                if (p.useCutoff && (maximize ? (g < cutoffGain) : (g > cutoffGain))) continue;  // cutHyp, hpp:130-131
-                store_hyp(nextHyp, v, c4r, r4c, forbm | bit64(__builtin_amdgcn_readlane(r4c, c)));  // cpp:362
-                heap_push(nextHyp, c, g);
-                nextHyp++;
-                pushed++;
+                int idx = -1;
+                if (!dijkstra<false>(Cs, LDC, uL, rl, lane, v, c4r, cand, forbm, c, INF, spc, pred, scanned, delta, sink)) {  // else infeasible: cpp:496, 521
+                    dual_update_flip(uL, lane, v, c4r, r4c, spc, pred, scanned, delta, sink, c);
+                    wave_fence();
+                    const double g = serial_gain(Cs, LDC, lane, r4c, M, gainW);
+                    if (!(p.useCutoff && (maximize ? (g < cutoffGain) : (g > cutoffGain)))) {  // cutHyp, hpp:130-131
+                        if (lane == 0) idx = atomicAdd(&bc[BC_NEXT], 1);
+                        idx = __builtin_amdgcn_readfirstlane(idx);
+                        if (idx >= p.hypPerSlot) {  // (cannot happen: at most 1 + (k - 1) M pushes, plan_exact)
+                            if (lane == 0) bc[BC_ERR] = 1;
+                            idx = -1;
+                        } else {
+                            store_hyp(idx, v, c4r, r4c, forbm | bit64(__builtin_amdgcn_readlane(r4c, c)));  // cpp:362
+                            if (lane == 0) resG[c] = g;
+                        }
+                    }
+                }
+                if (lane == 0) resIdx[c] = idx;
             }
-            if (err || heapN == 0) break;
-            heap_top(gTop, cur, a);
-            const double gs = emit(cur, gTop, sweep);
-            if (p.useCutoff) {  // cpp:709-719
-                if (!maximize) { if (gs > gain0 + p.cutoff) break; }
-                else           { if (gs < gain0 - p.cutoff) break; }
-            }
+            __syncthreads();
+            if (wave == 0) turn(sweep, a, false);
+            __syncthreads();
+            stop = bc[BC_STOP];
         }
-        if (lane == 0) {
-            p.nf[b] = err ? -4 : sweep;
+        if (threadIdx.x == 0) {
+            p.nf[b] = stop < 0 ? -4 : stop - 1;
             if (p.pushed) p.pushed[b] = pushed;
         }
-        wave_fence();
+        __syncthreads();
     }
 }
 
@@ -570,10 +630,23 @@ hipError_t launch_kbest_exact(const ExactParams &p, int grid, hipStream_t stream
 {
     if (p.B <= 0) return hipSuccess;
     if (p.maxRow <= 64) {
+        // Eight waves per problem (a sweep's children in parallel) where a sweep has children to deal out -- 16 columns and more -- or
+        // the batch leaves most of the chip empty anyway; one wave per problem for large batches of small frames, whose sweeps have
+        // a handful of children and would pay the two barriers per sweep for nothing (1 000 integer 28 x 10 frames: 9.0 against 9.8 ms;
+        // 1 024 x 64x64: 61 against 34 ms; one 64x64 problem: 36 against 9.7 ms).  KBEST_EXACT_WAVES=1 / 8 forces either (A/B).
         const int ldc = p.maxRow | 1;
-        const long long base = (64 + 72 + ((p.maxRow * ldc + 1) & ~1)) * 8, withHeap = base + 16ll * p.hypPerSlot;
-        if (withHeap <= 40 * 1024) hipLaunchKernelGGL(kbest_exact64_kernel<true>, dim3(grid), dim3(64), (int)withHeap, stream, p);
-        else hipLaunchKernelGGL(kbest_exact64_kernel<false>, dim3(grid), dim3(64), (int)base, stream, p);
+        auto bytes = [&](int nw) { return (long long)(nw * 136 + 64 + 32 + 8 + ((nw + 1) & ~1) + ((p.maxRow * ldc + 1) & ~1)) * 8; };
+        const char *force = getenv("KBEST_EXACT_WAVES");
+        const bool many = force ? atoi(force) > 1 : (p.maxCol >= 16 || p.B < 512);
+        if (many) {
+            const long long base = bytes(8), withHeap = base + 16ll * p.hypPerSlot;
+            if (withHeap <= 48 * 1024) hipLaunchKernelGGL((kbest_exact64_kernel<true, 8>), dim3(grid), dim3(512), (int)withHeap, stream, p);
+            else hipLaunchKernelGGL((kbest_exact64_kernel<false, 8>), dim3(grid), dim3(512), (int)base, stream, p);
+        } else {
+            const long long base = bytes(1), withHeap = base + 16ll * p.hypPerSlot;
+            if (withHeap <= 40 * 1024) hipLaunchKernelGGL((kbest_exact64_kernel<true, 1>), dim3(grid), dim3(64), (int)withHeap, stream, p);
+            else hipLaunchKernelGGL((kbest_exact64_kernel<false, 1>), dim3(grid), dim3(64), (int)base, stream, p);
+        }
         return hipGetLastError();
     }
     // LDS: the scratch of a search (19 bytes per row), the hypothesis being solved and the one being split (25 each)
