@@ -22,14 +22,17 @@
 //     kernels (kbest_lap.h), a child a few register copies of its parent; one wave per problem, or EIGHT: the children of a sweep are
 //     independent of one another (each is solved completely from the parent), only their pushes have an order -- the waves solve
 //     them side by side, wave 0 then pushes them in column order;
-//   * beyond (kbest_exact_kernel<MODE>), one wave per problem: the lanes share the rows of a Dijkstra step (row = lane, lane + 64, ...: the reduced costs
-//     ((delta + C) - u) - v left to right, the strict-'<' update, the minimum with the LOWEST row among equal values: cpp:183-191,
-//     313-320), the dual update and the copies of a hypothesis; the path flip is one lane's; up to 1 024 rows the scratch of a search,
-//     the hypothesis being solved and the one being split are in LDS, the cost copy in an HBM work space.
-// In both the queue is lane 0's, in HBM, and the pool of hypotheses (25 N bytes each, one per push: a child only reaches it if it is
-// feasible and not cut) too.  This is the slow, total, literal path -- 256 problems of 64 x 64, k = 200 take 15 ms here (1 024 of
-// them 34 ms, one alone 9.7 ms; the reference on one host core: 10 ms per problem) against 0.7 ms on the LDS kernel; 1 000
-// integer-cost 28 x 10 problems 9 ms against 4.5; 64 problems of 200 x 150, k = 50: 650 ms -- and is only taken when asked for
+//   * 65 .. 1 024 rows (kbest_exactN_kernel: two to eight waves per problem, a sweep's children side by side in the same way) and
+//     beyond (kbest_exact_kernel: one wave): the lanes of a wave share the rows of a Dijkstra step (row = lane, lane + 64, ...: the
+//     reduced costs ((delta + C) - u) - v left to right, the strict-'<' update, the minimum with the LOWEST row among equal values:
+//     cpp:183-191, 313-320), the dual update and the copies of a hypothesis; the path flip is one lane's; up to 1 024 rows every
+//     wave's scratch of a search and hypothesis-being-solved and the hypothesis being split are in LDS, the cost copy in an HBM
+//     work space.
+// In all of them the queue is one lane's, in HBM (or LDS where it fits), and the pool of hypotheses (25 N bytes each, one per push: a
+// child only reaches it if it is feasible and not cut) is in HBM.  This is the slow, total, literal path -- 256 problems of 64 x 64,
+// k = 200 take 15 ms here (1 024 of them 34 ms, one alone 9.7 ms; the reference on one host core: 10 ms per problem) against 0.7 ms
+// on the LDS kernel; 1 000 integer-cost 28 x 10 problems 9 ms against 4.5; 64 problems of 200 x 150, k = 50: 115 ms (one: 76 ms);
+// two of 1 000 x 12, k = 10: 1.7 s, nearly all of it the root's 1 000 augmentations on one wave -- and is only taken when asked for
 // (KBEST_FLAG_REFERENCE_ORDER; the tied problems of a KBEST_FLAG_REFERENCE_TIES call) or when no other kernel takes the size.
 #include <hip/hip_runtime.h>
 
@@ -81,44 +84,20 @@ struct Hyp {
 
 long long exact_slot_bytes(int maxRow, int hypPerSlot) { return ExLayout(maxRow, hypPerSlot).total; }
 
-// 65 rows and more (up to 64: kbest_exact64_kernel below).  MODE 0: everything in the work space (more than EXACT_LDS_ROWS rows);
-// 1: the scratch of a search, the hypothesis being solved and the hypothesis being split in LDS, the padded cost copy in the work
-// space.  A template parameter, not a run-time choice: the pointers must be LDS pointers at compile time (flat accesses to LDS cost
-// a global access' latency).
-//
-// Who talks to whom through memory (one wave per problem, so "who" is a lane):
-//   * LDS: lanes read what other lanes wrote; a wave's LDS accesses execute in program order, so a compiler fence is all it takes
-//     (wave_fence(), kbest_wave.h);
-//   * the pool of hypotheses in HBM: a record is written (store_hyp) and read (the copy of the popped parent into LDS, emit) with
-//     the SAME element -> lane mapping (element i on lane i mod 64), so every lane only ever reads back what it wrote itself;
-//   * the heap in HBM: lane 0 alone; what the wave needs of it (the popped / the top entry) is broadcast from lane 0's registers;
-//   * the cost copy in HBM: written once at set-up, one real fence behind it.
-// MODE 0 has no LDS copies: there the lanes do read each other's global stores, and every hand-over is a real fence.
-template <int MODE>
+// More than EXACT_LDS_ROWS (1 024) rows: one wave per problem, everything in the work space -- the lanes read each other's global
+// stores, so every hand-over between them is a real fence (the heap is lane 0's alone; what the wave needs of it is broadcast from
+// lane 0's registers).  The slowest form, for the sizes nothing else takes: the reference has no size limit (cpp:571-644).
 __global__ void __launch_bounds__(64) kbest_exact_kernel(ExactParams p)
 {
     const int lane = threadIdx.x;
     const double INF = d_inf();
     const ExLayout L(p.maxRow, p.hypPerSlot);
     unsigned char *ws = p.work + (long long)blockIdx.x * L.total;
-    constexpr bool inLds = MODE >= 1;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const long long Dm = p.maxRow;
     // the scratch of a search (ScratchSpace, hpp:73-142)
-    double *spc = inLds ? reinterpret_cast<double *>(lds) : reinterpret_cast<double *>(ws + L.spc);
-    int *pred = inLds ? reinterpret_cast<int *>(lds + 8 * Dm) : reinterpret_cast<int *>(ws + L.pred);
-    int *scanCols = inLds ? reinterpret_cast<int *>(lds + 12 * Dm) : reinterpret_cast<int *>(ws + L.scanCols);
-    unsigned char *scanRow = inLds ? lds + 16 * Dm : ws + L.scanRow;
-    unsigned char *inScan = inLds ? lds + 17 * Dm : ws + L.inScan;
-    unsigned char *forbStart = inLds ? lds + 18 * Dm : ws + L.forbStart;
-    // the hypothesis that is being solved (a child is copied from its parent, solved in LDS, and only goes to the pool in HBM if it
-    // is feasible and not cut) and the hypothesis that is being split (copied from the pool once per sweep): 25 bytes per row each
-    const long long ldsHyp0 = (19 * Dm + 63) & ~63ll, ldsHypB = (25 * Dm + 63) & ~63ll;
-    auto lds_hyp = [&](long long o) {
-        return Hyp{reinterpret_cast<double *>(lds + o), reinterpret_cast<double *>(lds + o + 8 * Dm), reinterpret_cast<int *>(lds + o + 16 * Dm),
-                   reinterpret_cast<int *>(lds + o + 20 * Dm), lds + o + 24 * Dm};
-    };
-    const Hyp hLds = lds_hyp(ldsHyp0), pLds = lds_hyp(ldsHyp0 + ldsHypB);
+    double *spc = reinterpret_cast<double *>(ws + L.spc);
+    int *pred = reinterpret_cast<int *>(ws + L.pred);
+    int *scanCols = reinterpret_cast<int *>(ws + L.scanCols);
+    unsigned char *scanRow = ws + L.scanRow, *inScan = ws + L.inScan, *forbStart = ws + L.forbStart;
     double *Cw = reinterpret_cast<double *>(ws + L.C);
     struct HeapE { double g; long long idx; };  // idx: hypothesis | activeCol << 32
     HeapE *heap = reinterpret_cast<HeapE *>(ws + L.heap);
@@ -132,8 +111,7 @@ __global__ void __launch_bounds__(64) kbest_exact_kernel(ExactParams p)
     };
     // a real fence: what one lane wrote to the work space, every lane reads after this
     auto full_sync = [&]() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __syncthreads(); };
-    // hand-over between the lanes through the scratch / the hypothesis being solved: LDS in MODE 1 and 2
-    auto sync = [&]() { if (inLds) wave_fence(); else full_sync(); };
+    auto sync = [&]() { full_sync(); };
     auto first_i32 = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
     auto first_f64 = [](double x) {
         return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
@@ -277,10 +255,6 @@ __global__ void __launch_bounds__(64) kbest_exact_kernel(ExactParams p)
             }
             heapN = len;
         };
-        // a hypothesis between LDS and its record in the pool: element i on lane i mod 64, both ways
-        auto copy_hyp = [&](const Hyp &src, const Hyp &dst) {
-            for (int i = lane; i < D; i += 64) { dst.r4c[i] = src.r4c[i]; dst.c4r[i] = src.c4r[i]; dst.u[i] = src.u[i]; dst.v[i] = src.v[i]; dst.forb[i] = src.forb[i]; }
-        };
         auto emit = [&](int hidx, double g, int slot) {
             const Hyp h = hyp(hidx);
             for (int c = lane; c < M; c += 64) put_index(p.row4col, (outBase + slot) * p.ldCol + c, h.r4c[c], tabI8);
@@ -294,7 +268,7 @@ __global__ void __launch_bounds__(64) kbest_exact_kernel(ExactParams p)
         // ---- root: shortestPathCPP (cpp:119-238), N augmentations in column order on the padded problem ----
         if (p.hypPerSlot < 2) { if (lane == 0) p.nf[b] = -4; continue; }
         const Hyp hrG = hyp(nextHyp);
-        const Hyp hr = inLds ? hLds : hrG;
+        const Hyp hr = hrG;
         for (int i = lane; i < D; i += 64) { hr.c4r[i] = -1; hr.r4c[i] = -1; hr.u[i] = 0.0; hr.v[i] = 0.0; hr.forb[i] = 0; }
         sync();
         int infeasible = 0;
@@ -310,7 +284,6 @@ __global__ void __launch_bounds__(64) kbest_exact_kernel(ExactParams p)
         const double rootGain = gain_of(hr, M);
         if (lane == 0) hr.forb[hr.r4c[0]] = 1;  // cpp:232-235
         sync();
-        if (inLds) copy_hyp(hr, hrG);
         const double gain0 = emit(nextHyp, rootGain, 0);
         const double cutoffGain = maximize ? (rootGain - p.cutoff) : (rootGain + p.cutoff);  // cpp:680-686
         heap_push(nextHyp, 0, rootGain);
@@ -322,10 +295,10 @@ __global__ void __launch_bounds__(64) kbest_exact_kernel(ExactParams p)
             int cur, a;
             heap_top(gTop, cur, a);
             heap_pop();
-            // the hypothesis that is split: once from the pool into LDS (MODE 0: read where it lies, behind a real fence)
+            // the hypothesis that is split: read where it lies, behind a real fence
             const Hyp hpG = hyp(cur);
-            if (inLds) { copy_hyp(hpG, pLds); wave_fence(); } else full_sync();
-            const Hyp hp = inLds ? pLds : hpG;
+            full_sync();
+            const Hyp hp = hpG;
             // ---- split (cpp:455-532): the children of columns a .. M-1, each fully solved, pushed in that order ----
             for (int c = a; c < M; c++) {
                 // rows still owned by columns >= c of the parent (cpp:480-488; 506-508, 512, 525-527)
@@ -336,7 +309,7 @@ __global__ void __launch_bounds__(64) kbest_exact_kernel(ExactParams p)
                 sync();
                 if (nextHyp >= p.hypPerSlot) { err = 1; break; }  // (cannot happen: see the pool above)
                 const Hyp hcG = hyp(nextHyp);
-                const Hyp hc = inLds ? hLds : hcG;
+                const Hyp hc = hcG;
                 for (int i = lane; i < D; i += 64) {  // shortestPathUpdateCPP, cpp:262-278
                     hc.r4c[i] = hp.r4c[i]; hc.c4r[i] = hp.c4r[i]; hc.u[i] = hp.u[i]; hc.v[i] = hp.v[i]; hc.forb[i] = forbStart[i];
                 }
@@ -349,7 +322,6 @@ __global__ void __launch_bounds__(64) kbest_exact_kernel(ExactParams p)
                 if (cut) continue;
                 if (lane == 0) hc.forb[hc.r4c[c]] = 1;  // cpp:362
                 sync();
-                if (inLds) copy_hyp(hc, hcG);
                 heap_push(nextHyp, c, g);
                 nextHyp++;
                 pushed++;
@@ -367,6 +339,321 @@ __global__ void __launch_bounds__(64) kbest_exact_kernel(ExactParams p)
             if (p.pushed) p.pushed[b] = pushed;
         }
         full_sync();  // (the next problem of this slot reuses the work space)
+    }
+}
+
+// ---- 65 .. 1 024 rows, NW waves per problem ------------------------------------------------------------------------------------
+// kbest_exact_kernel<1>'s sequence of operations with a sweep's children dealt to the waves, as kbest_exact64_kernel below does it:
+// every wave has its own scratch of a search and its own hypothesis-being-solved in LDS, the hypothesis being split is loaded once
+// per sweep by all of them, wave 0 makes the pushes in column order behind a barrier.  (One problem of 200 x 150, k = 50: 640 ms
+// on one wave.)
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) kbest_exactN_kernel(ExactParams p)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    constexpr int NT = 64 * NW;
+    const double INF = d_inf();
+    const ExLayout L(p.maxRow, p.hypPerSlot);
+    unsigned char *ws = p.work + (long long)blockIdx.x * L.total;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const long long Dm = p.maxRow;
+    const long long scrB = (19 * Dm + 63) & ~63ll, hypB = (25 * Dm + 63) & ~63ll;
+    unsigned char *my = lds + wave * (scrB + hypB);
+    // this wave's scratch of a search (ScratchSpace, hpp:73-142) and the hypothesis it is solving
+    double *spc = reinterpret_cast<double *>(my);
+    int *pred = reinterpret_cast<int *>(my + 8 * Dm);
+    int *scanCols = reinterpret_cast<int *>(my + 12 * Dm);
+    unsigned char *scanRow = my + 16 * Dm, *inScan = my + 17 * Dm, *forbStart = my + 18 * Dm;
+    auto lds_hyp = [&](unsigned char *o) {
+        return Hyp{reinterpret_cast<double *>(o), reinterpret_cast<double *>(o + 8 * Dm), reinterpret_cast<int *>(o + 16 * Dm),
+                   reinterpret_cast<int *>(o + 20 * Dm), o + 24 * Dm};
+    };
+    const Hyp hLds = lds_hyp(my + scrB);
+    // everybody's: the hypothesis being split, the sweep's results by column, wave 0's words
+    unsigned char *sh = lds + NW * (scrB + hypB);
+    const Hyp pLds = lds_hyp(sh);
+    double *resG = reinterpret_cast<double *>(sh + hypB);
+    int *resIdx = reinterpret_cast<int *>(resG + ((p.maxCol + 1) & ~1));
+    int *bc = resIdx + ((p.maxCol + 3) & ~3);
+    double *red = reinterpret_cast<double *>(bc + 16);
+    enum { BC_CUR = 0, BC_ACT = 1, BC_STOP = 2, BC_NEXT = 3, BC_ERR = 4 };
+    double *Cw = reinterpret_cast<double *>(ws + L.C);
+    struct HeapE { double g; long long idx; };  // idx: hypothesis | activeCol << 32
+    HeapE *heap = reinterpret_cast<HeapE *>(ws + L.heap);
+    const bool tabI8 = (p.flags & KBEST_FLAG_TABLES_I8) != 0;
+    const bool maximize = p.maximize != 0;
+    auto hyp = [&](int i) {
+        unsigned char *b = ws + L.pool + (long long)i * L.hypStride;
+        return Hyp{reinterpret_cast<double *>(b + L.hu), reinterpret_cast<double *>(b + L.hv), reinterpret_cast<int *>(b + L.hc4r),
+                   reinterpret_cast<int *>(b + L.hr4c), b + L.hforb};
+    };
+    auto sync = [&]() { wave_fence(); };  // (hand-overs between the lanes of a wave through its own LDS)
+    auto first_i32 = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
+    auto first_f64 = [](double x) {
+        return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+    };
+
+    for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
+        const int N = p.nRow ? p.nRow[b] : p.maxRow, M = p.nCol ? p.nCol[b] : p.maxCol;
+        const long long outBase = (long long)b * p.k;
+        if (N < 1 || M < 1 || N < M || N > p.maxRow || M > p.maxCol) {  // undefined in the reference
+            if (threadIdx.x == 0) p.nf[b] = (M == 0 || N == 0) ? 0 : -1;
+            continue;
+        }
+        const int D = N;
+        const double *Cg = p.cost + (p.costOff ? p.costOff[b] : (long long)b * p.maxRow * p.maxCol);
+        // ---- makeCostMatrixSafe (cpp:534-569) + zero padding (cpp:582-585, 663-666) ----
+        double d = INF;
+        for (long long i = threadIdx.x; i < (long long)N * M; i += NT) d = min_keep(d, maximize ? -Cg[i] : Cg[i]);
+        d = wave_min_f64(d);
+        if (lane == 0) red[wave] = d;
+        __syncthreads();
+        d = red[0];
+        for (int w = 1; w < NW; w++) d = min_keep(d, red[w]);
+        for (long long i = threadIdx.x; i < (long long)N * M; i += NT) Cw[i] = (maximize ? -Cg[i] : Cg[i]) - d;
+        for (long long i = (long long)N * M + threadIdx.x; i < (long long)N * N; i += NT) Cw[i] = 0.0;
+        const double CDelta = (maximize ? -d : d) * (double)M;  // cpp:583 (maximize: CDelta is max C)
+        __syncthreads();
+        int heapN = 0;  // (wave 0's)
+
+        // one shortest augmenting path from column `start`, the dual update, the path flip (cpp:146-230, 283-358, 82-117).
+        // useForb: rows flagged in forbStart are skipped while the start column itself is scanned (cpp:310).  1 = infeasible.
+        auto augment = [&](const Hyp &h, int start, bool useForb) -> int {
+            for (int r = lane; r < D; r += 64) { scanRow[r] = 0; spc[r] = INF; }
+            sync();
+            int nScanned = 0, sink = -1, cur = start;
+            double delta = 0.0;
+            do {
+                if (lane == 0) scanCols[nScanned] = cur;
+                nScanned++;
+                const double uc = h.u[cur];
+                const double *Ccol = Cw + (long long)cur * D;
+                const bool forbNow = useForb && cur == start;
+                double best = INF;
+                int bestR = 0x7fffffff;
+                for (int r = lane; r < D; r += 64) {
+                    if (!inScan[r]) continue;
+                    if (forbNow && forbStart[r]) continue;
+                    const double rc = ((delta + Ccol[r]) - uc) - h.v[r];  // cpp:183 / 313: left to right
+                    double s = spc[r];
+                    if (rc < s) { pred[r] = cur; spc[r] = rc; s = rc; }
+                    if (s < best) { best = s; bestR = r; }  // (ascending r within the lane: the first minimum is the lowest row)
+                }
+                const double minVal = wave_min_f64(best);
+                if (!(minVal < INF)) return 1;  // cpp:197-203, 327-334
+                const int closest = wave_min_i32(best == minVal ? bestR : 0x7fffffff);  // lowest row among equal minima
+                if (lane == 0) { scanRow[closest] = 1; inScan[closest] = 0; }
+                sync();
+                delta = spc[closest];
+                const int col = h.c4r[closest];
+                if (col == -1) sink = closest; else cur = col;
+            } while (sink == -1);
+            // updateDualAndAugment (cpp:82-117)
+            for (int i = lane; i < nScanned; i += 64) {
+                const int c = scanCols[i];
+                if (i == 0) h.u[c] = h.u[c] + delta;
+                else h.u[c] = h.u[c] + delta - spc[h.r4c[c]];
+            }
+            for (int r = lane; r < D; r += 64)
+                if (scanRow[r]) h.v[r] = h.v[r] - delta + spc[r];
+            sync();
+            if (lane == 0) {
+                int r = sink, c;
+                do {
+                    c = pred[r];
+                    h.c4r[r] = c;
+                    const int nxt = h.r4c[c];
+                    h.r4c[c] = r;
+                    r = nxt;
+                } while (c != start);
+            }
+            sync();
+            return 0;
+        };
+        // calcGain (cpp:59-80): serial, left to right, from 0.0 (the terms of 64 columns fetched by the lanes at once)
+        auto gain_of = [&](const Hyp &h, int nCol4Gain) {
+            double g = 0.0;
+            for (int c0 = 0; c0 < nCol4Gain; c0 += 64) {
+                const int c = c0 + lane;
+                const double term = c < nCol4Gain ? Cw[(long long)c * D + h.r4c[c]] : 0.0;
+                const int n = nCol4Gain - c0 < 64 ? nCol4Gain - c0 : 64;
+                for (int j = 0; j < n; j++) g = g + readlane_f64(term, j);
+            }
+            return g;
+        };
+        // libstdc++'s __push_heap / __adjust_heap (wave 0, lane 0)
+        auto sift_up = [&](int hole, HeapE val) {
+            int parent = (hole - 1) / 2;
+            while (hole > 0) {
+                const HeapE pe = heap[parent];
+                if (!(pe.g > val.g)) break;
+                heap[hole] = pe;
+                hole = parent;
+                parent = (hole - 1) / 2;
+            }
+            heap[hole] = val;
+        };
+        auto heap_push = [&](int hidx, int act, double g) {
+            if (lane == 0) sift_up(heapN, HeapE{g, (long long)hidx | ((long long)act << 32)});
+            heapN++;
+        };
+        auto heap_top = [&](double &g, int &hidx, int &act) {
+            HeapE e{0.0, 0};
+            if (lane == 0) e = heap[0];
+            g = first_f64(e.g);
+            hidx = first_i32((int)(e.idx & 0xffffffffll));
+            act = first_i32((int)(e.idx >> 32));
+        };
+        auto heap_pop = [&]() {
+            const int len = heapN - 1;
+            if (lane == 0 && len > 0) {
+                const HeapE val = heap[len];
+                int hole = 0, child = 0;
+                while (child < (len - 1) / 2) {
+                    child = 2 * (child + 1);
+                    HeapE ce = heap[child];
+                    const HeapE le = heap[child - 1];
+                    if (ce.g > le.g) { child--; ce = le; }
+                    heap[hole] = ce;
+                    hole = child;
+                }
+                if ((len & 1) == 0 && child == (len - 2) / 2) {
+                    child = 2 * (child + 1);
+                    heap[hole] = heap[child - 1];
+                    hole = child - 1;
+                }
+                sift_up(hole, val);
+            }
+            heapN = len;
+        };
+        // a hypothesis between a wave's LDS and its record in the pool (other waves read a record only behind a barrier)
+        auto copy_hyp = [&](const Hyp &src, const Hyp &dst) {
+            for (int i = lane; i < D; i += 64) { dst.r4c[i] = src.r4c[i]; dst.c4r[i] = src.c4r[i]; dst.u[i] = src.u[i]; dst.v[i] = src.v[i]; dst.forb[i] = src.forb[i]; }
+        };
+        auto emit = [&](int hidx, double g, int slot) {
+            const Hyp h = hyp(hidx);
+            for (int c = lane; c < M; c += 64) put_index(p.row4col, (outBase + slot) * p.ldCol + c, h.r4c[c], tabI8);
+            if (p.col4row)
+                for (int r = lane; r < N; r += 64) put_index(p.col4row, (outBase + slot) * p.ldRow + r, h.c4r[r], tabI8);
+            const double out = maximize ? (-g + CDelta) : (g + CDelta);  // cpp:626-630
+            if (lane == 0) p.gain[outBase + slot] = out;
+            return out;
+        };
+        double gain0 = 0.0;
+        long long pushed = 0;
+        // wave 0, behind a sweep's children (and behind the root): the pushes in column order, the new top out, the next hypothesis
+        // popped -- or the end of the problem (BC_STOP: the number of solutions + 1; -1: the pool ran out)
+        auto turn = [&](int sweep, int a, bool root) {
+            if (!root) {
+                for (int c = a; c < M; c++) {
+                    const int idx = resIdx[c];
+                    if (idx < 0) continue;
+                    heap_push(idx, c, resG[c]);
+                    pushed++;
+                }
+            }
+            int stop = 0;
+            double gTop;
+            int cur, act;
+            if (bc[BC_ERR]) stop = -1;
+            else if (heapN == 0) stop = sweep + 1;
+            else if (!root) {
+                heap_top(gTop, cur, act);
+                const double gs = emit(cur, gTop, sweep);
+                if (p.useCutoff && (maximize ? (gs < gain0 - p.cutoff) : (gs > gain0 + p.cutoff))) stop = sweep + 1;  // cpp:709-719
+                else if (sweep + 1 >= p.k) stop = sweep + 2;
+            } else if (p.k <= 1) stop = 2;
+            if (!stop) {
+                heap_top(gTop, cur, act);
+                heap_pop();
+                if (lane == 0) { bc[BC_CUR] = cur; bc[BC_ACT] = act; }
+            }
+            if (lane == 0) bc[BC_STOP] = stop;
+        };
+
+        // ---- root: shortestPathCPP (cpp:119-238), N augmentations in column order on the padded problem (wave 0) ----
+        if (wave == 0) {
+            if (lane == 0) { bc[BC_ERR] = 0; bc[BC_NEXT] = 1; }
+            const Hyp hr = hLds;
+            for (int i = lane; i < D; i += 64) { hr.c4r[i] = -1; hr.r4c[i] = -1; hr.u[i] = 0.0; hr.v[i] = 0.0; hr.forb[i] = 0; }
+            sync();
+            int infeasible = 0;
+            for (int c = 0; c < D && !infeasible; c++) {
+                for (int r = lane; r < D; r += 64) inScan[r] = 1;
+                sync();
+                infeasible = augment(hr, c, false);
+            }
+            if (infeasible) {  // kBest2D returns 0 (cpp:588-593)
+                if (lane == 0) bc[BC_STOP] = 1;
+            } else if (p.hypPerSlot < 2) {
+                if (lane == 0) bc[BC_STOP] = -1;
+            } else {
+                const double rootGain = gain_of(hr, M);
+                if (lane == 0) hr.forb[hr.r4c[0]] = 1;  // cpp:232-235
+                sync();
+                copy_hyp(hr, hyp(0));
+                gain0 = emit(0, rootGain, 0);
+                if (lane == 0) resG[0] = rootGain;
+                heap_push(0, 0, rootGain);
+                turn(0, 0, true);
+            }
+        }
+        __syncthreads();
+        const double cutoffGain = maximize ? (resG[0] - p.cutoff) : (resG[0] + p.cutoff);  // cpp:680-686 (every wave's copy)
+        int stop = bc[BC_STOP];
+        __syncthreads();  // (resG[0] is a child's slot from here on)
+        for (int sweep = 1; !stop; sweep++) {  // cpp:607-634
+            const int cur = bc[BC_CUR], a = bc[BC_ACT];
+            // the hypothesis that is split: from the pool into LDS, by everybody, once
+            {
+                const Hyp hpG = hyp(cur);
+                for (int i = threadIdx.x; i < D; i += NT) { pLds.r4c[i] = hpG.r4c[i]; pLds.c4r[i] = hpG.c4r[i]; pLds.u[i] = hpG.u[i]; pLds.v[i] = hpG.v[i]; pLds.forb[i] = hpG.forb[i]; }
+            }
+            __syncthreads();
+            const Hyp hp = pLds, hc = hLds;
+            // ---- split (cpp:455-532): the children of columns a .. M-1, each fully solved; this wave's share ----
+            for (int c = a + wave; c < M; c += NW) {
+                // rows still owned by columns >= c of the parent (cpp:480-488; 506-508, 512, 525-527)
+                for (int r = lane; r < D; r += 64) { inScan[r] = 0; forbStart[r] = (c == a) ? hp.forb[r] : 0; }  // cpp:490 / 510
+                sync();
+                for (int j = c + lane; j < D; j += 64) inScan[hp.r4c[j]] = 1;
+                if (c != a && lane == 0) forbStart[hp.r4c[c]] = 1;  // cpp:516
+                sync();
+                for (int i = lane; i < D; i += 64) {  // shortestPathUpdateCPP, cpp:262-278
+                    hc.r4c[i] = hp.r4c[i]; hc.c4r[i] = hp.c4r[i]; hc.u[i] = hp.u[i]; hc.v[i] = hp.v[i]; hc.forb[i] = forbStart[i];
+                }
+                sync();
+                if (lane == 0) { hc.c4r[hc.r4c[c]] = -1; hc.r4c[c] = -1; }
+                sync();
+                int idx = -1;
+                if (!augment(hc, c, true)) {  // else infeasible: gain -1, dropped (cpp:496, 521)
+                    const double g = gain_of(hc, M);
+                    if (!(p.useCutoff && (maximize ? (g < cutoffGain) : (g > cutoffGain)))) {  // cutHyp, hpp:130-131
+                        if (lane == 0) hc.forb[hc.r4c[c]] = 1;  // cpp:362
+                        sync();
+                        if (lane == 0) idx = atomicAdd(&bc[BC_NEXT], 1);
+                        idx = first_i32(idx);
+                        if (idx >= p.hypPerSlot) {  // (cannot happen: at most 1 + (k - 1) M pushes, plan_exact)
+                            if (lane == 0) bc[BC_ERR] = 1;
+                            idx = -1;
+                        } else {
+                            copy_hyp(hc, hyp(idx));
+                            if (lane == 0) resG[c] = g;
+                        }
+                    }
+                }
+                if (lane == 0) resIdx[c] = idx;
+            }
+            __syncthreads();
+            if (wave == 0) turn(sweep, a, false);
+            __syncthreads();
+            stop = bc[BC_STOP];
+        }
+        if (threadIdx.x == 0) {
+            p.nf[b] = stop < 0 ? -4 : stop - 1;
+            if (p.pushed) p.pushed[b] = pushed;
+        }
+        __syncthreads();
     }
 }
 
@@ -649,11 +936,29 @@ hipError_t launch_kbest_exact(const ExactParams &p, int grid, hipStream_t stream
         }
         return hipGetLastError();
     }
-    // LDS: the scratch of a search (19 bytes per row), the hypothesis being solved and the one being split (25 each)
-    const int hypB = (25 * p.maxRow + 63) & ~63;
-    const int lds = p.maxRow <= EXACT_LDS_ROWS ? ((19 * p.maxRow + 63) & ~63) + 2 * hypB : 0;
-    if (p.maxRow <= EXACT_LDS_ROWS) hipLaunchKernelGGL(kbest_exact_kernel<1>, dim3(grid), dim3(64), lds, stream, p);
-    else hipLaunchKernelGGL(kbest_exact_kernel<0>, dim3(grid), dim3(64), lds, stream, p);
+    if (p.maxRow <= EXACT_LDS_ROWS) {
+        // NW waves per problem, as many as a CU's LDS holds scratch + hypothesis for (44 bytes per row and wave) beside the shared 25
+        // bytes per row and the sweep's results: eight while two workgroups still fit a CU, else four, else two
+        const long long scrB = (19ll * p.maxRow + 63) & ~63ll, hypB = (25ll * p.maxRow + 63) & ~63ll;
+        auto bytes = [&](int nw) { return nw * (scrB + hypB) + hypB + 8ll * ((p.maxCol + 1) & ~1) + 4ll * ((p.maxCol + 3) & ~3) + 64 + 8ll * nw + 64; };
+        const char *force = getenv("KBEST_EXACT_WAVES");
+        int nw = force ? atoi(force) : (bytes(8) <= 80 * 1024 ? 8 : (bytes(4) <= 150 * 1024 ? 4 : 2));
+        nw = nw >= 8 ? 8 : (nw >= 4 ? 4 : (nw >= 2 ? 2 : 1));
+        while (nw > 1 && bytes(nw) > 150 * 1024) nw >>= 1;
+        const int lds = (int)bytes(nw);
+        const void *fn = nw == 8 ? reinterpret_cast<const void *>(kbest_exactN_kernel<8>) : nw == 4 ? reinterpret_cast<const void *>(kbest_exactN_kernel<4>)
+                       : nw == 2 ? reinterpret_cast<const void *>(kbest_exactN_kernel<2>) : reinterpret_cast<const void *>(kbest_exactN_kernel<1>);
+        if (lds > 64 * 1024) {  // (more than the default limit of dynamic LDS)
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return e;
+        }
+        if (nw == 8) hipLaunchKernelGGL(kbest_exactN_kernel<8>, dim3(grid), dim3(512), lds, stream, p);
+        else if (nw == 4) hipLaunchKernelGGL(kbest_exactN_kernel<4>, dim3(grid), dim3(256), lds, stream, p);
+        else if (nw == 2) hipLaunchKernelGGL(kbest_exactN_kernel<2>, dim3(grid), dim3(128), lds, stream, p);
+        else hipLaunchKernelGGL(kbest_exactN_kernel<1>, dim3(grid), dim3(64), lds, stream, p);
+    } else {
+        hipLaunchKernelGGL(kbest_exact_kernel, dim3(grid), dim3(64), 0, stream, p);
+    }
     return hipGetLastError();
 }
 

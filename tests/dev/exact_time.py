@@ -11,3 +11,8 @@ for (B,N,M,k) in [(256,64,64,200),(1024,64,64,200),(1000,28,10,200),(64,200,150,
     eng.kbest(C,N,M,k,reference_order=True)
     t=time.perf_counter(); out=eng.kbest(C,N,M,k,reference_order=True); dt=time.perf_counter()-t
     print(B,N,M,k,"%.1f ms"%(dt*1e3), "nf", int(out[0].sum()))
+for (B,N,M,k) in [(1,200,150,50),(8,500,40,20),(2,1000,12,10)]:
+    C = np.random.default_rng(2).random((B,N*M))
+    eng.kbest(C,N,M,k,reference_order=True)
+    t=time.perf_counter(); out=eng.kbest(C,N,M,k,reference_order=True); dt=time.perf_counter()-t
+    print(B,N,M,k,"%.1f ms"%(dt*1e3), "nf", int(out[0].sum()))

@@ -38,7 +38,7 @@ KNOBS = [
     (["KBEST_ZC_COST"], "csrc", "`kbest_batch_f64`, registered cost blocks: `0` all pieces' uploads at once, `2` read in place by the kernels over the link (default: uploaded piece after piece on a copy stream)"),
     (["KBEST_ZC_LIMIT_KB", "KBEST_NO_POLL"], "csrc", "association host entries: largest call (bytes in + out) that runs on the pinned staging memory in place (default 65 536); wait with `hipStreamSynchronize` instead of polling the completion word"),
     (["KBEST_MULTI_WIDE", "KBEST_MULTI_WHOLE_LISTS"], "csrc", "multi-device entries: row4col travels as int32 even where bytes would do (round 5's exchange); subtree mode always exchanges the whole lists (no gains-first exchange)"),
-    (["KBEST_EXACT_WAVES"], "csrc", "reference-order kernel up to 64 rows (`kbest_exact.hip`): `1` one wave per problem, `8` eight (a sweep's children in parallel); unset: eight where a problem has 16 columns or more or the batch has fewer than 512 problems (A/B; same tables)"),
+    (["KBEST_EXACT_WAVES"], "csrc", "reference-order kernels up to 1 024 rows (`kbest_exact.hip`): waves per problem (`1`, `2`, `4`, `8`: a sweep's children side by side); unset: up to 64 rows eight where a problem has 16 columns or more or the batch has fewer than 512 problems, else one; 65 … 1 024 rows as many of 8 / 4 / 2 as a CU's LDS holds (A/B; same tables; read at every launch)"),
     (["KBEST_SHIM_REFERENCE_ORDER"], "csrc", "the reference-named C++ shims (`kBest2D`, `kBest2DCutoff`, `assignmentProb`, `bruteForceProb`): `=1` answers in the reference's own order of operations (`KBEST_FLAG_REFERENCE_ORDER` / `kbest_set_reference_order`, `kbest_exact.hip`): exact ties as the reference's heap pops them; `=2` the same answer with only the tied problems / frames on that kernel (`KBEST_FLAG_REFERENCE_TIES` / `kbest_set_reference_order(ctx, 2)`) -- the one knob that selects another (documented) answer on exact ties"),
     (["KBEST_LIB"], "python", "Python driver: file name of the library to load from the package directory (e.g. the `PROFILE=1` build)"),
     (["KBEST_BENCH_BACKEND", "KBEST_BENCH_FORCE_DIST", "KBEST_BENCH_SELF_LAUNCH", "KBEST_BENCH_WIDE_SLICES"], "python",
