@@ -673,7 +673,7 @@ def reference_order_entry(eng, torch, dev, tstream):
         out[name]["problems_run_again"] = int((res[-1] & 8).astype(bool).sum())  # KBEST_TIE_REFERENCE
         out[name]["reference_ties_equals_reference_order"] = bool((res[3].view(np.int64) == g_ref.view(np.int64)).all() and
                                                                   (res[1] == d_r_ref).all())
-    out["what"] = ("kbest_batch_f64_dev with KBEST_FLAG_REFERENCE_ORDER: the reference's algorithm as it stands, one wave per problem, exact ties in "
+    out["what"] = ("kbest_batch_f64_dev with KBEST_FLAG_REFERENCE_ORDER: the reference's algorithm as it stands, one to eight waves per problem, exact ties in "
                    "the reference's heap order (tests: bit-identical to the compiled reference's goldens incl. col4row) -- next to the default kernels; "
                    "ms_host_*: the host entry with its default rule and with KBEST_FLAG_REFERENCE_TIES (only the problems with an exact tie among "
                    "their k + 1 best gains run again on the reference-order kernel: `problems_run_again`)")
