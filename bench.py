@@ -658,10 +658,10 @@ def reference_order_entry(eng, torch, dev, tstream):
                 d_r_ref = d_r.cpu().numpy().copy()
         out[name] = {"problems": B, "ms_reference_order": ms["reference_order"], "ms_default": ms["default"],
                      "same_gains": bool((g_ref.view(np.int64) == d_g.cpu().numpy().view(np.int64)).all())}
-        # KBEST_FLAG_REFERENCE_TIES through the host entry: the fast kernels + only the problems with an exact tie again on the
-        # reference-order kernel (the same answer; what it costs next to the host entry's default rule)
+        # the host entry: its default (the fast kernels + only the problems with an exact tie again on the reference-order kernel: the
+        # reference's answer) next to the engine's own rule on ties (KBEST_FLAG_CANONICAL_TIES: tied levels completed in steps)
         hm = {}
-        for key, kw in (("ms_host_default", {}), ("ms_host_reference_ties", {"reference_ties": True})):
+        for key, kw in (("ms_host_canonical_ties", {"canonical_ties": True}), ("ms_host_default", {})):
             ts = []
             for i in range(3):
                 t0 = time.perf_counter()
@@ -671,12 +671,12 @@ def reference_order_entry(eng, torch, dev, tstream):
             hm[key] = min(ts)
         out[name].update(hm)
         out[name]["problems_run_again"] = int((res[-1] & 8).astype(bool).sum())  # KBEST_TIE_REFERENCE
-        out[name]["reference_ties_equals_reference_order"] = bool((res[3].view(np.int64) == g_ref.view(np.int64)).all() and
+        out[name]["default_equals_reference_order"] = bool((res[3].view(np.int64) == g_ref.view(np.int64)).all() and
                                                                   (res[1] == d_r_ref).all())
     out["what"] = ("kbest_batch_f64_dev with KBEST_FLAG_REFERENCE_ORDER: the reference's algorithm as it stands, one to eight waves per problem, exact ties in "
                    "the reference's heap order (tests: bit-identical to the compiled reference's goldens incl. col4row) -- next to the default kernels; "
-                   "ms_host_*: the host entry with its default rule and with KBEST_FLAG_REFERENCE_TIES (only the problems with an exact tie among "
-                   "their k + 1 best gains run again on the reference-order kernel: `problems_run_again`)")
+                   "ms_host_*: the host entry by default (only the problems with an exact tie among their k + 1 best gains run again on the "
+                   "reference-order kernel: `problems_run_again`; the reference's answer) and with KBEST_FLAG_CANONICAL_TIES (the engine's own rule)")
     return out
 
 

@@ -32,29 +32,33 @@
  *
  * Order of exact ties.  Hypotheses with EXACTLY equal gain have no defined relative order in the reference (it is an
  * artefact of std::priority_queue's binary heap, shortestPathCPP.cpp:30-42, 574; which of them fill the last slots of a
- * call is an artefact too).  The engine defines one, the same in every kernel and for every batch a problem may travel in:
- *   * solutions are ordered by (gain, row4col), row4col compared lexicographically in the reference's column order;
- *   * when the k-th and the (k+1)-th best gains are equal -- the k best are then not a unique set -- the lexicographically
- *     first assignments of that gain level are the ones kept.
- * For continuous costs ties have probability zero and every output is the reference's, bit for bit.  For integer-like costs
- * (conditionCosts produces exact zeros) the multiset of gains and the validity of every assignment are the reference's; the
- * order inside a run of equal gains, and the members of a gain level that straddles slot k, are this rule's.
- * How it is done: every enumeration launch enumerates ONE solution more than asked for (its gain only; measured free) and is
- * followed by a small launch that brings runs of equal gains into the order above and reports, per problem, KBEST_TIE_* flags
- * (kbest_opts.tie_flags).  A tie at slot k (KBEST_TIE_BOUNDARY) is completed by the SYNCHRONOUS entries themselves: the
- * problem is enumerated again with k + 64, then k + 256, k + 1 024, k + KBEST_TIE_CAP solutions until the level ends inside the
- * table, and the first k of the ordered table are kept (KBEST_TIE_RESOLVED; a level with more than KBEST_TIE_CAP members beyond k
- * -- on the association entries, whose weights are summed on the device: of more than 4 096 members in all -- stays
- * KBEST_TIE_UNRESOLVED: the emitted set is then one of several equally good ones and may depend on the kernel; a re-run that fails
- * leaves the first pass' tables and that flag).  The asynchronous _dev entries only
- * report the flags; kbest_resolve_ties_dev completes their tables afterwards, and the multi-device batch entry does so by itself.
- * The exhaustive association kernel and the bounded walk see a whole gain level and keep its lexicographically first
- * members themselves, whatever its size.  KBEST_FLAG_NO_TIE_CHECK switches all of it off (the kernels' own orders, round 4).
- * A caller who needs the REFERENCE's own order of equal gains instead -- slot for slot what its std::priority_queue pops -- sets
- * KBEST_FLAG_REFERENCE_ORDER: the problem then runs on the reference-order kernel (kbest_exact.hip; slow, exact) -- or
- * KBEST_FLAG_REFERENCE_TIES: the batch runs on the fast kernels and only the problems that DO have an exact tie among their k + 1
- * best gains are enumerated again by that kernel (a tie-free problem's tables are the reference's anyway): the same answer, at the
- * fast kernels' speed wherever nothing ties.
+ * call is an artefact too).  For continuous costs ties have probability zero and every output is the reference's, bit for bit.
+ * For integer-like costs (conditionCosts produces exact zeros) there are two answers to choose from:
+ *   (1) THE REFERENCE'S OWN -- what its heap pops, slot for slot.  The SYNCHRONOUS k-best entries (kbest_batch_f64,
+ *       kbest_resolve_ties_dev behind the asynchronous entry, kbest_batch_f64_multi in batch mode) give it BY DEFAULT: the batch runs
+ *       on the fast kernels, every enumeration launch enumerates ONE solution more than asked for (its gain only; measured free) and
+ *       is followed by a small launch that reports, per problem, KBEST_TIE_* flags (kbest_opts.tie_flags): every problem with two
+ *       exactly equal gains among its k + 1 best -- inside the table or across slot k -- is then enumerated AGAIN by the
+ *       reference-order kernel (kbest_exact.hip: the reference's algorithm as it stands) and its tables are replaced
+ *       (KBEST_TIE_REFERENCE).  A tie-free problem has ONE sequence of k best, which the fast kernels return bit for bit, so the call
+ *       as a whole answers as the reference does, at the fast kernels' speed wherever nothing ties.  KBEST_FLAG_REFERENCE_ORDER runs
+ *       EVERY problem on that kernel (slow, exact; also names col4row's padded columns as the reference does on every problem).
+ *   (2) THE ENGINE'S RULE, the same in every kernel and for every batch a problem may travel in: solutions ordered by
+ *       (gain, row4col), row4col compared lexicographically in the reference's column order; when the k-th and the (k+1)-th best
+ *       gains are equal -- the k best are then not a unique set -- the lexicographically first assignments of that gain level are
+ *       kept.  The multiset of gains and the validity of every assignment are the reference's; the order inside a run of equal gains
+ *       and the members of a level that straddles slot k are the rule's.  This is what the finishing launch leaves in the tables, so
+ *       what the ASYNCHRONOUS entries return (with the flags), what the association entries weigh by default (the exhaustive kernel
+ *       and the bounded walk see a whole gain level and keep its lexicographically first members themselves, whatever its size), and
+ *       what the synchronous entries return with KBEST_FLAG_CANONICAL_TIES: a tie at slot k (KBEST_TIE_BOUNDARY) is then completed by
+ *       enumerating the problem again with k + 64, then k + 256, k + 1 024, k + KBEST_TIE_CAP solutions until the level ends inside
+ *       the table (KBEST_TIE_RESOLVED; a level with more than KBEST_TIE_CAP members beyond k -- on the association entries, whose
+ *       weights are summed on the device: of more than 4 096 members in all -- stays KBEST_TIE_UNRESOLVED: the emitted set is then one
+ *       of several equally good ones and may depend on the kernel; a re-run that fails leaves the first pass' tables and that flag).
+ *       On tie-heavy batches (1) is also the cheaper one: one more run of k solutions instead of thousands of members of a level.
+ * KBEST_FLAG_NO_TIE_RESOLVE: the synchronous entries only report the flags; KBEST_FLAG_NO_TIE_CHECK switches all of it off (the
+ * kernels' own orders, round 4).  Association entries: kbest_set_reference_order(ctx, 2) weighs the reference's own k best on frames
+ * with a tie at slot k (1: on every frame).
  * Index outputs are int32 (the reference ABI uses ptrdiff_t; the C++ shims in
  * include/kbest_shims.hpp widen on the host).
  *
@@ -107,17 +111,13 @@ enum {
                                         /* zero-padded N x N formulation, one priority queue of fully solved hypotheses with libstdc++'s */
                                         /* sift rules: hypotheses with exactly equal gains come out in the order the reference's heap  */
                                         /* pops them (shortestPathCPP.cpp:30-42, 574) and col4row names the padded column of every      */
-                                        /* left-over row as the reference does.  Slow (one wave per problem, nothing pruned): for     */
+                                        /* left-over row as the reference does.  Slow (up to 8 waves per problem, nothing pruned): for */
                                         /* callers with integer-like costs who need the reference's answer slot for slot.  No tie flags. */
-#define KBEST_FLAG_REFERENCE_TIES 4096u /* synchronous k-best entries, kbest_resolve_ties_dev, the multi-device batch entry: the     */
-                                       /* REFERENCE's answer wherever gains tie.  The batch runs on the fast kernels; every problem */
-                                       /* whose k + 1 best gains hold an exact tie (inside the table or across slot k; or that      */
-                                       /* could not be checked) is then enumerated AGAIN by the reference-order kernel and its      */
-                                       /* tables replaced (KBEST_TIE_REFERENCE).  Tie-free problems keep the fast kernels' tables,  */
-                                       /* which are the reference's bit for bit: the whole call then answers as the reference does  */
-                                       /* -- order of equal gains and members of a level across slot k included -- at the fast      */
-                                       /* kernels' speed where nothing ties.  (col4row of rows on padded columns: the reference's   */
-                                       /* names on the re-run problems, valid names elsewhere: SURVEY 8(a) quirk 6.)                */
+#define KBEST_FLAG_REFERENCE_TIES 4096u /* (accepted; the DEFAULT of the synchronous k-best entries since round 6: every problem whose    */
+                                       /* k + 1 best gains hold an exact tie is enumerated again by the reference-order kernel and its  */
+                                       /* tables replaced, KBEST_TIE_REFERENCE: "Order of exact ties" (1))                              */
+#define KBEST_FLAG_CANONICAL_TIES 8192u /* synchronous k-best entries, kbest_resolve_ties_dev, the multi-device batch entry: the        */
+                                       /* engine's own rule on exact ties instead of the reference's answer: "Order of exact ties" (2)  */
 #define KBEST_FLAG_NO_TIE_RESOLVE 1024u /* synchronous entries: report a tie at slot k (KBEST_TIE_BOUNDARY), do not complete its gain level */
 #define KBEST_FLAG_TABLES_I8 64u   /* kbest_batch_f64 / kbest_batch_f64_dev: row4col / col4row are tables of int8_t (same shapes, */
                                    /* same values, -1 = unassigned / unused) instead of int32_t: every index of a problem of up   */
@@ -200,10 +200,13 @@ int kbest_batch_f64_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRo
 /*
  * The second call for callers of kbest_batch_f64_dev whose costs can tie exactly (integer-like costs): SYNCHRONOUS.  Same
  * arguments as the launch it follows (same opts, shapes, cost blocks, tables -- all still on the device), d_tie_flags = the
- * opts->tie_flags the launch wrote.  Waits for `stream`, and for every problem flagged KBEST_TIE_BOUNDARY completes the gain level
- * at slot k as the synchronous entries do (the problem again with k + 64 / 256 / KBEST_TIE_CAP solutions), writes the first k of the
- * canonically ordered table over the problem's slots of d_row4col / d_col4row / d_gain and updates its flag (KBEST_TIE_RESOLVED, or
- * KBEST_TIE_UNRESOLVED where the level is larger than the cap).  A batch without flagged problems costs one small copy.
+ * opts->tie_flags the launch wrote.  Waits for `stream` and does what the synchronous entries do with flagged problems ("Order of exact
+ * ties"): by default every problem flagged with a tie (inside its table, across slot k, or unchecked) is enumerated again by the
+ * reference-order kernel and its slots of d_row4col / d_col4row / d_gain are replaced (KBEST_TIE_REFERENCE: the reference's own answer);
+ * with KBEST_FLAG_CANONICAL_TIES every problem flagged KBEST_TIE_BOUNDARY has its gain level at slot k completed under the engine's rule
+ * (the problem again with k + 64 / 256 / 1 024 / KBEST_TIE_CAP solutions; the first k of the canonically ordered table written over the
+ * problem's slots; KBEST_TIE_RESOLVED, or KBEST_TIE_UNRESOLVED where the level is larger than the cap).  A batch without flagged
+ * problems costs one small copy.
  */
 int kbest_resolve_ties_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, int maxCol, const int32_t *d_nRow,
                            const int32_t *d_nCol, const double *d_cost, const int64_t *d_costOff, int k, int32_t *d_row4col,

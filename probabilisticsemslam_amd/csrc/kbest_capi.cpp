@@ -1896,10 +1896,11 @@ void kb_complete_tie_levels(kbest_ctx *ctx, const kbest_opts *opts, int B, int m
     static const int steps[4] = {64, 256, 1024, KBEST_TIE_CAP};
     const bool i8 = (opts->flags & KBEST_FLAG_TABLES_I8) != 0;
     const size_t esz = i8 ? 1 : 4;
-    if (opts->flags & KBEST_FLAG_REFERENCE_TIES) {
-        // The REFERENCE's answer wherever gains tie (kbest_c.h): every problem whose k + 1 best gains hold an exact tie -- inside the
-        // table or across slot k -- or that could not be checked is enumerated again by the reference-order kernel (kbest_exact.hip),
-        // and its tables replace the first pass'.  Tie-free problems keep the fast kernels' tables: those ARE the reference's.
+    if (!(opts->flags & KBEST_FLAG_CANONICAL_TIES)) {
+        // The REFERENCE's answer wherever gains tie (kbest_c.h; the default of the synchronous entries): every problem whose k + 1 best
+        // gains hold an exact tie -- inside the table or across slot k -- or that could not be checked is enumerated again by the
+        // reference-order kernel (kbest_exact.hip), and its tables replace the first pass'.  Tie-free problems keep the fast kernels'
+        // tables: those ARE the reference's.  (KBEST_FLAG_CANONICAL_TIES: the engine's own rule instead -- the steps below.)
         const int tied = KBEST_TIE_INSIDE | KBEST_TIE_BOUNDARY | KBEST_TIE_UNCHECKED | KBEST_TIE_UNORDERED;
         std::vector<int> idx;
         for (int b = 0; b < B; b++)
@@ -1927,8 +1928,9 @@ void kb_complete_tie_levels(kbest_ctx *ctx, const kbest_opts *opts, int B, int m
         const int rc = kbest_batch_f64_keep(ctx, &o2, n, maxRow, maxCol, sRow.data(), sCol.data(), sCost.data(), sOff.data(), k,
                                             reinterpret_cast<int32_t *>(sR.data()), col4row ? reinterpret_cast<int32_t *>(sC.data()) : nullptr, sGain.data(),
                                             sNf.data(), nullptr, nullptr);
-        if (rc != KBEST_OK) return;  // (the first pass' tables stand -- in the engine's own order; the problems stay flagged as they were)
-        for (int i = 0; i < n; i++) {
+        // (a re-run that fails -- no memory for a pool of hypotheses -- leaves the first pass' tables, in the engine's own order, and
+        //  the engine's own rule completes the levels at slot k below)
+        for (int i = 0; i < n && rc == KBEST_OK; i++) {
             const int b = idx[i];
             memcpy(static_cast<char *>(row4col) + (size_t)b * k * maxCol * esz, sR.data() + (size_t)i * k * maxCol * esz, (size_t)k * maxCol * esz);
             if (col4row)
@@ -1937,7 +1939,7 @@ void kb_complete_tie_levels(kbest_ctx *ctx, const kbest_opts *opts, int B, int m
             fl[b] = (fl[b] & KBEST_TIE_INSIDE) | KBEST_TIE_REFERENCE;
             if (changed) changed->push_back(b);
         }
-        return;
+        if (rc == KBEST_OK) return;
     }
     for (int step = 0; step < 4; step++) {
         std::vector<int> idx;
@@ -2018,7 +2020,7 @@ int kbest_resolve_ties_dev(kbest_ctx *ctx, const kbest_opts *opts, int B, int ma
     std::vector<int32_t> fl((size_t)B);
     HIP_TRY(ctx, hipMemcpy(fl.data(), d_tie_flags, (size_t)B * 4, hipMemcpyDeviceToHost));
     std::vector<int> idx;
-    const bool refTies = (opts->flags & KBEST_FLAG_REFERENCE_TIES) != 0;
+    const bool refTies = !(opts->flags & KBEST_FLAG_CANONICAL_TIES);
     const int tied = KBEST_TIE_INSIDE | KBEST_TIE_BOUNDARY | KBEST_TIE_UNCHECKED | KBEST_TIE_UNORDERED;
     for (int b = 0; b < B; b++)
         if (refTies ? ((fl[b] & tied) && !(fl[b] & KBEST_TIE_REFERENCE)) : ((fl[b] & KBEST_TIE_BOUNDARY) && !(fl[b] & KBEST_TIE_RESOLVED))) idx.push_back(b);

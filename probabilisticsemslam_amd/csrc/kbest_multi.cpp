@@ -531,8 +531,8 @@ int kbest_batch_f64_multi_ex(kbest_multi *m, const kbest_opts *opts, int mode, i
             int32_t *fl = m->lastTie.data() + b0;
             W_HIP(d, hipMemcpy(fl, d.tieFl, (size_t)nb * 4, hipMemcpyDeviceToHost));
             bool any = false;
-            const int tiedMask = (opts->flags & KBEST_FLAG_REFERENCE_TIES) ? (KBEST_TIE_INSIDE | KBEST_TIE_BOUNDARY | KBEST_TIE_UNCHECKED | KBEST_TIE_UNORDERED)
-                                                                            : KBEST_TIE_BOUNDARY;
+            const int tiedMask = (opts->flags & KBEST_FLAG_CANONICAL_TIES) ? KBEST_TIE_BOUNDARY
+                                                                            : (KBEST_TIE_INSIDE | KBEST_TIE_BOUNDARY | KBEST_TIE_UNCHECKED | KBEST_TIE_UNORDERED);
             for (int i = 0; i < nb; i++) any = any || (fl[i] & tiedMask);
             if (any && !(opts->flags & KBEST_FLAG_NO_TIE_RESOLVE)) {
                 std::vector<int> changed;

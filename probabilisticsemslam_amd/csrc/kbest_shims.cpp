@@ -15,11 +15,14 @@
 
 namespace {
 
-// KBEST_SHIM_REFERENCE_ORDER: 1 = everything on the reference-order kernel; 2 = only what has an exact tie (KBEST_FLAG_REFERENCE_TIES /
-// kbest_set_reference_order(ctx, 2): the same answer, the fast kernels wherever nothing ties); unset / 0 = the engine's own rule
+// KBEST_SHIM_REFERENCE_ORDER, exact ties in the drop-in (kbest_c.h, "Order of exact ties").  Unset (-1): kBest2D / kBest2DCutoff answer
+// as the reference does -- the synchronous entry's default: a problem with an exact tie among its k + 1 best gains runs again on the
+// reference-order kernel --, assignmentProb / bruteForceProb weigh the engine's choice among a tied level.  2: those too weigh the
+// reference's own k best (kbest_set_reference_order(ctx, 2): frames with a tie at slot k run again).  1: everything on the
+// reference-order kernel.  0: the engine's own rule everywhere (KBEST_FLAG_CANONICAL_TIES).
 int shim_reference_order()
 {
-    static const int on = [] { const char *e = getenv("KBEST_SHIM_REFERENCE_ORDER"); return (e && *e && *e != '0') ? (*e == '2' ? 2 : 1) : 0; }();
+    static const int on = [] { const char *e = getenv("KBEST_SHIM_REFERENCE_ORDER"); return (e && *e) ? (*e == '2' ? 2 : (*e == '0' ? 0 : 1)) : -1; }();
     return on;
 }
 
@@ -30,7 +33,7 @@ kbest_ctx *global_ctx()
     static int rc = KBEST_OK;
     std::call_once(once, [] {
         rc = kbest_create(&ctx, 0);
-        if (rc == KBEST_OK && shim_reference_order()) kbest_set_reference_order(ctx, shim_reference_order());  // (assignmentProb / bruteForceProb as well)
+        if (rc == KBEST_OK && shim_reference_order() > 0) kbest_set_reference_order(ctx, shim_reference_order());  // (assignmentProb / bruteForceProb as well)
     });
     if (rc != KBEST_OK || !ctx) throw std::runtime_error(std::string("kbest engine: ") + kbest_strerror(rc));
     return ctx;
@@ -51,11 +54,11 @@ size_t kbest_one(size_t k, size_t numRow, size_t numCol, bool maximize, const do
     o.maximize = maximize;
     o.use_cutoff = useCut;
     o.cutoff = cutoff;
-    // KBEST_SHIM_REFERENCE_ORDER=1: the drop-in answers in the reference's own order of operations (kbest_exact.hip) -- exact ties as
-    // the reference's heap pops them, col4row on padded columns as the reference names them; slower (kbest_c.h, KBEST_FLAG_REFERENCE_ORDER)
-    // (=2: KBEST_FLAG_REFERENCE_TIES -- only a problem with an exact tie among its k + 1 best gains takes that kernel)
+    // By default a problem with an exact tie among its k + 1 best gains runs again on the reference-order kernel: the reference's own
+    // answer (kbest_c.h).  KBEST_SHIM_REFERENCE_ORDER=1: every problem on that kernel (col4row on padded columns as the reference names
+    // them too; slower); =0: the engine's own rule on exact ties
     if (shim_reference_order() == 1) o.flags |= KBEST_FLAG_REFERENCE_ORDER;
-    else if (shim_reference_order() == 2) o.flags |= KBEST_FLAG_REFERENCE_TIES;
+    else if (shim_reference_order() == 0) o.flags |= KBEST_FLAG_CANONICAL_TIES;
     std::vector<int32_t> r4c(k * numCol), c4r(k * numRow);
     int32_t nf = 0;
     check(ctx, kbest_batch_f64(ctx, &o, 1, (int)numRow, (int)numCol, nullptr, nullptr, C, nullptr, (int)k, r4c.data(),

@@ -18,6 +18,7 @@ KBEST_FLAG_NO_TIE_CHECK = 512
 KBEST_FLAG_NO_TIE_RESOLVE = 1024
 KBEST_FLAG_REFERENCE_ORDER = 2048
 KBEST_FLAG_REFERENCE_TIES = 4096
+KBEST_FLAG_CANONICAL_TIES = 8192
 # per-problem tie flags (kbest_c.h, "Order of exact ties")
 KBEST_TIE_INSIDE, KBEST_TIE_BOUNDARY, KBEST_TIE_RESOLVED, KBEST_TIE_REFERENCE = 1, 2, 4, 8
 KBEST_TIE_UNCHECKED, KBEST_TIE_UNORDERED, KBEST_TIE_UNRESOLVED = 1 << 28, 1 << 29, 1 << 30
@@ -185,7 +186,7 @@ class KBestEngine:
     # ---- host buffers -----------------------------------------------------------------
     def kbest(self, costs, N, M, k, maximize=False, cutoff=None, nRow=None, nCol=None, costOff=None,
               count_pushed=False, prune=True, root_shard=None, tables_i8=False, reorder=True, tie_flags=False,
-              tie_check=True, tie_resolve=True, reference_order=False, reference_ties=False):
+              tie_check=True, tie_resolve=True, reference_order=False, reference_ties=False, canonical_ties=False):
         """Batched kBest2D / kBest2DCutoff.  costs: (B, N*M) for uniform shapes, or a flat packed
         array with per-problem nRow/nCol/costOff (N, M are then the maxima).
         Returns (nf[B], row4col[B,k,M], col4row[B,k,N], gain[B,k]) (+ pushed[B] if count_pushed).
@@ -194,7 +195,10 @@ class KBestEngine:
         reference_order: KBEST_FLAG_REFERENCE_ORDER -- the reference's own order of operations (exact ties in its heap's order,
         col4row on padded columns as the reference names them; slow).
         reference_ties: KBEST_FLAG_REFERENCE_TIES -- the fast kernels, and every problem with an exact tie among its k + 1 best gains
-        again on the reference-order kernel (KBEST_TIE_REFERENCE): the reference's answer everywhere, fast where nothing ties."""
+        again on the reference-order kernel (KBEST_TIE_REFERENCE): the reference's answer everywhere, fast where nothing ties.  This
+        is the DEFAULT of the synchronous entries (the flag is accepted and changes nothing).
+        canonical_ties: KBEST_FLAG_CANONICAL_TIES -- the engine's own rule on exact ties instead ((gain, row4col) lexicographic; a
+        level that straddles slot k completed in steps of up to 4 096 solutions)."""
         costs = np.ascontiguousarray(costs, dtype=np.float64)
         if nRow is None:
             costs = costs.reshape(-1, N * M)
@@ -213,7 +217,8 @@ class KBestEngine:
         flags = ((KBEST_FLAG_COUNT_PUSHED if count_pushed else 0) | (0 if prune else KBEST_FLAG_NO_PRUNE) |
                  (KBEST_FLAG_TABLES_I8 if tables_i8 else 0) | (0 if reorder else KBEST_FLAG_NO_REORDER) |
                  (0 if tie_check else KBEST_FLAG_NO_TIE_CHECK) | (0 if tie_resolve else KBEST_FLAG_NO_TIE_RESOLVE) |
-                 (KBEST_FLAG_REFERENCE_ORDER if reference_order else 0) | (KBEST_FLAG_REFERENCE_TIES if reference_ties else 0))
+                 (KBEST_FLAG_REFERENCE_ORDER if reference_order else 0) | (KBEST_FLAG_REFERENCE_TIES if reference_ties else 0) |
+                 (KBEST_FLAG_CANONICAL_TIES if canonical_ties else 0))
         o = self._opts(maximize, cutoff, flags, root_shard)
         tf = np.zeros(B, np.int32) if tie_flags else None
         if tf is not None:
@@ -393,11 +398,13 @@ class KBestEngine:
 
 
     def resolve_ties_dev(self, d_cost, B, N, M, k, d_row4col, d_col4row, d_gain, d_tie_flags, maximize=False, cutoff=None, stream=None,
-                         d_nRow=None, d_nCol=None, d_costOff=None, tables_i8=False, reference_ties=False):
+                         d_nRow=None, d_nCol=None, d_costOff=None, tables_i8=False, reference_ties=False, canonical_ties=False):
         """kbest_resolve_ties_dev: the synchronous second call behind kbest_dev -- completes the gain levels that straddle slot k
-        in the device tables (same arguments as the launch).  reference_ties: KBEST_FLAG_REFERENCE_TIES -- every problem flagged with
-        a tie is replaced by the reference-order kernel's tables instead."""
-        o = self._opts(maximize, cutoff, (KBEST_FLAG_TABLES_I8 if tables_i8 else 0) | (KBEST_FLAG_REFERENCE_TIES if reference_ties else 0))
+        in the device tables (same arguments as the launch).  By default (reference_ties: the accepted no-op flag) every problem flagged
+        with a tie is replaced by the reference-order kernel's tables; canonical_ties: KBEST_FLAG_CANONICAL_TIES -- the engine's own
+        rule instead (levels that straddle slot k completed in steps)."""
+        o = self._opts(maximize, cutoff, (KBEST_FLAG_TABLES_I8 if tables_i8 else 0) | (KBEST_FLAG_REFERENCE_TIES if reference_ties else 0) |
+                       (KBEST_FLAG_CANONICAL_TIES if canonical_ties else 0))
 
         def dp(t):
             return None if t is None else C.c_void_p(t.data_ptr())
@@ -461,7 +468,8 @@ class KBestMulti:
         except Exception:
             pass
 
-    def kbest(self, costs, N, M, k, maximize=False, cutoff=None, nRow=None, nCol=None, subtree=False, n_shard=0, reference_ties=False):
+    def kbest(self, costs, N, M, k, maximize=False, cutoff=None, nRow=None, nCol=None, subtree=False, n_shard=0, reference_ties=False,
+              canonical_ties=False):
         """Batch mode (default): contiguous blocks of the batch per device.  subtree=True: every device enumerates its share
         of the root's subtrees of every matrix (n_shard shards, 0 = one per device), one all-gather of the packed lists,
         k-way merge on the device (kbest_merge.hip)."""
@@ -472,8 +480,10 @@ class KBestMulti:
         o = KBestOpts()
         self.lib.kbest_default_opts(C.byref(o))
         o.maximize = int(bool(maximize)); o.use_cutoff = int(cutoff is not None); o.cutoff = float(cutoff or 0.0)
-        if reference_ties:  # (batch mode: kbest_c.h, KBEST_FLAG_REFERENCE_TIES)
+        if reference_ties:  # (batch mode: kbest_c.h, KBEST_FLAG_REFERENCE_TIES -- the default; accepted)
             o.flags |= KBEST_FLAG_REFERENCE_TIES
+        if canonical_ties:  # (the engine's own rule on exact ties)
+            o.flags |= KBEST_FLAG_CANONICAL_TIES
         if nRow is not None:
             nRow = np.ascontiguousarray(nRow, dtype=np.int32); nCol = np.ascontiguousarray(nCol, dtype=np.int32)
         if subtree:

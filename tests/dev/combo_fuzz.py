@@ -35,11 +35,13 @@ while time.time() - t0 < budget:
         blocks = [np.where(np.isinf(x), -np.inf, x) for x in blocks]
     opt = dict(tables_i8=bool(rng.random() < 0.3), tie_flags=bool(rng.random() < 0.5), tie_check=bool(rng.random() < 0.85),
                tie_resolve=bool(rng.random() < 0.85), count_pushed=bool(rng.random() < 0.15), prune=bool(rng.random() < 0.85))
-    mode = rng.choice(["default", "default", "order", "ties"])
+    mode = rng.choice(["default", "canonical", "order", "ties"])  # (default = the reference's answer on ties; "ties": the accepted flag)
     if mode == "order":
         opt["reference_order"] = True
     elif mode == "ties":
         opt["reference_ties"] = True
+    elif mode == "canonical":
+        opt["canonical_ties"] = True
     flat = np.concatenate(blocks)
     if ragged:
         out = eng.kbest(flat, maxN, maxM, k, nRow=nRow, nCol=nCol, costOff=off, **kw, **opt)
@@ -58,7 +60,7 @@ while time.time() - t0 < budget:
             assert len(set(rows.tolist())) == m_ and rows.min() >= 0 and rows.max() < n_, ("assignment", desc, s)
             inv = c4r[b, s, :n_].astype(np.int64)
             assert all(inv[rows[c]] == c for c in range(m_)), ("col4row", desc, s)
-        if mode != "default" and opt["tie_check"] and opt["tie_resolve"] and not opt["count_pushed"] and opt["prune"] or mode == "order":
+        if mode != "canonical" and opt["tie_check"] and opt["tie_resolve"] and not opt["count_pushed"] and opt["prune"] or mode == "order":
             assert (r4c[b, :wn, :m_] == wr[:wn]).all(), ("reference order", desc)
     ncall += 1
 print(f"combo fuzz ok: {ncall} calls in {budget:.0f} s (seed {seed})")

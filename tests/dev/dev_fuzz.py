@@ -1,6 +1,7 @@
 """Dev aid (GPU box): the ASYNCHRONOUS entry (kbest_batch_f64_dev) + its second call (kbest_resolve_ties_dev) under random batches --
-uniform and ragged shapes, int8 tables, integer (exact ties) and continuous costs, maximise, cutoff.  With the default rule the device
-tables and flags must end up equal to the synchronous host entry's; with KBEST_FLAG_REFERENCE_TIES equal to the checker's, slot for slot.
+uniform and ragged shapes, int8 tables, integer (exact ties) and continuous costs, maximise, cutoff.  By default (the reference's answer on
+ties) the device tables must end up equal to the checker's, slot for slot; with KBEST_FLAG_CANONICAL_TIES (the engine's own rule) tables and
+flags equal to the synchronous host entry's under the same flag.
 usage: python tests/dev/dev_fuzz.py [seconds] [seed]"""
 import sys, time
 import numpy as np
@@ -49,7 +50,7 @@ while time.time() - t0 < budget:
     if ref:
         eng.lib.kbest_reserve_exact(eng.ctx, B, maxN, maxM, k)
     eng.kbest_dev(d_cost, B, maxN, maxM, k, d_r, d_c, d_g, d_n, stream=st, d_tie_flags=d_f, tables_i8=i8, **kw, **shp)
-    eng.resolve_ties_dev(d_cost, B, maxN, maxM, k, d_r, d_c, d_g, d_f, stream=st, tables_i8=i8, reference_ties=ref, **kw, **shp)
+    eng.resolve_ties_dev(d_cost, B, maxN, maxM, k, d_r, d_c, d_g, d_f, stream=st, tables_i8=i8, canonical_ties=not ref, **kw, **shp)
     torch.cuda.synchronize()
     nf, r4c, c4r, g, fl = d_n.cpu().numpy(), d_r.cpu().numpy().astype(np.int32), d_c.cpu().numpy().astype(np.int32), d_g.cpu().numpy(), d_f.cpu().numpy()
     desc = (seed, ncall, B, maxN, maxM, k, i8, ragged, integer, ref, kw)
@@ -63,9 +64,9 @@ while time.time() - t0 < budget:
         nref += 1
     else:
         if ragged:
-            want = eng.kbest(flat, maxN, maxM, k, nRow=nRow, nCol=nCol, costOff=off, tie_flags=True, tables_i8=i8, **kw)
+            want = eng.kbest(flat, maxN, maxM, k, nRow=nRow, nCol=nCol, costOff=off, tie_flags=True, tables_i8=i8, canonical_ties=True, **kw)
         else:
-            want = eng.kbest(flat.reshape(B, -1), maxN, maxM, k, tie_flags=True, tables_i8=i8, **kw)
+            want = eng.kbest(flat.reshape(B, -1), maxN, maxM, k, tie_flags=True, tables_i8=i8, canonical_ties=True, **kw)
         assert (nf == want[0]).all(), ("nf", desc)
         # (the asynchronous entry may run WITHOUT the extra solution where k sits at a kernel's limit: KBEST_TIE_UNCHECKED there)
         same = (fl & ~E.KBEST_TIE_UNCHECKED) == want[4]
@@ -77,4 +78,4 @@ while time.time() - t0 < budget:
             n = int(nf[b])
             assert (g[b, :n].view(np.int64) == want[3][b, :n].view(np.int64)).all() and (r4c[b, :n, :m_] == want[1][b, :n, :m_]).all(), ("tables", desc, b, hex(int(fl[b])))
     ncall += 1
-print(f"dev fuzz ok: {ncall} calls ({nref} with reference ties) in {budget:.0f} s (seed {seed})")
+print(f"dev fuzz ok: {ncall} calls ({nref} with the reference's ties -- the default --, the others with the engine's rule) in {budget:.0f} s (seed {seed})")

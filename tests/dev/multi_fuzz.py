@@ -1,6 +1,6 @@
 """Dev aid (GPU box): the one-process multi-device entry on LOGICAL devices (the same GPU several times) under random batches -- batch
 mode and subtree mode (gains first / whole lists, S shards over G devices), uniform and ragged shapes, integer (exact ties) and
-continuous costs, maximise, cutoff, with and without KBEST_FLAG_REFERENCE_TIES -- against the checker: counts, gains (bits), valid
+continuous costs, maximise, cutoff, with and without KBEST_FLAG_CANONICAL_TIES -- against the checker: counts, gains (bits), valid
 assignments; row4col slot for slot where the checker's k + 1 best gains are all different (or reference ties were asked for); every
 device's global table equal.  usage: python tests/dev/multi_fuzz.py [seconds] [seed]"""
 import sys, time
@@ -32,9 +32,9 @@ while time.time() - t0 < budget:
         nRow = rng.integers(1, N + 1, B).astype(np.int32)
         nCol = np.array([int(rng.integers(1, min(int(r), M) + 1)) for r in nRow], np.int32)
         nRow[0], nCol[0] = N, M
-    ref_ties = (not subtree) and rng.random() < 0.3
+    ref_ties = (not subtree) and rng.random() < 0.7  # (batch mode: the reference's answer on ties is the default; else the engine's rule)
     n_shard = int(rng.choice([0, 2, 5, 16])) if subtree else 0
-    nf, r4c, c4r, g = m.kbest(costs, N, M, k, nRow=nRow, nCol=nCol, subtree=subtree, n_shard=n_shard, reference_ties=ref_ties, **kw)
+    nf, r4c, c4r, g = m.kbest(costs, N, M, k, nRow=nRow, nCol=nCol, subtree=subtree, n_shard=n_shard, canonical_ties=not ref_ties, **kw)
     desc = (seed, ncall, G, "subtree" if subtree else "batch", n_shard, B, N, M, k, integer, ragged, ref_ties, kw)
     assert m.tables_agree(), ("devices hold different global tables", desc)
     for b in range(B):

@@ -50,11 +50,13 @@ def check_case(eng, case, reference_order=False):
     N, M, k, C = case["N"], case["M"], case["k"], case["C"]
     # every third case takes its tables as int8 (KBEST_FLAG_TABLES_I8): the same values from every kernel's output phase
     i8 = N <= 127 and (N + M + k + case["B"]) % 3 == 0
-    # reference_order == 2: KBEST_FLAG_REFERENCE_TIES -- the fast kernels, the tied problems again on the reference-order kernel: gains
-    # and row4col the checker's slot for slot on EVERY problem, col4row up to the names of padded columns (raw on the re-run problems)
+    # reference_order == 2: the synchronous entry's DEFAULT -- the fast kernels, the tied problems again on the reference-order kernel:
+    # gains and row4col the checker's slot for slot on EVERY problem, col4row up to the names of padded columns (raw on the re-run
+    # problems).  reference_order False: KBEST_FLAG_CANONICAL_TIES -- the engine's own rule on ties, every kernel and its completion of
+    # tied levels (equal gains compared as multisets below)
     ties_only = reference_order == 2
     nf, r4c, c4r, g = eng.kbest(C, N, M, k, case["maximize"], case["cutoff"], tables_i8=i8, reference_order=reference_order is True or reference_order == 1,
-                                reference_ties=ties_only)[:4]
+                                canonical_ties=reference_order is False)[:4]
     onf, or4c, oc4r, og, _ = ol.orc_kbest_batch(C, N, M, k, case["maximize"], case["cutoff"])
     for b in range(case["B"]):
         n = int(onf[b])

@@ -177,7 +177,7 @@ def test_exact_ties_one_answer_whatever_the_kernel(monkeypatch, shape):
         if knobs.get("KBEST_FORCE_SMALL") and N > 32 or knobs.get("KBEST_FORCE_LANE") and N > 32:
             continue
         eng = engine_with(monkeypatch, **knobs)
-        nf, r4c, c4r, g, fl = eng.kbest(costs, N, M, k, tie_flags=True)
+        nf, r4c, c4r, g, fl = eng.kbest(costs, N, M, k, tie_flags=True, canonical_ties=True)
         for b in range(B):
             wn, wr, wg, boundary, resolved = want[b]
             assert nf[b] == wn, (knobs, b)

@@ -337,7 +337,7 @@ def test_tie_levels_of_more_than_64_members_are_completed_on_every_route(monkeyp
     first = None
     for knobs in TIE_ROUTES:
         eng = engine_with(monkeypatch, **knobs)
-        nf, r4c, c4r, g, fl = eng.kbest(costs, N, M, k, tie_flags=True)
+        nf, r4c, c4r, g, fl = eng.kbest(costs, N, M, k, tie_flags=True, canonical_ties=True)
         for b in range(B):
             wn, wr, wg, boundary, resolved = want[b]
             assert nf[b] == wn and (bits(g[b, :wn]) == bits(wg)).all(), (knobs, b)
@@ -355,7 +355,8 @@ def test_tie_levels_of_more_than_64_members_are_completed_on_every_route(monkeyp
 
 
 def test_resolve_ties_dev_completes_the_device_tables(engine):
-    """kbest_resolve_ties_dev: the second call behind the asynchronous entry.  Integer costs through kbest_batch_f64_dev leave
+    """kbest_resolve_ties_dev with KBEST_FLAG_CANONICAL_TIES (the engine's own rule; the default -- the reference's answer -- is
+    test_reference_ties_behind_the_device_entry_and_on_two_devices): the second call behind the asynchronous entry.  Integer costs through kbest_batch_f64_dev leave
     KBEST_TIE_BOUNDARY flags; the helper completes those levels in the DEVICE tables: afterwards they equal the synchronous
     entry's (= the checker's canonical k best) and the flags say RESOLVED / UNRESOLVED.  Also through a multi-device batch call."""
     import torch
@@ -364,7 +365,7 @@ def test_resolve_ties_dev_completes_the_device_tables(engine):
     rng = np.random.default_rng(99)
     for (N, M, k, hi, B, i8) in ((8, 8, 20, 4, 40, False), (16, 16, 50, 30, 300, False), (40, 40, 60, 200, 24, True), (12, 7, 30, 25, 30, False)):
         costs = rng.integers(0, hi, size=(B, N * M)).astype(np.float64)
-        want = engine.kbest(costs, N, M, k, tie_flags=True, tables_i8=i8)
+        want = engine.kbest(costs, N, M, k, tie_flags=True, tables_i8=i8, canonical_ties=True)
         tdt = torch.int8 if i8 else torch.int32
         d_cost = torch.from_numpy(costs).to(dev)
         d_r = torch.empty((B, k, M), dtype=tdt, device=dev)
@@ -378,7 +379,7 @@ def test_resolve_ties_dev_completes_the_device_tables(engine):
         torch.cuda.synchronize()
         f0 = d_f.cpu().numpy()
         assert ((f0 & E.KBEST_TIE_BOUNDARY) != 0).sum() > 0 and ((f0 & (E.KBEST_TIE_RESOLVED | E.KBEST_TIE_UNRESOLVED)) == 0).all()
-        engine.resolve_ties_dev(d_cost, B, N, M, k, d_r, d_c, d_g, d_f, stream=s.cuda_stream, tables_i8=i8)
+        engine.resolve_ties_dev(d_cost, B, N, M, k, d_r, d_c, d_g, d_f, stream=s.cuda_stream, tables_i8=i8, canonical_ties=True)
         torch.cuda.synchronize()
         f1 = d_f.cpu().numpy()
         assert (f1 == want[4]).all()
@@ -397,7 +398,7 @@ def test_resolve_ties_dev_completes_the_device_tables(engine):
     off = np.zeros(B, np.int64)
     off[1:] = np.cumsum([len(b_) for b_ in blocks[:-1]])
     flat = np.concatenate(blocks)
-    want = engine.kbest(flat, maxRow, maxCol, k, nRow=nRow, nCol=nCol, costOff=off, tie_flags=True)
+    want = engine.kbest(flat, maxRow, maxCol, k, nRow=nRow, nCol=nCol, costOff=off, tie_flags=True, canonical_ties=True)
     d_cost = torch.from_numpy(flat).to(dev)
     d_nR, d_nC, d_off = torch.from_numpy(nRow).to(dev), torch.from_numpy(nCol).to(dev), torch.from_numpy(off).to(dev)
     d_r = torch.full((B, k, maxCol), -1, dtype=torch.int32, device=dev)
@@ -408,7 +409,7 @@ def test_resolve_ties_dev_completes_the_device_tables(engine):
     torch.cuda.synchronize()
     st = torch.cuda.current_stream().cuda_stream
     engine.kbest_dev(d_cost, B, maxRow, maxCol, k, d_r, d_c, d_g, d_n, stream=st, d_tie_flags=d_f, d_nRow=d_nR, d_nCol=d_nC, d_costOff=d_off)
-    engine.resolve_ties_dev(d_cost, B, maxRow, maxCol, k, d_r, d_c, d_g, d_f, stream=st, d_nRow=d_nR, d_nCol=d_nC, d_costOff=d_off)
+    engine.resolve_ties_dev(d_cost, B, maxRow, maxCol, k, d_r, d_c, d_g, d_f, stream=st, d_nRow=d_nR, d_nCol=d_nC, d_costOff=d_off, canonical_ties=True)
     torch.cuda.synchronize()
     f1, nfd = d_f.cpu().numpy(), d_n.cpu().numpy()
     assert (f1 == want[4]).all() and ((f1 & E.KBEST_TIE_RESOLVED) != 0).sum() > 0 and (nfd == want[0]).all()
@@ -421,9 +422,9 @@ def test_resolve_ties_dev_completes_the_device_tables(engine):
     # the multi-device batch entry completes tied levels by itself: in the caller's tables AND in the devices' slices
     N, M, k, hi, B = 10, 10, 30, 4, 50
     costs = rng.integers(0, hi, size=(B, N * M)).astype(np.float64)
-    want = engine.kbest(costs, N, M, k, tie_flags=True)
+    want = engine.kbest(costs, N, M, k, tie_flags=True, canonical_ties=True)
     multi = pk.KBestMulti([0, 0, 0])
-    got = multi.kbest(costs, N, M, k)
+    got = multi.kbest(costs, N, M, k, canonical_ties=True)
     assert multi.tables_agree()
     fl = multi.last_tie_flags()
     multi.close()
@@ -588,7 +589,7 @@ def test_reference_order_on_exact_ties_is_the_heap_order(engine, shape):
             assert (r4c[b, :n] == or4c[b, :n]).all(), (kw, b)
             assert (c4r[b, :n] == oc4r[b, :n]).all(), (kw, b)
             assert (bits(g[b, :n]) == bits(og[b, :n])).all(), (kw, b)
-        d = engine.kbest(costs, N, M, k, **kw)   # the engine's own rule: same gains, its own order of ties
+        d = engine.kbest(costs, N, M, k, canonical_ties=True, **kw)   # the engine's own rule: same gains, its own order of ties
         assert (d[0] == onf).all()
         for b in range(B):
             n = int(onf[b])

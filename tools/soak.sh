@@ -10,12 +10,12 @@ mkdir -p $out
 t=$((secs * 3 + 120))
 {
 echo "# soak of $(git rev-parse --short HEAD 2>/dev/null || echo 'the working tree'), $secs s per leg, seeds $seed.."
-echo "k-best tables, every kernel against the checker: $(timeout $t python3 tests/dev/soak.py $secs $seed 2>&1 | tail -1)"
+echo "k-best tables, every kernel against the checker (KBEST_FLAG_CANONICAL_TIES: the engine's own rule on exact ties, equal gains compared as sets): $(timeout $t python3 tests/dev/soak.py $secs $seed 2>&1 | tail -1)"
 for nw in 4 8 12; do
 echo "k-best tables, every 64-row launch forced into a relay of three pieces of the $nw-wave shape (KBEST_RELAY=3 KBEST_NWAVES=$nw KBEST_NO_SMALL KBEST_NO_LANE) against the checker: $(KBEST_RELAY=3 KBEST_NWAVES=$nw KBEST_NO_SMALL=1 KBEST_NO_LANE=1 timeout $t python3 tests/dev/soak.py $secs $((seed + 5 + nw)) 2>&1 | tail -1)"
 done
 echo "k-best tables in the reference's own order (KBEST_FLAG_REFERENCE_ORDER, kbest_exact.hip) against the checker SLOT FOR SLOT -- order of equal gains and col4row on padded columns included: $(SOAK_REFERENCE_ORDER=1 timeout $t python3 tests/dev/soak.py $secs $((seed + 40)) 2>&1 | tail -1)"
-echo "k-best tables with KBEST_FLAG_REFERENCE_TIES (the fast kernels; every problem with an exact tie among its k + 1 best gains again on the reference-order kernel) against the checker: gains and row4col SLOT FOR SLOT on every problem: $(SOAK_REFERENCE_ORDER=2 timeout $t python3 tests/dev/soak.py $secs $((seed + 41)) 2>&1 | tail -1)"
+echo "k-best tables as the synchronous entry returns them BY DEFAULT (the fast kernels; every problem with an exact tie among its k + 1 best gains again on the reference-order kernel) against the checker: gains and row4col SLOT FOR SLOT on every problem: $(SOAK_REFERENCE_ORDER=2 timeout $t python3 tests/dev/soak.py $secs $((seed + 41)) 2>&1 | tail -1)"
 echo "relay launches of batches of several generations (the plan, 2, 5, 8 pieces) against plain launches, every table word: $(timeout $t python3 tests/dev/relay_stress.py $secs $((seed + 30)) 2>&1 | tail -1)"
 echo "association path against the checker: $(timeout $t python3 tests/dev/soak_assoc.py $secs $((seed + 1)) 2>&1 | tail -1)"
 echo "association path on the enumeration kernels only (KBEST_NO_TINY KBEST_NO_BNB) against the checker: $(KBEST_NO_TINY=1 KBEST_NO_BNB=1 timeout $t python3 tests/dev/soak_assoc.py $secs $((seed + 2)) 2>&1 | tail -1)"
