@@ -1841,10 +1841,10 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
         o.tie_flags = nullptr;
         return kbest_batch_f64_keep(ctx, &o, B, maxRow, maxCol, nRow, nCol, cost, costOff, k, row4col, col4row, gain, nf, pushed, nullptr);
     }
-    // Exact ties (kbest_ties.h; "Order of exact ties" in kbest_c.h).  The launch reports per problem whether the k-th and the
-    // (k+1)-th best gains are equal; this synchronous entry then completes that gain level for those problems (kb_complete_tie_levels)
-    // and keeps the lexicographically first assignments of the level: the answer no longer depends on the kernel the batch was
-    // routed to.
+    // Exact ties (kbest_ties.h; "Order of exact ties" in kbest_c.h).  The launch reports per problem whether any two of its k + 1
+    // best gains are equal; this synchronous entry then gives those problems the REFERENCE's answer -- they run again on the
+    // reference-order kernel -- or, with KBEST_FLAG_CANONICAL_TIES, completes a level that straddles slot k under the engine's own rule
+    // (kb_complete_tie_levels): either way the answer does not depend on the kernel the batch was routed to.
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DevBuf dFlags;
     HIP_TRY(ctx, dFlags.alloc(ctx, (size_t)B * 4));
@@ -1881,8 +1881,11 @@ int kbest_batch_f64(kbest_ctx *ctx, const kbest_opts *opts, int B, int maxRow, i
 
 }  // extern "C"
 
-// Completes the gain levels that straddle slot k (fl[b] & KBEST_TIE_BOUNDARY without KBEST_TIE_RESOLVED): those problems again,
-// alone, with k + 64, then k + 256, then k + KBEST_TIE_CAP solutions -- whichever kernel takes that k; the table comes back in the
+// What the synchronous entries do with the problems a launch flagged.  By default: every problem with an exact tie among its k + 1
+// best gains again on the reference-order kernel, its tables replaced (KBEST_TIE_REFERENCE; the first block below).  With
+// KBEST_FLAG_CANONICAL_TIES (or where that re-run fails): completes the gain levels that straddle slot k under the engine's own rule
+// (fl[b] & KBEST_TIE_BOUNDARY without KBEST_TIE_RESOLVED): those problems again,
+// alone, with k + 64, then k + 256, k + 1 024, then k + KBEST_TIE_CAP solutions -- whichever kernel takes that k; the table comes back in the
 // canonical order -- until the level ends inside the table; the first k of the ordered table then replace the problem's slots in the
 // caller's HOST tables (row4col / col4row: int32, or int8 with KBEST_FLAG_TABLES_I8; col4row may be null) and the problem is flagged
 // KBEST_TIE_RESOLVED.  Nothing of a problem is touched before its re-run has validated; a re-run that fails (beyond a kernel's
