@@ -499,6 +499,7 @@ struct ExactParams {
     long long *pushed;         // or null
     unsigned char *work;       // gridDim.x slots of exact_slot_bytes(maxRow, hypPerSlot)
     int hypPerSlot;
+    int childWaves;            // (set by launch_kbest_exact: waves of a workgroup that solve children, 65 .. 1 024 rows)
 };
 long long exact_slot_bytes(int maxRow, int hypPerSlot);
 hipError_t launch_kbest_exact(const ExactParams &p, int grid, hipStream_t stream);

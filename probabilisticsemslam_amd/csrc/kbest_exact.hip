@@ -22,7 +22,8 @@
 //     kernels (kbest_lap.h), a child a few register copies of its parent; one wave per problem, or EIGHT: the children of a sweep are
 //     independent of one another (each is solved completely from the parent), only their pushes have an order -- the waves solve
 //     them side by side, wave 0 then pushes them in column order;
-//   * 65 .. 1 024 rows (kbest_exactN_kernel: two to eight waves per problem, a sweep's children side by side in the same way) and
+//   * 65 .. 1 024 rows (kbest_exactN_kernel: eight waves per problem -- the root's Dijkstra steps shared by all of them, a sweep's
+//     children side by side on as many of them as the LDS holds scratch for) and
 //     beyond (kbest_exact_kernel: one wave): the lanes of a wave share the rows of a Dijkstra step (row = lane, lane + 64, ...: the
 //     reduced costs ((delta + C) - u) - v left to right, the strict-'<' update, the minimum with the LOWEST row among equal values:
 //     cpp:183-191, 313-320), the dual update and the copies of a hypothesis; the path flip is one lane's; up to 1 024 rows every
@@ -31,8 +32,9 @@
 // In all of them the queue is one lane's, in HBM (or LDS where it fits), and the pool of hypotheses (25 N bytes each, one per push: a
 // child only reaches it if it is feasible and not cut) is in HBM.  This is the slow, total, literal path -- 256 problems of 64 x 64,
 // k = 200 take 15 ms here (1 024 of them 34 ms, one alone 9.7 ms; the reference on one host core: 10 ms per problem) against 0.7 ms
-// on the LDS kernel; 1 000 integer-cost 28 x 10 problems 9 ms against 4.5; 64 problems of 200 x 150, k = 50: 115 ms (one: 76 ms);
-// two of 1 000 x 12, k = 10: 1.7 s, nearly all of it the root's 1 000 augmentations on one wave -- and is only taken when asked for
+// on the LDS kernel; 1 000 integer-cost 28 x 10 problems 9 ms against 4.5; 64 problems of 200 x 150, k = 50: 108 ms (one: 71 ms);
+// two of 1 000 x 12, k = 10: 0.76 s, most of it the root's 1 000 augmentations, whose steps all eight waves share (the compiled
+// reference on a host core: 0.71 s for one) -- and is only taken when asked for
 // (KBEST_FLAG_REFERENCE_ORDER; the tied problems of a KBEST_FLAG_REFERENCE_TIES call) or when no other kernel takes the size.
 #include <hip/hip_runtime.h>
 
@@ -154,13 +156,14 @@ __global__ void __launch_bounds__(64) kbest_exact_kernel(ExactParams p)
                 nScanned++;
                 const double uc = h.u[cur];
                 const double *Ccol = Cw + (long long)cur * D;
+                const bool padded = cur >= M;  // (a zero-padded column, cpp:582-585: its costs are 0.0 -- no trip to memory for them)
                 const bool forbNow = useForb && cur == start;
                 double best = INF;
                 int bestR = 0x7fffffff;
                 for (int r = lane; r < D; r += 64) {
                     if (!inScan[r]) continue;
                     if (forbNow && forbStart[r]) continue;
-                    const double rc = ((delta + Ccol[r]) - uc) - h.v[r];  // cpp:183 / 313: left to right
+                    const double rc = ((delta + (padded ? 0.0 : Ccol[r])) - uc) - h.v[r];  // cpp:183 / 313: left to right
                     double s = spc[r];
                     if (rc < s) { pred[r] = cur; spc[r] = rc; s = rc; }
                     if (s < best) { best = s; bestR = r; }  // (ascending r within the lane: the first minimum is the lowest row)
@@ -344,9 +347,10 @@ __global__ void __launch_bounds__(64) kbest_exact_kernel(ExactParams p)
 
 // ---- 65 .. 1 024 rows, NW waves per problem ------------------------------------------------------------------------------------
 // kbest_exact_kernel<1>'s sequence of operations with a sweep's children dealt to the waves, as kbest_exact64_kernel below does it:
-// every wave has its own scratch of a search and its own hypothesis-being-solved in LDS, the hypothesis being split is loaded once
-// per sweep by all of them, wave 0 makes the pushes in column order behind a barrier.  (One problem of 200 x 150, k = 50: 640 ms
-// on one wave.)
+// every child-solving wave has its own scratch of a search and its own hypothesis-being-solved in LDS, the hypothesis being split is
+// loaded once per sweep by all of them, wave 0 makes the pushes in column order behind a barrier; the ROOT's N augmentations -- most of
+// the run on problems of many rows and few columns -- are shared by all eight waves, a Dijkstra step's rows dealt to the threads.
+// (One problem of 200 x 150, k = 50: 446 ms on one wave, 71 ms here; two of 1 000 x 12, k = 10: 1.80 s / 0.76 s.)
 template <int NW>
 __global__ void __launch_bounds__(64 * NW) kbest_exactN_kernel(ExactParams p)
 {
@@ -358,7 +362,10 @@ __global__ void __launch_bounds__(64 * NW) kbest_exactN_kernel(ExactParams p)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const long long Dm = p.maxRow;
     const long long scrB = (19 * Dm + 63) & ~63ll, hypB = (25 * Dm + 63) & ~63ll;
-    unsigned char *my = lds + wave * (scrB + hypB);
+    // CW of the NW waves solve children (as many as the LDS holds scratch + hypothesis for); ALL of them share the rows of the root's
+    // Dijkstra steps (augment_all below: on wave 0's scratch and hypothesis)
+    const int CW = p.childWaves;
+    unsigned char *my = lds + (wave < CW ? wave : 0) * (scrB + hypB);
     // this wave's scratch of a search (ScratchSpace, hpp:73-142) and the hypothesis it is solving
     double *spc = reinterpret_cast<double *>(my);
     int *pred = reinterpret_cast<int *>(my + 8 * Dm);
@@ -370,12 +377,17 @@ __global__ void __launch_bounds__(64 * NW) kbest_exactN_kernel(ExactParams p)
     };
     const Hyp hLds = lds_hyp(my + scrB);
     // everybody's: the hypothesis being split, the sweep's results by column, wave 0's words
-    unsigned char *sh = lds + NW * (scrB + hypB);
+    unsigned char *sh = lds + CW * (scrB + hypB);
     const Hyp pLds = lds_hyp(sh);
     double *resG = reinterpret_cast<double *>(sh + hypB);
     int *resIdx = reinterpret_cast<int *>(resG + ((p.maxCol + 1) & ~1));
     int *bc = resIdx + ((p.maxCol + 3) & ~3);
-    double *red = reinterpret_cast<double *>(bc + 16);
+    double *red = reinterpret_cast<double *>(bc + 16);  // [2][NW] minima of the waves (double-buffered by step)
+    int *redR = reinterpret_cast<int *>(red + 2 * NW);   // [2][NW] ... and their rows
+    // wave 0's scratch and hypothesis, as everybody sees them (the root)
+    double *spc0 = reinterpret_cast<double *>(lds);
+    int *pred0 = reinterpret_cast<int *>(lds + 8 * Dm), *scanCols0 = reinterpret_cast<int *>(lds + 12 * Dm);
+    unsigned char *scanRow0 = lds + 16 * Dm, *inScan0 = lds + 17 * Dm;
     enum { BC_CUR = 0, BC_ACT = 1, BC_STOP = 2, BC_NEXT = 3, BC_ERR = 4 };
     double *Cw = reinterpret_cast<double *>(ws + L.C);
     struct HeapE { double g; long long idx; };  // idx: hypothesis | activeCol << 32
@@ -428,13 +440,14 @@ __global__ void __launch_bounds__(64 * NW) kbest_exactN_kernel(ExactParams p)
                 nScanned++;
                 const double uc = h.u[cur];
                 const double *Ccol = Cw + (long long)cur * D;
+                const bool padded = cur >= M;  // (a zero-padded column, cpp:582-585: its costs are 0.0 -- no trip to memory for them)
                 const bool forbNow = useForb && cur == start;
                 double best = INF;
                 int bestR = 0x7fffffff;
                 for (int r = lane; r < D; r += 64) {
                     if (!inScan[r]) continue;
                     if (forbNow && forbStart[r]) continue;
-                    const double rc = ((delta + Ccol[r]) - uc) - h.v[r];  // cpp:183 / 313: left to right
+                    const double rc = ((delta + (padded ? 0.0 : Ccol[r])) - uc) - h.v[r];  // cpp:183 / 313: left to right
                     double s = spc[r];
                     if (rc < s) { pred[r] = cur; spc[r] = rc; s = rc; }
                     if (s < best) { best = s; bestR = r; }  // (ascending r within the lane: the first minimum is the lowest row)
@@ -571,31 +584,97 @@ __global__ void __launch_bounds__(64 * NW) kbest_exactN_kernel(ExactParams p)
             if (lane == 0) bc[BC_STOP] = stop;
         };
 
-        // ---- root: shortestPathCPP (cpp:119-238), N augmentations in column order on the padded problem (wave 0) ----
-        if (wave == 0) {
-            if (lane == 0) { bc[BC_ERR] = 0; bc[BC_NEXT] = 1; }
-            const Hyp hr = hLds;
-            for (int i = lane; i < D; i += 64) { hr.c4r[i] = -1; hr.r4c[i] = -1; hr.u[i] = 0.0; hr.v[i] = 0.0; hr.forb[i] = 0; }
-            sync();
+        // ---- root: shortestPathCPP (cpp:119-238), N augmentations in column order on the padded problem.  EVERY wave takes part:
+        // the rows of a Dijkstra step are shared by all threads (row = thread, thread + 64 NW, ...), each wave reduces its rows, the
+        // waves' minima meet in LDS (the lowest row among equal minima, as everywhere) -- two barriers per step.  On problems of
+        // hundreds of rows the root's N augmentations on ONE wave were most of the run (2 x 1 000x12, k = 10: 1.6 of 1.7 s).
+        auto augment_all = [&](const Hyp &h, int start) -> int {
+            for (int r = threadIdx.x; r < D; r += NT) { scanRow0[r] = 0; spc0[r] = INF; }
+            __syncthreads();
+            int nScanned = 0, sink = -1, cur = start, par = 0;
+            double delta = 0.0;
+            do {
+                if (threadIdx.x == 0) scanCols0[nScanned] = cur;
+                nScanned++;
+                const double uc = h.u[cur];
+                const double *Ccol = Cw + (long long)cur * D;
+                const bool padded = cur >= M;  // (a zero-padded column, cpp:582-585: its costs are 0.0 -- no trip to memory for them)
+                double best = INF;
+                int bestR = 0x7fffffff;
+                for (int r = threadIdx.x; r < D; r += NT) {
+                    if (!inScan0[r]) continue;
+                    const double rc = ((delta + (padded ? 0.0 : Ccol[r])) - uc) - h.v[r];  // cpp:183: left to right
+                    double sv = spc0[r];
+                    if (rc < sv) { pred0[r] = cur; spc0[r] = rc; sv = rc; }
+                    if (sv < best) { best = sv; bestR = r; }  // (ascending r within the thread: the first minimum is its lowest row)
+                }
+                const double wmin = wave_min_f64(best);
+                const int wrow = wave_min_i32(best == wmin ? bestR : 0x7fffffff);
+                if (lane == 0) { red[par * NW + wave] = wmin; redR[par * NW + wave] = wrow; }
+                __syncthreads();
+                double minVal = red[par * NW];
+                int closest = redR[par * NW];
+                for (int w = 1; w < NW; w++) {
+                    const double vw = red[par * NW + w];
+                    const int rw = redR[par * NW + w];
+                    if (vw < minVal || (vw == minVal && rw < closest)) { minVal = vw; closest = rw; }
+                }
+                par ^= 1;
+                if (!(minVal < INF)) return 1;  // cpp:197-203 (the same value in every thread)
+                if (threadIdx.x == 0) { scanRow0[closest] = 1; inScan0[closest] = 0; }
+                __syncthreads();
+                delta = spc0[closest];
+                const int col = h.c4r[closest];
+                if (col == -1) sink = closest; else cur = col;
+            } while (sink == -1);
+            // updateDualAndAugment (cpp:82-117)
+            for (int i = threadIdx.x; i < nScanned; i += NT) {
+                const int c = scanCols0[i];
+                if (i == 0) h.u[c] = h.u[c] + delta;
+                else h.u[c] = h.u[c] + delta - spc0[h.r4c[c]];
+            }
+            for (int r = threadIdx.x; r < D; r += NT)
+                if (scanRow0[r]) h.v[r] = h.v[r] - delta + spc0[r];
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int r = sink, c;
+                do {
+                    c = pred0[r];
+                    h.c4r[r] = c;
+                    const int nxt = h.r4c[c];
+                    h.r4c[c] = r;
+                    r = nxt;
+                } while (c != start);
+            }
+            __syncthreads();
+            return 0;
+        };
+        {
+            const Hyp hr = lds_hyp(lds + scrB);  // (wave 0's hypothesis-being-solved)
+            if (threadIdx.x == 0) { bc[BC_ERR] = 0; bc[BC_NEXT] = 1; }
+            for (int i = threadIdx.x; i < D; i += NT) { hr.c4r[i] = -1; hr.r4c[i] = -1; hr.u[i] = 0.0; hr.v[i] = 0.0; hr.forb[i] = 0; }
+            __syncthreads();
             int infeasible = 0;
             for (int c = 0; c < D && !infeasible; c++) {
-                for (int r = lane; r < D; r += 64) inScan[r] = 1;
-                sync();
-                infeasible = augment(hr, c, false);
+                for (int r = threadIdx.x; r < D; r += NT) inScan0[r] = 1;
+                __syncthreads();
+                infeasible = augment_all(hr, c);
             }
-            if (infeasible) {  // kBest2D returns 0 (cpp:588-593)
-                if (lane == 0) bc[BC_STOP] = 1;
-            } else if (p.hypPerSlot < 2) {
-                if (lane == 0) bc[BC_STOP] = -1;
-            } else {
-                const double rootGain = gain_of(hr, M);
-                if (lane == 0) hr.forb[hr.r4c[0]] = 1;  // cpp:232-235
-                sync();
-                copy_hyp(hr, hyp(0));
-                gain0 = emit(0, rootGain, 0);
-                if (lane == 0) resG[0] = rootGain;
-                heap_push(0, 0, rootGain);
-                turn(0, 0, true);
+            if (wave == 0) {
+                if (infeasible) {  // kBest2D returns 0 (cpp:588-593)
+                    if (lane == 0) bc[BC_STOP] = 1;
+                } else if (p.hypPerSlot < 2) {
+                    if (lane == 0) bc[BC_STOP] = -1;
+                } else {
+                    const double rootGain = gain_of(hr, M);
+                    if (lane == 0) hr.forb[hr.r4c[0]] = 1;  // cpp:232-235
+                    sync();
+                    copy_hyp(hr, hyp(0));
+                    gain0 = emit(0, rootGain, 0);
+                    if (lane == 0) resG[0] = rootGain;
+                    heap_push(0, 0, rootGain);
+                    turn(0, 0, true);
+                }
             }
         }
         __syncthreads();
@@ -612,7 +691,7 @@ __global__ void __launch_bounds__(64 * NW) kbest_exactN_kernel(ExactParams p)
             __syncthreads();
             const Hyp hp = pLds, hc = hLds;
             // ---- split (cpp:455-532): the children of columns a .. M-1, each fully solved; this wave's share ----
-            for (int c = a + wave; c < M; c += NW) {
+            for (int c = wave < CW ? a + wave : M; c < M; c += CW) {
                 // rows still owned by columns >= c of the parent (cpp:480-488; 506-508, 512, 525-527)
                 for (int r = lane; r < D; r += 64) { inScan[r] = 0; forbStart[r] = (c == a) ? hp.forb[r] : 0; }  // cpp:490 / 510
                 sync();
@@ -937,25 +1016,25 @@ hipError_t launch_kbest_exact(const ExactParams &p, int grid, hipStream_t stream
         return hipGetLastError();
     }
     if (p.maxRow <= EXACT_LDS_ROWS) {
-        // NW waves per problem, as many as a CU's LDS holds scratch + hypothesis for (44 bytes per row and wave) beside the shared 25
-        // bytes per row and the sweep's results: eight while two workgroups still fit a CU, else four, else two
+        // Eight waves per problem: all of them share the rows of the root's Dijkstra steps; as many of them as a CU's LDS holds scratch +
+        // hypothesis for (44 bytes per row and wave, beside the shared 25 bytes per row and the sweep's results) solve a sweep's
+        // children side by side: eight while two workgroups still fit a CU, else four, two, one.  KBEST_EXACT_WAVES = 1 / 2 / 4 / 8
+        // forces the number of child-solving waves (A/B).
+        constexpr int NW = 8;
         const long long scrB = (19ll * p.maxRow + 63) & ~63ll, hypB = (25ll * p.maxRow + 63) & ~63ll;
-        auto bytes = [&](int nw) { return nw * (scrB + hypB) + hypB + 8ll * ((p.maxCol + 1) & ~1) + 4ll * ((p.maxCol + 3) & ~3) + 64 + 8ll * nw + 64; };
+        auto bytes = [&](int cw) { return cw * (scrB + hypB) + hypB + 8ll * ((p.maxCol + 1) & ~1) + 4ll * ((p.maxCol + 3) & ~3) + 64 + 2 * NW * 12ll + 64; };
         const char *force = getenv("KBEST_EXACT_WAVES");
-        int nw = force ? atoi(force) : (bytes(8) <= 80 * 1024 ? 8 : (bytes(4) <= 150 * 1024 ? 4 : 2));
-        nw = nw >= 8 ? 8 : (nw >= 4 ? 4 : (nw >= 2 ? 2 : 1));
-        while (nw > 1 && bytes(nw) > 150 * 1024) nw >>= 1;
-        const int lds = (int)bytes(nw);
-        const void *fn = nw == 8 ? reinterpret_cast<const void *>(kbest_exactN_kernel<8>) : nw == 4 ? reinterpret_cast<const void *>(kbest_exactN_kernel<4>)
-                       : nw == 2 ? reinterpret_cast<const void *>(kbest_exactN_kernel<2>) : reinterpret_cast<const void *>(kbest_exactN_kernel<1>);
+        int cw = force ? atoi(force) : (bytes(8) <= 80 * 1024 ? 8 : 4);
+        cw = cw >= 8 ? 8 : (cw >= 4 ? 4 : (cw >= 2 ? 2 : 1));
+        while (cw > 1 && bytes(cw) > 150 * 1024) cw >>= 1;
+        const int lds = (int)bytes(cw);
         if (lds > 64 * 1024) {  // (more than the default limit of dynamic LDS)
-            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kbest_exactN_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e != hipSuccess) return e;
         }
-        if (nw == 8) hipLaunchKernelGGL(kbest_exactN_kernel<8>, dim3(grid), dim3(512), lds, stream, p);
-        else if (nw == 4) hipLaunchKernelGGL(kbest_exactN_kernel<4>, dim3(grid), dim3(256), lds, stream, p);
-        else if (nw == 2) hipLaunchKernelGGL(kbest_exactN_kernel<2>, dim3(grid), dim3(128), lds, stream, p);
-        else hipLaunchKernelGGL(kbest_exactN_kernel<1>, dim3(grid), dim3(64), lds, stream, p);
+        ExactParams q = p;
+        q.childWaves = cw;
+        hipLaunchKernelGGL(kbest_exactN_kernel<NW>, dim3(grid), dim3(64 * NW), lds, stream, q);
     } else {
         hipLaunchKernelGGL(kbest_exact_kernel, dim3(grid), dim3(64), 0, stream, p);
     }

@@ -38,7 +38,7 @@ KNOBS = [
     (["KBEST_ZC_COST"], "csrc", "`kbest_batch_f64`, registered cost blocks: `0` all pieces' uploads at once, `2` read in place by the kernels over the link (default: uploaded piece after piece on a copy stream)"),
     (["KBEST_ZC_LIMIT_KB", "KBEST_NO_POLL"], "csrc", "association host entries: largest call (bytes in + out) that runs on the pinned staging memory in place (default 65 536); wait with `hipStreamSynchronize` instead of polling the completion word"),
     (["KBEST_MULTI_WIDE", "KBEST_MULTI_WHOLE_LISTS"], "csrc", "multi-device entries: row4col travels as int32 even where bytes would do (round 5's exchange); subtree mode always exchanges the whole lists (no gains-first exchange)"),
-    (["KBEST_EXACT_WAVES"], "csrc", "reference-order kernels up to 1 024 rows (`kbest_exact.hip`): waves per problem (`1`, `2`, `4`, `8`: a sweep's children side by side); unset: up to 64 rows eight where a problem has 16 columns or more or the batch has fewer than 512 problems, else one; 65 … 1 024 rows as many of 8 / 4 / 2 as a CU's LDS holds (A/B; same tables; read at every launch)"),
+    (["KBEST_EXACT_WAVES"], "csrc", "reference-order kernels up to 1 024 rows (`kbest_exact.hip`): waves per problem (`1`, `2`, `4`, `8`: a sweep's children side by side); unset: up to 64 rows eight where a problem has 16 columns or more or the batch has fewer than 512 problems, else one; 65 … 1 024 rows the child-solving waves of the eight: as many of 8 / 4 / 2 / 1 as a CU's LDS holds scratch for (A/B; same tables; read at every launch)"),
     (["KBEST_SHIM_REFERENCE_ORDER"], "csrc", "the reference-named C++ shims, exact ties: unset -- `kBest2D` / `kBest2DCutoff` answer as the reference does (the synchronous entry's default: a problem with an exact tie among its k + 1 best gains runs again on the reference-order kernel), `assignmentProb` / `bruteForceProb` weigh the engine's choice among a tied level; `=2` those too weigh the reference's own k best (`kbest_set_reference_order(ctx, 2)`); `=1` everything on the reference-order kernel (`KBEST_FLAG_REFERENCE_ORDER`); `=0` the engine's own rule everywhere (`KBEST_FLAG_CANONICAL_TIES`) -- the one knob that selects another (documented) answer on exact ties"),
     (["KBEST_LIB"], "python", "Python driver: file name of the library to load from the package directory (e.g. the `PROFILE=1` build)"),
     (["KBEST_BENCH_BACKEND", "KBEST_BENCH_FORCE_DIST", "KBEST_BENCH_SELF_LAUNCH", "KBEST_BENCH_WIDE_SLICES"], "python",
